@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""bench.py — throughput of the HERRO hot path (pileup featurisation + correction-model forward)
+on synthetic overlap batches, one process per GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one batch of `--batch` (128) 4096-bp windows with 32 overlaps
+each (BASELINE.json configs[2]): featurise the windows' reads on the GPU, batch the windows with >=1
+informative position across reads, run the model.  Inputs (2-bit read store, window descriptors) are
+resident in HBM before the timed region.  Weak scaling: every rank processes its own batches; there
+is no data-path collective (windows are independent, SURVEY.md §8 e).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0
+
+
+def cpu_baseline(seed: int) -> dict:
+    """Reference algorithm on the host: oracle restatement (features) + PyTorch-CPU twin (model),
+    on a bounded sample of the same workload.  Checker code is used ONLY here."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_lib as O
+    import model_ref as MR
+    import torch
+    from herro_amd import model_io, synth
+    sb = synth.generate(24, 4 * 4096, 32, seed=seed)
+    store = O.store_from_synth(sb)
+    t0 = time.perf_counter()
+    res = []
+    for t in range(sb.n_targets):
+        rid, rows, cigs = O.target_alignments(sb, t)
+        res.append(store.extract_features(rid, rows, cigs, 4096))
+    t_feat = time.perf_counter() - t0
+    n_win = sum(len(r) for r in res)
+    # model: dense twin on one read's windows (reference grouping), all host cores
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    _, raw = model_io.default_model_file(os.path.join(ROOT, "tests", "_cache"))
+    twin = MR.build(raw, model_io.Hyper())
+    nb, bt = res[0].collate(4, 0)
+    t0 = time.perf_counter()
+    MR.run_batch(twin, bt["bases"], bt["quals"], bt["lens"], bt["indices"])
+    t_model = time.perf_counter() - t0
+    n_mwin = len(bt["lens"])
+    per_win = t_feat / n_win + t_model / n_mwin
+    return {"value": 1.0 / per_win, "unit": "windows/s", "cores": cores, "kind": "port",
+            "sample": f"oracle extract_features on {n_win} windows (1 thread, {n_win / t_feat:.1f} win/s) + "
+                      f"dense PyTorch-CPU fp32 twin on {n_mwin} windows ({cores} threads, {n_mwin / t_model:.2f} win/s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--pool", type=int, default=4, help="distinct synthetic batches cycled through")
+    ap.add_argument("--precision", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from herro_amd import api, model_io, synth
+    W, n_ovl = 4096, 32
+    targets_per_step = args.batch // 4
+    ctx = api.Context(local)
+    path, _ = model_io.default_model_file(os.path.join(ROOT, "tests", "_cache"))
+    ctx.load_model(path)
+    ctx.set_precision(args.precision)
+    pool = max(1, min(args.pool, args.steps + args.warmup))
+    sb = synth.generate(pool * targets_per_step, 4 * W, n_ovl, seed=synth.SEED + 2 + 1000 * rank)
+    ctx.set_reads(sb.seq, sb.qual, sb.off)
+    jobs = [api.job_from_synth(ctx, sb, W, range(i * targets_per_step, (i + 1) * targets_per_step)) for i in range(pool)]
+    assert all(j.n_windows == args.batch for j in jobs)
+
+    def step(i):
+        j = jobs[i % pool]
+        j.featurize()
+        j.infer(args.batch, 1)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    barrier()
+    if world > 1:
+        tt = torch.tensor([el], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+
+    # ---- per-kernel durations with HIP events on the launch stream (second pass, same steps)
+    st = jobs[0].stats()
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    ctx.synchronize()
+    tm = ctx.timing()
+    ctx.timing_enable(False)
+
+    if rank == 0:
+        total_windows = args.steps * args.batch * world
+        kern = {k: {"ms_total": v[0], "calls": v[1], "avg_us": 1e3 * v[0] / max(v[1], 1)} for k, v in tm.items()}
+        feat_names = ["ow_stats", "win_layout", "columns", "pass1", "select"]
+        feat_ms = sum(tm[k][0] for k in feat_names if k in tm) / args.steps
+        model_ms = sum(v[0] for k, v in tm.items() if k not in feat_names) / args.steps
+        alg_bytes = st["read_bytes"] + st["op_bytes"] + st["out_bytes"]   # SURVEY §8 d, measured on the data
+        dom = max(tm, key=lambda k: tm[k][0])
+        dom_avg_s = tm[dom][0] / max(tm[dom][1], 1) * 1e-3
+        # algorithmic bytes of each featurisation kernel per launch
+        out = {
+            "metric": "4096-bp windows corrected/sec at batch=128",
+            "value": total_windows / el,
+            "unit": "windows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * el / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": {0: "f32", 1: "bf16x3", 2: "f32-valu"}[args.precision],
+            "data": "synthetic (SURVEY §8d generator, seed 0x48455252+2; random-init weights of the assumed architecture)",
+            "config": {"workload": "synthetic windows, 4096 bp, 32 overlaps each, batch=128, 1xMI355X per rank "
+                                   "(BASELINE configs[2])", "batch": args.batch, "window": W, "overlaps": n_ovl,
+                       "mean_len": st["sum_len"] / args.batch, "mean_informative": st["sum_supported"] / args.batch,
+                       "model_windows_per_batch": st["n_model_windows"]},
+            "mbases_per_s": total_windows / el * W / 1e6,
+            "roofline": {
+                "kernel": "featurize (ow_stats+win_layout+columns+pass1+select)",
+                "bound": "hbm",
+                "achieved": alg_bytes / (feat_ms * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": alg_bytes / (feat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "launch_ms": feat_ms,
+            },
+            "dominant_kernel": {"name": dom, "avg_us": dom_avg_s * 1e6},
+            "stage_ms_per_step": {"featurize": feat_ms, "model": model_ms},
+            "kernels": kern,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(synth.SEED + 2)
+        print(json.dumps(out))
+    for j in jobs:
+        j.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

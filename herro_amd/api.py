@@ -1,0 +1,303 @@
+"""ctypes binding of libherro_amd.so (include/herro_amd.h).  Fails loudly if the HIP library is
+missing or no GPU is present — there is no CPU fallback in this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libherro_amd.so")
+_LIB = None
+
+EXPORTS = [
+    "herro_version", "herro_create", "herro_destroy", "herro_last_error", "herro_set_stream", "herro_synchronize",
+    "herro_encode_2bit", "herro_decode_2bit", "herro_set_reads", "herro_set_reads_packed", "herro_load_model",
+    "herro_set_precision", "herro_job_create", "herro_job_free", "herro_job_n_windows", "herro_job_featurize",
+    "herro_job_infer", "herro_job_window_info", "herro_job_window_copy", "herro_job_window_logits",
+    "herro_job_consensus_fasta", "herro_model_forward", "herro_timing_enable", "herro_timing_reset",
+    "herro_timing_get", "herro_job_stats", "herro_debug_extract_windows",
+]
+
+
+class HerroError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"herro_amd error {code}: {msg}")
+        self.code = code
+
+
+class Alignment(C.Structure):  # herro_alignment
+    _fields_ = [(n, C.c_uint32) for n in
+                ("qid", "qlen", "qstart", "qend", "strand", "tid", "tlen", "tstart", "tend", "cigar_len")] + \
+               [("cigar", C.c_void_p)]
+
+
+class WindowInfo(C.Structure):  # herro_window_info
+    _fields_ = [(n, C.c_uint32) for n in
+                ("rid", "wid", "n_total_wins", "length", "n_alns", "n_overlaps", "n_supported", "win_len")]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not built — run __graft_entry__.build(); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+        L.herro_version.restype = C.c_char_p
+        L.herro_create.restype = vp
+        L.herro_create.argtypes = [i32]
+        L.herro_destroy.argtypes = [vp]
+        L.herro_last_error.restype = C.c_char_p
+        L.herro_last_error.argtypes = [vp]
+        L.herro_set_stream.argtypes = [vp, vp]
+        L.herro_synchronize.argtypes = [vp]
+        L.herro_encode_2bit.restype = C.c_int64
+        L.herro_encode_2bit.argtypes = [vp, u64, vp]
+        L.herro_decode_2bit.argtypes = [vp, u64, u64, u64, i32, vp]
+        L.herro_set_reads.argtypes = [vp, u32, vp, vp, vp, vp]
+        L.herro_set_reads_packed.argtypes = [vp, u32, vp, vp, vp, vp, vp]
+        L.herro_load_model.argtypes = [vp, C.c_char_p]
+        L.herro_set_precision.argtypes = [vp, i32]
+        L.herro_job_create.restype = vp
+        L.herro_job_create.argtypes = [vp, u32, vp, vp, vp, u32]
+        L.herro_job_free.argtypes = [vp]
+        L.herro_job_n_windows.restype = u32
+        L.herro_job_n_windows.argtypes = [vp]
+        L.herro_job_featurize.argtypes = [vp]
+        L.herro_job_infer.argtypes = [vp, u32, i32]
+        L.herro_job_window_info.argtypes = [vp, u32, vp]
+        L.herro_job_window_copy.argtypes = [vp, u32, i32, vp, vp, vp, vp, vp]
+        L.herro_job_window_logits.argtypes = [vp, u32, vp, vp]
+        L.herro_job_consensus_fasta.restype = C.c_int64
+        L.herro_job_consensus_fasta.argtypes = [vp, u32, C.c_char_p, C.c_char_p, vp, u64]
+        L.herro_model_forward.argtypes = [vp, u32, u32, vp, vp, vp, vp, vp, vp]
+        L.herro_timing_enable.argtypes = [vp, i32]
+        L.herro_timing_reset.argtypes = [vp]
+        L.herro_timing_get.argtypes = [vp, vp, u64, vp, vp, vp]
+        L.herro_job_stats.argtypes = [vp, vp]
+        L.herro_debug_extract_windows.restype = C.c_int64
+        L.herro_debug_extract_windows.argtypes = [vp, u32, u32, vp, u64, vp, u64]
+        _LIB = L
+    return _LIB
+
+
+def encode_2bit(seq: bytes) -> np.ndarray:
+    """haec_io.rs:121-136 (host utility)."""
+    words = np.zeros((len(seq) + 31) // 32 + 1, np.uint64)
+    buf = np.frombuffer(seq, np.uint8)
+    n = lib().herro_encode_2bit(buf.ctypes.data if len(seq) else None, len(seq), words.ctypes.data)
+    if n < 0:
+        raise HerroError(int(n), "byte >= 128 in sequence")
+    return words[:n].copy()
+
+
+def decode_2bit(words: np.ndarray, length: int, start: int, end: int, rc: bool) -> bytes:
+    """haec_io.rs:138-173 (host utility)."""
+    words = np.ascontiguousarray(words, np.uint64)
+    out = np.zeros(max(end - start, 0), np.uint8)
+    r = lib().herro_decode_2bit(words.ctypes.data, length, start, end, int(rc), out.ctypes.data)
+    if r:
+        raise HerroError(r, "Out of bounds for 2-bit sequence decoding.")
+    return out.tobytes()
+
+
+def debug_extract_windows(row, cigar: bytes, n_windows: int, window_size: int) -> np.ndarray:
+    """Product windowing for one alignment (host only).  Rows: window,tstart,qstart,qend,op_lo,op_hi,so,eo."""
+    a = Alignment()
+    (a.qid, a.qlen, a.qstart, a.qend, a.strand, a.tid, a.tlen, a.tstart, a.tend) = (int(x) for x in row)
+    buf = np.frombuffer(cigar + b"\0", np.uint8).copy()
+    a.cigar_len, a.cigar = len(cigar), buf.ctypes.data
+    out = np.zeros((65536, 8), np.uint64)
+    err = C.create_string_buffer(512)
+    n = lib().herro_debug_extract_windows(C.byref(a), n_windows, window_size, out.ctypes.data, len(out), err, 512)
+    if n < 0:
+        raise HerroError(int(n), err.value.decode())
+    return out[:n].astype(np.int64)
+
+
+@dataclass
+class Window:
+    info: WindowInfo
+    bases: np.ndarray     # u8 [L',31]
+    quals: np.ndarray     # u8 [L',31]
+    sup_pos: np.ndarray   # u16
+    sup_ins: np.ndarray   # u8
+    qids: np.ndarray      # u32 ranked overlap ids
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        self._l = lib()
+        self.h = self._l.herro_create(device)
+        if not self.h:
+            raise HerroError(-2, self._l.herro_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._l.herro_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise HerroError(rc, self._l.herro_last_error(self.h).decode())
+
+    def set_stream(self, hip_stream: int | None):
+        self._chk(self._l.herro_set_stream(self.h, hip_stream))
+
+    def synchronize(self):
+        self._chk(self._l.herro_synchronize(self.h))
+
+    def set_reads(self, seq: np.ndarray, qual: np.ndarray, off: np.ndarray, name_class: np.ndarray | None = None):
+        seq = np.ascontiguousarray(seq, np.uint8)
+        qual = np.ascontiguousarray(qual, np.uint8)
+        off = np.ascontiguousarray(off, np.uint64)
+        nc = None if name_class is None else np.ascontiguousarray(name_class, np.uint32)
+        self._chk(self._l.herro_set_reads(self.h, len(off) - 1, seq.ctypes.data, qual.ctypes.data, off.ctypes.data,
+                                          None if nc is None else nc.ctypes.data))
+
+    def load_model(self, path: str):
+        self._chk(self._l.herro_load_model(self.h, path.encode()))
+
+    def set_precision(self, mode: int):
+        self._chk(self._l.herro_set_precision(self.h, mode))
+
+    def create_job(self, rids, aln_rows: np.ndarray, aln_off, cigars: list[bytes] | None, window_size: int,
+                   cig_blob: np.ndarray | None = None, cig_off: np.ndarray | None = None) -> "Job":
+        """aln_rows u32 [n,>=9] (qid,qlen,qstart,qend,strand,tid,tlen,tstart,tend[,cigar_len]); CIGARs either
+        as a list of bytes or as blob + offsets (+ lengths in column 9)."""
+        rids = np.ascontiguousarray(rids, np.uint32)
+        aln_off = np.ascontiguousarray(aln_off, np.uint64)
+        n = len(aln_rows)
+        if cigars is not None:
+            lens = np.array([len(c) for c in cigars], np.uint64)
+            cig_off = np.zeros(n, np.uint64)
+            if n:
+                cig_off[1:] = np.cumsum(lens)[:-1]
+            cig_blob = np.frombuffer(b"".join(cigars) + b"\0", np.uint8).copy()
+            cl = lens
+        else:
+            cig_blob = np.ascontiguousarray(cig_blob, np.uint8)
+            cl = aln_rows[:, 9].astype(np.uint64)
+        arr = (Alignment * max(n, 1))()
+        base = cig_blob.ctypes.data
+        # vectorised fill through a numpy view of the ctypes array
+        view = np.frombuffer(arr, dtype=np.dtype([("f", np.uint32, 10), ("p", np.uint64)], align=True), count=max(n, 1))
+        if n:
+            view["f"][:n, :9] = aln_rows[:, :9]
+            view["f"][:n, 9] = cl
+            view["p"][:n] = base + np.asarray(cig_off, np.uint64)
+        h = self._l.herro_job_create(self.h, len(rids), rids.ctypes.data, aln_off.ctypes.data, C.byref(arr), window_size)
+        if not h:
+            msg = self._l.herro_last_error(self.h).decode()
+            code = -1
+            if "[code " in msg:
+                code = int(msg.rsplit("[code ", 1)[1].rstrip("]"))
+            raise HerroError(code, msg)
+        return Job(self, h, len(rids))
+
+    def model_forward(self, bases: np.ndarray, quals: np.ndarray, lens: np.ndarray, indices: np.ndarray):
+        """inference.rs:147-175: tokens u8 [B,L,31], raw quals u8 [B,L,31], lens, flat indices -> logits."""
+        bases = np.ascontiguousarray(bases, np.uint8)
+        quals = np.ascontiguousarray(quals, np.uint8)
+        lens = np.ascontiguousarray(lens, np.int32)
+        indices = np.ascontiguousarray(indices, np.int32)
+        B, L, R = bases.shape
+        assert R == 31 and quals.shape == bases.shape
+        N = int(lens.sum())
+        info = np.zeros(N, np.float32)
+        base = np.zeros((N, 5), np.float32)
+        self._chk(self._l.herro_model_forward(self.h, B, L, bases.ctypes.data, quals.ctypes.data, lens.ctypes.data,
+                                              indices.ctypes.data if N else None, info.ctypes.data, base.ctypes.data))
+        return info, base
+
+    def timing_enable(self, on: bool = True):
+        self._chk(self._l.herro_timing_enable(self.h, int(on)))
+
+    def timing_reset(self):
+        self._chk(self._l.herro_timing_reset(self.h))
+
+    def timing(self) -> dict[str, tuple[float, int]]:
+        n = C.c_uint32(256)
+        names = C.create_string_buffer(8192)
+        ms = (C.c_double * 256)()
+        calls = (C.c_uint64 * 256)()
+        self._chk(self._l.herro_timing_get(self.h, names, 8192, ms, calls, C.byref(n)))
+        nm = [x for x in names.value.decode().split("\n") if x]
+        return {nm[i]: (ms[i], int(calls[i])) for i in range(min(n.value, len(nm)))}
+
+
+class Job:
+    def __init__(self, ctx: Context, h, n_targets: int):
+        self.ctx, self.h, self.n_targets = ctx, h, n_targets
+        self._l = ctx._l
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self._l.herro_job_free(self.h)
+        self.h = None
+
+    __del__ = close
+
+    @property
+    def n_windows(self) -> int:
+        return self._l.herro_job_n_windows(self.h)
+
+    def featurize(self):
+        self.ctx._chk(self._l.herro_job_featurize(self.h))
+
+    def infer(self, batch_size: int, batch_mode: int = 0):
+        self.ctx._chk(self._l.herro_job_infer(self.h, batch_size, batch_mode))
+
+    def info(self, w: int) -> WindowInfo:
+        wi = WindowInfo()
+        self.ctx._chk(self._l.herro_job_window_info(self.h, w, C.byref(wi)))
+        return wi
+
+    def window(self, w: int, encoded: bool = False) -> Window:
+        wi = self.info(w)
+        bases = np.zeros((wi.length, 31), np.uint8)
+        quals = np.zeros((wi.length, 31), np.uint8)
+        sp = np.zeros(wi.n_supported, np.uint16)
+        si = np.zeros(wi.n_supported, np.uint8)
+        qids = np.zeros(wi.n_overlaps, np.uint32)
+        self.ctx._chk(self._l.herro_job_window_copy(self.h, w, int(encoded), bases.ctypes.data, quals.ctypes.data,
+                                                    sp.ctypes.data, si.ctypes.data, qids.ctypes.data))
+        return Window(wi, bases, quals, sp, si, qids)
+
+    def logits(self, w: int):
+        wi = self.info(w)
+        info = np.zeros(wi.n_supported, np.float32)
+        base = np.zeros((wi.n_supported, 5), np.float32)
+        self.ctx._chk(self._l.herro_job_window_logits(self.h, w, info.ctypes.data, base.ctypes.data))
+        return info, base
+
+    def consensus_fasta(self, t: int, read_id: str, desc: str | None = None) -> str:
+        cap = 1 << 24
+        out = C.create_string_buffer(cap)
+        n = self._l.herro_job_consensus_fasta(self.h, t, read_id.encode(), None if desc is None else desc.encode(), out, cap)
+        if n < 0:
+            self.ctx._chk(int(n))
+        return out.raw[:n].decode()
+
+    def stats(self) -> dict[str, int]:
+        o = np.zeros(6, np.uint64)
+        self.ctx._chk(self._l.herro_job_stats(self.h, o.ctypes.data))
+        k = ("read_bytes", "op_bytes", "out_bytes", "sum_len", "sum_supported", "n_model_windows")
+        return {a: int(b) for a, b in zip(k, o)}
+
+
+def job_from_synth(ctx: Context, sb, window_size: int, targets=None) -> Job:
+    """Job over targets of a SynthBatch (all by default)."""
+    ts = list(range(sb.n_targets)) if targets is None else list(targets)
+    a0 = [int(sb.tgt_aln_off[t]) for t in ts]
+    a1 = [int(sb.tgt_aln_off[t + 1]) for t in ts]
+    sel = np.concatenate([np.arange(x, y) for x, y in zip(a0, a1)]).astype(np.int64) if ts else np.zeros(0, np.int64)
+    off = np.zeros(len(ts) + 1, np.uint64)
+    off[1:] = np.cumsum([y - x for x, y in zip(a0, a1)])
+    rows = sb.aln[sel]
+    return ctx.create_job(sb.tgt_rid[ts], rows, off, None, window_size, cig_blob=sb.cig, cig_off=sb.cig_off[sel])

@@ -1,0 +1,1013 @@
+// herro_api.hip — C ABI (include/herro_amd.h) over the HIP kernels.  Host C++ (compiled by hipcc).
+// No CPU fallback anywhere: if HIP is unavailable every device call returns HERRO_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/herro_amd.h"
+#include "job_dev.h"
+#include "model_dev.h"
+#include "windowing.hpp"
+
+using namespace herro;
+
+namespace {
+std::string g_create_err;
+
+#define HIP_TRY(ctx, expr)                                                              \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                   \
+      return HERRO_E_NO_DEVICE;                                                         \
+    }                                                                                   \
+  } while (0)
+
+template <typename T>
+T* dev_alloc_copy(const std::vector<T>& v, hipStream_t st, hipError_t& err) {
+  T* p = nullptr;
+  const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  err = hipMalloc((void**)&p, bytes);
+  if (err != hipSuccess) return nullptr;
+  if (!v.empty()) err = hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st);
+  return p;
+}
+}  // namespace
+
+struct herro_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::string err;
+  // read store
+  uint32_t n_reads = 0;
+  std::vector<uint32_t> read_len, name_class;
+  uint64_t* d_words = nullptr;
+  uint64_t* d_word_off = nullptr;
+  uint8_t* d_qual = nullptr;
+  uint64_t* d_qual_off = nullptr;
+  double* d_ln = nullptr;
+  uint32_t ln_n = 0;
+  uint64_t read_bytes = 0;
+  // model
+  bool has_model = false;
+  ModelDev M{};
+  std::vector<void*> model_allocs;
+  int precision = 1;
+  ModelScratch S{};
+  uint32_t scratch_cap = 0;
+  std::vector<void*> scratch_allocs;
+  KernelTimer timer;
+};
+
+struct BatchPlan {
+  std::vector<uint32_t> wins;  // job window indices
+  uint32_t n_tok = 0, lmax = 0;
+  size_t desc_off = 0;  // byte offset of this batch's descriptor block in d_bdesc
+};
+
+struct herro_job {
+  herro_ctx* ctx = nullptr;
+  uint32_t W = 0, n_targets = 0;
+  std::vector<WinDesc> win;
+  std::vector<OwDesc> ow;
+  std::vector<uint32_t> ops;
+  std::vector<uint32_t> tgt_win_off;  // [n_targets+1]
+  JobDev J{};
+  std::vector<void*> allocs;
+  bool featurized = false, synced = false, inferred = false;
+  // host copies after sync
+  std::vector<uint32_t> h_Lf, h_nsup, h_nkept, h_L;
+  std::vector<uint64_t> sup_off;  // [n_win+1] prefix of nsup
+  float* d_info = nullptr;
+  float* d_base = nullptr;
+  std::vector<float> h_info, h_base;
+  bool logits_on_host = false;
+  std::vector<BatchPlan> batches;
+  void* d_bdesc = nullptr;
+  uint64_t alg_read_bytes = 0, alg_op_bytes = 0;
+};
+
+static int job_sync(herro_job* job);
+
+extern "C" {
+
+const char* herro_version(void) { return "herro_amd 0.1 (gfx950)"; }
+
+const char* herro_last_error(const herro_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+herro_ctx* herro_create(int device_id) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_create_err = std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    return nullptr;
+  }
+  if (device_id < 0 || device_id >= n) { g_create_err = "device id out of range"; return nullptr; }
+  if ((e = hipSetDevice(device_id)) != hipSuccess) { g_create_err = hipGetErrorString(e); return nullptr; }
+  auto ctx = std::make_unique<herro_ctx>();
+  ctx->device = device_id;
+  if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+    g_create_err = hipGetErrorString(e);
+    return nullptr;
+  }
+  ctx->stream = ctx->own_stream;
+  // ln(k+1) table from the host libm — what Rust's f64::ln calls on Linux (features.rs:507)
+  std::vector<double> ln(1u << 20);
+  for (size_t k = 0; k < ln.size(); k++) ln[k] = std::log((double)k + 1.0);
+  ctx->d_ln = dev_alloc_copy(ln, ctx->stream, e);
+  if (e != hipSuccess) { g_create_err = hipGetErrorString(e); return nullptr; }
+  hipStreamSynchronize(ctx->stream);
+  ctx->ln_n = (uint32_t)ln.size();
+  return ctx.release();
+}
+
+static void free_all(std::vector<void*>& v) {
+  for (void* p : v) if (p) hipFree(p);
+  v.clear();
+}
+
+void herro_destroy(herro_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipDeviceSynchronize();
+  ctx->timer.reset();
+  hipFree(ctx->d_words); hipFree(ctx->d_word_off); hipFree(ctx->d_qual); hipFree(ctx->d_qual_off);
+  hipFree(ctx->d_ln);
+  free_all(ctx->model_allocs);
+  free_all(ctx->scratch_allocs);
+  if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+int herro_set_stream(herro_ctx* ctx, void* s) {
+  if (!ctx) return HERRO_E_INVALID;
+  ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+  return HERRO_OK;
+}
+
+int herro_synchronize(herro_ctx* ctx) {
+  if (!ctx) return HERRO_E_INVALID;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->timer.collect();
+  return HERRO_OK;
+}
+
+// ---- codec ---------------------------------------------------------------------------------------
+int64_t herro_encode_2bit(const uint8_t* seq, uint64_t n, uint64_t* words) {
+  uint64_t block = 0, nw = 0;
+  for (uint64_t i = 0; i < n; i++) {
+    const uint8_t b = seq[i];
+    if (b >= 128) return HERRO_E_REFERENCE_PANIC;
+    uint64_t c;
+    switch (b) {
+      case 'A': case 'a': c = 0; break;
+      case 'C': case 'c': c = 1; break;
+      case 'G': case 'g': c = 2; break;
+      case 'T': case 't': c = 3; break;
+      default: c = 255; break;  // OR-ed unmasked, exactly like the reference (haec_io.rs:126-128)
+    }
+    block |= c << ((i << 1) & 63);
+    if (((i + 1) & 31) == 0 || i == n - 1) { words[nw++] = block; block = 0; }
+  }
+  return (int64_t)nw;
+}
+
+int herro_decode_2bit(const uint64_t* words, uint64_t length, uint64_t start, uint64_t end, int rc,
+                      uint8_t* out) {
+  if (end > length) return HERRO_E_REFERENCE_PANIC;  // "Out of bounds for 2-bit sequence decoding."
+  static const char D[4] = {'A', 'C', 'G', 'T'};
+  for (uint64_t k = 0; start + k < end; k++) {
+    const uint64_t i = rc ? end - 1 - k : start + k;
+    const uint64_t code = ((words[i >> 5] >> ((i << 1) & 63)) & 3) ^ (rc ? 3 : 0);
+    out[k] = (uint8_t)D[code];
+  }
+  return HERRO_OK;
+}
+
+// ---- read store ----------------------------------------------------------------------------------
+static int upload_reads(herro_ctx* ctx, uint32_t n_reads, const std::vector<uint64_t>& words,
+                        const std::vector<uint64_t>& word_off, const uint8_t* qual,
+                        const std::vector<uint64_t>& qual_off, const uint32_t* name_class) {
+  hipSetDevice(ctx->device);
+  hipFree(ctx->d_words); hipFree(ctx->d_word_off); hipFree(ctx->d_qual); hipFree(ctx->d_qual_off);
+  ctx->d_words = nullptr; ctx->d_word_off = nullptr; ctx->d_qual = nullptr; ctx->d_qual_off = nullptr;
+  hipError_t e;
+  ctx->d_words = dev_alloc_copy(words, ctx->stream, e); HIP_TRY(ctx, e);
+  ctx->d_word_off = dev_alloc_copy(word_off, ctx->stream, e); HIP_TRY(ctx, e);
+  ctx->d_qual_off = dev_alloc_copy(qual_off, ctx->stream, e); HIP_TRY(ctx, e);
+  const uint64_t nq = qual_off[n_reads];
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->d_qual, std::max<uint64_t>(nq, 1)));
+  if (nq) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_qual, qual, nq, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->n_reads = n_reads;
+  ctx->read_len.resize(n_reads);
+  for (uint32_t i = 0; i < n_reads; i++) ctx->read_len[i] = (uint32_t)(qual_off[i + 1] - qual_off[i]);
+  ctx->name_class.resize(n_reads);
+  for (uint32_t i = 0; i < n_reads; i++) ctx->name_class[i] = name_class ? name_class[i] : i;
+  ctx->read_bytes = words.size() * 8 + nq;
+  return HERRO_OK;
+}
+
+int herro_set_reads(herro_ctx* ctx, uint32_t n_reads, const uint8_t* seq, const uint8_t* qual,
+                    const uint64_t* off, const uint32_t* name_class) {
+  if (!ctx || (n_reads && (!seq || !qual || !off))) return HERRO_E_INVALID;
+  std::vector<uint64_t> word_off(n_reads + 1, 0), qual_off(off, off + n_reads + 1);
+  for (uint32_t i = 0; i < n_reads; i++) {
+    if (off[i + 1] < off[i] || off[i + 1] - off[i] > 0xffffffffull) { ctx->err = "bad read offsets"; return HERRO_E_INVALID; }
+    word_off[i + 1] = word_off[i] + (off[i + 1] - off[i] + 31) / 32;
+  }
+  std::vector<uint64_t> words(word_off[n_reads]);
+  for (uint32_t i = 0; i < n_reads; i++) {
+    const int64_t r = herro_encode_2bit(seq + off[i], off[i + 1] - off[i], words.data() + word_off[i]);
+    if (r < 0) { ctx->err = "read " + std::to_string(i) + ": byte >= 128 in sequence"; return (int)r; }
+  }
+  // qualities are addressed relative to off[0]
+  std::vector<uint64_t> qo(n_reads + 1);
+  for (uint32_t i = 0; i <= n_reads; i++) qo[i] = off[i] - off[0];
+  return upload_reads(ctx, n_reads, words, word_off, qual + off[0], qo, name_class);
+}
+
+int herro_set_reads_packed(herro_ctx* ctx, uint32_t n_reads, const uint64_t* words, const uint64_t* word_off,
+                           const uint8_t* qual, const uint64_t* qual_off, const uint32_t* name_class) {
+  if (!ctx || (n_reads && (!words || !word_off || !qual || !qual_off))) return HERRO_E_INVALID;
+  std::vector<uint64_t> w(words + word_off[0], words + word_off[n_reads]);
+  std::vector<uint64_t> wo(n_reads + 1), qo(n_reads + 1);
+  for (uint32_t i = 0; i <= n_reads; i++) { wo[i] = word_off[i] - word_off[0]; qo[i] = qual_off[i] - qual_off[0]; }
+  return upload_reads(ctx, n_reads, w, wo, qual + qual_off[0], qo, name_class);
+}
+
+// ---- model ---------------------------------------------------------------------------------------
+namespace {
+struct HostTensor { std::vector<uint32_t> dims; std::vector<float> data; };
+
+uint16_t h_bf16(float f) {
+  uint32_t u; std::memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+float h_bf16f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
+
+const float* up_f32(herro_ctx* ctx, const std::vector<float>& v, hipError_t& e) {
+  float* p = dev_alloc_copy(v, ctx->stream, e);
+  if (p) ctx->model_allocs.push_back(p);
+  return p;
+}
+}  // namespace
+
+int herro_load_model(herro_ctx* ctx, const char* path) {
+  if (!ctx || !path) return HERRO_E_INVALID;
+  hipSetDevice(ctx->device);
+  FILE* f = std::fopen(path, "rb");
+  if (!f) { ctx->err = std::string("cannot open model file ") + path; return HERRO_E_NO_MODEL; }
+  ModelHyper h;
+  std::map<std::string, HostTensor> T;
+  bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && h.magic == 0x4f525248u /* 'HRRO' */ && h.version == 1;
+  for (uint32_t i = 0; ok && i < h.n_tensors; i++) {
+    char name[32];
+    uint32_t nd, dims[4];
+    ok = std::fread(name, 32, 1, f) == 1 && std::fread(&nd, 4, 1, f) == 1 && std::fread(dims, 16, 1, f) == 1 && nd <= 4;
+    if (!ok) break;
+    name[31] = 0;
+    HostTensor t;
+    size_t n = 1;
+    for (uint32_t d = 0; d < nd; d++) { t.dims.push_back(dims[d]); n *= dims[d]; }
+    t.data.resize(n);
+    ok = std::fread(t.data.data(), 4, n, f) == n;
+    T[name] = std::move(t);
+  }
+  std::fclose(f);
+  if (!ok) { ctx->err = "malformed model file"; return HERRO_E_NO_MODEL; }
+  if (h.rows != HERRO_ROWS || h.n_layers > 16 || (h.kw & 1) == 0 || h.d_model % 64 || h.d_model / h.n_heads != 32 ||
+      (h.kw * h.c1) % 32 || (h.rows * h.c2) % 32 || h.d_ff % 32 || h.c2 % 16) {
+    ctx->err = "unsupported model hyper-parameters";
+    return HERRO_E_UNSUPPORTED;
+  }
+  free_all(ctx->model_allocs);
+  ModelDev M{};
+  M.h = h;
+  hipError_t e = hipSuccess;
+  bool missing = false;
+  auto get = [&](const std::string& n, size_t expect) -> const std::vector<float>& {
+    static std::vector<float> empty;
+    auto it = T.find(n);
+    if (it == T.end() || it->second.data.size() != expect) { missing = true; ctx->err = "model tensor missing/mis-sized: " + n; return empty; }
+    return it->second.data;
+  };
+  auto vec = [&](const std::string& n, size_t expect) -> const float* {
+    const auto& v = get(n, expect);
+    if (missing) return nullptr;
+    return up_f32(ctx, v, e);
+  };
+  auto weight = [&](const std::string& n, uint32_t K, uint32_t N) -> Weight {
+    Weight w;
+    w.K = K; w.N = N;
+    const auto& wt = get(n + ".wt", (size_t)K * N);
+    if (missing) return w;
+    w.f32 = up_f32(ctx, wt, e);
+    std::vector<uint16_t> hi(wt.size()), lo(wt.size());
+    for (size_t i = 0; i < wt.size(); i++) { hi[i] = h_bf16(wt[i]); lo[i] = h_bf16(wt[i] - h_bf16f(hi[i])); }
+    uint16_t* dh = dev_alloc_copy(hi, ctx->stream, e); ctx->model_allocs.push_back(dh);
+    uint16_t* dl = dev_alloc_copy(lo, ctx->stream, e); ctx->model_allocs.push_back(dl);
+    w.hi = dh; w.lo = dl;
+    w.bias = vec(n + ".b", N);
+    return w;
+  };
+  const uint32_t D = h.d_model;
+  M.t1 = vec("t1", (size_t)h.kw * 12 * h.c1);
+  M.wq1 = vec("wq1", (size_t)h.kw * h.c1);
+  M.b1 = vec("b1", h.c1);
+  M.conv2 = weight("conv2", h.kw * h.c1, h.c2);
+  M.fc = weight("fc", h.rows * h.c2, D);
+  M.pe_div = vec("pe_div", D / 2);
+  for (uint32_t l = 0; l < h.n_layers && !missing; l++) {
+    const std::string p = "L" + std::to_string(l) + ".";
+    M.layer[l].ln1_g = vec(p + "ln1.g", D); M.layer[l].ln1_b = vec(p + "ln1.b", D);
+    M.layer[l].ln2_g = vec(p + "ln2.g", D); M.layer[l].ln2_b = vec(p + "ln2.b", D);
+    M.layer[l].qkv = weight(p + "qkv", D, 3 * D);
+    M.layer[l].proj = weight(p + "proj", D, D);
+    M.layer[l].ff1 = weight(p + "ff1", D, h.d_ff);
+    M.layer[l].ff2 = weight(p + "ff2", h.d_ff, D);
+  }
+  M.lnf_g = vec("lnf.g", D); M.lnf_b = vec("lnf.b", D);
+  M.heads = weight("heads", D, 16);
+  if (missing) { free_all(ctx->model_allocs); return HERRO_E_NO_MODEL; }
+  HIP_TRY(ctx, e);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->M = M;
+  ctx->has_model = true;
+  return HERRO_OK;
+}
+
+int herro_set_precision(herro_ctx* ctx, int mode) {
+  if (!ctx || mode < 0 || mode > 2) return HERRO_E_INVALID;
+  ctx->precision = mode;
+  return HERRO_OK;
+}
+
+static int ensure_scratch(herro_ctx* ctx, uint32_t n_tok) {
+  if (n_tok <= ctx->scratch_cap) return HERRO_OK;
+  hipSetDevice(ctx->device);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  free_all(ctx->scratch_allocs);
+  const ModelHyper& h = ctx->M.h;
+  const uint64_t cap = (uint64_t)n_tok + n_tok / 4 + 256;
+  ModelScratch S{};
+  auto A = [&](uint64_t bytes) -> void* {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    ctx->scratch_allocs.push_back(p);
+    return p;
+  };
+  S.tok_win = (uint32_t*)A(cap * 4);
+  S.tok_row = (uint32_t*)A(cap * 4);
+  S.y1 = (float*)A(cap * HERRO_ROWS * h.kw * h.c1 * 4);
+  S.y2 = (float*)A(cap * HERRO_ROWS * h.c2 * 4);
+  S.x = (float*)A(cap * h.d_model * 4);
+  S.hbuf = (float*)A(cap * h.d_model * 4);
+  S.qkv = (float*)A(cap * 3 * h.d_model * 4);
+  S.att = (float*)A(cap * h.d_model * 4);
+  S.ff = (float*)A(cap * h.d_ff * 4);
+  S.logits = (float*)A(cap * 16 * 4);
+  if (!S.tok_win || !S.tok_row || !S.y1 || !S.y2 || !S.x || !S.hbuf || !S.qkv || !S.att || !S.ff || !S.logits) {
+    free_all(ctx->scratch_allocs);
+    ctx->scratch_cap = 0;
+    ctx->err = "out of device memory for model scratch (" + std::to_string(cap) + " tokens)";
+    return HERRO_E_NO_DEVICE;
+  }
+  ctx->S = S;
+  ctx->scratch_cap = (uint32_t)cap;
+  return HERRO_OK;
+}
+
+// ---- job -------------------------------------------------------------------------------------------
+herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* rids, const uint64_t* aln_off,
+                            const herro_alignment* alns, uint32_t W) {
+  if (!ctx) return nullptr;
+  auto fail = [&](int code, const std::string& m) -> herro_job* {
+    ctx->err = m + " [code " + std::to_string(code) + "]";
+    return nullptr;
+  };
+  if (!ctx->d_words) return fail(HERRO_E_STATE, "herro_set_reads must be called first");
+  if (W < 16 || W > HERRO_MAX_WINDOW) return fail(HERRO_E_UNSUPPORTED, "window_size must be in [16, 8192]");
+  if (n_targets && (!rids || !aln_off)) return fail(HERRO_E_INVALID, "null argument");
+  hipSetDevice(ctx->device);
+
+  auto job = std::make_unique<herro_job>();
+  job->ctx = ctx;
+  job->W = W;
+  job->n_targets = n_targets;
+  job->tgt_win_off.assign(n_targets + 1, 0);
+  uint32_t n_cls = 0;
+  uint64_t scr_ops = 0, col_bytes = 0, fin_bytes = 0, row_elems = 0, pos_elems = 0;
+  std::vector<uint32_t> aops;
+  std::vector<HostOw> hows;
+  for (uint32_t t = 0; t < n_targets; t++) {
+    const uint32_t rid = rids[t];
+    if (rid >= ctx->n_reads) return fail(HERRO_E_REFERENCE_PANIC, "target rid out of range (reads[rid])");
+    const uint32_t tlen = ctx->read_len[rid];
+    const uint32_t n_windows = (tlen + W - 1) / W;  // features.rs:338
+    if (n_windows > 65535) return fail(HERRO_E_UNSUPPORTED, "more than 65535 windows in a read (wid is u16 in the reference)");
+    const uint32_t win0 = (uint32_t)job->win.size();
+    // collect (window, overlap) in alignment order, then bucket by window (stable)
+    struct Tmp { HostOw h; uint32_t op_base; uint32_t aln; };
+    std::vector<Tmp> tmp;
+    std::unordered_map<uint32_t, uint32_t> cls_of_name;  // name class -> accumulator slot
+    std::unordered_map<uint32_t, uint32_t> last_aln_of_qid;
+    for (uint64_t a = aln_off[t]; a < aln_off[t + 1]; a++) {
+      const herro_alignment& al = alns[a];
+      if (al.tid != rid) return fail(HERRO_E_UNSUPPORTED, "alignment tid != target rid (parse_paf groups by target, overlaps.rs:189-192)");
+      if (al.qid >= ctx->n_reads) return fail(HERRO_E_REFERENCE_PANIC, "alignment qid out of range");
+      if (al.qid == rid) return fail(HERRO_E_UNSUPPORTED, "self overlap (dropped by parse_paf, overlaps.rs:175-179)");
+      if (last_aln_of_qid.count(al.qid)) return fail(HERRO_E_UNSUPPORTED, "second alignment of the same (query,target) pair (dropped by parse_paf, overlaps.rs:181-185)");
+      last_aln_of_qid[al.qid] = (uint32_t)(a - aln_off[t]);
+      if (al.tlen != tlen) return fail(HERRO_E_INVALID, "alignment tlen differs from the stored read length");
+      if (al.qend > ctx->read_len[al.qid] || al.tend > tlen) return fail(HERRO_E_REFERENCE_PANIC, "alignment coordinates exceed the read length");
+      BuildError be;
+      aops.clear();
+      if (!parse_cigar(al.cigar, al.cigar_len, aops, be)) return fail(be.code, be.msg);
+      hows.clear();
+      if (!window_alignment(aops, al, W, n_windows, hows, be)) return fail(be.code, be.msg);
+      const uint32_t op_base = (uint32_t)job->ops.size();
+      if (!hows.empty()) job->ops.insert(job->ops.end(), aops.begin(), aops.end());
+      for (auto& h : hows) tmp.push_back(Tmp{h, op_base, (uint32_t)(a - aln_off[t])});
+      const uint32_t nc = ctx->name_class[al.qid];
+      if (!cls_of_name.count(nc)) cls_of_name[nc] = n_cls++;
+    }
+    std::vector<uint32_t> cnt(n_windows + 1, 0);
+    for (auto& x : tmp) cnt[x.h.win + 1]++;
+    for (uint32_t i = 0; i < n_windows; i++) cnt[i + 1] += cnt[i];
+    const uint32_t ow0 = (uint32_t)job->ow.size();
+    job->ow.resize(ow0 + tmp.size());
+    std::vector<uint32_t> fill(cnt.begin(), cnt.end() - 1);
+    std::vector<uint64_t> ins_sum(n_windows, 0);
+    for (auto& x : tmp) {
+      const herro_alignment& al = alns[aln_off[t] + x.aln];
+      const uint32_t wi = x.h.win;
+      const uint32_t win_start = wi * W;
+      const uint32_t win_len = (wi == n_windows - 1) ? tlen - wi * W : W;
+      OwDesc d{};
+      d.win = win0 + wi;
+      d.qid = al.qid;
+      d.cls = cls_of_name[ctx->name_class[al.qid]];
+      d.tstart = x.h.tstart;
+      d.qlen = x.h.qend - x.h.qstart;
+      d.strand = al.strand ? 1 : 0;
+      if (x.h.qend < x.h.qstart) return fail(HERRO_E_REFERENCE_PANIC, "window qend < qstart");
+      if (d.strand == 0) d.qbeg = al.qstart + x.h.qstart;
+      else {
+        if (al.qend < x.h.qend) return fail(HERRO_E_REFERENCE_PANIC, "attempt to subtract with overflow (qend - window.qend)");
+        d.qbeg = al.qend - x.h.qend;
+      }
+      d.op_begin = x.op_base + x.h.op_lo;
+      d.op_cnt = x.h.op_hi - x.h.op_lo;
+      d.start_off = x.h.start_off;
+      d.end_off = x.h.end_off;
+      d.scr_off = (uint32_t)scr_ops;
+      // ---- validate what the reference would assert / index (features.rs:585-679, 110-237)
+      if (x.h.op_hi <= x.h.op_lo) return fail(HERRO_E_REFERENCE_PANIC, "empty cigar slice");
+      if (d.tstart < win_start) return fail(HERRO_E_REFERENCE_PANIC, "overlap starts before its window (usize underflow)");
+      if (op_type(job->ops[d.op_begin]) == OP_I)
+        return fail(HERRO_E_UNSUPPORTED, "cigar slice starts with an insertion (leading or consecutive I ops; the reference panics or writes into the previous position)");
+      uint64_t tt = 0, qq = 0;
+      for (uint32_t k = 0; k < d.op_cnt; k++) {
+        const uint32_t op = job->ops[d.op_begin + k];
+        const uint32_t l = op_len(op);
+        if (k == 0 && d.op_cnt == 1) { if (d.end_off <= d.start_off) return fail(HERRO_E_REFERENCE_PANIC, "cigar_end_offset <= cigar_start_offset"); }
+        else if (k == 0) { if (l <= d.start_off) return fail(HERRO_E_REFERENCE_PANIC, "op length <= cigar_start_offset"); }
+        const uint32_t e = eff_len(op, k, d.op_cnt, d.start_off, d.end_off);
+        if (e == 0) return fail(HERRO_E_REFERENCE_PANIC, "Operation length cannot be 0");
+        if (op_type(op) != OP_I) tt += e;
+        if (op_type(op) != OP_D) qq += e;
+        if (op_type(op) == OP_I) ins_sum[wi] += l;
+      }
+      if ((uint64_t)(d.tstart - win_start) + tt > win_len) return fail(HERRO_E_REFERENCE_PANIC, "cigar slice overruns the target window");
+      if (qq > d.qlen) return fail(HERRO_E_REFERENCE_PANIC, "cigar slice overruns the query region");
+      if ((uint64_t)d.qbeg + d.qlen > ctx->read_len[al.qid]) return fail(HERRO_E_REFERENCE_PANIC, "query region exceeds the query read");
+      scr_ops += d.op_cnt;
+      job->alg_read_bytes += (uint64_t)d.qlen + (d.qlen + 3) / 4;
+      job->alg_op_bytes += (uint64_t)d.op_cnt * 4;
+      job->ow[ow0 + fill[wi]++] = d;
+    }
+    for (uint32_t wi = 0; wi < n_windows; wi++) {
+      WinDesc wd{};
+      wd.rid = rid; wd.wid = wi; wd.n_wids = n_windows;
+      wd.tstart = wi * W;
+      wd.win_len = (wi == n_windows - 1) ? tlen - wi * W : W;
+      wd.ow_begin = ow0 + cnt[wi];
+      wd.ow_cnt = cnt[wi + 1] - cnt[wi];
+      const uint64_t lub = ((uint64_t)wd.win_len + std::min<uint64_t>(ins_sum[wi], (uint64_t)50 * wd.win_len) + 15) & ~15ull;
+      wd.lub = (uint32_t)lub;
+      wd.col_off = col_bytes; col_bytes += (uint64_t)(wd.ow_cnt + 1) * lub;
+      wd.fin_off = fin_bytes; fin_bytes += (uint64_t)HERRO_ROWS * lub;
+      wd.row_off = row_elems; row_elems += lub;
+      wd.pos_off = pos_elems; pos_elems += (uint64_t)W + 1;
+      job->alg_read_bytes += (uint64_t)wd.win_len + (wd.win_len + 3) / 4;
+      job->win.push_back(wd);
+    }
+    job->tgt_win_off[t + 1] = (uint32_t)job->win.size();
+  }
+  if (scr_ops > 0xffffffffull) return fail(HERRO_E_UNSUPPORTED, "job too large (op scratch exceeds 2^32)");
+
+  // ---- device allocation + upload
+  const uint32_t n_ow = (uint32_t)job->ow.size(), n_win = (uint32_t)job->win.size();
+  JobDev& J = job->J;
+  J.read_words = ctx->d_words; J.read_word_off = ctx->d_word_off;
+  J.read_qual = ctx->d_qual; J.read_qual_off = ctx->d_qual_off;
+  J.ln_table = ctx->d_ln; J.ln_table_n = ctx->ln_n;
+  J.n_ow = n_ow; J.n_win = n_win; J.n_cls = n_cls;
+  hipError_t e = hipSuccess;
+  bool oom = false;
+  auto A = [&](uint64_t bytes) -> void* {
+    void* p = nullptr;
+    if (hipMalloc(&p, std::max<uint64_t>(bytes, 16)) != hipSuccess) { oom = true; return nullptr; }
+    job->allocs.push_back(p);
+    return p;
+  };
+  auto up = [&](const void* src, uint64_t bytes) -> void* {
+    void* p = A(bytes);
+    if (p && bytes) e = hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+    return p;
+  };
+  J.ops = (const uint32_t*)up(job->ops.data(), job->ops.size() * 4);
+  J.ow = (const OwDesc*)up(job->ow.data(), job->ow.size() * sizeof(OwDesc));
+  J.win = (const WinDesc*)up(job->win.data(), job->win.size() * sizeof(WinDesc));
+  J.op_t = (uint32_t*)A(scr_ops * 4); J.op_q = (uint32_t*)A(scr_ops * 4);
+  J.ow_keep = (uint8_t*)A(n_ow); J.ow_acc = (float*)A((uint64_t)n_ow * 4);
+  J.ow_ttotal = (uint32_t*)A((uint64_t)n_ow * 4); J.ow_slot = (uint32_t*)A((uint64_t)n_ow * 4);
+  J.slot_ow = (uint32_t*)A((uint64_t)n_ow * 4); J.rank_qid = (uint32_t*)A((uint64_t)n_ow * 4);
+  J.score = (double*)A((uint64_t)n_ow * 8);
+  J.win_L = (uint32_t*)A((uint64_t)n_win * 4); J.win_nkept = (uint32_t*)A((uint64_t)n_win * 4);
+  J.win_p1sup = (uint32_t*)A((uint64_t)n_win * 4); J.win_Lf = (uint32_t*)A((uint64_t)n_win * 4);
+  J.win_nsup = (uint32_t*)A((uint64_t)n_win * 4);
+  J.row_of_pos = (uint32_t*)A(pos_elems * 4);
+  J.rowmap = (uint32_t*)A(row_elems * 4); J.newidx = (uint32_t*)A(row_elems * 4);
+  J.sup_row = (uint32_t*)A(row_elems * 4); J.sup_pi = (uint32_t*)A(row_elems * 4);
+  J.cols_b = (uint8_t*)A(col_bytes); J.cols_q = (uint8_t*)A(col_bytes);
+  J.fin_b = (uint8_t*)A(fin_bytes); J.fin_q = (uint8_t*)A(fin_bytes);
+  J.nd = (uint32_t*)A((uint64_t)n_cls * 8);
+  if (oom || e != hipSuccess) {
+    free_all(job->allocs);
+    return fail(HERRO_E_NO_DEVICE, oom ? "out of device memory for the job" : hipGetErrorString(e));
+  }
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) { free_all(job->allocs); return fail(HERRO_E_NO_DEVICE, "upload failed"); }
+  return job.release();
+}
+
+void herro_job_free(herro_job* job) {
+  if (!job) return;
+  hipSetDevice(job->ctx->device);
+  hipStreamSynchronize(job->ctx->stream);
+  free_all(job->allocs);
+  if (job->d_info) hipFree(job->d_info);
+  if (job->d_base) hipFree(job->d_base);
+  if (job->d_bdesc) hipFree(job->d_bdesc);
+  delete job;
+}
+
+uint32_t herro_job_n_windows(const herro_job* job) { return job ? (uint32_t)job->win.size() : 0; }
+
+int herro_job_featurize(herro_job* job) {
+  if (!job) return HERRO_E_INVALID;
+  herro_ctx* ctx = job->ctx;
+  hipSetDevice(ctx->device);
+  if (job->J.n_win == 0) { job->featurized = true; return HERRO_OK; }
+  HIP_TRY(ctx, hipMemsetAsync(job->J.nd, 0, std::max<uint64_t>((uint64_t)job->J.n_cls * 8, 8), ctx->stream));
+  launch_featurize(job->J, ctx->stream, &ctx->timer);
+  HIP_TRY(ctx, hipGetLastError());
+  job->featurized = true;
+  job->synced = false;
+  job->inferred = false;
+  return HERRO_OK;
+}
+
+}  // extern "C"
+
+static int job_sync(herro_job* job) {
+  herro_ctx* ctx = job->ctx;
+  if (!job->featurized) { ctx->err = "herro_job_featurize has not run"; return HERRO_E_STATE; }
+  if (job->synced) return HERRO_OK;
+  hipSetDevice(ctx->device);
+  const uint32_t n = job->J.n_win;
+  job->h_Lf.resize(n); job->h_nsup.resize(n); job->h_nkept.resize(n); job->h_L.resize(n);
+  if (n) {
+    HIP_TRY(ctx, hipMemcpyAsync(job->h_Lf.data(), job->J.win_Lf, n * 4ull, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(job->h_nsup.data(), job->J.win_nsup, n * 4ull, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(job->h_nkept.data(), job->J.win_nkept, n * 4ull, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(job->h_L.data(), job->J.win_L, n * 4ull, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->timer.collect();
+  job->sup_off.assign(n + 1, 0);
+  for (uint32_t w = 0; w < n; w++) job->sup_off[w + 1] = job->sup_off[w] + job->h_nsup[w];
+  job->synced = true;
+  return HERRO_OK;
+}
+
+extern "C" {
+
+int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
+  if (!job || batch_size == 0) return HERRO_E_INVALID;
+  herro_ctx* ctx = job->ctx;
+  if (!ctx->has_model) { ctx->err = "no model loaded"; return HERRO_E_NO_MODEL; }
+  int rc = job_sync(job);
+  if (rc) return rc;
+  hipSetDevice(ctx->device);
+  const uint32_t n = job->J.n_win;
+  const uint64_t total_sup = job->sup_off[n];
+  if (!job->d_info) {
+    HIP_TRY(ctx, hipMalloc((void**)&job->d_info, std::max<uint64_t>(total_sup, 1) * 4));
+    HIP_TRY(ctx, hipMalloc((void**)&job->d_base, std::max<uint64_t>(total_sup, 1) * 20));
+  }
+  // ---- plan batches (prepare_examples, inference.rs:241-250; flush rule features.rs:884-893)
+  job->batches.clear();
+  auto flush = [&](std::vector<uint32_t>& cur) {
+    if (cur.empty()) return;
+    BatchPlan bp;
+    bp.wins = cur;
+    for (uint32_t w : cur) { bp.n_tok += job->h_nsup[w]; bp.lmax = std::max(bp.lmax, job->h_Lf[w]); }
+    job->batches.push_back(std::move(bp));
+    cur.clear();
+  };
+  std::vector<uint32_t> cur;
+  if (batch_mode == 0) {
+    for (uint32_t t = 0; t < job->n_targets; t++) {
+      uint32_t seen = 0;
+      for (uint32_t w = job->tgt_win_off[t]; w < job->tgt_win_off[t + 1]; w++) {
+        if (job->h_nsup[w] > 0) cur.push_back(w);
+        if (++seen == batch_size) { flush(cur); seen = 0; }  // InferenceOutput::update flush
+      }
+      flush(cur);  // InferenceOutput::emit at end of read
+    }
+  } else {
+    for (uint32_t w = 0; w < n; w++) {
+      if (job->h_nsup[w] == 0) continue;
+      cur.push_back(w);
+      if (cur.size() == batch_size) flush(cur);
+    }
+    flush(cur);
+  }
+  // ---- descriptor block for all batches, one upload
+  std::vector<unsigned char> blob;
+  auto put = [&](const void* p, size_t bytes) {
+    const size_t o = (blob.size() + 15) & ~size_t(15);
+    blob.resize(o + bytes);
+    std::memcpy(blob.data() + o, p, bytes);
+    return o;
+  };
+  struct Offs { size_t plane_off, plane_ld, len, tok_off, sup_off, out_off; };
+  std::vector<Offs> offs;
+  uint32_t max_tok = 0;
+  for (auto& bp : job->batches) {
+    const size_t B = bp.wins.size();
+    std::vector<uint64_t> plane_off(B), sup_o(B), out_o(B);
+    std::vector<uint32_t> ld(B), len(B), tok_off(B + 1, 0);
+    for (size_t i = 0; i < B; i++) {
+      const WinDesc& wd = job->win[bp.wins[i]];
+      plane_off[i] = wd.fin_off; ld[i] = wd.lub; len[i] = job->h_Lf[bp.wins[i]];
+      tok_off[i + 1] = tok_off[i] + job->h_nsup[bp.wins[i]];
+      sup_o[i] = wd.row_off; out_o[i] = job->sup_off[bp.wins[i]];
+    }
+    Offs o;
+    o.plane_off = put(plane_off.data(), B * 8); o.plane_ld = put(ld.data(), B * 4);
+    o.len = put(len.data(), B * 4); o.tok_off = put(tok_off.data(), (B + 1) * 4);
+    o.sup_off = put(sup_o.data(), B * 8); o.out_off = put(out_o.data(), B * 8);
+    offs.push_back(o);
+    max_tok = std::max(max_tok, bp.n_tok);
+  }
+  if (job->d_bdesc) { hipFree(job->d_bdesc); job->d_bdesc = nullptr; }
+  if (!blob.empty()) {
+    HIP_TRY(ctx, hipMalloc(&job->d_bdesc, blob.size()));
+    HIP_TRY(ctx, hipMemcpyAsync(job->d_bdesc, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream));
+    // the blob lives on the host stack frame: finish the copy before returning
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  rc = ensure_scratch(ctx, max_tok);
+  if (rc) return rc;
+  for (size_t bi = 0; bi < job->batches.size(); bi++) {
+    const BatchPlan& bp = job->batches[bi];
+    const unsigned char* base = (const unsigned char*)job->d_bdesc;
+    BatchDev B{};
+    B.n_win = (uint32_t)bp.wins.size(); B.n_tok = bp.n_tok; B.lmax = bp.lmax;
+    B.plane_off = (const uint64_t*)(base + offs[bi].plane_off);
+    B.plane_ld = (const uint32_t*)(base + offs[bi].plane_ld);
+    B.len = (const uint32_t*)(base + offs[bi].len);
+    B.tok_off = (const uint32_t*)(base + offs[bi].tok_off);
+    B.sup_off = (const uint64_t*)(base + offs[bi].sup_off);
+    B.out_off = (const uint64_t*)(base + offs[bi].out_off);
+    B.planes_b = job->J.fin_b; B.planes_q = job->J.fin_q; B.sup_row = job->J.sup_row;
+    B.out_info = job->d_info; B.out_base = job->d_base;
+    launch_model(ctx->M, B, ctx->S, ctx->precision, ctx->stream, &ctx->timer);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  job->inferred = true;
+  job->logits_on_host = false;
+  return HERRO_OK;
+}
+
+int herro_job_window_info(herro_job* job, uint32_t w, herro_window_info* info) {
+  if (!job || !info || w >= job->win.size()) return HERRO_E_INVALID;
+  int rc = job_sync(job);
+  if (rc) return rc;
+  const WinDesc& wd = job->win[w];
+  info->rid = wd.rid; info->wid = wd.wid; info->n_total_wins = wd.n_wids;
+  info->length = job->h_Lf[w];
+  info->n_overlaps = job->h_nkept[w];
+  info->n_alns = std::min<uint32_t>(job->h_nkept[w], 30);
+  info->n_supported = job->h_nsup[w];
+  info->win_len = wd.win_len;
+  return HERRO_OK;
+}
+
+static int fetch_planes(herro_job* job, uint32_t w, std::vector<uint8_t>& pb, std::vector<uint8_t>* pq) {
+  herro_ctx* ctx = job->ctx;
+  const WinDesc& wd = job->win[w];
+  const size_t bytes = (size_t)HERRO_ROWS * wd.lub;
+  pb.resize(bytes);
+  HIP_TRY(ctx, hipMemcpy(pb.data(), job->J.fin_b + wd.fin_off, bytes, hipMemcpyDeviceToHost));
+  if (pq) {
+    pq->resize(bytes);
+    HIP_TRY(ctx, hipMemcpy(pq->data(), job->J.fin_q + wd.fin_off, bytes, hipMemcpyDeviceToHost));
+  }
+  return HERRO_OK;
+}
+
+int herro_job_window_copy(herro_job* job, uint32_t w, int encoded, uint8_t* bases, uint8_t* quals,
+                          uint16_t* sup_pos, uint8_t* sup_ins, uint32_t* qids) {
+  if (!job || w >= job->win.size()) return HERRO_E_INVALID;
+  int rc = job_sync(job);
+  if (rc) return rc;
+  herro_ctx* ctx = job->ctx;
+  hipSetDevice(ctx->device);
+  const WinDesc& wd = job->win[w];
+  const uint32_t L = job->h_Lf[w];
+  if (bases || quals) {
+    std::vector<uint8_t> pb, pq;
+    rc = fetch_planes(job, w, pb, quals ? &pq : nullptr);
+    if (rc) return rc;
+    for (uint32_t r = 0; r < L; r++)
+      for (uint32_t c = 0; c < HERRO_ROWS; c++) {
+        if (bases) {
+          const uint8_t t = pb[(size_t)c * wd.lub + r];
+          bases[(size_t)r * HERRO_ROWS + c] = encoded ? t : (uint8_t)TOK_ASCII[t < 12 ? t : 12 - 1];
+        }
+        if (quals) quals[(size_t)r * HERRO_ROWS + c] = pq[(size_t)c * wd.lub + r];
+      }
+  }
+  const uint32_t ns = job->h_nsup[w];
+  if ((sup_pos || sup_ins) && ns) {
+    std::vector<uint32_t> pi(ns);
+    HIP_TRY(ctx, hipMemcpy(pi.data(), job->J.sup_pi + wd.row_off, ns * 4ull, hipMemcpyDeviceToHost));
+    for (uint32_t k = 0; k < ns; k++) {
+      if (sup_pos) sup_pos[k] = (uint16_t)(pi[k] & 0xffffu);
+      if (sup_ins) sup_ins[k] = (uint8_t)(pi[k] >> 16);
+    }
+  }
+  if (qids && job->h_nkept[w])
+    HIP_TRY(ctx, hipMemcpy(qids, job->J.rank_qid + wd.ow_begin, job->h_nkept[w] * 4ull, hipMemcpyDeviceToHost));
+  return HERRO_OK;
+}
+
+static int logits_to_host(herro_job* job) {
+  herro_ctx* ctx = job->ctx;
+  if (!job->inferred) { ctx->err = "herro_job_infer has not run"; return HERRO_E_STATE; }
+  if (job->logits_on_host) return HERRO_OK;
+  hipSetDevice(ctx->device);
+  const uint64_t tot = job->sup_off.back();
+  job->h_info.resize(tot);
+  job->h_base.resize(tot * 5);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->timer.collect();
+  if (tot) {
+    HIP_TRY(ctx, hipMemcpy(job->h_info.data(), job->d_info, tot * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(job->h_base.data(), job->d_base, tot * 20, hipMemcpyDeviceToHost));
+  }
+  job->logits_on_host = true;
+  return HERRO_OK;
+}
+
+int herro_job_window_logits(herro_job* job, uint32_t w, float* info_logits, float* bases_logits) {
+  if (!job || w >= job->win.size()) return HERRO_E_INVALID;
+  int rc = logits_to_host(job);
+  if (rc) return rc;
+  const uint64_t o = job->sup_off[w], n = job->h_nsup[w];
+  if (info_logits) std::memcpy(info_logits, job->h_info.data() + o, n * 4);
+  if (bases_logits) std::memcpy(bases_logits, job->h_base.data() + o * 5, n * 20);
+  return HERRO_OK;
+}
+
+// consensus.rs:86-227 + lib.rs:282-317 on the host, from device results.
+int64_t herro_job_consensus_fasta(herro_job* job, uint32_t t, const char* id, const char* desc, char* out,
+                                  uint64_t cap) {
+  if (!job || t >= job->n_targets || !id || !out) return HERRO_E_INVALID;
+  herro_ctx* ctx = job->ctx;
+  int rc = job_sync(job);
+  if (rc) return rc;
+  const uint32_t w0 = job->tgt_win_off[t], w1 = job->tgt_win_off[t + 1];
+  bool need_logits = false;
+  for (uint32_t w = w0; w < w1; w++) need_logits |= job->h_nsup[w] > 0 && std::min<uint32_t>(job->h_nkept[w], 30) >= 2;
+  if (need_logits && (rc = logits_to_host(job))) return rc;
+  hipSetDevice(ctx->device);
+  // first..last window with n_alns > 1 (consensus.rs:90-101)
+  int64_t st = -1, en = -1;
+  for (uint32_t w = w0; w < w1; w++)
+    if (std::min<uint32_t>(job->h_nkept[w], 30) > 1) { if (st < 0) st = w; en = w + 1; }
+  if (st < 0) return 0;
+  std::vector<std::string> seqs;
+  std::string cur;
+  static const char UP[10] = {'A', 'C', 'G', 'T', '*', 'A', 'C', 'G', 'T', '*'};
+  static const int CNT[10] = {0, 1, 2, 3, 4, 0, 1, 2, 3, 4};
+  std::vector<uint8_t> pb;
+  for (uint32_t w = (uint32_t)st; w < (uint32_t)en; w++) {
+    const uint32_t n_alns = std::min<uint32_t>(job->h_nkept[w], 30);
+    if (n_alns < 2) {
+      if (!cur.empty()) { seqs.push_back(cur); cur.clear(); }
+      continue;
+    }
+    const WinDesc& wd = job->win[w];
+    const uint32_t L = job->h_Lf[w], ns = job->h_nsup[w], n_rows = n_alns + 1;
+    if ((rc = fetch_planes(job, w, pb, nullptr))) return rc;
+    std::vector<uint32_t> srow(ns);
+    if (ns) HIP_TRY(ctx, hipMemcpy(srow.data(), job->J.sup_row + wd.row_off, ns * 4ull, hipMemcpyDeviceToHost));
+    const float* bl = ns ? job->h_base.data() + job->sup_off[w] * 5 : nullptr;
+    uint32_t k = 0;  // informative rows are sorted by row, so one cursor replaces the hash map
+    for (uint32_t r = 0; r < L; r++) {
+      char base;
+      if (k < ns && srow[k] == r) {
+        const float* b = bl + (size_t)k * 5;
+        int arg = 0;  // max_by_key: the LAST maximum wins; NaN is the greatest (consensus.rs:136-141)
+        for (int c = 1; c < 5; c++) {
+          const float v = b[c], m = b[arg];
+          const bool ge = std::isnan(v) ? true : (std::isnan(m) ? false : v >= m);
+          if (ge) arg = c;
+        }
+        base = "ACGT*"[arg];
+        k++;
+      } else {
+        uint8_t counts[5] = {0, 0, 0, 0, 0};
+        for (uint32_t c = 0; c < n_rows; c++) {
+          const uint8_t tk = pb[(size_t)c * wd.lub + r];
+          if (tk != TOK_NONE) {
+            if (tk >= 10) { ctx->err = "token >= 10 in consensus"; return HERRO_E_REFERENCE_PANIC; }
+            counts[CNT[tk]]++;
+          }
+        }
+        int ord[5] = {0, 1, 2, 3, 4};
+        std::stable_sort(ord, ord + 5, [&](int a, int b) { return counts[a] > counts[b]; });
+        const uint8_t c0 = counts[ord[0]], c1 = counts[ord[1]];
+        const char b0 = UP[ord[0]], b1 = UP[ord[1]];
+        const uint8_t t0 = pb[r];
+        if (t0 >= 10) { ctx->err = "target token >= 10 in consensus"; return HERRO_E_REFERENCE_PANIC; }
+        const char tb = UP[t0];
+        base = (c0 < 2 || (c0 == c1 && (b0 == tb || b1 == tb))) ? tb : b0;
+      }
+      if (base != '*') cur.push_back(base);
+    }
+  }
+  if (!cur.empty()) seqs.push_back(cur);
+  std::string fa;
+  for (size_t i = 0; i < seqs.size(); i++) {  // lib.rs:282-317
+    fa += ">";
+    fa += id;
+    if (seqs.size() == 1) fa += " ";
+    else fa += ":" + std::to_string(i) + " ";
+    if (desc) fa += desc;
+    fa += "\n";
+    fa += seqs[i];
+    fa += "\n";
+  }
+  if (fa.size() > cap) { ctx->err = "output buffer too small"; return HERRO_E_INVALID; }
+  std::memcpy(out, fa.data(), fa.size());
+  return (int64_t)fa.size();
+}
+
+// ---- stand-alone model entry (inference.rs:147-175) ----------------------------------------------
+int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* bases, const uint8_t* quals,
+                        const int32_t* lens, const int32_t* indices, float* info_logits, float* bases_logits) {
+  if (!ctx || !bases || !quals || !lens) return HERRO_E_INVALID;
+  if (!ctx->has_model) { ctx->err = "no model loaded"; return HERRO_E_NO_MODEL; }
+  hipSetDevice(ctx->device);
+  uint64_t N = 0;
+  std::vector<uint32_t> tok_off(B + 1, 0), len(B, L), ld(B, (L + 15) & ~15u), srow;
+  for (uint32_t b = 0; b < B; b++) {
+    if (lens[b] < 0) return HERRO_E_INVALID;
+    tok_off[b + 1] = tok_off[b] + (uint32_t)lens[b];
+    N += (uint64_t)lens[b];
+  }
+  if (N && (!indices || !info_logits || !bases_logits)) return HERRO_E_INVALID;
+  srow.resize(N);
+  for (uint64_t i = 0; i < N; i++) {
+    if (indices[i] < 0 || (uint32_t)indices[i] >= L) { ctx->err = "index out of range"; return HERRO_E_REFERENCE_PANIC; }
+    srow[i] = (uint32_t)indices[i];
+  }
+  if (N == 0) return HERRO_OK;
+  const uint64_t cells = (uint64_t)B * L * HERRO_ROWS;
+  std::vector<uint64_t> plane_off(B), sup_off(B), out_off(B);
+  for (uint32_t b = 0; b < B; b++) { plane_off[b] = (uint64_t)b * HERRO_ROWS * L; sup_off[b] = tok_off[b]; out_off[b] = tok_off[b]; ld[b] = L; }
+  std::vector<void*> tmp;
+  auto A = [&](uint64_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, std::max<uint64_t>(bytes, 16)) == hipSuccess) tmp.push_back(p); return p; };
+  uint8_t* d_src_b = (uint8_t*)A(cells); uint8_t* d_src_q = (uint8_t*)A(cells);
+  uint8_t* d_pb = (uint8_t*)A(cells); uint8_t* d_pq = (uint8_t*)A(cells);
+  uint64_t* d_po = (uint64_t*)A(B * 8ull); uint32_t* d_ld = (uint32_t*)A(B * 4ull); uint32_t* d_len = (uint32_t*)A(B * 4ull);
+  uint32_t* d_to = (uint32_t*)A((B + 1) * 4ull); uint64_t* d_so = (uint64_t*)A(B * 8ull); uint64_t* d_oo = (uint64_t*)A(B * 8ull);
+  uint32_t* d_sr = (uint32_t*)A(N * 4); float* d_info = (float*)A(N * 4); float* d_base = (float*)A(N * 20);
+  int rc = HERRO_OK;
+  auto done = [&](int code) { for (void* p : tmp) hipFree(p); return code; };
+  if (!d_src_b || !d_src_q || !d_pb || !d_pq || !d_po || !d_ld || !d_len || !d_to || !d_so || !d_oo || !d_sr || !d_info || !d_base) {
+    ctx->err = "out of device memory";
+    return done(HERRO_E_NO_DEVICE);
+  }
+  hipStream_t st = ctx->stream;
+  hipMemcpyAsync(d_src_b, bases, cells, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(d_src_q, quals, cells, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(d_po, plane_off.data(), B * 8ull, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(d_ld, ld.data(), B * 4ull, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(d_len, len.data(), B * 4ull, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(d_to, tok_off.data(), (B + 1) * 4ull, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(d_so, sup_off.data(), B * 8ull, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(d_oo, out_off.data(), B * 8ull, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(d_sr, srow.data(), N * 4, hipMemcpyHostToDevice, st);
+  launch_transpose_blr(d_src_b, d_pb, B, L, st);
+  launch_transpose_blr(d_src_q, d_pq, B, L, st);
+  if ((rc = ensure_scratch(ctx, (uint32_t)N))) return done(rc);
+  BatchDev bd{};
+  bd.n_win = B; bd.n_tok = (uint32_t)N; bd.lmax = L;
+  bd.plane_off = d_po; bd.plane_ld = d_ld; bd.len = d_len; bd.tok_off = d_to; bd.sup_off = d_so; bd.out_off = d_oo;
+  bd.planes_b = d_pb; bd.planes_q = d_pq; bd.sup_row = d_sr; bd.out_info = d_info; bd.out_base = d_base;
+  launch_model(ctx->M, bd, ctx->S, ctx->precision, st, &ctx->timer);
+  hipError_t e = hipStreamSynchronize(st);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return done(HERRO_E_NO_DEVICE); }
+  ctx->timer.collect();
+  hipMemcpy(info_logits, d_info, N * 4, hipMemcpyDeviceToHost);
+  hipMemcpy(bases_logits, d_base, N * 20, hipMemcpyDeviceToHost);
+  return done(HERRO_OK);
+}
+
+// ---- host-only test hook: the product's windowing on one alignment (no device needed) -----------
+// out rows of 8 u64: window, tstart, qstart, qend, op_lo, op_hi, start_off, end_off.
+int64_t herro_debug_extract_windows(const herro_alignment* a, uint32_t n_windows, uint32_t W, uint64_t* out,
+                                    uint64_t cap, char* err, uint64_t err_cap) {
+  std::vector<uint32_t> ops;
+  std::vector<HostOw> hows;
+  BuildError be;
+  if (!a || !parse_cigar(a->cigar, a->cigar_len, ops, be) || !window_alignment(ops, *a, W, n_windows, hows, be)) {
+    if (err && err_cap) { std::strncpy(err, a ? be.msg.c_str() : "null", err_cap - 1); err[err_cap - 1] = 0; }
+    return a ? be.code : HERRO_E_INVALID;
+  }
+  if (hows.size() > cap) return HERRO_E_INVALID;
+  for (size_t k = 0; k < hows.size(); k++) {
+    uint64_t* o = out + 8 * k;
+    o[0] = hows[k].win; o[1] = hows[k].tstart; o[2] = hows[k].qstart; o[3] = hows[k].qend;
+    o[4] = hows[k].op_lo; o[5] = hows[k].op_hi; o[6] = hows[k].start_off; o[7] = hows[k].end_off;
+  }
+  return (int64_t)hows.size();
+}
+
+// ---- measurement -----------------------------------------------------------------------------------
+int herro_timing_enable(herro_ctx* ctx, int on) { if (!ctx) return HERRO_E_INVALID; ctx->timer.on = on != 0; return HERRO_OK; }
+int herro_timing_reset(herro_ctx* ctx) {
+  if (!ctx) return HERRO_E_INVALID;
+  hipStreamSynchronize(ctx->stream);
+  ctx->timer.reset();
+  return HERRO_OK;
+}
+int herro_timing_get(herro_ctx* ctx, char* names, uint64_t cap, double* ms, uint64_t* calls, uint32_t* n) {
+  if (!ctx || !n) return HERRO_E_INVALID;
+  hipStreamSynchronize(ctx->stream);
+  ctx->timer.collect();
+  std::string s;
+  uint32_t k = 0;
+  for (auto& nm : ctx->timer.order) {
+    if (k < *n) {
+      if (ms) ms[k] = ctx->timer.acc[nm].first;
+      if (calls) calls[k] = ctx->timer.acc[nm].second;
+    }
+    s += nm;
+    s += "\n";
+    k++;
+  }
+  if (names && cap) { std::strncpy(names, s.c_str(), cap - 1); names[cap - 1] = 0; }
+  *n = k;
+  return HERRO_OK;
+}
+
+int herro_job_stats(herro_job* job, uint64_t* out) {
+  if (!job || !out) return HERRO_E_INVALID;
+  int rc = job_sync(job);
+  if (rc) return rc;
+  uint64_t sumL = 0, sumS = 0, nz = 0;
+  for (size_t w = 0; w < job->win.size(); w++) { sumL += job->h_Lf[w]; sumS += job->h_nsup[w]; nz += job->h_nsup[w] > 0; }
+  out[0] = job->alg_read_bytes; out[1] = job->alg_op_bytes; out[2] = 2ull * HERRO_ROWS * sumL;
+  out[3] = sumL; out[4] = sumS; out[5] = nz;
+  return HERRO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+// job_dev.h — device-side view of one job (plain pointers, passed to kernels by value) and the
+// HIP-event kernel timer used by bench.py's roofline leg.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "pileup_core.h"
+
+#define HERRO_ROWS 31
+#define HERRO_MAX_WINDOW 8192
+
+namespace herro {
+
+struct JobDev {
+  // ---- read store (context-owned; HBM-resident for the life of the context)
+  const uint64_t* read_words;     // 2-bit packed bases, every read starts on a u64 boundary
+  const uint64_t* read_word_off;  // [n_reads+1]
+  const uint8_t* read_qual;       // phred+33 bytes
+  const uint64_t* read_qual_off;  // [n_reads+1]
+  const double* ln_table;         // ln(k+1) computed on the host with glibc (bit-faithful to Rust std)
+  uint32_t ln_table_n;
+  // ---- descriptors (uploaded by herro_job_create)
+  uint32_t n_ow, n_win, n_cls;
+  const uint32_t* ops;
+  const OwDesc* ow;
+  const WinDesc* win;
+  // ---- scratch / results
+  uint32_t* op_t;        // per (overlap, op): target bases consumed before the op
+  uint32_t* op_q;        // ... query bases consumed before the op
+  uint8_t* ow_keep;      // long-indel filter verdict
+  float* ow_acc;         // accuracy
+  uint32_t* ow_ttotal;   // target bases consumed by the slice
+  uint32_t* ow_slot;     // 1-based pass-1 column of the overlap (0: filtered)
+  uint32_t* slot_ow;     // [win.ow_begin + slot-1] -> overlap index
+  uint32_t* win_L;       // rows of the pass-1 matrix
+  uint32_t* win_nkept;
+  uint32_t* win_p1sup;
+  uint32_t* win_Lf;      // rows of the final matrix (L')
+  uint32_t* win_nsup;
+  uint32_t* row_of_pos;  // [win.pos_off + p], p in [0, win_len]
+  uint32_t* rowmap;      // [win.row_off + row] = pos | ins << 16
+  uint32_t* newidx;      // [win.row_off + row] -> compacted row
+  uint32_t* sup_row;     // [win.row_off + k]   compacted row of informative position k
+  uint32_t* sup_pi;      // [win.row_off + k]   pos | ins << 16
+  uint8_t* cols_b;       // pass-1 token planes  [win.col_off + slot*lub + row]
+  uint8_t* cols_q;       // pass-1 quality planes
+  uint8_t* fin_b;        // final token planes   [win.fin_off + c*lub + row], c in [0,31)
+  uint8_t* fin_q;
+  uint32_t* nd;          // [2*cls]: matches, mismatches (features.rs:461-500)
+  double* score;         // [ow] haplotype score per pass-1 slot
+  uint32_t* rank_qid;    // [win.ow_begin + rank] ranked query ids (features.rs:569)
+};
+
+// Accumulates GPU time per kernel group with HIP events recorded on the launch stream.
+struct KernelTimer {
+  bool on = false;
+  struct Rec { std::string name; hipEvent_t a, b; };
+  std::vector<Rec> pending;
+  std::map<std::string, std::pair<double, uint64_t>> acc;  // name -> (ms, calls)
+  std::vector<std::string> order;
+  void begin(const char* name, hipStream_t st) {
+    Rec r;
+    r.name = name;
+    hipEventCreate(&r.a);
+    hipEventCreate(&r.b);
+    hipEventRecord(r.a, st);
+    pending.push_back(r);
+  }
+  void end(hipStream_t st) { hipEventRecord(pending.back().b, st); }
+  void collect() {  // caller has synchronised the stream
+    for (auto& r : pending) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+        if (!acc.count(r.name)) order.push_back(r.name);
+        auto& e = acc[r.name];
+        e.first += ms;
+        e.second += 1;
+      }
+      hipEventDestroy(r.a);
+      hipEventDestroy(r.b);
+    }
+    pending.clear();
+  }
+  void reset() {
+    collect();
+    acc.clear();
+    order.clear();
+  }
+};
+
+#define KT_BEGIN(tm, name, st) do { if ((tm) && (tm)->on) (tm)->begin(name, st); } while (0)
+#define KT_END(tm, st) do { if ((tm) && (tm)->on) (tm)->end(st); } while (0)
+
+void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm);
+
+}  // namespace herro

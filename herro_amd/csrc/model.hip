@@ -1,0 +1,453 @@
+// model.hip — correction-model forward on gfx950 (replaces the libtorch call at reference
+// src/inference.rs:152-172).  See model_dev.h for the (assumed) architecture.
+//
+// Exactness note: the conv stack and the per-position linear are evaluated ONLY for the rows the
+// reference's model gathers (`indices`, inference.rs:136-141), over the receptive field of each
+// such row.  A dense evaluation over all L x 31 cells followed by the gather gives the same
+// numbers, 30-100x slower; the batch-padding cells the dense model would see near a window's tail
+// (token 11 / quality 126 up to the batch's max length, zeros beyond — inference.rs:86-97) are
+// reproduced exactly.
+//
+// GEMMs run on the matrix cores.  precision 0: v_mfma_f32_16x16x4_f32 (exact f32);
+// precision 1: v_mfma_f32_16x16x32_bf16 on a hi/lo bf16 split of both operands, 3 MFMAs per
+// k-step (a*b ~= ah*bh + ah*bl + al*bh, ~2^-16 relative) — this is what keeps logits inside the
+// 1e-3 contract while running ~5x the f32 MFMA rate; precision 2: plain VALU (debug reference).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "model_dev.h"
+
+namespace herro {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+// inference.rs:16-21,153: x = QUAL_SCALE * q - QUAL_OFFSET evaluated in f32, two roundings.
+__device__ __forceinline__ float norm_qual(uint32_t q) {
+  const float QS = (float)(2.0 / 93.0);
+  const float QO = (float)(2.0 * 33.0 / 93.0 + 1.0);
+  return __fsub_rn(__fmul_rn(QS, (float)q), QO);
+}
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+// ---------------------------------------------------------------------------------------------------
+// token table
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_build_tokens(BatchDev B, ModelScratch S) {
+  const uint32_t b = blockIdx.x;
+  const uint32_t t0 = B.tok_off[b], t1 = B.tok_off[b + 1];
+  for (uint32_t n = t0 + threadIdx.x; n < t1; n += blockDim.x) {
+    S.tok_win[n] = b;
+    S.tok_row[n] = B.sup_row[B.sup_off[b] + (n - t0)];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// embedding + quality channel + conv1 (+BN folded) + ReLU on the receptive field of one token.
+// One workgroup per token.  y1[n][r][dl][c] = conv1 output of read row r at position l+dl-h.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_patch_conv1(ModelDev M, BatchDev B, ModelScratch S) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t kw = M.h.kw, c1 = M.h.c1, h = kw / 2, P = 4 * h + 1;
+  float* s_t1 = reinterpret_cast<float*>(smem);  // [kw][12][c1]
+  float* s_wq = s_t1 + kw * 12 * c1;              // [kw][c1]
+  float* s_b1 = s_wq + kw * c1;                   // [c1]
+  float* s_qn = s_b1 + c1;                        // [31][P] normalised quality (0 where invalid)
+  uint32_t* s_tok = reinterpret_cast<uint32_t*>(s_qn + HERRO_ROWS * P);  // [31][P] token, 255 = outside
+
+  const uint32_t n = blockIdx.x;
+  const uint32_t b = S.tok_win[n];
+  const int32_t l = (int32_t)S.tok_row[n];
+  const int32_t len = (int32_t)B.len[b], lmax = (int32_t)B.lmax;
+  const uint8_t* pb = B.planes_b + B.plane_off[b];
+  const uint8_t* pq = B.planes_q + B.plane_off[b];
+  const uint32_t ld = B.plane_ld[b];
+
+  for (uint32_t e = threadIdx.x; e < kw * 12 * c1; e += blockDim.x) s_t1[e] = M.t1[e];
+  for (uint32_t e = threadIdx.x; e < kw * c1; e += blockDim.x) s_wq[e] = M.wq1[e];
+  for (uint32_t e = threadIdx.x; e < c1; e += blockDim.x) s_b1[e] = M.b1[e];
+  for (uint32_t e = threadIdx.x; e < HERRO_ROWS * P; e += blockDim.x) {
+    const uint32_t r = e / P;
+    const int32_t q = l - 2 * (int32_t)h + (int32_t)(e % P);
+    uint32_t tok = 255u;
+    float qn = 0.f;
+    if (q >= 0 && q < lmax) {
+      if (q < len) {
+        tok = pb[(uint64_t)r * ld + q];
+        qn = norm_qual(pq[(uint64_t)r * ld + q]);
+      } else {  // batch padding (inference.rs:86-97)
+        tok = TOK_PAD;
+        qn = norm_qual(126u);
+      }
+    }
+    s_tok[e] = tok;
+    s_qn[e] = qn;
+  }
+  __syncthreads();
+
+  float* y1 = S.y1 + (uint64_t)n * HERRO_ROWS * kw * c1;
+  const uint32_t total = HERRO_ROWS * kw * c1;
+  for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
+    const uint32_t c = e % c1, dl = (e / c1) % kw, r = e / (c1 * kw);
+    const int32_t pos = l + (int32_t)dl - (int32_t)h;
+    float v = 0.f;
+    if (pos >= 0 && pos < lmax) {  // outside: conv2's zero padding
+      v = s_b1[c];
+      for (uint32_t t = 0; t < kw; t++) {
+        const uint32_t pi = dl + t;  // patch index of position pos + t - h
+        const uint32_t tok = s_tok[r * P + pi];
+        if (tok != 255u) v += s_t1[(t * 12 + tok) * c1 + c] + s_wq[t * c1 + c] * s_qn[r * P + pi];
+      }
+      v = fmaxf(v, 0.f);
+    }
+    y1[e] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Generic GEMM: C[M,N] = epi(A[M,K] . W[K,N] + bias) (+ R).  W is stored transposed ([N][K]).
+// 64x64 tile per workgroup (4 waves as 2x2, each 32x32 = 2x2 MFMA 16x16 tiles), BK = 32.
+// ---------------------------------------------------------------------------------------------------
+static constexpr int BM = 64, BN = 64, BK = 32;
+static constexpr int LDH = BK + 8;  // bf16 row stride (80 B: keeps 16-B alignment, spreads banks)
+static constexpr int LDF = BK + 1;  // f32 row stride
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, uint32_t lda, Weight W,
+                                              float* C, uint32_t ldc, const float* R, uint32_t M,
+                                              int relu) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(MODE == 1) ? 4 * BM * LDH * 2 : 2 * BM * LDF * 4];
+  const uint32_t K = W.K, N = W.N;
+  const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t wy = wave >> 1, wx = wave & 1;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float vacc[4][4];  // MODE 2
+  if (MODE == 2) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) vacc[i][j] = 0.f;
+  }
+
+  for (uint32_t k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();
+    if constexpr (MODE == 1) {
+      uint16_t* a_hi = reinterpret_cast<uint16_t*>(smem);
+      uint16_t* a_lo = a_hi + BM * LDH;
+      uint16_t* b_hi = a_lo + BM * LDH;
+      uint16_t* b_lo = b_hi + BN * LDH;
+      // A: 64x32 f32 -> split on the fly
+#pragma unroll
+      for (int it = 0; it < 2; it++) {
+        const uint32_t e = tid + it * 256, row = e >> 3, c4 = (e & 7) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m0 + row < M) v = *reinterpret_cast<const float4*>(A + (uint64_t)(m0 + row) * lda + k0 + c4);
+        const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint16_t hb = f32_to_bf16_rne(f[q]);
+          a_hi[row * LDH + c4 + q] = hb;
+          a_lo[row * LDH + c4 + q] = f32_to_bf16_rne(f[q] - bf16_to_f32(hb));
+        }
+      }
+      {  // W^T hi/lo: 64 rows x 32 bf16 = 4 x 16 B per row
+        const uint32_t row = tid >> 2, c8 = (tid & 3) * 8;
+        uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
+        if (n0 + row < N) {
+          vh = *reinterpret_cast<const uint4*>(W.hi + (uint64_t)(n0 + row) * K + k0 + c8);
+          vl = *reinterpret_cast<const uint4*>(W.lo + (uint64_t)(n0 + row) * K + k0 + c8);
+        }
+        *reinterpret_cast<uint4*>(b_hi + row * LDH + c8) = vh;
+        *reinterpret_cast<uint4*>(b_lo + row * LDH + c8) = vl;
+      }
+      __syncthreads();
+      const uint32_t fr = lane & 15, fk = (lane >> 4) * 8;
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        ah[i] = *reinterpret_cast<const bf16x8*>(a_hi + (wy * 32 + i * 16 + fr) * LDH + fk);
+        al[i] = *reinterpret_cast<const bf16x8*>(a_lo + (wy * 32 + i * 16 + fr) * LDH + fk);
+        bh[i] = *reinterpret_cast<const bf16x8*>(b_hi + (wx * 32 + i * 16 + fr) * LDH + fk);
+        bl[i] = *reinterpret_cast<const bf16x8*>(b_lo + (wx * 32 + i * 16 + fr) * LDH + fk);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    } else {
+      float* as = reinterpret_cast<float*>(smem);
+      float* bs = as + BM * LDF;
+#pragma unroll
+      for (int it = 0; it < 2; it++) {
+        const uint32_t e = tid + it * 256, row = e >> 3, c4 = (e & 7) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m0 + row < M) v = *reinterpret_cast<const float4*>(A + (uint64_t)(m0 + row) * lda + k0 + c4);
+        if (n0 + row < N) w = *reinterpret_cast<const float4*>(W.f32 + (uint64_t)(n0 + row) * K + k0 + c4);
+        as[row * LDF + c4 + 0] = v.x; as[row * LDF + c4 + 1] = v.y;
+        as[row * LDF + c4 + 2] = v.z; as[row * LDF + c4 + 3] = v.w;
+        bs[row * LDF + c4 + 0] = w.x; bs[row * LDF + c4 + 1] = w.y;
+        bs[row * LDF + c4 + 2] = w.z; bs[row * LDF + c4 + 3] = w.w;
+      }
+      __syncthreads();
+      if constexpr (MODE == 0) {
+        const uint32_t fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; kk++) {
+          float a[2], b[2];
+#pragma unroll
+          for (int i = 0; i < 2; i++) {
+            a[i] = as[(wy * 32 + i * 16 + fr) * LDF + kk * 4 + fk];
+            b[i] = bs[(wx * 32 + i * 16 + fr) * LDF + kk * 4 + fk];
+          }
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+      } else {  // MODE 2: VALU, thread owns rows ty*4.., cols tx*4..
+        const uint32_t ty = tid >> 4, tx = tid & 15;
+        for (int kk = 0; kk < BK; kk++) {
+          float a[4], b[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            a[i] = as[(ty * 4 + i) * LDF + kk];
+            b[i] = bs[(tx * 4 + i) * LDF + kk];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) vacc[i][j] = fmaf(a[i], b[j], vacc[i][j]);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue
+  if constexpr (MODE == 2) {
+    const uint32_t ty = tid >> 4, tx = tid & 15;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+        if (m < M && n < N) {
+          float v = vacc[i][j] + (W.bias ? W.bias[n] : 0.f);
+          if (relu) v = fmaxf(v, 0.f);
+          if (R) v += R[(uint64_t)m * ldc + n];
+          C[(uint64_t)m * ldc + n] = v;
+        }
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const uint32_t n = n0 + wx * 32 + j * 16 + (lane & 15);
+        const float bias = (W.bias && n < N) ? W.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const uint32_t m = m0 + wy * 32 + i * 16 + (lane >> 4) * 4 + r;
+          if (m < M && n < N) {
+            float v = acc[i][j][r] + bias;
+            if (relu) v = fmaxf(v, 0.f);
+            if (R) v += R[(uint64_t)m * ldc + n];
+            C[(uint64_t)m * ldc + n] = v;
+          }
+        }
+      }
+  }
+}
+
+static void gemm(const float* A, uint32_t lda, const Weight& W, float* C, uint32_t ldc, const float* R,
+                 uint32_t M, int relu, int precision, hipStream_t st) {
+  if (M == 0) return;
+  dim3 grid((W.N + BN - 1) / BN, (M + BM - 1) / BM);
+  if (precision == 0) hipLaunchKernelGGL(k_gemm<0>, grid, dim3(256), 0, st, A, lda, W, C, ldc, R, M, relu);
+  else if (precision == 1) hipLaunchKernelGGL(k_gemm<1>, grid, dim3(256), 0, st, A, lda, W, C, ldc, R, M, relu);
+  else hipLaunchKernelGGL(k_gemm<2>, grid, dim3(256), 0, st, A, lda, W, C, ldc, R, M, relu);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// positional encoding (sinusoidal over the row index), LayerNorm, attention, output scatter
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_add_pe(ModelDev M, ModelScratch S, uint32_t n_tok) {
+  const uint32_t half = M.h.d_model / 2;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (uint64_t)n_tok * half) return;
+  const uint32_t n = (uint32_t)(i / half), k = (uint32_t)(i % half);
+  const float ang = __fmul_rn((float)S.tok_row[n], M.pe_div[k]);
+  float* x = S.x + (uint64_t)n * M.h.d_model;
+  x[2 * k] += sinf(ang);
+  x[2 * k + 1] += cosf(ang);
+}
+
+// one wave per row
+__global__ __launch_bounds__(256) void k_layernorm(const float* x, float* y, const float* g, const float* b,
+                                                   uint32_t n_rows, uint32_t D, float eps) {
+  const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n_rows) return;
+  const float* xr = x + (uint64_t)row * D;
+  float s = 0.f;
+  for (uint32_t i = lane; i < D; i += 64) s += xr[i];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+  const float mean = s / (float)D;
+  float v = 0.f;
+  for (uint32_t i = lane; i < D; i += 64) {
+    const float t = xr[i] - mean;
+    v += t * t;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  const float rstd = 1.0f / sqrtf(v / (float)D + eps);
+  float* yr = y + (uint64_t)row * D;
+  for (uint32_t i = lane; i < D; i += 64) yr[i] = (xr[i] - mean) * rstd * g[i] + b[i];
+}
+
+// Attention inside one window (its informative positions are the sequence).  One wave per
+// (window, head); a lane owns one query row at a time; keys/values are wave-uniform (broadcast)
+// loads; online softmax in registers.  head_dim <= 64.
+template <int DH>
+__global__ __launch_bounds__(64) void k_attention(BatchDev B, ModelScratch S, uint32_t D) {
+  const uint32_t b = blockIdx.x, hd = blockIdx.y;
+  const uint32_t t0 = B.tok_off[b], len = B.tok_off[b + 1] - t0;
+  const float scale = 1.0f / sqrtf((float)DH);
+  for (uint32_t i = threadIdx.x; i < len; i += 64) {
+    const float* q = S.qkv + (uint64_t)(t0 + i) * 3 * D + hd * DH;
+    float qr[DH], o[DH];
+#pragma unroll
+    for (int d = 0; d < DH; d++) {
+      qr[d] = q[d] * scale;
+      o[d] = 0.f;
+    }
+    float m = -INFINITY, l = 0.f;
+    for (uint32_t j = 0; j < len; j++) {
+      const float* k = S.qkv + (uint64_t)(t0 + j) * 3 * D + D + hd * DH;
+      const float* v = k + D;
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < DH; d++) s = fmaf(qr[d], k[d], s);
+      const float mn = fmaxf(m, s);
+      const float alpha = expf(m - mn), p = expf(s - mn);
+      l = l * alpha + p;
+#pragma unroll
+      for (int d = 0; d < DH; d++) o[d] = o[d] * alpha + p * v[d];
+      m = mn;
+    }
+    float* out = S.att + (uint64_t)(t0 + i) * D + hd * DH;
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int d = 0; d < DH; d++) out[d] = o[d] * inv;
+  }
+}
+
+__global__ void k_scatter_logits(BatchDev B, ModelScratch S) {
+  const uint32_t b = blockIdx.x;
+  const uint32_t t0 = B.tok_off[b], t1 = B.tok_off[b + 1];
+  for (uint32_t n = t0 + threadIdx.x; n < t1; n += blockDim.x) {
+    const float* lg = S.logits + (uint64_t)n * 16;
+    const uint64_t o = B.out_off[b] + (n - t0);
+    B.out_info[o] = lg[0];
+#pragma unroll
+    for (int c = 0; c < 5; c++) B.out_base[o * 5 + c] = lg[1 + c];
+  }
+}
+
+__global__ void k_transpose_blr(const uint8_t* src, uint8_t* dst, uint32_t L) {
+  // src [B][L][31] -> dst [B][31][L]
+  const uint32_t b = blockIdx.y;
+  const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L) return;
+  const uint8_t* s = src + ((uint64_t)b * L + l) * HERRO_ROWS;
+  uint8_t* d = dst + (uint64_t)b * HERRO_ROWS * L + l;
+#pragma unroll
+  for (int r = 0; r < HERRO_ROWS; r++) d[(uint64_t)r * L] = s[r];
+}
+
+void launch_transpose_blr(const uint8_t* src, uint8_t* dst, uint32_t B, uint32_t L, hipStream_t st) {
+  hipLaunchKernelGGL(k_transpose_blr, dim3((L + 255) / 256, B), dim3(256), 0, st, src, dst, L);
+}
+
+void launch_model(const ModelDev& M, const BatchDev& B, const ModelScratch& S, int precision,
+                  hipStream_t st, KernelTimer* tm) {
+  const uint32_t N = B.n_tok;
+  if (N == 0) return;
+  const ModelHyper& h = M.h;
+  const uint32_t D = h.d_model;
+  KT_BEGIN(tm, "build_tokens", st);
+  hipLaunchKernelGGL(k_build_tokens, dim3(B.n_win), dim3(64), 0, st, B, S);
+  KT_END(tm, st);
+
+  const uint32_t P = 4 * (h.kw / 2) + 1;
+  const size_t shm = (size_t)(h.kw * 12 * h.c1 + h.kw * h.c1 + h.c1 + HERRO_ROWS * P) * 4 + (size_t)HERRO_ROWS * P * 4;
+  KT_BEGIN(tm, "patch_conv1", st);
+  hipLaunchKernelGGL(k_patch_conv1, dim3(N), dim3(256), shm, st, M, B, S);
+  KT_END(tm, st);
+
+  KT_BEGIN(tm, "conv2_gemm", st);
+  gemm(S.y1, h.kw * h.c1, M.conv2, S.y2, h.c2, nullptr, N * HERRO_ROWS, 1, precision, st);
+  KT_END(tm, st);
+  KT_BEGIN(tm, "fc_gemm", st);
+  gemm(S.y2, HERRO_ROWS * h.c2, M.fc, S.x, D, nullptr, N, 0, precision, st);
+  KT_END(tm, st);
+  KT_BEGIN(tm, "add_pe", st);
+  {
+    const uint64_t tot = (uint64_t)N * (D / 2);
+    hipLaunchKernelGGL(k_add_pe, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, st, M, S, N);
+  }
+  KT_END(tm, st);
+
+  const dim3 ln_grid((N + 3) / 4);
+  for (uint32_t li = 0; li < h.n_layers; li++) {
+    const LayerW& L = M.layer[li];
+    KT_BEGIN(tm, "layernorm", st);
+    hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, st, S.x, S.hbuf, L.ln1_g, L.ln1_b, N, D, h.ln_eps);
+    KT_END(tm, st);
+    KT_BEGIN(tm, "qkv_gemm", st);
+    gemm(S.hbuf, D, L.qkv, S.qkv, 3 * D, nullptr, N, 0, precision, st);
+    KT_END(tm, st);
+    KT_BEGIN(tm, "attention", st);
+    hipLaunchKernelGGL(k_attention<32>, dim3(B.n_win, h.n_heads), dim3(64), 0, st, B, S, D);
+    KT_END(tm, st);
+    KT_BEGIN(tm, "proj_gemm", st);
+    gemm(S.att, D, L.proj, S.x, D, S.x, N, 0, precision, st);
+    KT_END(tm, st);
+    KT_BEGIN(tm, "layernorm", st);
+    hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, st, S.x, S.hbuf, L.ln2_g, L.ln2_b, N, D, h.ln_eps);
+    KT_END(tm, st);
+    KT_BEGIN(tm, "ff1_gemm", st);
+    gemm(S.hbuf, D, L.ff1, S.ff, h.d_ff, nullptr, N, 1, precision, st);
+    KT_END(tm, st);
+    KT_BEGIN(tm, "ff2_gemm", st);
+    gemm(S.ff, h.d_ff, L.ff2, S.x, D, S.x, N, 0, precision, st);
+    KT_END(tm, st);
+  }
+  KT_BEGIN(tm, "layernorm", st);
+  hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, st, S.x, S.hbuf, M.lnf_g, M.lnf_b, N, D, h.ln_eps);
+  KT_END(tm, st);
+  KT_BEGIN(tm, "heads_gemm", st);
+  gemm(S.hbuf, D, M.heads, S.logits, 16, nullptr, N, 0, precision, st);
+  KT_END(tm, st);
+  KT_BEGIN(tm, "scatter_logits", st);
+  hipLaunchKernelGGL(k_scatter_logits, dim3(B.n_win), dim3(64), 0, st, B, S);
+  KT_END(tm, st);
+}
+
+}  // namespace herro

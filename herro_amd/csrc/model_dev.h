@@ -1,0 +1,91 @@
+// model_dev.h — device-side view of the correction model and of one inference batch.
+//
+// The reference executes an opaque TorchScript file (inference.rs:162-163, 185) that is NOT part
+// of /root/reference; only its I/O contract is (inference.rs:152-174).  The architecture below is
+// the ASSUMED one (oracle/model_ref.py is its PyTorch twin): token embedding +
+// quality channel -> two read-wise 1-D conv blocks along the window axis -> per-position linear
+// over the 31 rows -> informative positions only -> Pre-LN Transformer encoder -> two heads.
+// Model parity with the real weights is therefore "unpinned".
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "job_dev.h"
+
+namespace herro {
+
+struct ModelHyper {  // header of the flat weight file (tools/export_weights.py)
+  uint32_t magic;    // 'HRRO'
+  uint32_t version;
+  uint32_t rows;     // 31
+  uint32_t kw;       // conv kernel width along the window axis (odd)
+  uint32_t c1, c2;   // conv channels
+  uint32_t d_model, n_heads, d_ff, n_layers;
+  uint32_t n_tensors;
+  float ln_eps;
+};
+
+// A [K,N] row-major weight kept in three forms: f32, and its bf16 hi/lo split (w ~= hi + lo).
+struct Weight {
+  const float* f32 = nullptr;
+  const uint16_t* hi = nullptr;
+  const uint16_t* lo = nullptr;
+  const float* bias = nullptr;  // [N] or null
+  uint32_t K = 0, N = 0;
+};
+
+struct LayerW {
+  const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+  Weight qkv, proj, ff1, ff2;
+};
+
+struct ModelDev {
+  ModelHyper h;
+  const float* t1;      // [kw][12][c1] embedding folded through conv1 (+BN), tap-major
+  const float* wq1;     // [kw][c1]     conv1 weights of the quality channel
+  const float* b1;      // [c1]
+  Weight conv2;         // [kw*c1, c2]  (BN folded), k = tap*c1 + c
+  Weight fc;            // [rows*c2, d_model], k = row*c2 + c
+  const float* pe_div;  // [d_model/2]
+  LayerW layer[16];
+  const float *lnf_g, *lnf_b;
+  Weight heads;         // [d_model, 16]: col 0 info, cols 1..5 bases
+};
+
+// One inference batch: windows are ragged planes [31][len] (stride lub), never padded in memory.
+struct BatchDev {
+  uint32_t n_win;             // B
+  uint32_t n_tok;             // N = sum of informative positions
+  uint32_t lmax;              // batch max window length (collate pads to it, inference.rs:75-97)
+  const uint64_t* plane_off;  // [B] byte offset of the window's token/quality planes
+  const uint32_t* plane_ld;   // [B] plane stride (lub)
+  const uint32_t* len;        // [B] L' of each window
+  const uint32_t* tok_off;    // [B+1] first token of each window
+  const uint64_t* sup_off;    // [B] element offset of the window's informative-row list
+  const uint64_t* out_off;    // [B] element offset of the window's logits in the job buffers
+  const uint8_t* planes_b;    // tokens
+  const uint8_t* planes_q;    // raw qualities
+  const uint32_t* sup_row;    // informative rows
+  float* out_info;            // job-level [sum nsup]
+  float* out_base;            // job-level [sum nsup][5]
+};
+
+struct ModelScratch {  // sized for n_tok tokens
+  uint32_t* tok_win;  // [N] window (batch-local) of each token
+  uint32_t* tok_row;  // [N] row of each token
+  float* y1;          // [N][31][kw][c1]
+  float* y2;          // [N][31*c2]
+  float* x;           // [N][d_model] residual stream
+  float* hbuf;        // [N][d_model] normalised
+  float* qkv;         // [N][3*d_model]
+  float* att;         // [N][d_model]
+  float* ff;          // [N][d_ff]
+  float* logits;      // [N][16]
+};
+
+void launch_model(const ModelDev& M, const BatchDev& B, const ModelScratch& S, int precision,
+                  hipStream_t st, KernelTimer* tm);
+// [B,L,31] -> [B][31][L] planes (stand-alone entry only)
+void launch_transpose_blr(const uint8_t* src, uint8_t* dst, uint32_t B, uint32_t L, hipStream_t st);
+
+}  // namespace herro

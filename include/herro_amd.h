@@ -1,0 +1,169 @@
+/* herro_amd.h — C ABI of the MI355X-native HERRO hot path (libherro_amd.so).
+ *
+ * Scope: the per-window pileup feature generation (reference src/features.rs) and the
+ * correction-model forward (reference src/inference.rs) of lbcb-sci/herro v0.1.1, as
+ * hand-written HIP kernels for gfx950.  The reference has no FFI of its own; the entry
+ * points below are what a cgo/Rust-FFI binding for this path would bind — each one cites
+ * the reference interface it replaces.  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions: every function returning int returns HERRO_OK (0) or a negative error code;
+ * the text of the last error is available from herro_last_error().  Where the reference
+ * would panic (Cargo.toml:18 panic = "abort") this library returns HERRO_E_REFERENCE_PANIC.
+ * Nothing here ever falls back to a CPU implementation: without a HIP device every
+ * device-touching call fails with HERRO_E_NO_DEVICE.
+ */
+#ifndef HERRO_AMD_H
+#define HERRO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HERRO_OK 0
+#define HERRO_E_INVALID (-1)          /* bad argument */
+#define HERRO_E_NO_DEVICE (-2)        /* no HIP device / HIP runtime error */
+#define HERRO_E_REFERENCE_PANIC (-3)  /* input on which the reference itself panics */
+#define HERRO_E_UNSUPPORTED (-4)      /* legal for the reference, not supported here */
+#define HERRO_E_NO_MODEL (-5)
+#define HERRO_E_STATE (-6)            /* call order violated */
+
+#define HERRO_ROWS 31      /* target + TOP_K_SORT(30) overlaps — features.rs:22 */
+#define HERRO_N_CLASSES 5  /* A C G T * — consensus.rs:142-149 */
+
+typedef struct herro_ctx herro_ctx;
+typedef struct herro_job herro_job;
+
+/* One PAF record + its cg:Z: CIGAR — reference overlaps.rs:45-55 (Overlap) and :92-95
+ * (Alignment).  strand: 0 = '+', 1 = '-'.  cigar: ASCII "\d+[MID]" (aligners.rs:252-293). */
+typedef struct {
+  uint32_t qid, qlen, qstart, qend;
+  uint32_t strand;
+  uint32_t tid, tlen, tstart, tend;
+  uint32_t cigar_len;
+  const uint8_t* cigar;
+} herro_alignment;
+
+/* Per-window result header — the fields of WindowExample / ConsensusWindow that the path
+ * hands on (inference.rs:270-278, consensus.rs:22-33). */
+typedef struct {
+  uint32_t rid;          /* target read */
+  uint32_t wid;          /* window index within the read */
+  uint32_t n_total_wins; /* windows of that read */
+  uint32_t length;       /* L' — rows after all-gap-row removal (features.rs:531-556) */
+  uint32_t n_alns;       /* min(#ranked overlaps, 30) (features.rs:877) */
+  uint32_t n_overlaps;   /* #ranked overlaps ("ids", features.rs:569) */
+  uint32_t n_supported;  /* informative positions (features.rs:558) */
+  uint32_t win_len;      /* target bases in the window */
+} herro_window_info;
+
+/* ---- library / context ------------------------------------------------------------------ */
+const char* herro_version(void);
+/* One context per GPU (the reference runs one worker set per `-d` device, lib.rs:154-200). */
+herro_ctx* herro_create(int device_id);
+void herro_destroy(herro_ctx* ctx);
+const char* herro_last_error(const herro_ctx* ctx); /* ctx may be NULL (creation errors) */
+/* Run all subsequent work of this context on an externally owned hipStream_t (e.g. the
+ * current torch stream).  NULL restores the context's own stream. */
+int herro_set_stream(herro_ctx* ctx, void* hip_stream);
+int herro_synchronize(herro_ctx* ctx);
+
+/* ---- 2-bit codec — haec_io.rs:121-173 (host utility, no device) --------------------------- */
+/* words must hold (n+31)/32 u64.  Returns word count, or HERRO_E_REFERENCE_PANIC for a
+ * byte >= 128 (the reference indexes a 128-entry table). */
+int64_t herro_encode_2bit(const uint8_t* seq, uint64_t n, uint64_t* words);
+int herro_decode_2bit(const uint64_t* words, uint64_t length, uint64_t start, uint64_t end,
+                      int reverse_complement, uint8_t* out);
+
+/* ---- device-resident read store — replaces `reads: &[HAECRecord]` (lib.rs:133, haec_io.rs:19-24).
+ * Read i: bases seq[off[i]..off[i+1]) (ASCII; packed to 2 bit on the host exactly as
+ * haec_io.rs:121-136 incl. the non-ACGT quirk), quals the same slice of `qual` (phred+33 bytes).
+ * name_class (nullable): name_class[i] == name_class[j] iff reads i and j have the same id
+ * string (the reference keys the haplotype ratios by read *name*, features.rs:494); NULL means
+ * all names are distinct. */
+int herro_set_reads(herro_ctx* ctx, uint32_t n_reads, const uint8_t* seq, const uint8_t* qual,
+                    const uint64_t* off, const uint32_t* name_class);
+/* Same, from already packed words (HAECSeq.data, haec_io.rs:78-81): word_off[n_reads+1]. */
+int herro_set_reads_packed(herro_ctx* ctx, uint32_t n_reads, const uint64_t* words,
+                           const uint64_t* word_off, const uint8_t* qual, const uint64_t* qual_off,
+                           const uint32_t* name_class);
+
+/* ---- model ----------------------------------------------------------------------------------
+ * Flat little-endian weight file written by tools/export_weights.py (stands in for
+ * tch::CModule::load_on_device, inference.rs:185). */
+int herro_load_model(herro_ctx* ctx, const char* path);
+/* precision of the model GEMMs: 0 = f32 MFMA (exact f32), 1 = bf16x3 split MFMA (default). */
+int herro_set_precision(herro_ctx* ctx, int mode);
+
+/* ---- job = a set of target reads with their alignments -------------------------------------
+ * herro_job_create replaces the front half of `extract_features` (features.rs:326-361): it runs
+ * `extract_windows` (windowing.rs:44-273) for every alignment on the host, converts CIGARs to a
+ * binary op stream and uploads the descriptors.  Alignments of target t are
+ * alns[aln_off[t] .. aln_off[t+1]); every alignment must have tid == rids[t] (overlaps.rs:189-192).
+ * window_size: the `-w` flag (main.rs:69-74); 16 <= window_size <= 8192 here. */
+herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* rids,
+                            const uint64_t* aln_off, const herro_alignment* alns,
+                            uint32_t window_size);
+void herro_job_free(herro_job* job);
+uint32_t herro_job_n_windows(const herro_job* job);
+
+/* GPU feature generation for all windows of the job — features.rs:364-580 (filter, accuracy
+ * ranking, max-insertion map, pileup scatter, informative positions, haplotype-ratio re-ranking,
+ * top-30 selection, all-gap-row removal, token encoding inference.rs:222).  Asynchronous on the
+ * context stream; the accessors below synchronise. */
+int herro_job_featurize(herro_job* job);
+
+/* Model forward over the job's windows with >=1 informative position, batched in submission
+ * order in chunks of batch_size (prepare_examples/collate/inference, inference.rs:73-175,214-253).
+ * batch_mode 0: batches never span reads (the reference's grouping, features.rs:884-893);
+ * batch_mode 1: windows of different reads share batches (BASELINE batch=64/128 configs). */
+int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode);
+
+/* Results (synchronise first).  Window order = (target order, wid). */
+int herro_job_window_info(herro_job* job, uint32_t w, herro_window_info* info);
+/* bases/quals: [length, 31] row-major as the reference emits them (features.rs:547-556);
+ * bases are ASCII when encoded == 0, BASES_MAP tokens (inference.rs:23-31) when encoded != 0.
+ * sup_pos/sup_ins: SupportedPos (features.rs:896-900); qids: ranked overlap read ids.
+ * Any output pointer may be NULL. */
+int herro_job_window_copy(herro_job* job, uint32_t w, int encoded, uint8_t* bases, uint8_t* quals,
+                          uint16_t* sup_pos, uint8_t* sup_ins, uint32_t* qids);
+/* Logits of window w after herro_job_infer: info[n_supported], bases[n_supported*5]. */
+int herro_job_window_logits(herro_job* job, uint32_t w, float* info_logits, float* bases_logits);
+
+/* Consensus + FASTA text for target t (consensus.rs:86-227, lib.rs:282-317); id/desc are the
+ * read's id and optional description (NULL: none).  Returns bytes written (0: read not
+ * emitted), or a negative error.  Host-side integer decode of device results. */
+int64_t herro_job_consensus_fasta(herro_job* job, uint32_t t, const char* id, const char* desc,
+                                  char* out, uint64_t cap);
+
+/* ---- stand-alone model entry (parity checks) — mirrors `inference` (inference.rs:147-175):
+ * bases u8 tokens [B,L,31], quals raw u8 [B,L,31] (normalised on device, :153), lens [B],
+ * indices flat [sum(lens)].  Outputs info_logits [N], bases_logits [N,5] (host). */
+int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* bases,
+                        const uint8_t* quals, const int32_t* lens, const int32_t* indices,
+                        float* info_logits, float* bases_logits);
+
+/* ---- measurement hooks (bench.py) -------------------------------------------------------- */
+/* Per-kernel GPU time accumulated with HIP events on the context stream since the last reset.
+ * names: '\n'-separated kernel-group names; ms/calls: arrays of n entries. */
+int herro_timing_enable(herro_ctx* ctx, int on);
+int herro_timing_reset(herro_ctx* ctx);
+int herro_timing_get(herro_ctx* ctx, char* names, uint64_t names_cap, double* ms, uint64_t* calls,
+                     uint32_t* n);
+/* Algorithmic bytes of the job's featurisation (SURVEY.md §8 d formula), measured on the data:
+ * out[0]=2-bit+qual bytes read, out[1]=cigar-op bytes, out[2]=model-ready bytes written,
+ * out[3]=sum L', out[4]=sum n_supported, out[5]=windows with n_supported>0. */
+int herro_job_stats(herro_job* job, uint64_t* out);
+
+/* ---- host-only test hook: the library's windowing (windowing.rs:44-273 restated on binary ops)
+ * for one alignment; needs no device.  out rows of 8 u64: window, tstart, qstart, qend, op_lo,
+ * op_hi (op-index slice), cigar_start_offset, cigar_end_offset.  Returns row count or <0. */
+int64_t herro_debug_extract_windows(const herro_alignment* a, uint32_t n_windows, uint32_t window_size,
+                                    uint64_t* out, uint64_t cap, char* err, uint64_t err_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HERRO_AMD_H */

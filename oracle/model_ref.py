@@ -1,0 +1,119 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+Plain PyTorch fp32 twin of the ASSUMED correction-model architecture, executed densely exactly
+the way the reference drives its TorchScript model (reference inference.rs:147-175):
+
+    forward(bases:int32[B,L,31], quals:f32[B,L,31], lens:int32[B], indices:List[int32[len_i]])
+        -> (info_logits f32[N], bases_logits f32[N,5]),  N = sum(lens)
+
+PARITY UNPINNED: the real model (`model_R10_v0.1.pt`, Zenodo 12683277, reference
+README.md:56-66) is not in /root/reference and its internals are not visible in the repo; the
+reference's own model test is commented out and its fixtures are absent
+(inference.rs:302-410).  This twin pins the HIP kernels to *an* fp32 PyTorch execution of the
+documented architecture, not to the published weights.
+
+The twin is deliberately dense (embedding -> conv over every cell -> linear at every position ->
+gather) — it is what a TorchScript executor would do, and it is the check that the product's
+receptive-field evaluation is exact, including the batch-padding cells (token 11, quality 126)
+that `collate` adds (inference.rs:86-97).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+QUAL_MIN, QUAL_MAX = 33.0, 126.0  # inference.rs:16-17
+
+
+def normalise_quals(q_u8: torch.Tensor) -> torch.Tensor:
+    """inference.rs:19-21,153: QUAL_SCALE * quals - QUAL_OFFSET on an f32 tensor."""
+    diff = float(np.float32(QUAL_MAX) - np.float32(QUAL_MIN))
+    scale = 2.0 / diff
+    offset = 2.0 * float(np.float32(QUAL_MIN)) / diff + 1.0
+    return scale * q_u8.to(torch.float32) - offset
+
+
+class HerroNet(nn.Module):
+    def __init__(self, hp):
+        super().__init__()
+        self.hp = hp
+        self.embedding = nn.Embedding(12, hp.emb, padding_idx=11)
+        cin = hp.emb + 1
+        pad = (hp.kw // 2, 0)
+        self.conv1 = nn.Conv2d(cin, hp.c1, (hp.kw, 1), padding=pad)
+        self.bn1 = nn.BatchNorm2d(hp.c1, eps=hp.bn_eps)
+        self.conv2 = nn.Conv2d(hp.c1, hp.c2, (hp.kw, 1), padding=pad)
+        self.bn2 = nn.BatchNorm2d(hp.c2, eps=hp.bn_eps)
+        self.fc = nn.Linear(hp.rows * hp.c2, hp.d_model)
+        layer = nn.TransformerEncoderLayer(hp.d_model, hp.n_heads, hp.d_ff, dropout=0.0, activation="relu",
+                                           layer_norm_eps=hp.ln_eps, batch_first=True, norm_first=True)
+        self.encoder = nn.TransformerEncoder(layer, hp.n_layers, norm=nn.LayerNorm(hp.d_model, eps=hp.ln_eps),
+                                             enable_nested_tensor=False)
+        self.info_head = nn.Linear(hp.d_model, 1)
+        self.base_head = nn.Linear(hp.d_model, 5)
+        from herro_amd.model_io import pe_div_term  # a constant table, shared verbatim
+        self.register_buffer("pe_div", torch.from_numpy(pe_div_term(hp.d_model)))
+
+    def load_raw(self, raw: dict):
+        sd = {k: torch.from_numpy(np.asarray(v)) for k, v in raw.items()}
+        sd["pe_div"] = self.pe_div
+        for n in ("bn1", "bn2"):
+            sd[f"{n}.num_batches_tracked"] = torch.tensor(0)
+        self.load_state_dict(sd)
+        return self
+
+    def positional(self, idx: torch.Tensor) -> torch.Tensor:
+        ang = idx.to(torch.float32)[:, None] * self.pe_div[None, :]  # f32 product, as on device
+        pe = torch.zeros(idx.shape[0], self.hp.d_model)
+        pe[:, 0::2] = torch.sin(ang)
+        pe[:, 1::2] = torch.cos(ang)
+        return pe
+
+    @torch.no_grad()
+    def forward(self, bases, quals, lens, indices):
+        B, L, R = bases.shape
+        x = torch.cat([self.embedding(bases.long()), quals[..., None]], dim=-1)  # [B,L,R,7]
+        x = x.permute(0, 3, 1, 2)                                                # [B,7,L,R]
+        x = F.relu(self.bn1(self.conv1(x)))
+        x = F.relu(self.bn2(self.conv2(x)))                                      # [B,C2,L,R]
+        x = x.permute(0, 2, 3, 1).reshape(B, L, R * self.hp.c2)
+        x = self.fc(x)                                                           # [B,L,D]
+        lens_l = [int(v) for v in lens]
+        tmax = max(lens_l) if lens_l else 0
+        if tmax == 0:
+            return torch.zeros(0), torch.zeros(0, 5)
+        toks = torch.zeros(B, tmax, self.hp.d_model)
+        mask = torch.ones(B, tmax, dtype=torch.bool)  # True = padding
+        for i in range(B):
+            if lens_l[i]:
+                idx = indices[i].long()
+                toks[i, : lens_l[i]] = x[i, idx] + self.positional(idx)
+                mask[i, : lens_l[i]] = False
+        # windows without informative positions never reach the model in the reference
+        # (inference.rs:243); keep them out of attention to avoid all-masked rows
+        keep = [i for i in range(B) if lens_l[i] > 0]
+        y = self.encoder(toks[keep], src_key_padding_mask=mask[keep])
+        y = y[~mask[keep]]
+        return self.info_head(y).squeeze(-1), self.base_head(y)
+
+
+def build(raw: dict, hp) -> HerroNet:
+    torch.manual_seed(0)
+    m = HerroNet(hp).load_raw(raw)
+    m.eval()
+    return m
+
+
+def run_batch(model: HerroNet, bases_u8: np.ndarray, quals_u8: np.ndarray, lens: np.ndarray, indices_flat: np.ndarray):
+    """Drive the twin exactly like `inference` (inference.rs:147-175): raw u8 in, logits out."""
+    b = torch.from_numpy(bases_u8.astype(np.int32))
+    q = normalise_quals(torch.from_numpy(quals_u8))
+    idx, o = [], 0
+    for n in lens:
+        idx.append(torch.from_numpy(indices_flat[o:o + int(n)].astype(np.int32)))
+        o += int(n)
+    with torch.no_grad():
+        info, base = model(b, q, torch.from_numpy(lens.astype(np.int32)), idx)
+    return info.numpy(), base.numpy()

@@ -1,0 +1,63 @@
+"""Shared helpers for the -m gpu parity tests (HIP path through the C-ABI vs the oracle)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import oracle_lib as O
+from herro_amd import api, model_io, synth
+
+CACHE = os.path.join(ROOT, "tests", "_cache")
+_CTX = {}
+
+
+def ctx():
+    if "c" not in _CTX:
+        c = api.Context(0)
+        path, raw = model_io.default_model_file(CACHE)
+        c.load_model(path)
+        _CTX["c"], _CTX["raw"] = c, raw
+    return _CTX["c"]
+
+
+def raw_params():
+    ctx()
+    return _CTX["raw"]
+
+
+def twin():
+    if "twin" not in _CTX:
+        import model_ref as MR
+        _CTX["twin"] = MR.build(raw_params(), model_io.Hyper())
+    return _CTX["twin"]
+
+
+def load_synth(c, sb):
+    c.set_reads(sb.seq, sb.qual, sb.off)
+
+
+def compare_features(job, sb, store, W, targets=None):
+    """Bit-exact comparison of every window of the job with the oracle.  Returns #windows."""
+    ts = list(range(sb.n_targets)) if targets is None else list(targets)
+    w = 0
+    for t in ts:
+        rid, rows, cigs = O.target_alignments(sb, t)
+        res = store.extract_features(rid, rows, cigs, W)
+        for wi in range(len(res)):
+            ow = res.window(wi)
+            gw = job.window(w)
+            tag = f"target {t} window {wi}"
+            assert (gw.info.rid, gw.info.wid, gw.info.n_total_wins) == (rid, wi, len(res)), tag
+            assert gw.info.n_overlaps == len(ow.qids), tag
+            assert gw.qids.tolist() == ow.qids.tolist(), tag
+            assert gw.info.n_alns == ow.n_alns, tag
+            assert gw.info.length == ow.bases.shape[0], (tag, gw.info.length, ow.bases.shape)
+            assert np.array_equal(gw.bases, ow.bases), tag
+            assert np.array_equal(gw.quals, ow.quals), tag
+            assert gw.sup_pos.tolist() == ow.sup_pos.tolist() and gw.sup_ins.tolist() == ow.sup_ins.tolist(), tag
+            w += 1
+    assert w == job.n_windows
+    return w

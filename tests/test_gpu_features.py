@@ -1,0 +1,87 @@
+"""-m gpu: pileup feature generation (HIP, through the C-ABI) is bit-exact with the oracle's
+restatement of features.rs:326-583 on seeded synthetic overlap batches, including the edge
+cases the reference's code paths distinguish."""
+import numpy as np
+import pytest
+
+import gpu_common as G
+import oracle_lib as O
+from herro_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "baseline_w4096": dict(W=4096, n=3, tl=4 * 4096, ov=32, kw={}),
+    "ragged_tail_w4096": dict(W=4096, n=2, tl=2 * 4096 + 1234, ov=20, kw=dict(p_partial=0.3)),
+    "few_overlaps": dict(W=512, n=4, tl=2048, ov=3, kw=dict(flank_min=60, flank_max=90, p_partial=0.5)),
+    "many_overlaps": dict(W=256, n=2, tl=1024, ov=70, kw=dict(flank_min=30, flank_max=60)),
+    "long_indels_filtered": dict(W=512, n=3, tl=2048, ov=24, kw=dict(flank_min=60, flank_max=90, p_long_indel=0.05)),
+    "noisy": dict(W=256, n=4, tl=1500, ov=16, kw=dict(flank_min=30, flank_max=60, p_sub=0.05, p_ins=0.05, p_del=0.05, p_partial=0.2)),
+    "n_bases_quirk": dict(W=256, n=3, tl=1024, ov=12, kw=dict(flank_min=30, flank_max=60, p_n_base=0.01)),
+    "tiny_window": dict(W=16, n=3, tl=200, ov=8, kw=dict(flank_min=2, flank_max=5)),
+    "no_overlaps": dict(W=256, n=2, tl=700, ov=0, kw=dict(flank_min=30, flank_max=60)),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_features_bit_exact(name):
+    cs = CASES[name]
+    sb = synth.generate(cs["n"], cs["tl"], cs["ov"], seed=synth.SEED + sum(map(ord, name)), **cs["kw"])
+    c = G.ctx()
+    G.load_synth(c, sb)
+    store = O.store_from_synth(sb)
+    job = api.job_from_synth(c, sb, cs["W"])
+    job.featurize()
+    n = G.compare_features(job, sb, store, cs["W"])
+    assert n > 0
+    job.close()
+
+
+def test_duplicate_read_names_share_ratio():
+    # the reference keys haplotype ratios by read *name* (features.rs:494): two reads with the same id
+    sb = synth.generate(1, 1024, 10, seed=99, flank_min=30, flank_max=60)
+    names = [sb.read_name(i) for i in range(sb.n_reads)]
+    names[3] = names[5]
+    cls = np.arange(sb.n_reads, dtype=np.uint32)
+    cls[5] = 3
+    c = G.ctx()
+    c.set_reads(sb.seq, sb.qual, sb.off, cls)
+    store = O.Store(sb.seq, sb.qual, sb.off, names)
+    job = api.job_from_synth(c, sb, 256)
+    job.featurize()
+    G.compare_features(job, sb, store, 256)
+    job.close()
+
+
+def test_reference_panics_become_errors():
+    sb = synth.generate(1, 1024, 4, seed=5, flank_min=30, flank_max=60)
+    c = G.ctx()
+    G.load_synth(c, sb)
+    rows = sb.aln[:1].copy()
+    with pytest.raises(api.HerroError) as e:
+        c.create_job(sb.tgt_rid[:1], rows, np.array([0, 1], np.uint64), [b"100M5X919M"], 256)
+    assert e.value.code == -3
+    with pytest.raises(api.HerroError):
+        c.create_job(sb.tgt_rid[:1], rows, np.array([0, 1], np.uint64), [b"5000M"], 256)  # overruns the target
+
+
+def test_properties_full_size():
+    """Size-independent invariants (SURVEY.md §8 a) on a larger full-size batch."""
+    sb = synth.generate(8, 4 * 4096, 32, seed=4242)
+    c = G.ctx()
+    G.load_synth(c, sb)
+    job = api.job_from_synth(c, sb, 4096)
+    job.featurize()
+    for w in range(job.n_windows):
+        g = job.window(w, encoded=True)
+        b = g.bases
+        assert (b[:, 0] <= 4).all()                               # target column: ACGT or '*', never '.'
+        isbase = (b < 4) | ((b >= 5) & (b <= 8))
+        assert isbase.any(axis=1).all()                           # no all-gap rows survive
+        assert (b[:, 0] != 4).sum() == g.info.win_len             # every target base has its row
+        assert (b[:, g.info.n_alns + 1:] == 10).all()             # unused rows are '.'
+        key = g.sup_pos.astype(np.int64) * 256 + g.sup_ins
+        assert (np.diff(key) > 0).all()                           # informative positions strictly increasing
+        assert g.quals.min() >= 33
+        assert ((g.quals == 33) | isbase).all()                   # non-base cells carry the default quality
+    job.close()

@@ -1,0 +1,141 @@
+"""-m gpu: correction-model forward (HIP) against the dense PyTorch fp32 twin (oracle/model_ref.py)
+of the assumed architecture.  Tolerance: |a-b| <= 1e-3 (BASELINE.json north_star), checked for all
+three GEMM precisions; consensus from those logits is bit-exact with the oracle's decoder."""
+import numpy as np
+import pytest
+
+import gpu_common as G
+import oracle_lib as O
+from herro_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _rand_batch(rng, B, L, win_len):
+    bases = rng.integers(0, 11, (B, L, 31)).astype(np.uint8)
+    quals = rng.integers(33, 90, (B, L, 31)).astype(np.uint8)
+    for b in range(B):
+        bases[b, win_len[b]:] = 11
+        quals[b, win_len[b]:] = 126
+    return bases, quals
+
+
+@pytest.mark.parametrize("precision", [0, 1, 2])
+def test_model_forward_vs_twin(precision):
+    import model_ref as MR
+    rng = np.random.default_rng(11)
+    B, L = 5, 300
+    win_len = np.array([300, 280, 300, 150, 299])
+    bases, quals = _rand_batch(rng, B, L, win_len)
+    idx = [np.sort(rng.choice(win_len[b], size=k, replace=False)) for b, k in enumerate([40, 1, 0, 17, 64])]
+    idx[0][:2] = [0, 1]
+    idx[4][-1] = 298
+    lens = np.array([len(i) for i in idx], np.int32)
+    flat = np.concatenate(idx).astype(np.int32)
+    c = G.ctx()
+    c.set_precision(precision)
+    info, base = c.model_forward(bases, quals, lens, flat)
+    c.set_precision(1)
+    ti, tb = MR.run_batch(G.twin(), bases, quals, lens, flat)
+    assert info.shape == ti.shape and base.shape == tb.shape
+    err = max(np.abs(info - ti).max(), np.abs(base - tb).max())
+    print(f"precision {precision}: max abs logit error {err:.3e}")
+    assert err <= TOL
+    if precision == 0:
+        assert err <= 1e-4
+
+
+def test_job_logits_and_fasta_reference_grouping():
+    """features -> batches (reference grouping: never across reads) -> model -> consensus -> FASTA."""
+    import model_ref as MR
+    W, bs = 512, 3
+    sb = synth.generate(3, 5 * 512 + 100, 20, seed=77, flank_min=60, flank_max=90, p_partial=0.25)
+    c = G.ctx()
+    G.load_synth(c, sb)
+    store = O.store_from_synth(sb)
+    job = api.job_from_synth(c, sb, W)
+    job.featurize()
+    job.infer(bs, 0)
+    w0 = 0
+    checked = 0
+    for t in range(sb.n_targets):
+        rid, rows, cigs = O.target_alignments(sb, t)
+        res = store.extract_features(rid, rows, cigs, W)
+        # the reference flushes every `bs` windows and at end of read (features.rs:884-893): collate
+        # each flush group separately, exactly like prepare_examples would see it
+        nwin = len(res)
+        all_logits = []
+        for g0 in range(0, nwin, bs):
+            sub = list(range(g0, min(g0 + bs, nwin)))
+            wins = [res.window(i) for i in sub]
+            sel = [i for i, ow in zip(sub, wins) if len(ow.sup_pos)]
+            if not sel:
+                continue
+            ows = [res.window(i) for i in sel]
+            Lmax = max(o.bases.shape[0] for o in ows)
+            bases = np.full((len(sel), Lmax, 31), 11, np.uint8)
+            quals = np.full((len(sel), Lmax, 31), 126, np.uint8)
+            lens, flat = [], []
+            tokmap = {ord(ch): i for i, ch in enumerate("ACGT*acgt#.")}
+            for k, o in enumerate(ows):
+                enc = np.vectorize(tokmap.get)(o.bases).astype(np.uint8)
+                bases[k, :enc.shape[0]] = enc
+                quals[k, :enc.shape[0]] = o.quals
+                tidx = np.flatnonzero(enc[:, 0] != 4)
+                lens.append(len(o.sup_pos))
+                flat.extend((tidx[o.sup_pos] + o.sup_ins).tolist())
+            ti, tb = MR.run_batch(G.twin(), bases, quals, np.array(lens, np.int32), np.array(flat, np.int32))
+            o = 0
+            for k, i in enumerate(sel):
+                gi, gb = job.logits(w0 + i)
+                assert np.abs(gi - ti[o:o + lens[k]]).max() <= TOL
+                assert np.abs(gb - tb[o:o + lens[k]]).max() <= TOL
+                o += lens[k]
+                checked += lens[k]
+        # consensus + FASTA: decode the product's own logits with the oracle's consensus.rs restatement
+        for i in range(nwin):
+            if len(res.window(i).sup_pos):
+                all_logits.append(job.logits(w0 + i)[1])
+        lg = np.concatenate(all_logits) if all_logits else np.zeros((0, 5), np.float32)
+        want = res.consensus_fasta(lg)
+        got = job.consensus_fasta(t, sb.read_name(rid))
+        assert got == want
+        w0 += nwin
+    assert checked > 0
+    job.close()
+
+
+def test_cross_read_batching_matches_twin():
+    """batch_mode 1 (BASELINE batch=64/128 configs): windows of different reads share a batch; parity is
+    against the twin fed the same grouping (SURVEY.md §8 d)."""
+    import model_ref as MR
+    W = 256
+    sb = synth.generate(4, 1024, 16, seed=31, flank_min=30, flank_max=60)
+    c = G.ctx()
+    G.load_synth(c, sb)
+    job = api.job_from_synth(c, sb, W)
+    job.featurize()
+    job.infer(8, 1)
+    wins = [w for w in range(job.n_windows) if job.info(w).n_supported]
+    assert len(wins) > 8
+    for g0 in range(0, len(wins), 8):
+        grp = wins[g0:g0 + 8]
+        gws = [job.window(w, encoded=True) for w in grp]
+        Lmax = max(g.info.length for g in gws)
+        bases = np.full((len(grp), Lmax, 31), 11, np.uint8)
+        quals = np.full((len(grp), Lmax, 31), 126, np.uint8)
+        lens, flat = [], []
+        for k, g in enumerate(gws):
+            bases[k, :g.info.length] = g.bases
+            quals[k, :g.info.length] = g.quals
+            tidx = np.flatnonzero(g.bases[:, 0] != 4)
+            lens.append(len(g.sup_pos))
+            flat.extend((tidx[g.sup_pos] + g.sup_ins).tolist())
+        ti, tb = MR.run_batch(G.twin(), bases, quals, np.array(lens, np.int32), np.array(flat, np.int32))
+        o = 0
+        for k, w in enumerate(grp):
+            gi, gb = job.logits(w)
+            assert np.abs(gb - tb[o:o + lens[k]]).max() <= TOL and np.abs(gi - ti[o:o + lens[k]]).max() <= TOL
+            o += lens[k]
+    job.close()
