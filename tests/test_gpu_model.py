@@ -111,16 +111,16 @@ def test_cross_read_batching_matches_twin():
     against the twin fed the same grouping (SURVEY.md §8 d)."""
     import model_ref as MR
     W = 256
-    sb = synth.generate(4, 1024, 16, seed=31, flank_min=30, flank_max=60)
+    sb = synth.generate(8, 1024, 16, seed=31, flank_min=30, flank_max=60)
     c = G.ctx()
     G.load_synth(c, sb)
     job = api.job_from_synth(c, sb, W)
     job.featurize()
-    job.infer(8, 1)
+    job.infer(5, 1)
     wins = [w for w in range(job.n_windows) if job.info(w).n_supported]
-    assert len(wins) > 8
-    for g0 in range(0, len(wins), 8):
-        grp = wins[g0:g0 + 8]
+    assert len(wins) > 5
+    for g0 in range(0, len(wins), 5):
+        grp = wins[g0:g0 + 5]
         gws = [job.window(w, encoded=True) for w in grp]
         Lmax = max(g.info.length for g in gws)
         bases = np.full((len(grp), Lmax, 31), 11, np.uint8)
