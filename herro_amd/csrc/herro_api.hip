@@ -80,6 +80,7 @@ struct herro_job {
   std::vector<OwDesc> ow;
   std::vector<uint32_t> ops;
   std::vector<uint32_t> tgt_win_off;  // [n_targets+1]
+  std::vector<uint32_t> tile_win, tile_r0;
   JobDev J{};
   std::vector<void*> allocs;
   bool featurized = false, synced = false, inferred = false;
@@ -200,7 +201,9 @@ static int upload_reads(herro_ctx* ctx, uint32_t n_reads, const std::vector<uint
   hipFree(ctx->d_words); hipFree(ctx->d_word_off); hipFree(ctx->d_qual); hipFree(ctx->d_qual_off);
   ctx->d_words = nullptr; ctx->d_word_off = nullptr; ctx->d_qual = nullptr; ctx->d_qual_off = nullptr;
   hipError_t e;
-  ctx->d_words = dev_alloc_copy(words, ctx->stream, e); HIP_TRY(ctx, e);
+  std::vector<uint64_t> wp(words);
+  wp.push_back(0);  // pad word: get16() may touch one word past a read
+  ctx->d_words = dev_alloc_copy(wp, ctx->stream, e); HIP_TRY(ctx, e);
   ctx->d_word_off = dev_alloc_copy(word_off, ctx->stream, e); HIP_TRY(ctx, e);
   ctx->d_qual_off = dev_alloc_copy(qual_off, ctx->stream, e); HIP_TRY(ctx, e);
   const uint64_t nq = qual_off[n_reads];
@@ -406,7 +409,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   job->n_targets = n_targets;
   job->tgt_win_off.assign(n_targets + 1, 0);
   uint32_t n_cls = 0;
-  uint64_t scr_ops = 0, col_bytes = 0, fin_bytes = 0, row_elems = 0, pos_elems = 0;
+  uint64_t scr_ops = 0, fin_bytes = 0, row_elems = 0, pos_elems = 0;
   std::vector<uint32_t> aops;
   std::vector<HostOw> hows;
   for (uint32_t t = 0; t < n_targets; t++) {
@@ -505,10 +508,12 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
       wd.ow_cnt = cnt[wi + 1] - cnt[wi];
       const uint64_t lub = ((uint64_t)wd.win_len + std::min<uint64_t>(ins_sum[wi], (uint64_t)50 * wd.win_len) + 15) & ~15ull;
       wd.lub = (uint32_t)lub;
-      wd.col_off = col_bytes; col_bytes += (uint64_t)(wd.ow_cnt + 1) * lub;
+      wd.col_off = 0;
       wd.fin_off = fin_bytes; fin_bytes += (uint64_t)HERRO_ROWS * lub;
       wd.row_off = row_elems; row_elems += lub;
       wd.pos_off = pos_elems; pos_elems += (uint64_t)W + 1;
+      for (uint32_t r0 = 0; r0 < wd.lub; r0 += HERRO_TILE) { job->tile_win.push_back((uint32_t)job->win.size()); job->tile_r0.push_back(r0); }
+      if (wd.ow_cnt > 4000) return fail(HERRO_E_UNSUPPORTED, "more than 4000 overlaps in one window");
       job->alg_read_bytes += (uint64_t)wd.win_len + (wd.win_len + 3) / 4;
       job->win.push_back(wd);
     }
@@ -523,6 +528,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.read_qual = ctx->d_qual; J.read_qual_off = ctx->d_qual_off;
   J.ln_table = ctx->d_ln; J.ln_table_n = ctx->ln_n;
   J.n_ow = n_ow; J.n_win = n_win; J.n_cls = n_cls;
+  J.n_tiles = (uint32_t)job->tile_win.size(); J.window_size = W; J.n_ckpt = (W >> HERRO_CKPT_SHIFT) + 1;
   hipError_t e = hipSuccess;
   bool oom = false;
   auto A = [&](uint64_t bytes) -> void* {
@@ -539,18 +545,20 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.ops = (const uint32_t*)up(job->ops.data(), job->ops.size() * 4);
   J.ow = (const OwDesc*)up(job->ow.data(), job->ow.size() * sizeof(OwDesc));
   J.win = (const WinDesc*)up(job->win.data(), job->win.size() * sizeof(WinDesc));
-  J.op_t = (uint32_t*)A(scr_ops * 4); J.op_q = (uint32_t*)A(scr_ops * 4);
+  J.tile_win = (const uint32_t*)up(job->tile_win.data(), job->tile_win.size() * 4);
+  J.tile_r0 = (const uint32_t*)up(job->tile_r0.data(), job->tile_r0.size() * 4);
+  J.op_t = (uint32_t*)A(scr_ops * 4); J.op_q = (uint32_t*)A(scr_ops * 4); J.ins_ev = (uint32_t*)A(scr_ops * 4);
+  J.ins_cnt = (uint32_t*)A((uint64_t)n_ow * 4); J.ckpt = (uint32_t*)A((uint64_t)n_ow * J.n_ckpt * 4);
   J.ow_keep = (uint8_t*)A(n_ow); J.ow_acc = (float*)A((uint64_t)n_ow * 4);
-  J.ow_ttotal = (uint32_t*)A((uint64_t)n_ow * 4); J.ow_slot = (uint32_t*)A((uint64_t)n_ow * 4);
+  J.ow_ttotal = (uint32_t*)A((uint64_t)n_ow * 4);
   J.slot_ow = (uint32_t*)A((uint64_t)n_ow * 4); J.rank_qid = (uint32_t*)A((uint64_t)n_ow * 4);
-  J.score = (double*)A((uint64_t)n_ow * 8);
+  J.sel_ow = (uint32_t*)A((uint64_t)n_win * 32 * 4);
   J.win_L = (uint32_t*)A((uint64_t)n_win * 4); J.win_nkept = (uint32_t*)A((uint64_t)n_win * 4);
-  J.win_p1sup = (uint32_t*)A((uint64_t)n_win * 4); J.win_Lf = (uint32_t*)A((uint64_t)n_win * 4);
-  J.win_nsup = (uint32_t*)A((uint64_t)n_win * 4);
-  J.row_of_pos = (uint32_t*)A(pos_elems * 4);
-  J.rowmap = (uint32_t*)A(row_elems * 4); J.newidx = (uint32_t*)A(row_elems * 4);
+  J.win_Lf = (uint32_t*)A((uint64_t)n_win * 4); J.win_nsup = (uint32_t*)A((uint64_t)n_win * 4);
+  J.row_of_pos = (uint32_t*)A(pos_elems * 4); J.row_of_pos2 = (uint32_t*)A(pos_elems * 4);
+  J.rowmap = (uint32_t*)A(row_elems * 4); J.rowmap2 = (uint32_t*)A(row_elems * 4);
+  J.sup_flag = (uint8_t*)A(row_elems);
   J.sup_row = (uint32_t*)A(row_elems * 4); J.sup_pi = (uint32_t*)A(row_elems * 4);
-  J.cols_b = (uint8_t*)A(col_bytes); J.cols_q = (uint8_t*)A(col_bytes);
   J.fin_b = (uint8_t*)A(fin_bytes); J.fin_q = (uint8_t*)A(fin_bytes);
   J.nd = (uint32_t*)A((uint64_t)n_cls * 8);
   if (oom || e != hipSuccess) {
@@ -654,7 +662,22 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
     }
     flush(cur);
   }
-  // ---- descriptor block for all batches, one upload
+  // ---- all batches of the job go through ONE set of launches: a window's batch only matters
+  // through the padding length lmax (the longest window of its batch), which travels per window.
+  // Launch groups are capped at TOK_CAP tokens to bound the activation scratch.
+  const uint32_t TOK_CAP = 1u << 16;
+  struct Group { size_t b0, b1; uint32_t n_win, n_tok; };
+  std::vector<Group> groups;
+  for (size_t bi = 0; bi < job->batches.size();) {
+    Group g{bi, bi, 0, 0};
+    while (g.b1 < job->batches.size() && (g.b1 == g.b0 || g.n_tok + job->batches[g.b1].n_tok <= TOK_CAP)) {
+      g.n_win += (uint32_t)job->batches[g.b1].wins.size();
+      g.n_tok += job->batches[g.b1].n_tok;
+      g.b1++;
+    }
+    groups.push_back(g);
+    bi = g.b1;
+  }
   std::vector<unsigned char> blob;
   auto put = [&](const void* p, size_t bytes) {
     const size_t o = (blob.size() + 15) & ~size_t(15);
@@ -662,46 +685,50 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
     std::memcpy(blob.data() + o, p, bytes);
     return o;
   };
-  struct Offs { size_t plane_off, plane_ld, len, tok_off, sup_off, out_off; };
+  struct Offs { size_t plane_off, plane_ld, len, lmax, tok_off, sup_off, out_off; };
   std::vector<Offs> offs;
   uint32_t max_tok = 0;
-  for (auto& bp : job->batches) {
-    const size_t B = bp.wins.size();
-    std::vector<uint64_t> plane_off(B), sup_o(B), out_o(B);
-    std::vector<uint32_t> ld(B), len(B), tok_off(B + 1, 0);
-    for (size_t i = 0; i < B; i++) {
-      const WinDesc& wd = job->win[bp.wins[i]];
-      plane_off[i] = wd.fin_off; ld[i] = wd.lub; len[i] = job->h_Lf[bp.wins[i]];
-      tok_off[i + 1] = tok_off[i] + job->h_nsup[bp.wins[i]];
-      sup_o[i] = wd.row_off; out_o[i] = job->sup_off[bp.wins[i]];
+  for (auto& g : groups) {
+    const size_t B = g.n_win;
+    std::vector<uint64_t> plane_off, sup_o, out_o;
+    std::vector<uint32_t> ld, len, lmax, tok_off(1, 0);
+    for (size_t bi = g.b0; bi < g.b1; bi++) {
+      const BatchPlan& bp = job->batches[bi];
+      for (uint32_t w : bp.wins) {
+        const WinDesc& wd = job->win[w];
+        plane_off.push_back(wd.fin_off); ld.push_back(wd.lub); len.push_back(job->h_Lf[w]);
+        lmax.push_back(bp.lmax);
+        tok_off.push_back(tok_off.back() + job->h_nsup[w]);
+        sup_o.push_back(wd.row_off); out_o.push_back(job->sup_off[w]);
+      }
     }
     Offs o;
     o.plane_off = put(plane_off.data(), B * 8); o.plane_ld = put(ld.data(), B * 4);
-    o.len = put(len.data(), B * 4); o.tok_off = put(tok_off.data(), (B + 1) * 4);
+    o.len = put(len.data(), B * 4); o.lmax = put(lmax.data(), B * 4);
+    o.tok_off = put(tok_off.data(), (B + 1) * 4);
     o.sup_off = put(sup_o.data(), B * 8); o.out_off = put(out_o.data(), B * 8);
     offs.push_back(o);
-    max_tok = std::max(max_tok, bp.n_tok);
+    max_tok = std::max(max_tok, g.n_tok);
   }
   if (job->d_bdesc) { hipFree(job->d_bdesc); job->d_bdesc = nullptr; }
   if (!blob.empty()) {
     HIP_TRY(ctx, hipMalloc(&job->d_bdesc, blob.size()));
     HIP_TRY(ctx, hipMemcpyAsync(job->d_bdesc, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream));
-    // the blob lives on the host stack frame: finish the copy before returning
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // blob is a local: finish the copy before returning
   }
   rc = ensure_scratch(ctx, max_tok);
   if (rc) return rc;
-  for (size_t bi = 0; bi < job->batches.size(); bi++) {
-    const BatchPlan& bp = job->batches[bi];
+  for (size_t gi = 0; gi < groups.size(); gi++) {
     const unsigned char* base = (const unsigned char*)job->d_bdesc;
     BatchDev B{};
-    B.n_win = (uint32_t)bp.wins.size(); B.n_tok = bp.n_tok; B.lmax = bp.lmax;
-    B.plane_off = (const uint64_t*)(base + offs[bi].plane_off);
-    B.plane_ld = (const uint32_t*)(base + offs[bi].plane_ld);
-    B.len = (const uint32_t*)(base + offs[bi].len);
-    B.tok_off = (const uint32_t*)(base + offs[bi].tok_off);
-    B.sup_off = (const uint64_t*)(base + offs[bi].sup_off);
-    B.out_off = (const uint64_t*)(base + offs[bi].out_off);
+    B.n_win = groups[gi].n_win; B.n_tok = groups[gi].n_tok;
+    B.plane_off = (const uint64_t*)(base + offs[gi].plane_off);
+    B.plane_ld = (const uint32_t*)(base + offs[gi].plane_ld);
+    B.len = (const uint32_t*)(base + offs[gi].len);
+    B.lmax = (const uint32_t*)(base + offs[gi].lmax);
+    B.tok_off = (const uint32_t*)(base + offs[gi].tok_off);
+    B.sup_off = (const uint64_t*)(base + offs[gi].sup_off);
+    B.out_off = (const uint64_t*)(base + offs[gi].out_off);
     B.planes_b = job->J.fin_b; B.planes_q = job->J.fin_q; B.sup_row = job->J.sup_row;
     B.out_info = job->d_info; B.out_base = job->d_base;
     launch_model(ctx->M, B, ctx->S, ctx->precision, ctx->stream, &ctx->timer);
@@ -895,7 +922,7 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
   if (!ctx->has_model) { ctx->err = "no model loaded"; return HERRO_E_NO_MODEL; }
   hipSetDevice(ctx->device);
   uint64_t N = 0;
-  std::vector<uint32_t> tok_off(B + 1, 0), len(B, L), ld(B, (L + 15) & ~15u), srow;
+  std::vector<uint32_t> tok_off(B + 1, 0), len(B, L), lmaxv(B, L), ld(B, (L + 15) & ~15u), srow;
   for (uint32_t b = 0; b < B; b++) {
     if (lens[b] < 0) return HERRO_E_INVALID;
     tok_off[b + 1] = tok_off[b] + (uint32_t)lens[b];
@@ -915,12 +942,12 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
   auto A = [&](uint64_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, std::max<uint64_t>(bytes, 16)) == hipSuccess) tmp.push_back(p); return p; };
   uint8_t* d_src_b = (uint8_t*)A(cells); uint8_t* d_src_q = (uint8_t*)A(cells);
   uint8_t* d_pb = (uint8_t*)A(cells); uint8_t* d_pq = (uint8_t*)A(cells);
-  uint64_t* d_po = (uint64_t*)A(B * 8ull); uint32_t* d_ld = (uint32_t*)A(B * 4ull); uint32_t* d_len = (uint32_t*)A(B * 4ull);
+  uint64_t* d_po = (uint64_t*)A(B * 8ull); uint32_t* d_ld = (uint32_t*)A(B * 4ull); uint32_t* d_len = (uint32_t*)A(B * 4ull); uint32_t* d_lmax = (uint32_t*)A(B * 4ull);
   uint32_t* d_to = (uint32_t*)A((B + 1) * 4ull); uint64_t* d_so = (uint64_t*)A(B * 8ull); uint64_t* d_oo = (uint64_t*)A(B * 8ull);
   uint32_t* d_sr = (uint32_t*)A(N * 4); float* d_info = (float*)A(N * 4); float* d_base = (float*)A(N * 20);
   int rc = HERRO_OK;
   auto done = [&](int code) { for (void* p : tmp) hipFree(p); return code; };
-  if (!d_src_b || !d_src_q || !d_pb || !d_pq || !d_po || !d_ld || !d_len || !d_to || !d_so || !d_oo || !d_sr || !d_info || !d_base) {
+  if (!d_src_b || !d_src_q || !d_pb || !d_pq || !d_po || !d_ld || !d_len || !d_lmax || !d_to || !d_so || !d_oo || !d_sr || !d_info || !d_base) {
     ctx->err = "out of device memory";
     return done(HERRO_E_NO_DEVICE);
   }
@@ -930,6 +957,7 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
   hipMemcpyAsync(d_po, plane_off.data(), B * 8ull, hipMemcpyHostToDevice, st);
   hipMemcpyAsync(d_ld, ld.data(), B * 4ull, hipMemcpyHostToDevice, st);
   hipMemcpyAsync(d_len, len.data(), B * 4ull, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(d_lmax, lmaxv.data(), B * 4ull, hipMemcpyHostToDevice, st);
   hipMemcpyAsync(d_to, tok_off.data(), (B + 1) * 4ull, hipMemcpyHostToDevice, st);
   hipMemcpyAsync(d_so, sup_off.data(), B * 8ull, hipMemcpyHostToDevice, st);
   hipMemcpyAsync(d_oo, out_off.data(), B * 8ull, hipMemcpyHostToDevice, st);
@@ -938,8 +966,8 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
   launch_transpose_blr(d_src_q, d_pq, B, L, st);
   if ((rc = ensure_scratch(ctx, (uint32_t)N))) return done(rc);
   BatchDev bd{};
-  bd.n_win = B; bd.n_tok = (uint32_t)N; bd.lmax = L;
-  bd.plane_off = d_po; bd.plane_ld = d_ld; bd.len = d_len; bd.tok_off = d_to; bd.sup_off = d_so; bd.out_off = d_oo;
+  bd.n_win = B; bd.n_tok = (uint32_t)N;
+  bd.plane_off = d_po; bd.plane_ld = d_ld; bd.len = d_len; bd.lmax = d_lmax; bd.tok_off = d_to; bd.sup_off = d_so; bd.out_off = d_oo;
   bd.planes_b = d_pb; bd.planes_q = d_pq; bd.sup_row = d_sr; bd.out_info = d_info; bd.out_base = d_base;
   launch_model(ctx->M, bd, ctx->S, ctx->precision, st, &ctx->timer);
   hipError_t e = hipStreamSynchronize(st);

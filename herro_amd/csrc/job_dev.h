@@ -12,46 +12,51 @@
 
 #define HERRO_ROWS 31
 #define HERRO_MAX_WINDOW 8192
+#define HERRO_TILE 256        // pileup rows per workgroup in the tile kernels
+#define HERRO_CKPT_SHIFT 7    // op checkpoints every 128 target positions
 
 namespace herro {
 
 struct JobDev {
   // ---- read store (context-owned; HBM-resident for the life of the context)
-  const uint64_t* read_words;     // 2-bit packed bases, every read starts on a u64 boundary
+  const uint64_t* read_words;     // 2-bit packed bases, every read starts on a u64 boundary (+1 pad word)
   const uint64_t* read_word_off;  // [n_reads+1]
   const uint8_t* read_qual;       // phred+33 bytes
   const uint64_t* read_qual_off;  // [n_reads+1]
   const double* ln_table;         // ln(k+1) computed on the host with glibc (bit-faithful to Rust std)
   uint32_t ln_table_n;
   // ---- descriptors (uploaded by herro_job_create)
-  uint32_t n_ow, n_win, n_cls;
+  uint32_t n_ow, n_win, n_cls, n_tiles, window_size, n_ckpt;
   const uint32_t* ops;
   const OwDesc* ow;
   const WinDesc* win;
+  const uint32_t* tile_win;  // [n_tiles] window of each row tile
+  const uint32_t* tile_r0;   // [n_tiles] first row of the tile
   // ---- scratch / results
   uint32_t* op_t;        // per (overlap, op): target bases consumed before the op
   uint32_t* op_q;        // ... query bases consumed before the op
+  uint32_t* ins_ev;      // per overlap (at scr_off): insertion events, window-relative pos | len << 16
+  uint32_t* ins_cnt;     // [ow] number of insertion events
+  uint32_t* ckpt;        // [ow * n_ckpt + c] op covering target-relative position c << CKPT_SHIFT
   uint8_t* ow_keep;      // long-indel filter verdict
   float* ow_acc;         // accuracy
   uint32_t* ow_ttotal;   // target bases consumed by the slice
-  uint32_t* ow_slot;     // 1-based pass-1 column of the overlap (0: filtered)
-  uint32_t* slot_ow;     // [win.ow_begin + slot-1] -> overlap index
+  uint32_t* slot_ow;     // [win.ow_begin + slot] -> overlap index, slots ordered by accuracy rank
+  uint32_t* sel_ow;      // [win * 32 + c], c in [1,31): overlap feeding final row c (0xffffffff: padding)
   uint32_t* win_L;       // rows of the pass-1 matrix
   uint32_t* win_nkept;
-  uint32_t* win_p1sup;
   uint32_t* win_Lf;      // rows of the final matrix (L')
   uint32_t* win_nsup;
-  uint32_t* row_of_pos;  // [win.pos_off + p], p in [0, win_len]
-  uint32_t* rowmap;      // [win.row_off + row] = pos | ins << 16
-  uint32_t* newidx;      // [win.row_off + row] -> compacted row
-  uint32_t* sup_row;     // [win.row_off + k]   compacted row of informative position k
+  uint32_t* row_of_pos;  // [win.pos_off + p], p in [0, win_len]   (pass-1 layout)
+  uint32_t* rowmap;      // [win.row_off + row] = pos | ins << 16   (pass-1 layout)
+  uint32_t* row_of_pos2; // final layout
+  uint32_t* rowmap2;     // final layout
+  uint8_t* sup_flag;     // [win.row_off + final row] informative?
+  uint32_t* sup_row;     // [win.row_off + k]   final row of informative position k
   uint32_t* sup_pi;      // [win.row_off + k]   pos | ins << 16
-  uint8_t* cols_b;       // pass-1 token planes  [win.col_off + slot*lub + row]
-  uint8_t* cols_q;       // pass-1 quality planes
   uint8_t* fin_b;        // final token planes   [win.fin_off + c*lub + row], c in [0,31)
   uint8_t* fin_q;
   uint32_t* nd;          // [2*cls]: matches, mismatches (features.rs:461-500)
-  double* score;         // [ow] haplotype score per pass-1 slot
   uint32_t* rank_qid;    // [win.ow_begin + rank] ranked query ids (features.rs:569)
 };
 

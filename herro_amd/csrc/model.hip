@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void k_patch_conv1(ModelDev M, BatchDev B, Mod
   const uint32_t n = blockIdx.x;
   const uint32_t b = S.tok_win[n];
   const int32_t l = (int32_t)S.tok_row[n];
-  const int32_t len = (int32_t)B.len[b], lmax = (int32_t)B.lmax;
+  const int32_t len = (int32_t)B.len[b], lmax = (int32_t)B.lmax[b];
   const uint8_t* pb = B.planes_b + B.plane_off[b];
   const uint8_t* pq = B.planes_q + B.plane_off[b];
   const uint32_t ld = B.plane_ld[b];

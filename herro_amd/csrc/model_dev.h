@@ -52,14 +52,16 @@ struct ModelDev {
   Weight heads;         // [d_model, 16]: col 0 info, cols 1..5 bases
 };
 
-// One inference batch: windows are ragged planes [31][len] (stride lub), never padded in memory.
+// One launch group = one or more inference batches back to back: windows are ragged planes
+// [31][len] (stride lub), never padded in memory; the batch a window belongs to only matters through
+// lmax[b] (the padding the reference's collate would add), so several batches share one launch.
 struct BatchDev {
   uint32_t n_win;             // B
   uint32_t n_tok;             // N = sum of informative positions
-  uint32_t lmax;              // batch max window length (collate pads to it, inference.rs:75-97)
   const uint64_t* plane_off;  // [B] byte offset of the window's token/quality planes
   const uint32_t* plane_ld;   // [B] plane stride (lub)
   const uint32_t* len;        // [B] L' of each window
+  const uint32_t* lmax;       // [B] max L' over the window's *batch* (collate pads to it, inference.rs:75-97)
   const uint32_t* tok_off;    // [B+1] first token of each window
   const uint64_t* sup_off;    // [B] element offset of the window's informative-row list
   const uint64_t* out_off;    // [B] element offset of the window's logits in the job buffers
