@@ -152,7 +152,7 @@ def main():
     if rank == 0:
         total_windows = args.steps * args.batch * world
         kern = {k: {"ms_total": v[0], "calls": v[1], "avg_us": 1e3 * v[0] / max(v[1], 1)} for k, v in tm.items()}
-        feat_names = ["ow_stats", "win_layout", "pass1_tiles", "select_layout", "final_tiles", "sup_compact"]
+        feat_names = ["ow_stats", "win_rank", "pass1_pos", "select_layout", "final_tiles", "sup_compact"]
         feat_ms = sum(tm[k][0] for k in feat_names if k in tm) / args.steps
         model_ms = sum(v[0] for k, v in tm.items() if k not in feat_names) / args.steps
         alg_bytes = (st["read_bytes"] + st["op_bytes"] + st["out_bytes"]) / G   # per 128-window step (SURVEY §8 d, measured)
@@ -178,7 +178,7 @@ def main():
                        "model_windows_per_batch": st["n_model_windows"] / G, "batches_per_launch_group": G},
             "mbases_per_s": total_windows / el * W / 1e6,
             "roofline": {
-                "kernel": "featurize (ow_stats+win_layout+pass1_tiles+select_layout+final_tiles+sup_compact)",
+                "kernel": "featurize (ow_stats+win_rank+pass1_pos+select_layout+final_tiles+sup_compact)",
                 "bound": "hbm",
                 "achieved": alg_bytes / (feat_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS,

@@ -81,6 +81,7 @@ __device__ __forceinline__ uint32_t rev_pairs(uint32_t x) {
 __global__ __launch_bounds__(NT) void k_ow_stats(JobDev J) {
   __shared__ uint32_t s_wave[NT / 64];
   __shared__ uint32_t s_op[OPCAP], s_t[OPCAP], s_q[OPCAP];
+  __shared__ uint32_t s_bm[HERRO_MAX_WINDOW / 32 + 1];
   const uint32_t o = blockIdx.x;
   const OwDesc d = J.ow[o];
   const WinDesc wd = J.win[d.win];
@@ -92,7 +93,10 @@ __global__ __launch_bounds__(NT) void k_ow_stats(JobDev J) {
   const uint32_t off = d.tstart - wd.tstart;
   const bool in_lds = cnt <= OPCAP;
 
-  uint32_t carry_t = 0, carry_q = 0, carry_i = 0, isum = 0, dsum = 0, longindel = 0;
+  for (uint32_t i = threadIdx.x; i < J.n_bw; i += NT) s_bm[i] = 0;
+  __syncthreads();
+  uint4* md = J.md + d.scr_off;
+  uint32_t carry_t = 0, carry_q = 0, carry_i = 0, carry_m = 0, isum = 0, dsum = 0, longindel = 0;
   for (uint32_t base = 0; base < cnt; base += NT) {
     const uint32_t k = base + threadIdx.x;
     uint32_t tadv = 0, qadv = 0, is_i = 0, op = 0;
@@ -106,10 +110,12 @@ __global__ __launch_bounds__(NT) void k_ow_stats(JobDev J) {
       if (ty == OP_I) { isum += e; is_i = 1; }
       if (ty == OP_D) dsum += e;
     }
-    uint32_t tot_t, tot_q, tot_i;
+    const uint32_t is_md = (k < cnt && !is_i) ? 1u : 0u;
+    uint32_t tot_t, tot_q, tot_i, tot_m;
     const uint32_t ex_t = block_scan(tadv, &tot_t, s_wave);
     const uint32_t ex_q = block_scan(qadv, &tot_q, s_wave);
     const uint32_t ex_i = block_scan(is_i, &tot_i, s_wave);
+    const uint32_t ex_m = block_scan(is_md, &tot_m, s_wave);
     if (k < cnt) {
       const uint32_t t = carry_t + ex_t, q = carry_q + ex_q;
       op_t[k] = t;
@@ -117,10 +123,20 @@ __global__ __launch_bounds__(NT) void k_ow_stats(JobDev J) {
       if (in_lds) { s_op[k] = op; s_t[k] = t; s_q[k] = q; }
       // insertion behind window position off+t-1 (features.rs:77); t >= 1: a slice never starts with I
       if (is_i) ins_ev[carry_i + ex_i] = ((off + t - 1u) & 0xffffu) | (op_len(op) << 16);
+      if (is_md) {
+        // compact M/D op table + bitmap of op starts: the tile kernels find the op covering a target
+        // position with one popcount (rank) instead of a search.  An M/D op is followed by at most one
+        // insertion (the host rejects consecutive I ops); I ops are never trimmed by window offsets.
+        const uint32_t nxt = (k + 1 < cnt) ? ops[k + 1] : 0u;
+        const uint32_t ins_len = (k + 1 < cnt && op_type(nxt) == OP_I) ? op_len(nxt) : 0u;
+        md[carry_m + ex_m] = make_uint4(t, q, tadv | (op_type(op) == OP_M ? 0x80000000u : 0u), ins_len);
+        atomicOr(&s_bm[t >> 5], 1u << (t & 31u));
+      }
     }
     carry_t += tot_t;
     carry_q += tot_q;
     carry_i += tot_i;
+    carry_m += tot_m;
   }
   const uint32_t t_total = carry_t;
   __syncthreads();  // LDS tables / global op_t visible to the whole workgroup
@@ -128,10 +144,33 @@ __global__ __launch_bounds__(NT) void k_ow_stats(JobDev J) {
   const uint32_t* pt = in_lds ? s_t : op_t;
   const uint32_t* pq = in_lds ? s_q : op_q;
 
-  // op checkpoints every 128 target positions (entry points for the tile kernels)
-  for (uint32_t c = threadIdx.x; c < J.n_ckpt; c += NT) {
-    const uint32_t u = c << HERRO_CKPT_SHIFT;
-    J.ckpt[(uint64_t)o * J.n_ckpt + c] = u < t_total ? find_op(pt, cnt, u) : 0u;
+  // bitmap words + cumulative popcounts (rank directory), and the column header
+  {
+    uint2* bm = J.bm + (uint64_t)o * J.n_bw;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < J.n_bw; base += NT) {
+      const uint32_t i = base + threadIdx.x;
+      const uint32_t bits = i < J.n_bw ? s_bm[i] : 0u;
+      uint32_t tot;
+      const uint32_t ex = block_scan(__popc(bits), &tot, s_wave);
+      if (i < J.n_bw) bm[i] = make_uint2(bits, carry + ex);
+      carry += tot;
+    }
+    if (threadIdx.x == 0) {
+      ColHdr h;
+      h.off = (int32_t)off;
+      h.t_total = t_total;
+      h.strand = d.strand;
+      h.cls = d.cls;
+      // stored index of alignment-orientation base q: sbase + sdir * q (features.rs:97-108,128-153)
+      h.sbase = d.strand ? (int32_t)(d.qbeg + d.qlen - 1u) : (int32_t)d.qbeg;
+      h.sdir = d.strand ? -1 : 1;
+      h.md_off = d.scr_off;
+      h.n_md = carry_m;
+      h.q_woff = J.read_word_off[d.qid];
+      h.qual_off = J.read_qual_off[d.qid];
+      J.chdr[o] = h;
+    }
   }
 
   // accuracy: matches / mismatches over M ops (features.rs:650-665), 16 target bases per step
@@ -233,19 +272,15 @@ __device__ __forceinline__ uint32_t write_layout(const uint32_t* s_mi, uint32_t 
 }
 
 // =====================================================================================================
-// k_win_layout — one workgroup per window
+// k_win_rank — one workgroup per window: stable rank of kept overlaps by descending accuracy
 // =====================================================================================================
-__global__ __launch_bounds__(NT) void k_win_layout(JobDev J) {
+__global__ __launch_bounds__(NT) void k_win_rank(JobDev J) {
   __shared__ uint32_t s_wave[NT / 64];
-  __shared__ uint32_t s_mi[HERRO_MAX_WINDOW];
-  __shared__ uint32_t s_pref[EVCAP];
   const uint32_t w = blockIdx.x;
   const WinDesc wd = J.win[w];
   const uint32_t n = wd.ow_cnt;
-
-  // stable rank of kept overlaps by descending accuracy (sort_by_key(-acc), features.rs:386)
   uint32_t kept_local = 0;
-  for (uint32_t i = threadIdx.x; i < n; i += NT) {
+  for (uint32_t i = threadIdx.x; i < n; i += NT) {  // sort_by_key(-acc), stable (features.rs:386-409)
     const uint32_t oi = wd.ow_begin + i;
     if (J.ow_keep[oi]) {
       kept_local++;
@@ -260,188 +295,313 @@ __global__ __launch_bounds__(NT) void k_win_layout(JobDev J) {
       J.slot_ow[wd.ow_begin + rank] = oi;
     }
   }
-  for (uint32_t p = threadIdx.x; p < wd.win_len; p += NT) s_mi[p] = 0;
-  const uint32_t n_kept = block_sum(kept_local, s_wave);  // also orders slot_ow / s_mi writes
-  __syncthreads();
-
-  // max insertion per target position over ALL kept overlaps (features.rs:44-95)
-  scatter_max_ins(J, J.slot_ow + wd.ow_begin, n_kept, wd.win_len, s_mi, s_pref, s_wave);
-
-  const uint32_t L = write_layout(s_mi, wd.win_len, wd.lub, J.row_of_pos + wd.pos_off,
-                                  J.rowmap + wd.row_off, s_wave);
-  if (threadIdx.x == 0) {
-    J.win_L[w] = L;  // <= lub by construction of lub (host)
-    J.win_nkept[w] = n_kept;
-  }
+  const uint32_t n_kept = block_sum(kept_local, s_wave);
+  if (threadIdx.x == 0) J.win_nkept[w] = n_kept;
 }
 
-// ---- pileup columns of one row tile, evaluated lane = row --------------------------------------------
-// Consecutive lanes own consecutive pileup rows, so the loads of query bases / qualities are
-// coalesced and control flow is uniform across the wave.  For each column the CIGAR ops that can
-// touch the tile (a window of WOPS ops starting at the checkpointed op) are staged into LDS by all
-// threads at once; a cell then needs a 6-step binary search in LDS.
-static constexpr int NCOL = 32;   // columns staged per pass
-static constexpr int WOPS = 64;   // ops staged per column
+// =====================================================================================================
+// k_pass1_pos — informative target positions + match/mismatch tallies, in POSITION space, bit-sliced
+// =====================================================================================================
+// What pass 1 of the reference leaves behind is only the per-query tallies (features.rs:461-500), and
+// those are taken at informative rows that carry a target base — insertion rows are skipped
+// (features.rs:489-491).  A target-base row is a target position, so pass 1 needs no row layout at all:
+// a lane owns 16 consecutive positions as bit-vectors, each column contributes its symbols as bit
+// planes (query bases come from the bit-plane copy of the read store, a whole M run per shift), and the
+// per-position symbol counts over all columns live in bit-sliced counters (features.rs:681-722).
+__device__ __forceinline__ uint32_t plane_bits(const uint32_t* __restrict__ pl, uint64_t woff, int32_t s) {
+  // 32 consecutive plane bits starting at base index s (s may be negative: those bits read 0)
+  if (s < 0) return s <= -32 ? 0u : (pl[woff] << (uint32_t)(-s));
+  const uint32_t w = (uint32_t)s >> 5;
+  return __funnelshift_r(pl[woff + w], pl[woff + w + 1], (uint32_t)s & 31u);
+}
 
-struct SHdr {
-  int32_t off;        // window-relative position where the overlap starts
-  uint32_t t_total;   // target bases the slice consumes
-  uint32_t k0;        // first staged op (absolute index in the slice)
-  uint32_t cnt;       // ops in the slice
-  uint32_t fallback;  // staged window does not reach the end of the tile: use the global tables
-  uint32_t ow, qbeg, qlen, strand, cls;
-  uint64_t q_woff;
-  const uint8_t* qual;
+struct ColPlanes { uint32_t m, lo, hi, gap; };  // per position bit: M base present / code planes / deletion
+
+__device__ __forceinline__ ColPlanes column_planes(const JobDev& J, const ColHdr& h, uint32_t o, uint32_t P) {
+  ColPlanes out{0u, 0u, 0u, 0u};
+  const int32_t u0 = (int32_t)P - h.off;
+  const int32_t lo_u = max(u0, 0), hi_u = min(u0 + 16, (int32_t)h.t_total);
+  if (lo_u >= hi_u) return out;
+  const uint2 bw = J.bm[(uint64_t)o * J.n_bw + ((uint32_t)lo_u >> 5)];
+  uint32_t r = bw.y + __popc(bw.x & (0xffffffffu >> (31u - ((uint32_t)lo_u & 31u)))) - 1u;
+  int32_t u = lo_u;
+  while (u < hi_u) {
+    const uint4 e = J.md[h.md_off + r];
+    const int32_t oend = (int32_t)(e.x + (e.z & 0x7fffffffu));
+    const int32_t se = min(hi_u, oend);
+    const uint32_t n = (uint32_t)(se - u), sh = (uint32_t)(u - u0);
+    const uint32_t seg = ((1u << n) - 1u) << sh;
+    if (e.z >> 31) {
+      const int32_t q = (int32_t)e.y + (u - (int32_t)e.x);
+      uint32_t b0, b1;
+      if (h.sdir > 0) {
+        b0 = plane_bits(J.read_p0, h.q_woff, h.sbase + q);
+        b1 = plane_bits(J.read_p1, h.q_woff, h.sbase + q);
+      } else {  // alignment-orientation base k = complement of stored base (sbase - q) - k
+        const int32_t s_hi = h.sbase - q;
+        b0 = ~__brev(plane_bits(J.read_p0, h.q_woff, s_hi - 31));
+        b1 = ~__brev(plane_bits(J.read_p1, h.q_woff, s_hi - 31));
+      }
+      out.lo |= (b0 << sh) & seg;
+      out.hi |= (b1 << sh) & seg;
+      out.m |= seg;
+    } else {
+      out.gap |= seg;
+    }
+    u = se;
+    r++;
+  }
+  return out;
+}
+
+template <int NB>
+struct SlicedCounters {
+  uint32_t c[5][NB];  // A C G T *
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int s = 0; s < 5; s++)
+#pragma unroll
+      for (int b = 0; b < NB; b++) c[s][b] = 0;
+  }
+  __device__ __forceinline__ void add1(int s, uint32_t x) {  // saturating at 2^NB - 1 (>= the threshold)
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      const uint32_t carry = c[s][b] & x;
+      c[s][b] ^= x;
+      x = carry;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; b++) c[s][b] |= x;
+  }
+  __device__ __forceinline__ void add(const ColPlanes& p) {
+    add1(0, p.m & ~p.lo & ~p.hi);
+    add1(1, p.m & p.lo & ~p.hi);
+    add1(2, p.m & ~p.lo & p.hi);
+    add1(3, p.m & p.lo & p.hi);
+    add1(4, p.gap);
+  }
+  __device__ __forceinline__ uint32_t ge(int s, uint32_t thresh) const {  // positions with count >= thresh
+    uint32_t gt = 0, eq = 0xffffffffu;
+#pragma unroll
+    for (int b = NB - 1; b >= 0; b--) {
+      const uint32_t tb = ((thresh >> b) & 1u) ? 0xffffffffu : 0u;
+      gt |= eq & c[s][b] & ~tb;
+      eq &= ~(c[s][b] ^ tb);
+    }
+    return gt | eq;
+  }
 };
 
-struct TileLds {
-  SHdr hdr[NCOL];
-  uint32_t op[NCOL * WOPS], t[NCOL * WOPS], q[NCOL * WOPS];
+struct CellOut { uint32_t tok, qual; };
+template <bool WITH_QUAL>
+__device__ __forceinline__ CellOut column_cell(const JobDev& J, const ColHdr& h, uint32_t o, int32_t p, uint32_t j);
+__device__ __forceinline__ void count_sym(uint64_t& c, uint32_t folded);
+
+// LDS staging for k_pass1_pos: PG columns at a time, each with its rank directory, op table and the
+// bit planes of the query stretch the overlap-window covers.
+static constexpr int PG = 8;
+static constexpr int MDCAP = 176;  // M/D ops per column   (typical: ~100)
+static constexpr int PWCAP = 168;  // plane words per column (typical: ~150 for a 4096-bp window)
+
+struct PCol {
+  ColHdr h;
+  uint32_t ow, pw0, fb, pad;  // pw0: first staged plane word (relative to the read's words)
 };
 
-// Stage columns `ow_list[0..ng)` for the tile covering window positions [p_lo, p_hi].
-__device__ __forceinline__ void stage_group(const JobDev& J, const WinDesc& wd, const uint32_t* ow_list,
-                                            uint32_t ng, uint32_t p_lo, uint32_t p_hi, TileLds& S) {
-  if (threadIdx.x < ng) {
-    const uint32_t o = ow_list[threadIdx.x];
-    SHdr h;
-    h.ow = o;
-    if (o != 0xffffffffu) {
-      const OwDesc d = J.ow[o];
-      h.off = (int32_t)(d.tstart - wd.tstart);
-      h.t_total = J.ow_ttotal[o];
-      h.cnt = d.op_cnt;
-      h.qbeg = d.qbeg; h.qlen = d.qlen; h.strand = d.strand; h.cls = d.cls;
-      h.q_woff = J.read_word_off[d.qid];
-      h.qual = J.read_qual + J.read_qual_off[d.qid];
-      const int32_t ulo = max((int32_t)p_lo - h.off, 0);
-      const int32_t uhi = min((int32_t)p_hi - h.off, (int32_t)h.t_total - 1);
-      h.k0 = 0;
-      h.fallback = 0;
-      if (ulo <= uhi) {
-        h.k0 = J.ckpt[(uint64_t)o * J.n_ckpt + ((uint32_t)ulo >> HERRO_CKPT_SHIFT)];
-        // the window must hold the op covering uhi plus the insertions right behind it
-        const uint32_t last = h.k0 + WOPS - 1;
-        if (last + 1 < d.op_cnt && J.op_t[d.scr_off + last] <= (uint32_t)uhi + 1u) h.fallback = 1;
+__device__ __forceinline__ uint32_t lds_plane_bits(const uint32_t* pl, uint32_t npw, int32_t s_rel) {
+  // 32 plane bits starting at staged bit index s_rel (may be negative / run past the staged words -> 0s)
+  if (s_rel < 0) return s_rel <= -32 ? 0u : (pl[0] << (uint32_t)(-s_rel));
+  const uint32_t w = (uint32_t)s_rel >> 5;
+  const uint32_t a = w < npw ? pl[w] : 0u, b = w + 1 < npw ? pl[w + 1] : 0u;
+  return __funnelshift_r(a, b, (uint32_t)s_rel & 31u);
+}
+
+template <int NB>
+__global__ __launch_bounds__(NT) void k_pass1_pos(JobDev J) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  PCol* pc = reinterpret_cast<PCol*>(smem);
+  uint4* s_md = reinterpret_cast<uint4*>(pc + PG);
+  uint2* s_bm = reinterpret_cast<uint2*>(s_md + PG * MDCAP);
+  uint32_t* s_p0 = reinterpret_cast<uint32_t*>(s_bm + PG * J.n_bw);
+  uint32_t* s_p1 = s_p0 + PG * PWCAP;
+
+  const uint32_t w = blockIdx.x;
+  const WinDesc wd = J.win[w];
+  const uint32_t n_kept = J.win_nkept[w];
+  const uint32_t* slots = J.slot_ow + wd.ow_begin;
+  const uint32_t ncols = 1u + (n_kept > 30u ? n_kept : 30u);  // features.rs:282
+  const uint32_t thresh = (uint32_t)((double)ncols * 0.1);    // features.rs:712
+  const uint64_t t_woff = J.read_word_off[wd.rid];
+
+  // planes of staged column ci for the 16 positions starting at P (see column_planes)
+  auto staged_planes = [&](uint32_t ci, uint32_t P) -> ColPlanes {
+    const PCol& c = pc[ci];
+    if (c.fb) return column_planes(J, c.h, c.ow, P);
+    ColPlanes out{0u, 0u, 0u, 0u};
+    const int32_t u0 = (int32_t)P - c.h.off;
+    const int32_t lo_u = max(u0, 0), hi_u = min(u0 + 16, (int32_t)c.h.t_total);
+    if (lo_u >= hi_u) return out;
+    const uint2 bw = s_bm[ci * J.n_bw + ((uint32_t)lo_u >> 5)];
+    uint32_t r = bw.y + __popc(bw.x & (0xffffffffu >> (31u - ((uint32_t)lo_u & 31u)))) - 1u;
+    const uint32_t* p0 = s_p0 + ci * PWCAP;
+    const uint32_t* p1 = s_p1 + ci * PWCAP;
+    const int32_t rel = -(int32_t)(c.pw0 << 5);  // staged bit index = stored index + rel
+    int32_t u = lo_u;
+    while (u < hi_u) {
+      const uint4 e = s_md[ci * MDCAP + r];
+      const int32_t oend = (int32_t)(e.x + (e.z & 0x7fffffffu));
+      const int32_t se = min(hi_u, oend);
+      const uint32_t n = (uint32_t)(se - u), sh = (uint32_t)(u - u0);
+      const uint32_t seg = ((1u << n) - 1u) << sh;
+      if (e.z >> 31) {
+        const int32_t q = (int32_t)e.y + (u - (int32_t)e.x);
+        uint32_t b0, b1;
+        if (c.h.sdir > 0) {
+          b0 = lds_plane_bits(p0, PWCAP, c.h.sbase + q + rel);
+          b1 = lds_plane_bits(p1, PWCAP, c.h.sbase + q + rel);
+        } else {
+          const int32_t s_hi = c.h.sbase - q;
+          b0 = ~__brev(lds_plane_bits(p0, PWCAP, s_hi - 31 + rel));
+          b1 = ~__brev(lds_plane_bits(p1, PWCAP, s_hi - 31 + rel));
+        }
+        out.lo |= (b0 << sh) & seg;
+        out.hi |= (b1 << sh) & seg;
+        out.m |= seg;
       } else {
-        h.t_total = 0;  // the tile lies outside the overlap: every cell is '.'
+        out.gap |= seg;
+      }
+      u = se;
+      r++;
+    }
+    return out;
+  };
+  auto stage = [&](uint32_t g0, uint32_t ng) {
+    __syncthreads();
+    if (threadIdx.x < ng) {
+      PCol c;
+      c.ow = slots[g0 + threadIdx.x];
+      c.h = J.chdr[c.ow];
+      const OwDesc& d = J.ow[c.ow];
+      c.pw0 = d.qbeg >> 5;
+      const uint32_t npw = ((d.qbeg + d.qlen) >> 5) - c.pw0 + 2;  // +1 for the funnel shift's second word
+      c.fb = (c.h.n_md > MDCAP || npw > PWCAP) ? 1u : 0u;
+      c.pad = 0;
+      pc[threadIdx.x] = c;
+    }
+    __syncthreads();
+    for (uint32_t idx = threadIdx.x; idx < ng * MDCAP; idx += NT) {
+      const uint32_t ci = idx / MDCAP, i = idx % MDCAP;
+      const PCol& c = pc[ci];
+      if (!c.fb && i < c.h.n_md) s_md[idx] = J.md[c.h.md_off + i];
+    }
+    for (uint32_t idx = threadIdx.x; idx < ng * J.n_bw; idx += NT) {
+      const uint32_t ci = idx / J.n_bw, i = idx % J.n_bw;
+      s_bm[idx] = J.bm[(uint64_t)pc[ci].ow * J.n_bw + i];
+    }
+    for (uint32_t idx = threadIdx.x; idx < ng * PWCAP; idx += NT) {
+      const uint32_t ci = idx / PWCAP, i = idx % PWCAP;
+      const PCol& c = pc[ci];
+      uint32_t a = 0, b = 0;
+      if (!c.fb && c.h.q_woff + c.pw0 + i < J.read_n_words + 2) {
+        a = J.read_p0[c.h.q_woff + c.pw0 + i];
+        b = J.read_p1[c.h.q_woff + c.pw0 + i];
+      }
+      s_p0[idx] = a;
+      s_p1[idx] = b;
+    }
+    __syncthreads();
+  };
+
+  for (uint32_t base = 0; base < wd.win_len; base += NT * 16u) {  // wave-uniform trip count (shuffles below)
+    const uint32_t P = base + threadIdx.x * 16u;
+    const bool act = P < wd.win_len;
+    const uint32_t npos = act ? min(16u, wd.win_len - P) : 0u, vmask = (1u << npos) - 1u;
+    const uint32_t tlo = act ? plane_bits(J.read_p0, t_woff, (int32_t)(wd.tstart + P)) & vmask : 0u;
+    const uint32_t thi = act ? plane_bits(J.read_p1, t_woff, (int32_t)(wd.tstart + P)) & vmask : 0u;
+    SlicedCounters<NB> cnt;
+    cnt.clear();
+    cnt.add(ColPlanes{vmask, tlo, thi, 0u});  // the target column: always a base on these rows
+    for (uint32_t g0 = 0; g0 < n_kept; g0 += PG) {
+      const uint32_t ng = min((uint32_t)PG, n_kept - g0);
+      stage(g0, ng);
+      for (uint32_t ci = 0; ci < ng; ci++) {
+        ColPlanes cp = act ? staged_planes(ci, P) : ColPlanes{0u, 0u, 0u, 0u};
+        cp.m &= vmask; cp.gap &= vmask;
+        cnt.add(cp);
       }
     }
-    S.hdr[threadIdx.x] = h;
-  }
-  __syncthreads();
-  for (uint32_t idx = threadIdx.x; idx < ng * WOPS; idx += NT) {
-    const uint32_t c = idx / WOPS, i = idx % WOPS;
-    const SHdr& h = S.hdr[c];
-    uint32_t op = 0, t = 0xffffffffu, q = 0;
-    if (h.ow != 0xffffffffu && h.t_total && h.k0 + i < h.cnt) {
-      const OwDesc& d = J.ow[h.ow];
-      op = J.ops[d.op_begin + h.k0 + i];
-      t = J.op_t[d.scr_off + h.k0 + i];
-      q = J.op_q[d.scr_off + h.k0 + i];
-    }
-    S.op[idx] = op; S.t[idx] = t; S.q[idx] = q;
-  }
-  __syncthreads();
-}
-
-// Cell of staged column c at target-relative position u, insertion ordinal j (features.rs:173-231).
-__device__ __forceinline__ Cell eval_lane(const JobDev& J, const TileLds& S, uint32_t c, int32_t u, uint32_t j) {
-  const SHdr& h = S.hdr[c];
-  Cell cell;
-  cell.kind = CELL_NONE;
-  cell.q = 0;
-  if (u < 0 || (uint32_t)u >= h.t_total) return cell;
-  if (h.fallback) {  // rare: more than WOPS ops between the checkpoint and the end of the tile
-    const OwDesc d = J.ow[h.ow];
-    return eval_cell(J.ops + d.op_begin, J.op_t + d.scr_off, J.op_q + d.scr_off, d.op_cnt, d.start_off,
-                     d.end_off, h.t_total, u, j);
-  }
-  const uint32_t uu = (uint32_t)u;
-  const uint32_t* T = S.t + c * WOPS;
-  uint32_t pos = 0;  // largest i with T[i] <= uu (T sorted, padded with 0xffffffff; T[0] <= uu)
+    // informative: at least two symbols reach the threshold
+    uint32_t one = 0, two = 0;
 #pragma unroll
-  for (uint32_t st = WOPS / 2; st; st >>= 1)
-    if (T[pos + st] <= uu) pos += st;
-  const uint32_t op = S.op[c * WOPS + pos];
-  if (j == 0) {
-    if (op_type(op) == OP_M) { cell.kind = CELL_BASE; cell.q = S.q[c * WOPS + pos] + (uu - T[pos]); }
-    else cell.kind = CELL_GAP;  // deletion
-    return cell;
+    for (int s5 = 0; s5 < 5; s5++) {
+      const uint32_t g = cnt.ge(s5, thresh) & vmask;
+      two |= one & g;
+      one |= g;
+    }
+    const uint32_t sup = thresh == 0 ? vmask : two;  // thresh 0 cannot happen (ncols >= 31) but stay exact
+    // tallies (features.rs:478-498): every kept column is scored at every informative position;
+    // anything but the target's base ('.', '*', '#', other bases) is a mismatch.  Informative
+    // positions are rare (~0.4 %), so they are listed in LDS (the staging area is free now) and only
+    // those (position, column) cells are evaluated, one per thread, straight from the rank directory.
+    __syncthreads();
+    uint32_t* s_n = reinterpret_cast<uint32_t*>(s_md);
+    uint16_t* s_list = reinterpret_cast<uint16_t*>(s_n + 4);
+    if (threadIdx.x == 0) *s_n = 0;
+    __syncthreads();
+    for (uint32_t m = sup; m; m &= m - 1u) s_list[atomicAdd(s_n, 1u)] = (uint16_t)(P + (uint32_t)__ffs(m) - 1u);
+    __syncthreads();
+    const uint32_t npair = *s_n * n_kept;
+    for (uint32_t pr = threadIdx.x; pr < npair; pr += NT) {
+      const uint32_t pos = s_list[pr / n_kept], o = slots[pr % n_kept];
+      const ColHdr h = J.chdr[o];
+      const CellOut co = column_cell<false>(J, h, o, (int32_t)pos, 0);
+      const uint32_t t = read_code(J.read_words, t_woff, wd.tstart + pos);
+      atomicAdd(&J.nd[2 * (uint64_t)h.cls + (tok_fold(co.tok) == t ? 0 : 1)], 1u);
+    }
   }
-  // insertion slot j-1 behind u: only if u is the last target base of its op and insertions follow.
-  // (an I op is never trimmed by the window offsets, so its effective length is its length)
-  cell.kind = CELL_GAP;
-  uint32_t x = pos + 1;
-  const uint32_t t_next = (h.k0 + x < h.cnt) ? T[x] : h.t_total;
-  if (uu + 1 != t_next) return cell;
-  for (; h.k0 + x < h.cnt && x < WOPS; x++) {
-    const uint32_t opx = S.op[c * WOPS + x];
-    if (op_type(opx) != OP_I) break;
-    if (op_len(opx) > j - 1) { cell.kind = CELL_BASE; cell.q = S.q[c * WOPS + x] + (j - 1); }
-  }
-  return cell;
 }
 
-// token (and quality) of a cell; forward: stored index qbeg+q, upper case; reverse: complement of
-// stored index qbeg+qlen-1-q, lower case, quality of that same stored base (features.rs:128-153)
+// ---- one pileup cell, lane = row, no search ------------------------------------------------------------
+// Consecutive lanes own consecutive pileup rows: loads of bitmap words, op entries, query bases and
+// qualities are coalesced or broadcast, and there is no divergent control flow.  The op covering
+// target-relative position u is entry rank(u)-1 of the overlap's compact M/D table, with
+// rank(u) = cum[u>>5] + popc(bits[u>>5] & mask(u&31))  (bitmap of op starts, built by k_ow_stats).
+// CellOut: tok = token (inference.rs:23-31), qual = phred+33 (33 '!' where the cell holds no base)
+
 template <bool WITH_QUAL>
-__device__ __forceinline__ uint32_t cell_token(const JobDev& J, const SHdr& h, const Cell& c, uint32_t* qual) {
-  if (c.kind == CELL_NONE) return TOK_NONE;
-  if (c.kind == CELL_GAP) return h.strand ? TOK_GAP_R : TOK_GAP_F;
-  const uint32_t si = h.strand ? h.qbeg + h.qlen - 1 - c.q : h.qbeg + c.q;
-  const uint32_t code = read_code(J.read_words, h.q_woff, si);
-  if (WITH_QUAL) *qual = h.qual[si];
-  return h.strand ? 5u + (code ^ 3u) : code;
-}
-
-
-// Tokens (and qualities) of NB consecutive staged columns at one row, with all NB base (and quality)
-// loads issued back to back before any is consumed (memory-level parallelism instead of NB
-// serialized HBM/L2 round trips per wave).
-static constexpr int NB = 8;
-template <bool WITH_QUAL>
-__device__ __forceinline__ void eval_batch(const JobDev& J, const TileLds& S, uint32_t c0, uint32_t nc, int32_t p,
-                                           uint32_t j, uint32_t (&tok)[NB], uint32_t (&ql)[NB]) {
-  uint32_t si[NB];
-  uint64_t wd64[NB];
-  uint8_t qb[NB];
-#pragma unroll
-  for (int k = 0; k < NB; k++) {
-    tok[k] = TOK_NONE;
-    ql[k] = 33;
-    si[k] = 0xffffffffu;
-    if ((uint32_t)k < nc && S.hdr[c0 + k].ow != 0xffffffffu) {
-      const SHdr& h = S.hdr[c0 + k];
-      const Cell cell = eval_lane(J, S, c0 + k, p - h.off, j);
-      if (cell.kind == CELL_GAP) tok[k] = h.strand ? TOK_GAP_R : TOK_GAP_F;
-      else if (cell.kind == CELL_BASE) si[k] = h.strand ? h.qbeg + h.qlen - 1 - cell.q : h.qbeg + cell.q;
-    }
+__device__ __forceinline__ CellOut column_cell(const JobDev& J, const ColHdr& h, uint32_t o, int32_t p, uint32_t j) {
+  const uint32_t uu_raw = (uint32_t)(p - h.off);
+  const bool inr = uu_raw < h.t_total;  // also false for p < off (wraps)
+  const uint32_t uu = inr ? uu_raw : 0u;
+  const uint2 bw = J.bm[(uint64_t)o * J.n_bw + (uu >> 5)];
+  const uint32_t rank = bw.y + __popc(bw.x & (0xffffffffu >> (31u - (uu & 31u))));
+  const uint4 e = J.md[h.md_off + (inr && h.t_total ? rank - 1u : 0u)];  // t_beg, q_beg, len | M<<31, ins_len
+  const bool is_m = (e.z >> 31) != 0;
+  const uint32_t len = e.z & 0x7fffffffu;
+  const bool last = (uu + 1u == e.x + len);
+  // j == 0: M -> query base, D -> gap.  j > 0 (insertion slot j-1 behind u): base iff u is the op's last
+  // target base and the following insertion is at least j long (features.rs:173-231)
+  const bool isbase = inr && (j == 0 ? is_m : (last && e.w >= j));
+  const uint32_t q = j == 0 ? e.y + (uu - e.x) : e.y + (is_m ? len : 0u) + (j - 1u);
+  CellOut out;
+  out.qual = 33;
+  const uint32_t si = isbase ? (uint32_t)(h.sbase + h.sdir * (int32_t)q) : 0u;
+  const uint64_t word = J.read_words[h.q_woff + (si >> 5)];
+  if (WITH_QUAL) {
+    const uint32_t qv = J.read_qual[h.qual_off + si];
+    out.qual = isbase ? qv : 33u;
   }
-#pragma unroll
-  for (int k = 0; k < NB; k++) {
-    wd64[k] = 0;
-    qb[k] = 33;
-    if (si[k] != 0xffffffffu) {
-      const SHdr& h = S.hdr[c0 + k];
-      wd64[k] = J.read_words[h.q_woff + (si[k] >> 5)];
-      if (WITH_QUAL) qb[k] = h.qual[si[k]];
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < NB; k++) {
-    if (si[k] != 0xffffffffu) {
-      const uint32_t code = (uint32_t)(wd64[k] >> ((si[k] & 31u) << 1)) & 3u;
-      tok[k] = S.hdr[c0 + k].strand ? 5u + (code ^ 3u) : code;
-      ql[k] = qb[k];
-    }
-  }
+  const uint32_t code = (uint32_t)(word >> ((si & 31u) << 1)) & 3u;
+  const uint32_t base_tok = h.strand ? 5u + (code ^ 3u) : code;              // reverse: complement, lower case
+  const uint32_t gap_tok = h.strand ? (uint32_t)TOK_GAP_R : (uint32_t)TOK_GAP_F;
+  out.tok = !inr ? (uint32_t)TOK_NONE : (isbase ? base_tok : gap_tok);
+  return out;
 }
 
 // Symbol counters A,C,G,T,* packed as five 12-bit fields (a runtime-indexed register array would
 // live in scratch memory); the host caps overlaps per window at 4000.
 __device__ __forceinline__ void count_sym(uint64_t& c, uint32_t folded) {
-  if (folded < 5u) c += 1ull << (12u * folded);
+  c += folded < 5u ? 1ull << (12u * folded) : 0ull;
 }
 // informative row test (features.rs:681-722): >= 2 symbols with count >= thresh.
 __device__ __forceinline__ bool supported_from_counts(uint64_t c, uint32_t thresh) {
@@ -451,61 +611,143 @@ __device__ __forceinline__ bool supported_from_counts(uint64_t c, uint32_t thres
   return ns >= 2;
 }
 
-// =====================================================================================================
-// k_pass1_tiles — one workgroup per 256 pass-1 rows
-// =====================================================================================================
-__global__ __launch_bounds__(NT) void k_pass1_tiles(JobDev J) {
-  __shared__ TileLds S;
-  const uint32_t w = J.tile_win[blockIdx.x], r0 = J.tile_r0[blockIdx.x];
-  const uint32_t L = J.win_L[w];
-  if (r0 >= L) return;
-  const WinDesc wd = J.win[w];
-  const uint32_t n_kept = J.win_nkept[w];
-  const uint32_t* rowmap = J.rowmap + wd.row_off;
-  const uint32_t p_lo = rowmap[r0] & 0xffffu, p_hi = rowmap[min(r0 + NT, L) - 1] & 0xffffu;
-  const uint32_t r = r0 + threadIdx.x;
-  const bool valid = r < L;
-  const uint32_t rm = valid ? rowmap[r] : 0u;
-  const int32_t p = (int32_t)(rm & 0xffffu);
-  const uint32_t j = rm >> 16;
-  // target column (features.rs:239-266): base on j == 0 rows, '*' on insertion rows
-  const uint32_t t = (valid && j == 0) ? read_code(J.read_words, J.read_word_off[wd.rid], wd.tstart + (uint32_t)p)
-                                       : (uint32_t)TOK_GAP_F;
-  const uint32_t ncols = 1u + (n_kept > 30u ? n_kept : 30u);  // features.rs:282
-  const uint32_t thresh = (uint32_t)((double)ncols * 0.1);    // features.rs:712
-  uint64_t cnt = 0;
-  if (valid) count_sym(cnt, t);
-  const bool single = n_kept <= NCOL;
-  bool sup = false;
-  for (int pass = 0; pass < 2; pass++) {
-    for (uint32_t g0 = 0; g0 < n_kept; g0 += NCOL) {
-      const uint32_t ng = min((uint32_t)NCOL, n_kept - g0);
-      if (!(single && pass == 1)) {
-        __syncthreads();
-        stage_group(J, wd, J.slot_ow + wd.ow_begin + g0, ng, p_lo, p_hi, S);
-      }
-      if (pass == 0 ? valid : sup) {
-        for (uint32_t c0 = 0; c0 < ng; c0 += NB) {
-          uint32_t tok[NB], ql[NB];
-          const uint32_t nc = min((uint32_t)NB, ng - c0);
-          eval_batch<false>(J, S, c0, nc, p, j, tok, ql);
-#pragma unroll
-          for (int k = 0; k < NB; k++) {
-            if ((uint32_t)k >= nc) break;
-            const uint32_t f = tok_fold(tok[k]);
-            if (pass == 0) count_sym(cnt, f);
-            else  // tallies (features.rs:478-498): '.', '*', '#' count as mismatch
-              atomicAdd(&J.nd[2 * (uint64_t)S.hdr[c0 + k].cls + (f == t ? 0 : 1)], 1u);
-          }
-        }
+// ---- LDS-staged columns of one row tile ---------------------------------------------------------------
+// Everything a 256-row tile needs from a column — header, bitmap words, M/D op entries, the 2-bit
+// words and the quality bytes of the query stretch it can touch — is copied into LDS by all threads
+// at once (a handful of dependent global round trips per workgroup instead of per cell); the per-cell
+// loop then reads LDS only.  Columns whose stretch does not fit the staging slots (very dense CIGARs,
+// huge insertions) fall back to column_cell() on global memory.
+static constexpr int NCOL = 32;   // columns per staging pass
+static constexpr int TLD = HERRO_TILE + 4;  // byte-tile row stride for the output transpose (bank spread)
+static constexpr int BMW = 10;    // bitmap words per column   (tile spans <= 256 positions -> <= 9 words)
+static constexpr int MDS = 24;    // M/D op entries per column
+static constexpr int WW = 14;     // 2-bit words per column    (<= 448 query bases)
+static constexpr int QB = 480;    // quality bytes per column  (multiple of 4)
+
+struct TCol {
+  ColHdr h;
+  uint32_t ow;      // 0xffffffff: padding column
+  uint32_t w0;      // first staged bitmap word
+  uint32_t r0;      // md entry staged in slot 0
+  uint32_t word0;   // first staged 2-bit word (index into the query read's words)
+  uint64_t qg0;     // 4-aligned index into read_qual of the first staged quality byte
+  uint32_t fb;      // 1: stretch does not fit, use the global path
+  uint32_t nmd, nw; // staged entries / words
+};
+
+template <bool WITH_QUAL>
+struct TileLds {
+  TCol col[NCOL];
+  uint2 bm[NCOL * BMW];
+  uint4 md[NCOL * MDS];
+  uint64_t words[NCOL * WW];
+  uint32_t quals[WITH_QUAL ? NCOL * QB / 4 : 1];
+};
+
+template <bool WITH_QUAL>
+__device__ __forceinline__ void stage_tile(const JobDev& J, const uint32_t* ow_list, uint32_t ng, uint32_t p_lo,
+                                           uint32_t p_hi, TileLds<WITH_QUAL>& S) {
+  if (threadIdx.x < ng) {
+    TCol t;
+    t.ow = ow_list[threadIdx.x];
+    t.fb = 0; t.w0 = 0; t.r0 = 0; t.word0 = 0; t.qg0 = 0; t.nmd = 0; t.nw = 0;
+    if (t.ow != 0xffffffffu) {
+      t.h = J.chdr[t.ow];
+      const int32_t ulo = max((int32_t)p_lo - t.h.off, 0);
+      const int32_t uhi = min((int32_t)p_hi - t.h.off, (int32_t)t.h.t_total - 1);
+      if (ulo > uhi) {
+        t.h.t_total = 0;  // the tile lies outside the overlap: every cell is '.'
+      } else {
+        const uint2* bm = J.bm + (uint64_t)t.ow * J.n_bw;
+        const uint2 blo = bm[ulo >> 5], bhi = bm[uhi >> 5];
+        const uint32_t rlo = blo.y + __popc(blo.x & (0xffffffffu >> (31 - (ulo & 31))));
+        const uint32_t rhi = bhi.y + __popc(bhi.x & (0xffffffffu >> (31 - (uhi & 31))));
+        t.w0 = (uint32_t)ulo >> 5;
+        t.r0 = rlo - 1;
+        t.nmd = rhi - rlo + 1;
+        const uint4 e0 = J.md[t.h.md_off + rlo - 1], e1 = J.md[t.h.md_off + rhi - 1];
+        // query stretch [q0, q1) the tile can touch, as stored indices [s0, s1]
+        const uint32_t q0 = e0.y, q1 = e1.y + ((e1.z >> 31) ? (e1.z & 0x7fffffffu) : 0u) + e1.w + 1u;
+        const int32_t sa = t.h.sbase + t.h.sdir * (int32_t)q0, sb = t.h.sbase + t.h.sdir * (int32_t)(q1 - 1u);
+        const uint32_t s0 = (uint32_t)max(min(sa, sb), 0), s1 = (uint32_t)max(sa, sb);
+        t.word0 = s0 >> 5;
+        t.nw = (s1 >> 5) - t.word0 + 1;
+        // quality bytes are copied as aligned dwords of the global array
+        t.qg0 = (t.h.qual_off + s0) & ~3ull;
+        const uint64_t g1 = t.h.qual_off + s1;
+        if (t.nmd > MDS || t.nw > WW || (WITH_QUAL && g1 - t.qg0 >= QB)) t.fb = 1;
       }
     }
-    if (pass == 0) {
-      // '*' target rows (insertion rows) are never tallied (features.rs:489-491)
-      sup = valid && t != TOK_GAP_F && supported_from_counts(cnt, thresh);
-      if (!__syncthreads_or(sup)) break;
+    S.col[threadIdx.x] = t;
+  }
+  __syncthreads();
+  for (uint32_t idx = threadIdx.x; idx < ng * BMW; idx += NT) {
+    const uint32_t c = idx / BMW, i = idx % BMW;
+    const TCol& t = S.col[c];
+    uint2 v = make_uint2(0, 0);
+    if (t.ow != 0xffffffffu && t.h.t_total && t.w0 + i < J.n_bw) v = J.bm[(uint64_t)t.ow * J.n_bw + t.w0 + i];
+    S.bm[idx] = v;
+  }
+  for (uint32_t idx = threadIdx.x; idx < ng * MDS; idx += NT) {
+    const uint32_t c = idx / MDS, i = idx % MDS;
+    const TCol& t = S.col[c];
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (t.ow != 0xffffffffu && t.h.t_total && i < t.nmd && !t.fb) v = J.md[t.h.md_off + t.r0 + i];
+    S.md[idx] = v;
+  }
+  for (uint32_t idx = threadIdx.x; idx < ng * WW; idx += NT) {
+    const uint32_t c = idx / WW, i = idx % WW;
+    const TCol& t = S.col[c];
+    uint64_t v = 0;
+    if (t.ow != 0xffffffffu && t.h.t_total && i < t.nw && !t.fb) v = J.read_words[t.h.q_woff + t.word0 + i];
+    S.words[idx] = v;
+  }
+  if (WITH_QUAL) {
+    for (uint32_t idx = threadIdx.x; idx < ng * (QB / 4); idx += NT) {
+      const uint32_t c = idx / (QB / 4), i = idx % (QB / 4);
+      const TCol& t = S.col[c];
+      uint32_t v = 0;
+      if (t.ow != 0xffffffffu && t.h.t_total && !t.fb) {
+        const uint64_t g = t.qg0 + 4ull * i;  // the allocation carries 8 pad bytes
+        if (g < J.read_qual_bytes) v = *reinterpret_cast<const uint32_t*>(J.read_qual + g);
+      }
+      S.quals[idx] = v;
     }
   }
+  __syncthreads();
+}
+
+// cell of staged column c at window position p / insertion ordinal j — LDS only (see column_cell)
+template <bool WITH_QUAL>
+__device__ __forceinline__ CellOut staged_cell(const JobDev& J, const TileLds<WITH_QUAL>& S, uint32_t c, int32_t p,
+                                               uint32_t j) {
+  const TCol& t = S.col[c];
+  if (t.fb) return column_cell<WITH_QUAL>(J, t.h, t.ow, p, j);  // wave-uniform, rare
+  const uint32_t uu_raw = (uint32_t)(p - t.h.off);
+  const bool inr = uu_raw < t.h.t_total;
+  const uint32_t uu = inr ? uu_raw : (t.w0 << 5);
+  const uint2 bw = S.bm[c * BMW + ((uu >> 5) - t.w0)];
+  const uint32_t rank = bw.y + __popc(bw.x & (0xffffffffu >> (31u - (uu & 31u))));
+  const uint4 e = S.md[c * MDS + (inr ? rank - 1u - t.r0 : 0u)];
+  const bool is_m = (e.z >> 31) != 0;
+  const uint32_t len = e.z & 0x7fffffffu;
+  const bool last = (uu + 1u == e.x + len);
+  const bool isbase = inr && (j == 0 ? is_m : (last && e.w >= j));
+  const uint32_t q = j == 0 ? e.y + (uu - e.x) : e.y + (is_m ? len : 0u) + (j - 1u);
+  const uint32_t si = isbase ? (uint32_t)(t.h.sbase + t.h.sdir * (int32_t)q) : (t.word0 << 5);
+  const uint64_t word = S.words[c * WW + ((si >> 5) - t.word0)];
+  CellOut out;
+  out.qual = 33;
+  if (WITH_QUAL) {
+    const uint32_t bi = isbase ? (uint32_t)(t.h.qual_off + si - t.qg0) : 0u;
+    const uint32_t qv = (S.quals[c * (QB / 4) + (bi >> 2)] >> ((bi & 3u) << 3)) & 0xffu;
+    out.qual = isbase ? qv : 33u;
+  }
+  const uint32_t code = (uint32_t)(word >> ((si & 31u) << 1)) & 3u;
+  const uint32_t base_tok = t.h.strand ? 5u + (code ^ 3u) : code;
+  const uint32_t gap_tok = t.h.strand ? (uint32_t)TOK_GAP_R : (uint32_t)TOK_GAP_F;
+  out.tok = !inr ? (uint32_t)TOK_NONE : (isbase ? base_tok : gap_tok);
+  return out;
 }
 
 // =====================================================================================================
@@ -567,47 +809,64 @@ __global__ __launch_bounds__(NT) void k_select_layout(JobDev J) {
 // k_final_tiles — one workgroup per 256 final rows
 // =====================================================================================================
 __global__ __launch_bounds__(NT) void k_final_tiles(JobDev J) {
-  __shared__ TileLds S;
+  __shared__ TileLds<true> S;
   const uint32_t w = J.tile_win[blockIdx.x], r0 = J.tile_r0[blockIdx.x];
   const uint32_t Lf = J.win_Lf[w];
   if (r0 >= Lf) return;
   const WinDesc wd = J.win[w];
   const uint32_t* rowmap = J.rowmap2 + wd.row_off;
   const uint32_t p_lo = rowmap[r0] & 0xffffu, p_hi = rowmap[min(r0 + NT, Lf) - 1] & 0xffffu;
-  stage_group(J, wd, J.sel_ow + (uint64_t)w * 32 + 1, HERRO_ROWS - 1, p_lo, p_hi, S);
+  stage_tile<true>(J, J.sel_ow + (uint64_t)w * 32 + 1, HERRO_ROWS - 1, p_lo, p_hi, S);
   const uint32_t r = r0 + threadIdx.x;
-  if (r >= Lf) return;
-  const uint32_t rm = rowmap[r];
+  const bool valid = r < Lf;
+  const uint32_t rm = valid ? rowmap[r] : 0u;
   const int32_t p = (int32_t)(rm & 0xffffu);
   const uint32_t j = rm >> 16;
-  uint8_t* fb = J.fin_b + wd.fin_off + r;
-  uint8_t* fq = J.fin_q + wd.fin_off + r;
+  // tokens / qualities of this row's 31 cells, packed 4 per register
+  uint32_t tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ql[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t cnt = 0;
-  {
+  if (valid) {
     uint32_t t = TOK_GAP_F, q = 33;
     if (j == 0) {
       t = read_code(J.read_words, J.read_word_off[wd.rid], wd.tstart + (uint32_t)p);
       q = J.read_qual[J.read_qual_off[wd.rid] + wd.tstart + (uint32_t)p];
     }
-    fb[0] = (uint8_t)t;
-    fq[0] = (uint8_t)q;
+    tk[0] = t;
+    ql[0] = q;
     count_sym(cnt, t);
-  }
-  // fewer than 30 overlaps: untouched '.' / '!' columns (features.rs:522-525)
-  for (uint32_t c0 = 0; c0 < HERRO_ROWS - 1; c0 += NB) {
-    uint32_t tok[NB], ql[NB];
-    const uint32_t nc = min((uint32_t)NB, (uint32_t)(HERRO_ROWS - 1) - c0);
-    eval_batch<true>(J, S, c0, nc, p, j, tok, ql);
 #pragma unroll
-    for (int k = 0; k < NB; k++) {
-      if ((uint32_t)k >= nc) break;
-      fb[(uint64_t)(c0 + k + 1) * wd.lub] = (uint8_t)tok[k];
-      fq[(uint64_t)(c0 + k + 1) * wd.lub] = (uint8_t)ql[k];
-      count_sym(cnt, tok_fold(tok[k]));
+    for (uint32_t c = 1; c < HERRO_ROWS; c++) {
+      CellOut co;
+      co.tok = TOK_NONE;  // fewer than 30 overlaps: untouched '.' / '!' columns (features.rs:522-525)
+      co.qual = 33;
+      if (S.col[c - 1].ow != 0xffffffffu) co = staged_cell<true>(J, S, c - 1, p, j);
+      tk[c >> 2] |= co.tok << ((c & 3u) << 3);
+      ql[c >> 2] |= co.qual << ((c & 3u) << 3);
+      count_sym(cnt, tok_fold(co.tok));
     }
+    // informative rows of the final [L',31] matrix: thresh = (31 * 0.1) as usize = 3 (features.rs:558,712)
+    J.sup_flag[wd.row_off + r] = supported_from_counts(cnt, (uint32_t)((double)HERRO_ROWS * 0.1)) ? 1 : 0;
   }
-  // informative rows of the final [L',31] matrix: thresh = (31 * 0.1) as usize = 3 (features.rs:558,712)
-  J.sup_flag[wd.row_off + r] = supported_from_counts(cnt, (uint32_t)((double)HERRO_ROWS * 0.1)) ? 1 : 0;
+  // transpose through LDS (the staging area is dead now) so that the [31][rows] planes, whose row axis
+  // is contiguous in HBM, are written with 16-byte stores
+  __syncthreads();
+  uint8_t* tb = reinterpret_cast<uint8_t*>(&S);
+  uint8_t* tq = tb + HERRO_ROWS * TLD;
+#pragma unroll
+  for (uint32_t c = 0; c < HERRO_ROWS; c++) {
+    tb[c * TLD + threadIdx.x] = (uint8_t)(tk[c >> 2] >> ((c & 3u) << 3));
+    tq[c * TLD + threadIdx.x] = (uint8_t)(ql[c >> 2] >> ((c & 3u) << 3));
+  }
+  __syncthreads();
+  const uint32_t nseg = (min(wd.lub - r0, (uint32_t)HERRO_TILE) + 15) / 16;
+  for (uint32_t it = threadIdx.x; it < HERRO_ROWS * nseg; it += NT) {
+    const uint32_t c = it / nseg, sg = it % nseg;
+    const uint32_t* lb = reinterpret_cast<const uint32_t*>(tb + c * TLD + sg * 16);
+    const uint32_t* lq = reinterpret_cast<const uint32_t*>(tq + c * TLD + sg * 16);
+    const uint64_t go = wd.fin_off + (uint64_t)c * wd.lub + r0 + sg * 16;
+    *reinterpret_cast<uint4*>(J.fin_b + go) = make_uint4(lb[0], lb[1], lb[2], lb[3]);
+    *reinterpret_cast<uint4*>(J.fin_q + go) = make_uint4(lq[0], lq[1], lq[2], lq[3]);
+  }
 }
 
 // =====================================================================================================
@@ -643,11 +902,20 @@ void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm) {
     hipLaunchKernelGGL(k_ow_stats, dim3(J.n_ow), dim3(NT), 0, st, J);
     KT_END(tm, st);
   }
-  KT_BEGIN(tm, "win_layout", st);
-  hipLaunchKernelGGL(k_win_layout, dim3(J.n_win), dim3(NT), 0, st, J);
+  KT_BEGIN(tm, "win_rank", st);
+  hipLaunchKernelGGL(k_win_rank, dim3(J.n_win), dim3(NT), 0, st, J);
   KT_END(tm, st);
-  KT_BEGIN(tm, "pass1_tiles", st);
-  hipLaunchKernelGGL(k_pass1_tiles, dim3(J.n_tiles), dim3(NT), 0, st, J);
+  KT_BEGIN(tm, "pass1_pos", st);
+  {
+    const size_t shm = PG * sizeof(PCol) + (size_t)PG * MDCAP * 16 + (size_t)PG * J.n_bw * 8 + (size_t)PG * PWCAP * 8;
+    // counter width: enough bits for the largest threshold floor(0.1 * max(31, columns))
+    const uint32_t tmax = (uint32_t)((double)(J.max_cols > 31 ? J.max_cols : 31) * 0.1);
+    if (tmax < 4) hipLaunchKernelGGL(k_pass1_pos<2>, dim3(J.n_win), dim3(NT), shm, st, J);
+    else if (tmax < 8) hipLaunchKernelGGL(k_pass1_pos<3>, dim3(J.n_win), dim3(NT), shm, st, J);
+    else if (tmax < 16) hipLaunchKernelGGL(k_pass1_pos<4>, dim3(J.n_win), dim3(NT), shm, st, J);
+    else if (tmax < 64) hipLaunchKernelGGL(k_pass1_pos<6>, dim3(J.n_win), dim3(NT), shm, st, J);
+    else hipLaunchKernelGGL(k_pass1_pos<9>, dim3(J.n_win), dim3(NT), shm, st, J);
+  }
   KT_END(tm, st);
   KT_BEGIN(tm, "select_layout", st);
   hipLaunchKernelGGL(k_select_layout, dim3(J.n_win), dim3(NT), 0, st, J);

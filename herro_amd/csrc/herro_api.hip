@@ -50,12 +50,14 @@ struct herro_ctx {
   uint32_t n_reads = 0;
   std::vector<uint32_t> read_len, name_class;
   uint64_t* d_words = nullptr;
+  uint32_t* d_p0 = nullptr;
+  uint32_t* d_p1 = nullptr;
   uint64_t* d_word_off = nullptr;
   uint8_t* d_qual = nullptr;
   uint64_t* d_qual_off = nullptr;
   double* d_ln = nullptr;
   uint32_t ln_n = 0;
-  uint64_t read_bytes = 0;
+  uint64_t read_bytes = 0, qual_bytes = 0, n_words = 0;
   // model
   bool has_model = false;
   ModelDev M{};
@@ -85,7 +87,7 @@ struct herro_job {
   std::vector<void*> allocs;
   bool featurized = false, synced = false, inferred = false;
   // host copies after sync
-  std::vector<uint32_t> h_Lf, h_nsup, h_nkept, h_L;
+  std::vector<uint32_t> h_Lf, h_nsup, h_nkept;
   std::vector<uint64_t> sup_off;  // [n_win+1] prefix of nsup
   float* d_info = nullptr;
   float* d_base = nullptr;
@@ -141,6 +143,7 @@ void herro_destroy(herro_ctx* ctx) {
   hipDeviceSynchronize();
   ctx->timer.reset();
   hipFree(ctx->d_words); hipFree(ctx->d_word_off); hipFree(ctx->d_qual); hipFree(ctx->d_qual_off);
+  hipFree(ctx->d_p0); hipFree(ctx->d_p1);
   hipFree(ctx->d_ln);
   free_all(ctx->model_allocs);
   free_all(ctx->scratch_allocs);
@@ -199,15 +202,29 @@ static int upload_reads(herro_ctx* ctx, uint32_t n_reads, const std::vector<uint
                         const std::vector<uint64_t>& qual_off, const uint32_t* name_class) {
   hipSetDevice(ctx->device);
   hipFree(ctx->d_words); hipFree(ctx->d_word_off); hipFree(ctx->d_qual); hipFree(ctx->d_qual_off);
+  hipFree(ctx->d_p0); hipFree(ctx->d_p1); ctx->d_p0 = nullptr; ctx->d_p1 = nullptr;
   ctx->d_words = nullptr; ctx->d_word_off = nullptr; ctx->d_qual = nullptr; ctx->d_qual_off = nullptr;
   hipError_t e;
   std::vector<uint64_t> wp(words);
   wp.push_back(0);  // pad word: get16() may touch one word past a read
   ctx->d_words = dev_alloc_copy(wp, ctx->stream, e); HIP_TRY(ctx, e);
+  {  // bit-plane copy of the same bases (pass 1 counts symbols bit-sliced)
+    std::vector<uint32_t> p0(words.size() + 2, 0), p1(words.size() + 2, 0);
+    for (size_t i = 0; i < words.size(); i++) {
+      const uint64_t x = words[i];
+      uint32_t a = 0, b = 0;
+      for (int k = 0; k < 32; k++) { a |= (uint32_t)((x >> (2 * k)) & 1ull) << k; b |= (uint32_t)((x >> (2 * k + 1)) & 1ull) << k; }
+      p0[i] = a; p1[i] = b;
+    }
+    ctx->d_p0 = dev_alloc_copy(p0, ctx->stream, e); HIP_TRY(ctx, e);
+    ctx->d_p1 = dev_alloc_copy(p1, ctx->stream, e); HIP_TRY(ctx, e);
+  }
   ctx->d_word_off = dev_alloc_copy(word_off, ctx->stream, e); HIP_TRY(ctx, e);
   ctx->d_qual_off = dev_alloc_copy(qual_off, ctx->stream, e); HIP_TRY(ctx, e);
   const uint64_t nq = qual_off[n_reads];
-  HIP_TRY(ctx, hipMalloc((void**)&ctx->d_qual, std::max<uint64_t>(nq, 1)));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->d_qual, std::max<uint64_t>(nq, 1) + 8));
+  ctx->qual_bytes = nq;
+  ctx->n_words = words.size();
   if (nq) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_qual, qual, nq, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->n_reads = n_reads;
@@ -408,7 +425,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   job->W = W;
   job->n_targets = n_targets;
   job->tgt_win_off.assign(n_targets + 1, 0);
-  uint32_t n_cls = 0;
+  uint32_t n_cls = 0, max_cols = 1;
   uint64_t scr_ops = 0, fin_bytes = 0, row_elems = 0, pos_elems = 0;
   std::vector<uint32_t> aops;
   std::vector<HostOw> hows;
@@ -489,7 +506,11 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
         if (e == 0) return fail(HERRO_E_REFERENCE_PANIC, "Operation length cannot be 0");
         if (op_type(op) != OP_I) tt += e;
         if (op_type(op) != OP_D) qq += e;
-        if (op_type(op) == OP_I) ins_sum[wi] += l;
+        if (op_type(op) == OP_I) {
+          ins_sum[wi] += l;
+          if (k + 1 < d.op_cnt && op_type(job->ops[d.op_begin + k + 1]) == OP_I)
+            return fail(HERRO_E_UNSUPPORTED, "consecutive insertion ops in a CIGAR (never produced by minimap2)");
+        }
       }
       if ((uint64_t)(d.tstart - win_start) + tt > win_len) return fail(HERRO_E_REFERENCE_PANIC, "cigar slice overruns the target window");
       if (qq > d.qlen) return fail(HERRO_E_REFERENCE_PANIC, "cigar slice overruns the query region");
@@ -514,6 +535,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
       wd.pos_off = pos_elems; pos_elems += (uint64_t)W + 1;
       for (uint32_t r0 = 0; r0 < wd.lub; r0 += HERRO_TILE) { job->tile_win.push_back((uint32_t)job->win.size()); job->tile_r0.push_back(r0); }
       if (wd.ow_cnt > 4000) return fail(HERRO_E_UNSUPPORTED, "more than 4000 overlaps in one window");
+      max_cols = std::max(max_cols, wd.ow_cnt + 1);
       job->alg_read_bytes += (uint64_t)wd.win_len + (wd.win_len + 3) / 4;
       job->win.push_back(wd);
     }
@@ -524,11 +546,11 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   // ---- device allocation + upload
   const uint32_t n_ow = (uint32_t)job->ow.size(), n_win = (uint32_t)job->win.size();
   JobDev& J = job->J;
-  J.read_words = ctx->d_words; J.read_word_off = ctx->d_word_off;
-  J.read_qual = ctx->d_qual; J.read_qual_off = ctx->d_qual_off;
+  J.read_words = ctx->d_words; J.read_word_off = ctx->d_word_off; J.read_p0 = ctx->d_p0; J.read_p1 = ctx->d_p1;
+  J.read_qual = ctx->d_qual; J.read_qual_off = ctx->d_qual_off; J.read_qual_bytes = ctx->qual_bytes; J.read_n_words = ctx->n_words;
   J.ln_table = ctx->d_ln; J.ln_table_n = ctx->ln_n;
   J.n_ow = n_ow; J.n_win = n_win; J.n_cls = n_cls;
-  J.n_tiles = (uint32_t)job->tile_win.size(); J.window_size = W; J.n_ckpt = (W >> HERRO_CKPT_SHIFT) + 1;
+  J.n_tiles = (uint32_t)job->tile_win.size(); J.window_size = W; J.n_bw = W / 32 + 1; J.max_cols = max_cols;
   hipError_t e = hipSuccess;
   bool oom = false;
   auto A = [&](uint64_t bytes) -> void* {
@@ -548,15 +570,16 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.tile_win = (const uint32_t*)up(job->tile_win.data(), job->tile_win.size() * 4);
   J.tile_r0 = (const uint32_t*)up(job->tile_r0.data(), job->tile_r0.size() * 4);
   J.op_t = (uint32_t*)A(scr_ops * 4); J.op_q = (uint32_t*)A(scr_ops * 4); J.ins_ev = (uint32_t*)A(scr_ops * 4);
-  J.ins_cnt = (uint32_t*)A((uint64_t)n_ow * 4); J.ckpt = (uint32_t*)A((uint64_t)n_ow * J.n_ckpt * 4);
+  J.ins_cnt = (uint32_t*)A((uint64_t)n_ow * 4);
+  J.md = (uint4*)A(scr_ops * 16); J.bm = (uint2*)A((uint64_t)n_ow * J.n_bw * 8); J.chdr = (ColHdr*)A((uint64_t)n_ow * sizeof(ColHdr));
   J.ow_keep = (uint8_t*)A(n_ow); J.ow_acc = (float*)A((uint64_t)n_ow * 4);
   J.ow_ttotal = (uint32_t*)A((uint64_t)n_ow * 4);
   J.slot_ow = (uint32_t*)A((uint64_t)n_ow * 4); J.rank_qid = (uint32_t*)A((uint64_t)n_ow * 4);
   J.sel_ow = (uint32_t*)A((uint64_t)n_win * 32 * 4);
-  J.win_L = (uint32_t*)A((uint64_t)n_win * 4); J.win_nkept = (uint32_t*)A((uint64_t)n_win * 4);
+  J.win_nkept = (uint32_t*)A((uint64_t)n_win * 4);
   J.win_Lf = (uint32_t*)A((uint64_t)n_win * 4); J.win_nsup = (uint32_t*)A((uint64_t)n_win * 4);
-  J.row_of_pos = (uint32_t*)A(pos_elems * 4); J.row_of_pos2 = (uint32_t*)A(pos_elems * 4);
-  J.rowmap = (uint32_t*)A(row_elems * 4); J.rowmap2 = (uint32_t*)A(row_elems * 4);
+  J.row_of_pos2 = (uint32_t*)A(pos_elems * 4);
+  J.rowmap2 = (uint32_t*)A(row_elems * 4);
   J.sup_flag = (uint8_t*)A(row_elems);
   J.sup_row = (uint32_t*)A(row_elems * 4); J.sup_pi = (uint32_t*)A(row_elems * 4);
   J.fin_b = (uint8_t*)A(fin_bytes); J.fin_q = (uint8_t*)A(fin_bytes);
@@ -604,12 +627,11 @@ static int job_sync(herro_job* job) {
   if (job->synced) return HERRO_OK;
   hipSetDevice(ctx->device);
   const uint32_t n = job->J.n_win;
-  job->h_Lf.resize(n); job->h_nsup.resize(n); job->h_nkept.resize(n); job->h_L.resize(n);
+  job->h_Lf.resize(n); job->h_nsup.resize(n); job->h_nkept.resize(n);
   if (n) {
     HIP_TRY(ctx, hipMemcpyAsync(job->h_Lf.data(), job->J.win_Lf, n * 4ull, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(job->h_nsup.data(), job->J.win_nsup, n * 4ull, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(job->h_nkept.data(), job->J.win_nkept, n * 4ull, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(job->h_L.data(), job->J.win_L, n * 4ull, hipMemcpyDeviceToHost, ctx->stream));
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->timer.collect();

@@ -13,20 +13,36 @@
 #define HERRO_ROWS 31
 #define HERRO_MAX_WINDOW 8192
 #define HERRO_TILE 256        // pileup rows per workgroup in the tile kernels
-#define HERRO_CKPT_SHIFT 7    // op checkpoints every 128 target positions
 
 namespace herro {
+
+// Per overlap-window column header, read through scalar loads by the tile kernels.
+struct __attribute__((aligned(16))) ColHdr {
+  int32_t off;        // window-relative position where the overlap starts
+  uint32_t t_total;   // target bases the slice consumes
+  uint32_t strand, cls;
+  int32_t sbase, sdir;  // stored index of alignment-orientation query base q = sbase + sdir*q
+  uint32_t md_off;    // first entry of the overlap's M/D op table
+  uint32_t n_md;      // entries in it
+  uint64_t q_woff;    // first 2-bit word of the query read
+  uint64_t qual_off;  // first quality byte of the query read
+};
 
 struct JobDev {
   // ---- read store (context-owned; HBM-resident for the life of the context)
   const uint64_t* read_words;     // 2-bit packed bases, every read starts on a u64 boundary (+1 pad word)
+  const uint32_t* read_p0;        // the same bases as bit planes: bit i of word k = low code bit of base 32k+i
+  const uint32_t* read_p1;        // ... high code bit (A0 C1 G2 T3); indexed like read_words, +2 pad words
   const uint64_t* read_word_off;  // [n_reads+1]
   const uint8_t* read_qual;       // phred+33 bytes
   const uint64_t* read_qual_off;  // [n_reads+1]
+  uint64_t read_qual_bytes;       // size of read_qual
+  uint64_t read_n_words;          // u64 words in read_words (planes hold as many u32 words + 2)
   const double* ln_table;         // ln(k+1) computed on the host with glibc (bit-faithful to Rust std)
   uint32_t ln_table_n;
   // ---- descriptors (uploaded by herro_job_create)
-  uint32_t n_ow, n_win, n_cls, n_tiles, window_size, n_ckpt;
+  uint32_t n_ow, n_win, n_cls, n_tiles, window_size, n_bw;
+  uint32_t max_cols;  // 1 + max overlaps per window (sizes the bit-sliced counters)
   const uint32_t* ops;
   const OwDesc* ow;
   const WinDesc* win;
@@ -37,20 +53,19 @@ struct JobDev {
   uint32_t* op_q;        // ... query bases consumed before the op
   uint32_t* ins_ev;      // per overlap (at scr_off): insertion events, window-relative pos | len << 16
   uint32_t* ins_cnt;     // [ow] number of insertion events
-  uint32_t* ckpt;        // [ow * n_ckpt + c] op covering target-relative position c << CKPT_SHIFT
+  uint4* md;             // per overlap (at scr_off): M/D ops {t_beg, q_beg, len | isM<<31, following ins len}
+  uint2* bm;             // [ow * n_bw + i] {bitmap of M/D op starts for positions 32i.., ops before 32i}
+  ColHdr* chdr;          // [ow]
   uint8_t* ow_keep;      // long-indel filter verdict
   float* ow_acc;         // accuracy
   uint32_t* ow_ttotal;   // target bases consumed by the slice
   uint32_t* slot_ow;     // [win.ow_begin + slot] -> overlap index, slots ordered by accuracy rank
   uint32_t* sel_ow;      // [win * 32 + c], c in [1,31): overlap feeding final row c (0xffffffff: padding)
-  uint32_t* win_L;       // rows of the pass-1 matrix
   uint32_t* win_nkept;
   uint32_t* win_Lf;      // rows of the final matrix (L')
   uint32_t* win_nsup;
-  uint32_t* row_of_pos;  // [win.pos_off + p], p in [0, win_len]   (pass-1 layout)
-  uint32_t* rowmap;      // [win.row_off + row] = pos | ins << 16   (pass-1 layout)
-  uint32_t* row_of_pos2; // final layout
-  uint32_t* rowmap2;     // final layout
+  uint32_t* row_of_pos2; // [win.pos_off + p], p in [0, win_len]: final row of each target position
+  uint32_t* rowmap2;     // [win.row_off + row] = pos | ins << 16
   uint8_t* sup_flag;     // [win.row_off + final row] informative?
   uint32_t* sup_row;     // [win.row_off + k]   final row of informative position k
   uint32_t* sup_pi;      // [win.row_off + k]   pos | ins << 16
