@@ -155,10 +155,42 @@ def main():
         feat_names = ["ow_stats", "win_rank", "pass1_pos", "select_layout", "final_tiles", "sup_compact"]
         feat_ms = sum(tm[k][0] for k in feat_names if k in tm) / args.steps
         model_ms = sum(v[0] for k, v in tm.items() if k not in feat_names) / args.steps
-        alg_bytes = (st["read_bytes"] + st["op_bytes"] + st["out_bytes"]) / G   # per 128-window step (SURVEY §8 d, measured)
-        dom = max(tm, key=lambda k: tm[k][0])
+        # ---- algorithmic work per launch (one launch = G steps = G*batch windows); DESIGN.md §4/§5
+        per_job = {k: float(v) for k, v in st.items()}
+        n_cols = 1 + n_ovl
+        tokens = per_job["sum_supported"]
+        D, FF, C1, C2, KW = 256, 1024, 64, 128, 3
+        feat_bytes = per_job["read_bytes"] + per_job["op_bytes"] + per_job["out_bytes"]        # SURVEY §8 d
+        alg = {  # name -> (bound, work per launch, unit)
+            "final_tiles": ("hbm", per_job["out_bytes"] + per_job["read_bytes"] * 31.0 / n_cols, "B"),
+            "ow_stats": ("hbm", per_job["read_bytes"] / 5.0 + per_job["op_bytes"], "B"),          # 2-bit only
+            "pass1_pos": ("hbm", per_job["read_bytes"] / 5.0, "B"),
+            "patch_conv1": ("hbm", tokens * 31 * KW * C1 * 4, "B"),                               # y1 hi/lo written
+            "conv2_gemm": ("mfma", 2.0 * tokens * 31 * (KW * C1) * C2, "F"),
+            "fc_gemm": ("mfma", 2.0 * tokens * (31 * C2) * D, "F"),
+            "qkv_gemm": ("mfma", 2.0 * tokens * D * 3 * D, "F"),
+            "proj_gemm": ("mfma", 2.0 * tokens * D * D, "F"),
+            "ff1_gemm": ("mfma", 2.0 * tokens * D * FF, "F"),
+            "ff2_gemm": ("mfma", 2.0 * tokens * FF * D, "F"),
+        }
+        dom = max((k for k in tm if k in alg), key=lambda k: tm[k][0])
         dom_avg_s = tm[dom][0] / max(tm[dom][1], 1) * 1e-3
-        # algorithmic bytes of each featurisation kernel per launch
+        bound, work, _ = alg[dom]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")     # written by tools/pmc_traffic.py from a --pmc run
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if dom in tj.get("kernels", {}) and tj.get("group") == G:
+                traffic = tj["kernels"][dom]["hbm_bytes_corrected"]
+        if bound == "hbm":
+            roof = {"kernel": dom, "bound": "hbm", "achieved": work / dom_avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": work / dom_avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": work, "launch_us": dom_avg_s * 1e6, "windows_per_launch": G * args.batch}
+        else:
+            roof = {"kernel": dom, "bound": "mfma", "achieved": work / dom_avg_s / 1e12, "peak": MFMA_BF16_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": work / dom_avg_s / 1e12 / MFMA_BF16_PEAK_TF, "traffic": traffic,
+                    "algorithmic_flops_per_launch": work, "launch_us": dom_avg_s * 1e6,
+                    "note": "algorithmic 2MNK flops; the bf16x3 split issues 3x that many MFMA flops"}
         out = {
             "metric": "4096-bp windows corrected/sec at batch=128",
             "value": total_windows / el,
@@ -177,18 +209,11 @@ def main():
                        "mean_len": st["sum_len"] / (G * args.batch), "mean_informative": st["sum_supported"] / (G * args.batch),
                        "model_windows_per_batch": st["n_model_windows"] / G, "batches_per_launch_group": G},
             "mbases_per_s": total_windows / el * W / 1e6,
-            "roofline": {
-                "kernel": "featurize (ow_stats+win_rank+pass1_pos+select_layout+final_tiles+sup_compact)",
-                "bound": "hbm",
-                "achieved": alg_bytes / (feat_ms * 1e-3) / 1e9,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": alg_bytes / (feat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "traffic": None,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "launch_ms": feat_ms,
-            },
-            "dominant_kernel": {"name": dom, "avg_us": dom_avg_s * 1e6},
+            "roofline": roof,
+            "roofline_featurize_group": {
+                "kernels": feat_names, "bound": "hbm", "achieved": feat_bytes / G / (feat_ms * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": feat_bytes / G / (feat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_step": feat_bytes / G, "ms_per_step": feat_ms},
             "stage_ms_per_step": {"featurize": feat_ms, "model": model_ms},
             "kernels": kern,
         }

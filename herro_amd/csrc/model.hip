@@ -385,10 +385,357 @@ void launch_transpose_blr(const uint8_t* src, uint8_t* dst, uint32_t B, uint32_t
   hipLaunchKernelGGL(k_transpose_blr, dim3((L + 255) / 256, B), dim3(256), 0, st, src, dst, L);
 }
 
+
+// ===================================================================================================
+// bf16x3 pipeline (precision 1)
+// ===================================================================================================
+__device__ __forceinline__ void split_store(uint16_t* hi, uint16_t* lo, uint64_t idx, float v) {
+  const uint16_t h = f32_to_bf16_rne(v);
+  hi[idx] = h;
+  lo[idx] = f32_to_bf16_rne(v - bf16_to_f32(h));
+}
+
+// conv1 on the receptive fields of TOKB tokens per workgroup (tables loaded once), output pre-split.
+static constexpr int TOKB = 8;
+__global__ __launch_bounds__(256) void k_patch_conv1_s(ModelDev M, BatchDev B, ModelScratch S, uint32_t n_tok) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t kw = M.h.kw, c1 = M.h.c1, h = kw / 2, P = 4 * h + 1;
+  float* s_t1 = reinterpret_cast<float*>(smem);  // [kw][12][c1]
+  float* s_wq = s_t1 + kw * 12 * c1;              // [kw][c1]
+  float* s_b1 = s_wq + kw * c1;                   // [c1]
+  float* s_qn = s_b1 + c1;                        // [31][P]
+  uint32_t* s_tok = reinterpret_cast<uint32_t*>(s_qn + HERRO_ROWS * P);  // [31][P], 255 = outside
+  for (uint32_t e = threadIdx.x; e < kw * 12 * c1; e += blockDim.x) s_t1[e] = M.t1[e];
+  for (uint32_t e = threadIdx.x; e < kw * c1; e += blockDim.x) s_wq[e] = M.wq1[e];
+  for (uint32_t e = threadIdx.x; e < c1; e += blockDim.x) s_b1[e] = M.b1[e];
+  const uint32_t total = HERRO_ROWS * kw * c1;
+  for (uint32_t tk = 0; tk < TOKB; tk++) {
+    const uint32_t n = blockIdx.x * TOKB + tk;
+    if (n >= n_tok) break;
+    const uint32_t b = S.tok_win[n];
+    const int32_t l = (int32_t)S.tok_row[n];
+    const int32_t len = (int32_t)B.len[b], lmax = (int32_t)B.lmax[b];
+    const uint8_t* pb = B.planes_b + B.plane_off[b];
+    const uint8_t* pq = B.planes_q + B.plane_off[b];
+    const uint32_t ld = B.plane_ld[b];
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < HERRO_ROWS * P; e += blockDim.x) {
+      const uint32_t r = e / P;
+      const int32_t q = l - 2 * (int32_t)h + (int32_t)(e % P);
+      uint32_t tok = 255u;
+      float qn = 0.f;
+      if (q >= 0 && q < lmax) {
+        if (q < len) {
+          tok = pb[(uint64_t)r * ld + q];
+          qn = norm_qual(pq[(uint64_t)r * ld + q]);
+        } else {  // batch padding (inference.rs:86-97)
+          tok = TOK_PAD;
+          qn = norm_qual(126u);
+        }
+      }
+      s_tok[e] = tok;
+      s_qn[e] = qn;
+    }
+    __syncthreads();
+    const uint64_t ob = (uint64_t)n * total;
+    for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
+      const uint32_t c = e % c1, dl = (e / c1) % kw, r = e / (c1 * kw);
+      const int32_t pos = l + (int32_t)dl - (int32_t)h;
+      float v = 0.f;
+      if (pos >= 0 && pos < lmax) {  // outside: conv2's zero padding
+        v = s_b1[c];
+        for (uint32_t t = 0; t < kw; t++) {
+          const uint32_t pi = dl + t;
+          const uint32_t tok = s_tok[r * P + pi];
+          if (tok != 255u) v += s_t1[(t * 12 + tok) * c1 + c] + s_wq[t * c1 + c] * s_qn[r * P + pi];
+        }
+        v = fmaxf(v, 0.f);
+      }
+      split_store(S.y1_hi, S.y1_lo, ob + e, v);
+    }
+  }
+}
+
+// C[M,N] = epi(A . W^T + bias) (+R) with A given as bf16 hi/lo planes and W as [N][K] hi/lo planes.
+// 128x64 tile per workgroup, 4 waves (wave w: rows 32w..32w+31 x all 64 columns = 2x4 MFMA tiles),
+// BK = 32, next k-tile prefetched into registers while the current one is consumed from LDS.
+// 3 MFMAs per k-step and tile: al*bh + ah*bl + ah*bh.
+static constexpr int GM = 128, GN = 64;
+template <bool OUT_SPLIT>
+__global__ __launch_bounds__(256) void k_gemm_s(const uint16_t* __restrict__ Ahi, const uint16_t* __restrict__ Alo,
+                                                uint32_t lda, Weight W, float* C, uint16_t* Chi, uint16_t* Clo,
+                                                uint32_t ldc, const float* R, uint32_t M, int relu) {
+  __shared__ __attribute__((aligned(16))) uint16_t s_ah[GM * LDH], s_al[GM * LDH], s_bh[GN * LDH], s_bl[GN * LDH];
+  const uint32_t K = W.K, N = W.N;
+  const uint32_t m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const uint32_t arow0 = tid >> 2, ac8 = (tid & 3) * 8;  // A rows arow0 and arow0+64; B row arow0
+  uint4 ra_h[2], ra_l[2], rb_h, rb_l;
+  auto gload = [&](uint32_t k0) {
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      const uint32_t row = arow0 + it * 64;
+      ra_h[it] = make_uint4(0, 0, 0, 0);
+      ra_l[it] = make_uint4(0, 0, 0, 0);
+      if (m0 + row < M) {
+        const uint64_t o = (uint64_t)(m0 + row) * lda + k0 + ac8;
+        ra_h[it] = *reinterpret_cast<const uint4*>(Ahi + o);
+        ra_l[it] = *reinterpret_cast<const uint4*>(Alo + o);
+      }
+    }
+    rb_h = make_uint4(0, 0, 0, 0);
+    rb_l = make_uint4(0, 0, 0, 0);
+    if (n0 + arow0 < N) {
+      const uint64_t o = (uint64_t)(n0 + arow0) * K + k0 + ac8;
+      rb_h = *reinterpret_cast<const uint4*>(W.hi + o);
+      rb_l = *reinterpret_cast<const uint4*>(W.lo + o);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      const uint32_t row = arow0 + it * 64;
+      *reinterpret_cast<uint4*>(s_ah + row * LDH + ac8) = ra_h[it];
+      *reinterpret_cast<uint4*>(s_al + row * LDH + ac8) = ra_l[it];
+    }
+    *reinterpret_cast<uint4*>(s_bh + arow0 * LDH + ac8) = rb_h;
+    *reinterpret_cast<uint4*>(s_bl + arow0 * LDH + ac8) = rb_l;
+  };
+
+  gload(0);
+  lstore();
+  __syncthreads();
+  const uint32_t fr = lane & 15, fk = (lane >> 4) * 8;
+  for (uint32_t k0 = 0; k0 < K; k0 += BK) {
+    const bool more = k0 + BK < K;
+    if (more) gload(k0 + BK);
+    bf16x8 ah[2], al[2], bh[4], bl[4];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      ah[i] = *reinterpret_cast<const bf16x8*>(s_ah + (wave * 32 + i * 16 + fr) * LDH + fk);
+      al[i] = *reinterpret_cast<const bf16x8*>(s_al + (wave * 32 + i * 16 + fr) * LDH + fk);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      bh[j] = *reinterpret_cast<const bf16x8*>(s_bh + (j * 16 + fr) * LDH + fk);
+      bl[j] = *reinterpret_cast<const bf16x8*>(s_bl + (j * 16 + fr) * LDH + fk);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+    __syncthreads();
+    if (more) {
+      lstore();
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t n = n0 + j * 16 + (lane & 15);
+      const float bias = (W.bias && n < N) ? W.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t m = m0 + wave * 32 + i * 16 + (lane >> 4) * 4 + r;
+        if (m < M && n < N) {
+          float v = acc[i][j][r] + bias;
+          if (relu) v = fmaxf(v, 0.f);
+          const uint64_t o = (uint64_t)m * ldc + n;
+          if (OUT_SPLIT) {
+            split_store(Chi, Clo, o, v);
+          } else {
+            if (R) v += R[o];
+            C[o] = v;
+          }
+        }
+      }
+    }
+}
+
+
+static void gemm_s(const uint16_t* Ahi, const uint16_t* Alo, uint32_t lda, const Weight& W, float* C, uint16_t* Chi,
+                   uint16_t* Clo, uint32_t ldc, const float* R, uint32_t M, int relu, hipStream_t st) {
+  if (M == 0) return;
+  dim3 grid((W.N + GN - 1) / GN, (M + GM - 1) / GM);
+  if (Chi) hipLaunchKernelGGL(k_gemm_s<true>, grid, dim3(256), 0, st, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu);
+  else hipLaunchKernelGGL(k_gemm_s<false>, grid, dim3(256), 0, st, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu);
+}
+
+// LayerNorm, one wave per row, output pre-split
+__global__ __launch_bounds__(256) void k_layernorm_s(const float* x, uint16_t* yh, uint16_t* yl, const float* g,
+                                                     const float* b, uint32_t n_rows, uint32_t D, float eps) {
+  const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n_rows) return;
+  const float* xr = x + (uint64_t)row * D;
+  float s = 0.f;
+  for (uint32_t i = lane; i < D; i += 64) s += xr[i];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+  const float mean = s / (float)D;
+  float v = 0.f;
+  for (uint32_t i = lane; i < D; i += 64) {
+    const float t = xr[i] - mean;
+    v += t * t;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  const float rstd = 1.0f / sqrtf(v / (float)D + eps);
+  for (uint32_t i = lane; i < D; i += 64) split_store(yh, yl, (uint64_t)row * D + i, (xr[i] - mean) * rstd * g[i] + b[i]);
+}
+
+// Attention inside one window, all heads in one workgroup: 16 lanes per head, a lane owns one query
+// at a time (the window's informative positions are the sequence; typically 10-30 tokens).  K and V
+// rows are staged through LDS in chunks of KC keys with coalesced 16-byte loads; reads are broadcast
+// within a head's 16 lanes.  Softmax is kept online in registers across chunks.  Output pre-split.
+static constexpr int KC = 32;
+template <int DH>
+__global__ __launch_bounds__(128) void k_attention_s(BatchDev B, ModelScratch S, uint32_t D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* s_k = reinterpret_cast<float*>(smem);  // [KC][D]
+  float* s_v = s_k + KC * D;                     // [KC][D]
+  const uint32_t b = blockIdx.x, hd = threadIdx.x >> 4, ql = threadIdx.x & 15;
+  const uint32_t t0 = B.tok_off[b], len = B.tok_off[b + 1] - t0;
+  const float scale = 1.0f / sqrtf((float)DH);
+  for (uint32_t i0 = 0; i0 < len; i0 += 16) {  // block-uniform trip count (barriers inside)
+    const uint32_t i = i0 + ql;
+    const bool act = i < len;
+    float qr[DH], o[DH];
+    if (act) {
+      const float4* q4 = reinterpret_cast<const float4*>(S.qkv + (uint64_t)(t0 + i) * 3 * D + hd * DH);
+#pragma unroll
+      for (int d = 0; d < DH / 4; d++) {
+        const float4 v = q4[d];
+        qr[4 * d] = v.x * scale; qr[4 * d + 1] = v.y * scale; qr[4 * d + 2] = v.z * scale; qr[4 * d + 3] = v.w * scale;
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < DH; d++) o[d] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    for (uint32_t j0 = 0; j0 < len; j0 += KC) {
+      const uint32_t nk = min((uint32_t)KC, len - j0);
+      __syncthreads();
+      for (uint32_t e = threadIdx.x; e < nk * (D / 4); e += blockDim.x) {
+        const uint32_t jr = e / (D / 4), c4 = e % (D / 4);
+        const float4* src = reinterpret_cast<const float4*>(S.qkv + (uint64_t)(t0 + j0 + jr) * 3 * D + D);
+        reinterpret_cast<float4*>(s_k)[jr * (D / 4) + c4] = src[c4];
+        reinterpret_cast<float4*>(s_v)[jr * (D / 4) + c4] = src[D / 4 + c4];
+      }
+      __syncthreads();
+      if (act) {
+        for (uint32_t j = 0; j < nk; j++) {
+          const float4* k4 = reinterpret_cast<const float4*>(s_k + j * D + hd * DH);
+          const float4* v4 = reinterpret_cast<const float4*>(s_v + j * D + hd * DH);
+          float sc = 0.f;
+#pragma unroll
+          for (int d = 0; d < DH / 4; d++) {
+            const float4 kv = k4[d];
+            sc = fmaf(qr[4 * d], kv.x, sc); sc = fmaf(qr[4 * d + 1], kv.y, sc);
+            sc = fmaf(qr[4 * d + 2], kv.z, sc); sc = fmaf(qr[4 * d + 3], kv.w, sc);
+          }
+          const float mn = fmaxf(m, sc);
+          const float alpha = expf(m - mn), pw = expf(sc - mn);
+          l = l * alpha + pw;
+#pragma unroll
+          for (int d = 0; d < DH / 4; d++) {
+            const float4 vv = v4[d];
+            o[4 * d] = o[4 * d] * alpha + pw * vv.x; o[4 * d + 1] = o[4 * d + 1] * alpha + pw * vv.y;
+            o[4 * d + 2] = o[4 * d + 2] * alpha + pw * vv.z; o[4 * d + 3] = o[4 * d + 3] * alpha + pw * vv.w;
+          }
+          m = mn;
+        }
+      }
+    }
+    if (act) {
+      const float inv = 1.0f / l;
+      const uint64_t ob = (uint64_t)(t0 + i) * D + hd * DH;
+#pragma unroll
+      for (int d = 0; d < DH; d++) split_store(S.att_hi, S.att_lo, ob + d, o[d] * inv);
+    }
+  }
+}
+
+static void launch_model_s(const ModelDev& M, const BatchDev& B, const ModelScratch& S, hipStream_t st, KernelTimer* tm) {
+  const uint32_t N = B.n_tok;
+  const ModelHyper& h = M.h;
+  const uint32_t D = h.d_model;
+  KT_BEGIN(tm, "build_tokens", st);
+  hipLaunchKernelGGL(k_build_tokens, dim3(B.n_win), dim3(64), 0, st, B, S);
+  KT_END(tm, st);
+  const uint32_t P = 4 * (h.kw / 2) + 1;
+  {
+    const size_t shm = (size_t)(h.kw * 12 * h.c1 + h.kw * h.c1 + h.c1 + HERRO_ROWS * P) * 4 + (size_t)HERRO_ROWS * P * 4;
+    KT_BEGIN(tm, "patch_conv1", st);
+    hipLaunchKernelGGL(k_patch_conv1_s, dim3((N + TOKB - 1) / TOKB), dim3(256), shm, st, M, B, S, N);
+    KT_END(tm, st);
+    KT_BEGIN(tm, "conv2_gemm", st);
+    gemm_s(S.y1_hi, S.y1_lo, h.kw * h.c1, M.conv2, nullptr, S.y2_hi, S.y2_lo, h.c2, nullptr, N * HERRO_ROWS, 1, st);
+    KT_END(tm, st);
+  }
+  KT_BEGIN(tm, "fc_gemm", st);
+  gemm_s(S.y2_hi, S.y2_lo, HERRO_ROWS * h.c2, M.fc, S.x, nullptr, nullptr, D, nullptr, N, 0, st);
+  KT_END(tm, st);
+  KT_BEGIN(tm, "add_pe", st);
+  {
+    const uint64_t tot = (uint64_t)N * (D / 2);
+    hipLaunchKernelGGL(k_add_pe, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, st, M, S, N);
+  }
+  KT_END(tm, st);
+  const dim3 ln_grid((N + 3) / 4);
+  for (uint32_t li = 0; li < h.n_layers; li++) {
+    const LayerW& L = M.layer[li];
+    KT_BEGIN(tm, "layernorm", st);
+    hipLaunchKernelGGL(k_layernorm_s, ln_grid, dim3(256), 0, st, S.x, S.h_hi, S.h_lo, L.ln1_g, L.ln1_b, N, D, h.ln_eps);
+    KT_END(tm, st);
+    KT_BEGIN(tm, "qkv_gemm", st);
+    gemm_s(S.h_hi, S.h_lo, D, L.qkv, S.qkv, nullptr, nullptr, 3 * D, nullptr, N, 0, st);
+    KT_END(tm, st);
+    KT_BEGIN(tm, "attention", st);
+    hipLaunchKernelGGL(k_attention_s<32>, dim3(B.n_win), dim3(16 * h.n_heads), (size_t)2 * KC * D * 4, st, B, S, D);
+    KT_END(tm, st);
+    KT_BEGIN(tm, "proj_gemm", st);
+    gemm_s(S.att_hi, S.att_lo, D, L.proj, S.x, nullptr, nullptr, D, S.x, N, 0, st);
+    KT_END(tm, st);
+    KT_BEGIN(tm, "layernorm", st);
+    hipLaunchKernelGGL(k_layernorm_s, ln_grid, dim3(256), 0, st, S.x, S.h_hi, S.h_lo, L.ln2_g, L.ln2_b, N, D, h.ln_eps);
+    KT_END(tm, st);
+    KT_BEGIN(tm, "ff1_gemm", st);
+    gemm_s(S.h_hi, S.h_lo, D, L.ff1, nullptr, S.ff_hi, S.ff_lo, h.d_ff, nullptr, N, 1, st);
+    KT_END(tm, st);
+    KT_BEGIN(tm, "ff2_gemm", st);
+    gemm_s(S.ff_hi, S.ff_lo, h.d_ff, L.ff2, S.x, nullptr, nullptr, D, S.x, N, 0, st);
+    KT_END(tm, st);
+  }
+  KT_BEGIN(tm, "layernorm", st);
+  hipLaunchKernelGGL(k_layernorm_s, ln_grid, dim3(256), 0, st, S.x, S.h_hi, S.h_lo, M.lnf_g, M.lnf_b, N, D, h.ln_eps);
+  KT_END(tm, st);
+  KT_BEGIN(tm, "heads_gemm", st);
+  gemm_s(S.h_hi, S.h_lo, D, M.heads, S.logits, nullptr, nullptr, 16, nullptr, N, 0, st);
+  KT_END(tm, st);
+  KT_BEGIN(tm, "scatter_logits", st);
+  hipLaunchKernelGGL(k_scatter_logits, dim3(B.n_win), dim3(64), 0, st, B, S);
+  KT_END(tm, st);
+}
+
 void launch_model(const ModelDev& M, const BatchDev& B, const ModelScratch& S, int precision,
                   hipStream_t st, KernelTimer* tm) {
   const uint32_t N = B.n_tok;
   if (N == 0) return;
+  if (precision == 1) {
+    launch_model_s(M, B, S, st, tm);
+    return;
+  }
   const ModelHyper& h = M.h;
   const uint32_t D = h.d_model;
   KT_BEGIN(tm, "build_tokens", st);

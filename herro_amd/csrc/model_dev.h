@@ -83,6 +83,13 @@ struct ModelScratch {  // sized for n_tok tokens
   float* att;         // [N][d_model]
   float* ff;          // [N][d_ff]
   float* logits;      // [N][16]
+  // bf16x3 pipeline: activations that feed a GEMM are kept pre-split as bf16 hi/lo planes
+  // (a ~= hi + lo, 16 mantissa bits) so the GEMM never converts in its inner loop
+  uint16_t *y1_hi, *y1_lo;    // [N][31][kw][c1]
+  uint16_t *y2_hi, *y2_lo;    // [N][31*c2]
+  uint16_t *h_hi, *h_lo;      // [N][d_model]
+  uint16_t *att_hi, *att_lo;  // [N][d_model]
+  uint16_t *ff_hi, *ff_lo;    // [N][d_ff]
 };
 
 void launch_model(const ModelDev& M, const BatchDev& B, const ModelScratch& S, int precision,

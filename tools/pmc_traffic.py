@@ -1,0 +1,30 @@
+#!/usr/bin/env python
+"""HBM traffic per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate passes: TCC has 4
+slots, FETCH_SIZE costs 3 and WRITE_SIZE 2).  Units: rocprofv3 reports KiB.  gfx950 correction
+(MI355X_MICROARCH.md §HBM): FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads -> doubled in
+`hbm_bytes_corrected`; WRITE_SIZE is used as reported (uncalibrated).
+usage: pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv GROUP out.json"""
+import collections
+import csv
+import json
+import sys
+
+
+def avg(path, counter):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("herro::", "").split("<")[0]
+            agg[name].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+f, w = avg(sys.argv[1], "FETCH_SIZE"), avg(sys.argv[2], "WRITE_SIZE")
+rename = {"k_ow_stats": "ow_stats", "k_win_rank": "win_rank", "k_pass1_pos": "pass1_pos", "k_select_layout": "select_layout",
+          "k_final_tiles": "final_tiles", "k_sup_compact": "sup_compact", "k_patch_conv1_s": "patch_conv1"}
+out = {"group": int(sys.argv[3]), "unit": "bytes per launch", "kernels": {}}
+for k in sorted(set(f) | set(w)):
+    fb, wb = f.get(k, 0.0) * 1024, w.get(k, 0.0) * 1024
+    out["kernels"][rename.get(k, k)] = {"fetch_bytes_raw": fb, "write_bytes": wb, "hbm_bytes_corrected": 2 * fb + wb}
+json.dump(out, open(sys.argv[4], "w"), indent=1)
+print(json.dumps(out["kernels"].get("final_tiles"), indent=1))
