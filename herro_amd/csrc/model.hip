@@ -438,20 +438,33 @@ __global__ __launch_bounds__(256) void k_patch_conv1_s(ModelDev M, BatchDev B, M
     }
     __syncthreads();
     const uint64_t ob = (uint64_t)n * total;
-    for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
-      const uint32_t c = e % c1, dl = (e / c1) % kw, r = e / (c1 * kw);
+    for (uint32_t e4 = threadIdx.x * 4; e4 < total; e4 += blockDim.x * 4) {  // 4 consecutive channels per thread
+      const uint32_t c = e4 % c1, dl = (e4 / c1) % kw, r = e4 / (c1 * kw);
       const int32_t pos = l + (int32_t)dl - (int32_t)h;
-      float v = 0.f;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (pos >= 0 && pos < lmax) {  // outside: conv2's zero padding
-        v = s_b1[c];
+        v = *reinterpret_cast<const float4*>(s_b1 + c);
         for (uint32_t t = 0; t < kw; t++) {
           const uint32_t pi = dl + t;
           const uint32_t tok = s_tok[r * P + pi];
-          if (tok != 255u) v += s_t1[(t * 12 + tok) * c1 + c] + s_wq[t * c1 + c] * s_qn[r * P + pi];
+          if (tok != 255u) {
+            const float4 tv = *reinterpret_cast<const float4*>(s_t1 + (t * 12 + tok) * c1 + c);
+            const float4 wv = *reinterpret_cast<const float4*>(s_wq + t * c1 + c);
+            const float qn = s_qn[r * P + pi];
+            v.x += tv.x + wv.x * qn; v.y += tv.y + wv.y * qn; v.z += tv.z + wv.z * qn; v.w += tv.w + wv.w * qn;
+          }
         }
-        v = fmaxf(v, 0.f);
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       }
-      split_store(S.y1_hi, S.y1_lo, ob + e, v);
+      const float f[4] = {v.x, v.y, v.z, v.w};
+      uint16_t hb[4], lb[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        hb[q] = f32_to_bf16_rne(f[q]);
+        lb[q] = f32_to_bf16_rne(f[q] - bf16_to_f32(hb[q]));
+      }
+      *reinterpret_cast<uint2*>(S.y1_hi + ob + e4) = make_uint2(hb[0] | ((uint32_t)hb[1] << 16), hb[2] | ((uint32_t)hb[3] << 16));
+      *reinterpret_cast<uint2*>(S.y1_lo + ob + e4) = make_uint2(lb[0] | ((uint32_t)lb[1] << 16), lb[2] | ((uint32_t)lb[3] << 16));
     }
   }
 }
@@ -461,26 +474,38 @@ __global__ __launch_bounds__(256) void k_patch_conv1_s(ModelDev M, BatchDev B, M
 // BK = 32, next k-tile prefetched into registers while the current one is consumed from LDS.
 // 3 MFMAs per k-step and tile: al*bh + ah*bl + ah*bh.
 static constexpr int GM = 128, GN = 64;
-template <bool OUT_SPLIT>
+// TM = 128: 4 waves x (32 rows x 64 cols); TM = 64: 4 waves x (16 rows x 64 cols) — used when the 128-row
+// grid would leave the chip under-filled (these GEMMs are latency-bound per k-step, so more resident
+// workgroups per CU is what hides the global->LDS round trip).
+template <bool OUT_SPLIT, int TM, int KB>
 __global__ __launch_bounds__(256) void k_gemm_s(const uint16_t* __restrict__ Ahi, const uint16_t* __restrict__ Alo,
                                                 uint32_t lda, Weight W, float* C, uint16_t* Chi, uint16_t* Clo,
                                                 uint32_t ldc, const float* R, uint32_t M, int relu) {
-  __shared__ __attribute__((aligned(16))) uint16_t s_ah[GM * LDH], s_al[GM * LDH], s_bh[GN * LDH], s_bl[GN * LDH];
+  constexpr int LDK = KB + 8;   // bf16 row stride: 16-B aligned, spreads banks
+  __shared__ __attribute__((aligned(16))) uint16_t s_raw[2 * TM * LDK + 2 * GN * LDK];
+  uint16_t* s_ah = s_raw;
+  uint16_t* s_al = s_ah + TM * LDK;
+  uint16_t* s_bh = s_al + TM * LDK;
+  uint16_t* s_bl = s_bh + GN * LDK;
+  constexpr int RI = TM / 64;   // 16-row MFMA tiles per wave
+  constexpr int CPR = KB / 8;   // 16-byte chunks per tile row
+  constexpr int RPP = 256 / CPR; // tile rows covered by one pass of the 256 threads
+  constexpr int NA = TM / RPP, NBP = GN / RPP;
   const uint32_t K = W.K, N = W.N;
-  const uint32_t m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
+  const uint32_t m0 = blockIdx.y * TM, n0 = blockIdx.x * GN;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  f32x4 acc[2][4];
+  f32x4 acc[RI][4];
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < RI; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const uint32_t arow0 = tid >> 2, ac8 = (tid & 3) * 8;  // A rows arow0 and arow0+64; B row arow0
-  uint4 ra_h[2], ra_l[2], rb_h, rb_l;
+  const uint32_t arow0 = tid / CPR, ac8 = (tid % CPR) * 8;
+  uint4 ra_h[NA], ra_l[NA], rb_h[NBP], rb_l[NBP];
   auto gload = [&](uint32_t k0) {
 #pragma unroll
-    for (int it = 0; it < 2; it++) {
-      const uint32_t row = arow0 + it * 64;
+    for (int it = 0; it < NA; it++) {
+      const uint32_t row = arow0 + it * RPP;
       ra_h[it] = make_uint4(0, 0, 0, 0);
       ra_l[it] = make_uint4(0, 0, 0, 0);
       if (m0 + row < M) {
@@ -489,88 +514,315 @@ __global__ __launch_bounds__(256) void k_gemm_s(const uint16_t* __restrict__ Ahi
         ra_l[it] = *reinterpret_cast<const uint4*>(Alo + o);
       }
     }
-    rb_h = make_uint4(0, 0, 0, 0);
-    rb_l = make_uint4(0, 0, 0, 0);
-    if (n0 + arow0 < N) {
-      const uint64_t o = (uint64_t)(n0 + arow0) * K + k0 + ac8;
-      rb_h = *reinterpret_cast<const uint4*>(W.hi + o);
-      rb_l = *reinterpret_cast<const uint4*>(W.lo + o);
+#pragma unroll
+    for (int it = 0; it < NBP; it++) {
+      const uint32_t row = arow0 + it * RPP;
+      rb_h[it] = make_uint4(0, 0, 0, 0);
+      rb_l[it] = make_uint4(0, 0, 0, 0);
+      if (n0 + row < N) {
+        const uint64_t o = (uint64_t)(n0 + row) * K + k0 + ac8;
+        rb_h[it] = *reinterpret_cast<const uint4*>(W.hi + o);
+        rb_l[it] = *reinterpret_cast<const uint4*>(W.lo + o);
+      }
     }
   };
   auto lstore = [&]() {
 #pragma unroll
-    for (int it = 0; it < 2; it++) {
-      const uint32_t row = arow0 + it * 64;
-      *reinterpret_cast<uint4*>(s_ah + row * LDH + ac8) = ra_h[it];
-      *reinterpret_cast<uint4*>(s_al + row * LDH + ac8) = ra_l[it];
+    for (int it = 0; it < NA; it++) {
+      const uint32_t row = arow0 + it * RPP;
+      *reinterpret_cast<uint4*>(s_ah + row * LDK + ac8) = ra_h[it];
+      *reinterpret_cast<uint4*>(s_al + row * LDK + ac8) = ra_l[it];
     }
-    *reinterpret_cast<uint4*>(s_bh + arow0 * LDH + ac8) = rb_h;
-    *reinterpret_cast<uint4*>(s_bl + arow0 * LDH + ac8) = rb_l;
+#pragma unroll
+    for (int it = 0; it < NBP; it++) {
+      const uint32_t row = arow0 + it * RPP;
+      *reinterpret_cast<uint4*>(s_bh + row * LDK + ac8) = rb_h[it];
+      *reinterpret_cast<uint4*>(s_bl + row * LDK + ac8) = rb_l[it];
+    }
   };
 
   gload(0);
   lstore();
   __syncthreads();
   const uint32_t fr = lane & 15, fk = (lane >> 4) * 8;
-  for (uint32_t k0 = 0; k0 < K; k0 += BK) {
-    const bool more = k0 + BK < K;
-    if (more) gload(k0 + BK);
-    bf16x8 ah[2], al[2], bh[4], bl[4];
+  for (uint32_t k0 = 0; k0 < K; k0 += KB) {
+    const bool more = k0 + KB < K;
+    if (more) gload(k0 + KB);
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-      ah[i] = *reinterpret_cast<const bf16x8*>(s_ah + (wave * 32 + i * 16 + fr) * LDH + fk);
-      al[i] = *reinterpret_cast<const bf16x8*>(s_al + (wave * 32 + i * 16 + fr) * LDH + fk);
-    }
+    for (int ks = 0; ks < KB / 32; ks++) {
+      bf16x8 ah[RI], al[RI], bh[4], bl[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      bh[j] = *reinterpret_cast<const bf16x8*>(s_bh + (j * 16 + fr) * LDH + fk);
-      bl[j] = *reinterpret_cast<const bf16x8*>(s_bl + (j * 16 + fr) * LDH + fk);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; i++)
+      for (int i = 0; i < RI; i++) {
+        ah[i] = *reinterpret_cast<const bf16x8*>(s_ah + (wave * (TM / 4) + i * 16 + fr) * LDK + ks * 32 + fk);
+        al[i] = *reinterpret_cast<const bf16x8*>(s_al + (wave * (TM / 4) + i * 16 + fr) * LDK + ks * 32 + fk);
+      }
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        bh[j] = *reinterpret_cast<const bf16x8*>(s_bh + (j * 16 + fr) * LDK + ks * 32 + fk);
+        bl[j] = *reinterpret_cast<const bf16x8*>(s_bl + (j * 16 + fr) * LDK + ks * 32 + fk);
       }
+#pragma unroll
+      for (int i = 0; i < RI; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
     __syncthreads();
     if (more) {
       lstore();
       __syncthreads();
     }
   }
+  if constexpr (OUT_SPLIT) {
+    // bias / ReLU / split, then each wave transposes its (TM/4) x 64 tile through LDS (tiles are dead:
+    // the k-loop ended with a barrier) and writes 128-byte rows of the hi / lo planes as 16-byte stores
+    constexpr int OLD = GN + 8, WR = TM / 4;
+    static_assert(4 * WR * OLD <= 2 * TM * LDK + 2 * GN * LDK, "staging tile must fit the operand tiles");
+    uint16_t* so = s_raw + wave * WR * OLD;
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+    for (int plane = 0; plane < 2; plane++) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const uint32_t n = n0 + j * 16 + (lane & 15);
-      const float bias = (W.bias && n < N) ? W.bias[n] : 0.f;
+      for (int i = 0; i < RI; i++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const uint32_t m = m0 + wave * 32 + i * 16 + (lane >> 4) * 4 + r;
-        if (m < M && n < N) {
-          float v = acc[i][j][r] + bias;
-          if (relu) v = fmaxf(v, 0.f);
-          const uint64_t o = (uint64_t)m * ldc + n;
-          if (OUT_SPLIT) {
-            split_store(Chi, Clo, o, v);
-          } else {
+        for (int j = 0; j < 4; j++) {
+          const uint32_t nl = j * 16 + (lane & 15), n = n0 + nl;
+          const float bias = (W.bias && n < N) ? W.bias[n] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            float v = acc[i][j][r] + bias;
+            if (relu) v = fmaxf(v, 0.f);
+            const uint16_t hb = f32_to_bf16_rne(v);
+            so[(i * 16 + (lane >> 4) * 4 + r) * OLD + nl] = plane == 0 ? hb : f32_to_bf16_rne(v - bf16_to_f32(hb));
+          }
+        }
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed (wave-private region)
+      __builtin_amdgcn_wave_barrier();
+      uint16_t* dst = plane == 0 ? Chi : Clo;
+#pragma unroll
+      for (int it = 0; it < WR / 8; it++) {  // WR rows x 8 chunks of 16 B
+        const uint32_t ch = lane + it * 64, rr = ch >> 3, c8 = (ch & 7) * 8;
+        const uint32_t m = m0 + wave * WR + rr, n = n0 + c8;
+        if (m < M && n < N) *reinterpret_cast<uint4*>(dst + (uint64_t)m * ldc + n) = *reinterpret_cast<const uint4*>(so + rr * OLD + c8);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < RI; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t n = n0 + j * 16 + (lane & 15);
+        const float bias = (W.bias && n < N) ? W.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const uint32_t m = m0 + wave * (TM / 4) + i * 16 + (lane >> 4) * 4 + r;
+          if (m < M && n < N) {
+            float v = acc[i][j][r] + bias;
+            if (relu) v = fmaxf(v, 0.f);
+            const uint64_t o = (uint64_t)m * ldc + n;
             if (R) v += R[o];
             C[o] = v;
           }
         }
       }
-    }
+  }
 }
 
+// conv1 fused into the conv2 GEMM.  GEMM rows are (token, read row) pairs; their conv1 activations
+// (kw taps x c1 channels = the K axis) are computed on the fly from the window's token / quality planes
+// straight into the LDS A tile, so the [N*31, kw*c1] tensor never exists in HBM (it was the largest
+// stream of the whole model: 24 KB per token written and read back).  128 rows x 128 columns (= c2) per
+// workgroup; wave w owns rows 32w..32w+31 x all columns.  The weight tile of the next k-step is
+// prefetched into registers; the y2 tile leaves through LDS as 16-byte stores of the hi / lo planes.
+static constexpr int FC2 = 128;
+__global__ __launch_bounds__(256) void k_conv_fused(ModelDev M, BatchDev B, ModelScratch S, uint32_t n_rows) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t kw = M.h.kw, c1 = M.h.c1, hh = kw / 2, P = 4 * hh + 1, K = kw * c1;
+  uint16_t* s_ah = reinterpret_cast<uint16_t*>(smem);  // [128][LDH]
+  uint16_t* s_al = s_ah + GM * LDH;
+  uint16_t* s_bh = s_al + GM * LDH;                      // [128][LDH]
+  uint16_t* s_bl = s_bh + FC2 * LDH;
+  float* s_t1 = reinterpret_cast<float*>(s_bl + FC2 * LDH);  // [kw][12][c1]
+  float* s_wq = s_t1 + kw * 12 * c1;                          // [kw][c1]
+  float* s_b1 = s_wq + kw * c1;                               // [c1]
+  float* s_qn = s_b1 + c1;                                    // [128][P] normalised quality
+  uint8_t* s_tok = reinterpret_cast<uint8_t*>(s_qn + GM * P);  // [128][P] token, 255 = outside
+  uint8_t* s_val = s_tok + GM * P;                            // [128][kw] conv1 position inside [0,lmax)?
+
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t m0 = blockIdx.x * GM;
+  const Weight& W = M.conv2;
+  // weight tile prefetch: 128 rows x 32 k of hi and lo = 2 x 512 x 16 B -> 2 + 2 uint4 per thread
+  uint4 rb_h[2], rb_l[2];
+  auto bload = [&](uint32_t k0) {
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      const uint32_t e = tid + it * 256, row = e >> 2, c8 = (e & 3) * 8;
+      rb_h[it] = *reinterpret_cast<const uint4*>(W.hi + (uint64_t)row * K + k0 + c8);
+      rb_l[it] = *reinterpret_cast<const uint4*>(W.lo + (uint64_t)row * K + k0 + c8);
+    }
+  };
+  bload(0);
+  for (uint32_t e = tid; e < kw * 12 * c1; e += 256) s_t1[e] = M.t1[e];
+  for (uint32_t e = tid; e < kw * c1; e += 256) s_wq[e] = M.wq1[e];
+  for (uint32_t e = tid; e < c1; e += 256) s_b1[e] = M.b1[e];
+  for (uint32_t e = tid; e < GM * P; e += 256) {  // input patch of every row: P cells around the token's row
+    const uint32_t rr = e / P, pi = e % P, row = m0 + rr;
+    uint32_t tok = 255u;
+    float qn = 0.f;
+    if (row < n_rows) {
+      const uint32_t n = row / HERRO_ROWS, r = row % HERRO_ROWS;
+      const uint32_t b = S.tok_win[n];
+      const int32_t q = (int32_t)S.tok_row[n] - 2 * (int32_t)hh + (int32_t)pi;
+      const int32_t len = (int32_t)B.len[b], lmax = (int32_t)B.lmax[b];
+      if (q >= 0 && q < lmax) {
+        if (q < len) {
+          const uint64_t o = B.plane_off[b] + (uint64_t)r * B.plane_ld[b] + (uint32_t)q;
+          tok = B.planes_b[o];
+          qn = norm_qual(B.planes_q[o]);
+        } else {  // batch padding (inference.rs:86-97)
+          tok = TOK_PAD;
+          qn = norm_qual(126u);
+        }
+      }
+    }
+    s_tok[e] = (uint8_t)tok;
+    s_qn[e] = qn;
+  }
+  for (uint32_t e = tid; e < GM * kw; e += 256) {
+    const uint32_t rr = e / kw, dl = e % kw, row = m0 + rr;
+    uint8_t v = 0;
+    if (row < n_rows) {
+      const uint32_t n = row / HERRO_ROWS;
+      const int32_t pos = (int32_t)S.tok_row[n] + (int32_t)dl - (int32_t)hh;
+      v = (pos >= 0 && pos < (int32_t)B.lmax[S.tok_win[n]]) ? 1 : 0;  // else: conv2's zero padding
+    }
+    s_val[e] = v;
+  }
+
+  f32x4 acc[2][FC2 / 16];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < FC2 / 16; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t fr = lane & 15, fk = (lane >> 4) * 8;
+  for (uint32_t k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();  // previous k-step's fragments are consumed (first pass: tables are complete)
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      const uint32_t e = tid + it * 256, row = e >> 2, c8 = (e & 3) * 8;
+      *reinterpret_cast<uint4*>(s_bh + row * LDH + c8) = rb_h[it];
+      *reinterpret_cast<uint4*>(s_bl + row * LDH + c8) = rb_l[it];
+    }
+    if (k0 + BK < K) bload(k0 + BK);
+    {  // A tile: conv1 (+BN folded) + ReLU of 128 rows x 32 channels of tap dl, 4 channels per thread-step
+      const uint32_t dl = k0 / c1, cb = k0 % c1;
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        const uint32_t e4 = tid + it * 256, rr = e4 >> 3, kk = (e4 & 7) * 4, c = cb + kk;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s_val[rr * kw + dl]) {
+          v = *reinterpret_cast<const float4*>(s_b1 + c);
+          for (uint32_t t = 0; t < kw; t++) {
+            const uint32_t tok = s_tok[rr * P + dl + t];
+            if (tok != 255u) {
+              const float4 tv = *reinterpret_cast<const float4*>(s_t1 + (t * 12 + tok) * c1 + c);
+              const float4 wv = *reinterpret_cast<const float4*>(s_wq + t * c1 + c);
+              const float qn = s_qn[rr * P + dl + t];
+              v.x += tv.x + wv.x * qn; v.y += tv.y + wv.y * qn; v.z += tv.z + wv.z * qn; v.w += tv.w + wv.w * qn;
+            }
+          }
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        uint16_t hb[4], lb[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          hb[q] = f32_to_bf16_rne(f[q]);
+          lb[q] = f32_to_bf16_rne(f[q] - bf16_to_f32(hb[q]));
+        }
+        *reinterpret_cast<uint2*>(s_ah + rr * LDH + kk) = make_uint2(hb[0] | ((uint32_t)hb[1] << 16), hb[2] | ((uint32_t)hb[3] << 16));
+        *reinterpret_cast<uint2*>(s_al + rr * LDH + kk) = make_uint2(lb[0] | ((uint32_t)lb[1] << 16), lb[2] | ((uint32_t)lb[3] << 16));
+      }
+    }
+    __syncthreads();
+    bf16x8 ah[2], al[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      ah[i] = *reinterpret_cast<const bf16x8*>(s_ah + (wave * 32 + i * 16 + fr) * LDH + fk);
+      al[i] = *reinterpret_cast<const bf16x8*>(s_al + (wave * 32 + i * 16 + fr) * LDH + fk);
+    }
+#pragma unroll
+    for (int j = 0; j < FC2 / 16; j++) {
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(s_bh + (j * 16 + fr) * LDH + fk);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(s_bl + (j * 16 + fr) * LDH + fk);
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  // epilogue: + bias (BN folded), ReLU, split; each wave transposes its 32 x 128 tile through LDS (the
+  // A/B tiles are dead) and writes full 256-byte rows of the hi / lo planes with 16-byte stores
+  __syncthreads();
+  constexpr int OLD = FC2 + 8;  // bf16 row stride of the staging tile
+  uint16_t* so = reinterpret_cast<uint16_t*>(smem) + wave * 32 * OLD;
+#pragma unroll
+  for (int plane = 0; plane < 2; plane++) {
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < FC2 / 16; j++) {
+        const uint32_t n = j * 16 + (lane & 15);
+        const float bias = W.bias[n];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float v = fmaxf(acc[i][j][r] + bias, 0.f);
+          const uint16_t hb = f32_to_bf16_rne(v);
+          so[(i * 16 + (lane >> 4) * 4 + r) * OLD + n] = plane == 0 ? hb : f32_to_bf16_rne(v - bf16_to_f32(hb));
+        }
+      }
+    // wave-private region: no workgroup barrier needed, only that this wave's LDS writes have landed
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    uint16_t* dst = plane == 0 ? S.y2_hi : S.y2_lo;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {  // 32 rows x 16 chunks of 16 B = 512 chunks / 64 lanes
+      const uint32_t ch = lane + it * 64, rr = ch >> 4, c8 = (ch & 15) * 8;
+      const uint32_t m = m0 + wave * 32 + rr;
+      if (m < n_rows)
+        *reinterpret_cast<uint4*>(dst + (uint64_t)m * FC2 + c8) = *reinterpret_cast<const uint4*>(so + rr * OLD + c8);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <bool SPLIT, int TM>
+static void gemm_launch(dim3 grid, const uint16_t* Ahi, const uint16_t* Alo, uint32_t lda, const Weight& W, float* C,
+                        uint16_t* Chi, uint16_t* Clo, uint32_t ldc, const float* R, uint32_t M, int relu, hipStream_t st) {
+  if (W.K % 64 == 0 && W.K >= 2048) hipLaunchKernelGGL((k_gemm_s<SPLIT, TM, 64>), grid, dim3(256), 0, st, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu);
+  else hipLaunchKernelGGL((k_gemm_s<SPLIT, TM, 32>), grid, dim3(256), 0, st, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu);
+}
 
 static void gemm_s(const uint16_t* Ahi, const uint16_t* Alo, uint32_t lda, const Weight& W, float* C, uint16_t* Chi,
                    uint16_t* Clo, uint32_t ldc, const float* R, uint32_t M, int relu, hipStream_t st) {
   if (M == 0) return;
-  dim3 grid((W.N + GN - 1) / GN, (M + GM - 1) / GM);
-  if (Chi) hipLaunchKernelGGL(k_gemm_s<true>, grid, dim3(256), 0, st, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu);
-  else hipLaunchKernelGGL(k_gemm_s<false>, grid, dim3(256), 0, st, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu);
+  const uint32_t gx = (W.N + GN - 1) / GN;
+  const bool small = (uint64_t)gx * ((M + 127) / 128) < 1536;  // < ~6 workgroups per CU with 128-row tiles
+  if (small) {
+    dim3 grid(gx, (M + 63) / 64);
+    if (Chi) gemm_launch<true, 64>(grid, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu, st);
+    else gemm_launch<false, 64>(grid, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu, st);
+  } else {
+    dim3 grid(gx, (M + 127) / 128);
+    if (Chi) gemm_launch<true, 128>(grid, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu, st);
+    else gemm_launch<false, 128>(grid, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu, st);
+  }
 }
 
 // LayerNorm, one wave per row, output pre-split
@@ -599,7 +851,7 @@ __global__ __launch_bounds__(256) void k_layernorm_s(const float* x, uint16_t* y
 // at a time (the window's informative positions are the sequence; typically 10-30 tokens).  K and V
 // rows are staged through LDS in chunks of KC keys with coalesced 16-byte loads; reads are broadcast
 // within a head's 16 lanes.  Softmax is kept online in registers across chunks.  Output pre-split.
-static constexpr int KC = 32;
+static constexpr int KC = 16;
 template <int DH>
 __global__ __launch_bounds__(128) void k_attention_s(BatchDev B, ModelScratch S, uint32_t D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -660,8 +912,19 @@ __global__ __launch_bounds__(128) void k_attention_s(BatchDev B, ModelScratch S,
     if (act) {
       const float inv = 1.0f / l;
       const uint64_t ob = (uint64_t)(t0 + i) * D + hd * DH;
+      uint32_t ph[DH / 2], pl[DH / 2];  // the head's DH outputs as packed bf16 pairs -> 16-byte stores
 #pragma unroll
-      for (int d = 0; d < DH; d++) split_store(S.att_hi, S.att_lo, ob + d, o[d] * inv);
+      for (int d = 0; d < DH; d += 2) {
+        const float v0 = o[d] * inv, v1 = o[d + 1] * inv;
+        const uint16_t h0 = f32_to_bf16_rne(v0), h1 = f32_to_bf16_rne(v1);
+        ph[d / 2] = h0 | ((uint32_t)h1 << 16);
+        pl[d / 2] = f32_to_bf16_rne(v0 - bf16_to_f32(h0)) | ((uint32_t)f32_to_bf16_rne(v1 - bf16_to_f32(h1)) << 16);
+      }
+#pragma unroll
+      for (int d = 0; d < DH / 8; d++) {
+        *reinterpret_cast<uint4*>(S.att_hi + ob + 8 * d) = make_uint4(ph[4 * d], ph[4 * d + 1], ph[4 * d + 2], ph[4 * d + 3]);
+        *reinterpret_cast<uint4*>(S.att_lo + ob + 8 * d) = make_uint4(pl[4 * d], pl[4 * d + 1], pl[4 * d + 2], pl[4 * d + 3]);
+      }
     }
   }
 }
@@ -674,7 +937,13 @@ static void launch_model_s(const ModelDev& M, const BatchDev& B, const ModelScra
   hipLaunchKernelGGL(k_build_tokens, dim3(B.n_win), dim3(64), 0, st, B, S);
   KT_END(tm, st);
   const uint32_t P = 4 * (h.kw / 2) + 1;
-  {
+  if (h.c2 == FC2 && h.c1 % 32 == 0) {
+    const size_t shm = (size_t)(2 * GM + 2 * FC2) * LDH * 2 + (size_t)(h.kw * 12 * h.c1 + h.kw * h.c1 + h.c1 + GM * P) * 4 +
+                       (size_t)GM * P + (size_t)GM * h.kw + 16;
+    KT_BEGIN(tm, "conv_fused", st);
+    hipLaunchKernelGGL(k_conv_fused, dim3((N * HERRO_ROWS + GM - 1) / GM), dim3(256), shm, st, M, B, S, N * HERRO_ROWS);
+    KT_END(tm, st);
+  } else {
     const size_t shm = (size_t)(h.kw * 12 * h.c1 + h.kw * h.c1 + h.c1 + HERRO_ROWS * P) * 4 + (size_t)HERRO_ROWS * P * 4;
     KT_BEGIN(tm, "patch_conv1", st);
     hipLaunchKernelGGL(k_patch_conv1_s, dim3((N + TOKB - 1) / TOKB), dim3(256), shm, st, M, B, S, N);
