@@ -152,7 +152,7 @@ def main():
     if rank == 0:
         total_windows = args.steps * args.batch * world
         kern = {k: {"ms_total": v[0], "calls": v[1], "avg_us": 1e3 * v[0] / max(v[1], 1)} for k, v in tm.items()}
-        feat_names = ["ow_stats", "win_rank", "pass1_pos", "select_layout", "final_tiles", "sup_compact"]
+        feat_names = ["ow_stats", "win_rank", "pass1_pos", "select_layout", "tile_plan", "final_tiles", "sup_compact"]
         feat_ms = sum(tm[k][0] for k in feat_names if k in tm) / args.steps
         model_ms = sum(v[0] for k, v in tm.items() if k not in feat_names) / args.steps
         # ---- algorithmic work per launch (one launch = G steps = G*batch windows); DESIGN.md §4/§5

@@ -55,6 +55,29 @@ __device__ __forceinline__ uint32_t block_scan(uint32_t v, uint32_t* total, uint
   return base + inc - v;
 }
 
+// the same for a u64 (several packed counters scanned at once: one pair of barriers instead of several)
+__device__ __forceinline__ uint64_t block_scan64(uint64_t v, uint64_t* total, uint64_t* s_wave64 /*[NT/64]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint64_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  __syncthreads();
+  if (lane == 63) s_wave64[wave] = inc;
+  __syncthreads();
+  uint64_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; w++) {
+    const uint64_t x = s_wave64[w];
+    if (w < wave) base += x;
+    tot += x;
+  }
+  *total = tot;
+  return base + inc - v;
+}
+
 __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* s_wave) {
   uint32_t tot;
   block_scan(v, &tot, s_wave);
@@ -76,29 +99,68 @@ __device__ __forceinline__ uint32_t rev_pairs(uint32_t x) {
 }
 
 // =====================================================================================================
-// k_ow_stats — one workgroup per overlap-window
+// k_ow_stats — one WAVE per overlap-window (4 per workgroup), no workgroup barriers
 // =====================================================================================================
+// The work of one overlap-window is small (~100 ops, <= 8192 positions) and is a chain of dependent
+// global loads; one wave each keeps 4x more of those chains in flight per CU than one workgroup each.
+static constexpr int OWCAP = 256;  // ops staged in LDS per wave (more: tables are read back from global)
+static constexpr int TWCAP = HERRO_MAX_WINDOW / 32 + 2;  // staged target 2-bit words per wave
+static constexpr int QWCAP = 320;                         // staged query 2-bit words per wave (10k bases)
+
+__device__ __forceinline__ uint64_t wave_scan64(uint64_t v, uint64_t* total) {  // exclusive, within the wave
+  const int lane = threadIdx.x & 63;
+  uint64_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  *total = __shfl(inc, 63, 64);
+  return inc - v;
+}
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
 __global__ __launch_bounds__(NT) void k_ow_stats(JobDev J) {
-  __shared__ uint32_t s_wave[NT / 64];
-  __shared__ uint32_t s_op[OPCAP], s_t[OPCAP], s_q[OPCAP];
-  __shared__ uint32_t s_bm[HERRO_MAX_WINDOW / 32 + 1];
-  const uint32_t o = blockIdx.x;
+  __shared__ uint32_t s_op_all[4][OWCAP], s_t_all[4][OWCAP], s_q_all[4][OWCAP];
+  __shared__ uint32_t s_bm_all[4][HERRO_MAX_WINDOW / 32 + 1];
+  __shared__ uint64_t s_tw_all[4][TWCAP], s_qw_all[4][QWCAP];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t o = blockIdx.x * 4 + wave;
+  if (o >= J.n_ow) return;
+  uint64_t* s_tw = s_tw_all[wave];
+  uint64_t* s_qw = s_qw_all[wave];
+  uint32_t* s_op = s_op_all[wave];
+  uint32_t* s_t = s_t_all[wave];
+  uint32_t* s_q = s_q_all[wave];
+  uint32_t* s_bm = s_bm_all[wave];
   const OwDesc d = J.ow[o];
   const WinDesc wd = J.win[d.win];
   const uint32_t* ops = J.ops + d.op_begin;
   uint32_t* op_t = J.op_t + d.scr_off;
   uint32_t* op_q = J.op_q + d.scr_off;
   uint32_t* ins_ev = J.ins_ev + d.scr_off;
+  uint4* md = J.md + d.scr_off;
   const uint32_t cnt = d.op_cnt;
   const uint32_t off = d.tstart - wd.tstart;
-  const bool in_lds = cnt <= OPCAP;
+  const bool in_lds = cnt <= OWCAP;
 
-  for (uint32_t i = threadIdx.x; i < J.n_bw; i += NT) s_bm[i] = 0;
-  __syncthreads();
-  uint4* md = J.md + d.scr_off;
+  for (uint32_t i = lane; i < J.n_bw; i += 64) s_bm[i] = 0;
+  // 2-bit words of the target stretch and of the query stretch, coalesced, for the accuracy pass below
+  const uint64_t t_woff = J.read_word_off[wd.rid];
+  const uint64_t q_woff = J.read_word_off[d.qid];
+  const uint32_t tw0 = d.tstart >> 5, ntw = ((wd.tstart + wd.win_len) >> 5) - tw0 + 2;
+  const uint32_t qw0 = d.qbeg >> 5, nqw = ((d.qbeg + d.qlen) >> 5) - qw0 + 2;
+  const bool q_lds = nqw <= QWCAP;
+  for (uint32_t i = lane; i < ntw; i += 64) s_tw[i] = t_woff + tw0 + i <= J.read_n_words ? J.read_words[t_woff + tw0 + i] : 0ull;
+  if (q_lds)
+    for (uint32_t i = lane; i < nqw; i += 64) s_qw[i] = q_woff + qw0 + i <= J.read_n_words ? J.read_words[q_woff + qw0 + i] : 0ull;
   uint32_t carry_t = 0, carry_q = 0, carry_i = 0, carry_m = 0, isum = 0, dsum = 0, longindel = 0;
-  for (uint32_t base = 0; base < cnt; base += NT) {
-    const uint32_t k = base + threadIdx.x;
+  for (uint32_t base = 0; base < cnt; base += 64) {
+    const uint32_t k = base + lane;
     uint32_t tadv = 0, qadv = 0, is_i = 0, op = 0;
     if (k < cnt) {
       op = ops[k];
@@ -111,35 +173,37 @@ __global__ __launch_bounds__(NT) void k_ow_stats(JobDev J) {
       if (ty == OP_D) dsum += e;
     }
     const uint32_t is_md = (k < cnt && !is_i) ? 1u : 0u;
-    uint32_t tot_t, tot_q, tot_i, tot_m;
-    const uint32_t ex_t = block_scan(tadv, &tot_t, s_wave);
-    const uint32_t ex_q = block_scan(qadv, &tot_q, s_wave);
-    const uint32_t ex_i = block_scan(is_i, &tot_i, s_wave);
-    const uint32_t ex_m = block_scan(is_md, &tot_m, s_wave);
+    // four prefix sums in two 64-bit wave scans
+    uint64_t tot_tq, tot_im;
+    const uint64_t ex_tq = wave_scan64((uint64_t)tadv | ((uint64_t)qadv << 32), &tot_tq);
+    const uint64_t ex_im = wave_scan64((uint64_t)is_i | ((uint64_t)is_md << 32), &tot_im);
     if (k < cnt) {
-      const uint32_t t = carry_t + ex_t, q = carry_q + ex_q;
+      const uint32_t t = carry_t + (uint32_t)ex_tq, q = carry_q + (uint32_t)(ex_tq >> 32);
       op_t[k] = t;
       op_q[k] = q;
       if (in_lds) { s_op[k] = op; s_t[k] = t; s_q[k] = q; }
       // insertion behind window position off+t-1 (features.rs:77); t >= 1: a slice never starts with I
-      if (is_i) ins_ev[carry_i + ex_i] = ((off + t - 1u) & 0xffffu) | (op_len(op) << 16);
+      if (is_i) ins_ev[carry_i + (uint32_t)ex_im] = ((off + t - 1u) & 0xffffu) | (op_len(op) << 16);
       if (is_md) {
         // compact M/D op table + bitmap of op starts: the tile kernels find the op covering a target
         // position with one popcount (rank) instead of a search.  An M/D op is followed by at most one
         // insertion (the host rejects consecutive I ops); I ops are never trimmed by window offsets.
         const uint32_t nxt = (k + 1 < cnt) ? ops[k + 1] : 0u;
         const uint32_t ins_len = (k + 1 < cnt && op_type(nxt) == OP_I) ? op_len(nxt) : 0u;
-        md[carry_m + ex_m] = make_uint4(t, q, tadv | (op_type(op) == OP_M ? 0x80000000u : 0u), ins_len);
+        md[carry_m + (uint32_t)(ex_im >> 32)] = make_uint4(t, q, tadv | (op_type(op) == OP_M ? 0x80000000u : 0u), ins_len);
         atomicOr(&s_bm[t >> 5], 1u << (t & 31u));
       }
     }
-    carry_t += tot_t;
-    carry_q += tot_q;
-    carry_i += tot_i;
-    carry_m += tot_m;
+    carry_t += (uint32_t)tot_tq;
+    carry_q += (uint32_t)(tot_tq >> 32);
+    carry_i += (uint32_t)tot_im;
+    carry_m += (uint32_t)(tot_im >> 32);
   }
   const uint32_t t_total = carry_t;
-  __syncthreads();  // LDS tables / global op_t visible to the whole workgroup
+  // this wave's LDS / global writes are read back below by the same wave
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   const uint32_t* po = in_lds ? s_op : ops;
   const uint32_t* pt = in_lds ? s_t : op_t;
   const uint32_t* pq = in_lds ? s_q : op_q;
@@ -148,15 +212,15 @@ __global__ __launch_bounds__(NT) void k_ow_stats(JobDev J) {
   {
     uint2* bm = J.bm + (uint64_t)o * J.n_bw;
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < J.n_bw; base += NT) {
-      const uint32_t i = base + threadIdx.x;
+    for (uint32_t base = 0; base < J.n_bw; base += 64) {
+      const uint32_t i = base + lane;
       const uint32_t bits = i < J.n_bw ? s_bm[i] : 0u;
-      uint32_t tot;
-      const uint32_t ex = block_scan(__popc(bits), &tot, s_wave);
+      uint64_t tot;
+      const uint32_t ex = (uint32_t)wave_scan64(__popc(bits), &tot);
       if (i < J.n_bw) bm[i] = make_uint2(bits, carry + ex);
-      carry += tot;
+      carry += (uint32_t)tot;
     }
-    if (threadIdx.x == 0) {
+    if (lane == 0) {
       ColHdr h;
       h.off = (int32_t)off;
       h.t_total = t_total;
@@ -174,10 +238,10 @@ __global__ __launch_bounds__(NT) void k_ow_stats(JobDev J) {
   }
 
   // accuracy: matches / mismatches over M ops (features.rs:650-665), 16 target bases per step
-  const uint64_t t_woff = J.read_word_off[wd.rid];
-  const uint64_t q_woff = J.read_word_off[d.qid];
+  const uint64_t* twp = s_tw;                              // staged: index relative to word tw0
+  const uint64_t* qwp = q_lds ? s_qw : J.read_words + q_woff + qw0;
   uint32_t m = 0, s = 0;
-  for (uint32_t u0 = threadIdx.x * 16u; u0 < t_total; u0 += NT * 16u) {
+  for (uint32_t u0 = lane * 16u; u0 < t_total; u0 += 64u * 16u) {
     const uint32_t u1 = min(u0 + 16u, t_total);
     uint32_t k = find_op(pt, cnt, u0), u = u0;
     while (u < u1) {
@@ -187,13 +251,13 @@ __global__ __launch_bounds__(NT) void k_ow_stats(JobDev J) {
       const uint32_t se = min(u1, oend);
       if (ty == OP_M) {
         const uint32_t n = se - u, q = pq[k] + (u - t0);
-        const uint32_t tb = get16(J.read_words, t_woff, d.tstart + u);
+        const uint32_t tb = get16(twp, 0, d.tstart + u - (tw0 << 5));
         uint32_t qb;
         if (d.strand == 0) {
-          qb = get16(J.read_words, q_woff, d.qbeg + q);
+          qb = get16(qwp, 0, d.qbeg + q - (qw0 << 5));
         } else {  // alignment-orientation bases q..q+n-1 = complement of stored bases s_lo+n-1 .. s_lo
           const uint32_t s_lo = d.qbeg + d.qlen - q - n;
-          qb = ~(rev_pairs(get16(J.read_words, q_woff, s_lo)) >> (32u - 2u * n));
+          qb = ~(rev_pairs(get16(qwp, 0, s_lo - (qw0 << 5))) >> (32u - 2u * n));
         }
         const uint32_t x = tb ^ qb;
         const uint32_t mask = n >= 16u ? 0x55555555u : (0x55555555u & ((1u << (2u * n)) - 1u));
@@ -205,12 +269,11 @@ __global__ __launch_bounds__(NT) void k_ow_stats(JobDev J) {
       if (se == oend) k++;
     }
   }
-  m = block_sum(m, s_wave);
-  s = block_sum(s, s_wave);
-  isum = block_sum(isum, s_wave);
-  dsum = block_sum(dsum, s_wave);
-  longindel = block_sum(longindel, s_wave);
-  if (threadIdx.x == 0) {
+  const uint64_t t1 = wave_sum64((uint64_t)m | ((uint64_t)s << 32));
+  const uint64_t t2 = wave_sum64((uint64_t)isum | ((uint64_t)dsum << 32));
+  longindel = __ballot(longindel != 0u) != 0ull ? 1u : 0u;
+  if (lane == 0) {
+    m = (uint32_t)t1; s = (uint32_t)(t1 >> 32); isum = (uint32_t)t2; dsum = (uint32_t)(t2 >> 32);
     J.ow_keep[o] = longindel ? 0 : 1;
     // (m as f32) / ((m+s+i+d) as f32), correctly rounded (features.rs:678)
     J.ow_acc[o] = __fdiv_rn((float)m, (float)(m + s + isum + dsum));
@@ -632,7 +695,7 @@ struct TCol {
   uint32_t word0;   // first staged 2-bit word (index into the query read's words)
   uint64_t qg0;     // 4-aligned index into read_qual of the first staged quality byte
   uint32_t fb;      // 1: stretch does not fit, use the global path
-  uint32_t nmd, nw; // staged entries / words
+  uint32_t nmd, nw, nq; // staged entries / words / quality dwords
 };
 
 template <bool WITH_QUAL>
@@ -650,7 +713,7 @@ __device__ __forceinline__ void stage_tile(const JobDev& J, const uint32_t* ow_l
   if (threadIdx.x < ng) {
     TCol t;
     t.ow = ow_list[threadIdx.x];
-    t.fb = 0; t.w0 = 0; t.r0 = 0; t.word0 = 0; t.qg0 = 0; t.nmd = 0; t.nw = 0;
+    t.fb = 0; t.w0 = 0; t.r0 = 0; t.word0 = 0; t.qg0 = 0; t.nmd = 0; t.nw = 0; t.nq = 0;
     if (t.ow != 0xffffffffu) {
       t.h = J.chdr[t.ow];
       const int32_t ulo = max((int32_t)p_lo - t.h.off, 0);
@@ -675,6 +738,7 @@ __device__ __forceinline__ void stage_tile(const JobDev& J, const uint32_t* ow_l
         // quality bytes are copied as aligned dwords of the global array
         t.qg0 = (t.h.qual_off + s0) & ~3ull;
         const uint64_t g1 = t.h.qual_off + s1;
+        t.nq = (uint32_t)((g1 - t.qg0) >> 2) + 1u;
         if (t.nmd > MDS || t.nw > WW || (WITH_QUAL && g1 - t.qg0 >= QB)) t.fb = 1;
       }
     }
@@ -685,7 +749,7 @@ __device__ __forceinline__ void stage_tile(const JobDev& J, const uint32_t* ow_l
     const uint32_t c = idx / BMW, i = idx % BMW;
     const TCol& t = S.col[c];
     uint2 v = make_uint2(0, 0);
-    if (t.ow != 0xffffffffu && t.h.t_total && t.w0 + i < J.n_bw) v = J.bm[(uint64_t)t.ow * J.n_bw + t.w0 + i];
+    if (t.ow != 0xffffffffu && t.h.t_total && t.w0 + i < J.n_bw && i <= ((p_hi - p_lo) >> 5) + 1u) v = J.bm[(uint64_t)t.ow * J.n_bw + t.w0 + i];
     S.bm[idx] = v;
   }
   for (uint32_t idx = threadIdx.x; idx < ng * MDS; idx += NT) {
@@ -707,7 +771,7 @@ __device__ __forceinline__ void stage_tile(const JobDev& J, const uint32_t* ow_l
       const uint32_t c = idx / (QB / 4), i = idx % (QB / 4);
       const TCol& t = S.col[c];
       uint32_t v = 0;
-      if (t.ow != 0xffffffffu && t.h.t_total && !t.fb) {
+      if (t.ow != 0xffffffffu && t.h.t_total && !t.fb && i < t.nq) {
         const uint64_t g = t.qg0 + 4ull * i;  // the allocation carries 8 pad bytes
         if (g < J.read_qual_bytes) v = *reinterpret_cast<const uint32_t*>(J.read_qual + g);
       }
@@ -805,6 +869,94 @@ __global__ __launch_bounds__(NT) void k_select_layout(JobDev J) {
   if (threadIdx.x == 0) J.win_Lf[w] = Lf;
 }
 
+// ---- per (tile, column) staging plan --------------------------------------------------------------------
+// Which bitmap words / op entries / query words / quality bytes a final-row tile needs from a selected
+// column follows from a chain of dependent loads (row map -> selection -> header -> rank directory -> op
+// table).  Done inside the tile kernel that chain is paid per workgroup with 30 active lanes; here it is
+// one thread per (tile, column), fully parallel, and the tile kernel just reads the 32-byte records.
+struct TPlan {
+  uint32_t ow;      // 0xffffffff: padding column
+  uint32_t w0, r0, word0;
+  uint64_t qg0;
+  uint32_t cnt;     // nmd | nw << 8 | outside << 30 | fb << 31
+  uint32_t nq;
+};
+
+__global__ __launch_bounds__(NT) void k_tile_plan(JobDev J) {
+  const uint32_t idx = blockIdx.x * NT + threadIdx.x;
+  const uint32_t tile = idx >> 5, c = idx & 31u;
+  if (tile >= J.n_tiles || c >= HERRO_ROWS - 1) return;
+  const uint32_t w = J.tile_win[tile], r0 = J.tile_r0[tile];
+  const uint32_t Lf = J.win_Lf[w];
+  if (r0 >= Lf) return;
+  const WinDesc& wd = J.win[w];
+  const uint32_t* rowmap = J.rowmap2 + wd.row_off;
+  const uint32_t p_lo = rowmap[r0] & 0xffffu, p_hi = rowmap[min(r0 + (uint32_t)HERRO_TILE, Lf) - 1] & 0xffffu;
+  TPlan t;
+  t.ow = J.sel_ow[(uint64_t)w * 32 + 1 + c];
+  t.w0 = 0; t.r0 = 0; t.word0 = 0; t.qg0 = 0; t.cnt = 0; t.nq = 0;
+  if (t.ow != 0xffffffffu) {
+    const ColHdr h = J.chdr[t.ow];
+    const int32_t ulo = max((int32_t)p_lo - h.off, 0);
+    const int32_t uhi = min((int32_t)p_hi - h.off, (int32_t)h.t_total - 1);
+    if (ulo > uhi) {
+      t.cnt = 1u << 30;  // the tile lies outside the overlap: every cell is '.'
+    } else {
+      const uint2* bm = J.bm + (uint64_t)t.ow * J.n_bw;
+      const uint2 blo = bm[ulo >> 5], bhi = bm[uhi >> 5];
+      const uint32_t rlo = blo.y + __popc(blo.x & (0xffffffffu >> (31 - (ulo & 31))));
+      const uint32_t rhi = bhi.y + __popc(bhi.x & (0xffffffffu >> (31 - (uhi & 31))));
+      t.w0 = (uint32_t)ulo >> 5;
+      t.r0 = rlo - 1;
+      const uint32_t nmd = rhi - rlo + 1;
+      const uint4 e0 = J.md[h.md_off + rlo - 1], e1 = J.md[h.md_off + rhi - 1];
+      // query stretch [q0, q1) the tile can touch, as stored indices [s0, s1]
+      const uint32_t q0 = e0.y, q1 = e1.y + ((e1.z >> 31) ? (e1.z & 0x7fffffffu) : 0u) + e1.w + 1u;
+      const int32_t sa = h.sbase + h.sdir * (int32_t)q0, sb = h.sbase + h.sdir * (int32_t)(q1 - 1u);
+      const uint32_t s0 = (uint32_t)max(min(sa, sb), 0), s1 = (uint32_t)max(sa, sb);
+      t.word0 = s0 >> 5;
+      const uint32_t nw = (s1 >> 5) - t.word0 + 1;
+      t.qg0 = (h.qual_off + s0) & ~3ull;  // quality bytes are copied as aligned dwords of the global array
+      const uint64_t g1 = h.qual_off + s1;
+      t.nq = (uint32_t)((g1 - t.qg0) >> 2) + 1u;
+      const bool fb = nmd > MDS || nw > WW || g1 - t.qg0 >= QB;
+      t.cnt = (fb ? 0u : (nmd | (nw << 8))) | (fb ? 1u << 31 : 0u);
+    }
+  }
+  J.tplan[(uint64_t)tile * 32 + c] = t;
+}
+
+
+// Staging for k_final_tiles from the precomputed plan (see k_tile_plan): 8 threads per column, the
+// column's plan and header live in registers, every loop runs over exactly what the tile needs.
+__device__ __forceinline__ void stage_from_plan(const JobDev& J, uint32_t tile, uint32_t nspan, TileLds<true>& S) {
+  const uint32_t c = threadIdx.x >> 3, l8 = threadIdx.x & 7u;
+  if (c < HERRO_ROWS - 1) {
+    const TPlan p = J.tplan[(uint64_t)tile * 32 + c];
+    TCol t;
+    t.ow = p.ow; t.w0 = p.w0; t.r0 = p.r0; t.word0 = p.word0; t.qg0 = p.qg0; t.nq = p.nq;
+    t.fb = p.cnt >> 31; t.nmd = p.cnt & 0xffu; t.nw = (p.cnt >> 8) & 0xffu;
+    if (p.ow != 0xffffffffu) {
+      t.h = J.chdr[p.ow];
+      if ((p.cnt >> 30) & 1u) t.h.t_total = 0;
+      if (t.h.t_total) {
+        const uint2* bm = J.bm + (uint64_t)t.ow * J.n_bw + t.w0;
+        for (uint32_t i = l8; i <= nspan && i < BMW && t.w0 + i < J.n_bw; i += 8) S.bm[c * BMW + i] = bm[i];
+        const uint4* md = J.md + t.h.md_off + t.r0;
+        for (uint32_t i = l8; i < t.nmd; i += 8) S.md[c * MDS + i] = md[i];
+        const uint64_t* wsrc = J.read_words + t.h.q_woff + t.word0;
+        for (uint32_t i = l8; i < t.nw; i += 8) S.words[c * WW + i] = wsrc[i];
+        if (!t.fb) {
+          const uint32_t* qsrc = reinterpret_cast<const uint32_t*>(J.read_qual + t.qg0);  // 8 pad bytes at the end
+          for (uint32_t i = l8; i < t.nq; i += 8) S.quals[c * (QB / 4) + i] = qsrc[i];
+        }
+      }
+    }
+    if (l8 == 0) S.col[c] = t;
+  }
+  __syncthreads();
+}
+
 // =====================================================================================================
 // k_final_tiles — one workgroup per 256 final rows
 // =====================================================================================================
@@ -812,11 +964,11 @@ __global__ __launch_bounds__(NT) void k_final_tiles(JobDev J) {
   __shared__ TileLds<true> S;
   const uint32_t w = J.tile_win[blockIdx.x], r0 = J.tile_r0[blockIdx.x];
   const uint32_t Lf = J.win_Lf[w];
-  if (r0 >= Lf) return;
+  if (r0 >= Lf || (J.dbg & 16u)) return;
   const WinDesc wd = J.win[w];
   const uint32_t* rowmap = J.rowmap2 + wd.row_off;
   const uint32_t p_lo = rowmap[r0] & 0xffffu, p_hi = rowmap[min(r0 + NT, Lf) - 1] & 0xffffu;
-  stage_tile<true>(J, J.sel_ow + (uint64_t)w * 32 + 1, HERRO_ROWS - 1, p_lo, p_hi, S);
+  if (!(J.dbg & 2u)) stage_from_plan(J, blockIdx.x, ((p_hi - p_lo) >> 5) + 1u, S);
   const uint32_t r = r0 + threadIdx.x;
   const bool valid = r < Lf;
   const uint32_t rm = valid ? rowmap[r] : 0u;
@@ -839,7 +991,7 @@ __global__ __launch_bounds__(NT) void k_final_tiles(JobDev J) {
       CellOut co;
       co.tok = TOK_NONE;  // fewer than 30 overlaps: untouched '.' / '!' columns (features.rs:522-525)
       co.qual = 33;
-      if (S.col[c - 1].ow != 0xffffffffu) co = staged_cell<true>(J, S, c - 1, p, j);
+      if (S.col[c - 1].ow != 0xffffffffu && !(J.dbg & 1u)) co = staged_cell<true>(J, S, c - 1, p, j);
       tk[c >> 2] |= co.tok << ((c & 3u) << 3);
       ql[c >> 2] |= co.qual << ((c & 3u) << 3);
       count_sym(cnt, tok_fold(co.tok));
@@ -854,12 +1006,13 @@ __global__ __launch_bounds__(NT) void k_final_tiles(JobDev J) {
   uint8_t* tq = tb + HERRO_ROWS * TLD;
 #pragma unroll
   for (uint32_t c = 0; c < HERRO_ROWS; c++) {
+    if (J.dbg & 8u) break;
     tb[c * TLD + threadIdx.x] = (uint8_t)(tk[c >> 2] >> ((c & 3u) << 3));
     tq[c * TLD + threadIdx.x] = (uint8_t)(ql[c >> 2] >> ((c & 3u) << 3));
   }
   __syncthreads();
   const uint32_t nseg = (min(wd.lub - r0, (uint32_t)HERRO_TILE) + 15) / 16;
-  for (uint32_t it = threadIdx.x; it < HERRO_ROWS * nseg; it += NT) {
+  for (uint32_t it = threadIdx.x; it < ((J.dbg & 4u) ? 0u : HERRO_ROWS * nseg); it += NT) {
     const uint32_t c = it / nseg, sg = it % nseg;
     const uint32_t* lb = reinterpret_cast<const uint32_t*>(tb + c * TLD + sg * 16);
     const uint32_t* lq = reinterpret_cast<const uint32_t*>(tq + c * TLD + sg * 16);
@@ -899,7 +1052,7 @@ __global__ __launch_bounds__(NT) void k_sup_compact(JobDev J) {
 void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm) {
   if (J.n_ow) {
     KT_BEGIN(tm, "ow_stats", st);
-    hipLaunchKernelGGL(k_ow_stats, dim3(J.n_ow), dim3(NT), 0, st, J);
+    hipLaunchKernelGGL(k_ow_stats, dim3((J.n_ow + 3) / 4), dim3(NT), 0, st, J);
     KT_END(tm, st);
   }
   KT_BEGIN(tm, "win_rank", st);
@@ -919,6 +1072,9 @@ void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm) {
   KT_END(tm, st);
   KT_BEGIN(tm, "select_layout", st);
   hipLaunchKernelGGL(k_select_layout, dim3(J.n_win), dim3(NT), 0, st, J);
+  KT_END(tm, st);
+  KT_BEGIN(tm, "tile_plan", st);
+  hipLaunchKernelGGL(k_tile_plan, dim3((J.n_tiles * 32 + NT - 1) / NT), dim3(NT), 0, st, J);
   KT_END(tm, st);
   KT_BEGIN(tm, "final_tiles", st);
   hipLaunchKernelGGL(k_final_tiles, dim3(J.n_tiles), dim3(NT), 0, st, J);

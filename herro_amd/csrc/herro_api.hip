@@ -556,6 +556,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.ln_table = ctx->d_ln; J.ln_table_n = ctx->ln_n;
   J.n_ow = n_ow; J.n_win = n_win; J.n_cls = n_cls;
   J.n_tiles = (uint32_t)job->tile_win.size(); J.window_size = W; J.n_bw = W / 32 + 1; J.max_cols = max_cols;
+  { const char* d = getenv("HERRO_DBG"); J.dbg = d ? (uint32_t)atoi(d) : 0u; }
   hipError_t e = hipSuccess;
   bool oom = false;
   auto A = [&](uint64_t bytes) -> void* {
@@ -581,6 +582,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.ow_ttotal = (uint32_t*)A((uint64_t)n_ow * 4);
   J.slot_ow = (uint32_t*)A((uint64_t)n_ow * 4); J.rank_qid = (uint32_t*)A((uint64_t)n_ow * 4);
   J.sel_ow = (uint32_t*)A((uint64_t)n_win * 32 * 4);
+  J.tplan = (struct herro::TPlan*)A((uint64_t)J.n_tiles * 32 * 32);
   J.win_nkept = (uint32_t*)A((uint64_t)n_win * 4);
   J.win_Lf = (uint32_t*)A((uint64_t)n_win * 4); J.win_nsup = (uint32_t*)A((uint64_t)n_win * 4);
   J.row_of_pos2 = (uint32_t*)A(pos_elems * 4);

@@ -43,6 +43,7 @@ struct JobDev {
   // ---- descriptors (uploaded by herro_job_create)
   uint32_t n_ow, n_win, n_cls, n_tiles, window_size, n_bw;
   uint32_t max_cols;  // 1 + max overlaps per window (sizes the bit-sliced counters)
+  uint32_t dbg;       // HERRO_DBG phase mask (profiling experiments only; 0 in production)
   const uint32_t* ops;
   const OwDesc* ow;
   const WinDesc* win;
@@ -56,6 +57,7 @@ struct JobDev {
   uint4* md;             // per overlap (at scr_off): M/D ops {t_beg, q_beg, len | isM<<31, following ins len}
   uint2* bm;             // [ow * n_bw + i] {bitmap of M/D op starts for positions 32i.., ops before 32i}
   ColHdr* chdr;          // [ow]
+  struct TPlan* tplan;   // [tile * 32 + c] staging plan of final-row tile x selected column (32 B)
   uint8_t* ow_keep;      // long-indel filter verdict
   float* ow_acc;         // accuracy
   uint32_t* ow_ttotal;   // target bases consumed by the slice
