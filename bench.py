@@ -109,6 +109,7 @@ def main():
     def run_job(j):
         j.featurize()
         j.infer(args.batch, 1)
+        j.consensus()      # corrected bases stay in HBM (≈4 KB/window); only they would cross PCIe
 
     def run_steps(n_steps):
         """exactly n_steps batches of `batch` windows"""

@@ -16,7 +16,7 @@ EXPORTS = [
     "herro_version", "herro_create", "herro_destroy", "herro_last_error", "herro_set_stream", "herro_synchronize",
     "herro_encode_2bit", "herro_decode_2bit", "herro_set_reads", "herro_set_reads_packed", "herro_load_model",
     "herro_set_precision", "herro_job_create", "herro_job_free", "herro_job_n_windows", "herro_job_featurize",
-    "herro_job_infer", "herro_job_window_info", "herro_job_window_copy", "herro_job_window_logits",
+    "herro_job_infer", "herro_job_consensus", "herro_job_window_info", "herro_job_window_copy", "herro_job_window_logits",
     "herro_job_consensus_fasta", "herro_model_forward", "herro_timing_enable", "herro_timing_reset",
     "herro_timing_get", "herro_job_stats", "herro_debug_extract_windows",
 ]
@@ -68,6 +68,7 @@ def lib():
         L.herro_job_n_windows.argtypes = [vp]
         L.herro_job_featurize.argtypes = [vp]
         L.herro_job_infer.argtypes = [vp, u32, i32]
+        L.herro_job_consensus.argtypes = [vp]
         L.herro_job_window_info.argtypes = [vp, u32, vp]
         L.herro_job_window_copy.argtypes = [vp, u32, i32, vp, vp, vp, vp, vp]
         L.herro_job_window_logits.argtypes = [vp, u32, vp, vp]
@@ -252,6 +253,10 @@ class Job:
 
     def infer(self, batch_size: int, batch_mode: int = 0):
         self.ctx._chk(self._l.herro_job_infer(self.h, batch_size, batch_mode))
+
+    def consensus(self):
+        """consensus.rs:86-227 on the device; consensus_fasta() then only concatenates windows."""
+        self.ctx._chk(self._l.herro_job_consensus(self.h))
 
     def info(self, w: int) -> WindowInfo:
         wi = WindowInfo()

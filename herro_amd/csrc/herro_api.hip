@@ -95,6 +95,11 @@ struct herro_job {
   bool logits_on_host = false;
   std::vector<BatchPlan> batches;
   void* d_bdesc = nullptr;
+  uint64_t* d_supoff = nullptr;
+  bool consensus_done = false, consensus_on_host = false;
+  std::vector<uint32_t> h_cons_len;
+  std::vector<uint8_t> h_cons_seq;
+  uint64_t row_elems = 0;
   uint64_t alg_read_bytes = 0, alg_op_bytes = 0;
 };
 
@@ -547,6 +552,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
     job->tgt_win_off[t + 1] = (uint32_t)job->win.size();
   }
   if (scr_ops > 0xffffffffull) return fail(HERRO_E_UNSUPPORTED, "job too large (op scratch exceeds 2^32)");
+  job->row_elems = row_elems;
 
   // ---- device allocation + upload
   const uint32_t n_ow = (uint32_t)job->ow.size(), n_win = (uint32_t)job->win.size();
@@ -588,6 +594,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.row_of_pos2 = (uint32_t*)A(pos_elems * 4);
   J.rowmap2 = (uint32_t*)A(row_elems * 4);
   J.sup_flag = (uint8_t*)A(row_elems);
+  J.cons_seq = (uint8_t*)A(row_elems); J.cons_tmp = (uint8_t*)A(row_elems); J.cons_len = (uint32_t*)A((uint64_t)n_win * 4);
   J.sup_row = (uint32_t*)A(row_elems * 4); J.sup_pi = (uint32_t*)A(row_elems * 4);
   J.fin_b = (uint8_t*)A(fin_bytes); J.fin_q = (uint8_t*)A(fin_bytes);
   J.nd = (uint32_t*)A((uint64_t)n_cls * 8);
@@ -607,6 +614,7 @@ void herro_job_free(herro_job* job) {
   if (job->d_info) hipFree(job->d_info);
   if (job->d_base) hipFree(job->d_base);
   if (job->d_bdesc) hipFree(job->d_bdesc);
+  if (job->d_supoff) hipFree(job->d_supoff);
   delete job;
 }
 
@@ -765,6 +773,28 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   HIP_TRY(ctx, hipGetLastError());
   job->inferred = true;
   job->logits_on_host = false;
+  job->consensus_done = false;
+  return HERRO_OK;
+}
+
+int herro_job_consensus(herro_job* job) {
+  if (!job) return HERRO_E_INVALID;
+  herro_ctx* ctx = job->ctx;
+  int rc = job_sync(job);
+  if (rc) return rc;
+  hipSetDevice(ctx->device);
+  const uint32_t n = job->J.n_win;
+  if (job->sup_off.back() > 0 && !job->inferred) { ctx->err = "herro_job_infer has not run"; return HERRO_E_STATE; }
+  if (!job->d_supoff) HIP_TRY(ctx, hipMalloc((void**)&job->d_supoff, std::max<uint64_t>(n, 1) * 8));
+  if (!job->d_base) {  // no informative position anywhere: a dummy logits buffer
+    HIP_TRY(ctx, hipMalloc((void**)&job->d_info, 4));
+    HIP_TRY(ctx, hipMalloc((void**)&job->d_base, 20));
+  }
+  if (n) HIP_TRY(ctx, hipMemcpyAsync(job->d_supoff, job->sup_off.data(), n * 8ull, hipMemcpyHostToDevice, ctx->stream));
+  launch_consensus(job->J, job->d_supoff, job->d_base, ctx->stream, &ctx->timer);
+  HIP_TRY(ctx, hipGetLastError());
+  job->consensus_done = true;
+  job->consensus_on_host = false;
   return HERRO_OK;
 }
 
@@ -878,6 +908,36 @@ int64_t herro_job_consensus_fasta(herro_job* job, uint32_t t, const char* id, co
   if (st < 0) return 0;
   std::vector<std::string> seqs;
   std::string cur;
+  if (job->consensus_done) {  // device consensus: concatenate the windows' corrected bases
+    if (!job->consensus_on_host) {
+      const uint32_t n = job->J.n_win;
+      job->h_cons_len.resize(n);
+      job->h_cons_seq.resize(job->row_elems);
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      ctx->timer.collect();
+      if (n) HIP_TRY(ctx, hipMemcpy(job->h_cons_len.data(), job->J.cons_len, n * 4ull, hipMemcpyDeviceToHost));
+      if (job->row_elems) HIP_TRY(ctx, hipMemcpy(job->h_cons_seq.data(), job->J.cons_seq, job->row_elems, hipMemcpyDeviceToHost));
+      job->consensus_on_host = true;
+    }
+    for (uint32_t w = (uint32_t)st; w < (uint32_t)en; w++) {
+      if (std::min<uint32_t>(job->h_nkept[w], 30) < 2) {
+        if (!cur.empty()) { seqs.push_back(cur); cur.clear(); }
+        continue;
+      }
+      cur.append((const char*)job->h_cons_seq.data() + job->win[w].row_off, job->h_cons_len[w]);
+    }
+    if (!cur.empty()) seqs.push_back(cur);
+    std::string fa;
+    for (size_t i = 0; i < seqs.size(); i++) {
+      fa += ">"; fa += id;
+      if (seqs.size() == 1) fa += " "; else fa += ":" + std::to_string(i) + " ";
+      if (desc) fa += desc;
+      fa += "\n"; fa += seqs[i]; fa += "\n";
+    }
+    if (fa.size() > cap) { ctx->err = "output buffer too small"; return HERRO_E_INVALID; }
+    std::memcpy(out, fa.data(), fa.size());
+    return (int64_t)fa.size();
+  }
   static const char UP[10] = {'A', 'C', 'G', 'T', '*', 'A', 'C', 'G', 'T', '*'};
   static const int CNT[10] = {0, 1, 2, 3, 4, 0, 1, 2, 3, 4};
   std::vector<uint8_t> pb;

@@ -75,6 +75,9 @@ struct JobDev {
   uint8_t* fin_q;
   uint32_t* nd;          // [2*cls]: matches, mismatches (features.rs:461-500)
   uint32_t* rank_qid;    // [win.ow_begin + rank] ranked query ids (features.rs:569)
+  uint8_t* cons_seq;     // [win.row_off ..] corrected bases of the window (ASCII), cons_len[w] of them
+  uint8_t* cons_tmp;     // [win.row_off + row] per-row call before '*' removal
+  uint32_t* cons_len;    // [win]
 };
 
 // Accumulates GPU time per kernel group with HIP events recorded on the launch stream.
@@ -118,5 +121,6 @@ struct KernelTimer {
 #define KT_END(tm, st) do { if ((tm) && (tm)->on) (tm)->end(st); } while (0)
 
 void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm);
+void launch_consensus(const JobDev& J, const uint64_t* sup_off, const float* base_logits, hipStream_t st, KernelTimer* tm);
 
 }  // namespace herro

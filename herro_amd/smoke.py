@@ -30,6 +30,7 @@ def run() -> None:
     twin = MR.build(raw, model_io.Hyper())
     w = 0
     n_tok = 0
+    fastas = []
     for t in range(sb.n_targets):
         rid, rows, cigs = O.target_alignments(sb, t)
         res = store.extract_features(rid, rows, cigs, W)
@@ -68,8 +69,13 @@ def run() -> None:
                 o += lens[k]
                 n_tok += lens[k]
         lg = np.concatenate(logits) if logits else np.zeros((0, 5), np.float32)
-        assert job.consensus_fasta(t, sb.read_name(rid)) == res.consensus_fasta(lg), "FASTA mismatch"
+        want = res.consensus_fasta(lg)
+        assert job.consensus_fasta(t, sb.read_name(rid)) == want, "FASTA mismatch (host decode)"
+        fastas.append((t, rid, want))
         w += len(res)
+    job.consensus()
+    for t, rid, want in fastas:
+        assert job.consensus_fasta(t, sb.read_name(rid)) == want, "FASTA mismatch (device consensus)"
     job.close()
     ctx.close()
     print(f"smoke ok: {w} windows, {n_tok} informative positions, pileup bit-exact, logits within 1e-3, FASTA identical")

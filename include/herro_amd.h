@@ -132,6 +132,12 @@ int herro_job_window_copy(herro_job* job, uint32_t w, int encoded, uint8_t* base
 /* Logits of window w after herro_job_infer: info[n_supported], bases[n_supported*5]. */
 int herro_job_window_logits(herro_job* job, uint32_t w, float* info_logits, float* bases_logits);
 
+/* Consensus on the device (consensus.rs:86-227): per window, the corrected bases (informative rows:
+ * argmax of the base logits; other rows: majority vote with target tie-break; '*' dropped) are left in
+ * HBM; herro_job_consensus_fasta then only concatenates windows.  Optional: without it the FASTA call
+ * decodes on the host from the planes.  Requires herro_job_infer if any window has informative rows. */
+int herro_job_consensus(herro_job* job);
+
 /* Consensus + FASTA text for target t (consensus.rs:86-227, lib.rs:282-317); id/desc are the
  * read's id and optional description (NULL: none).  Returns bytes written (0: read not
  * emitted), or a negative error.  Host-side integer decode of device results. */

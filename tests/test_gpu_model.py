@@ -59,6 +59,7 @@ def test_job_logits_and_fasta_reference_grouping():
     job.infer(bs, 0)
     w0 = 0
     checked = 0
+    wants = []
     for t in range(sb.n_targets):
         rid, rows, cigs = O.target_alignments(sb, t)
         res = store.extract_features(rid, rows, cigs, W)
@@ -99,10 +100,15 @@ def test_job_logits_and_fasta_reference_grouping():
                 all_logits.append(job.logits(w0 + i)[1])
         lg = np.concatenate(all_logits) if all_logits else np.zeros((0, 5), np.float32)
         want = res.consensus_fasta(lg)
-        got = job.consensus_fasta(t, sb.read_name(rid))
+        got = job.consensus_fasta(t, sb.read_name(rid))      # host decode of the device planes + logits
         assert got == want
+        wants.append((t, rid, want))
         w0 += nwin
     assert checked > 0
+    job.consensus()                                          # consensus.rs on the device
+    for t, rid, want in wants:
+        assert job.consensus_fasta(t, sb.read_name(rid)) == want
+    assert any(w for _, _, w in wants)
     job.close()
 
 
