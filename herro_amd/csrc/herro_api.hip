@@ -9,6 +9,8 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -417,6 +419,126 @@ static int ensure_scratch(herro_ctx* ctx, uint32_t n_tok) {
   return HERRO_OK;
 }
 
+
+namespace {
+// Everything herro_job_create derives from ONE target read, with target-local offsets.
+struct TargetOut {
+  BuildError err;
+  std::vector<uint32_t> ops;
+  std::vector<OwDesc> ow;    // win / cls / op_begin / scr_off are target-local
+  std::vector<WinDesc> win;  // ow_begin target-local; device offsets filled at merge
+  uint32_t n_cls = 0;
+  uint64_t scr_ops = 0, alg_read_bytes = 0, alg_op_bytes = 0;
+};
+
+void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* alns, uint32_t n_aln, uint32_t W,
+                  TargetOut& out) {
+  auto fail = [&](int code, const std::string& m) { out.err = BuildError{code, m}; };
+  if (rid >= ctx->n_reads) return fail(HERRO_E_REFERENCE_PANIC, "target rid out of range (reads[rid])");
+  const uint32_t tlen = ctx->read_len[rid];
+  const uint32_t n_windows = (tlen + W - 1) / W;  // features.rs:338
+  if (n_windows > 65535) return fail(HERRO_E_UNSUPPORTED, "more than 65535 windows in a read (wid is u16 in the reference)");
+  // collect (window, overlap) in alignment order, then bucket by window (stable)
+  struct Tmp { HostOw h; uint32_t op_base; uint32_t aln; };
+  std::vector<Tmp> tmp;
+  std::vector<uint32_t> aops;
+  std::vector<HostOw> hows;
+  std::unordered_map<uint32_t, uint32_t> cls_of_name;  // name class -> accumulator slot
+  std::unordered_map<uint32_t, uint32_t> seen_qid;
+  for (uint32_t a = 0; a < n_aln; a++) {
+    const herro_alignment& al = alns[a];
+    if (al.tid != rid) return fail(HERRO_E_UNSUPPORTED, "alignment tid != target rid (parse_paf groups by target, overlaps.rs:189-192)");
+    if (al.qid >= ctx->n_reads) return fail(HERRO_E_REFERENCE_PANIC, "alignment qid out of range");
+    if (al.qid == rid) return fail(HERRO_E_UNSUPPORTED, "self overlap (dropped by parse_paf, overlaps.rs:175-179)");
+    if (seen_qid.count(al.qid)) return fail(HERRO_E_UNSUPPORTED, "second alignment of the same (query,target) pair (dropped by parse_paf, overlaps.rs:181-185)");
+    seen_qid[al.qid] = a;
+    if (al.tlen != tlen) return fail(HERRO_E_INVALID, "alignment tlen differs from the stored read length");
+    if (al.qend > ctx->read_len[al.qid] || al.tend > tlen) return fail(HERRO_E_REFERENCE_PANIC, "alignment coordinates exceed the read length");
+    BuildError be;
+    aops.clear();
+    if (!parse_cigar(al.cigar, al.cigar_len, aops, be)) return fail(be.code, be.msg);
+    hows.clear();
+    if (!window_alignment(aops, al, W, n_windows, hows, be)) return fail(be.code, be.msg);
+    const uint32_t op_base = (uint32_t)out.ops.size();
+    if (!hows.empty()) out.ops.insert(out.ops.end(), aops.begin(), aops.end());
+    for (auto& h : hows) tmp.push_back(Tmp{h, op_base, a});
+    const uint32_t nc = ctx->name_class[al.qid];
+    if (!cls_of_name.count(nc)) cls_of_name[nc] = out.n_cls++;
+  }
+  std::vector<uint32_t> cnt(n_windows + 1, 0);
+  for (auto& x : tmp) cnt[x.h.win + 1]++;
+  for (uint32_t i = 0; i < n_windows; i++) cnt[i + 1] += cnt[i];
+  out.ow.resize(tmp.size());
+  std::vector<uint32_t> fill(cnt.begin(), cnt.end() - 1);
+  std::vector<uint64_t> ins_sum(n_windows, 0);
+  for (auto& x : tmp) {
+    const herro_alignment& al = alns[x.aln];
+    const uint32_t wi = x.h.win;
+    const uint32_t win_start = wi * W;
+    const uint32_t win_len = (wi == n_windows - 1) ? tlen - wi * W : W;
+    OwDesc d{};
+    d.win = wi;
+    d.qid = al.qid;
+    d.cls = cls_of_name[ctx->name_class[al.qid]];
+    d.tstart = x.h.tstart;
+    d.qlen = x.h.qend - x.h.qstart;
+    d.strand = al.strand ? 1 : 0;
+    if (x.h.qend < x.h.qstart) return fail(HERRO_E_REFERENCE_PANIC, "window qend < qstart");
+    if (d.strand == 0) d.qbeg = al.qstart + x.h.qstart;
+    else {
+      if (al.qend < x.h.qend) return fail(HERRO_E_REFERENCE_PANIC, "attempt to subtract with overflow (qend - window.qend)");
+      d.qbeg = al.qend - x.h.qend;
+    }
+    d.op_begin = x.op_base + x.h.op_lo;
+    d.op_cnt = x.h.op_hi - x.h.op_lo;
+    d.start_off = x.h.start_off;
+    d.end_off = x.h.end_off;
+    d.scr_off = (uint32_t)out.scr_ops;
+    // ---- validate what the reference would assert / index (features.rs:585-679, 110-237)
+    if (x.h.op_hi <= x.h.op_lo) return fail(HERRO_E_REFERENCE_PANIC, "empty cigar slice");
+    if (d.tstart < win_start) return fail(HERRO_E_REFERENCE_PANIC, "overlap starts before its window (usize underflow)");
+    if (op_type(out.ops[d.op_begin]) == OP_I)
+      return fail(HERRO_E_UNSUPPORTED, "cigar slice starts with an insertion (leading or consecutive I ops; the reference panics or writes into the previous position)");
+    uint64_t tt = 0, qq = 0;
+    for (uint32_t k = 0; k < d.op_cnt; k++) {
+      const uint32_t op = out.ops[d.op_begin + k];
+      const uint32_t l = op_len(op);
+      if (k == 0 && d.op_cnt == 1) { if (d.end_off <= d.start_off) return fail(HERRO_E_REFERENCE_PANIC, "cigar_end_offset <= cigar_start_offset"); }
+      else if (k == 0) { if (l <= d.start_off) return fail(HERRO_E_REFERENCE_PANIC, "op length <= cigar_start_offset"); }
+      const uint32_t e = eff_len(op, k, d.op_cnt, d.start_off, d.end_off);
+      if (e == 0) return fail(HERRO_E_REFERENCE_PANIC, "Operation length cannot be 0");
+      if (op_type(op) != OP_I) tt += e;
+      if (op_type(op) != OP_D) qq += e;
+      if (op_type(op) == OP_I) {
+        ins_sum[wi] += l;
+        if (k + 1 < d.op_cnt && op_type(out.ops[d.op_begin + k + 1]) == OP_I)
+          return fail(HERRO_E_UNSUPPORTED, "consecutive insertion ops in a CIGAR (never produced by minimap2)");
+      }
+    }
+    if ((uint64_t)(d.tstart - win_start) + tt > win_len) return fail(HERRO_E_REFERENCE_PANIC, "cigar slice overruns the target window");
+    if (qq > d.qlen) return fail(HERRO_E_REFERENCE_PANIC, "cigar slice overruns the query region");
+    if ((uint64_t)d.qbeg + d.qlen > ctx->read_len[al.qid]) return fail(HERRO_E_REFERENCE_PANIC, "query region exceeds the query read");
+    out.scr_ops += d.op_cnt;
+    out.alg_read_bytes += (uint64_t)d.qlen + (d.qlen + 3) / 4;
+    out.alg_op_bytes += (uint64_t)d.op_cnt * 4;
+    out.ow[fill[wi]++] = d;
+  }
+  for (uint32_t wi = 0; wi < n_windows; wi++) {
+    WinDesc wd{};
+    wd.rid = rid; wd.wid = wi; wd.n_wids = n_windows;
+    wd.tstart = wi * W;
+    wd.win_len = (wi == n_windows - 1) ? tlen - wi * W : W;
+    wd.ow_begin = cnt[wi];
+    wd.ow_cnt = cnt[wi + 1] - cnt[wi];
+    if (wd.ow_cnt > 4000) return fail(HERRO_E_UNSUPPORTED, "more than 4000 overlaps in one window");
+    const uint64_t lub = ((uint64_t)wd.win_len + std::min<uint64_t>(ins_sum[wi], (uint64_t)50 * wd.win_len) + 15) & ~15ull;
+    wd.lub = (uint32_t)lub;
+    out.alg_read_bytes += (uint64_t)wd.win_len + (wd.win_len + 3) / 4;
+    out.win.push_back(wd);
+  }
+}
+}  // namespace
+
 // ---- job -------------------------------------------------------------------------------------------
 herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* rids, const uint64_t* aln_off,
                             const herro_alignment* alns, uint32_t W) {
@@ -435,121 +557,57 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   job->W = W;
   job->n_targets = n_targets;
   job->tgt_win_off.assign(n_targets + 1, 0);
+  // ---- per-target host work (CIGAR parse, windowing, validation) is independent: run it on a pool of
+  // threads, each target into its own buffers with target-local offsets, then merge in target order.
+  std::vector<TargetOut> outs(n_targets);
+  {
+    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const char* env = getenv("HERRO_HOST_THREADS");
+    const uint32_t want = env ? (uint32_t)std::max(1, atoi(env)) : std::min(hw, 32u);
+    const uint32_t nthr = std::max(1u, std::min(want, n_targets));
+    std::atomic<uint32_t> next{0};
+    auto worker = [&]() {
+      for (;;) {
+        const uint32_t t = next.fetch_add(1);
+        if (t >= n_targets) break;
+        build_target(ctx, rids[t], alns + aln_off[t], (uint32_t)(aln_off[t + 1] - aln_off[t]), W, outs[t]);
+      }
+    };
+    if (nthr == 1) worker();
+    else {
+      std::vector<std::thread> th;
+      for (uint32_t i = 0; i < nthr; i++) th.emplace_back(worker);
+      for (auto& x : th) x.join();
+    }
+  }
   uint32_t n_cls = 0, max_cols = 1;
   uint64_t scr_ops = 0, fin_bytes = 0, row_elems = 0, pos_elems = 0;
-  std::vector<uint32_t> aops;
-  std::vector<HostOw> hows;
   for (uint32_t t = 0; t < n_targets; t++) {
-    const uint32_t rid = rids[t];
-    if (rid >= ctx->n_reads) return fail(HERRO_E_REFERENCE_PANIC, "target rid out of range (reads[rid])");
-    const uint32_t tlen = ctx->read_len[rid];
-    const uint32_t n_windows = (tlen + W - 1) / W;  // features.rs:338
-    if (n_windows > 65535) return fail(HERRO_E_UNSUPPORTED, "more than 65535 windows in a read (wid is u16 in the reference)");
-    const uint32_t win0 = (uint32_t)job->win.size();
-    // collect (window, overlap) in alignment order, then bucket by window (stable)
-    struct Tmp { HostOw h; uint32_t op_base; uint32_t aln; };
-    std::vector<Tmp> tmp;
-    std::unordered_map<uint32_t, uint32_t> cls_of_name;  // name class -> accumulator slot
-    std::unordered_map<uint32_t, uint32_t> last_aln_of_qid;
-    for (uint64_t a = aln_off[t]; a < aln_off[t + 1]; a++) {
-      const herro_alignment& al = alns[a];
-      if (al.tid != rid) return fail(HERRO_E_UNSUPPORTED, "alignment tid != target rid (parse_paf groups by target, overlaps.rs:189-192)");
-      if (al.qid >= ctx->n_reads) return fail(HERRO_E_REFERENCE_PANIC, "alignment qid out of range");
-      if (al.qid == rid) return fail(HERRO_E_UNSUPPORTED, "self overlap (dropped by parse_paf, overlaps.rs:175-179)");
-      if (last_aln_of_qid.count(al.qid)) return fail(HERRO_E_UNSUPPORTED, "second alignment of the same (query,target) pair (dropped by parse_paf, overlaps.rs:181-185)");
-      last_aln_of_qid[al.qid] = (uint32_t)(a - aln_off[t]);
-      if (al.tlen != tlen) return fail(HERRO_E_INVALID, "alignment tlen differs from the stored read length");
-      if (al.qend > ctx->read_len[al.qid] || al.tend > tlen) return fail(HERRO_E_REFERENCE_PANIC, "alignment coordinates exceed the read length");
-      BuildError be;
-      aops.clear();
-      if (!parse_cigar(al.cigar, al.cigar_len, aops, be)) return fail(be.code, be.msg);
-      hows.clear();
-      if (!window_alignment(aops, al, W, n_windows, hows, be)) return fail(be.code, be.msg);
-      const uint32_t op_base = (uint32_t)job->ops.size();
-      if (!hows.empty()) job->ops.insert(job->ops.end(), aops.begin(), aops.end());
-      for (auto& h : hows) tmp.push_back(Tmp{h, op_base, (uint32_t)(a - aln_off[t])});
-      const uint32_t nc = ctx->name_class[al.qid];
-      if (!cls_of_name.count(nc)) cls_of_name[nc] = n_cls++;
+    TargetOut& o = outs[t];
+    if (o.err.code != HERRO_OK) return fail(o.err.code, o.err.msg);
+    const uint32_t op_base = (uint32_t)job->ops.size(), ow_base = (uint32_t)job->ow.size(), win_base = (uint32_t)job->win.size();
+    if ((uint64_t)op_base + o.ops.size() > 0xffffffffull) return fail(HERRO_E_UNSUPPORTED, "job too large (ops exceed 2^32)");
+    job->ops.insert(job->ops.end(), o.ops.begin(), o.ops.end());
+    for (OwDesc d : o.ow) {
+      d.win += win_base; d.cls += n_cls; d.op_begin += op_base; d.scr_off += (uint32_t)scr_ops;
+      job->ow.push_back(d);
     }
-    std::vector<uint32_t> cnt(n_windows + 1, 0);
-    for (auto& x : tmp) cnt[x.h.win + 1]++;
-    for (uint32_t i = 0; i < n_windows; i++) cnt[i + 1] += cnt[i];
-    const uint32_t ow0 = (uint32_t)job->ow.size();
-    job->ow.resize(ow0 + tmp.size());
-    std::vector<uint32_t> fill(cnt.begin(), cnt.end() - 1);
-    std::vector<uint64_t> ins_sum(n_windows, 0);
-    for (auto& x : tmp) {
-      const herro_alignment& al = alns[aln_off[t] + x.aln];
-      const uint32_t wi = x.h.win;
-      const uint32_t win_start = wi * W;
-      const uint32_t win_len = (wi == n_windows - 1) ? tlen - wi * W : W;
-      OwDesc d{};
-      d.win = win0 + wi;
-      d.qid = al.qid;
-      d.cls = cls_of_name[ctx->name_class[al.qid]];
-      d.tstart = x.h.tstart;
-      d.qlen = x.h.qend - x.h.qstart;
-      d.strand = al.strand ? 1 : 0;
-      if (x.h.qend < x.h.qstart) return fail(HERRO_E_REFERENCE_PANIC, "window qend < qstart");
-      if (d.strand == 0) d.qbeg = al.qstart + x.h.qstart;
-      else {
-        if (al.qend < x.h.qend) return fail(HERRO_E_REFERENCE_PANIC, "attempt to subtract with overflow (qend - window.qend)");
-        d.qbeg = al.qend - x.h.qend;
-      }
-      d.op_begin = x.op_base + x.h.op_lo;
-      d.op_cnt = x.h.op_hi - x.h.op_lo;
-      d.start_off = x.h.start_off;
-      d.end_off = x.h.end_off;
-      d.scr_off = (uint32_t)scr_ops;
-      // ---- validate what the reference would assert / index (features.rs:585-679, 110-237)
-      if (x.h.op_hi <= x.h.op_lo) return fail(HERRO_E_REFERENCE_PANIC, "empty cigar slice");
-      if (d.tstart < win_start) return fail(HERRO_E_REFERENCE_PANIC, "overlap starts before its window (usize underflow)");
-      if (op_type(job->ops[d.op_begin]) == OP_I)
-        return fail(HERRO_E_UNSUPPORTED, "cigar slice starts with an insertion (leading or consecutive I ops; the reference panics or writes into the previous position)");
-      uint64_t tt = 0, qq = 0;
-      for (uint32_t k = 0; k < d.op_cnt; k++) {
-        const uint32_t op = job->ops[d.op_begin + k];
-        const uint32_t l = op_len(op);
-        if (k == 0 && d.op_cnt == 1) { if (d.end_off <= d.start_off) return fail(HERRO_E_REFERENCE_PANIC, "cigar_end_offset <= cigar_start_offset"); }
-        else if (k == 0) { if (l <= d.start_off) return fail(HERRO_E_REFERENCE_PANIC, "op length <= cigar_start_offset"); }
-        const uint32_t e = eff_len(op, k, d.op_cnt, d.start_off, d.end_off);
-        if (e == 0) return fail(HERRO_E_REFERENCE_PANIC, "Operation length cannot be 0");
-        if (op_type(op) != OP_I) tt += e;
-        if (op_type(op) != OP_D) qq += e;
-        if (op_type(op) == OP_I) {
-          ins_sum[wi] += l;
-          if (k + 1 < d.op_cnt && op_type(job->ops[d.op_begin + k + 1]) == OP_I)
-            return fail(HERRO_E_UNSUPPORTED, "consecutive insertion ops in a CIGAR (never produced by minimap2)");
-        }
-      }
-      if ((uint64_t)(d.tstart - win_start) + tt > win_len) return fail(HERRO_E_REFERENCE_PANIC, "cigar slice overruns the target window");
-      if (qq > d.qlen) return fail(HERRO_E_REFERENCE_PANIC, "cigar slice overruns the query region");
-      if ((uint64_t)d.qbeg + d.qlen > ctx->read_len[al.qid]) return fail(HERRO_E_REFERENCE_PANIC, "query region exceeds the query read");
-      scr_ops += d.op_cnt;
-      job->alg_read_bytes += (uint64_t)d.qlen + (d.qlen + 3) / 4;
-      job->alg_op_bytes += (uint64_t)d.op_cnt * 4;
-      job->ow[ow0 + fill[wi]++] = d;
-    }
-    for (uint32_t wi = 0; wi < n_windows; wi++) {
-      WinDesc wd{};
-      wd.rid = rid; wd.wid = wi; wd.n_wids = n_windows;
-      wd.tstart = wi * W;
-      wd.win_len = (wi == n_windows - 1) ? tlen - wi * W : W;
-      wd.ow_begin = ow0 + cnt[wi];
-      wd.ow_cnt = cnt[wi + 1] - cnt[wi];
-      const uint64_t lub = ((uint64_t)wd.win_len + std::min<uint64_t>(ins_sum[wi], (uint64_t)50 * wd.win_len) + 15) & ~15ull;
-      wd.lub = (uint32_t)lub;
+    for (WinDesc wd : o.win) {
+      wd.ow_begin += ow_base;
       wd.col_off = 0;
-      wd.fin_off = fin_bytes; fin_bytes += (uint64_t)HERRO_ROWS * lub;
-      wd.row_off = row_elems; row_elems += lub;
+      wd.fin_off = fin_bytes; fin_bytes += (uint64_t)HERRO_ROWS * wd.lub;
+      wd.row_off = row_elems; row_elems += wd.lub;
       wd.pos_off = pos_elems; pos_elems += (uint64_t)W + 1;
       for (uint32_t r0 = 0; r0 < wd.lub; r0 += HERRO_TILE) { job->tile_win.push_back((uint32_t)job->win.size()); job->tile_r0.push_back(r0); }
-      if (wd.ow_cnt > 4000) return fail(HERRO_E_UNSUPPORTED, "more than 4000 overlaps in one window");
       max_cols = std::max(max_cols, wd.ow_cnt + 1);
-      job->alg_read_bytes += (uint64_t)wd.win_len + (wd.win_len + 3) / 4;
       job->win.push_back(wd);
     }
+    n_cls += o.n_cls;
+    scr_ops += o.scr_ops;
+    job->alg_read_bytes += o.alg_read_bytes;
+    job->alg_op_bytes += o.alg_op_bytes;
     job->tgt_win_off[t + 1] = (uint32_t)job->win.size();
+    o = TargetOut();  // release
   }
   if (scr_ops > 0xffffffffull) return fail(HERRO_E_UNSUPPORTED, "job too large (op scratch exceeds 2^32)");
   job->row_elems = row_elems;
