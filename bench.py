@@ -73,6 +73,9 @@ def main():
                     help="batches per launch group: the windows of GROUP consecutive steps are featurised and run "
                          "through the model in one set of kernel launches (each window keeps its own batch's padding)")
     ap.add_argument("--precision", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent contexts (HIP streams) per GPU, each driven by its own host thread, like the "
+                         "reference's concurrent feature / inference threads per device (lib.rs:154-200)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -91,47 +94,74 @@ def main():
     from herro_amd import api, model_io, synth
     W, n_ovl = 4096, 32
     targets_per_step = args.batch // 4
-    ctx = api.Context(local)
     path, _ = model_io.default_model_file(os.path.join(ROOT, "tests", "_cache"))
-    ctx.load_model(path)
-    ctx.set_precision(args.precision)
     G = max(1, min(args.group, args.steps))
     n_full, rem = divmod(args.steps, G)
-    pool = max(1, min(args.pool, n_full))
-    n_t = pool * G * targets_per_step + rem * targets_per_step
+    NS = max(1, min(args.streams, n_full)) if n_full else 1
+    pool = max(1, min(args.pool, (n_full + NS - 1) // NS if n_full else 1))
+    n_jobs = NS * pool
+    n_t = n_jobs * G * targets_per_step + rem * targets_per_step
     sb = synth.generate(n_t, 4 * W, n_ovl, seed=synth.SEED + 2 + 1000 * rank)
-    ctx.set_reads(sb.seq, sb.qual, sb.off)
-    jobs = [api.job_from_synth(ctx, sb, W, range(i * G * targets_per_step, (i + 1) * G * targets_per_step))
-            for i in range(pool)]
-    rem_job = api.job_from_synth(ctx, sb, W, range(pool * G * targets_per_step, n_t)) if rem else None
-    assert all(j.n_windows == G * args.batch for j in jobs)
+    ctxs = []
+    for s_i in range(NS):
+        c = api.Context(local)
+        c.load_model(path)
+        c.set_precision(args.precision)
+        c.set_reads(sb.seq, sb.qual, sb.off)
+        ctxs.append(c)
+    ctx = ctxs[0]
+    t0 = time.perf_counter()
+    jobs = [[api.job_from_synth(ctxs[s_i], sb, W, range((s_i * pool + i) * G * targets_per_step,
+                                                          (s_i * pool + i + 1) * G * targets_per_step))
+             for i in range(pool)] for s_i in range(NS)]
+    host_prepare_s = time.perf_counter() - t0
+    rem_job = api.job_from_synth(ctx, sb, W, range(n_jobs * G * targets_per_step, n_t)) if rem else None
+    assert all(j.n_windows == G * args.batch for js in jobs for j in js)
 
     def run_job(j):
         j.featurize()
         j.infer(args.batch, 1)
         j.consensus()      # corrected bases stay in HBM (≈4 KB/window); only they would cross PCIe
 
+    import threading
+
     def run_steps(n_steps):
-        """exactly n_steps batches of `batch` windows"""
+        """exactly n_steps batches of `batch` windows, launch groups dealt round-robin to the streams"""
         nf, r = divmod(n_steps, G)
-        for i in range(nf):
-            run_job(jobs[i % pool])
+
+        def worker(s_i):
+            for i in range(s_i, nf, NS):
+                run_job(jobs[s_i][(i // NS) % pool])
+            ctxs[s_i].synchronize()
+
+        if NS == 1:
+            worker(0)
+        else:
+            th = [threading.Thread(target=worker, args=(s_i,)) for s_i in range(NS)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
         if r:
             assert rem_job is not None and r == rem
             run_job(rem_job)
+            ctx.synchronize()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        ctx.synchronize()
+        for c in ctxs:
+            c.synchronize()
 
-    for i in range(max(1, (args.warmup + G - 1) // G)):
-        run_job(jobs[i % pool])
+    for s_i in range(NS):
+        for i in range(max(1, (args.warmup + G * NS - 1) // (G * NS))):
+            run_job(jobs[s_i][i % pool])
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps)
-    ctx.synchronize()
+    for c in ctxs:
+        c.synchronize()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     barrier()
@@ -141,21 +171,26 @@ def main():
         el = float(tt.item())
 
     # ---- per-kernel durations with HIP events on the launch stream (second pass, same steps)
-    st = jobs[0].stats()
-    launches = n_full + (1 if rem else 0)
+    # (single stream, so that kernel durations are not inflated by the other stream's kernels)
+    st = jobs[0][0].stats()
     ctx.timing_enable(True)
     ctx.timing_reset()
-    run_steps(args.steps)
+    n_timed = max(1, min(n_full, 4)) if n_full else 0
+    for i in range(n_timed):
+        run_job(jobs[0][i % pool])
+    if not n_full:
+        run_job(rem_job)
     ctx.synchronize()
     tm = ctx.timing()
     ctx.timing_enable(False)
+    timed_steps = n_timed * G if n_full else rem
 
     if rank == 0:
         total_windows = args.steps * args.batch * world
         kern = {k: {"ms_total": v[0], "calls": v[1], "avg_us": 1e3 * v[0] / max(v[1], 1)} for k, v in tm.items()}
         feat_names = ["ow_stats", "win_rank", "pass1_pos", "select_layout", "tile_plan", "final_tiles", "sup_compact"]
-        feat_ms = sum(tm[k][0] for k in feat_names if k in tm) / args.steps
-        model_ms = sum(v[0] for k, v in tm.items() if k not in feat_names) / args.steps
+        feat_ms = sum(tm[k][0] for k in feat_names if k in tm) / timed_steps
+        model_ms = sum(v[0] for k, v in tm.items() if k not in feat_names) / timed_steps
         # ---- algorithmic work per launch (one launch = G steps = G*batch windows); DESIGN.md §4/§5
         per_job = {k: float(v) for k, v in st.items()}
         n_cols = 1 + n_ovl
@@ -208,7 +243,8 @@ def main():
             "config": {"workload": "synthetic windows, 4096 bp, 32 overlaps each, batch=128, 1xMI355X per rank "
                                    "(BASELINE configs[2])", "batch": args.batch, "window": W, "overlaps": n_ovl,
                        "mean_len": st["sum_len"] / (G * args.batch), "mean_informative": st["sum_supported"] / (G * args.batch),
-                       "model_windows_per_batch": st["n_model_windows"] / G, "batches_per_launch_group": G},
+                       "model_windows_per_batch": st["n_model_windows"] / G, "batches_per_launch_group": G,
+                       "streams_per_gpu": NS},
             "mbases_per_s": total_windows / el * W / 1e6,
             "roofline": roof,
             "roofline_featurize_group": {
@@ -216,14 +252,18 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": feat_bytes / G / (feat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_step": feat_bytes / G, "ms_per_step": feat_ms},
             "stage_ms_per_step": {"featurize": feat_ms, "model": model_ms},
+            "host_prepare": {"windows_per_s": n_jobs * G * args.batch / host_prepare_s,
+                             "note": "herro_job_create (CIGAR parse + windowing on a host thread pool + descriptor upload), "
+                                     "outside the timed region; includes the Python-side array packing"},
             "kernels": kern,
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(synth.SEED + 2)
         print(json.dumps(out))
-    for j in jobs + ([rem_job] if rem_job else []):
+    for j in [j for js in jobs for j in js] + ([rem_job] if rem_job else []):
         j.close()
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.destroy_process_group()
 

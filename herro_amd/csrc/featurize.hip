@@ -940,16 +940,37 @@ __device__ __forceinline__ void stage_from_plan(const JobDev& J, uint32_t tile, 
       t.h = J.chdr[p.ow];
       if ((p.cnt >> 30) & 1u) t.h.t_total = 0;
       if (t.h.t_total) {
-        const uint2* bm = J.bm + (uint64_t)t.ow * J.n_bw + t.w0;
-        for (uint32_t i = l8; i <= nspan && i < BMW && t.w0 + i < J.n_bw; i += 8) S.bm[c * BMW + i] = bm[i];
-        const uint4* md = J.md + t.h.md_off + t.r0;
-        for (uint32_t i = l8; i < t.nmd; i += 8) S.md[c * MDS + i] = md[i];
-        const uint64_t* wsrc = J.read_words + t.h.q_woff + t.word0;
-        for (uint32_t i = l8; i < t.nw; i += 8) S.words[c * WW + i] = wsrc[i];
-        if (!t.fb) {
-          const uint32_t* qsrc = reinterpret_cast<const uint32_t*>(J.read_qual + t.qg0);  // 8 pad bytes at the end
-          for (uint32_t i = l8; i < t.nq; i += 8) S.quals[c * (QB / 4) + i] = qsrc[i];
+        // all loads of a thread are independent: issue them in batches, then store to LDS
+        const uint2* __restrict__ bm = J.bm + (uint64_t)t.ow * J.n_bw + t.w0;
+        const uint4* __restrict__ md = J.md + t.h.md_off + t.r0;
+        const uint64_t* __restrict__ wsrc = J.read_words + t.h.q_woff + t.word0;
+        const uint32_t* __restrict__ qsrc = reinterpret_cast<const uint32_t*>(J.read_qual + t.qg0);  // 8 pad bytes at the end
+        const uint32_t nbm = min(min(nspan + 1u, (uint32_t)BMW), J.n_bw - t.w0);
+        // small tables: at most 2 items per thread each (BMW <= 16, MDS <= 24 -> 3, WW <= 16)
+        uint2 vb[2];
+        uint4 vm[3];
+        uint64_t vw[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) vb[k] = (l8 + 8 * k < nbm) ? bm[l8 + 8 * k] : make_uint2(0, 0);
+#pragma unroll
+        for (int k = 0; k < 3; k++) vm[k] = (l8 + 8 * k < t.nmd) ? md[l8 + 8 * k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 2; k++) vw[k] = (l8 + 8 * k < t.nw) ? wsrc[l8 + 8 * k] : 0ull;
+        const uint32_t nq = t.fb ? 0u : t.nq;
+        for (uint32_t i0 = 0; i0 < nq; i0 += 32) {  // quality dwords: 4 per thread per round
+          uint32_t vq[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) vq[k] = (i0 + l8 + 8 * k < nq) ? qsrc[i0 + l8 + 8 * k] : 0u;
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (i0 + l8 + 8 * k < nq) S.quals[c * (QB / 4) + i0 + l8 + 8 * k] = vq[k];
         }
+#pragma unroll
+        for (int k = 0; k < 2; k++) if (l8 + 8 * k < nbm) S.bm[c * BMW + l8 + 8 * k] = vb[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) if (l8 + 8 * k < t.nmd) S.md[c * MDS + l8 + 8 * k] = vm[k];
+#pragma unroll
+        for (int k = 0; k < 2; k++) if (l8 + 8 * k < t.nw) S.words[c * WW + l8 + 8 * k] = vw[k];
       }
     }
     if (l8 == 0) S.col[c] = t;

@@ -15,6 +15,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+#include <type_traits>
+
 #include "model_dev.h"
 
 namespace herro {
@@ -29,10 +32,18 @@ __device__ __forceinline__ float norm_qual(uint32_t q) {
   return __fsub_rn(__fmul_rn(QS, (float)q), QO);
 }
 
-__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+// gfx950 converts f32 -> bf16 (round to nearest even) in hardware: v_cvt_pk_bf16_f32, one instruction per
+// PAIR of values; the integer sequence it replaces was ~5 VALU ops per value and made the split epilogues
+// (and conv1's on-the-fly A tile) VALU-bound.
+typedef __bf16 hbf16x2 __attribute__((ext_vector_type(2)));
+typedef float hf32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+// (a, b) -> packed bf16 pairs hi, lo with a ~= hi.x + lo.x, b ~= hi.y + lo.y (5 instructions)
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const hf32x2 v = {a, b};
+  hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hbf16x2));
+  const hf32x2 hf = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - hf, hbf16x2));
 }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
@@ -469,118 +480,144 @@ __global__ __launch_bounds__(256) void k_patch_conv1_s(ModelDev M, BatchDev B, M
   }
 }
 
-// C[M,N] = epi(A . W^T + bias) (+R) with A given as bf16 hi/lo planes and W as [N][K] hi/lo planes.
-// 128x64 tile per workgroup, 4 waves (wave w: rows 32w..32w+31 x all 64 columns = 2x4 MFMA tiles),
-// BK = 32, next k-tile prefetched into registers while the current one is consumed from LDS.
+// C[M,N] = epi(A . W^T + bias) (+R) with A given as bf16 hi/lo planes and W as [N][K] hi/lo planes;
 // 3 MFMAs per k-step and tile: al*bh + ah*bl + ah*bh.
 static constexpr int GM = 128, GN = 64;
 // TM = 128: 4 waves x (32 rows x 64 cols); TM = 64: 4 waves x (16 rows x 64 cols) — used when the 128-row
-// grid would leave the chip under-filled (these GEMMs are latency-bound per k-step, so more resident
-// workgroups per CU is what hides the global->LDS round trip).
-template <bool OUT_SPLIT, int TM, int KB>
-__global__ __launch_bounds__(256) void k_gemm_s(const uint16_t* __restrict__ Ahi, const uint16_t* __restrict__ Alo,
+// grid would leave the chip under-filled.
+
+// ---------------------------------------------------------------------------------------------------
+// LDS-DMA GEMM (bf16x3).  Phase-mask measurements of the register-staged predecessor (global -> VGPR ->
+// ds_write, two barriers per k-step) showed its cost was additive — loop skeleton + global-load wait + MFMA
+// + epilogue, nothing overlapped.  Here tiles go global -> LDS with global_load_lds_dwordx4 (no staging VGPRs, no ds_write), three LDS
+// buffers keep two k-tiles in flight, waits are counted (vmcnt never drains inside the loop) and there is
+// ONE barrier per k-step.  Every wave stages the A rows it alone consumes plus a quarter of the B tile.
+// LDS rows are 64 bytes (BK = 32); the DMA destination is lane-linear, so the bank swizzle of the
+// fragment reads (chunk ^ (row>>1)&3) is applied on the per-lane SOURCE address (same involution).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+template <bool OUT_SPLIT, int TM>
+__global__ __launch_bounds__(256) void k_gemm_g(const uint16_t* __restrict__ Ahi, const uint16_t* __restrict__ Alo,
                                                 uint32_t lda, Weight W, float* C, uint16_t* Chi, uint16_t* Clo,
-                                                uint32_t ldc, const float* R, uint32_t M, int relu) {
-  constexpr int LDK = KB + 8;   // bf16 row stride: 16-B aligned, spreads banks
-  __shared__ __attribute__((aligned(16))) uint16_t s_raw[2 * TM * LDK + 2 * GN * LDK];
-  uint16_t* s_ah = s_raw;
-  uint16_t* s_al = s_ah + TM * LDK;
-  uint16_t* s_bh = s_al + TM * LDK;
-  uint16_t* s_bl = s_bh + GN * LDK;
-  constexpr int RI = TM / 64;   // 16-row MFMA tiles per wave
-  constexpr int CPR = KB / 8;   // 16-byte chunks per tile row
-  constexpr int RPP = 256 / CPR; // tile rows covered by one pass of the 256 threads
-  constexpr int NA = TM / RPP, NBP = GN / RPP;
+                                                uint32_t ldc, const float* R, uint32_t M, int relu, uint32_t gx, uint32_t gy) {
+  constexpr int RI = TM / 64;              // 16-row MFMA tiles per wave
+  constexpr int BS = (2 * TM + 2 * GN) * 32;  // u16 elements of one buffer: A hi, A lo, B hi, B lo tiles of 64-byte rows
+  constexpr int NBUF = 3;
+  constexpr int NP = 2 * RI + 2;           // DMA pieces (1 KiB each) a wave issues per k-tile
+  __shared__ __attribute__((aligned(1024))) uint16_t s_raw[NBUF * BS];
   const uint32_t K = W.K, N = W.N;
-  const uint32_t m0 = blockIdx.y * TM, n0 = blockIdx.x * GN;
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware tile order (8 XCDs with private L2s; workgroup b runs on XCD b % 8): every XCD owns a
+  // contiguous range of row tiles and walks (row tile, column tile) with the column fastest, so all
+  // column tiles that share an A row tile hit the same L2 instead of pulling A through the fabric 8x.
+  const uint32_t xcd = blockIdx.x & 7u, iin = blockIdx.x >> 3;
+  const uint32_t rpx = (gy + 7u) / 8u;
+  const uint32_t rt = xcd * rpx + iin / gx, ct = iin % gx;
+  if (iin / gx >= rpx || rt >= gy) return;
+  const uint32_t m0 = rt * TM, n0 = ct * GN;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t fr = lane & 15, fc = lane >> 4;
+
   f32x4 acc[RI][4];
 #pragma unroll
   for (int i = 0; i < RI; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias of this lane's four output columns, fetched once up front (as 16 predicated loads in the epilogue
+  // they were 16 serialized round trips)
+  float bs[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) bs[j] = W.bias ? W.bias[min(n0 + j * 16 + (lane & 15), N - 1)] : 0.f;
 
-  const uint32_t arow0 = tid / CPR, ac8 = (tid % CPR) * 8;
-  uint4 ra_h[NA], ra_l[NA], rb_h[NBP], rb_l[NBP];
-  auto gload = [&](uint32_t k0) {
+  // staging plan: lane l of a piece fills row (l >> 2), 16-byte slot (l & 3); rows past M / N are clamped
+  // (their products land in accumulators that are never stored)
+  const uint32_t lr = lane >> 2, lc = lane & 3;
+  const uint16_t* src[NP];
+  uint32_t dst[NP];  // byte offset of the piece inside a buffer (wave-uniform)
 #pragma unroll
-    for (int it = 0; it < NA; it++) {
-      const uint32_t row = arow0 + it * RPP;
-      ra_h[it] = make_uint4(0, 0, 0, 0);
-      ra_l[it] = make_uint4(0, 0, 0, 0);
-      if (m0 + row < M) {
-        const uint64_t o = (uint64_t)(m0 + row) * lda + k0 + ac8;
-        ra_h[it] = *reinterpret_cast<const uint4*>(Ahi + o);
-        ra_l[it] = *reinterpret_cast<const uint4*>(Alo + o);
-      }
-    }
+  for (int i = 0; i < RI; i++) {
+    const uint32_t row0 = wave * (TM / 4) + i * 16, row = row0 + lr;
+    const uint32_t ch = lc ^ ((row >> 1) & 3u);
+    const uint64_t g = (uint64_t)min(m0 + row, M - 1) * lda + ch * 8;
+    src[2 * i] = Ahi + g;
+    src[2 * i + 1] = Alo + g;
+    dst[2 * i] = row0 * 64;
+    dst[2 * i + 1] = TM * 64 + row0 * 64;
+  }
+  {
+    const uint32_t row0 = wave * 16, row = row0 + lr;
+    const uint32_t ch = lc ^ ((row >> 1) & 3u);
+    const uint64_t g = (uint64_t)min(n0 + row, N - 1) * K + ch * 8;
+    src[2 * RI] = W.hi + g;
+    src[2 * RI + 1] = W.lo + g;
+    dst[2 * RI] = 2 * TM * 64 + row0 * 64;
+    dst[2 * RI + 1] = 2 * TM * 64 + GN * 64 + row0 * 64;
+  }
+  const uint32_t lds_base = (uint32_t)(uintptr_t)s_raw;
+  auto stage = [&](uint32_t kt, uint32_t buf) {
+    const uint32_t b0 = lds_base + buf * (BS * 2);
 #pragma unroll
-    for (int it = 0; it < NBP; it++) {
-      const uint32_t row = arow0 + it * RPP;
-      rb_h[it] = make_uint4(0, 0, 0, 0);
-      rb_l[it] = make_uint4(0, 0, 0, 0);
-      if (n0 + row < N) {
-        const uint64_t o = (uint64_t)(n0 + row) * K + k0 + ac8;
-        rb_h[it] = *reinterpret_cast<const uint4*>(W.hi + o);
-        rb_l[it] = *reinterpret_cast<const uint4*>(W.lo + o);
-      }
-    }
+    for (int p = 0; p < NP; p++) glds16(src[p] + kt * 32, __builtin_amdgcn_readfirstlane(b0 + dst[p]));
   };
-  auto lstore = [&]() {
+  auto compute = [&](uint32_t buf) {
+    const uint16_t* s_ah = s_raw + buf * BS;
+    const uint16_t* s_al = s_ah + TM * 32;
+    const uint16_t* s_bh = s_al + TM * 32;
+    const uint16_t* s_bl = s_bh + GN * 32;
+    bf16x8 ah[RI], al[RI], bh[4], bl[4];
 #pragma unroll
-    for (int it = 0; it < NA; it++) {
-      const uint32_t row = arow0 + it * RPP;
-      *reinterpret_cast<uint4*>(s_ah + row * LDK + ac8) = ra_h[it];
-      *reinterpret_cast<uint4*>(s_al + row * LDK + ac8) = ra_l[it];
+    for (int i = 0; i < RI; i++) {
+      const uint32_t ar = wave * (TM / 4) + i * 16 + fr;
+      const uint32_t o = ar * 32 + (fc ^ ((ar >> 1) & 3u)) * 8;
+      ah[i] = *reinterpret_cast<const bf16x8*>(s_ah + o);
+      al[i] = *reinterpret_cast<const bf16x8*>(s_al + o);
     }
 #pragma unroll
-    for (int it = 0; it < NBP; it++) {
-      const uint32_t row = arow0 + it * RPP;
-      *reinterpret_cast<uint4*>(s_bh + row * LDK + ac8) = rb_h[it];
-      *reinterpret_cast<uint4*>(s_bl + row * LDK + ac8) = rb_l[it];
+    for (int j = 0; j < 4; j++) {
+      const uint32_t br = j * 16 + fr;
+      const uint32_t o = br * 32 + (fc ^ ((br >> 1) & 3u)) * 8;
+      bh[j] = *reinterpret_cast<const bf16x8*>(s_bh + o);
+      bl[j] = *reinterpret_cast<const bf16x8*>(s_bl + o);
     }
-  };
-
-  gload(0);
-  lstore();
-  __syncthreads();
-  const uint32_t fr = lane & 15, fk = (lane >> 4) * 8;
-  for (uint32_t k0 = 0; k0 < K; k0 += KB) {
-    const bool more = k0 + KB < K;
-    if (more) gload(k0 + KB);
 #pragma unroll
-    for (int ks = 0; ks < KB / 32; ks++) {
-      bf16x8 ah[RI], al[RI], bh[4], bl[4];
-#pragma unroll
-      for (int i = 0; i < RI; i++) {
-        ah[i] = *reinterpret_cast<const bf16x8*>(s_ah + (wave * (TM / 4) + i * 16 + fr) * LDK + ks * 32 + fk);
-        al[i] = *reinterpret_cast<const bf16x8*>(s_al + (wave * (TM / 4) + i * 16 + fr) * LDK + ks * 32 + fk);
-      }
+    for (int i = 0; i < RI; i++)
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        bh[j] = *reinterpret_cast<const bf16x8*>(s_bh + (j * 16 + fr) * LDK + ks * 32 + fk);
-        bl[j] = *reinterpret_cast<const bf16x8*>(s_bl + (j * 16 + fr) * LDK + ks * 32 + fk);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int i = 0; i < RI; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-    if (more) {
-      lstore();
-      __syncthreads();
-    }
+  };
+
+  const uint32_t nk = K / 32;
+  stage(0, 0);
+  if (nk > 1) stage(1, 1);
+  uint32_t buf = 0, nbuf = 2;  // buffer of tile k / of tile k+2
+  for (uint32_t k = 0; k < nk; k++) {
+    // this wave's pieces of tile k have landed (tile k+1 may stay in flight) ...
+    if (k + 1 < nk) wait_vmcnt<NP>(); else wait_vmcnt<0>();
+    // ... and so have everybody else's; also every wave is done reading tile k-1, whose buffer tile k+2 reuses
+    __builtin_amdgcn_s_barrier();
+    if (k + 2 < nk) stage(k + 2, nbuf);
+    compute(buf);
+    buf = buf == NBUF - 1 ? 0 : buf + 1;
+    nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
   }
+  __syncthreads();  // tiles are dead from here on (the epilogue reuses the LDS)
+
   if constexpr (OUT_SPLIT) {
-    // bias / ReLU / split, then each wave transposes its (TM/4) x 64 tile through LDS (tiles are dead:
-    // the k-loop ended with a barrier) and writes 128-byte rows of the hi / lo planes as 16-byte stores
     constexpr int OLD = GN + 8, WR = TM / 4;
-    static_assert(4 * WR * OLD <= 2 * TM * LDK + 2 * GN * LDK, "staging tile must fit the operand tiles");
+    static_assert(4 * WR * OLD <= NBUF * BS, "staging tile must fit the operand tiles");
     uint16_t* so = s_raw + wave * WR * OLD;
 #pragma unroll
     for (int plane = 0; plane < 2; plane++) {
@@ -589,10 +626,9 @@ __global__ __launch_bounds__(256) void k_gemm_s(const uint16_t* __restrict__ Ahi
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const uint32_t nl = j * 16 + (lane & 15), n = n0 + nl;
-          const float bias = (W.bias && n < N) ? W.bias[n] : 0.f;
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            float v = acc[i][j][r] + bias;
+            float v = acc[i][j][r] + bs[j];
             if (relu) v = fmaxf(v, 0.f);
             const uint16_t hb = f32_to_bf16_rne(v);
             so[(i * 16 + (lane >> 4) * 4 + r) * OLD + nl] = plane == 0 ? hb : f32_to_bf16_rne(v - bf16_to_f32(hb));
@@ -600,31 +636,46 @@ __global__ __launch_bounds__(256) void k_gemm_s(const uint16_t* __restrict__ Ahi
         }
       __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed (wave-private region)
       __builtin_amdgcn_wave_barrier();
-      uint16_t* dst = plane == 0 ? Chi : Clo;
+      uint16_t* dstp = plane == 0 ? Chi : Clo;
 #pragma unroll
       for (int it = 0; it < WR / 8; it++) {  // WR rows x 8 chunks of 16 B
         const uint32_t ch = lane + it * 64, rr = ch >> 3, c8 = (ch & 7) * 8;
         const uint32_t m = m0 + wave * WR + rr, n = n0 + c8;
-        if (m < M && n < N) *reinterpret_cast<uint4*>(dst + (uint64_t)m * ldc + n) = *reinterpret_cast<const uint4*>(so + rr * OLD + c8);
+        if (m < M && n < N) *reinterpret_cast<uint4*>(dstp + (uint64_t)m * ldc + n) = *reinterpret_cast<const uint4*>(so + rr * OLD + c8);
       }
       __builtin_amdgcn_wave_barrier();
     }
   } else {
+    // residual rows are fetched branch-free (clamped addresses) so the loads are all in flight together
+    // (no ReLU between GEMM and residual anywhere in this model; the general order is kept below)
+    if (R && !relu) {
+#pragma unroll
+      for (int i = 0; i < RI; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint32_t n = min(n0 + j * 16 + (lane & 15), N - 1);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const uint32_t m = min(m0 + wave * (TM / 4) + i * 16 + (lane >> 4) * 4 + r, M - 1);
+            acc[i][j][r] += R[(uint64_t)m * ldc + n];
+          }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < RI; i++)
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const uint32_t n = n0 + j * 16 + (lane & 15);
-        const float bias = (W.bias && n < N) ? W.bias[n] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const uint32_t m = m0 + wave * (TM / 4) + i * 16 + (lane >> 4) * 4 + r;
           if (m < M && n < N) {
-            float v = acc[i][j][r] + bias;
-            if (relu) v = fmaxf(v, 0.f);
-            const uint64_t o = (uint64_t)m * ldc + n;
-            if (R) v += R[o];
-            C[o] = v;
+            float v = acc[i][j][r] + bs[j];
+            if (relu) {
+              v = fmaxf(v, 0.f);
+              if (R) v += R[(uint64_t)m * ldc + n];
+            }
+            C[(uint64_t)m * ldc + n] = v;
           }
         }
       }
@@ -638,14 +689,16 @@ __global__ __launch_bounds__(256) void k_gemm_s(const uint16_t* __restrict__ Ahi
 // workgroup; wave w owns rows 32w..32w+31 x all columns.  The weight tile of the next k-step is
 // prefetched into registers; the y2 tile leaves through LDS as 16-byte stores of the hi / lo planes.
 static constexpr int FC2 = 128;
+static constexpr int CLD = 32;  // unpadded 64-byte LDS rows, 16-byte chunks XOR-swizzled by (row>>1)&3 (conflict-free b128 reads)
+__device__ __forceinline__ uint32_t cswz(uint32_t row, uint32_t chunk) { return chunk ^ ((row >> 1) & 3u); }
 __global__ __launch_bounds__(256) void k_conv_fused(ModelDev M, BatchDev B, ModelScratch S, uint32_t n_rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t kw = M.h.kw, c1 = M.h.c1, hh = kw / 2, P = 4 * hh + 1, K = kw * c1;
   uint16_t* s_ah = reinterpret_cast<uint16_t*>(smem);  // [128][LDH]
-  uint16_t* s_al = s_ah + GM * LDH;
-  uint16_t* s_bh = s_al + GM * LDH;                      // [128][LDH]
-  uint16_t* s_bl = s_bh + FC2 * LDH;
-  float* s_t1 = reinterpret_cast<float*>(s_bl + FC2 * LDH);  // [kw][12][c1]
+  uint16_t* s_al = s_ah + GM * CLD;
+  uint16_t* s_bh = s_al + GM * CLD;                      // [128][LDH]
+  uint16_t* s_bl = s_bh + FC2 * CLD;
+  float* s_t1 = reinterpret_cast<float*>(s_bl + FC2 * CLD);  // [kw][12][c1]
   float* s_wq = s_t1 + kw * 12 * c1;                          // [kw][c1]
   float* s_b1 = s_wq + kw * c1;                               // [c1]
   float* s_qn = s_b1 + c1;                                    // [128][P] normalised quality
@@ -708,14 +761,14 @@ __global__ __launch_bounds__(256) void k_conv_fused(ModelDev M, BatchDev B, Mode
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int j = 0; j < FC2 / 16; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const uint32_t fr = lane & 15, fk = (lane >> 4) * 8;
+  const uint32_t fr = lane & 15, fc = lane >> 4;
   for (uint32_t k0 = 0; k0 < K; k0 += BK) {
     __syncthreads();  // previous k-step's fragments are consumed (first pass: tables are complete)
 #pragma unroll
     for (int it = 0; it < 2; it++) {
       const uint32_t e = tid + it * 256, row = e >> 2, c8 = (e & 3) * 8;
-      *reinterpret_cast<uint4*>(s_bh + row * LDH + c8) = rb_h[it];
-      *reinterpret_cast<uint4*>(s_bl + row * LDH + c8) = rb_l[it];
+      *reinterpret_cast<uint4*>(s_bh + row * CLD + cswz(row, c8 >> 3) * 8) = rb_h[it];
+      *reinterpret_cast<uint4*>(s_bl + row * CLD + cswz(row, c8 >> 3) * 8) = rb_l[it];
     }
     if (k0 + BK < K) bload(k0 + BK);
     {  // A tile: conv1 (+BN folded) + ReLU of 128 rows x 32 channels of tap dl, 4 channels per thread-step
@@ -737,28 +790,26 @@ __global__ __launch_bounds__(256) void k_conv_fused(ModelDev M, BatchDev B, Mode
           }
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        const float f[4] = {v.x, v.y, v.z, v.w};
-        uint16_t hb[4], lb[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          hb[q] = f32_to_bf16_rne(f[q]);
-          lb[q] = f32_to_bf16_rne(f[q] - bf16_to_f32(hb[q]));
-        }
-        *reinterpret_cast<uint2*>(s_ah + rr * LDH + kk) = make_uint2(hb[0] | ((uint32_t)hb[1] << 16), hb[2] | ((uint32_t)hb[3] << 16));
-        *reinterpret_cast<uint2*>(s_al + rr * LDH + kk) = make_uint2(lb[0] | ((uint32_t)lb[1] << 16), lb[2] | ((uint32_t)lb[3] << 16));
+        uint32_t h01, l01, h23, l23;
+        split2(v.x, v.y, h01, l01);
+        split2(v.z, v.w, h23, l23);
+        *reinterpret_cast<uint2*>(s_ah + rr * CLD + cswz(rr, kk >> 3) * 8 + (kk & 7)) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(s_al + rr * CLD + cswz(rr, kk >> 3) * 8 + (kk & 7)) = make_uint2(l01, l23);
       }
     }
     __syncthreads();
     bf16x8 ah[2], al[2];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      ah[i] = *reinterpret_cast<const bf16x8*>(s_ah + (wave * 32 + i * 16 + fr) * LDH + fk);
-      al[i] = *reinterpret_cast<const bf16x8*>(s_al + (wave * 32 + i * 16 + fr) * LDH + fk);
+      const uint32_t ar = wave * 32 + i * 16 + fr;
+      ah[i] = *reinterpret_cast<const bf16x8*>(s_ah + ar * CLD + cswz(ar, fc) * 8);
+      al[i] = *reinterpret_cast<const bf16x8*>(s_al + ar * CLD + cswz(ar, fc) * 8);
     }
 #pragma unroll
     for (int j = 0; j < FC2 / 16; j++) {
-      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(s_bh + (j * 16 + fr) * LDH + fk);
-      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(s_bl + (j * 16 + fr) * LDH + fk);
+      const uint32_t br = j * 16 + fr;
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(s_bh + br * CLD + cswz(br, fc) * 8);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(s_bl + br * CLD + cswz(br, fc) * 8);
 #pragma unroll
       for (int i = 0; i < 2; i++) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
@@ -803,10 +854,11 @@ __global__ __launch_bounds__(256) void k_conv_fused(ModelDev M, BatchDev B, Mode
 }
 
 template <bool SPLIT, int TM>
-static void gemm_launch(dim3 grid, const uint16_t* Ahi, const uint16_t* Alo, uint32_t lda, const Weight& W, float* C,
-                        uint16_t* Chi, uint16_t* Clo, uint32_t ldc, const float* R, uint32_t M, int relu, hipStream_t st) {
-  if (W.K % 64 == 0 && W.K >= 2048) hipLaunchKernelGGL((k_gemm_s<SPLIT, TM, 64>), grid, dim3(256), 0, st, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu);
-  else hipLaunchKernelGGL((k_gemm_s<SPLIT, TM, 32>), grid, dim3(256), 0, st, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu);
+static void gemm_launch(uint32_t gx, uint32_t gy, const uint16_t* Ahi, const uint16_t* Alo, uint32_t lda, const Weight& W,
+                        float* C, uint16_t* Chi, uint16_t* Clo, uint32_t ldc, const float* R, uint32_t M, int relu,
+                        hipStream_t st) {
+  const dim3 grid(8u * ((gy + 7u) / 8u) * gx);  // 1-D, remapped inside the kernel
+  hipLaunchKernelGGL((k_gemm_g<SPLIT, TM>), grid, dim3(256), 0, st, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu, gx, gy);
 }
 
 static void gemm_s(const uint16_t* Ahi, const uint16_t* Alo, uint32_t lda, const Weight& W, float* C, uint16_t* Chi,
@@ -815,13 +867,13 @@ static void gemm_s(const uint16_t* Ahi, const uint16_t* Alo, uint32_t lda, const
   const uint32_t gx = (W.N + GN - 1) / GN;
   const bool small = (uint64_t)gx * ((M + 127) / 128) < 1536;  // < ~6 workgroups per CU with 128-row tiles
   if (small) {
-    dim3 grid(gx, (M + 63) / 64);
-    if (Chi) gemm_launch<true, 64>(grid, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu, st);
-    else gemm_launch<false, 64>(grid, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu, st);
+    const uint32_t gy = (M + 63) / 64;
+    if (Chi) gemm_launch<true, 64>(gx, gy, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu, st);
+    else gemm_launch<false, 64>(gx, gy, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu, st);
   } else {
-    dim3 grid(gx, (M + 127) / 128);
-    if (Chi) gemm_launch<true, 128>(grid, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu, st);
-    else gemm_launch<false, 128>(grid, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu, st);
+    const uint32_t gy = (M + 127) / 128;
+    if (Chi) gemm_launch<true, 128>(gx, gy, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu, st);
+    else gemm_launch<false, 128>(gx, gy, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu, st);
   }
 }
 
@@ -915,10 +967,7 @@ __global__ __launch_bounds__(128) void k_attention_s(BatchDev B, ModelScratch S,
       uint32_t ph[DH / 2], pl[DH / 2];  // the head's DH outputs as packed bf16 pairs -> 16-byte stores
 #pragma unroll
       for (int d = 0; d < DH; d += 2) {
-        const float v0 = o[d] * inv, v1 = o[d + 1] * inv;
-        const uint16_t h0 = f32_to_bf16_rne(v0), h1 = f32_to_bf16_rne(v1);
-        ph[d / 2] = h0 | ((uint32_t)h1 << 16);
-        pl[d / 2] = f32_to_bf16_rne(v0 - bf16_to_f32(h0)) | ((uint32_t)f32_to_bf16_rne(v1 - bf16_to_f32(h1)) << 16);
+        split2(o[d] * inv, o[d + 1] * inv, ph[d / 2], pl[d / 2]);
       }
 #pragma unroll
       for (int d = 0; d < DH / 8; d++) {
@@ -938,7 +987,7 @@ static void launch_model_s(const ModelDev& M, const BatchDev& B, const ModelScra
   KT_END(tm, st);
   const uint32_t P = 4 * (h.kw / 2) + 1;
   if (h.c2 == FC2 && h.c1 % 32 == 0) {
-    const size_t shm = (size_t)(2 * GM + 2 * FC2) * LDH * 2 + (size_t)(h.kw * 12 * h.c1 + h.kw * h.c1 + h.c1 + GM * P) * 4 +
+    const size_t shm = std::max<size_t>((size_t)(2 * GM + 2 * FC2) * CLD * 2, (size_t)4 * 32 * (FC2 + 8) * 2) + (size_t)(h.kw * 12 * h.c1 + h.kw * h.c1 + h.c1 + GM * P) * 4 +
                        (size_t)GM * P + (size_t)GM * h.kw + 16;
     KT_BEGIN(tm, "conv_fused", st);
     hipLaunchKernelGGL(k_conv_fused, dim3((N * HERRO_ROWS + GM - 1) / GM), dim3(256), shm, st, M, B, S, N * HERRO_ROWS);
