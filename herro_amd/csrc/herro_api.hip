@@ -395,6 +395,7 @@ static int ensure_scratch(herro_ctx* ctx, uint32_t n_tok) {
   };
   S.tok_win = (uint32_t*)A(cap * 4);
   S.tok_row = (uint32_t*)A(cap * 4);
+  S.tok_meta = (TokMeta*)A(cap * sizeof(TokMeta));
   S.y1 = (float*)A(cap * HERRO_ROWS * h.kw * h.c1 * 4);
   S.y2 = (float*)A(cap * HERRO_ROWS * h.c2 * 4);
   S.x = (float*)A(cap * h.d_model * 4);
@@ -408,7 +409,7 @@ static int ensure_scratch(herro_ctx* ctx, uint32_t n_tok) {
   S.h_hi = (uint16_t*)A(cap * h.d_model * 2); S.h_lo = (uint16_t*)A(cap * h.d_model * 2);
   S.att_hi = (uint16_t*)A(cap * h.d_model * 2); S.att_lo = (uint16_t*)A(cap * h.d_model * 2);
   S.ff_hi = (uint16_t*)A(cap * h.d_ff * 2); S.ff_lo = (uint16_t*)A(cap * h.d_ff * 2);
-  if (!S.y1_hi || !S.y1_lo || !S.y2_hi || !S.y2_lo || !S.h_hi || !S.h_lo || !S.att_hi || !S.att_lo || !S.ff_hi || !S.ff_lo ||!S.tok_win || !S.tok_row || !S.y1 || !S.y2 || !S.x || !S.hbuf || !S.qkv || !S.att || !S.ff || !S.logits) {
+  if (!S.y1_hi || !S.y1_lo || !S.y2_hi || !S.y2_lo || !S.h_hi || !S.h_lo || !S.att_hi || !S.att_lo || !S.ff_hi || !S.ff_lo ||!S.tok_win || !S.tok_row || !S.tok_meta || !S.y1 || !S.y2 || !S.x || !S.hbuf || !S.qkv || !S.att || !S.ff || !S.logits) {
     free_all(ctx->scratch_allocs);
     ctx->scratch_cap = 0;
     ctx->err = "out of device memory for model scratch (" + std::to_string(cap) + " tokens)";

@@ -54,8 +54,17 @@ __global__ void k_build_tokens(BatchDev B, ModelScratch S) {
   const uint32_t b = blockIdx.x;
   const uint32_t t0 = B.tok_off[b], t1 = B.tok_off[b + 1];
   for (uint32_t n = t0 + threadIdx.x; n < t1; n += blockDim.x) {
+    const uint32_t row = B.sup_row[B.sup_off[b] + (n - t0)];
     S.tok_win[n] = b;
-    S.tok_row[n] = B.sup_row[B.sup_off[b] + (n - t0)];
+    S.tok_row[n] = row;
+    TokMeta tm;
+    tm.plane_off = B.plane_off[b];
+    tm.plane_ld = B.plane_ld[b];
+    tm.tok_row = row;
+    tm.len = B.len[b];
+    tm.lmax = B.lmax[b];
+    tm.pad0 = tm.pad1 = 0;
+    S.tok_meta[n] = tm;
   }
 }
 
@@ -682,174 +691,216 @@ __global__ __launch_bounds__(256) void k_gemm_g(const uint16_t* __restrict__ Ahi
   }
 }
 
-// conv1 fused into the conv2 GEMM.  GEMM rows are (token, read row) pairs; their conv1 activations
-// (kw taps x c1 channels = the K axis) are computed on the fly from the window's token / quality planes
-// straight into the LDS A tile, so the [N*31, kw*c1] tensor never exists in HBM (it was the largest
-// stream of the whole model: 24 KB per token written and read back).  128 rows x 128 columns (= c2) per
-// workgroup; wave w owns rows 32w..32w+31 x all columns.  The weight tile of the next k-step is
-// prefetched into registers; the y2 tile leaves through LDS as 16-byte stores of the hi / lo planes.
+// ---------------------------------------------------------------------------------------------------
+// conv1 fused into the conv2 GEMM (kw = 3, c1 = 64, c2 = 128).  GEMM rows are (token, read row) pairs;
+// their conv1 activations (3 taps x 64 channels = the K axis, 192) are computed on the fly from the
+// window's token / quality planes straight into an LDS tile, so the [N*31, 192] tensor never exists in
+// HBM.  Phase masks on the first version of this kernel (one 128-pair tile per workgroup, weights
+// re-staged through LDS every k-step) showed 40 % of its time in the skeleton (weight staging +
+// barriers) and 28 % in the latency chain of the input gather, so this one is built the other way round:
+//   * persistent workgroups (2 per CU) walk the pair tiles;
+//   * the conv2 weights never touch LDS: wave w owns output channels 32w..32w+31 and keeps their
+//     hi / lo fragments for all 6 k-steps in 96 VGPRs, loaded once per workgroup;
+//   * MFMA roles are swapped (weights = A operand, pairs = B operand), and the channel order inside the
+//     wave's two 16-channel tiles is permuted so that a lane ends up with 8 CONSECUTIVE channels of one
+//     pair: y2 leaves as 16-byte stores straight from the accumulators, no LDS transpose;
+//   * the input patch of the next tile (and the token records of the one after) is prefetched into
+//     registers while the current tile computes;
+//   * the activation tile is double-buffered: one barrier per k-step.
+// ---------------------------------------------------------------------------------------------------
 static constexpr int FC2 = 128;
 static constexpr int CLD = 32;  // unpadded 64-byte LDS rows, 16-byte chunks XOR-swizzled by (row>>1)&3 (conflict-free b128 reads)
 __device__ __forceinline__ uint32_t cswz(uint32_t row, uint32_t chunk) { return chunk ^ ((row >> 1) & 3u); }
-__global__ __launch_bounds__(256) void k_conv_fused(ModelDev M, BatchDev B, ModelScratch S, uint32_t n_rows) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t kw = M.h.kw, c1 = M.h.c1, hh = kw / 2, P = 4 * hh + 1, K = kw * c1;
-  uint16_t* s_ah = reinterpret_cast<uint16_t*>(smem);  // [128][LDH]
-  uint16_t* s_al = s_ah + GM * CLD;
-  uint16_t* s_bh = s_al + GM * CLD;                      // [128][LDH]
-  uint16_t* s_bl = s_bh + FC2 * CLD;
-  float* s_t1 = reinterpret_cast<float*>(s_bl + FC2 * CLD);  // [kw][12][c1]
-  float* s_wq = s_t1 + kw * 12 * c1;                          // [kw][c1]
-  float* s_b1 = s_wq + kw * c1;                               // [c1]
-  float* s_qn = s_b1 + c1;                                    // [128][P] normalised quality
-  uint8_t* s_tok = reinterpret_cast<uint8_t*>(s_qn + GM * P);  // [128][P] token, 255 = outside
-  uint8_t* s_val = s_tok + GM * P;                            // [128][kw] conv1 position inside [0,lmax)?
+static constexpr int CW_TP = 128;   // pairs per tile
+static constexpr int CW_T1R = 13;   // token rows of the LDS table: 12 tokens + a zero row for cells outside the window
+static constexpr size_t CW_SHM = (size_t)2 * 2 * CW_TP * CLD * 2 + (size_t)(3 * CW_T1R * 64 + 3 * 64 + 64) * 4 + (size_t)CW_TP * 8 * 4 +
+                                 (size_t)CW_TP * 8 + (size_t)CW_TP * 4;
 
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t m0 = blockIdx.x * GM;
+__global__ __launch_bounds__(256, 2) void k_conv_w(ModelDev M, BatchDev B, ModelScratch S, uint32_t n_rows, uint32_t n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t* s_x = reinterpret_cast<uint16_t*>(smem);                 // [2 buffers][hi, lo][128][32]
+  float* s_t1 = reinterpret_cast<float*>(s_x + 2 * 2 * CW_TP * CLD);  // [3][13][64]
+  float* s_wq = s_t1 + 3 * CW_T1R * 64;                               // [3][64]
+  float* s_b1 = s_wq + 3 * 64;                                        // [64]
+  float* s_qn = s_b1 + 64;                                            // [128][8] normalised quality (5 used)
+  uint8_t* s_tok = reinterpret_cast<uint8_t*>(s_qn + CW_TP * 8);      // [128][8] token, 12 = outside
+  uint8_t* s_val = s_tok + CW_TP * 8;                                 // [128][4] conv1 position inside [0,lmax)?
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t fr = lane & 15, fg = lane >> 4;
+
+  // ---- once per workgroup: tables, weight fragments, bias
+  for (uint32_t e = tid; e < 3 * CW_T1R * 64; e += 256) {
+    const uint32_t t = e / (CW_T1R * 64), rem = e % (CW_T1R * 64), tok = rem / 64, c = rem % 64;
+    s_t1[e] = tok < 12 ? M.t1[(t * 12 + tok) * 64 + c] : 0.f;
+  }
+  for (uint32_t e = tid; e < 3 * 64; e += 256) s_wq[e] = M.wq1[e];
+  for (uint32_t e = tid; e < 64; e += 256) s_b1[e] = M.b1[e];
   const Weight& W = M.conv2;
-  // weight tile prefetch: 128 rows x 32 k of hi and lo = 2 x 512 x 16 B -> 2 + 2 uint4 per thread
-  uint4 rb_h[2], rb_l[2];
-  auto bload = [&](uint32_t k0) {
+  const uint32_t c0 = wave * 32;
+  bf16x8 wh[6][2], wl[6][2];
 #pragma unroll
-    for (int it = 0; it < 2; it++) {
-      const uint32_t e = tid + it * 256, row = e >> 2, c8 = (e & 3) * 8;
-      rb_h[it] = *reinterpret_cast<const uint4*>(W.hi + (uint64_t)row * K + k0 + c8);
-      rb_l[it] = *reinterpret_cast<const uint4*>(W.lo + (uint64_t)row * K + k0 + c8);
+  for (int jt = 0; jt < 2; jt++) {
+    // MFMA row i of tile jt <-> channel c0 + 8*(i>>2) + 4*jt + (i&3): lane group g then holds channels c0+8g..+7
+    const uint32_t ch = c0 + 8 * (fr >> 2) + 4 * jt + (fr & 3);
+#pragma unroll
+    for (int ks = 0; ks < 6; ks++) {
+      wh[ks][jt] = *reinterpret_cast<const bf16x8*>(W.hi + (uint64_t)ch * 192 + ks * 32 + fg * 8);
+      wl[ks][jt] = *reinterpret_cast<const bf16x8*>(W.lo + (uint64_t)ch * 192 + ks * 32 + fg * 8);
+    }
+  }
+  float bias8[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) bias8[q] = W.bias[c0 + 8 * fg + q];
+
+  // ---- gather: threads 0..127 fetch the 5 tokens of pair tid, threads 128..255 its 5 qualities
+  const uint32_t grr = tid & 127u;
+  const bool gq = tid >= 128;
+  const uint8_t* gplane = gq ? B.planes_q : B.planes_b;
+  struct PairMeta { uint64_t rowbase; uint32_t tok_row, len, lmax; };  // lmax = 0: no such pair
+  auto load_meta = [&](uint32_t tile) -> PairMeta {
+    const uint32_t m = tile * CW_TP + grr;
+    PairMeta r{0, 0, 0, 0};
+    if (tile < n_tiles && m < n_rows) {
+      const TokMeta tm = S.tok_meta[m / HERRO_ROWS];
+      r.rowbase = tm.plane_off + (uint64_t)(m % HERRO_ROWS) * tm.plane_ld;  // byte offset of the read row
+      r.tok_row = tm.tok_row;
+      r.len = tm.len;
+      r.lmax = tm.lmax;
+    }
+    return r;
+  };
+  auto load_cells = [&](const PairMeta& mt, uint32_t (&g)[5]) {
+#pragma unroll
+    for (int pi = 0; pi < 5; pi++) {
+      const int32_t q = (int32_t)mt.tok_row - 2 + pi;
+      uint32_t v = gq ? 0xffffffffu : 12u;  // outside [0, lmax): contributes nothing
+      if (q >= 0 && q < (int32_t)mt.lmax) v = q < (int32_t)mt.len ? (uint32_t)gplane[mt.rowbase + (uint32_t)q] : (gq ? 126u : (uint32_t)TOK_PAD);
+      g[pi] = v;
     }
   };
-  bload(0);
-  for (uint32_t e = tid; e < kw * 12 * c1; e += 256) s_t1[e] = M.t1[e];
-  for (uint32_t e = tid; e < kw * c1; e += 256) s_wq[e] = M.wq1[e];
-  for (uint32_t e = tid; e < c1; e += 256) s_b1[e] = M.b1[e];
-  for (uint32_t e = tid; e < GM * P; e += 256) {  // input patch of every row: P cells around the token's row
-    const uint32_t rr = e / P, pi = e % P, row = m0 + rr;
-    uint32_t tok = 255u;
-    float qn = 0.f;
-    if (row < n_rows) {
-      const uint32_t n = row / HERRO_ROWS, r = row % HERRO_ROWS;
-      const uint32_t b = S.tok_win[n];
-      const int32_t q = (int32_t)S.tok_row[n] - 2 * (int32_t)hh + (int32_t)pi;
-      const int32_t len = (int32_t)B.len[b], lmax = (int32_t)B.lmax[b];
-      if (q >= 0 && q < lmax) {
-        if (q < len) {
-          const uint64_t o = B.plane_off[b] + (uint64_t)r * B.plane_ld[b] + (uint32_t)q;
-          tok = B.planes_b[o];
-          qn = norm_qual(B.planes_q[o]);
-        } else {  // batch padding (inference.rs:86-97)
-          tok = TOK_PAD;
-          qn = norm_qual(126u);
-        }
-      }
-    }
-    s_tok[e] = (uint8_t)tok;
-    s_qn[e] = qn;
-  }
-  for (uint32_t e = tid; e < GM * kw; e += 256) {
-    const uint32_t rr = e / kw, dl = e % kw, row = m0 + rr;
-    uint8_t v = 0;
-    if (row < n_rows) {
-      const uint32_t n = row / HERRO_ROWS;
-      const int32_t pos = (int32_t)S.tok_row[n] + (int32_t)dl - (int32_t)hh;
-      v = (pos >= 0 && pos < (int32_t)B.lmax[S.tok_win[n]]) ? 1 : 0;  // else: conv2's zero padding
-    }
-    s_val[e] = v;
-  }
+  uint32_t g[5];
+  PairMeta mcur = load_meta(blockIdx.x);
+  load_cells(mcur, g);
+  PairMeta mnext = load_meta(blockIdx.x + gridDim.x);
 
-  f32x4 acc[2][FC2 / 16];
+  f32x4 acc[8][2];
+  const uint32_t arow = tid >> 3, kk = (tid & 7) * 4;  // activation items: rows arow + 32*it, channels kk..kk+3 of the k-step
+  __syncthreads();  // tables complete
+
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint32_t m0 = tile * CW_TP;
+    // patch of this tile: registers -> LDS
+    if (!gq) {
+      *reinterpret_cast<uint2*>(s_tok + grr * 8) = make_uint2(g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24), g[4]);
+      uint32_t vb = 0;
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+      for (int dl = 0; dl < 3; dl++) {
+        const int32_t pos = (int32_t)mcur.tok_row + dl - 1;
+        if (pos >= 0 && pos < (int32_t)mcur.lmax) vb |= 1u << (8 * dl);  // else: conv2's zero padding
+      }
+      *reinterpret_cast<uint32_t*>(s_val + grr * 4) = vb;
+    } else {
+      float qn[5];
 #pragma unroll
-    for (int j = 0; j < FC2 / 16; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const uint32_t fr = lane & 15, fc = lane >> 4;
-  for (uint32_t k0 = 0; k0 < K; k0 += BK) {
-    __syncthreads();  // previous k-step's fragments are consumed (first pass: tables are complete)
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-      const uint32_t e = tid + it * 256, row = e >> 2, c8 = (e & 3) * 8;
-      *reinterpret_cast<uint4*>(s_bh + row * CLD + cswz(row, c8 >> 3) * 8) = rb_h[it];
-      *reinterpret_cast<uint4*>(s_bl + row * CLD + cswz(row, c8 >> 3) * 8) = rb_l[it];
+      for (int pi = 0; pi < 5; pi++) qn[pi] = g[pi] != 0xffffffffu ? norm_qual(g[pi]) : 0.f;
+      *reinterpret_cast<float4*>(s_qn + grr * 8) = make_float4(qn[0], qn[1], qn[2], qn[3]);
+      s_qn[grr * 8 + 4] = qn[4];
     }
-    if (k0 + BK < K) bload(k0 + BK);
-    {  // A tile: conv1 (+BN folded) + ReLU of 128 rows x 32 channels of tap dl, 4 channels per thread-step
-      const uint32_t dl = k0 / c1, cb = k0 % c1;
+    __syncthreads();
+    // prefetch: cells of the next tile, token records of the one after
+    mcur = mnext;
+    load_cells(mcur, g);
+    mnext = load_meta(tile + 2 * gridDim.x);
+
+#pragma unroll
+    for (int pt = 0; pt < 8; pt++)
+#pragma unroll
+      for (int jt = 0; jt < 2; jt++) acc[pt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto gen = [&](auto ksc) {  // conv1 (+BN folded) + ReLU of 128 pairs x 32 channels of k-step ks -> buffer ks & 1
+      constexpr int ks = decltype(ksc)::value;
+      constexpr int dl = ks >> 1, cb = (ks & 1) * 32;
+      uint16_t* xh = s_x + (ks & 1) * (2 * CW_TP * CLD);
+      uint16_t* xl = xh + CW_TP * CLD;
+      const uint32_t c = cb + kk;
+      const float4 b1v = *reinterpret_cast<const float4*>(s_b1 + c);
+      float4 wq[3];
+#pragma unroll
+      for (int t = 0; t < 3; t++) wq[t] = *reinterpret_cast<const float4*>(s_wq + t * 64 + c);
 #pragma unroll
       for (int it = 0; it < 4; it++) {
-        const uint32_t e4 = tid + it * 256, rr = e4 >> 3, kk = (e4 & 7) * 4, c = cb + kk;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s_val[rr * kw + dl]) {
-          v = *reinterpret_cast<const float4*>(s_b1 + c);
-          for (uint32_t t = 0; t < kw; t++) {
-            const uint32_t tok = s_tok[rr * P + dl + t];
-            if (tok != 255u) {
-              const float4 tv = *reinterpret_cast<const float4*>(s_t1 + (t * 12 + tok) * c1 + c);
-              const float4 wv = *reinterpret_cast<const float4*>(s_wq + t * c1 + c);
-              const float qn = s_qn[rr * P + dl + t];
-              v.x += tv.x + wv.x * qn; v.y += tv.y + wv.y * qn; v.z += tv.z + wv.z * qn; v.w += tv.w + wv.w * qn;
-            }
-          }
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        const uint32_t rr = arow + it * 32;
+        const uint2 tk = *reinterpret_cast<const uint2*>(s_tok + rr * 8);
+        const uint64_t tk64 = (uint64_t)tk.x | ((uint64_t)tk.y << 32);
+        float4 v = b1v;
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          const uint32_t tok = (uint32_t)(tk64 >> (8 * (dl + t))) & 0xffu;
+          const float4 tv = *reinterpret_cast<const float4*>(s_t1 + (t * CW_T1R + tok) * 64 + c);
+          const float qn = s_qn[rr * 8 + dl + t];
+          v.x += tv.x + wq[t].x * qn; v.y += tv.y + wq[t].y * qn; v.z += tv.z + wq[t].z * qn; v.w += tv.w + wq[t].w * qn;
         }
+        const bool ok = s_val[rr * 4 + dl] != 0;
+        v.x = ok ? fmaxf(v.x, 0.f) : 0.f; v.y = ok ? fmaxf(v.y, 0.f) : 0.f;
+        v.z = ok ? fmaxf(v.z, 0.f) : 0.f; v.w = ok ? fmaxf(v.w, 0.f) : 0.f;
         uint32_t h01, l01, h23, l23;
         split2(v.x, v.y, h01, l01);
         split2(v.z, v.w, h23, l23);
-        *reinterpret_cast<uint2*>(s_ah + rr * CLD + cswz(rr, kk >> 3) * 8 + (kk & 7)) = make_uint2(h01, h23);
-        *reinterpret_cast<uint2*>(s_al + rr * CLD + cswz(rr, kk >> 3) * 8 + (kk & 7)) = make_uint2(l01, l23);
+        const uint32_t o = rr * CLD + cswz(rr, kk >> 3) * 8 + (kk & 7);
+        *reinterpret_cast<uint2*>(xh + o) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(xl + o) = make_uint2(l01, l23);
       }
-    }
-    __syncthreads();
-    bf16x8 ah[2], al[2];
+    };
+    auto mma = [&](auto ksc) {
+      constexpr int ks = decltype(ksc)::value;
+      const uint16_t* xh = s_x + (ks & 1) * (2 * CW_TP * CLD);
+      const uint16_t* xl = xh + CW_TP * CLD;
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const uint32_t ar = wave * 32 + i * 16 + fr;
-      ah[i] = *reinterpret_cast<const bf16x8*>(s_ah + ar * CLD + cswz(ar, fc) * 8);
-      al[i] = *reinterpret_cast<const bf16x8*>(s_al + ar * CLD + cswz(ar, fc) * 8);
-    }
+      for (int pt = 0; pt < 8; pt++) {
+        const uint32_t pr = pt * 16 + fr;
+        const uint32_t o = pr * CLD + cswz(pr, fg) * 8;
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(xh + o);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(xl + o);
 #pragma unroll
-    for (int j = 0; j < FC2 / 16; j++) {
-      const uint32_t br = j * 16 + fr;
-      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(s_bh + br * CLD + cswz(br, fc) * 8);
-      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(s_bl + br * CLD + cswz(br, fc) * 8);
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
-      }
-    }
-  }
-  // epilogue: + bias (BN folded), ReLU, split; each wave transposes its 32 x 128 tile through LDS (the
-  // A/B tiles are dead) and writes full 256-byte rows of the hi / lo planes with 16-byte stores
-  __syncthreads();
-  constexpr int OLD = FC2 + 8;  // bf16 row stride of the staging tile
-  uint16_t* so = reinterpret_cast<uint16_t*>(smem) + wave * 32 * OLD;
-#pragma unroll
-  for (int plane = 0; plane < 2; plane++) {
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < FC2 / 16; j++) {
-        const uint32_t n = j * 16 + (lane & 15);
-        const float bias = W.bias[n];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const float v = fmaxf(acc[i][j][r] + bias, 0.f);
-          const uint16_t hb = f32_to_bf16_rne(v);
-          so[(i * 16 + (lane >> 4) * 4 + r) * OLD + n] = plane == 0 ? hb : f32_to_bf16_rne(v - bf16_to_f32(hb));
+        for (int jt = 0; jt < 2; jt++) {
+          acc[pt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks][jt], bh, acc[pt][jt], 0, 0, 0);
+          acc[pt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks][jt], bl, acc[pt][jt], 0, 0, 0);
+          acc[pt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks][jt], bh, acc[pt][jt], 0, 0, 0);
         }
       }
-    // wave-private region: no workgroup barrier needed, only that this wave's LDS writes have landed
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-    __builtin_amdgcn_wave_barrier();
-    uint16_t* dst = plane == 0 ? S.y2_hi : S.y2_lo;
+    };
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+    using K4 = std::integral_constant<int, 4>; using K5 = std::integral_constant<int, 5>;
+    gen(K0{});
+    __syncthreads();
+    gen(K1{}); mma(K0{}); __syncthreads();
+    gen(K2{}); mma(K1{}); __syncthreads();
+    gen(K3{}); mma(K2{}); __syncthreads();
+    gen(K4{}); mma(K3{}); __syncthreads();
+    gen(K5{}); mma(K4{}); __syncthreads();
+    mma(K5{});
+    // epilogue: + bias (BN folded), ReLU, split; lane = pair (fr) x 8 consecutive channels (c0 + 8 fg ..)
 #pragma unroll
-    for (int it = 0; it < 8; it++) {  // 32 rows x 16 chunks of 16 B = 512 chunks / 64 lanes
-      const uint32_t ch = lane + it * 64, rr = ch >> 4, c8 = (ch & 15) * 8;
-      const uint32_t m = m0 + wave * 32 + rr;
-      if (m < n_rows)
-        *reinterpret_cast<uint4*>(dst + (uint64_t)m * FC2 + c8) = *reinterpret_cast<const uint4*>(so + rr * OLD + c8);
+    for (int pt = 0; pt < 8; pt++) {
+      const uint32_t m = m0 + pt * 16 + fr;
+      float v[8];
+#pragma unroll
+      for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[jt * 4 + r] = fmaxf(acc[pt][jt][r] + bias8[jt * 4 + r], 0.f);
+      uint4 hv, lv;
+      split2(v[0], v[1], hv.x, lv.x);
+      split2(v[2], v[3], hv.y, lv.y);
+      split2(v[4], v[5], hv.z, lv.z);
+      split2(v[6], v[7], hv.w, lv.w);
+      if (m < n_rows) {
+        const uint64_t o = (uint64_t)m * FC2 + c0 + 8 * fg;
+        *reinterpret_cast<uint4*>(S.y2_hi + o) = hv;
+        *reinterpret_cast<uint4*>(S.y2_lo + o) = lv;
+      }
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();  // the last k-step's reads are done before the next tile overwrites the patch / buffer 1
   }
 }
 
@@ -986,11 +1037,10 @@ static void launch_model_s(const ModelDev& M, const BatchDev& B, const ModelScra
   hipLaunchKernelGGL(k_build_tokens, dim3(B.n_win), dim3(64), 0, st, B, S);
   KT_END(tm, st);
   const uint32_t P = 4 * (h.kw / 2) + 1;
-  if (h.c2 == FC2 && h.c1 % 32 == 0) {
-    const size_t shm = std::max<size_t>((size_t)(2 * GM + 2 * FC2) * CLD * 2, (size_t)4 * 32 * (FC2 + 8) * 2) + (size_t)(h.kw * 12 * h.c1 + h.kw * h.c1 + h.c1 + GM * P) * 4 +
-                       (size_t)GM * P + (size_t)GM * h.kw + 16;
+  if (h.c2 == FC2 && h.c1 == 64 && h.kw == 3) {
+    const uint32_t n_tiles = (N * HERRO_ROWS + CW_TP - 1) / CW_TP;
     KT_BEGIN(tm, "conv_fused", st);
-    hipLaunchKernelGGL(k_conv_fused, dim3((N * HERRO_ROWS + GM - 1) / GM), dim3(256), shm, st, M, B, S, N * HERRO_ROWS);
+    hipLaunchKernelGGL(k_conv_w, dim3(std::min<uint32_t>(n_tiles, 512u)), dim3(256), CW_SHM, st, M, B, S, N * HERRO_ROWS, n_tiles);
     KT_END(tm, st);
   } else {
     const size_t shm = (size_t)(h.kw * 12 * h.c1 + h.kw * h.c1 + h.c1 + HERRO_ROWS * P) * 4 + (size_t)HERRO_ROWS * P * 4;

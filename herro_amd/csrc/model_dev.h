@@ -72,9 +72,19 @@ struct BatchDev {
   float* out_base;            // job-level [sum nsup][5]
 };
 
+// Everything the conv kernel needs to fetch the receptive field of one token, in one 32-byte record.
+struct __attribute__((aligned(16))) TokMeta {
+  uint64_t plane_off;  // byte offset of the window's token / quality planes
+  uint32_t plane_ld;   // plane stride
+  uint32_t tok_row;    // row of the token inside the window
+  uint32_t len, lmax;  // L' of the window, max L' of its batch (both < 65536)
+  uint32_t pad0, pad1;
+};
+
 struct ModelScratch {  // sized for n_tok tokens
   uint32_t* tok_win;  // [N] window (batch-local) of each token
   uint32_t* tok_row;  // [N] row of each token
+  TokMeta* tok_meta;  // [N]
   float* y1;          // [N][31][kw][c1]
   float* y2;          // [N][31*c2]
   float* x;           // [N][d_model] residual stream
