@@ -130,8 +130,22 @@ def main():
         nf, r = divmod(n_steps, G)
 
         def worker(s_i):
-            for i in range(s_i, nf, NS):
-                run_job(jobs[s_i][(i // NS) % pool])
+            seq = [jobs[s_i][(i // NS) % pool] for i in range(s_i, nf, NS)]
+            if pool < 2:
+                for j in seq:
+                    run_job(j)
+            else:
+                # software pipeline on one in-order stream: the featurize kernels of job k+1 are queued
+                # before the host waits for job k's per-window counts (needed to plan its batches), so
+                # the GPU works through featurize(k+1) while the host builds the descriptors of infer(k).
+                # Same work per step as run_job, only the enqueue order differs.
+                if seq:
+                    seq[0].featurize()
+                for k, j in enumerate(seq):
+                    if k + 1 < len(seq):
+                        seq[k + 1].featurize()
+                    j.infer(args.batch, 1)
+                    j.consensus()
             ctxs[s_i].synchronize()
 
         if NS == 1:

@@ -360,6 +360,8 @@ __global__ __launch_bounds__(NT) void k_win_rank(JobDev J) {
   }
   const uint32_t n_kept = block_sum(kept_local, s_wave);
   if (threadIdx.x == 0) J.win_nkept[w] = n_kept;
+  // match / mismatch tallies start from zero (pass 1, the next kernel, accumulates into them)
+  for (uint32_t i = blockIdx.x * NT + threadIdx.x; i < 2 * J.n_cls; i += gridDim.x * NT) J.nd[i] = 0;
 }
 
 // =====================================================================================================

@@ -97,7 +97,15 @@ struct herro_job {
   bool logits_on_host = false;
   std::vector<BatchPlan> batches;
   void* d_bdesc = nullptr;
+  uint64_t bdesc_cap = 0;
+  std::vector<unsigned char> blob;   // host image of d_bdesc (kept alive: its upload is asynchronous)
+  hipEvent_t ev_blob = nullptr;      // upload of blob finished
   uint64_t* d_supoff = nullptr;
+  const uint64_t* d_supoff_blob = nullptr;  // sup_off inside d_bdesc (valid once infer has run)
+  uint32_t* d_counts = nullptr;      // [3][n_win]: L', informative rows, kept overlaps (one D2H per job)
+  uint32_t* h_counts = nullptr;      // pinned
+  hipEvent_t ev_counts = nullptr;    // featurize + the copy of the counts finished
+  uint64_t logit_cap = 0;
   bool consensus_done = false, consensus_on_host = false;
   std::vector<uint32_t> h_cons_len;
   std::vector<uint8_t> h_cons_seq;
@@ -648,8 +656,8 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.slot_ow = (uint32_t*)A((uint64_t)n_ow * 4); J.rank_qid = (uint32_t*)A((uint64_t)n_ow * 4);
   J.sel_ow = (uint32_t*)A((uint64_t)n_win * 32 * 4);
   J.tplan = (struct herro::TPlan*)A((uint64_t)J.n_tiles * 32 * 32);
-  J.win_nkept = (uint32_t*)A((uint64_t)n_win * 4);
-  J.win_Lf = (uint32_t*)A((uint64_t)n_win * 4); J.win_nsup = (uint32_t*)A((uint64_t)n_win * 4);
+  job->d_counts = (uint32_t*)A((uint64_t)n_win * 12);
+  J.win_Lf = job->d_counts; J.win_nsup = job->d_counts + n_win; J.win_nkept = job->d_counts + 2ull * n_win;
   J.row_of_pos2 = (uint32_t*)A(pos_elems * 4);
   J.rowmap2 = (uint32_t*)A(row_elems * 4);
   J.sup_flag = (uint8_t*)A(row_elems);
@@ -662,6 +670,12 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
     return fail(HERRO_E_NO_DEVICE, oom ? "out of device memory for the job" : hipGetErrorString(e));
   }
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) { free_all(job->allocs); return fail(HERRO_E_NO_DEVICE, "upload failed"); }
+  if (hipHostMalloc((void**)&job->h_counts, std::max<uint64_t>((uint64_t)n_win * 12, 16), hipHostMallocDefault) != hipSuccess ||
+      hipEventCreateWithFlags(&job->ev_counts, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&job->ev_blob, hipEventDisableTiming) != hipSuccess) {
+    free_all(job->allocs);
+    return fail(HERRO_E_NO_DEVICE, "pinned buffer / event creation failed");
+  }
   return job.release();
 }
 
@@ -673,6 +687,9 @@ void herro_job_free(herro_job* job) {
   if (job->d_info) hipFree(job->d_info);
   if (job->d_base) hipFree(job->d_base);
   if (job->d_bdesc) hipFree(job->d_bdesc);
+  if (job->h_counts) hipHostFree(job->h_counts);
+  if (job->ev_counts) hipEventDestroy(job->ev_counts);
+  if (job->ev_blob) hipEventDestroy(job->ev_blob);
   if (job->d_supoff) hipFree(job->d_supoff);
   delete job;
 }
@@ -684,9 +701,12 @@ int herro_job_featurize(herro_job* job) {
   herro_ctx* ctx = job->ctx;
   hipSetDevice(ctx->device);
   if (job->J.n_win == 0) { job->featurized = true; return HERRO_OK; }
-  HIP_TRY(ctx, hipMemsetAsync(job->J.nd, 0, std::max<uint64_t>((uint64_t)job->J.n_cls * 8, 8), ctx->stream));
   launch_featurize(job->J, ctx->stream, &ctx->timer);
   HIP_TRY(ctx, hipGetLastError());
+  // the per-window counts follow the kernels into pinned memory; whoever needs them waits for the event,
+  // not for the stream, so the next job's kernels can already be queued behind this one
+  HIP_TRY(ctx, hipMemcpyAsync(job->h_counts, job->d_counts, (uint64_t)job->J.n_win * 12, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(job->ev_counts, ctx->stream));
   job->featurized = true;
   job->synced = false;
   job->inferred = false;
@@ -701,14 +721,14 @@ static int job_sync(herro_job* job) {
   if (job->synced) return HERRO_OK;
   hipSetDevice(ctx->device);
   const uint32_t n = job->J.n_win;
-  job->h_Lf.resize(n); job->h_nsup.resize(n); job->h_nkept.resize(n);
-  if (n) {
-    HIP_TRY(ctx, hipMemcpyAsync(job->h_Lf.data(), job->J.win_Lf, n * 4ull, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(job->h_nsup.data(), job->J.win_nsup, n * 4ull, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(job->h_nkept.data(), job->J.win_nkept, n * 4ull, hipMemcpyDeviceToHost, ctx->stream));
+  if (n) HIP_TRY(ctx, hipEventSynchronize(job->ev_counts));
+  job->h_Lf.assign(job->h_counts, job->h_counts + n);
+  job->h_nsup.assign(job->h_counts + n, job->h_counts + 2ull * n);
+  job->h_nkept.assign(job->h_counts + 2ull * n, job->h_counts + 3ull * n);
+  if (ctx->timer.on) {  // per-kernel timing reads its events back: needs the whole stream
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->timer.collect();
   }
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->timer.collect();
   job->sup_off.assign(n + 1, 0);
   for (uint32_t w = 0; w < n; w++) job->sup_off[w + 1] = job->sup_off[w] + job->h_nsup[w];
   job->synced = true;
@@ -726,9 +746,11 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   hipSetDevice(ctx->device);
   const uint32_t n = job->J.n_win;
   const uint64_t total_sup = job->sup_off[n];
-  if (!job->d_info) {
-    HIP_TRY(ctx, hipMalloc((void**)&job->d_info, std::max<uint64_t>(total_sup, 1) * 4));
-    HIP_TRY(ctx, hipMalloc((void**)&job->d_base, std::max<uint64_t>(total_sup, 1) * 20));
+  if (!job->d_info || job->logit_cap < total_sup) {
+    if (job->d_info) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); hipFree(job->d_info); hipFree(job->d_base); job->d_info = job->d_base = nullptr; }
+    job->logit_cap = std::max<uint64_t>(total_sup + total_sup / 8, 1);
+    HIP_TRY(ctx, hipMalloc((void**)&job->d_info, job->logit_cap * 4));
+    HIP_TRY(ctx, hipMalloc((void**)&job->d_base, job->logit_cap * 20));
   }
   // ---- plan batches (prepare_examples, inference.rs:241-250; flush rule features.rs:884-893)
   job->batches.clear();
@@ -774,7 +796,9 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
     groups.push_back(g);
     bi = g.b1;
   }
-  std::vector<unsigned char> blob;
+  if (job->d_bdesc) HIP_TRY(ctx, hipEventSynchronize(job->ev_blob));  // a previous upload of the blob is over
+  std::vector<unsigned char>& blob = job->blob;
+  blob.clear();
   auto put = [&](const void* p, size_t bytes) {
     const size_t o = (blob.size() + 15) & ~size_t(15);
     blob.resize(o + bytes);
@@ -806,12 +830,15 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
     offs.push_back(o);
     max_tok = std::max(max_tok, g.n_tok);
   }
-  if (job->d_bdesc) { hipFree(job->d_bdesc); job->d_bdesc = nullptr; }
-  if (!blob.empty()) {
-    HIP_TRY(ctx, hipMalloc(&job->d_bdesc, blob.size()));
-    HIP_TRY(ctx, hipMemcpyAsync(job->d_bdesc, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // blob is a local: finish the copy before returning
+  const size_t supoff_at = put(job->sup_off.data(), ((size_t)n + 1) * 8);  // consensus reads it from the same blob
+  if (job->bdesc_cap < blob.size()) {
+    if (job->d_bdesc) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); hipFree(job->d_bdesc); job->d_bdesc = nullptr; }
+    job->bdesc_cap = blob.size() + blob.size() / 4 + 4096;
+    HIP_TRY(ctx, hipMalloc(&job->d_bdesc, job->bdesc_cap));
   }
+  HIP_TRY(ctx, hipMemcpyAsync(job->d_bdesc, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(job->ev_blob, ctx->stream));
+  job->d_supoff_blob = (const uint64_t*)((const unsigned char*)job->d_bdesc + supoff_at);
   rc = ensure_scratch(ctx, max_tok);
   if (rc) return rc;
   for (size_t gi = 0; gi < groups.size(); gi++) {
@@ -844,13 +871,18 @@ int herro_job_consensus(herro_job* job) {
   hipSetDevice(ctx->device);
   const uint32_t n = job->J.n_win;
   if (job->sup_off.back() > 0 && !job->inferred) { ctx->err = "herro_job_infer has not run"; return HERRO_E_STATE; }
-  if (!job->d_supoff) HIP_TRY(ctx, hipMalloc((void**)&job->d_supoff, std::max<uint64_t>(n, 1) * 8));
-  if (!job->d_base) {  // no informative position anywhere: a dummy logits buffer
-    HIP_TRY(ctx, hipMalloc((void**)&job->d_info, 4));
-    HIP_TRY(ctx, hipMalloc((void**)&job->d_base, 20));
+  const uint64_t* d_so = job->d_supoff_blob;
+  if (!job->inferred || !d_so) {  // nothing informative anywhere: infer never ran for this job
+    if (!job->d_supoff) HIP_TRY(ctx, hipMalloc((void**)&job->d_supoff, std::max<uint64_t>(n, 1) * 8));
+    if (!job->d_base) {  // a dummy logits buffer
+      HIP_TRY(ctx, hipMalloc((void**)&job->d_info, 4));
+      HIP_TRY(ctx, hipMalloc((void**)&job->d_base, 20));
+      job->logit_cap = 1;
+    }
+    if (n) HIP_TRY(ctx, hipMemcpyAsync(job->d_supoff, job->sup_off.data(), n * 8ull, hipMemcpyHostToDevice, ctx->stream));
+    d_so = job->d_supoff;
   }
-  if (n) HIP_TRY(ctx, hipMemcpyAsync(job->d_supoff, job->sup_off.data(), n * 8ull, hipMemcpyHostToDevice, ctx->stream));
-  launch_consensus(job->J, job->d_supoff, job->d_base, ctx->stream, &ctx->timer);
+  launch_consensus(job->J, d_so, job->d_base, ctx->stream, &ctx->timer);
   HIP_TRY(ctx, hipGetLastError());
   job->consensus_done = true;
   job->consensus_on_host = false;

@@ -692,6 +692,153 @@ __global__ __launch_bounds__(256) void k_gemm_g(const uint16_t* __restrict__ Ahi
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K = 256 GEMM with the weights resident in registers (the layout that halved the conv kernel): a
+// workgroup owns a 128-channel slab of W (wave w: 32 channels, hi / lo fragments of all 8 k-steps =
+// 128 VGPRs, loaded once) and walks token tiles of 128 persistently.  Only the activation tile moves:
+// global -> LDS by LDS-DMA, three buffers, the pipeline runs straight across tile boundaries, one
+// barrier per k-step.  MFMA roles are swapped (weights = A operand) and the channel order of the wave's
+// two 16-channel tiles is permuted so that a lane ends up with 8 consecutive output channels of one
+// token: results leave as 16-byte stores straight from the accumulators.
+// L2 -> CU traffic per GEMM: A x (N / 128) + W once per workgroup, against A x (N / 64) + W x (M / 128)
+// for the tiled kernel above, which measured ~10 TB/s of exactly that traffic and nothing else.
+// ---------------------------------------------------------------------------------------------------
+template <bool OUT_SPLIT>
+__global__ __launch_bounds__(256, 2) void k_gemm_w(const uint16_t* __restrict__ Ahi, const uint16_t* __restrict__ Alo,
+                                                   uint32_t lda, Weight W, float* C, uint16_t* Chi, uint16_t* Clo,
+                                                   uint32_t ldc, const float* R, uint32_t M, int relu, uint32_t ns,
+                                                   uint32_t ntiles) {
+  constexpr int KS = 8, TP = 128, NBUF = 3, NP = 4;
+  constexpr int BS = 2 * TP * 32;  // u16 elements of one buffer: hi tile, lo tile of 64-byte rows
+  __shared__ __attribute__((aligned(1024))) uint16_t s_x[NBUF * BS];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t fr = lane & 15, fg = lane >> 4;
+  const uint32_t slab = blockIdx.x % ns, tl = blockIdx.x / ns, tstride = gridDim.x / ns;
+  if (tl >= ntiles) return;
+  const uint32_t c0 = slab * 128 + wave * 32;
+
+  bf16x8 wh[KS][2], wl[KS][2];
+#pragma unroll
+  for (int jt = 0; jt < 2; jt++) {
+    const uint32_t ch = c0 + 8 * (fr >> 2) + 4 * jt + (fr & 3);  // lane group g ends up with channels c0+8g..+7
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      wh[ks][jt] = *reinterpret_cast<const bf16x8*>(W.hi + (uint64_t)ch * 256 + ks * 32 + fg * 8);
+      wl[ks][jt] = *reinterpret_cast<const bf16x8*>(W.lo + (uint64_t)ch * 256 + ks * 32 + fg * 8);
+    }
+  }
+  float bias8[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) bias8[q] = W.bias ? W.bias[c0 + 8 * fg + q] : 0.f;
+
+  // staging plan: wave w moves rows 32w..32w+31 of the hi and lo tiles (4 pieces of 1 KiB per k-step);
+  // lane l of a piece fills row (l >> 2), 16-byte slot (l & 3), swizzle applied on the source address
+  const uint32_t lr = lane >> 2, lc = lane & 3;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)s_x;
+  uint64_t off_cur[2], off_nxt[2];
+  auto tile_offs = [&](uint32_t t, uint64_t (&o)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const uint32_t row = wave * 32 + i * 16 + lr;
+      o[i] = (uint64_t)min(t * TP + row, M - 1) * lda + (lc ^ ((row >> 1) & 3u)) * 8;
+    }
+  };
+  auto stage = [&](const uint64_t (&o)[2], uint32_t ks, uint32_t buf) {
+    const uint32_t b0 = lds_base + buf * (BS * 2) + wave * 32 * 64;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      glds16(Ahi + o[i] + ks * 32, __builtin_amdgcn_readfirstlane(b0 + i * 16 * 64));
+      glds16(Alo + o[i] + ks * 32, __builtin_amdgcn_readfirstlane(b0 + TP * 64 + i * 16 * 64));
+    }
+  };
+
+  f32x4 acc[8][2];
+#pragma unroll
+  for (int pt = 0; pt < 8; pt++)
+#pragma unroll
+    for (int jt = 0; jt < 2; jt++) acc[pt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  tile_offs(tl, off_cur);
+  stage(off_cur, 0, 0);
+  stage(off_cur, 1, 1);
+  uint32_t buf = 0, nbuf = 2;  // buffer of the current step / of the step two ahead
+  for (uint32_t t = tl; t < ntiles; t += tstride) {
+    const bool more = t + tstride < ntiles;
+    if (more) tile_offs(t + tstride, off_nxt);
+    auto step = [&](auto ksc) {
+      constexpr int ks = decltype(ksc)::value;
+      // this wave's pieces of the current step have landed (the next step's may stay in flight) ...
+      if (ks < KS - 1 || more) wait_vmcnt<NP>(); else wait_vmcnt<0>();
+      // ... and everybody else's; every wave is also done reading the buffer the step two ahead reuses
+      __builtin_amdgcn_s_barrier();
+      if (ks + 2 < KS) stage(off_cur, ks + 2, nbuf);
+      else if (more) stage(off_nxt, ks + 2 - KS, nbuf);
+      const uint16_t* xh = s_x + buf * BS;
+      const uint16_t* xl = xh + TP * 32;
+#pragma unroll
+      for (int pt = 0; pt < 8; pt++) {
+        const uint32_t pr = pt * 16 + fr;
+        const uint32_t o = pr * 32 + (fg ^ ((pr >> 1) & 3u)) * 8;
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(xh + o);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(xl + o);
+#pragma unroll
+        for (int jt = 0; jt < 2; jt++) {
+          acc[pt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks][jt], bh, acc[pt][jt], 0, 0, 0);
+          acc[pt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks][jt], bl, acc[pt][jt], 0, 0, 0);
+          acc[pt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks][jt], bh, acc[pt][jt], 0, 0, 0);
+        }
+      }
+      buf = buf == NBUF - 1 ? 0 : buf + 1;
+      nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
+    };
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+
+    // epilogue: lane = token (fr) x 8 consecutive channels (c0 + 8 fg ..)
+#pragma unroll
+    for (int pt = 0; pt < 8; pt++) {
+      const uint32_t m = t * TP + pt * 16 + fr;
+      const uint64_t o = (uint64_t)min(m, M - 1) * ldc + c0 + 8 * fg;
+      float v[8];
+#pragma unroll
+      for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          v[jt * 4 + r] = acc[pt][jt][r] + bias8[jt * 4 + r];
+          acc[pt][jt][r] = 0.f;
+        }
+      if (relu) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = fmaxf(v[q], 0.f);
+      }
+      if constexpr (OUT_SPLIT) {
+        uint4 hv, lv;
+        split2(v[0], v[1], hv.x, lv.x);
+        split2(v[2], v[3], hv.y, lv.y);
+        split2(v[4], v[5], hv.z, lv.z);
+        split2(v[6], v[7], hv.w, lv.w);
+        if (m < M) {
+          *reinterpret_cast<uint4*>(Chi + o) = hv;
+          *reinterpret_cast<uint4*>(Clo + o) = lv;
+        }
+      } else {
+        if (R) {
+          const float4 r0 = *reinterpret_cast<const float4*>(R + o), r1 = *reinterpret_cast<const float4*>(R + o + 4);
+          v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+          v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+        }
+        if (m < M) {
+          *reinterpret_cast<float4*>(C + o) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(C + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+      }
+    }
+    if (more) { off_cur[0] = off_nxt[0]; off_cur[1] = off_nxt[1]; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // conv1 fused into the conv2 GEMM (kw = 3, c1 = 64, c2 = 128).  GEMM rows are (token, read row) pairs;
 // their conv1 activations (3 taps x 64 channels = the K axis, 192) are computed on the fly from the
 // window's token / quality planes straight into an LDS tile, so the [N*31, 192] tensor never exists in
@@ -915,6 +1062,15 @@ static void gemm_launch(uint32_t gx, uint32_t gy, const uint16_t* Ahi, const uin
 static void gemm_s(const uint16_t* Ahi, const uint16_t* Alo, uint32_t lda, const Weight& W, float* C, uint16_t* Chi,
                    uint16_t* Clo, uint32_t ldc, const float* R, uint32_t M, int relu, hipStream_t st) {
   if (M == 0) return;
+  if (W.K == 256 && W.N % 128 == 0) {  // weights-in-registers kernel
+    const uint32_t ns = W.N / 128, ntiles = (M + 127) / 128;
+    const uint32_t per_slab = std::min<uint32_t>(ntiles, std::max<uint32_t>(512u / ns, 1u));
+    if (Chi)
+      hipLaunchKernelGGL(k_gemm_w<true>, dim3(per_slab * ns), dim3(256), 0, st, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu, ns, ntiles);
+    else
+      hipLaunchKernelGGL(k_gemm_w<false>, dim3(per_slab * ns), dim3(256), 0, st, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu, ns, ntiles);
+    return;
+  }
   const uint32_t gx = (W.N + GN - 1) / GN;
   const bool small = (uint64_t)gx * ((M + 127) / 128) < 1536;  // < ~6 workgroups per CU with 128-row tiles
   if (small) {
