@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--pool", type=int, default=2, help="distinct synthetic jobs cycled through")
-    ap.add_argument("--group", type=int, default=8,
+    ap.add_argument("--group", type=int, default=32,
                     help="batches per launch group: the windows of GROUP consecutive steps are featurised and run "
                          "through the model in one set of kernel launches (each window keeps its own batch's padding)")
     ap.add_argument("--precision", type=int, default=1)
@@ -252,7 +252,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {0: "f32", 1: "bf16x3", 2: "f32-valu"}[args.precision],
+            "dtype": {0: "f32", 1: "bf16x3", 2: "f32-valu", 3: "bf16x3"}[args.precision],
             "data": "synthetic (SURVEY §8d generator, seed 0x48455252+2; random-init weights of the assumed architecture)",
             "config": {"workload": "synthetic windows, 4096 bp, 32 overlaps each, batch=128, 1xMI355X per rank "
                                    "(BASELINE configs[2])", "batch": args.batch, "window": W, "overlaps": n_ovl,

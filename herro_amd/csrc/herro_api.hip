@@ -115,6 +115,20 @@ struct herro_job {
 
 static int job_sync(herro_job* job);
 
+// Tiles of whole windows for the fused transformer stack: consecutive windows packed greedily into at
+// most 64 tokens.  Returns the first token of each tile (+ end), or nothing if a window is too large
+// (the stack then runs layer by layer).
+static std::vector<uint32_t> token_tiles(const std::vector<uint32_t>& tok_off) {
+  std::vector<uint32_t> t(1, 0);
+  for (size_t w = 0; w + 1 < tok_off.size(); w++) {
+    const uint32_t n = tok_off[w + 1] - tok_off[w];
+    if (n > 64) return {};
+    if (tok_off[w + 1] - t.back() > 64) t.push_back(tok_off[w]);
+  }
+  if (tok_off.back() > t.back()) t.push_back(tok_off.back());
+  return t.size() > 1 ? t : std::vector<uint32_t>();
+}
+
 extern "C" {
 
 const char* herro_version(void) { return "herro_amd 0.1 (gfx950)"; }
@@ -352,6 +366,22 @@ int herro_load_model(herro_ctx* ctx, const char* path) {
     uint16_t* dh = dev_alloc_copy(hi, ctx->stream, e); ctx->model_allocs.push_back(dh);
     uint16_t* dl = dev_alloc_copy(lo, ctx->stream, e); ctx->model_allocs.push_back(dl);
     w.hi = dh; w.lo = dl;
+    if (N % 32 == 0 && K % 32 == 0) {  // fragment-ordered copy for the kernels that stream weights into registers
+      std::vector<uint16_t> ph(wt.size()), pl(wt.size());
+      const uint32_t nks = K / 32;
+      for (uint32_t n32 = 0; n32 < N / 32; n32++)
+        for (uint32_t jt = 0; jt < 2; jt++)
+          for (uint32_t ks = 0; ks < nks; ks++)
+            for (uint32_t lane = 0; lane < 64; lane++) {
+              const uint32_t fr = lane & 15, fg = lane >> 4;
+              const size_t src = (size_t)(n32 * 32 + 8 * (fr >> 2) + 4 * jt + (fr & 3)) * K + ks * 32 + fg * 8;
+              const size_t dst = ((((size_t)n32 * 2 + jt) * nks + ks) * 64 + lane) * 8;
+              for (uint32_t e8 = 0; e8 < 8; e8++) { ph[dst + e8] = hi[src + e8]; pl[dst + e8] = lo[src + e8]; }
+            }
+      uint16_t* dph = dev_alloc_copy(ph, ctx->stream, e); ctx->model_allocs.push_back(dph);
+      uint16_t* dpl = dev_alloc_copy(pl, ctx->stream, e); ctx->model_allocs.push_back(dpl);
+      w.phi = dph; w.plo = dpl;
+    }
     w.bias = vec(n + ".b", N);
     return w;
   };
@@ -382,7 +412,7 @@ int herro_load_model(herro_ctx* ctx, const char* path) {
 }
 
 int herro_set_precision(herro_ctx* ctx, int mode) {
-  if (!ctx || mode < 0 || mode > 2) return HERRO_E_INVALID;
+  if (!ctx || mode < 0 || mode > 3) return HERRO_E_INVALID;
   ctx->precision = mode;
   return HERRO_OK;
 }
@@ -805,7 +835,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
     std::memcpy(blob.data() + o, p, bytes);
     return o;
   };
-  struct Offs { size_t plane_off, plane_ld, len, lmax, tok_off, sup_off, out_off; };
+  struct Offs { size_t plane_off, plane_ld, len, lmax, tok_off, sup_off, out_off, tiles; uint32_t n_tiles; };
   std::vector<Offs> offs;
   uint32_t max_tok = 0;
   for (auto& g : groups) {
@@ -827,6 +857,9 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
     o.len = put(len.data(), B * 4); o.lmax = put(lmax.data(), B * 4);
     o.tok_off = put(tok_off.data(), (B + 1) * 4);
     o.sup_off = put(sup_o.data(), B * 8); o.out_off = put(out_o.data(), B * 8);
+    const std::vector<uint32_t> tiles = token_tiles(tok_off);
+    o.n_tiles = tiles.empty() ? 0u : (uint32_t)tiles.size() - 1;
+    o.tiles = put(tiles.data(), tiles.size() * 4);
     offs.push_back(o);
     max_tok = std::max(max_tok, g.n_tok);
   }
@@ -852,6 +885,8 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
     B.tok_off = (const uint32_t*)(base + offs[gi].tok_off);
     B.sup_off = (const uint64_t*)(base + offs[gi].sup_off);
     B.out_off = (const uint64_t*)(base + offs[gi].out_off);
+    B.n_tiles = offs[gi].n_tiles;
+    B.tile_tok0 = (const uint32_t*)(base + offs[gi].tiles);
     B.planes_b = job->J.fin_b; B.planes_q = job->J.fin_q; B.sup_row = job->J.sup_row;
     B.out_info = job->d_info; B.out_base = job->d_base;
     launch_model(ctx->M, B, ctx->S, ctx->precision, ctx->stream, &ctx->timer);
@@ -1125,9 +1160,11 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
   uint64_t* d_po = (uint64_t*)A(B * 8ull); uint32_t* d_ld = (uint32_t*)A(B * 4ull); uint32_t* d_len = (uint32_t*)A(B * 4ull); uint32_t* d_lmax = (uint32_t*)A(B * 4ull);
   uint32_t* d_to = (uint32_t*)A((B + 1) * 4ull); uint64_t* d_so = (uint64_t*)A(B * 8ull); uint64_t* d_oo = (uint64_t*)A(B * 8ull);
   uint32_t* d_sr = (uint32_t*)A(N * 4); float* d_info = (float*)A(N * 4); float* d_base = (float*)A(N * 20);
+  const std::vector<uint32_t> tiles = token_tiles(tok_off);
+  uint32_t* d_tiles = (uint32_t*)A(std::max<size_t>(tiles.size(), 1) * 4);
   int rc = HERRO_OK;
   auto done = [&](int code) { for (void* p : tmp) hipFree(p); return code; };
-  if (!d_src_b || !d_src_q || !d_pb || !d_pq || !d_po || !d_ld || !d_len || !d_lmax || !d_to || !d_so || !d_oo || !d_sr || !d_info || !d_base) {
+  if (!d_src_b || !d_src_q || !d_pb || !d_pq || !d_po || !d_ld || !d_len || !d_lmax || !d_to || !d_so || !d_oo || !d_sr || !d_info || !d_base || !d_tiles) {
     ctx->err = "out of device memory";
     return done(HERRO_E_NO_DEVICE);
   }
@@ -1142,6 +1179,7 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
   hipMemcpyAsync(d_so, sup_off.data(), B * 8ull, hipMemcpyHostToDevice, st);
   hipMemcpyAsync(d_oo, out_off.data(), B * 8ull, hipMemcpyHostToDevice, st);
   hipMemcpyAsync(d_sr, srow.data(), N * 4, hipMemcpyHostToDevice, st);
+  if (!tiles.empty()) hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, st);
   launch_transpose_blr(d_src_b, d_pb, B, L, st);
   launch_transpose_blr(d_src_q, d_pq, B, L, st);
   if ((rc = ensure_scratch(ctx, (uint32_t)N))) return done(rc);
@@ -1149,6 +1187,8 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
   bd.n_win = B; bd.n_tok = (uint32_t)N;
   bd.plane_off = d_po; bd.plane_ld = d_ld; bd.len = d_len; bd.lmax = d_lmax; bd.tok_off = d_to; bd.sup_off = d_so; bd.out_off = d_oo;
   bd.planes_b = d_pb; bd.planes_q = d_pq; bd.sup_row = d_sr; bd.out_info = d_info; bd.out_base = d_base;
+  bd.n_tiles = tiles.empty() ? 0u : (uint32_t)tiles.size() - 1;
+  bd.tile_tok0 = d_tiles;
   launch_model(ctx->M, bd, ctx->S, ctx->precision, st, &ctx->timer);
   hipError_t e = hipStreamSynchronize(st);
   if (e == hipSuccess) e = hipGetLastError();

@@ -1185,7 +1185,385 @@ __global__ __launch_bounds__(128) void k_attention_s(BatchDev B, ModelScratch S,
   }
 }
 
-static void launch_model_s(const ModelDev& M, const BatchDev& B, const ModelScratch& S, hipStream_t st, KernelTimer* tm) {
+
+// ===================================================================================================
+// The whole transformer stack in ONE kernel.
+//
+// Measured on the layer-by-layer pipeline (31 launches: LN, QKV, attention, proj, LN, FF1, FF2 per layer):
+// every one of those ~20-50 us kernels pays a ~9 us launch/ramp floor, its phases (weights in, activations
+// in, MFMA, stores out) run in lock-step over the chip and add up instead of overlapping, and all
+// activations bounce through HBM between them.  Attention never crosses a window, so a tile of whole
+// windows (<= 64 tokens) is independent through ALL layers: one workgroup takes a tile through the stack.
+//   * 8 waves; the residual stream x[64][256] lives in registers (wave w: channels 32w..32w+31, a lane
+//     holds 8 consecutive channels of 4 tokens) from the first LayerNorm to the logits;
+//   * LayerNorm output, attention output and the FF hidden chunk are bf16 hi/lo planes in LDS
+//     (XOR-swizzled 512-byte rows); nothing else touches memory;
+//   * weights stream L2 -> registers as MFMA operand fragments (every weight element is fetched once per
+//     workgroup); a wave owns 32 output channels of every GEMM;
+//   * wave = head for attention: Q, K come out of the QKV GEMM already in MFMA operand layout (weights
+//     as the A operand -> lane = token x 8 consecutive channels), V is produced with the MFMA roles
+//     swapped so that it is already "transposed"; S^T = K Q^T, softmax and O^T = V^T P^T stay in
+//     registers: the k-slot order (g, e) <-> token 32a + 16(e >> 2) + 4g + (e & 3) is the same for the
+//     P^T and V^T fragments, so no data ever has to be transposed;
+//   * FF1 -> ReLU -> FF2 is chunked over 256 hidden channels, the FF2 accumulator stays in registers.
+// ===================================================================================================
+static constexpr int LT = 64;  // tokens per tile
+static constexpr size_t LAYERS_SHM = (size_t)4 * LT * 256 * 2 + 8 * LT * 4 + LT * 4;
+
+__device__ __forceinline__ uint32_t lsw(uint32_t row, uint32_t chunk) { return row * 256 + ((chunk ^ (row & 15u)) << 3); }
+__device__ __forceinline__ bf16x8 as_bf16x8(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  return __builtin_bit_cast(bf16x8, make_uint4(a, b, c, d));
+}
+// 8 f32 values -> one MFMA k-chunk of 8 bf16, hi and lo planes
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+  uint4 h, l;
+  split2(v[0], v[1], h.x, l.x);
+  split2(v[2], v[3], h.y, l.y);
+  split2(v[4], v[5], h.z, l.z);
+  split2(v[6], v[7], h.w, l.w);
+  hi = __builtin_bit_cast(bf16x8, h);
+  lo = __builtin_bit_cast(bf16x8, l);
+}
+
+// acc[pt][jt] += W[32 channels at cb][K = 256 at kofs] x act[64 tokens][256] (LDS planes sh / sl).
+// SWAP = false: weights are the MFMA A operand -> lane (token fr of tile pt) x channels cb + 8 fg + 4 jt + r.
+// SWAP = true : activations are the A operand  -> lane (channel cb + 8 (fr>>2) + 4 jt + (fr&3)) x tokens 16 pt + 4 fg + r.
+template <bool SWAP>
+__device__ __forceinline__ void tile_gemm(const Weight& W, uint32_t cb, uint32_t kofs, const uint16_t* sh, const uint16_t* sl,
+                                          uint32_t fr, uint32_t fg, f32x4 (&acc)[4][2]) {
+  // weights arrive in two batches of 4 k-steps (64 VGPRs each): the full K at once does not fit next to the
+  // attention fragments
+  const uint32_t nks = W.K >> 5, lane = fg * 16 + fr;
+  uint64_t wo[2];  // fragment-ordered planes (Weight::phi / plo): a wave's load is one contiguous KiB
+#pragma unroll
+  for (int jt = 0; jt < 2; jt++) wo[jt] = ((((uint64_t)(cb >> 5) * 2 + jt) * nks + (kofs >> 5)) * 64 + lane) * 8;
+#pragma unroll
+  for (int kb = 0; kb < 8; kb += 4) {
+    bf16x8 wh[4][2], wl[4][2];
+#pragma unroll
+    for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+      for (int k4 = 0; k4 < 4; k4++) {
+        wh[k4][jt] = *reinterpret_cast<const bf16x8*>(W.phi + wo[jt] + (kb + k4) * 512);
+        wl[k4][jt] = *reinterpret_cast<const bf16x8*>(W.plo + wo[jt] + (kb + k4) * 512);
+      }
+    // keep the 16 loads together and ahead of the MFMAs: left alone, the scheduler sinks every load next
+    // to its first use (register pressure) and the kernel pays one L2 round trip per load
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k4 = 0; k4 < 4; k4++)
+#pragma unroll
+      for (int pt = 0; pt < 4; pt++) {
+        const uint32_t o = lsw(pt * 16 + fr, (kb + k4) * 4 + fg);
+        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(sh + o);
+        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(sl + o);
+#pragma unroll
+        for (int jt = 0; jt < 2; jt++) {
+          if (SWAP) {
+            acc[pt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wh[k4][jt], acc[pt][jt], 0, 0, 0);
+            acc[pt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wl[k4][jt], acc[pt][jt], 0, 0, 0);
+            acc[pt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wh[k4][jt], acc[pt][jt], 0, 0, 0);
+          } else {
+            acc[pt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[k4][jt], xh, acc[pt][jt], 0, 0, 0);
+            acc[pt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[k4][jt], xl, acc[pt][jt], 0, 0, 0);
+            acc[pt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[k4][jt], xh, acc[pt][jt], 0, 0, 0);
+          }
+        }
+      }
+  }
+}
+
+__global__ __launch_bounds__(512) void k_layers(ModelDev M, BatchDev B, ModelScratch S) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t* s_hh = reinterpret_cast<uint16_t*>(smem);  // LayerNorm output, hi / lo planes [64][256]
+  uint16_t* s_hl = s_hh + LT * 256;
+  uint16_t* s_ah = s_hl + LT * 256;                    // attention output, then FF hidden chunk
+  uint16_t* s_al = s_ah + LT * 256;
+  float* s_red = reinterpret_cast<float*>(s_al + LT * 256);      // [8 waves][64 tokens]
+  uint32_t* s_win = reinterpret_cast<uint32_t*>(s_red + 8 * LT);  // [64] window of each token
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t fr = lane & 15, fg = lane >> 4;
+  const uint32_t t0 = B.tile_tok0[blockIdx.x], nt = B.tile_tok0[blockIdx.x + 1] - t0;
+  const uint32_t cw = wave * 32;  // this wave's channel slab of every 256-wide GEMM output
+  const float eps = M.h.ln_eps;
+
+  if (tid < LT) s_win[tid] = tid < nt ? S.tok_win[t0 + tid] : 0xffffff00u + tid;  // padding slots: a window of their own
+  float x[4][8];
+
+  // LayerNorm of the register-resident x over the 256 channels (8 waves x 4 lane groups x 8 registers);
+  // two-pass like the unfused kernel; result goes to the s_hh / s_hl planes
+  auto layer_norm = [&](const float* __restrict__ g, const float* __restrict__ b) {
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+#pragma unroll
+      for (int pt = 0; pt < 4; pt++) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const float d = pass == 0 ? x[pt][q] : x[pt][q] - mean[pt];
+          s += pass == 0 ? d : d * d;
+        }
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (fg == 0) s_red[wave * LT + pt * 16 + fr] = s;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int pt = 0; pt < 4; pt++) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; w++) s += s_red[w * LT + pt * 16 + fr];
+        if (pass == 0) mean[pt] = s / 256.f;
+        else rstd[pt] = 1.0f / sqrtf(s / 256.f + eps);
+      }
+      __syncthreads();
+    }
+    const float4 g0 = *reinterpret_cast<const float4*>(g + cw + 8 * fg), g1 = *reinterpret_cast<const float4*>(g + cw + 8 * fg + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(b + cw + 8 * fg), b1 = *reinterpret_cast<const float4*>(b + cw + 8 * fg + 4);
+    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++) {
+      float y[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) y[q] = (x[pt][q] - mean[pt]) * rstd[pt] * gg[q] + bb[q];
+      bf16x8 hi, lo;
+      split8(y, hi, lo);
+      const uint32_t o = lsw(pt * 16 + fr, wave * 4 + fg);
+      *reinterpret_cast<bf16x8*>(s_hh + o) = hi;
+      *reinterpret_cast<bf16x8*>(s_hl + o) = lo;
+    }
+    __syncthreads();
+  };
+  // x is only needed at the residual adds and the LayerNorms: between them it is parked in the tile's own
+  // rows of S.x (nobody else reads them), which frees 32 VGPRs for the GEMM / attention phases
+  auto park_x = [&]() {
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++) {
+      const uint32_t tok = pt * 16 + fr;
+      if (tok < nt) {
+        float* xp = S.x + (uint64_t)(t0 + tok) * 256 + cw + 8 * fg;
+        *reinterpret_cast<float4*>(xp) = make_float4(x[pt][0], x[pt][1], x[pt][2], x[pt][3]);
+        *reinterpret_cast<float4*>(xp + 4) = make_float4(x[pt][4], x[pt][5], x[pt][6], x[pt][7]);
+      }
+    }
+  };
+  auto fetch_x = [&]() {
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++) {
+      const uint32_t tok = pt * 16 + fr;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+      if (tok < nt) {
+        const float* xp = S.x + (uint64_t)(t0 + tok) * 256 + cw + 8 * fg;
+        a = *reinterpret_cast<const float4*>(xp);
+        b = *reinterpret_cast<const float4*>(xp + 4);
+      }
+      x[pt][0] = a.x; x[pt][1] = a.y; x[pt][2] = a.z; x[pt][3] = a.w;
+      x[pt][4] = b.x; x[pt][5] = b.y; x[pt][6] = b.z; x[pt][7] = b.w;
+    }
+  };
+  auto zero = [](f32x4 (&a)[4][2]) {
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++)
+#pragma unroll
+      for (int jt = 0; jt < 2; jt++) a[pt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto bias8 = [&](const float* bias, uint32_t c, float (&o)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(bias + c), b = *reinterpret_cast<const float4*>(bias + c + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  };
+
+  const float scale = 1.0f / sqrtf(32.f);
+  fetch_x();
+  for (uint32_t li = 0; li < M.h.n_layers; li++) {
+    const LayerW& L = M.layer[li];
+    layer_norm(L.ln1_g, L.ln1_b);
+    if (li) park_x();  // (first layer: S.x still holds it)
+    {  // ---- attention, head = wave
+      bf16x8 qh[4], ql[4], kh[4], kl[4], vh[2][2], vl[2][2];
+      {
+        f32x4 a[4][2];
+        float bq[8];
+        zero(a);
+        tile_gemm<false>(L.qkv, cw, 0, s_hh, s_hl, fr, fg, a);
+        bias8(L.qkv.bias, cw + 8 * fg, bq);
+#pragma unroll
+        for (int pt = 0; pt < 4; pt++) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) v[q] = (a[pt][q >> 2][q & 3] + bq[q]) * scale;
+          split8(v, qh[pt], ql[pt]);
+        }
+        zero(a);
+        tile_gemm<false>(L.qkv, 256 + cw, 0, s_hh, s_hl, fr, fg, a);
+        bias8(L.qkv.bias, 256 + cw + 8 * fg, bq);
+#pragma unroll
+        for (int pt = 0; pt < 4; pt++) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) v[q] = a[pt][q >> 2][q & 3] + bq[q];
+          split8(v, kh[pt], kl[pt]);
+        }
+        zero(a);
+        tile_gemm<true>(L.qkv, 512 + cw, 0, s_hh, s_hl, fr, fg, a);
+        // lane = channel 512 + cw + 8 (fr>>2) + 4 ct + (fr&3), tokens 16 pt + 4 fg + r
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++) {
+          const float bv = L.qkv.bias[512 + cw + 8 * (fr >> 2) + 4 * ct + (fr & 3)];
+#pragma unroll
+          for (int kk = 0; kk < 2; kk++) {  // k-step of 32 tokens: slots e < 4 from token tile 2kk, e >= 4 from 2kk + 1
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = a[2 * kk + (e >> 2)][ct][e & 3] + bv;
+            split8(v, vh[ct][kk], vl[ct][kk]);
+          }
+        }
+      }
+      uint32_t wj[4][4];
+#pragma unroll
+      for (int pj = 0; pj < 4; pj++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) wj[pj][r] = s_win[pj * 16 + 4 * fg + r];
+#pragma unroll
+      for (int pi = 0; pi < 4; pi++) {
+        const uint32_t wi = s_win[pi * 16 + fr];
+        f32x4 st[4];  // S^T: lane = query pi*16 + fr, keys pj*16 + 4 fg + r
+        float m = -INFINITY;
+#pragma unroll
+        for (int pj = 0; pj < 4; pj++) {
+          st[pj] = f32x4{0.f, 0.f, 0.f, 0.f};
+          st[pj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl[pj], qh[pi], st[pj], 0, 0, 0);
+          st[pj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[pj], ql[pi], st[pj], 0, 0, 0);
+          st[pj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[pj], qh[pi], st[pj], 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            st[pj][r] = wj[pj][r] == wi ? st[pj][r] : -INFINITY;
+            m = fmaxf(m, st[pj][r]);
+          }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int pj = 0; pj < 4; pj++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float pexp = __expf(st[pj][r] - m);  // masked keys: exp(-inf) = 0; a query always sees itself
+            st[pj][r] = pexp;
+            l += pexp;
+          }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] = st[2 * kk + (e >> 2)][e & 3];
+          bf16x8 ph, pl;
+          split8(v, ph, pl);
+#pragma unroll
+          for (int ct = 0; ct < 2; ct++) {
+            o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl[ct][kk], ph, o[ct], 0, 0, 0);
+            o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[ct][kk], pl, o[ct], 0, 0, 0);
+            o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[ct][kk], ph, o[ct], 0, 0, 0);
+          }
+        }
+        // O^T: lane = query pi*16 + fr, channels cw + 8 fg + 4 ct + r
+        const float inv = 1.0f / l;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = o[e >> 2][e & 3] * inv;
+        bf16x8 hi, lo;
+        split8(v, hi, lo);
+        const uint32_t oo = lsw(pi * 16 + fr, wave * 4 + fg);
+        *reinterpret_cast<bf16x8*>(s_ah + oo) = hi;
+        *reinterpret_cast<bf16x8*>(s_al + oo) = lo;
+      }
+    }
+    __syncthreads();
+    {  // ---- output projection + residual
+      f32x4 a[4][2];
+      float bp[8];
+      zero(a);
+      tile_gemm<false>(L.proj, cw, 0, s_ah, s_al, fr, fg, a);
+      bias8(L.proj.bias, cw + 8 * fg, bp);
+      fetch_x();
+#pragma unroll
+      for (int pt = 0; pt < 4; pt++)
+#pragma unroll
+        for (int q = 0; q < 8; q++) x[pt][q] += a[pt][q >> 2][q & 3] + bp[q];
+    }
+    layer_norm(L.ln2_g, L.ln2_b);  // its barriers also fence the reuse of s_ah / s_al below
+    park_x();
+    {  // ---- feed-forward, 256 hidden channels at a time
+      f32x4 a2[4][2];
+      zero(a2);
+      for (uint32_t c = 0; c < M.h.d_ff; c += 256) {
+        f32x4 a1[4][2];
+        float b1[8];
+        zero(a1);
+        tile_gemm<false>(L.ff1, c + cw, 0, s_hh, s_hl, fr, fg, a1);
+        bias8(L.ff1.bias, c + cw + 8 * fg, b1);
+#pragma unroll
+        for (int pt = 0; pt < 4; pt++) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) v[q] = fmaxf(a1[pt][q >> 2][q & 3] + b1[q], 0.f);
+          bf16x8 hi, lo;
+          split8(v, hi, lo);
+          const uint32_t oo = lsw(pt * 16 + fr, wave * 4 + fg);
+          *reinterpret_cast<bf16x8*>(s_ah + oo) = hi;
+          *reinterpret_cast<bf16x8*>(s_al + oo) = lo;
+        }
+        __syncthreads();
+        tile_gemm<false>(L.ff2, cw, c, s_ah, s_al, fr, fg, a2);
+        __syncthreads();
+      }
+      float b2[8];
+      bias8(L.ff2.bias, cw + 8 * fg, b2);
+      fetch_x();
+#pragma unroll
+      for (int pt = 0; pt < 4; pt++)
+#pragma unroll
+        for (int q = 0; q < 8; q++) x[pt][q] += a2[pt][q >> 2][q & 3] + b2[q];
+    }
+  }
+  layer_norm(M.lnf_g, M.lnf_b);
+  // ---- heads: 16 output channels (0 info, 1..5 bases); wave w < 4 takes token tile w
+  if (wave < 4) {
+    const uint32_t pt = wave;
+    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+    const Weight& W = M.heads;
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      const bf16x8 wh = *reinterpret_cast<const bf16x8*>(W.hi + (uint64_t)fr * 256 + ks * 32 + fg * 8);
+      const bf16x8 wl = *reinterpret_cast<const bf16x8*>(W.lo + (uint64_t)fr * 256 + ks * 32 + fg * 8);
+      const uint32_t o = lsw(pt * 16 + fr, ks * 4 + fg);
+      const bf16x8 xh = *reinterpret_cast<const bf16x8*>(s_hh + o);
+      const bf16x8 xl = *reinterpret_cast<const bf16x8*>(s_hl + o);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, a, 0, 0, 0);
+    }
+    // lane = token pt*16 + fr, channels 4 fg + r
+    const uint32_t tok = pt * 16 + fr;
+    if (tok < nt) {
+      const uint32_t n = t0 + tok, b = S.tok_win[n];
+      const uint64_t o = B.out_off[b] + (n - B.tok_off[b]);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t ch = 4 * fg + r;
+        const float v = a[r] + W.bias[ch];
+        if (ch == 0) B.out_info[o] = v;
+        else if (ch < 6) B.out_base[o * 5 + (ch - 1)] = v;
+      }
+    }
+  }
+}
+
+static void launch_model_s(const ModelDev& M, const BatchDev& B, const ModelScratch& S, bool fused, hipStream_t st, KernelTimer* tm) {
   const uint32_t N = B.n_tok;
   const ModelHyper& h = M.h;
   const uint32_t D = h.d_model;
@@ -1216,6 +1594,17 @@ static void launch_model_s(const ModelDev& M, const BatchDev& B, const ModelScra
     hipLaunchKernelGGL(k_add_pe, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, st, M, S, N);
   }
   KT_END(tm, st);
+  if (fused && B.n_tiles && D == 256 && h.n_heads == 8 && h.d_ff % 256 == 0) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_layers), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LAYERS_SHM);
+      attr_set = true;
+    }
+    KT_BEGIN(tm, "layers_fused", st);
+    hipLaunchKernelGGL(k_layers, dim3(B.n_tiles), dim3(512), LAYERS_SHM, st, M, B, S);
+    KT_END(tm, st);
+    return;
+  }
   const dim3 ln_grid((N + 3) / 4);
   for (uint32_t li = 0; li < h.n_layers; li++) {
     const LayerW& L = M.layer[li];
@@ -1256,8 +1645,8 @@ void launch_model(const ModelDev& M, const BatchDev& B, const ModelScratch& S, i
                   hipStream_t st, KernelTimer* tm) {
   const uint32_t N = B.n_tok;
   if (N == 0) return;
-  if (precision == 1) {
-    launch_model_s(M, B, S, st, tm);
+  if (precision == 1 || precision == 3) {  // 3: bf16x3, layer by layer (the fused stack's fallback, selectable for A/B)
+    launch_model_s(M, B, S, precision == 1, st, tm);
     return;
   }
   const ModelHyper& h = M.h;

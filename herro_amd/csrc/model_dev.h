@@ -30,6 +30,11 @@ struct Weight {
   const float* f32 = nullptr;
   const uint16_t* hi = nullptr;
   const uint16_t* lo = nullptr;
+  // the same planes pre-shuffled into MFMA fragment order (N, K multiples of 32): element
+  //   ((((n / 32) * 2 + jt) * (K / 32) + ks) * 64 + lane) * 8 + e  =  W[32 (n/32) + 8 (fr >> 2) + 4 jt + (fr & 3)][32 ks + 8 fg + e],
+  // lane = 16 fg + fr — a wave's fragment load is one contiguous KiB instead of 16 scattered 64-byte pieces
+  const uint16_t* phi = nullptr;
+  const uint16_t* plo = nullptr;
   const float* bias = nullptr;  // [N] or null
   uint32_t K = 0, N = 0;
 };
@@ -68,6 +73,8 @@ struct BatchDev {
   const uint8_t* planes_b;    // tokens
   const uint8_t* planes_q;    // raw qualities
   const uint32_t* sup_row;    // informative rows
+  uint32_t n_tiles;           // token tiles of whole windows (<= 64 tokens each) for the fused stack; 0: not tileable
+  const uint32_t* tile_tok0;  // [n_tiles+1] first token of each tile
   float* out_info;            // job-level [sum nsup]
   float* out_base;            // job-level [sum nsup][5]
 };
