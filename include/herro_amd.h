@@ -94,7 +94,9 @@ int herro_set_reads_packed(herro_ctx* ctx, uint32_t n_reads, const uint64_t* wor
  * Flat little-endian weight file written by tools/export_weights.py (stands in for
  * tch::CModule::load_on_device, inference.rs:185). */
 int herro_load_model(herro_ctx* ctx, const char* path);
-/* precision of the model GEMMs: 0 = f32 MFMA (exact f32), 1 = bf16x3 split MFMA (default). */
+/* precision of the model GEMMs: 0 = f32 MFMA (exact f32), 1 = bf16x3 split MFMA (default; transformer stack
+ * fused into one kernel when every window has <= 64 informative rows), 2 = f32 VALU, 3 = bf16x3 with the
+ * stack run layer by layer (what mode 1 falls back to). */
 int herro_set_precision(herro_ctx* ctx, int mode);
 
 /* ---- job = a set of target reads with their alignments -------------------------------------

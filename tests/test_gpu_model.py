@@ -21,7 +21,7 @@ def _rand_batch(rng, B, L, win_len):
     return bases, quals
 
 
-@pytest.mark.parametrize("precision", [0, 1, 2])
+@pytest.mark.parametrize("precision", [0, 1, 2, 3])
 def test_model_forward_vs_twin(precision):
     import model_ref as MR
     rng = np.random.default_rng(11)
@@ -44,6 +44,36 @@ def test_model_forward_vs_twin(precision):
     assert err <= TOL
     if precision == 0:
         assert err <= 1e-4
+
+
+@pytest.mark.parametrize("counts", [
+    [63, 2, 64, 1, 1, 30, 34, 5],      # tiles 63 | 2 | 64 | 1+1+30 | 34+5: every packing boundary case
+    [1] * 70,                          # many one-token windows: 64 + 6
+    [70, 3, 64],                       # a window above the 64-token tile: the whole launch runs layer by layer
+    [0, 0, 5, 0],                      # windows without informative rows in between
+])
+def test_model_forward_tiling_edges(counts):
+    """precision 1 = the fused transformer stack over tiles of whole windows (<= 64 tokens); windows that do
+    not fit fall back to the layer-by-layer kernels.  Both must agree with the twin."""
+    import model_ref as MR
+    rng = np.random.default_rng(5 + len(counts))
+    B, L = len(counts), 120
+    win_len = rng.integers(80, L + 1, B)
+    win_len[0] = L
+    bases, quals = _rand_batch(rng, B, L, win_len)
+    idx = [np.sort(rng.choice(win_len[b], size=k, replace=False)) for b, k in enumerate(counts)]
+    lens = np.array([len(i) for i in idx], np.int32)
+    flat = np.concatenate(idx).astype(np.int32)
+    c = G.ctx()
+    c.set_precision(1)
+    info, base = c.model_forward(bases, quals, lens, flat)
+    ti, tb = MR.run_batch(G.twin(), bases, quals, lens, flat)
+    assert info.shape == ti.shape and base.shape == tb.shape
+    assert max(np.abs(info - ti).max(), np.abs(base - tb).max()) <= TOL
+    c.set_precision(3)
+    info3, base3 = c.model_forward(bases, quals, lens, flat)
+    c.set_precision(1)
+    assert max(np.abs(info3 - info).max(), np.abs(base3 - base).max()) <= 1e-4   # same arithmetic, different kernels
 
 
 def test_job_logits_and_fasta_reference_grouping():
