@@ -202,7 +202,7 @@ def main():
     if rank == 0:
         total_windows = args.steps * args.batch * world
         kern = {k: {"ms_total": v[0], "calls": v[1], "avg_us": 1e3 * v[0] / max(v[1], 1)} for k, v in tm.items()}
-        feat_names = ["ow_stats", "win_rank", "pass1_pos", "select_layout", "tile_plan", "final_tiles", "sup_compact"]
+        feat_names = ["ow_stats", "win_rank", "pass1_pos", "select_layout", "tile_plan", "final_tiles", "sup_compact", "rf_quals"]
         feat_ms = sum(tm[k][0] for k in feat_names if k in tm) / timed_steps
         model_ms = sum(v[0] for k, v in tm.items() if k not in feat_names) / timed_steps
         # ---- algorithmic work per launch (one launch = G steps = G*batch windows); DESIGN.md §4/§5
@@ -210,9 +210,16 @@ def main():
         n_cols = 1 + n_ovl
         tokens = per_job["sum_supported"]
         D, FF, C1, C2, KW = 256, 1024, 64, 128, 3
-        feat_bytes = per_job["read_bytes"] + per_job["op_bytes"] + per_job["out_bytes"]        # SURVEY §8 d
+        # SURVEY §8 d, minus what this design never moves: featurize writes the TOKEN planes only (31 L' bytes per
+        # window) and reads the 2-bit bases (1/5 of bases + qualities); the qualities are touched only inside the
+        # model's receptive fields (rf_quals: 5 rows x 31 columns per informative row, read + written)
+        NL = 4
+        rf_bytes = tokens * 5 * 31 * 2.0
+        feat_bytes = per_job["read_bytes"] / 5.0 + per_job["op_bytes"] + per_job["out_bytes"] / 2.0 + rf_bytes
         alg = {  # name -> (bound, work per launch, unit)
-            "final_tiles": ("hbm", per_job["out_bytes"] + per_job["read_bytes"] * 31.0 / n_cols, "B"),
+            "final_tiles": ("hbm", per_job["out_bytes"] / 2.0 + per_job["read_bytes"] / 5.0 * 31.0 / n_cols, "B"),
+            "conv_fused": ("mfma", 2.0 * tokens * 31 * (KW * C1) * C2, "F"),
+            "layers_fused": ("mfma", NL * (2.0 * tokens * D * 3 * D + 2.0 * tokens * D * D + 4.0 * tokens * D * FF), "F"),
             "ow_stats": ("hbm", per_job["read_bytes"] / 5.0 + per_job["op_bytes"], "B"),          # 2-bit only
             "pass1_pos": ("hbm", per_job["read_bytes"] / 5.0, "B"),
             "patch_conv1": ("hbm", tokens * 31 * KW * C1 * 4, "B"),                               # y1 hi/lo written

@@ -709,80 +709,6 @@ struct TileLds {
   uint32_t quals[WITH_QUAL ? NCOL * QB / 4 : 1];
 };
 
-template <bool WITH_QUAL>
-__device__ __forceinline__ void stage_tile(const JobDev& J, const uint32_t* ow_list, uint32_t ng, uint32_t p_lo,
-                                           uint32_t p_hi, TileLds<WITH_QUAL>& S) {
-  if (threadIdx.x < ng) {
-    TCol t;
-    t.ow = ow_list[threadIdx.x];
-    t.fb = 0; t.w0 = 0; t.r0 = 0; t.word0 = 0; t.qg0 = 0; t.nmd = 0; t.nw = 0; t.nq = 0;
-    if (t.ow != 0xffffffffu) {
-      t.h = J.chdr[t.ow];
-      const int32_t ulo = max((int32_t)p_lo - t.h.off, 0);
-      const int32_t uhi = min((int32_t)p_hi - t.h.off, (int32_t)t.h.t_total - 1);
-      if (ulo > uhi) {
-        t.h.t_total = 0;  // the tile lies outside the overlap: every cell is '.'
-      } else {
-        const uint2* bm = J.bm + (uint64_t)t.ow * J.n_bw;
-        const uint2 blo = bm[ulo >> 5], bhi = bm[uhi >> 5];
-        const uint32_t rlo = blo.y + __popc(blo.x & (0xffffffffu >> (31 - (ulo & 31))));
-        const uint32_t rhi = bhi.y + __popc(bhi.x & (0xffffffffu >> (31 - (uhi & 31))));
-        t.w0 = (uint32_t)ulo >> 5;
-        t.r0 = rlo - 1;
-        t.nmd = rhi - rlo + 1;
-        const uint4 e0 = J.md[t.h.md_off + rlo - 1], e1 = J.md[t.h.md_off + rhi - 1];
-        // query stretch [q0, q1) the tile can touch, as stored indices [s0, s1]
-        const uint32_t q0 = e0.y, q1 = e1.y + ((e1.z >> 31) ? (e1.z & 0x7fffffffu) : 0u) + e1.w + 1u;
-        const int32_t sa = t.h.sbase + t.h.sdir * (int32_t)q0, sb = t.h.sbase + t.h.sdir * (int32_t)(q1 - 1u);
-        const uint32_t s0 = (uint32_t)max(min(sa, sb), 0), s1 = (uint32_t)max(sa, sb);
-        t.word0 = s0 >> 5;
-        t.nw = (s1 >> 5) - t.word0 + 1;
-        // quality bytes are copied as aligned dwords of the global array
-        t.qg0 = (t.h.qual_off + s0) & ~3ull;
-        const uint64_t g1 = t.h.qual_off + s1;
-        t.nq = (uint32_t)((g1 - t.qg0) >> 2) + 1u;
-        if (t.nmd > MDS || t.nw > WW || (WITH_QUAL && g1 - t.qg0 >= QB)) t.fb = 1;
-      }
-    }
-    S.col[threadIdx.x] = t;
-  }
-  __syncthreads();
-  for (uint32_t idx = threadIdx.x; idx < ng * BMW; idx += NT) {
-    const uint32_t c = idx / BMW, i = idx % BMW;
-    const TCol& t = S.col[c];
-    uint2 v = make_uint2(0, 0);
-    if (t.ow != 0xffffffffu && t.h.t_total && t.w0 + i < J.n_bw && i <= ((p_hi - p_lo) >> 5) + 1u) v = J.bm[(uint64_t)t.ow * J.n_bw + t.w0 + i];
-    S.bm[idx] = v;
-  }
-  for (uint32_t idx = threadIdx.x; idx < ng * MDS; idx += NT) {
-    const uint32_t c = idx / MDS, i = idx % MDS;
-    const TCol& t = S.col[c];
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (t.ow != 0xffffffffu && t.h.t_total && i < t.nmd && !t.fb) v = J.md[t.h.md_off + t.r0 + i];
-    S.md[idx] = v;
-  }
-  for (uint32_t idx = threadIdx.x; idx < ng * WW; idx += NT) {
-    const uint32_t c = idx / WW, i = idx % WW;
-    const TCol& t = S.col[c];
-    uint64_t v = 0;
-    if (t.ow != 0xffffffffu && t.h.t_total && i < t.nw && !t.fb) v = J.read_words[t.h.q_woff + t.word0 + i];
-    S.words[idx] = v;
-  }
-  if (WITH_QUAL) {
-    for (uint32_t idx = threadIdx.x; idx < ng * (QB / 4); idx += NT) {
-      const uint32_t c = idx / (QB / 4), i = idx % (QB / 4);
-      const TCol& t = S.col[c];
-      uint32_t v = 0;
-      if (t.ow != 0xffffffffu && t.h.t_total && !t.fb && i < t.nq) {
-        const uint64_t g = t.qg0 + 4ull * i;  // the allocation carries 8 pad bytes
-        if (g < J.read_qual_bytes) v = *reinterpret_cast<const uint32_t*>(J.read_qual + g);
-      }
-      S.quals[idx] = v;
-    }
-  }
-  __syncthreads();
-}
-
 // cell of staged column c at window position p / insertion ordinal j — LDS only (see column_cell)
 template <bool WITH_QUAL>
 __device__ __forceinline__ CellOut staged_cell(const JobDev& J, const TileLds<WITH_QUAL>& S, uint32_t c, int32_t p,
@@ -931,7 +857,8 @@ __global__ __launch_bounds__(NT) void k_tile_plan(JobDev J) {
 
 // Staging for k_final_tiles from the precomputed plan (see k_tile_plan): 8 threads per column, the
 // column's plan and header live in registers, every loop runs over exactly what the tile needs.
-__device__ __forceinline__ void stage_from_plan(const JobDev& J, uint32_t tile, uint32_t nspan, TileLds<true>& S) {
+template <bool WQ>
+__device__ __forceinline__ void stage_from_plan(const JobDev& J, uint32_t tile, uint32_t nspan, TileLds<WQ>& S) {
   const uint32_t c = threadIdx.x >> 3, l8 = threadIdx.x & 7u;
   if (c < HERRO_ROWS - 1) {
     const TPlan p = J.tplan[(uint64_t)tile * 32 + c];
@@ -958,7 +885,7 @@ __device__ __forceinline__ void stage_from_plan(const JobDev& J, uint32_t tile, 
         for (int k = 0; k < 3; k++) vm[k] = (l8 + 8 * k < t.nmd) ? md[l8 + 8 * k] : make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int k = 0; k < 2; k++) vw[k] = (l8 + 8 * k < t.nw) ? wsrc[l8 + 8 * k] : 0ull;
-        const uint32_t nq = t.fb ? 0u : t.nq;
+        const uint32_t nq = (!WQ || t.fb) ? 0u : t.nq;
         for (uint32_t i0 = 0; i0 < nq; i0 += 32) {  // quality dwords: 4 per thread per round
           uint32_t vq[4];
 #pragma unroll
@@ -983,15 +910,19 @@ __device__ __forceinline__ void stage_from_plan(const JobDev& J, uint32_t tile, 
 // =====================================================================================================
 // k_final_tiles — one workgroup per 256 final rows
 // =====================================================================================================
+// WQ = false leaves the quality planes alone: the model only ever looks at the qualities inside the
+// receptive fields of informative rows (~1.6 % of the cells; k_rf_quals fills exactly those), and the
+// consensus decoder at none.  The full planes are produced on request (herro_job_window_copy).
+template <bool WQ>
 __global__ __launch_bounds__(NT) void k_final_tiles(JobDev J) {
-  __shared__ TileLds<true> S;
+  __shared__ TileLds<WQ> S;
   const uint32_t w = J.tile_win[blockIdx.x], r0 = J.tile_r0[blockIdx.x];
   const uint32_t Lf = J.win_Lf[w];
   if (r0 >= Lf || (J.dbg & 16u)) return;
   const WinDesc wd = J.win[w];
   const uint32_t* rowmap = J.rowmap2 + wd.row_off;
   const uint32_t p_lo = rowmap[r0] & 0xffffu, p_hi = rowmap[min(r0 + NT, Lf) - 1] & 0xffffu;
-  if (!(J.dbg & 2u)) stage_from_plan(J, blockIdx.x, ((p_hi - p_lo) >> 5) + 1u, S);
+  if (!(J.dbg & 2u)) stage_from_plan<WQ>(J, blockIdx.x, ((p_hi - p_lo) >> 5) + 1u, S);
   const uint32_t r = r0 + threadIdx.x;
   const bool valid = r < Lf;
   const uint32_t rm = valid ? rowmap[r] : 0u;
@@ -1004,7 +935,7 @@ __global__ __launch_bounds__(NT) void k_final_tiles(JobDev J) {
     uint32_t t = TOK_GAP_F, q = 33;
     if (j == 0) {
       t = read_code(J.read_words, J.read_word_off[wd.rid], wd.tstart + (uint32_t)p);
-      q = J.read_qual[J.read_qual_off[wd.rid] + wd.tstart + (uint32_t)p];
+      if (WQ) q = J.read_qual[J.read_qual_off[wd.rid] + wd.tstart + (uint32_t)p];
     }
     tk[0] = t;
     ql[0] = q;
@@ -1014,9 +945,9 @@ __global__ __launch_bounds__(NT) void k_final_tiles(JobDev J) {
       CellOut co;
       co.tok = TOK_NONE;  // fewer than 30 overlaps: untouched '.' / '!' columns (features.rs:522-525)
       co.qual = 33;
-      if (S.col[c - 1].ow != 0xffffffffu && !(J.dbg & 1u)) co = staged_cell<true>(J, S, c - 1, p, j);
+      if (S.col[c - 1].ow != 0xffffffffu && !(J.dbg & 1u)) co = staged_cell<WQ>(J, S, c - 1, p, j);
       tk[c >> 2] |= co.tok << ((c & 3u) << 3);
-      ql[c >> 2] |= co.qual << ((c & 3u) << 3);
+      if (WQ) ql[c >> 2] |= co.qual << ((c & 3u) << 3);
       count_sym(cnt, tok_fold(co.tok));
     }
     // informative rows of the final [L',31] matrix: thresh = (31 * 0.1) as usize = 3 (features.rs:558,712)
@@ -1049,7 +980,7 @@ __global__ __launch_bounds__(NT) void k_final_tiles(JobDev J) {
   for (uint32_t c = 0; c < HERRO_ROWS; c++) {
     if (J.dbg & 8u) break;
     tb[c * TLD + threadIdx.x] = (uint8_t)(tk[c >> 2] >> ((c & 3u) << 3));
-    tq[c * TLD + threadIdx.x] = (uint8_t)(ql[c >> 2] >> ((c & 3u) << 3));
+    if (WQ) tq[c * TLD + threadIdx.x] = (uint8_t)(ql[c >> 2] >> ((c & 3u) << 3));
   }
   __syncthreads();
   const uint32_t nseg = (min(wd.lub - r0, (uint32_t)HERRO_TILE) + 15) / 16;
@@ -1059,7 +990,7 @@ __global__ __launch_bounds__(NT) void k_final_tiles(JobDev J) {
     const uint32_t* lq = reinterpret_cast<const uint32_t*>(tq + c * TLD + sg * 16);
     const uint64_t go = wd.fin_off + (uint64_t)c * wd.lub + r0 + sg * 16;
     *reinterpret_cast<uint4*>(J.fin_b + go) = make_uint4(lb[0], lb[1], lb[2], lb[3]);
-    *reinterpret_cast<uint4*>(J.fin_q + go) = make_uint4(lq[0], lq[1], lq[2], lq[3]);
+    if (WQ) *reinterpret_cast<uint4*>(J.fin_q + go) = make_uint4(lq[0], lq[1], lq[2], lq[3]);
   }
 }
 
@@ -1090,6 +1021,37 @@ __global__ __launch_bounds__(NT) void k_sup_compact(JobDev J) {
   if (threadIdx.x == 0) J.win_nsup[w] = tot;
 }
 
+
+// =====================================================================================================
+// k_rf_quals — one workgroup per window: the quality bytes the model reads
+// =====================================================================================================
+// The model is evaluated on the receptive fields of informative rows only (rows sup_row[k] - half ..
+// sup_row[k] + half of all 31 columns).  This kernel writes just those cells of the quality planes, straight
+// from the read store (column_cell on global memory; neighbouring informative rows recompute shared cells).
+__global__ __launch_bounds__(NT) void k_rf_quals(JobDev J, uint32_t half) {
+  const uint32_t w = blockIdx.x;
+  const uint32_t nsup = J.win_nsup[w], Lf = J.win_Lf[w];
+  if (!nsup) return;
+  const WinDesc wd = J.win[w];
+  const uint32_t span = 2 * half + 1, per = span * HERRO_ROWS, total = nsup * per;
+  const uint32_t* rowmap = J.rowmap2 + wd.row_off;
+  for (uint32_t idx = threadIdx.x; idx < total; idx += NT) {
+    const uint32_t k = idx / per, rem = idx % per, d = rem / HERRO_ROWS, c = rem % HERRO_ROWS;
+    const int32_t r = (int32_t)J.sup_row[wd.row_off + k] + (int32_t)d - (int32_t)half;
+    if (r < 0 || r >= (int32_t)Lf) continue;
+    const uint32_t rm = rowmap[r];
+    const int32_t p = (int32_t)(rm & 0xffffu);
+    const uint32_t j = rm >> 16;
+    uint32_t q = 33;
+    if (c == 0) {
+      if (j == 0) q = J.read_qual[J.read_qual_off[wd.rid] + wd.tstart + (uint32_t)p];
+    } else {
+      const uint32_t ow = J.sel_ow[(uint64_t)w * 32 + c];
+      if (ow != 0xffffffffu) q = column_cell<true>(J, J.chdr[ow], ow, p, j).qual;
+    }
+    J.fin_q[wd.fin_off + (uint64_t)c * wd.lub + (uint32_t)r] = (uint8_t)q;
+  }
+}
 
 // =====================================================================================================
 // k_consensus — one workgroup per window: corrected bases on the device (consensus.rs:86-227)
@@ -1148,6 +1110,17 @@ void launch_consensus(const JobDev& J, const uint64_t* sup_off, const float* bas
   KT_END(tm, st);
 }
 
+void launch_rf_quals(const JobDev& J, uint32_t half, hipStream_t st, KernelTimer* tm) {
+  if (!J.n_win) return;
+  KT_BEGIN(tm, "rf_quals", st);
+  hipLaunchKernelGGL(k_rf_quals, dim3(J.n_win), dim3(NT), 0, st, J, half);
+  KT_END(tm, st);
+}
+
+void launch_full_quals(const JobDev& J, hipStream_t st) {  // token planes are rewritten with identical contents
+  if (J.n_tiles) hipLaunchKernelGGL(k_final_tiles<true>, dim3(J.n_tiles), dim3(NT), 0, st, J);
+}
+
 void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm) {
   if (J.n_ow) {
     KT_BEGIN(tm, "ow_stats", st);
@@ -1176,7 +1149,7 @@ void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm) {
   hipLaunchKernelGGL(k_tile_plan, dim3((J.n_tiles * 32 + NT - 1) / NT), dim3(NT), 0, st, J);
   KT_END(tm, st);
   KT_BEGIN(tm, "final_tiles", st);
-  hipLaunchKernelGGL(k_final_tiles, dim3(J.n_tiles), dim3(NT), 0, st, J);
+  hipLaunchKernelGGL(k_final_tiles<false>, dim3(J.n_tiles), dim3(NT), 0, st, J);
   KT_END(tm, st);
   KT_BEGIN(tm, "sup_compact", st);
   hipLaunchKernelGGL(k_sup_compact, dim3(J.n_win), dim3(NT), 0, st, J);

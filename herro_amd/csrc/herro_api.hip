@@ -88,6 +88,7 @@ struct herro_job {
   JobDev J{};
   std::vector<void*> allocs;
   bool featurized = false, synced = false, inferred = false;
+  bool quals_full = false;   // the complete quality planes exist (featurize writes tokens only)
   // host copies after sync
   std::vector<uint32_t> h_Lf, h_nsup, h_nkept;
   std::vector<uint64_t> sup_off;  // [n_win+1] prefix of nsup
@@ -740,6 +741,7 @@ int herro_job_featurize(herro_job* job) {
   job->featurized = true;
   job->synced = false;
   job->inferred = false;
+  job->quals_full = false;
   return HERRO_OK;
 }
 
@@ -874,6 +876,8 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   job->d_supoff_blob = (const uint64_t*)((const unsigned char*)job->d_bdesc + supoff_at);
   rc = ensure_scratch(ctx, max_tok);
   if (rc) return rc;
+  // the qualities the model will read: rows within 2 * (kw / 2) of an informative row (two stacked convs)
+  if (!job->quals_full && !groups.empty()) launch_rf_quals(job->J, 2 * (ctx->M.h.kw / 2), ctx->stream, &ctx->timer);
   for (size_t gi = 0; gi < groups.size(); gi++) {
     const unsigned char* base = (const unsigned char*)job->d_bdesc;
     BatchDev B{};
@@ -945,6 +949,12 @@ static int fetch_planes(herro_job* job, uint32_t w, std::vector<uint8_t>& pb, st
   pb.resize(bytes);
   HIP_TRY(ctx, hipMemcpy(pb.data(), job->J.fin_b + wd.fin_off, bytes, hipMemcpyDeviceToHost));
   if (pq) {
+    if (!job->quals_full) {  // featurize leaves the quality planes to whoever asks for them
+      launch_full_quals(job->J, ctx->stream);
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      job->quals_full = true;
+    }
     pq->resize(bytes);
     HIP_TRY(ctx, hipMemcpy(pq->data(), job->J.fin_q + wd.fin_off, bytes, hipMemcpyDeviceToHost));
   }

@@ -72,7 +72,7 @@ struct JobDev {
   uint32_t* sup_row;     // [win.row_off + k]   final row of informative position k
   uint32_t* sup_pi;      // [win.row_off + k]   pos | ins << 16
   uint8_t* fin_b;        // final token planes   [win.fin_off + c*lub + row], c in [0,31)
-  uint8_t* fin_q;
+  uint8_t* fin_q;        // qualities: only receptive-field cells after infer, complete after launch_full_quals
   uint32_t* nd;          // [2*cls]: matches, mismatches (features.rs:461-500)
   uint32_t* rank_qid;    // [win.ow_begin + rank] ranked query ids (features.rs:569)
   uint8_t* cons_seq;     // [win.row_off ..] corrected bases of the window (ASCII), cons_len[w] of them
@@ -121,6 +121,10 @@ struct KernelTimer {
 #define KT_END(tm, st) do { if ((tm) && (tm)->on) (tm)->end(st); } while (0)
 
 void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm);
+// qualities inside the model's receptive fields (rows within `half` of an informative row)
+void launch_rf_quals(const JobDev& J, uint32_t half, hipStream_t st, KernelTimer* tm);
+// the complete quality planes (featurize itself only writes tokens)
+void launch_full_quals(const JobDev& J, hipStream_t st);
 void launch_consensus(const JobDev& J, const uint64_t* sup_off, const float* base_logits, hipStream_t st, KernelTimer* tm);
 
 }  // namespace herro
