@@ -1036,7 +1036,8 @@ __global__ __launch_bounds__(NT) void k_rf_quals(JobDev J, uint32_t half) {
   const uint32_t span = 2 * half + 1, per = span * HERRO_ROWS, total = nsup * per;
   const uint32_t* rowmap = J.rowmap2 + wd.row_off;
   for (uint32_t idx = threadIdx.x; idx < total; idx += NT) {
-    const uint32_t k = idx / per, rem = idx % per, d = rem / HERRO_ROWS, c = rem % HERRO_ROWS;
+    // neighbouring lanes: the rows of one receptive field in one column (same header, same ops, adjacent bytes)
+    const uint32_t k = idx / per, rem = idx % per, c = rem / span, d = rem % span;
     const int32_t r = (int32_t)J.sup_row[wd.row_off + k] + (int32_t)d - (int32_t)half;
     if (r < 0 || r >= (int32_t)Lf) continue;
     const uint32_t rm = rowmap[r];
