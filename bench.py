@@ -65,8 +65,8 @@ def cpu_baseline(seed: int) -> dict:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--pool", type=int, default=2, help="distinct synthetic jobs cycled through")
     ap.add_argument("--group", type=int, default=32,
@@ -95,7 +95,8 @@ def main():
     W, n_ovl = 4096, 32
     targets_per_step = args.batch // 4
     path, _ = model_io.default_model_file(os.path.join(ROOT, "tests", "_cache"))
-    G = max(1, min(args.group, args.steps))
+    # at least two launch groups per timed region when possible, so that featurize(k+1) can overlap infer(k)
+    G = max(1, min(args.group, args.steps // 2 if args.steps >= 2 else 1))
     n_full, rem = divmod(args.steps, G)
     NS = max(1, min(args.streams, n_full)) if n_full else 1
     pool = max(1, min(args.pool, (n_full + NS - 1) // NS if n_full else 1))
