@@ -685,7 +685,7 @@ __device__ __forceinline__ bool supported_from_counts(uint64_t c, uint32_t thres
 static constexpr int NCOL = 32;   // columns per staging pass
 static constexpr int TLD = HERRO_TILE + 4;  // byte-tile row stride for the output transpose (bank spread)
 static constexpr int BMW = 10;    // bitmap words per column   (tile spans <= 256 positions -> <= 9 words)
-static constexpr int MDS = 24;    // M/D op entries per column
+static constexpr int MDS = 20;    // M/D op entries per column (more: the column takes the global-memory path)
 static constexpr int WW = 14;     // 2-bit words per column    (<= 448 query bases)
 static constexpr int QB = 480;    // quality bytes per column  (multiple of 4)
 
@@ -802,12 +802,30 @@ __global__ __launch_bounds__(NT) void k_select_layout(JobDev J) {
 // column follows from a chain of dependent loads (row map -> selection -> header -> rank directory -> op
 // table).  Done inside the tile kernel that chain is paid per workgroup with 30 active lanes; here it is
 // one thread per (tile, column), fully parallel, and the tile kernel just reads the 32-byte records.
-struct TPlan {
+struct __attribute__((aligned(16))) TPlan {  // 64 B
   uint32_t ow;      // 0xffffffff: padding column
   uint32_t w0, r0, word0;
   uint64_t qg0;
   uint32_t cnt;     // nmd | nw << 8 | outside << 30 | fb << 31
   uint32_t nq;
+  // everything else the token kernel needs from the column header, so that its staging is plan -> data
+  // (two dependent round trips) instead of plan -> header -> data
+  int32_t off;
+  uint32_t t_total;
+  int32_t sbase;
+  uint32_t sdir_strand;  // bit 0: strand, bit 1: sdir < 0
+  uint32_t md_off;
+  uint32_t pad0;
+  uint64_t q_woff;
+};
+// what a tile kernel needs to know about its tile, gathered once by k_tile_plan (it was a chain of five
+// dependent loads at the head of every tile workgroup)
+struct __attribute__((aligned(16))) TileHdr {  // 64 B
+  uint32_t w, r0, Lf, lub;
+  uint64_t row_off, fin_off;
+  uint64_t tgt_woff;   // first 2-bit word of the target read
+  uint32_t tstart, p_lo, p_hi, pad;
+  uint64_t pad2;
 };
 
 __global__ __launch_bounds__(NT) void k_tile_plan(JobDev J) {
@@ -816,19 +834,38 @@ __global__ __launch_bounds__(NT) void k_tile_plan(JobDev J) {
   if (tile >= J.n_tiles || c >= HERRO_ROWS - 1) return;
   const uint32_t w = J.tile_win[tile], r0 = J.tile_r0[tile];
   const uint32_t Lf = J.win_Lf[w];
-  if (r0 >= Lf) return;
+  if (r0 >= Lf) {  // the tile lies past the window's last row (tiles are laid out for the upper bound lub)
+    if (c == 0) {
+      TileHdr th{};
+      th.w = w; th.r0 = r0; th.Lf = 0;
+      J.thdr[tile] = th;
+    }
+    return;
+  }
   const WinDesc& wd = J.win[w];
   const uint32_t* rowmap = J.rowmap2 + wd.row_off;
   const uint32_t p_lo = rowmap[r0] & 0xffffu, p_hi = rowmap[min(r0 + (uint32_t)HERRO_TILE, Lf) - 1] & 0xffffu;
+  if (c == 0) {
+    TileHdr th;
+    th.w = w; th.r0 = r0; th.Lf = Lf; th.lub = wd.lub;
+    th.row_off = wd.row_off; th.fin_off = wd.fin_off;
+    th.tgt_woff = J.read_word_off[wd.rid];
+    th.tstart = wd.tstart; th.p_lo = p_lo; th.p_hi = p_hi; th.pad = 0; th.pad2 = 0;
+    J.thdr[tile] = th;
+  }
   TPlan t;
   t.ow = J.sel_ow[(uint64_t)w * 32 + 1 + c];
   t.w0 = 0; t.r0 = 0; t.word0 = 0; t.qg0 = 0; t.cnt = 0; t.nq = 0;
+  t.off = 0; t.t_total = 0; t.sbase = 0; t.sdir_strand = 0; t.md_off = 0; t.pad0 = 0; t.q_woff = 0;
   if (t.ow != 0xffffffffu) {
     const ColHdr h = J.chdr[t.ow];
+    t.off = h.off; t.t_total = h.t_total; t.sbase = h.sbase; t.sdir_strand = (h.strand ? 1u : 0u) | (h.sdir < 0 ? 2u : 0u);
+    t.md_off = h.md_off; t.q_woff = h.q_woff;
     const int32_t ulo = max((int32_t)p_lo - h.off, 0);
     const int32_t uhi = min((int32_t)p_hi - h.off, (int32_t)h.t_total - 1);
     if (ulo > uhi) {
       t.cnt = 1u << 30;  // the tile lies outside the overlap: every cell is '.'
+      t.t_total = 0;
     } else {
       const uint2* bm = J.bm + (uint64_t)t.ow * J.n_bw;
       const uint2 blo = bm[ulo >> 5], bhi = bm[uhi >> 5];
@@ -995,6 +1032,212 @@ __global__ __launch_bounds__(NT) void k_final_tiles(JobDev J) {
 }
 
 // =====================================================================================================
+// k_final_tiles_t — the token plane, lean version (what herro_job_featurize runs)
+// =====================================================================================================
+// Same staging and the same arithmetic as k_final_tiles (kept for the quality planes and as an independent
+// cross-check), with the per-cell instruction count cut from ~190 (113 VALU + 74 SALU + 14 LDS; the ISA of
+// the generic kernel) to ~50: the column constants are pre-digested into a 32-byte descriptor read by two
+// broadcast LDS loads; no branch in the cell path (padding / out-of-range columns have t_total = 0, the
+// rare global-memory fallback columns are patched in a second loop); the 2-bit code comes from a byte read
+// instead of 64-bit shifts; the stored index is one 24-bit multiply-add; tokens go straight into the LDS
+// transpose tile with ds_write_b8 at a compile-time offset; symbol counts are 6-bit fields of one register.
+struct __attribute__((aligned(16))) CDesc {
+  int32_t off;        // uu = p - off
+  uint32_t t_total;   // 0: every cell of this column is '.' in this tile
+  uint32_t uu_clamp;  // uu used for cells outside the overlap (keeps every LDS address inside the staged data)
+  int32_t bm_base;    // byte offset into S.bm of bitmap word 0 of the overlap
+  int32_t md_base;    // byte offset into S.md of op entry with rank 0
+  int32_t sbase_rel;  // stored index of query base q, relative to the first staged base: sbase_rel + sdir * q
+  int32_t sdir;
+  uint32_t tokc;      // strand ? 3 : 0 | (strand ? 5 : 0) << 8 | gap token << 16
+};
+
+// One workgroup per tile.  (A persistent, software-pipelined variant — plan of tile i+2 and data of tile i+1
+// prefetched into registers under tile i's cell loop — was built and measured 1.7x SLOWER: 156 VGPRs, three
+// workgroups per CU and four barriers per tile cost more than the round trips it hid.)
+struct TileData {  // what one staging thread contributes to a tile
+  uint2 vb[2];
+  uint4 vm[3];
+  uint64_t vw[2];
+  uint32_t rm;
+};
+__device__ __forceinline__ void tile_fetch(const JobDev& J, const TileHdr& th, const TPlan& pl, uint32_t sc, uint32_t l8,
+                                           TileData& d) {
+  const bool act = th.r0 < th.Lf;
+  const uint32_t r = th.r0 + threadIdx.x;
+  d.rm = (act && r < th.Lf) ? J.rowmap2[th.row_off + r] : th.p_lo;  // rows past the window: an in-range position, unused
+  const uint32_t nspan = ((th.p_hi - th.p_lo) >> 5) + 1u;
+  const bool live = act && pl.ow != 0xffffffffu && !(pl.cnt >> 30) && pl.t_total != 0;
+  const uint32_t tw0 = (th.tstart + th.p_lo) >> 5;
+  const bool tgt = act && sc == HERRO_ROWS;  // threads 248..255 stage the target's words
+  const uint32_t nbm = live ? min(min(nspan + 1u, (uint32_t)BMW), J.n_bw - pl.w0) : 0u;
+  const uint32_t nmd = live ? (pl.cnt & 0xffu) : 0u;
+  const uint32_t nw = live ? ((pl.cnt >> 8) & 0xffu) : (tgt ? ((th.tstart + th.p_hi) >> 5) - tw0 + 1u : 0u);
+  const uint2* __restrict__ bm = J.bm + (uint64_t)pl.ow * J.n_bw + pl.w0;
+  const uint4* __restrict__ md = J.md + pl.md_off + pl.r0;
+  const uint64_t* __restrict__ wsrc = tgt ? J.read_words + th.tgt_woff + tw0 : J.read_words + pl.q_woff + pl.word0;
+#pragma unroll
+  for (int k = 0; k < 2; k++) d.vb[k] = (l8 + 8 * k < nbm) ? bm[l8 + 8 * k] : make_uint2(0, 0);
+#pragma unroll
+  for (int k = 0; k < 3; k++) d.vm[k] = (l8 + 8 * k < nmd) ? md[l8 + 8 * k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int k = 0; k < 2; k++) d.vw[k] = (l8 + 8 * k < nw) ? wsrc[l8 + 8 * k] : 0ull;
+}
+
+__global__ __launch_bounds__(NT) void k_final_tiles_t(JobDev J) {
+  __shared__ uint2 s_bm[NCOL * BMW];
+  __shared__ uint4 s_md[NCOL * MDS];
+  __shared__ uint64_t s_words[NCOL * WW];
+  __shared__ CDesc s_cd[32];
+  __shared__ __attribute__((aligned(16))) uint8_t s_tb[HERRO_ROWS * TLD];
+  __shared__ uint32_t s_fb_ow[32];
+  __shared__ uint32_t s_anyfb;
+  const uint32_t sc = threadIdx.x >> 3, l8 = threadIdx.x & 7u;  // staging role: 8 threads per column
+  // round trip 1: the tile header (uniform) and this thread's column plan (independent of each other)
+  const uint32_t tile = blockIdx.x;
+  const TileHdr th = J.thdr[tile];
+  TPlan pl0;
+  pl0.ow = 0xffffffffu; pl0.cnt = 0; pl0.t_total = 0; pl0.w0 = 0; pl0.r0 = 0; pl0.word0 = 0; pl0.md_off = 0; pl0.q_woff = 0;
+  pl0.off = 0; pl0.sbase = 0; pl0.sdir_strand = 0;
+  if (sc < HERRO_ROWS - 1) pl0 = J.tplan[(uint64_t)tile * 32 + sc];
+  if (th.r0 >= th.Lf || (J.dbg & 16u)) return;
+  // round trip 2: row map entry, rank directory words, op entries, 2-bit words
+  TileData d;
+  tile_fetch(J, th, pl0, sc, l8, d);
+  const unsigned char* bm_bytes = reinterpret_cast<const unsigned char*>(s_bm);
+  const unsigned char* md_bytes = reinterpret_cast<const unsigned char*>(s_md);
+  const uint8_t* w_bytes = reinterpret_cast<const uint8_t*>(s_words);
+  {
+    const bool act = true;
+    const uint32_t rm = d.rm;
+    if (act) {
+      // ---- staging data of this tile: registers -> LDS
+      const bool fb = (pl0.cnt >> 31) != 0;
+      const bool live = pl0.ow != 0xffffffffu && !(pl0.cnt >> 30) && pl0.t_total != 0;
+      const bool tgt = sc == HERRO_ROWS;
+      const uint32_t nspan = ((th.p_hi - th.p_lo) >> 5) + 1u;
+      const uint32_t nbm = live ? min(min(nspan + 1u, (uint32_t)BMW), J.n_bw - pl0.w0) : 0u;
+      const uint32_t nmd = live ? (pl0.cnt & 0xffu) : 0u;
+      const uint32_t nw = live ? ((pl0.cnt >> 8) & 0xffu) : (tgt ? ((th.tstart + th.p_hi) >> 5) - ((th.tstart + th.p_lo) >> 5) + 1u : 0u);
+      const uint32_t slot = tgt ? 30u : sc;
+#pragma unroll
+      for (int k = 0; k < 2; k++) if (l8 + 8 * k < nbm) s_bm[sc * BMW + l8 + 8 * k] = d.vb[k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) if (l8 + 8 * k < nmd) s_md[sc * MDS + l8 + 8 * k] = d.vm[k];
+#pragma unroll
+      for (int k = 0; k < 2; k++) if (l8 + 8 * k < nw) s_words[slot * WW + l8 + 8 * k] = d.vw[k];
+      if (threadIdx.x == 0) s_anyfb = 0;
+      if (l8 == 0 && sc < HERRO_ROWS - 1) {
+        CDesc cd;
+        cd.off = 0; cd.t_total = 0; cd.uu_clamp = 0; cd.bm_base = (int32_t)(sc * BMW * 8); cd.md_base = (int32_t)(sc * MDS * 16);
+        cd.sbase_rel = 0; cd.sdir = 1; cd.tokc = (uint32_t)TOK_GAP_F << 16;
+        if (live) {
+          const bool strand = (pl0.sdir_strand & 1u) != 0;
+          cd.off = pl0.off;
+          cd.t_total = pl0.t_total;
+          cd.uu_clamp = pl0.w0 << 5;
+          cd.bm_base = (int32_t)(sc * BMW * 8) - (int32_t)(pl0.w0 * 8);
+          cd.md_base = (int32_t)(sc * MDS * 16) - (int32_t)((pl0.r0 + 1u) * 16);
+          cd.sbase_rel = pl0.sbase - (int32_t)(pl0.word0 << 5);
+          cd.sdir = (pl0.sdir_strand & 2u) ? -1 : 1;
+          cd.tokc = strand ? (3u | (5u << 8) | ((uint32_t)TOK_GAP_R << 16)) : ((uint32_t)TOK_GAP_F << 16);
+        }
+        s_cd[sc] = cd;
+        s_fb_ow[sc] = (pl0.ow != 0xffffffffu && fb) ? pl0.ow : 0xffffffffu;
+      }
+    }
+    __syncthreads();
+    if (l8 == 0 && sc < HERRO_ROWS - 1 && pl0.ow != 0xffffffffu && (pl0.cnt >> 31)) s_anyfb = 1;  // after thread 0's reset
+    if (act) {
+      __syncthreads();  // s_anyfb
+      const uint32_t r = th.r0 + threadIdx.x;
+      const bool valid = r < th.Lf;
+      const int32_t p = (int32_t)(rm & 0xffffu);
+      const uint32_t j = rm >> 16;
+      const bool j0 = j == 0;
+      const uint32_t jm1 = j - 1u;
+      uint32_t cnt = 0;  // five 6-bit counters A,C,G,T,* (at most 31 columns)
+      uint32_t t0tok = TOK_GAP_F;
+      {
+        const uint32_t si = th.tstart + (uint32_t)p - (((th.tstart + th.p_lo) >> 5) << 5);
+        const uint32_t code = (w_bytes[30 * WW * 8 + (si >> 2)] >> ((si & 3u) << 1)) & 3u;
+        if (j0) t0tok = code;
+      }
+      s_tb[threadIdx.x] = (uint8_t)t0tok;
+      cnt += 1u << (6u * tok_fold(t0tok));
+      if (!(J.dbg & 1u))
+#pragma unroll
+      for (uint32_t c = 1; c < HERRO_ROWS; c++) {
+        const uint4 d0 = *reinterpret_cast<const uint4*>(&s_cd[c - 1]);
+        const uint4 d1 = *(reinterpret_cast<const uint4*>(&s_cd[c - 1]) + 1);
+        const uint32_t uu_raw = (uint32_t)(p - (int32_t)d0.x);
+        const bool inr = uu_raw < d0.y;
+        const uint32_t uu = inr ? uu_raw : d0.z;
+        const uint2 bw = *reinterpret_cast<const uint2*>(bm_bytes + (int32_t)d0.w + (int32_t)((uu >> 5) << 3));
+        const uint32_t rank = __popc(bw.x & ~(0xfffffffeu << (uu & 31u))) + bw.y;
+        const uint4 e = *reinterpret_cast<const uint4*>(md_bytes + (int32_t)d1.x + (int32_t)(rank << 4));
+        // all selects, no short-circuit: booleans are combined bitwise so that nothing here becomes a branch
+        const uint32_t m_bit = e.z >> 31;                      // 1: M op, 0: D op
+        const uint32_t len = e.z & 0x7fffffffu;
+        const uint32_t lenm = m_bit ? len : 0u;
+        const bool last = (uu + 1u == e.x + len);
+        const bool ins_ok = last & (e.w >= j);                 // insertion slot j-1 behind uu exists in this read
+        const bool isbase = inr & (j0 ? (m_bit != 0u) : ins_ok);
+        const uint32_t q = e.y + (j0 ? uu - e.x : lenm + jm1);
+        const uint32_t si = isbase ? (uint32_t)(__mul24((int32_t)d1.z, (int32_t)q) + (int32_t)d1.y) : 0u;
+        const uint32_t byte = w_bytes[(c - 1) * WW * 8 + (si >> 2)];
+        const uint32_t f = ((byte >> ((si & 3u) << 1)) & 3u) ^ (d1.w & 0xffu);
+        const uint32_t tokb = f + ((d1.w >> 8) & 0xffu);
+        const uint32_t tokg = d1.w >> 16;
+        const uint32_t tok = inr ? (isbase ? tokb : tokg) : (uint32_t)TOK_NONE;
+        s_tb[c * TLD + threadIdx.x] = (uint8_t)tok;
+        const uint32_t one = inr ? 1u : 0u;
+        cnt += one << (6u * (isbase ? f : 4u));
+      }
+      if (s_anyfb) {  // block-uniform, rare: columns whose stretch did not fit the staging slots
+        for (uint32_t c = 1; c < HERRO_ROWS; c++) {
+          const uint32_t ow = s_fb_ow[c - 1];
+          if (ow == 0xffffffffu) continue;
+          const uint32_t tok = column_cell<false>(J, J.chdr[ow], ow, p, j).tok;
+          s_tb[c * TLD + threadIdx.x] = (uint8_t)tok;
+          const uint32_t f = tok_fold(tok);
+          cnt += (f < 5u ? 1u : 0u) << (6u * min(f, 4u));
+        }
+      }
+      if (valid) {
+        uint32_t c5[5];
+#pragma unroll
+        for (int q = 0; q < 5; q++) c5[q] = (cnt >> (6 * q)) & 0x3fu;
+        // informative rows of the final [L',31] matrix: thresh = (31 * 0.1) as usize = 3 (features.rs:558,712)
+        const uint32_t thresh = (uint32_t)((double)HERRO_ROWS * 0.1);
+        uint32_t ns = 0;
+#pragma unroll
+        for (int q = 0; q < 5; q++) ns += c5[q] >= thresh ? 1u : 0u;
+        J.sup_flag[th.row_off + r] = ns >= 2 ? 1 : 0;
+        // majority vote of the consensus decoder (consensus.rs:178-200), see k_final_tiles
+        uint32_t c0 = c5[0], i0 = 0;
+#pragma unroll
+        for (uint32_t q = 1; q < 5; q++) if (c5[q] > c0) { c0 = c5[q]; i0 = q; }
+        uint32_t c1 = 0, i1 = 5;
+        bool have = false;
+#pragma unroll
+        for (uint32_t q = 0; q < 5; q++)
+          if (q != i0 && (!have || c5[q] > c1)) { c1 = c5[q]; i1 = q; have = true; }
+        const uint32_t tb0 = t0tok;
+        J.cons_tmp[th.row_off + r] = (uint8_t)((c0 < 2u || (c0 == c1 && (i0 == tb0 || i1 == tb0))) ? tb0 : i0);
+      }
+      __syncthreads();
+      const uint32_t nseg = (min(th.lub - th.r0, (uint32_t)HERRO_TILE) + 15) / 16;
+      for (uint32_t it = threadIdx.x; it < ((J.dbg & 4u) ? 0u : HERRO_ROWS * nseg); it += NT) {
+        const uint32_t c = it / nseg, sg = it % nseg;
+        const uint32_t* lb = reinterpret_cast<const uint32_t*>(s_tb + c * TLD + sg * 16);
+        *reinterpret_cast<uint4*>(J.fin_b + th.fin_off + (uint64_t)c * th.lub + th.r0 + sg * 16) = make_uint4(lb[0], lb[1], lb[2], lb[3]);
+      }
+    }
+  }
+}
+
+// =====================================================================================================
 // k_sup_compact — one workgroup per window: ordered informative-position list
 // =====================================================================================================
 __global__ __launch_bounds__(NT) void k_sup_compact(JobDev J) {
@@ -1150,7 +1393,7 @@ void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm) {
   hipLaunchKernelGGL(k_tile_plan, dim3((J.n_tiles * 32 + NT - 1) / NT), dim3(NT), 0, st, J);
   KT_END(tm, st);
   KT_BEGIN(tm, "final_tiles", st);
-  hipLaunchKernelGGL(k_final_tiles<false>, dim3(J.n_tiles), dim3(NT), 0, st, J);
+  hipLaunchKernelGGL(k_final_tiles_t, dim3(J.n_tiles), dim3(NT), 0, st, J);
   KT_END(tm, st);
   KT_BEGIN(tm, "sup_compact", st);
   hipLaunchKernelGGL(k_sup_compact, dim3(J.n_win), dim3(NT), 0, st, J);

@@ -686,7 +686,9 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.ow_ttotal = (uint32_t*)A((uint64_t)n_ow * 4);
   J.slot_ow = (uint32_t*)A((uint64_t)n_ow * 4); J.rank_qid = (uint32_t*)A((uint64_t)n_ow * 4);
   J.sel_ow = (uint32_t*)A((uint64_t)n_win * 32 * 4);
-  J.tplan = (struct herro::TPlan*)A((uint64_t)J.n_tiles * 32 * 32);
+  J.tplan = (struct herro::TPlan*)A((uint64_t)J.n_tiles * 32 * 64);
+  J.thdr = (struct herro::TileHdr*)A((uint64_t)J.n_tiles * 64);
+  if (J.tplan) hipMemsetAsync(J.tplan, 0xff, (uint64_t)J.n_tiles * 32 * 64, ctx->stream);  // records of empty tiles are loaded, never used
   job->d_counts = (uint32_t*)A((uint64_t)n_win * 12);
   J.win_Lf = job->d_counts; J.win_nsup = job->d_counts + n_win; J.win_nkept = job->d_counts + 2ull * n_win;
   J.row_of_pos2 = (uint32_t*)A(pos_elems * 4);

@@ -57,7 +57,8 @@ struct JobDev {
   uint4* md;             // per overlap (at scr_off): M/D ops {t_beg, q_beg, len | isM<<31, following ins len}
   uint2* bm;             // [ow * n_bw + i] {bitmap of M/D op starts for positions 32i.., ops before 32i}
   ColHdr* chdr;          // [ow]
-  struct TPlan* tplan;   // [tile * 32 + c] staging plan of final-row tile x selected column (32 B)
+  struct TPlan* tplan;   // [tile * 32 + c] staging plan of final-row tile x selected column (64 B)
+  struct TileHdr* thdr;  // [tile] window / row range / target words of the tile (64 B)
   uint8_t* ow_keep;      // long-indel filter verdict
   float* ow_acc;         // accuracy
   uint32_t* ow_ttotal;   // target bases consumed by the slice
