@@ -103,9 +103,9 @@ __device__ __forceinline__ uint32_t rev_pairs(uint32_t x) {
 // =====================================================================================================
 // The work of one overlap-window is small (~100 ops, <= 8192 positions) and is a chain of dependent
 // global loads; one wave each keeps 4x more of those chains in flight per CU than one workgroup each.
-static constexpr int OWCAP = 256;  // ops staged in LDS per wave (more: tables are read back from global)
+static constexpr int OWCAP = 192;  // ops staged in LDS per wave (more: tables are read back from global)
 static constexpr int TWCAP = HERRO_MAX_WINDOW / 32 + 2;  // staged target 2-bit words per wave
-static constexpr int QWCAP = 320;                         // staged query 2-bit words per wave (10k bases)
+static constexpr int QWCAP = 192;                         // staged query 2-bit words per wave (6k bases; more: read from global)
 
 __device__ __forceinline__ uint64_t wave_scan64(uint64_t v, uint64_t* total) {  // exclusive, within the wave
   const int lane = threadIdx.x & 63;
@@ -124,35 +124,39 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
   return v;
 }
 
+__host__ __device__ inline size_t ow_stats_lds_per_wave(uint32_t window_size) {
+  return (((size_t)(window_size / 32 + 2) + QWCAP) * 8 + (size_t)3 * OWCAP * 4 + (size_t)(window_size / 32 + 1) * 4 + 15) & ~(size_t)15;
+}
+
 __global__ __launch_bounds__(NT) void k_ow_stats(JobDev J) {
-  __shared__ uint32_t s_op_all[4][OWCAP], s_t_all[4][OWCAP], s_q_all[4][OWCAP];
-  __shared__ uint32_t s_bm_all[4][HERRO_MAX_WINDOW / 32 + 1];
-  __shared__ uint64_t s_tw_all[4][TWCAP], s_qw_all[4][QWCAP];
+  // per-wave LDS, sized for the job's window size (dynamic): [tw: ntw_cap u64][qw: QWCAP u64][op, t, q: OWCAP u32 each][bm: n_bw u32]
+  extern __shared__ __attribute__((aligned(16))) unsigned char ow_smem[];
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t o = blockIdx.x * 4 + wave;
   if (o >= J.n_ow) return;
-  uint64_t* s_tw = s_tw_all[wave];
-  uint64_t* s_qw = s_qw_all[wave];
-  uint32_t* s_op = s_op_all[wave];
-  uint32_t* s_t = s_t_all[wave];
-  uint32_t* s_q = s_q_all[wave];
-  uint32_t* s_bm = s_bm_all[wave];
-  const OwDesc d = J.ow[o];
-  const WinDesc wd = J.win[d.win];
+  const uint32_t ntw_cap = J.window_size / 32 + 2;
+  unsigned char* base_w = ow_smem + (size_t)wave * ow_stats_lds_per_wave(J.window_size);
+  uint64_t* s_tw = reinterpret_cast<uint64_t*>(base_w);
+  uint64_t* s_qw = s_tw + ntw_cap;
+  uint32_t* s_op = reinterpret_cast<uint32_t*>(s_qw + QWCAP);
+  uint32_t* s_t = s_op + OWCAP;
+  uint32_t* s_q = s_t + OWCAP;
+  uint32_t* s_bm = s_q + OWCAP;
+  const OwDesc d = J.ow[o];  // carries the window's and the reads' offsets: no further lookups before the data
   const uint32_t* ops = J.ops + d.op_begin;
   uint32_t* op_t = J.op_t + d.scr_off;
   uint32_t* op_q = J.op_q + d.scr_off;
   uint32_t* ins_ev = J.ins_ev + d.scr_off;
   uint4* md = J.md + d.scr_off;
   const uint32_t cnt = d.op_cnt;
-  const uint32_t off = d.tstart - wd.tstart;
+  const uint32_t off = d.tstart - d.wtstart;
   const bool in_lds = cnt <= OWCAP;
 
   for (uint32_t i = lane; i < J.n_bw; i += 64) s_bm[i] = 0;
   // 2-bit words of the target stretch and of the query stretch, coalesced, for the accuracy pass below
-  const uint64_t t_woff = J.read_word_off[wd.rid];
-  const uint64_t q_woff = J.read_word_off[d.qid];
-  const uint32_t tw0 = d.tstart >> 5, ntw = ((wd.tstart + wd.win_len) >> 5) - tw0 + 2;
+  const uint64_t t_woff = d.t_woff;
+  const uint64_t q_woff = d.q_woff;
+  const uint32_t tw0 = d.tstart >> 5, ntw = ((d.wtstart + d.wlen) >> 5) - tw0 + 2;
   const uint32_t qw0 = d.qbeg >> 5, nqw = ((d.qbeg + d.qlen) >> 5) - qw0 + 2;
   const bool q_lds = nqw <= QWCAP;
   for (uint32_t i = lane; i < ntw; i += 64) s_tw[i] = t_woff + tw0 + i <= J.read_n_words ? J.read_words[t_woff + tw0 + i] : 0ull;
@@ -179,9 +183,8 @@ __global__ __launch_bounds__(NT) void k_ow_stats(JobDev J) {
     const uint64_t ex_im = wave_scan64((uint64_t)is_i | ((uint64_t)is_md << 32), &tot_im);
     if (k < cnt) {
       const uint32_t t = carry_t + (uint32_t)ex_tq, q = carry_q + (uint32_t)(ex_tq >> 32);
-      op_t[k] = t;
-      op_q[k] = q;
       if (in_lds) { s_op[k] = op; s_t[k] = t; s_q[k] = q; }
+      else { op_t[k] = t; op_q[k] = q; }  // only this kernel reads them back (accuracy pass of very long CIGARs)
       // insertion behind window position off+t-1 (features.rs:77); t >= 1: a slice never starts with I
       if (is_i) ins_ev[carry_i + (uint32_t)ex_im] = ((off + t - 1u) & 0xffffu) | (op_len(op) << 16);
       if (is_md) {
@@ -231,8 +234,8 @@ __global__ __launch_bounds__(NT) void k_ow_stats(JobDev J) {
       h.sdir = d.strand ? -1 : 1;
       h.md_off = d.scr_off;
       h.n_md = carry_m;
-      h.q_woff = J.read_word_off[d.qid];
-      h.qual_off = J.read_qual_off[d.qid];
+      h.q_woff = d.q_woff;
+      h.qual_off = d.q_qual_off;
       J.chdr[o] = h;
     }
   }
@@ -1368,7 +1371,7 @@ void launch_full_quals(const JobDev& J, hipStream_t st) {  // token planes are r
 void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm) {
   if (J.n_ow) {
     KT_BEGIN(tm, "ow_stats", st);
-    hipLaunchKernelGGL(k_ow_stats, dim3((J.n_ow + 3) / 4), dim3(NT), 0, st, J);
+    hipLaunchKernelGGL(k_ow_stats, dim3((J.n_ow + 3) / 4), dim3(NT), 4 * ow_stats_lds_per_wave(J.window_size), st, J);
     KT_END(tm, st);
   }
   KT_BEGIN(tm, "win_rank", st);

@@ -51,6 +51,7 @@ struct herro_ctx {
   // read store
   uint32_t n_reads = 0;
   std::vector<uint32_t> read_len, name_class;
+  std::vector<uint64_t> h_word_off, h_qual_off;  // host copies: overlap descriptors carry them (saves the kernel a dependent load)
   uint64_t* d_words = nullptr;
   uint32_t* d_p0 = nullptr;
   uint32_t* d_p1 = nullptr;
@@ -258,6 +259,8 @@ static int upload_reads(herro_ctx* ctx, uint32_t n_reads, const std::vector<uint
   if (nq) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_qual, qual, nq, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->n_reads = n_reads;
+  ctx->h_word_off = word_off;
+  ctx->h_qual_off = qual_off;
   ctx->read_len.resize(n_reads);
   for (uint32_t i = 0; i < n_reads; i++) ctx->read_len[i] = (uint32_t)(qual_off[i + 1] - qual_off[i]);
   ctx->name_class.resize(n_reads);
@@ -534,6 +537,11 @@ void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* aln
     d.start_off = x.h.start_off;
     d.end_off = x.h.end_off;
     d.scr_off = (uint32_t)out.scr_ops;
+    d.wtstart = win_start;
+    d.wlen = win_len;
+    d.t_woff = ctx->h_word_off[rid];
+    d.q_woff = ctx->h_word_off[al.qid];
+    d.q_qual_off = ctx->h_qual_off[al.qid];
     // ---- validate what the reference would assert / index (features.rs:585-679, 110-237)
     if (x.h.op_hi <= x.h.op_lo) return fail(HERRO_E_REFERENCE_PANIC, "empty cigar slice");
     if (d.tstart < win_start) return fail(HERRO_E_REFERENCE_PANIC, "overlap starts before its window (usize underflow)");

@@ -43,6 +43,13 @@ struct OwDesc {
   uint32_t end_off;    // cigar_end_offset
   uint32_t scr_off;    // offset of this overlap's op_t/op_q scratch
   uint32_t strand;     // 0 forward, 1 reverse
+  // copies of per-window / per-read facts, so that the per-overlap kernel starts from ONE record instead of a
+  // chain of dependent loads (descriptor -> window -> read offsets -> data)
+  uint32_t wtstart;    // first target position of the window (WinDesc::tstart)
+  uint32_t wlen;       // target bases in the window (WinDesc::win_len)
+  uint64_t t_woff;     // first 2-bit word of the target read
+  uint64_t q_woff;     // first 2-bit word of the query read
+  uint64_t q_qual_off; // first quality byte of the query read
 };
 
 struct WinDesc {
