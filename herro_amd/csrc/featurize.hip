@@ -30,7 +30,7 @@ namespace herro {
 
 static constexpr int NT = 256;       // threads per workgroup (4 waves)
 static constexpr int OPCAP = 1024;   // ops of one overlap-window staged in LDS by k_ow_stats
-static constexpr int EVCAP = 1024;   // overlaps whose insertion events are flattened through LDS
+static constexpr int EVCAP = 128;    // overlaps whose insertion events are flattened through LDS
 
 // ---- block-wide exclusive scan of one u32 per thread; returns exclusive prefix, *total = sum ----
 __device__ __forceinline__ uint32_t block_scan(uint32_t v, uint32_t* total, uint32_t* s_wave /*[NT/64]*/) {
@@ -750,7 +750,7 @@ __device__ __forceinline__ CellOut staged_cell(const JobDev& J, const TileLds<WI
 // =====================================================================================================
 __global__ __launch_bounds__(NT) void k_select_layout(JobDev J) {
   __shared__ uint32_t s_wave[NT / 64];
-  __shared__ uint32_t s_mi[HERRO_MAX_WINDOW];
+  extern __shared__ uint32_t s_mi[];  // [window_size] max insertion behind every position (dynamic: 4 B per position)
   __shared__ uint32_t s_pref[EVCAP];
   __shared__ double s_score[EVCAP];
   __shared__ uint32_t s_sel[32];
@@ -1390,7 +1390,7 @@ void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm) {
   }
   KT_END(tm, st);
   KT_BEGIN(tm, "select_layout", st);
-  hipLaunchKernelGGL(k_select_layout, dim3(J.n_win), dim3(NT), 0, st, J);
+  hipLaunchKernelGGL(k_select_layout, dim3(J.n_win), dim3(NT), (size_t)J.window_size * 4, st, J);
   KT_END(tm, st);
   KT_BEGIN(tm, "tile_plan", st);
   hipLaunchKernelGGL(k_tile_plan, dim3((J.n_tiles * 32 + NT - 1) / NT), dim3(NT), 0, st, J);
