@@ -688,7 +688,7 @@ __device__ __forceinline__ bool supported_from_counts(uint64_t c, uint32_t thres
 static constexpr int NCOL = 32;   // columns per staging pass
 static constexpr int TLD = HERRO_TILE + 4;  // byte-tile row stride for the output transpose (bank spread)
 static constexpr int BMW = 10;    // bitmap words per column   (tile spans <= 256 positions -> <= 9 words)
-static constexpr int MDS = 20;    // M/D op entries per column (more: the column takes the global-memory path)
+static constexpr int MDS = 16;    // M/D op entries per column (more: the column takes the global-memory path)
 static constexpr int WW = 14;     // 2-bit words per column    (<= 448 query bases)
 static constexpr int QB = 480;    // quality bytes per column  (multiple of 4)
 
@@ -1088,9 +1088,9 @@ __device__ __forceinline__ void tile_fetch(const JobDev& J, const TileHdr& th, c
 }
 
 __global__ __launch_bounds__(NT) void k_final_tiles_t(JobDev J) {
-  __shared__ uint2 s_bm[NCOL * BMW];
-  __shared__ uint4 s_md[NCOL * MDS];
-  __shared__ uint64_t s_words[NCOL * WW];
+  __shared__ uint2 s_bm[(HERRO_ROWS - 1) * BMW];
+  __shared__ uint4 s_md[(HERRO_ROWS - 1) * MDS];
+  __shared__ uint64_t s_words[HERRO_ROWS * WW];  // 30 columns + the target (slot 30)
   __shared__ CDesc s_cd[32];
   __shared__ __attribute__((aligned(16))) uint8_t s_tb[HERRO_ROWS * TLD];
   __shared__ uint32_t s_fb_ow[32];

@@ -76,6 +76,41 @@ def test_model_forward_tiling_edges(counts):
     assert max(np.abs(info3 - info).max(), np.abs(base3 - base).max()) <= 1e-4   # same arithmetic, different kernels
 
 
+def test_full_width_fc_kernel_matches():
+    """The FC layer switches to a full-width-tile GEMM when a launch has >= 32768 informative rows; run it on a
+    small input in a subprocess with the threshold forced down and compare with the default kernels."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import numpy as np, sys
+        sys.path.insert(0, 'tests')
+        import gpu_common as G
+        rng = np.random.default_rng(3)
+        B, L = 9, 100
+        bases = rng.integers(0, 11, (B, L, 31)).astype(np.uint8)
+        quals = rng.integers(33, 90, (B, L, 31)).astype(np.uint8)
+        idx = [np.sort(rng.choice(L, size=k, replace=False)) for k in (33, 1, 60, 17, 64, 5, 40, 2, 50)]
+        lens = np.array([len(i) for i in idx], np.int32)
+        flat = np.concatenate(idx).astype(np.int32)
+        c = G.ctx()
+        for p in (1, 3):
+            c.set_precision(p)
+            info, base = c.model_forward(bases, quals, lens, flat)
+            np.save(sys.argv[1] + f'_{p}_info.npy', info); np.save(sys.argv[1] + f'_{p}_base.npy', base)
+    """)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        outs = {}
+        for tag, env in (("dflt", {}), ("g256", {"HERRO_G256_MIN_M": "1"})):
+            e = dict(os.environ, **env)
+            subprocess.run([sys.executable, "-c", code, os.path.join(td, tag)], check=True, env=e,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            outs[tag] = {p: (np.load(os.path.join(td, f"{tag}_{p}_info.npy")), np.load(os.path.join(td, f"{tag}_{p}_base.npy")))
+                         for p in (1, 3)}
+        for p in (1, 3):
+            assert np.abs(outs["dflt"][p][0] - outs["g256"][p][0]).max() <= 1e-4
+            assert np.abs(outs["dflt"][p][1] - outs["g256"][p][1]).max() <= 1e-4
+
+
 def test_job_logits_and_fasta_reference_grouping():
     """features -> batches (reference grouping: never across reads) -> model -> consensus -> FASTA."""
     import model_ref as MR
