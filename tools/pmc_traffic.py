@@ -23,7 +23,7 @@ f, w = avg(sys.argv[1], "FETCH_SIZE"), avg(sys.argv[2], "WRITE_SIZE")
 rename = {"k_ow_stats": "ow_stats", "k_win_rank": "win_rank", "k_pass1_pos": "pass1_pos", "k_select_layout": "select_layout",
           "k_final_tiles": "final_tiles", "k_sup_compact": "sup_compact", "k_patch_conv1_s": "patch_conv1",
           "k_tile_plan": "tile_plan", "k_rf_quals": "rf_quals", "k_conv_w": "conv_fused", "k_gemm_g": "fc_gemm",
-          "k_layers": "layers_fused", "k_add_pe": "add_pe", "k_build_tokens": "build_tokens", "k_consensus": "consensus"}
+          "k_layers": "layers_fused", "k_final_tiles_t": "final_tiles", "k_gemm_g256": "fc_gemm", "k_add_pe": "add_pe", "k_build_tokens": "build_tokens", "k_consensus": "consensus"}
 out = {"group": int(sys.argv[3]), "unit": "bytes per launch", "kernels": {}}
 for k in sorted(set(f) | set(w)):
     fb, wb = f.get(k, 0.0) * 1024, w.get(k, 0.0) * 1024
