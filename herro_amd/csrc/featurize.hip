@@ -1275,28 +1275,51 @@ __global__ __launch_bounds__(NT) void k_sup_compact(JobDev J) {
 // sup_row[k] + half of all 31 columns).  This kernel writes just those cells of the quality planes, straight
 // from the read store (column_cell on global memory; neighbouring informative rows recompute shared cells).
 __global__ __launch_bounds__(NT) void k_rf_quals(JobDev J, uint32_t half) {
+  constexpr uint32_t RCAP = 1024;  // receptive-field rows handled per pass
+  __shared__ ColHdr s_h[HERRO_ROWS];
+  __shared__ uint32_t s_ow[HERRO_ROWS];
+  __shared__ uint32_t s_rm[RCAP];   // row-map entry of each receptive-field row (0xffffffff: outside the window)
+  __shared__ uint32_t s_r[RCAP];    // its row
   const uint32_t w = blockIdx.x;
   const uint32_t nsup = J.win_nsup[w], Lf = J.win_Lf[w];
   if (!nsup) return;
   const WinDesc wd = J.win[w];
-  const uint32_t span = 2 * half + 1, per = span * HERRO_ROWS, total = nsup * per;
+  const uint32_t span = 2 * half + 1;
   const uint32_t* rowmap = J.rowmap2 + wd.row_off;
-  for (uint32_t idx = threadIdx.x; idx < total; idx += NT) {
-    // neighbouring lanes: the rows of one receptive field in one column (same header, same ops, adjacent bytes)
-    const uint32_t k = idx / per, rem = idx % per, c = rem / span, d = rem % span;
-    const int32_t r = (int32_t)J.sup_row[wd.row_off + k] + (int32_t)d - (int32_t)half;
-    if (r < 0 || r >= (int32_t)Lf) continue;
-    const uint32_t rm = rowmap[r];
-    const int32_t p = (int32_t)(rm & 0xffffu);
-    const uint32_t j = rm >> 16;
-    uint32_t q = 33;
-    if (c == 0) {
-      if (j == 0) q = J.read_qual[J.read_qual_off[wd.rid] + wd.tstart + (uint32_t)p];
-    } else {
-      const uint32_t ow = J.sel_ow[(uint64_t)w * 32 + c];
-      if (ow != 0xffffffffu) q = column_cell<true>(J, J.chdr[ow], ow, p, j).qual;
+  // the 30 selected columns' headers, once per window (they were re-fetched for every cell)
+  if (threadIdx.x >= 1 && threadIdx.x < HERRO_ROWS) {
+    const uint32_t ow = J.sel_ow[(uint64_t)w * 32 + threadIdx.x];
+    s_ow[threadIdx.x] = ow;
+    if (ow != 0xffffffffu) s_h[threadIdx.x] = J.chdr[ow];
+  }
+  const uint64_t tq_off = J.read_qual_off[wd.rid] + wd.tstart;
+  const uint32_t kper = max(1u, RCAP / span);  // informative rows per pass
+  for (uint32_t k0 = 0; k0 < nsup; k0 += kper) {
+    const uint32_t nk = min(kper, nsup - k0), nrows = nk * span;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nrows; i += NT) {
+      const int32_t r = (int32_t)J.sup_row[wd.row_off + k0 + i / span] + (int32_t)(i % span) - (int32_t)half;
+      const bool in = r >= 0 && r < (int32_t)Lf;
+      s_r[i] = (uint32_t)r;
+      s_rm[i] = in ? rowmap[r] : 0xffffffffu;
     }
-    J.fin_q[wd.fin_off + (uint64_t)c * wd.lub + (uint32_t)r] = (uint8_t)q;
+    __syncthreads();
+    // neighbouring lanes: the rows of one receptive field in one column (same header, same ops, adjacent bytes)
+    const uint32_t total = nrows * HERRO_ROWS;
+    for (uint32_t idx = threadIdx.x; idx < total; idx += NT) {
+      const uint32_t k = idx / (span * HERRO_ROWS), rem = idx % (span * HERRO_ROWS), c = rem / span, d = rem % span;
+      const uint32_t rm = s_rm[k * span + d];
+      if (rm == 0xffffffffu) continue;
+      const int32_t p = (int32_t)(rm & 0xffffu);
+      const uint32_t j = rm >> 16;
+      uint32_t q = 33;
+      if (c == 0) {
+        if (j == 0) q = J.read_qual[tq_off + (uint32_t)p];
+      } else if (s_ow[c] != 0xffffffffu) {
+        q = column_cell<true>(J, s_h[c], s_ow[c], p, j).qual;
+      }
+      J.fin_q[wd.fin_off + (uint64_t)c * wd.lub + s_r[k * span + d]] = (uint8_t)q;
+    }
   }
 }
 
