@@ -65,8 +65,8 @@ def cpu_baseline(seed: int) -> dict:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--pool", type=int, default=2, help="distinct synthetic jobs cycled through")
     ap.add_argument("--group", type=int, default=32,
