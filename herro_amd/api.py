@@ -19,6 +19,8 @@ EXPORTS = [
     "herro_job_infer", "herro_job_consensus", "herro_job_window_info", "herro_job_window_copy", "herro_job_window_logits",
     "herro_job_consensus_fasta", "herro_model_forward", "herro_timing_enable", "herro_timing_reset",
     "herro_timing_get", "herro_job_stats", "herro_debug_extract_windows",
+    "herro_paf_parse", "herro_oec_read", "herro_paf_n_targets", "herro_paf_target_ids", "herro_paf_aln_off",
+    "herro_paf_alignments", "herro_paf_free",
 ]
 
 
@@ -81,6 +83,17 @@ def lib():
         L.herro_job_stats.argtypes = [vp, vp]
         L.herro_debug_extract_windows.restype = C.c_int64
         L.herro_debug_extract_windows.argtypes = [vp, u32, u32, vp, u64, vp, u64]
+        L.herro_paf_parse.restype = vp
+        L.herro_paf_parse.argtypes = [C.c_char_p, u64, u32, C.c_char_p, vp, vp, i32, vp, u64]
+        L.herro_oec_read.restype = vp
+        L.herro_oec_read.argtypes = [C.c_char_p, u32, C.c_char_p, vp, vp, i32, vp, u64]
+        L.herro_paf_n_targets.restype = u32
+        L.herro_paf_n_targets.argtypes = [vp]
+        for f in (L.herro_paf_target_ids, L.herro_paf_aln_off, L.herro_paf_alignments):
+            f.restype = vp
+            f.argtypes = [vp]
+        L.herro_paf_free.restype = None
+        L.herro_paf_free.argtypes = [vp]
         _LIB = L
     return _LIB
 
@@ -201,6 +214,16 @@ class Context:
             raise HerroError(code, msg)
         return Job(self, h, len(rids))
 
+    def create_job_from_paf(self, paf: "Paf", window_size: int) -> "Job":
+        """herro_job_create straight from a parsed PAF batch (targets in its order); `paf` must outlive the call."""
+        h = self._l.herro_job_create(self.h, len(paf.targets), paf.targets.ctypes.data, paf.aln_off.ctypes.data,
+                                     paf._alns_ptr, window_size)
+        if not h:
+            msg = self._l.herro_last_error(self.h).decode()
+            code = int(msg.rsplit("[code ", 1)[1].rstrip("]")) if "[code " in msg else -1
+            raise HerroError(code, msg)
+        return Job(self, h, len(paf.targets))
+
     def model_forward(self, bases: np.ndarray, quals: np.ndarray, lens: np.ndarray, indices: np.ndarray):
         """inference.rs:147-175: tokens u8 [B,L,31], raw quals u8 [B,L,31], lens, flat indices -> logits."""
         bases = np.ascontiguousarray(bases, np.uint8)
@@ -294,6 +317,52 @@ class Job:
         self.ctx._chk(self._l.herro_job_stats(self.h, o.ctypes.data))
         k = ("read_bytes", "op_bytes", "out_bytes", "sum_len", "sum_supported", "n_model_windows")
         return {a: int(b) for a, b in zip(k, o)}
+
+
+class Paf:
+    """Parsed PAF / .oec.zst batch (host only; overlaps.rs:117-202, 292-323): targets in order of first
+    appearance, their alignments in file order.  `targets`, `aln_off`, `alns` are what herro_job_create takes;
+    the CIGAR pointers inside `alns` stay valid while this object lives."""
+
+    def __init__(self, names: list[bytes], text: bytes | None = None, path: str | None = None, core=None, threads: int = 0):
+        self.h = None
+        L = lib()
+        blob = b"".join(names)
+        off = np.zeros(len(names) + 1, np.uint64)
+        off[1:] = np.cumsum([len(n) for n in names])
+        core_a = None if core is None else np.ascontiguousarray(core, np.uint8)
+        err = C.create_string_buffer(512)
+        cptr = None if core_a is None else core_a.ctypes.data
+        if text is not None:
+            h = L.herro_paf_parse(text, len(text), len(names), blob, off.ctypes.data, cptr, threads, err, 512)
+        else:
+            h = L.herro_oec_read(path.encode(), len(names), blob, off.ctypes.data, cptr, threads, err, 512)
+        if not h:
+            raise HerroError(-3, err.value.decode())
+        self._l, self.h = L, h
+        n = L.herro_paf_n_targets(h)
+        self.targets = np.ctypeslib.as_array(C.cast(L.herro_paf_target_ids(h), C.POINTER(C.c_uint32)), (n,)).copy() if n else np.zeros(0, np.uint32)
+        self.aln_off = np.ctypeslib.as_array(C.cast(L.herro_paf_aln_off(h), C.POINTER(C.c_uint64)), (n + 1,)).copy()
+        na = int(self.aln_off[-1])
+        self.n_alns = na
+        self._alns_ptr = L.herro_paf_alignments(h)
+        self.alns = (Alignment * na).from_address(self._alns_ptr) if na else []
+
+    def rows(self):
+        """[(qid, qlen, qstart, qend, strand, tid, tlen, tstart, tend, cigar bytes)] in output order."""
+        out = []
+        for a in self.alns:
+            out.append((a.qid, a.qlen, a.qstart, a.qend, a.strand, a.tid, a.tlen, a.tstart, a.tend,
+                        C.string_at(a.cigar, a.cigar_len)))
+        return out
+
+    def close(self):
+        if self.h:
+            self._l.herro_paf_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
 
 
 def job_from_synth(ctx: Context, sb, window_size: int, targets=None) -> Job:

@@ -171,6 +171,32 @@ int herro_job_stats(herro_job* job, uint64_t* out);
 int64_t herro_debug_extract_windows(const herro_alignment* a, uint32_t n_windows, uint32_t window_size,
                                     uint64_t* out, uint64_t cap, char* err, uint64_t err_cap);
 
+/* ---- PAF / .oec.zst ingest on the host (needs no device) ---------------------------------------
+ * herro_paf_parse replaces `parse_paf` (overlaps.rs:117-202): one overlap per line, tab separated
+ *   qname qlen qstart qend strand tname tlen tstart tend ... cg:Z:<CIGAR>   (CIGAR in the LAST column),
+ * lines with unknown names, self overlaps and every (query, target) pair after its first occurrence are
+ * dropped; the rest is grouped by target.  Quirks kept: the last byte of every line is dropped whether or
+ * not it is a newline; numbers wrap in u32; malformed numbers / strand / CIGAR column are the reference's
+ * panics (NULL is returned, `err` carries the message and the line).  `names` + `name_off[n_reads+1]` give
+ * the read ids (index = read id of the read store; a repeated name maps to its last index, like the
+ * reference's HashMap).  `core` (optional, one byte per read) replaces the `core` name set: targets with a 0
+ * are skipped.  Targets come out in order of first appearance (the reference iterates a HashMap).
+ * herro_oec_read replaces `read_batches` for one file (overlaps.rs:292-323): zstd stream holding
+ * "<n_targets>\n", n_targets id lines (ignored, as in the reference), then PAF lines.
+ * The result feeds herro_job_create directly: rids = herro_paf_target_ids, aln_off, alns.  The CIGAR
+ * pointers stay valid until herro_paf_free. */
+typedef struct herro_paf herro_paf;
+herro_paf* herro_paf_parse(const char* text, uint64_t len, uint32_t n_reads, const char* names,
+                           const uint64_t* name_off, const uint8_t* core, int n_threads, char* err,
+                           uint64_t err_cap);
+herro_paf* herro_oec_read(const char* path, uint32_t n_reads, const char* names, const uint64_t* name_off,
+                          const uint8_t* core, int n_threads, char* err, uint64_t err_cap);
+uint32_t herro_paf_n_targets(const herro_paf* p);
+const uint32_t* herro_paf_target_ids(const herro_paf* p);
+const uint64_t* herro_paf_aln_off(const herro_paf* p);        /* [n_targets + 1] */
+const herro_alignment* herro_paf_alignments(const herro_paf* p);
+void herro_paf_free(herro_paf* p);
+
 #ifdef __cplusplus
 }
 #endif

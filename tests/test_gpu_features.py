@@ -85,3 +85,30 @@ def test_properties_full_size():
         assert g.quals.min() >= 33
         assert ((g.quals == 33) | isbase).all()                   # non-base cells carry the default quality
     job.close()
+
+
+def test_job_from_paf_text_equals_job_from_arrays():
+    """PAF text -> herro_paf_parse -> herro_job_create gives the same windows as the array entry (f2: ingest)."""
+    sb = synth.generate(4, 1500, 12, seed=9, flank_min=40, flank_max=80, p_partial=0.3)
+    c = G.ctx()
+    G.load_synth(c, sb)
+    names = [sb.read_name(i).encode() for i in range(sb.n_reads)]
+    lines = []
+    for t in range(sb.n_targets):
+        for a in range(int(sb.tgt_aln_off[t]), int(sb.tgt_aln_off[t + 1])):
+            r = sb.aln[a]
+            lines.append(b"\t".join([names[r[0]], str(r[1]).encode(), str(r[2]).encode(), str(r[3]).encode(), b"-" if r[4] else b"+",
+                                      names[r[5]], str(r[6]).encode(), str(r[7]).encode(), str(r[8]).encode(), b"60", b"60", b"255",
+                                      b"cg:Z:" + sb.cigar(a)]))
+    paf = api.Paf(names, text=b"\n".join(lines) + b"\n")
+    assert paf.targets.tolist() == sb.tgt_rid.tolist()
+    ja = api.job_from_synth(c, sb, 512)
+    jp = c.create_job_from_paf(paf, 512)
+    ja.featurize()
+    jp.featurize()
+    assert ja.n_windows == jp.n_windows
+    for w in range(ja.n_windows):
+        a, b = ja.window(w, encoded=True), jp.window(w, encoded=True)
+        assert a.info.length == b.info.length and a.info.n_supported == b.info.n_supported
+        assert np.array_equal(a.bases, b.bases) and np.array_equal(a.quals, b.quals)
+    ja.close(); jp.close(); paf.close()
