@@ -112,3 +112,33 @@ def test_job_from_paf_text_equals_job_from_arrays():
         assert a.info.length == b.info.length and a.info.n_supported == b.info.n_supported
         assert np.array_equal(a.bases, b.bases) and np.array_equal(a.quals, b.quals)
     ja.close(); jp.close(); paf.close()
+
+
+def test_features_directory_equals_oracle(tmp_path):
+    """`herro features` sink (features.rs:724-764): product files == files written from the oracle's windows."""
+    import os
+    from herro_amd import io as hio
+    sb = synth.generate(3, 900, 10, seed=21, flank_min=30, flank_max=60, p_partial=0.2)
+    c = G.ctx()
+    G.load_synth(c, sb)
+    store = O.store_from_synth(sb)
+    job = api.job_from_synth(c, sb, 256)
+    job.featurize()
+    tw, w0 = [], 0
+    for t in range(sb.n_targets):
+        rid, rows, cigs = O.target_alignments(sb, t)
+        res = store.extract_features(rid, rows, cigs, 256)
+        d = str(tmp_path / "oracle" / sb.read_name(rid))
+        for w in range(len(res)):
+            ow = res.window(w)
+            hio.write_window_features(d, w, [sb.read_name(int(q)) for q in ow.qids], ow.bases, ow.quals, ow.sup_pos, ow.sup_ins)
+        tw.append((rid, w0, len(res)))
+        w0 += len(res)
+    n = hio.write_job_features(job, str(tmp_path / "product"), sb.read_name, tw)
+    assert n == w0 == job.n_windows
+    for root, _, files in os.walk(tmp_path / "oracle"):
+        for f in files:
+            a = open(os.path.join(root, f), "rb").read()
+            b = open(os.path.join(str(root).replace("/oracle/", "/product/"), f), "rb").read()
+            assert a == b, (root, f)
+    job.close()
