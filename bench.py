@@ -73,7 +73,7 @@ def main():
                     help="batches per launch group: the windows of GROUP consecutive steps are featurised and run "
                          "through the model in one set of kernel launches (each window keeps its own batch's padding)")
     ap.add_argument("--precision", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=2,
                     help="independent contexts (HIP streams) per GPU, each driven by its own host thread, like the "
                          "reference's concurrent feature / inference threads per device (lib.rs:154-200)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
