@@ -102,7 +102,7 @@ def main():
     pool = max(1, min(args.pool, (n_full + NS - 1) // NS if n_full else 1))
     n_jobs = NS * pool
     n_t = n_jobs * G * targets_per_step + rem * targets_per_step
-    sb = synth.generate(n_t, 4 * W, n_ovl, seed=synth.SEED + 2 + 1000 * rank)
+    sb = synth.generate_parallel(n_t, 4 * W, n_ovl, seed=synth.SEED + 2 + 1000 * rank)  # chunks generated concurrently, merged
     ctxs = []
     for s_i in range(NS):
         c = api.Context(local)

@@ -98,3 +98,42 @@ def generate(n_targets: int, target_len: int = 4 * 4096, n_overlaps: int = 32, *
         return b
     finally:
         lib.herro_synth_free(h)
+
+
+def merge(batches: list[SynthBatch]) -> SynthBatch:
+    """Concatenate independent batches into one read store (read ids, alignment and CIGAR offsets rebased)."""
+    if len(batches) == 1:
+        return batches[0]
+    seq = np.concatenate([b.seq for b in batches])
+    qual = np.concatenate([b.qual for b in batches])
+    offs, alns, cig_offs, tgt_offs, tgt_rids = [np.zeros(1, np.uint64)], [], [], [np.zeros(1, np.uint64)], []
+    rbase = bbase = abase = cbase = 0
+    for b in batches:
+        offs.append(b.off[1:] + np.uint64(bbase))
+        a = b.aln.copy()
+        a[:, 0] += np.uint32(rbase)   # qid
+        a[:, 5] += np.uint32(rbase)   # tid
+        alns.append(a)
+        cig_offs.append(b.cig_off + np.uint64(cbase))
+        tgt_offs.append(b.tgt_aln_off[1:] + np.uint64(abase))
+        tgt_rids.append(b.tgt_rid + np.uint32(rbase))
+        rbase += b.n_reads; bbase += len(b.seq); abase += len(b.aln); cbase += len(b.cig)
+    return SynthBatch(seq=seq, qual=qual, off=np.concatenate(offs), aln=np.concatenate(alns),
+                      cig_off=np.concatenate(cig_offs), cig=np.concatenate([b.cig for b in batches]),
+                      tgt_aln_off=np.concatenate(tgt_offs), tgt_rid=np.concatenate(tgt_rids))
+
+
+def generate_parallel(n_targets: int, target_len: int = 4 * 4096, n_overlaps: int = 32, *, seed: int = SEED,
+                      chunk: int = 128, workers: int | None = None, **kw) -> SynthBatch:
+    """`generate` for large batches: chunks of `chunk` targets are generated concurrently (the generator is a
+    single-threaded C++ call that releases the GIL; chunk i uses seed + 7919 * i) and merged.  The data differ
+    from one `generate(n_targets, seed=seed)` call — same distribution, different draws."""
+    import concurrent.futures as cf
+    import os
+    sizes = [min(chunk, n_targets - i) for i in range(0, n_targets, chunk)]
+    if len(sizes) <= 1:
+        return generate(n_targets, target_len, n_overlaps, seed=seed, **kw)
+    workers = workers or min(len(sizes), max(1, (os.cpu_count() or 1)), 64)
+    with cf.ThreadPoolExecutor(workers) as ex:
+        parts = list(ex.map(lambda iz: generate(iz[1], target_len, n_overlaps, seed=seed + 7919 * iz[0], **kw), enumerate(sizes)))
+    return merge(parts)

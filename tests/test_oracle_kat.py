@@ -64,3 +64,29 @@ def test_bad_cigar_panics():
     st = _store()
     with pytest.raises(O.OracleError):
         st.extract_features(0, [ROW], [b"4M1X7M"], 5)  # aligners.rs:281-286
+
+
+def test_merged_synthetic_batches_keep_every_target_intact():
+    """synth.generate_parallel / merge (what bench.py feeds the GPU): a target of the merged batch gives the
+    oracle exactly the windows it gave inside its own chunk."""
+    import oracle_lib as O
+    from herro_amd import synth
+    parts = [synth.generate(2, 600, 6, seed=50 + i, flank_min=20, flank_max=40) for i in range(3)]
+    m = synth.merge(parts)
+    assert m.n_targets == 6 and m.n_reads == sum(p.n_reads for p in parts)
+    sm = O.store_from_synth(m)
+    t = 0
+    for p in parts:
+        sp = O.store_from_synth(p)
+        for tl in range(p.n_targets):
+            rid_p, rows_p, cigs_p = O.target_alignments(p, tl)
+            rid_m, rows_m, cigs_m = O.target_alignments(m, t)
+            assert cigs_p == cigs_m and m.read_seq(rid_m) == p.read_seq(rid_p)
+            rp, rm_ = sp.extract_features(rid_p, rows_p, cigs_p, 256), sm.extract_features(rid_m, rows_m, cigs_m, 256)
+            assert len(rp) == len(rm_)
+            for w in range(len(rp)):
+                a, b = rp.window(w), rm_.window(w)
+                assert (a.bases == b.bases).all() and (a.quals == b.quals).all() and list(a.sup_pos) == list(b.sup_pos)
+            t += 1
+    g = synth.generate_parallel(5, 600, 6, seed=9, chunk=2, flank_min=20, flank_max=40)
+    assert g.n_targets == 5 and int(g.tgt_aln_off[-1]) == len(g.aln) and int(g.off[-1]) == len(g.seq)
