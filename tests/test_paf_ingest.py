@@ -119,3 +119,55 @@ def test_oec_zst_file(tmp_path):
     p.close()
     with pytest.raises(api.HerroError):
         api.Paf(NAMES, path=str(tmp_path / "missing.oec.zst"))
+
+
+def test_randomised_differential():
+    """Random PAF-like text (valid lines, unknown names, duplicates, truncated / corrupted fields, missing final
+    newline): the product and the restatement agree on the result, or both report the reference's panic at the same line."""
+    rng = np.random.default_rng(12345)
+    names = [b"q%d" % i for i in range(12)] + [b"q3"]            # one repeated name
+    pool = names + [b"nope", b""]
+    for trial in range(300):
+        L = []
+        for _ in range(int(rng.integers(0, 12))):
+            q, t = pool[int(rng.integers(0, len(pool)))], pool[int(rng.integers(0, len(pool)))]
+            f = [q, b"%d" % rng.integers(0, 5000), b"%d" % rng.integers(0, 100), b"%d" % rng.integers(100, 5000),
+                 [b"+", b"-", b"*", b""][int(rng.choice(4, p=[0.45, 0.45, 0.05, 0.05]))], t,
+                 b"%d" % rng.integers(0, 5000), b"%d" % rng.integers(0, 100), b"%d" % rng.integers(100, 5000),
+                 b"60", b"cg:Z:%dM" % rng.integers(1, 900)]
+            r = rng.random()
+            if r < 0.06:
+                f[int(rng.integers(1, 9))] = b"12a"                # bad digit somewhere
+            elif r < 0.10:
+                f = f[:int(rng.integers(1, 10))]                   # truncated line
+            elif r < 0.13:
+                f[-1] = b"cg"                                      # short last column
+            elif r < 0.16:
+                f = f[:9] + [f[-1]]                                # no optional columns
+            L.append(b"\t".join(f))
+        text = b"\n".join(L) + (b"\n" if rng.random() < 0.8 and L else b"")
+        core = None if rng.random() < 0.7 else {names[int(i)] for i in rng.integers(0, len(names), 4)}
+        flags = None if core is None else np.array([1 if n in core else 0 for n in names], np.uint8)
+        try:
+            want_order, want = R.parse_paf(text, names, core)
+        except R.ReferencePanic:
+            # which line: re-run line by line prefixes until the panic appears
+            k = 1
+            lines = text.split(b"\n")
+            while True:
+                try:
+                    R.parse_paf(b"\n".join(lines[:k]) + b"\n", names, core)
+                except R.ReferencePanic:
+                    break
+                k += 1
+                assert k <= len(lines) + 1
+            with pytest.raises(api.HerroError) as e:
+                api.Paf(names, text=text, core=flags)
+            # the prefix test re-adds a newline the last line may not have had: only check the line when it is not the last
+            if k < len(lines):
+                assert f"line {k})" in str(e.value), (trial, k, str(e.value))
+            continue
+        p = api.Paf(names, text=text, core=flags, threads=int(rng.integers(1, 4)))
+        assert p.targets.tolist() == want_order, trial
+        assert p.rows() == [w for t in want_order for w in want[t]], trial
+        p.close()
