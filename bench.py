@@ -102,7 +102,11 @@ def main():
     pool = max(1, min(args.pool, (n_full + NS - 1) // NS if n_full else 1))
     n_jobs = NS * pool
     n_t = n_jobs * G * targets_per_step + rem * targets_per_step
-    sb = synth.generate_parallel(n_t, 4 * W, n_ovl, seed=synth.SEED + 2 + 1000 * rank)  # chunks generated concurrently, merged
+    try:  # chunks generated concurrently and merged (the generator is single-threaded; this is input preparation only)
+        sb = synth.generate_parallel(n_t, 4 * W, n_ovl, seed=synth.SEED + 2 + 1000 * rank)
+    except Exception as e:  # pragma: no cover
+        print(f"bench: parallel input generation failed ({e!r}); generating serially", file=sys.stderr)
+        sb = synth.generate(n_t, 4 * W, n_ovl, seed=synth.SEED + 2 + 1000 * rank)
     ctxs = []
     for s_i in range(NS):
         c = api.Context(local)
