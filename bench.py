@@ -283,7 +283,7 @@ def main():
                                      "outside the timed region; includes the Python-side array packing"},
             "kernels": kern,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(synth.SEED + 2)
         print(json.dumps(out))
     for j in [j for js in jobs for j in js] + ([rem_job] if rem_job else []):
