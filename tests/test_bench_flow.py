@@ -1,0 +1,110 @@
+"""not-gpu: bench.py's control flow end to end with the device API replaced by stand-ins — argument defaults, launch
+grouping, the pipelined enqueue order per stream, the second (timed) pass and the JSON contract.  The numbers are
+meaningless here; what is checked is that every step count is honoured and the line has every required field."""
+import importlib
+import json
+import os
+import sys
+import types
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+class FakeJob:
+    log = []
+
+    def __init__(self, ctx, n_windows):
+        self.ctx, self.n_windows, self.state = ctx, n_windows, "new"
+
+    def featurize(self):
+        FakeJob.log.append(("F", id(self)))
+        self.state = "featurized"
+
+    def infer(self, batch, mode):
+        assert self.state == "featurized", "infer before featurize"
+        FakeJob.log.append(("I", id(self)))
+        self.state = "inferred"
+
+    def consensus(self):
+        assert self.state == "inferred"
+        FakeJob.log.append(("C", id(self)))
+        self.state = "done"
+
+    def close(self):
+        pass
+
+    def stats(self):
+        n = self.n_windows
+        return {"read_bytes": 169000 * n, "op_bytes": 13000 * n, "out_bytes": 292000 * n, "sum_len": 4711 * n,
+                "sum_supported": 15 * n, "n_model_windows": n}
+
+
+class FakeCtx:
+    def __init__(self, dev):
+        self.on = False
+
+    def load_model(self, p): pass
+    def set_precision(self, m): pass
+    def set_reads(self, *a): pass
+    def synchronize(self): pass
+    def timing_enable(self, on=True): self.on = on
+    def timing_reset(self): pass
+    def close(self): pass
+
+    def timing(self):
+        names = ["ow_stats", "win_rank", "pass1_pos", "select_layout", "tile_plan", "final_tiles", "sup_compact", "rf_quals",
+                 "build_tokens", "conv_fused", "fc_gemm", "add_pe", "layers_fused", "consensus"]
+        return {n: (1.0 + i, 4) for i, n in enumerate(names)}
+
+
+@pytest.mark.parametrize("argv,steps", [(["--steps", "12", "--warmup", "4", "--group", "3", "--streams", "2"], 12),
+                                        (["--steps", "7", "--warmup", "1", "--group", "32", "--streams", "2"], 7),
+                                        (["--steps", "1", "--warmup", "0"], 1),
+                                        ([], None)])
+def test_bench_flow(monkeypatch, capsys, argv, steps):
+    import torch
+    from herro_amd import api, synth, model_io
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a: None)
+    monkeypatch.setattr(api, "Context", FakeCtx)
+    made = []
+
+    def fake_job_from_synth(ctx, sb, W, targets=None):
+        j = FakeJob(ctx, 4 * len(list(targets)))
+        made.append(j)
+        return j
+    monkeypatch.setattr(api, "job_from_synth", fake_job_from_synth)
+    fake_sb = types.SimpleNamespace(seq=None, qual=None, off=None)
+    monkeypatch.setattr(synth, "generate_parallel", lambda *a, **k: fake_sb)
+    monkeypatch.setattr(synth, "generate", lambda *a, **k: fake_sb)
+    monkeypatch.setattr(model_io, "default_model_file", lambda d: ("model.bin", None))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--no-cpu-baseline"] + argv)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    FakeJob.log = []
+    bench.main()
+    out = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
+    assert len(out) == 1, out
+    d = json.loads(out[0])
+    for k in REQUIRED:
+        assert k in d, k
+    if steps is not None:
+        assert d["steps"] == steps
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "windows/s" and "workload" in d["config"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+    # every job that ran went featurize -> infer -> consensus, and the timed region covered exactly `steps` batches:
+    # windows run in the timed region = steps * batch; count via the log between warm-up and the kernel-timing pass is
+    # not separable here, so check the invariant the pipeline relies on instead: no job is inferred twice in a row
+    last = {}
+    for ev, jid in FakeJob.log:
+        if ev == "I":
+            assert last.get(jid) == "F"
+        last[jid] = ev
