@@ -20,7 +20,7 @@ EXPORTS = [
     "herro_job_consensus_fasta", "herro_model_forward", "herro_timing_enable", "herro_timing_reset",
     "herro_timing_get", "herro_job_stats", "herro_debug_extract_windows",
     "herro_paf_parse", "herro_oec_read", "herro_paf_n_targets", "herro_paf_target_ids", "herro_paf_aln_off",
-    "herro_paf_alignments", "herro_paf_free",
+    "herro_paf_alignments", "herro_paf_free", "herro_debug_host_ctx", "herro_debug_job_array",
 ]
 
 
@@ -94,6 +94,10 @@ def lib():
             f.argtypes = [vp]
         L.herro_paf_free.restype = None
         L.herro_paf_free.argtypes = [vp]
+        L.herro_debug_host_ctx.restype = vp
+        L.herro_debug_host_ctx.argtypes = [u32, vp, vp]
+        L.herro_debug_job_array.restype = C.c_int64
+        L.herro_debug_job_array.argtypes = [vp, i32, vp, vp]
         _LIB = L
     return _LIB
 
@@ -317,6 +321,33 @@ class Job:
         self.ctx._chk(self._l.herro_job_stats(self.h, o.ctypes.data))
         k = ("read_bytes", "op_bytes", "out_bytes", "sum_len", "sum_supported", "n_model_windows")
         return {a: int(b) for a, b in zip(k, o)}
+
+
+OW_DTYPE = np.dtype([(n, "<u4") for n in ("win", "qid", "cls", "tstart", "qbeg", "qlen", "op_begin", "op_cnt", "start_off",
+                                            "end_off", "scr_off", "strand", "wtstart", "wlen")] +
+                    [(n, "<u8") for n in ("t_woff", "q_woff", "q_qual_off")], align=True)   # OwDesc (csrc/pileup_core.h)
+WIN_DTYPE = np.dtype([(n, "<u4") for n in ("rid", "wid", "n_wids", "tstart", "win_len", "ow_begin", "ow_cnt", "lub")] +
+                     [(n, "<u8") for n in ("col_off", "fin_off", "row_off", "pos_off")], align=True)   # WinDesc
+
+
+class HostContext(Context):
+    """Device-free context for testing the host half of herro_job_create (herro_debug_host_ctx)."""
+
+    def __init__(self, read_len, name_class=None):
+        self._l = lib()
+        rl = np.ascontiguousarray(read_len, np.uint32)
+        nc = None if name_class is None else np.ascontiguousarray(name_class, np.uint32)
+        self.h = self._l.herro_debug_host_ctx(len(rl), rl.ctypes.data, None if nc is None else nc.ctypes.data)
+
+    def job_arrays(self, job: "Job") -> dict:
+        out = {}
+        for which, (name, dt) in enumerate([("ops", np.dtype("<u4")), ("ow", OW_DTYPE), ("win", WIN_DTYPE), ("tile_win", np.dtype("<u4")),
+                                            ("tile_r0", np.dtype("<u4")), ("tgt_win_off", np.dtype("<u4"))]):
+            p, eb = C.c_void_p(), C.c_uint32()
+            n = self._l.herro_debug_job_array(job.h, which, C.byref(p), C.byref(eb))
+            assert n >= 0 and eb.value == dt.itemsize, (name, n, eb.value, dt.itemsize)
+            out[name] = np.frombuffer((C.c_char * (n * dt.itemsize)).from_address(p.value), dt, n).copy() if n else np.zeros(0, dt)
+        return out
 
 
 class Paf:

@@ -53,6 +53,7 @@ struct herro_ctx {
   uint32_t n_reads = 0;
   std::vector<uint32_t> read_len, name_class;
   std::vector<uint64_t> h_word_off, h_qual_off;  // host copies: overlap descriptors carry them (saves the kernel a dependent load)
+  bool host_only = false;  // herro_debug_host_ctx: no device; herro_job_create stops after the host half
   uint64_t* d_words = nullptr;
   uint32_t* d_p0 = nullptr;
   uint32_t* d_p1 = nullptr;
@@ -100,6 +101,8 @@ struct herro_job {
   JobDev J{};
   std::vector<void*> allocs;
   bool featurized = false, synced = false, inferred = false;
+  uint32_t host_max_cols = 0, host_n_cls = 0;   // filled for host-only jobs (herro_debug_host_ctx)
+  uint64_t host_scr_ops = 0, host_fin_bytes = 0;
   bool quals_full = false;   // the complete quality planes exist (featurize writes tokens only)
   // host copies after sync
   std::vector<uint32_t> h_Lf, h_nsup, h_nkept;
@@ -181,6 +184,7 @@ static void free_all(std::vector<void*>& v) {
 
 void herro_destroy(herro_ctx* ctx) {
   if (!ctx) return;
+  if (ctx->host_only) { delete ctx; return; }
   hipSetDevice(ctx->device);
   hipDeviceSynchronize();
   ctx->timer.reset();
@@ -606,10 +610,10 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
     ctx->err = m + " [code " + std::to_string(code) + "]";
     return nullptr;
   };
-  if (!ctx->d_words) return fail(HERRO_E_STATE, "herro_set_reads must be called first");
+  if (!ctx->d_words && !ctx->host_only) return fail(HERRO_E_STATE, "herro_set_reads must be called first");
   if (W < 16 || W > HERRO_MAX_WINDOW) return fail(HERRO_E_UNSUPPORTED, "window_size must be in [16, 8192]");
   if (n_targets && (!rids || !aln_off)) return fail(HERRO_E_INVALID, "null argument");
-  hipSetDevice(ctx->device);
+  if (!ctx->host_only) hipSetDevice(ctx->device);
 
   const bool prof = getenv("HERRO_HOST_PROFILE") != nullptr;
   auto tnow = [] { return std::chrono::steady_clock::now(); };
@@ -715,6 +719,10 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   job->row_elems = row_elems;
 
   auto t_merged = tnow();
+  if (ctx->host_only) {  // test hook: the host half (descriptors) only
+    job->host_max_cols = max_cols; job->host_n_cls = n_cls; job->host_scr_ops = scr_ops; job->host_fin_bytes = fin_bytes;
+    return job.release();
+  }
   // ---- device allocation + upload
   const uint32_t n_ow = (uint32_t)job->ow.size(), n_win = (uint32_t)job->win.size();
   JobDev& J = job->J;
@@ -784,6 +792,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
 
 void herro_job_free(herro_job* job) {
   if (!job) return;
+  if (job->ctx->host_only) { delete job; return; }
   hipSetDevice(job->ctx->device);
   hipStreamSynchronize(job->ctx->stream);
   free_all(job->allocs);
@@ -1279,6 +1288,40 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
   hipMemcpy(info_logits, d_info, N * 4, hipMemcpyDeviceToHost);
   hipMemcpy(bases_logits, d_base, N * 20, hipMemcpyDeviceToHost);
   return done(HERRO_OK);
+}
+
+// ---- host-only test hooks: the host half of herro_job_create without a device ------------------------
+// herro_debug_host_ctx builds a context that only knows the read lengths (and name classes); herro_job_create on it
+// runs CIGAR parsing, windowing, validation and the merge, then stops; herro_debug_job_array exposes the descriptors.
+herro_ctx* herro_debug_host_ctx(uint32_t n_reads, const uint32_t* read_len, const uint32_t* name_class) {
+  auto ctx = new herro_ctx();
+  ctx->host_only = true;
+  ctx->n_reads = n_reads;
+  ctx->read_len.assign(read_len, read_len + n_reads);
+  ctx->name_class.resize(n_reads);
+  for (uint32_t i = 0; i < n_reads; i++) ctx->name_class[i] = name_class ? name_class[i] : i;
+  ctx->h_word_off.assign(n_reads + 1, 0);
+  ctx->h_qual_off.assign(n_reads + 1, 0);
+  for (uint32_t i = 0; i < n_reads; i++) {  // the layout herro_set_reads produces
+    ctx->h_word_off[i + 1] = ctx->h_word_off[i] + ((uint64_t)read_len[i] + 31) / 32;
+    ctx->h_qual_off[i + 1] = ctx->h_qual_off[i] + read_len[i];
+  }
+  return ctx;
+}
+
+// which: 0 ops (u32), 1 OwDesc, 2 WinDesc, 3 tile_win (u32), 4 tile_r0 (u32), 5 tgt_win_off (u32).
+// Returns the element count, *ptr the array, *elem_bytes the element size.
+int64_t herro_debug_job_array(herro_job* job, int which, const void** ptr, uint32_t* elem_bytes) {
+  if (!job || !ptr || !elem_bytes) return HERRO_E_INVALID;
+  switch (which) {
+    case 0: *ptr = job->ops.data(); *elem_bytes = 4; return (int64_t)job->ops.size();
+    case 1: *ptr = job->ow.data(); *elem_bytes = sizeof(OwDesc); return (int64_t)job->ow.size();
+    case 2: *ptr = job->win.data(); *elem_bytes = sizeof(WinDesc); return (int64_t)job->win.size();
+    case 3: *ptr = job->tile_win.data(); *elem_bytes = 4; return (int64_t)job->tile_win.size();
+    case 4: *ptr = job->tile_r0.data(); *elem_bytes = 4; return (int64_t)job->tile_r0.size();
+    case 5: *ptr = job->tgt_win_off.data(); *elem_bytes = 4; return (int64_t)job->tgt_win_off.size();
+    default: return HERRO_E_INVALID;
+  }
 }
 
 // ---- host-only test hook: the product's windowing on one alignment (no device needed) -----------

@@ -171,6 +171,15 @@ int herro_job_stats(herro_job* job, uint64_t* out);
 int64_t herro_debug_extract_windows(const herro_alignment* a, uint32_t n_windows, uint32_t window_size,
                                     uint64_t* out, uint64_t cap, char* err, uint64_t err_cap);
 
+/* Host-only test hooks for the host half of herro_job_create (CIGAR parsing, windowing, validation, descriptor
+ * layout): herro_debug_host_ctx makes a context without a device from the read lengths (name_class may be NULL);
+ * herro_job_create on it returns a job that holds the descriptors only (free it with herro_job_free, the context with
+ * herro_destroy; no other call is valid on them); herro_debug_job_array exposes them: which = 0 binary ops (u32),
+ * 1 overlap-window descriptors, 2 window descriptors (layouts: csrc/pileup_core.h), 3 / 4 tile -> window / first row,
+ * 5 first window of every target.  Returns the element count (<0: error). */
+herro_ctx* herro_debug_host_ctx(uint32_t n_reads, const uint32_t* read_len, const uint32_t* name_class);
+int64_t herro_debug_job_array(herro_job* job, int which, const void** ptr, uint32_t* elem_bytes);
+
 /* ---- PAF / .oec.zst ingest on the host (needs no device) ---------------------------------------
  * herro_paf_parse replaces `parse_paf` (overlaps.rs:117-202): one overlap per line, tab separated
  *   qname qlen qstart qend strand tname tlen tstart tend ... cg:Z:<CIGAR>   (CIGAR in the LAST column),
