@@ -132,17 +132,27 @@ struct herro_job {
 static int job_sync(herro_job* job);
 
 // Tiles of whole windows for the fused transformer stack: consecutive windows packed greedily into at
-// most 64 tokens.  Returns the first token of each tile (+ end), or nothing if a window is too large
-// (the stack then runs layer by layer).
+// most 64 tokens.  Returns the first token of each tile (+ end).  Callers pass windows of <= FUSED_MAX_TOK
+// informative rows only (larger windows run layer by layer, see split_launch).
+static constexpr uint32_t FUSED_MAX_TOK = 64;
 static std::vector<uint32_t> token_tiles(const std::vector<uint32_t>& tok_off) {
   std::vector<uint32_t> t(1, 0);
   for (size_t w = 0; w + 1 < tok_off.size(); w++) {
-    const uint32_t n = tok_off[w + 1] - tok_off[w];
-    if (n > 64) return {};
-    if (tok_off[w + 1] - t.back() > 64) t.push_back(tok_off[w]);
+    if (tok_off[w + 1] - t.back() > FUSED_MAX_TOK) t.push_back(tok_off[w]);
   }
   if (tok_off.back() > t.back()) t.push_back(tok_off.back());
   return t.size() > 1 ? t : std::vector<uint32_t>();
+}
+
+// One model launch over a set of windows.  Fused stacks (precision 1, 4, 5) take tiles of whole windows of at most
+// 64 informative rows; a window above that does not make the launch group fall off the fused path any more: the
+// group is split into its small windows (tiles) and its large ones (layer-by-layer bf16x3 kernels, precision 3).
+static void run_model(herro_ctx* ctx, const BatchDev& B, bool tiled) {
+  if (B.n_tok == 0) return;
+  const int p = ctx->precision;
+  if (!tiled) { launch_model(ctx->M, B, ctx->S, (p == 1 || p >= 4) ? 3 : p, ctx->stream, &ctx->timer); return; }
+  if (p >= 4) launch_model_h(ctx->M, B, ctx->S, p == 4 ? 2 : 1, ctx->stream, &ctx->timer);
+  else launch_model(ctx->M, B, ctx->S, p, ctx->stream, &ctx->timer);
 }
 
 extern "C" {
@@ -323,6 +333,35 @@ uint16_t h_bf16(float f) {
 }
 float h_bf16f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
 
+// f32 -> IEEE binary16, round to nearest even (subnormals kept, overflow -> inf), and back
+uint16_t h_f16(float f) {
+  uint32_t u; std::memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  const uint32_t a = u & 0x7fffffffu;
+  if (a >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (a > 0x7f800000u ? 0x200u : 0u));  // inf / nan
+  if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                                     // rounds to >= 65520 -> inf
+  if (a < 0x33000001u) return (uint16_t)sign;                                                  // <= 2^-25 -> 0 (ties to even)
+  const int32_t e = (int32_t)(a >> 23) - 127;
+  uint32_t m = (a & 0x7fffffu) | 0x800000u;   // 24-bit significand
+  int shift;                                  // bits dropped from m
+  uint32_t base;
+  if (e >= -14) { shift = 13; base = (uint32_t)(e + 15) << 10; m &= 0x7fffffu; }   // normal: keep 10 fraction bits
+  else { shift = 13 + (-14 - e); base = 0; }                                        // subnormal: value = m * 2^(e-23), unit 2^-24
+  uint32_t q = m >> shift;
+  const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+  if (rem > half || (rem == half && (q & 1u))) q++;
+  return (uint16_t)(sign | (base + q));       // a carry out of the fraction bumps the exponent, as it must
+}
+float h_f16f(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
+  float f;
+  if (e == 0) f = std::ldexp((float)m, -24);
+  else if (e == 31) f = m ? NAN : INFINITY;
+  else f = std::ldexp((float)(m | 0x400u), (int)e - 25);
+  uint32_t u; std::memcpy(&u, &f, 4); u |= sign; std::memcpy(&f, &u, 4);
+  return f;
+}
+
 const float* up_f32(herro_ctx* ctx, const std::vector<float>& v, hipError_t& e) {
   float* p = dev_alloc_copy(v, ctx->stream, e);
   if (p) ctx->model_allocs.push_back(p);
@@ -401,6 +440,28 @@ int herro_load_model(herro_ctx* ctx, const char* path) {
       uint16_t* dpl = dev_alloc_copy(pl, ctx->stream, e); ctx->model_allocs.push_back(dpl);
       w.phi = dph; w.plo = dpl;
     }
+    {  // f16 forms (precision 4 / 5, model_h.hip)
+      std::vector<uint16_t> h16(wt.size()), l16(wt.size());
+      for (size_t i = 0; i < wt.size(); i++) { h16[i] = h_f16(wt[i]); l16[i] = h_f16(wt[i] - h_f16f(h16[i])); }
+      uint16_t* d1 = dev_alloc_copy(h16, ctx->stream, e); ctx->model_allocs.push_back(d1);
+      uint16_t* d2 = dev_alloc_copy(l16, ctx->stream, e); ctx->model_allocs.push_back(d2);
+      w.h16 = d1; w.l16 = d2;
+      if (N % 32 == 0 && K % 32 == 0) {
+        std::vector<uint16_t> ph(wt.size());
+        const uint32_t nks = K / 32;
+        for (uint32_t n32 = 0; n32 < N / 32; n32++)
+          for (uint32_t jt = 0; jt < 2; jt++)
+            for (uint32_t ks = 0; ks < nks; ks++)
+              for (uint32_t lane = 0; lane < 64; lane++) {
+                const uint32_t fr = lane & 15, fg = lane >> 4;
+                const size_t src = (size_t)(n32 * 32 + 8 * (fr >> 2) + 4 * jt + (fr & 3)) * K + ks * 32 + fg * 8;
+                const size_t dst = ((((size_t)n32 * 2 + jt) * nks + ks) * 64 + lane) * 8;
+                for (uint32_t e8 = 0; e8 < 8; e8++) ph[dst + e8] = h16[src + e8];
+              }
+        uint16_t* d3 = dev_alloc_copy(ph, ctx->stream, e); ctx->model_allocs.push_back(d3);
+        w.ph16 = d3;
+      }
+    }
     w.bias = vec(n + ".b", N);
     return w;
   };
@@ -431,7 +492,11 @@ int herro_load_model(herro_ctx* ctx, const char* path) {
 }
 
 int herro_set_precision(herro_ctx* ctx, int mode) {
-  if (!ctx || mode < 0 || mode > 3) return HERRO_E_INVALID;
+  if (!ctx || mode < 0 || mode > 5) return HERRO_E_INVALID;
+  if (mode >= 4 && ctx->has_model && !model_h_supported(ctx->M)) {
+    ctx->err = "precision 4 / 5 (f16 kernels) need kw 3, conv 64/128, d_model 256, 8 heads, d_ff % 256 == 0";
+    return HERRO_E_UNSUPPORTED;
+  }
   ctx->precision = mode;
   return HERRO_OK;
 }
@@ -918,37 +983,44 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
     std::memcpy(blob.data() + o, p, bytes);
     return o;
   };
-  struct Offs { size_t plane_off, plane_ld, len, lmax, tok_off, sup_off, out_off, tiles; uint32_t n_tiles; };
+  struct Offs { size_t plane_off, plane_ld, len, lmax, tok_off, sup_off, out_off, tiles; uint32_t n_tiles, n_win, n_tok; bool tiled; };
   std::vector<Offs> offs;
   uint32_t max_tok = 0;
+  const bool fused_mode = ctx->precision == 1 || ctx->precision >= 4;
   for (auto& g : groups) {
-    const size_t B = g.n_win;
-    std::vector<uint64_t> plane_off, sup_o, out_o;
-    std::vector<uint32_t> ld, len, lmax, tok_off(1, 0);
-    for (size_t bi = g.b0; bi < g.b1; bi++) {
-      const BatchPlan& bp = job->batches[bi];
-      for (uint32_t w : bp.wins) {
-        const WinDesc& wd = job->win[w];
-        plane_off.push_back(wd.fin_off); ld.push_back(wd.lub); len.push_back(job->h_Lf[w]);
-        lmax.push_back(bp.lmax);
-        tok_off.push_back(tok_off.back() + job->h_nsup[w]);
-        sup_o.push_back(wd.row_off); out_o.push_back(job->sup_off[w]);
+    for (int part = 0; part < 2; part++) {  // 0: windows that fit a fused tile (all of them in the unfused modes), 1: the rest
+      std::vector<uint64_t> plane_off, sup_o, out_o;
+      std::vector<uint32_t> ld, len, lmax, tok_off(1, 0);
+      for (size_t bi = g.b0; bi < g.b1; bi++) {
+        const BatchPlan& bp = job->batches[bi];
+        for (uint32_t w : bp.wins) {
+          const bool large = fused_mode && job->h_nsup[w] > FUSED_MAX_TOK;
+          if ((int)large != part) continue;
+          const WinDesc& wd = job->win[w];
+          plane_off.push_back(wd.fin_off); ld.push_back(wd.lub); len.push_back(job->h_Lf[w]);
+          lmax.push_back(bp.lmax);   // the padding length is that of the window's BATCH, whichever launch it runs in
+          tok_off.push_back(tok_off.back() + job->h_nsup[w]);
+          sup_o.push_back(wd.row_off); out_o.push_back(job->sup_off[w]);
+        }
       }
+      const size_t B = plane_off.size();
+      if (B == 0) continue;
+      Offs o;
+      o.n_win = (uint32_t)B; o.n_tok = tok_off.back(); o.tiled = fused_mode && part == 0;
+      o.plane_off = put(plane_off.data(), B * 8); o.plane_ld = put(ld.data(), B * 4);
+      o.len = put(len.data(), B * 4); o.lmax = put(lmax.data(), B * 4);
+      o.tok_off = put(tok_off.data(), (B + 1) * 4);
+      o.sup_off = put(sup_o.data(), B * 8); o.out_off = put(out_o.data(), B * 8);
+      const std::vector<uint32_t> tiles = o.tiled ? token_tiles(tok_off) : std::vector<uint32_t>();
+      o.n_tiles = tiles.empty() ? 0u : (uint32_t)tiles.size() - 1;
+      o.tiles = put(tiles.data(), tiles.size() * 4);
+      offs.push_back(o);
+      max_tok = std::max(max_tok, o.n_tok);
     }
-    Offs o;
-    o.plane_off = put(plane_off.data(), B * 8); o.plane_ld = put(ld.data(), B * 4);
-    o.len = put(len.data(), B * 4); o.lmax = put(lmax.data(), B * 4);
-    o.tok_off = put(tok_off.data(), (B + 1) * 4);
-    o.sup_off = put(sup_o.data(), B * 8); o.out_off = put(out_o.data(), B * 8);
-    const std::vector<uint32_t> tiles = token_tiles(tok_off);
-    o.n_tiles = tiles.empty() ? 0u : (uint32_t)tiles.size() - 1;
-    o.tiles = put(tiles.data(), tiles.size() * 4);
-    offs.push_back(o);
-    max_tok = std::max(max_tok, g.n_tok);
   }
   const size_t supoff_at = put(job->sup_off.data(), ((size_t)n + 1) * 8);  // consensus reads it from the same blob
   if (job->bdesc_cap < blob.size()) {
-    if (job->d_bdesc) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); hipFree(job->d_bdesc); job->d_bdesc = nullptr; }
+    if (job->d_bdesc) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(job->d_bdesc)); job->d_bdesc = nullptr; }
     job->bdesc_cap = blob.size() + blob.size() / 4 + 4096;
     HIP_TRY(ctx, hipMalloc(&job->d_bdesc, job->bdesc_cap));
   }
@@ -959,22 +1031,22 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   if (rc) return rc;
   // the qualities the model will read: rows within 2 * (kw / 2) of an informative row (two stacked convs)
   if (!job->quals_full && !groups.empty()) launch_rf_quals(job->J, 2 * (ctx->M.h.kw / 2), ctx->stream, &ctx->timer);
-  for (size_t gi = 0; gi < groups.size(); gi++) {
+  for (const Offs& o : offs) {
     const unsigned char* base = (const unsigned char*)job->d_bdesc;
     BatchDev B{};
-    B.n_win = groups[gi].n_win; B.n_tok = groups[gi].n_tok;
-    B.plane_off = (const uint64_t*)(base + offs[gi].plane_off);
-    B.plane_ld = (const uint32_t*)(base + offs[gi].plane_ld);
-    B.len = (const uint32_t*)(base + offs[gi].len);
-    B.lmax = (const uint32_t*)(base + offs[gi].lmax);
-    B.tok_off = (const uint32_t*)(base + offs[gi].tok_off);
-    B.sup_off = (const uint64_t*)(base + offs[gi].sup_off);
-    B.out_off = (const uint64_t*)(base + offs[gi].out_off);
-    B.n_tiles = offs[gi].n_tiles;
-    B.tile_tok0 = (const uint32_t*)(base + offs[gi].tiles);
+    B.n_win = o.n_win; B.n_tok = o.n_tok;
+    B.plane_off = (const uint64_t*)(base + o.plane_off);
+    B.plane_ld = (const uint32_t*)(base + o.plane_ld);
+    B.len = (const uint32_t*)(base + o.len);
+    B.lmax = (const uint32_t*)(base + o.lmax);
+    B.tok_off = (const uint32_t*)(base + o.tok_off);
+    B.sup_off = (const uint64_t*)(base + o.sup_off);
+    B.out_off = (const uint64_t*)(base + o.out_off);
+    B.n_tiles = o.n_tiles;
+    B.tile_tok0 = (const uint32_t*)(base + o.tiles);
     B.planes_b = job->J.fin_b; B.planes_q = job->J.fin_q; B.sup_row = job->J.sup_row;
     B.out_info = job->d_info; B.out_base = job->d_base;
-    launch_model(ctx->M, B, ctx->S, ctx->precision, ctx->stream, &ctx->timer);
+    run_model(ctx, B, o.tiled);
   }
   HIP_TRY(ctx, hipGetLastError());
   job->inferred = true;
@@ -1228,7 +1300,7 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
   if (!ctx->has_model) { ctx->err = "no model loaded"; return HERRO_E_NO_MODEL; }
   hipSetDevice(ctx->device);
   uint64_t N = 0;
-  std::vector<uint32_t> tok_off(B + 1, 0), len(B, L), lmaxv(B, L), ld(B, (L + 15) & ~15u), srow;
+  std::vector<uint32_t> tok_off(B + 1, 0), srow;
   for (uint32_t b = 0; b < B; b++) {
     if (lens[b] < 0) return HERRO_E_INVALID;
     tok_off[b + 1] = tok_off[b] + (uint32_t)lens[b];
@@ -1242,51 +1314,65 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
   }
   if (N == 0) return HERRO_OK;
   const uint64_t cells = (uint64_t)B * L * HERRO_ROWS;
-  std::vector<uint64_t> plane_off(B), sup_off(B), out_off(B);
-  for (uint32_t b = 0; b < B; b++) { plane_off[b] = (uint64_t)b * HERRO_ROWS * L; sup_off[b] = tok_off[b]; out_off[b] = tok_off[b]; ld[b] = L; }
   std::vector<void*> tmp;
   auto A = [&](uint64_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, std::max<uint64_t>(bytes, 16)) == hipSuccess) tmp.push_back(p); return p; };
-  uint8_t* d_src_b = (uint8_t*)A(cells); uint8_t* d_src_q = (uint8_t*)A(cells);
-  uint8_t* d_pb = (uint8_t*)A(cells); uint8_t* d_pq = (uint8_t*)A(cells);
-  uint64_t* d_po = (uint64_t*)A(B * 8ull); uint32_t* d_ld = (uint32_t*)A(B * 4ull); uint32_t* d_len = (uint32_t*)A(B * 4ull); uint32_t* d_lmax = (uint32_t*)A(B * 4ull);
-  uint32_t* d_to = (uint32_t*)A((B + 1) * 4ull); uint64_t* d_so = (uint64_t*)A(B * 8ull); uint64_t* d_oo = (uint64_t*)A(B * 8ull);
-  uint32_t* d_sr = (uint32_t*)A(N * 4); float* d_info = (float*)A(N * 4); float* d_base = (float*)A(N * 20);
-  const std::vector<uint32_t> tiles = token_tiles(tok_off);
-  uint32_t* d_tiles = (uint32_t*)A(std::max<size_t>(tiles.size(), 1) * 4);
-  int rc = HERRO_OK;
-  auto done = [&](int code) { for (void* p : tmp) hipFree(p); return code; };
-  if (!d_src_b || !d_src_q || !d_pb || !d_pq || !d_po || !d_ld || !d_len || !d_lmax || !d_to || !d_so || !d_oo || !d_sr || !d_info || !d_base || !d_tiles) {
-    ctx->err = "out of device memory";
-    return done(HERRO_E_NO_DEVICE);
-  }
+  auto done = [&](int code) { for (void* p : tmp) (void)hipFree(p); return code; };
   hipStream_t st = ctx->stream;
-  hipMemcpyAsync(d_src_b, bases, cells, hipMemcpyHostToDevice, st);
-  hipMemcpyAsync(d_src_q, quals, cells, hipMemcpyHostToDevice, st);
-  hipMemcpyAsync(d_po, plane_off.data(), B * 8ull, hipMemcpyHostToDevice, st);
-  hipMemcpyAsync(d_ld, ld.data(), B * 4ull, hipMemcpyHostToDevice, st);
-  hipMemcpyAsync(d_len, len.data(), B * 4ull, hipMemcpyHostToDevice, st);
-  hipMemcpyAsync(d_lmax, lmaxv.data(), B * 4ull, hipMemcpyHostToDevice, st);
-  hipMemcpyAsync(d_to, tok_off.data(), (B + 1) * 4ull, hipMemcpyHostToDevice, st);
-  hipMemcpyAsync(d_so, sup_off.data(), B * 8ull, hipMemcpyHostToDevice, st);
-  hipMemcpyAsync(d_oo, out_off.data(), B * 8ull, hipMemcpyHostToDevice, st);
-  hipMemcpyAsync(d_sr, srow.data(), N * 4, hipMemcpyHostToDevice, st);
-  if (!tiles.empty()) hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, st);
+  hipError_t e = hipSuccess;
+  auto up = [&](const void* src, uint64_t bytes) -> void* {
+    void* p = A(bytes);
+    if (p && bytes && e == hipSuccess) e = hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, st);
+    return p;
+  };
+  uint8_t* d_src_b = (uint8_t*)up(bases, cells); uint8_t* d_src_q = (uint8_t*)up(quals, cells);
+  uint8_t* d_pb = (uint8_t*)A(cells); uint8_t* d_pq = (uint8_t*)A(cells);
+  uint32_t* d_sr = (uint32_t*)up(srow.data(), N * 4);
+  float* d_info = (float*)A(N * 4); float* d_base = (float*)A(N * 20);
+  if (!d_src_b || !d_src_q || !d_pb || !d_pq || !d_sr || !d_info || !d_base) { ctx->err = "out of device memory"; return done(HERRO_E_NO_DEVICE); }
   launch_transpose_blr(d_src_b, d_pb, B, L, st);
   launch_transpose_blr(d_src_q, d_pq, B, L, st);
+  int rc = HERRO_OK;
   if ((rc = ensure_scratch(ctx, (uint32_t)N))) return done(rc);
-  BatchDev bd{};
-  bd.n_win = B; bd.n_tok = (uint32_t)N;
-  bd.plane_off = d_po; bd.plane_ld = d_ld; bd.len = d_len; bd.lmax = d_lmax; bd.tok_off = d_to; bd.sup_off = d_so; bd.out_off = d_oo;
-  bd.planes_b = d_pb; bd.planes_q = d_pq; bd.sup_row = d_sr; bd.out_info = d_info; bd.out_base = d_base;
-  bd.n_tiles = tiles.empty() ? 0u : (uint32_t)tiles.size() - 1;
-  bd.tile_tok0 = d_tiles;
-  launch_model(ctx->M, bd, ctx->S, ctx->precision, st, &ctx->timer);
-  hipError_t e = hipStreamSynchronize(st);
+  // the host arrays of both parts must outlive their asynchronous uploads
+  struct Part { std::vector<uint64_t> plane_off, sup_off, out_off; std::vector<uint32_t> ld, len, lmax, tok_off, tiles; };
+  Part parts[2];
+  const bool fused_mode = ctx->precision == 1 || ctx->precision >= 4;
+  for (int part = 0; part < 2; part++) {  // 0: windows that fit a fused tile (all windows in the unfused modes), 1: larger ones
+    Part& P = parts[part];
+    P.tok_off.assign(1, 0);
+    for (uint32_t b = 0; b < B; b++) {
+      const bool large = fused_mode && (uint32_t)lens[b] > FUSED_MAX_TOK;
+      if ((int)large != part) continue;
+      P.plane_off.push_back((uint64_t)b * HERRO_ROWS * L); P.ld.push_back(L); P.len.push_back(L); P.lmax.push_back(L);
+      P.sup_off.push_back(tok_off[b]); P.out_off.push_back(tok_off[b]);
+      P.tok_off.push_back(P.tok_off.back() + (uint32_t)lens[b]);
+    }
+    const size_t nb = P.plane_off.size();
+    if (nb == 0 || P.tok_off.back() == 0) continue;
+    const bool tiled = fused_mode && part == 0;
+    if (tiled) P.tiles = token_tiles(P.tok_off);
+    BatchDev bd{};
+    bd.n_win = (uint32_t)nb; bd.n_tok = P.tok_off.back();
+    bd.plane_off = (const uint64_t*)up(P.plane_off.data(), nb * 8); bd.plane_ld = (const uint32_t*)up(P.ld.data(), nb * 4);
+    bd.len = (const uint32_t*)up(P.len.data(), nb * 4); bd.lmax = (const uint32_t*)up(P.lmax.data(), nb * 4);
+    bd.tok_off = (const uint32_t*)up(P.tok_off.data(), (nb + 1) * 4);
+    bd.sup_off = (const uint64_t*)up(P.sup_off.data(), nb * 8); bd.out_off = (const uint64_t*)up(P.out_off.data(), nb * 8);
+    bd.tile_tok0 = (const uint32_t*)up(P.tiles.data(), P.tiles.size() * 4);
+    bd.n_tiles = P.tiles.empty() ? 0u : (uint32_t)P.tiles.size() - 1;
+    bd.planes_b = d_pb; bd.planes_q = d_pq; bd.sup_row = d_sr; bd.out_info = d_info; bd.out_base = d_base;
+    if (!bd.plane_off || !bd.plane_ld || !bd.len || !bd.lmax || !bd.tok_off || !bd.sup_off || !bd.out_off || !bd.tile_tok0 || e != hipSuccess) {
+      ctx->err = e != hipSuccess ? hipGetErrorString(e) : "out of device memory";
+      (void)hipStreamSynchronize(st);
+      return done(HERRO_E_NO_DEVICE);
+    }
+    run_model(ctx, bd, tiled);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return done(HERRO_E_NO_DEVICE); }
   ctx->timer.collect();
-  hipMemcpy(info_logits, d_info, N * 4, hipMemcpyDeviceToHost);
-  hipMemcpy(bases_logits, d_base, N * 20, hipMemcpyDeviceToHost);
+  HIP_TRY(ctx, hipMemcpy(info_logits, d_info, N * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(bases_logits, d_base, N * 20, hipMemcpyDeviceToHost));
   return done(HERRO_OK);
 }
 

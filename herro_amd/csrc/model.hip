@@ -16,7 +16,10 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <mutex>
+#include <set>
 #include <type_traits>
+#include <utility>
 
 #include "model_dev.h"
 
@@ -1162,6 +1165,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_w(ModelDev M, BatchDev B, Model
   }
 }
 
+// The opt-in for more than 64 KB of dynamic LDS is a per-DEVICE function attribute: a process that drives one context per
+// GPU must set it on every device it launches on, so the "done" set is keyed by (function, device).
+static void opt_in_dynamic_lds(const void* fn, size_t bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.insert({fn, dev}).second) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 template <bool SPLIT, int TM>
 static void gemm_launch(uint32_t gx, uint32_t gy, const uint16_t* Ahi, const uint16_t* Alo, uint32_t lda, const Weight& W,
                         float* C, uint16_t* Chi, uint16_t* Clo, uint32_t ldc, const float* R, uint32_t M, int relu,
@@ -1177,12 +1191,8 @@ static void gemm_s(const uint16_t* Ahi, const uint16_t* Alo, uint32_t lda, const
   // (HERRO_G256_MIN_M overrides the threshold: the tests use it to cover the kernel with small inputs)
   static const uint32_t g256_min_m = getenv("HERRO_G256_MIN_M") ? (uint32_t)atoi(getenv("HERRO_G256_MIN_M")) : 128u * 256u;
   if (W.N == 256 && !Chi && W.K >= 1024 && W.K % 32 == 0 && M >= g256_min_m) {
-    static bool attr_set = false;
     constexpr size_t shm = (size_t)3 * (2 * 128 + 2 * 256) * 32 * 2;
-    if (!attr_set) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_g256<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-      attr_set = true;
-    }
+    opt_in_dynamic_lds(reinterpret_cast<const void*>(k_gemm_g256<false>), shm);
     hipLaunchKernelGGL(k_gemm_g256<false>, dim3((M + 127) / 128), dim3(512), shm, st, Ahi, Alo, lda, W, C, Chi, Clo, ldc, R, M, relu);
     return;
   }
@@ -1719,11 +1729,7 @@ static void launch_model_s(const ModelDev& M, const BatchDev& B, const ModelScra
   }
   KT_END(tm, st);
   if (fused && B.n_tiles && D == 256 && h.n_heads == 8 && h.d_ff % 256 == 0) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k_layers), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LAYERS_SHM);
-      attr_set = true;
-    }
+    opt_in_dynamic_lds(reinterpret_cast<const void*>(k_layers), LAYERS_SHM);
     KT_BEGIN(tm, "layers_fused", st);
     hipLaunchKernelGGL(k_layers, dim3(B.n_tiles), dim3(512), LAYERS_SHM, st, M, B, S);
     KT_END(tm, st);

@@ -35,6 +35,11 @@ struct Weight {
   // lane = 16 fg + fr — a wave's fragment load is one contiguous KiB instead of 16 scattered 64-byte pieces
   const uint16_t* phi = nullptr;
   const uint16_t* plo = nullptr;
+  // f16 forms for precision modes 4 / 5 (model_h.hip): h16 = round-to-nearest f16 of the f32 weight, l16 = f16 of the
+  // remainder (only the heads use it), ph16 = h16 in the fragment order of phi
+  const uint16_t* h16 = nullptr;
+  const uint16_t* l16 = nullptr;
+  const uint16_t* ph16 = nullptr;
   const float* bias = nullptr;  // [N] or null
   uint32_t K = 0, N = 0;
 };
@@ -111,6 +116,9 @@ struct ModelScratch {  // sized for n_tok tokens
 
 void launch_model(const ModelDev& M, const BatchDev& B, const ModelScratch& S, int precision,
                   hipStream_t st, KernelTimer* tm);
+// f16-operand kernels (model_h.hip): terms = 2 -> precision 4, terms = 1 -> precision 5.  B must be tiled (n_tiles > 0).
+bool model_h_supported(const ModelDev& M);
+void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S, int terms, hipStream_t st, KernelTimer* tm);
 // [B,L,31] -> [B][31][L] planes (stand-alone entry only)
 void launch_transpose_blr(const uint8_t* src, uint8_t* dst, uint32_t B, uint32_t L, hipStream_t st);
 

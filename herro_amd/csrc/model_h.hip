@@ -1,0 +1,762 @@
+// model_h.hip — the correction-model forward with f16 MFMA operands (precision modes 4 and 5).
+//
+// Why a second operand format.  The logits contract is |error| <= 1e-3 (BASELINE.json north_star).  Plain bf16
+// operands miss it (6e-3); the bf16 hi/lo split of model.hip meets it with 3 MFMAs per product (1e-5).  f16 keeps
+// 11 mantissa bits per operand, and the error budget is not spent evenly over the model (tools/precision_study.py,
+// CPU emulation of this dataflow, max |logit error| on 481 tokens, every other GEMM in bf16x3):
+//     conv2 7.8e-5, FC 1.0e-4, Q.K^T 4.0e-5, P.V 1.8e-4  with single f16 operands (1 MFMA per product)
+//     QKV 2.0e-4, proj 2.2e-4, FF1 1.8e-4, FF2 1.8e-4    with the activation split in two f16 terms (2 MFMAs)
+//     heads 5.7e-4 single -> kept at three terms (a 256 x 16 GEMM: nothing to gain)
+// so precision 4 runs conv2 / FC / attention on single f16 operands (v_mfma_f32_16x16x32_f16), the four big GEMMs of
+// every encoder layer on `activation hi + lo` x `weight` (2 MFMAs; the weight planes streamed from L2 halve as well),
+// and the heads on three terms.  Precision 5 drops the activation lo term too (1 MFMA everywhere but the heads);
+// it is measured and reported, not the default.  Accumulation is f32 in every mode.
+//
+// Kernels (same dataflow as model.hip, re-derived for one 2-byte plane per operand):
+//   k_conv_h   embedding + quality + conv1 on the fly -> conv2 (K = 192) -> y2 as ONE f16 plane [N*31][128]
+//   k_fc_h     y2[N][3968] . Wfc -> x[N][256]; 128 x 256 tiles, LDS-DMA, three 24 KB buffers, 2 workgroups per CU
+//   k_layers_h the whole encoder stack per tile of <= 64 tokens: residual stream in registers from the FC output to
+//              the logits (positional encoding added on the way in), no parking of x in HBM, full-K weight
+//              fragments in flight per GEMM call
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <mutex>
+#include <set>
+#include <type_traits>
+#include <utility>
+
+#include "model_dev.h"
+
+namespace herro {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float norm_qual_h(uint32_t q) {  // inference.rs:16-21,153 — f32, two roundings
+  const float QS = (float)(2.0 / 93.0);
+  const float QO = (float)(2.0 * 33.0 / 93.0 + 1.0);
+  return __fsub_rn(__fmul_rn(QS, (float)q), QO);
+}
+
+// (a, b) -> packed f16 pair, round to nearest even (v_cvt_pk_f16_f32)
+__device__ __forceinline__ uint32_t pack_h2(float a, float b) {
+  const float2v v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, half2v));
+}
+// (a, b) -> hi, lo packed f16 pairs with a ~= hi.x + lo.x (22 mantissa bits)
+__device__ __forceinline__ void split_h2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const float2v v = {a, b};
+  const half2v h = __builtin_convertvector(v, half2v);
+  hi = __builtin_bit_cast(uint32_t, h);
+  const float2v hf = __builtin_convertvector(h, float2v);
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - hf, half2v));
+}
+__device__ __forceinline__ half8 as_half8(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  return __builtin_bit_cast(half8, make_uint4(a, b, c, d));
+}
+__device__ __forceinline__ half8 pack_h8(const float (&v)[8]) {
+  return as_half8(pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7]));
+}
+__device__ __forceinline__ void split_h8(const float (&v)[8], half8& hi, half8& lo) {
+  uint4 h, l;
+  split_h2(v[0], v[1], h.x, l.x);
+  split_h2(v[2], v[3], h.y, l.y);
+  split_h2(v[4], v[5], h.z, l.z);
+  split_h2(v[6], v[7], h.w, l.w);
+  hi = __builtin_bit_cast(half8, h);
+  lo = __builtin_bit_cast(half8, l);
+}
+__device__ __forceinline__ f32x4 mma(half8 a, half8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ void glds16_h(const void* gsrc, uint32_t lds_dst) {  // 16 B per lane, global -> LDS, no VGPR staging
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_h() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+// dynamic-LDS opt-in is a per-device function attribute: one context per GPU in one process must set it on each
+void opt_in_lds(const void* fn, size_t bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.insert({fn, dev}).second) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv1 (on the fly) -> conv2, single f16 operands.  Same organisation as k_conv_w (model.hip): persistent
+// workgroups walk tiles of 128 (token, read row) pairs, conv2 weights resident in VGPRs (wave = 32 output
+// channels, 48 registers), MFMA roles swapped so y2 leaves as 16-byte stores straight from the accumulators,
+// activation tile double-buffered (one barrier per k-step), next tile's cells prefetched into registers.
+// ---------------------------------------------------------------------------------------------------
+constexpr int HC2 = 128;
+constexpr int HLD = 32;  // 64-byte LDS rows, 16-byte chunks XOR-swizzled by (row >> 1) & 3
+__device__ __forceinline__ uint32_t hswz(uint32_t row, uint32_t chunk) { return chunk ^ ((row >> 1) & 3u); }
+constexpr int HTP = 128;
+constexpr int HT1R = 13;
+constexpr size_t CONV_H_SHM = (size_t)2 * HTP * HLD * 2 + (size_t)(3 * HT1R * 64 + 3 * 64 + 64) * 4 + (size_t)HTP * 8 * 4 + (size_t)HTP * 8 +
+                              (size_t)HTP * 4;
+
+__global__ __launch_bounds__(256, 2) void k_conv_h(ModelDev M, BatchDev B, ModelScratch S, uint32_t n_rows, uint32_t n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t* s_x = reinterpret_cast<uint16_t*>(smem);               // [2 buffers][128][32] f16
+  float* s_t1 = reinterpret_cast<float*>(s_x + 2 * HTP * HLD);      // [3][13][64]
+  float* s_wq = s_t1 + 3 * HT1R * 64;                               // [3][64]
+  float* s_b1 = s_wq + 3 * 64;                                      // [64]
+  float* s_qn = s_b1 + 64;                                          // [128][8]
+  uint8_t* s_tok = reinterpret_cast<uint8_t*>(s_qn + HTP * 8);      // [128][8]
+  uint8_t* s_val = s_tok + HTP * 8;                                 // [128][4]
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t fr = lane & 15, fg = lane >> 4;
+
+  for (uint32_t e = tid; e < 3 * HT1R * 64; e += 256) {
+    const uint32_t t = e / (HT1R * 64), rem = e % (HT1R * 64), tok = rem / 64, c = rem % 64;
+    s_t1[e] = tok < 12 ? M.t1[(t * 12 + tok) * 64 + c] : 0.f;
+  }
+  for (uint32_t e = tid; e < 3 * 64; e += 256) s_wq[e] = M.wq1[e];
+  for (uint32_t e = tid; e < 64; e += 256) s_b1[e] = M.b1[e];
+  const Weight& W = M.conv2;
+  const uint32_t c0 = wave * 32;
+  half8 wh[6][2];
+#pragma unroll
+  for (int jt = 0; jt < 2; jt++) {
+    const uint32_t ch = c0 + 8 * (fr >> 2) + 4 * jt + (fr & 3);  // lane group g ends up with channels c0 + 8g .. + 7
+#pragma unroll
+    for (int ks = 0; ks < 6; ks++) wh[ks][jt] = *reinterpret_cast<const half8*>(W.h16 + (uint64_t)ch * 192 + ks * 32 + fg * 8);
+  }
+  float bias8[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) bias8[q] = W.bias[c0 + 8 * fg + q];
+
+  const uint32_t grr = tid & 127u;
+  const bool gq = tid >= 128;
+  const uint8_t* gplane = gq ? B.planes_q : B.planes_b;
+  struct PairMeta { uint64_t rowbase; uint32_t tok_row, len, lmax; };
+  auto load_meta = [&](uint32_t tile) -> PairMeta {
+    const uint32_t m = tile * HTP + grr;
+    PairMeta r{0, 0, 0, 0};
+    if (tile < n_tiles && m < n_rows) {
+      const TokMeta tm = S.tok_meta[m / HERRO_ROWS];
+      r.rowbase = tm.plane_off + (uint64_t)(m % HERRO_ROWS) * tm.plane_ld;
+      r.tok_row = tm.tok_row;
+      r.len = tm.len;
+      r.lmax = tm.lmax;
+    }
+    return r;
+  };
+  auto load_cells = [&](const PairMeta& mt, uint32_t (&g)[5]) {
+#pragma unroll
+    for (int pi = 0; pi < 5; pi++) {
+      const int32_t q = (int32_t)mt.tok_row - 2 + pi;
+      uint32_t v = gq ? 0xffffffffu : 12u;
+      if (q >= 0 && q < (int32_t)mt.lmax) v = q < (int32_t)mt.len ? (uint32_t)gplane[mt.rowbase + (uint32_t)q] : (gq ? 126u : (uint32_t)TOK_PAD);
+      g[pi] = v;
+    }
+  };
+  uint32_t g[5];
+  PairMeta mcur = load_meta(blockIdx.x);
+  load_cells(mcur, g);
+  PairMeta mnext = load_meta(blockIdx.x + gridDim.x);
+
+  f32x4 acc[8][2];
+  const uint32_t arow = tid >> 3, kk = (tid & 7) * 4;
+  uint16_t* y2 = S.y2_hi;  // one f16 plane in this mode
+  __syncthreads();
+
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint32_t m0 = tile * HTP;
+    if (!gq) {
+      *reinterpret_cast<uint2*>(s_tok + grr * 8) = make_uint2(g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24), g[4]);
+      uint32_t vb = 0;
+#pragma unroll
+      for (int dl = 0; dl < 3; dl++) {
+        const int32_t pos = (int32_t)mcur.tok_row + dl - 1;
+        if (pos >= 0 && pos < (int32_t)mcur.lmax) vb |= 1u << (8 * dl);
+      }
+      *reinterpret_cast<uint32_t*>(s_val + grr * 4) = vb;
+    } else {
+      float qn[5];
+#pragma unroll
+      for (int pi = 0; pi < 5; pi++) qn[pi] = g[pi] != 0xffffffffu ? norm_qual_h(g[pi]) : 0.f;
+      *reinterpret_cast<float4*>(s_qn + grr * 8) = make_float4(qn[0], qn[1], qn[2], qn[3]);
+      s_qn[grr * 8 + 4] = qn[4];
+    }
+    __syncthreads();
+    mcur = mnext;
+    load_cells(mcur, g);
+    mnext = load_meta(tile + 2 * gridDim.x);
+
+#pragma unroll
+    for (int pt = 0; pt < 8; pt++)
+#pragma unroll
+      for (int jt = 0; jt < 2; jt++) acc[pt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto gen = [&](auto ksc) {
+      constexpr int ks = decltype(ksc)::value;
+      constexpr int dl = ks >> 1, cb = (ks & 1) * 32;
+      uint16_t* xh = s_x + (ks & 1) * (HTP * HLD);
+      const uint32_t c = cb + kk;
+      const float4 b1v = *reinterpret_cast<const float4*>(s_b1 + c);
+      float4 wq[3];
+#pragma unroll
+      for (int t = 0; t < 3; t++) wq[t] = *reinterpret_cast<const float4*>(s_wq + t * 64 + c);
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        const uint32_t rr = arow + it * 32;
+        const uint2 tk = *reinterpret_cast<const uint2*>(s_tok + rr * 8);
+        const uint64_t tk64 = (uint64_t)tk.x | ((uint64_t)tk.y << 32);
+        float4 v = b1v;
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          const uint32_t tok = (uint32_t)(tk64 >> (8 * (dl + t))) & 0xffu;
+          const float4 tv = *reinterpret_cast<const float4*>(s_t1 + (t * HT1R + tok) * 64 + c);
+          const float qn = s_qn[rr * 8 + dl + t];
+          v.x += tv.x + wq[t].x * qn; v.y += tv.y + wq[t].y * qn; v.z += tv.z + wq[t].z * qn; v.w += tv.w + wq[t].w * qn;
+        }
+        const bool ok = s_val[rr * 4 + dl] != 0;
+        v.x = ok ? fmaxf(v.x, 0.f) : 0.f; v.y = ok ? fmaxf(v.y, 0.f) : 0.f;
+        v.z = ok ? fmaxf(v.z, 0.f) : 0.f; v.w = ok ? fmaxf(v.w, 0.f) : 0.f;
+        const uint32_t o = rr * HLD + hswz(rr, kk >> 3) * 8 + (kk & 7);
+        *reinterpret_cast<uint2*>(xh + o) = make_uint2(pack_h2(v.x, v.y), pack_h2(v.z, v.w));
+      }
+    };
+    auto mm = [&](auto ksc) {
+      constexpr int ks = decltype(ksc)::value;
+      const uint16_t* xh = s_x + (ks & 1) * (HTP * HLD);
+#pragma unroll
+      for (int pt = 0; pt < 8; pt++) {
+        const uint32_t pr = pt * 16 + fr;
+        const half8 bh = *reinterpret_cast<const half8*>(xh + pr * HLD + hswz(pr, fg) * 8);
+#pragma unroll
+        for (int jt = 0; jt < 2; jt++) acc[pt][jt] = mma(wh[ks][jt], bh, acc[pt][jt]);
+      }
+    };
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+    using K4 = std::integral_constant<int, 4>; using K5 = std::integral_constant<int, 5>;
+    gen(K0{});
+    __syncthreads();
+    gen(K1{}); mm(K0{}); __syncthreads();
+    gen(K2{}); mm(K1{}); __syncthreads();
+    gen(K3{}); mm(K2{}); __syncthreads();
+    gen(K4{}); mm(K3{}); __syncthreads();
+    gen(K5{}); mm(K4{}); __syncthreads();
+    mm(K5{});
+#pragma unroll
+    for (int pt = 0; pt < 8; pt++) {
+      const uint32_t m = m0 + pt * 16 + fr;
+      float v[8];
+#pragma unroll
+      for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[jt * 4 + r] = fmaxf(acc[pt][jt][r] + bias8[jt * 4 + r], 0.f);
+      if (m < n_rows)
+        *reinterpret_cast<uint4*>(y2 + (uint64_t)m * HC2 + c0 + 8 * fg) =
+            make_uint4(pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7]));
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// FC: x[M][256] = y2[M][K] . W^T + bias, y2 and W single f16 planes.  One workgroup = 128 rows x all 256
+// columns (the 8 KB-per-token A operand passes through L2 once), 8 waves as 2 x 4 with 64 x 64 wave tiles.
+// A and B tiles go global -> LDS by LDS-DMA (3 pieces of 1 KiB per wave and k-step), three 24 KB buffers, counted
+// vmcnt, one barrier per k-step; 72 KB of LDS and <= 128 VGPRs leave room for two workgroups per CU.
+// ---------------------------------------------------------------------------------------------------
+constexpr int FC_TM = 128, FC_TN = 256, FC_NBUF = 3, FC_NP = 3;
+constexpr int FC_BS = (FC_TM + FC_TN) * 32;  // u16 elements per buffer
+constexpr size_t FC_H_SHM = (size_t)FC_NBUF * FC_BS * 2;
+
+__global__ __launch_bounds__(512, 4) void k_fc_h(const uint16_t* __restrict__ A, uint32_t lda, Weight W, float* C, uint32_t ldc, uint32_t M) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_fc[];
+  uint16_t* s_raw = reinterpret_cast<uint16_t*>(smem_fc);
+  const uint32_t K = W.K;
+  const uint32_t m0 = blockIdx.x * FC_TM;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t fr = lane & 15, fc = lane >> 4;
+  const uint32_t wr = wave >> 2, wc = wave & 3;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bs[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) bs[j] = W.bias ? W.bias[wc * 64 + j * 16 + fr] : 0.f;
+
+  // staging plan: lane l of a piece fills row (l >> 2), 16-byte slot (l & 3); the bank swizzle of the fragment reads is
+  // applied on the SOURCE address (the DMA destination is lane-linear).  Wave w: A rows 16w.., B rows 32w.. (two pieces)
+  const uint32_t lr = lane >> 2, lc = lane & 3;
+  const uint16_t* src[FC_NP];
+  uint32_t dst[FC_NP];
+  {
+    const uint32_t row0 = wave * 16, row = row0 + lr;
+    src[0] = A + (uint64_t)min(m0 + row, M - 1) * lda + (lc ^ ((row >> 1) & 3u)) * 8;
+    dst[0] = row0 * 64;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const uint32_t row0 = (wave * 2 + h) * 16, row = row0 + lr;
+    src[1 + h] = W.h16 + (uint64_t)row * K + (lc ^ ((row >> 1) & 3u)) * 8;
+    dst[1 + h] = FC_TM * 64 + row0 * 64;
+  }
+  const uint32_t lds_base = (uint32_t)(uintptr_t)s_raw;
+  auto stage = [&](uint32_t kt, uint32_t buf) {
+    const uint32_t b0 = lds_base + buf * (FC_BS * 2);
+#pragma unroll
+    for (int p = 0; p < FC_NP; p++) glds16_h(src[p] + kt * 32, __builtin_amdgcn_readfirstlane(b0 + dst[p]));
+  };
+  auto compute = [&](uint32_t buf) {
+    const uint16_t* s_a = s_raw + buf * FC_BS;
+    const uint16_t* s_b = s_a + FC_TM * 32;
+    half8 ah[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint32_t ar = wr * 64 + i * 16 + fr;
+      ah[i] = *reinterpret_cast<const half8*>(s_a + ar * 32 + (fc ^ ((ar >> 1) & 3u)) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t br = wc * 64 + j * 16 + fr;
+      const half8 bh = *reinterpret_cast<const half8*>(s_b + br * 32 + (fc ^ ((br >> 1) & 3u)) * 8);
+#pragma unroll
+      for (int i = 0; i < 4; i++) acc[i][j] = mma(ah[i], bh, acc[i][j]);
+    }
+  };
+  const uint32_t nk = K / 32;
+  stage(0, 0);
+  if (nk > 1) stage(1, 1);
+  uint32_t buf = 0, nbuf = 2;
+  for (uint32_t k = 0; k < nk; k++) {
+    if (k + 1 < nk) wait_vmcnt_h<FC_NP>(); else wait_vmcnt_h<0>();  // this wave's pieces of tile k have landed ...
+    __builtin_amdgcn_s_barrier();                                   // ... everybody's have; tile k-1 is no longer read
+    if (k + 2 < nk) stage(k + 2, nbuf);
+    compute(buf);
+    buf = buf == FC_NBUF - 1 ? 0 : buf + 1;
+    nbuf = nbuf == FC_NBUF - 1 ? 0 : nbuf + 1;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t n = wc * 64 + j * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t m = m0 + wr * 64 + i * 16 + fc * 4 + r;
+        if (m < M) C[(uint64_t)m * ldc + n] = acc[i][j][r] + bs[j];
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The encoder stack in one kernel, f16 operands.  Organisation as k_layers (model.hip): a tile of whole windows
+// (<= 64 tokens) per workgroup, 8 waves, wave = head for attention and = 32-channel slab of every GEMM output;
+// LayerNorm output / attention output / FF hidden chunk are f16 planes in LDS (hi and, with TERMS = 2, lo), weights
+// stream L2 -> registers in MFMA fragment order (Weight::ph16).  Differences that the smaller operands buy:
+//   * the residual stream x never leaves the registers (the bf16x3 kernel parked it in HBM around every GEMM phase
+//     to make room for 128 VGPRs of weight fragments; here a full-K weight batch is 64);
+//   * all 16 fragment loads of a GEMM call are in flight before its first MFMA (one L2 round trip per call);
+//   * Q, K, V, P are single f16 fragments (attention's error share is 4e-5 / 1.8e-4);
+//   * the positional encoding is added while x is fetched (no k_add_pe launch, no extra pass over x).
+// ---------------------------------------------------------------------------------------------------
+constexpr int HLT = 64;
+constexpr size_t LAYERS_H_SHM = (size_t)4 * HLT * 256 * 2 + 8 * HLT * 4 + HLT * 4;
+__device__ __forceinline__ uint32_t hlsw(uint32_t row, uint32_t chunk) { return row * 256 + ((chunk ^ (row & 15u)) << 3); }
+
+// acc[pt][jt] += W[32 channels at cb][K = 256 at kofs] x act[64 tokens][256] (LDS planes sh / sl).
+// SWAP = false: weights are the MFMA A operand -> lane (token fr of tile pt) x channels cb + 8 fg + 4 jt + r.
+// SWAP = true : activations are the A operand  -> lane (channel cb + 8 (fr>>2) + 4 jt + (fr&3)) x tokens 16 pt + 4 fg + r.
+template <bool SWAP, int TERMS>
+__device__ __forceinline__ void tile_gemm_h(const Weight& W, uint32_t cb, uint32_t kofs, const uint16_t* sh, const uint16_t* sl,
+                                            uint32_t fr, uint32_t fg, f32x4 (&acc)[4][2]) {
+  const uint32_t nks = W.K >> 5, lane = fg * 16 + fr;
+  half8 w[8][2];
+#pragma unroll
+  for (int jt = 0; jt < 2; jt++) {
+    const uint64_t wo = ((((uint64_t)(cb >> 5) * 2 + jt) * nks + (kofs >> 5)) * 64 + lane) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k][jt] = *reinterpret_cast<const half8*>(W.ph16 + wo + k * 512);
+  }
+  __builtin_amdgcn_sched_barrier(0);  // all 16 loads issued together, ahead of the MFMAs (waits are then counted per use)
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    half8 xh[4], xl[4];
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++) {
+      const uint32_t o = hlsw(pt * 16 + fr, k * 4 + fg);
+      xh[pt] = *reinterpret_cast<const half8*>(sh + o);
+      if (TERMS == 2) xl[pt] = *reinterpret_cast<const half8*>(sl + o);
+    }
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++)
+#pragma unroll
+      for (int jt = 0; jt < 2; jt++) acc[pt][jt] = SWAP ? mma(xh[pt], w[k][jt], acc[pt][jt]) : mma(w[k][jt], xh[pt], acc[pt][jt]);
+    if (TERMS == 2) {
+#pragma unroll
+      for (int pt = 0; pt < 4; pt++)
+#pragma unroll
+        for (int jt = 0; jt < 2; jt++) acc[pt][jt] = SWAP ? mma(xl[pt], w[k][jt], acc[pt][jt]) : mma(w[k][jt], xl[pt], acc[pt][jt]);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the next k-step's fragment reads from being hoisted over this one's MFMAs
+  }
+}
+
+template <int TERMS>
+__global__ __launch_bounds__(512) void k_layers_h(ModelDev M, BatchDev B, ModelScratch S) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t* s_hh = reinterpret_cast<uint16_t*>(smem);  // LayerNorm output, hi / lo planes [64][256]
+  uint16_t* s_hl = s_hh + HLT * 256;
+  uint16_t* s_ah = s_hl + HLT * 256;                   // attention output, then FF hidden chunk
+  uint16_t* s_al = s_ah + HLT * 256;
+  float* s_red = reinterpret_cast<float*>(s_al + HLT * 256);       // [8 waves][64 tokens]
+  uint32_t* s_win = reinterpret_cast<uint32_t*>(s_red + 8 * HLT);  // [64] window of each token
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t fr = lane & 15, fg = lane >> 4;
+  const uint32_t t0 = B.tile_tok0[blockIdx.x], nt = B.tile_tok0[blockIdx.x + 1] - t0;
+  const uint32_t cw = wave * 32;
+  const float eps = M.h.ln_eps;
+
+  if (tid < HLT) s_win[tid] = tid < nt ? S.tok_win[t0 + tid] : 0xffffff00u + tid;  // padding slots: a window of their own
+  float x[4][8];
+
+  // LayerNorm of the register-resident x over the 256 channels (8 waves x 4 lane groups x 8 registers), two passes;
+  // the result goes to the s_hh (/ s_hl) planes
+  auto layer_norm = [&](const float* __restrict__ g, const float* __restrict__ b, bool want_lo) {
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+#pragma unroll
+      for (int pt = 0; pt < 4; pt++) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const float d = pass == 0 ? x[pt][q] : x[pt][q] - mean[pt];
+          s += pass == 0 ? d : d * d;
+        }
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (fg == 0) s_red[wave * HLT + pt * 16 + fr] = s;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int pt = 0; pt < 4; pt++) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; w++) s += s_red[w * HLT + pt * 16 + fr];
+        if (pass == 0) mean[pt] = s / 256.f;
+        else rstd[pt] = 1.0f / sqrtf(s / 256.f + eps);
+      }
+      __syncthreads();
+    }
+    const float4 g0 = *reinterpret_cast<const float4*>(g + cw + 8 * fg), g1 = *reinterpret_cast<const float4*>(g + cw + 8 * fg + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(b + cw + 8 * fg), b1 = *reinterpret_cast<const float4*>(b + cw + 8 * fg + 4);
+    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++) {
+      float y[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) y[q] = (x[pt][q] - mean[pt]) * rstd[pt] * gg[q] + bb[q];
+      const uint32_t o = hlsw(pt * 16 + fr, wave * 4 + fg);
+      if (want_lo) {
+        half8 hi, lo;
+        split_h8(y, hi, lo);
+        *reinterpret_cast<half8*>(s_hh + o) = hi;
+        *reinterpret_cast<half8*>(s_hl + o) = lo;
+      } else {
+        *reinterpret_cast<half8*>(s_hh + o) = pack_h8(y);
+      }
+    }
+    __syncthreads();
+  };
+  auto zero = [](f32x4 (&a)[4][2]) {
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++)
+#pragma unroll
+      for (int jt = 0; jt < 2; jt++) a[pt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto bias8 = [&](const float* bias, uint32_t c, float (&o)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(bias + c), b = *reinterpret_cast<const float4*>(bias + c + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  };
+  // activations that feed a TERMS-term GEMM: 8 consecutive channels of one token -> one 16-byte chunk per plane
+  auto store_act = [&](uint16_t* ph, uint16_t* pl, uint32_t o, const float (&v)[8]) {
+    if (TERMS == 2) {
+      half8 hi, lo;
+      split_h8(v, hi, lo);
+      *reinterpret_cast<half8*>(ph + o) = hi;
+      *reinterpret_cast<half8*>(pl + o) = lo;
+    } else {
+      *reinterpret_cast<half8*>(ph + o) = pack_h8(v);
+    }
+  };
+
+  // ---- x = FC output + sinusoidal positional encoding of the row index (what k_add_pe does in the other modes:
+  // x[2k] += sin(row * div[k]), x[2k+1] += cos(row * div[k]), the product rounded to f32 first)
+  {
+    const float4 pdv = *reinterpret_cast<const float4*>(M.pe_div + ((cw + 8 * fg) >> 1));
+    const float pd[4] = {pdv.x, pdv.y, pdv.z, pdv.w};
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++) {
+      const uint32_t tok = pt * 16 + fr;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+      float row = 0.f;
+      if (tok < nt) {
+        const float* xp = S.x + (uint64_t)(t0 + tok) * 256 + cw + 8 * fg;
+        a = *reinterpret_cast<const float4*>(xp);
+        b = *reinterpret_cast<const float4*>(xp + 4);
+        row = (float)S.tok_row[t0 + tok];
+      }
+      x[pt][0] = a.x; x[pt][1] = a.y; x[pt][2] = a.z; x[pt][3] = a.w;
+      x[pt][4] = b.x; x[pt][5] = b.y; x[pt][6] = b.z; x[pt][7] = b.w;
+      if (tok < nt) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float ang = __fmul_rn(row, pd[j]);
+          x[pt][2 * j] += sinf(ang);
+          x[pt][2 * j + 1] += cosf(ang);
+        }
+      }
+    }
+  }
+
+  const float scale = 1.0f / sqrtf(32.f);
+  for (uint32_t li = 0; li < M.h.n_layers; li++) {
+    const LayerW& L = M.layer[li];
+    layer_norm(L.ln1_g, L.ln1_b, TERMS == 2);
+    {  // ---- attention, head = wave; Q, K, V, P are single f16 fragments
+      half8 qh[4], kh[4], vh[2][2];
+      {
+        f32x4 a[4][2];
+        float bq[8];
+        zero(a);
+        tile_gemm_h<false, TERMS>(L.qkv, cw, 0, s_hh, s_hl, fr, fg, a);
+        bias8(L.qkv.bias, cw + 8 * fg, bq);
+#pragma unroll
+        for (int pt = 0; pt < 4; pt++) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) v[q] = (a[pt][q >> 2][q & 3] + bq[q]) * scale;
+          qh[pt] = pack_h8(v);
+        }
+        zero(a);
+        tile_gemm_h<false, TERMS>(L.qkv, 256 + cw, 0, s_hh, s_hl, fr, fg, a);
+        bias8(L.qkv.bias, 256 + cw + 8 * fg, bq);
+#pragma unroll
+        for (int pt = 0; pt < 4; pt++) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) v[q] = a[pt][q >> 2][q & 3] + bq[q];
+          kh[pt] = pack_h8(v);
+        }
+        zero(a);
+        tile_gemm_h<true, TERMS>(L.qkv, 512 + cw, 0, s_hh, s_hl, fr, fg, a);
+        // lane = channel 512 + cw + 8 (fr>>2) + 4 ct + (fr&3), tokens 16 pt + 4 fg + r
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++) {
+          const float bv = L.qkv.bias[512 + cw + 8 * (fr >> 2) + 4 * ct + (fr & 3)];
+#pragma unroll
+          for (int kk = 0; kk < 2; kk++) {  // k-step of 32 tokens: slots e < 4 from token tile 2kk, e >= 4 from 2kk + 1
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = a[2 * kk + (e >> 2)][ct][e & 3] + bv;
+            vh[ct][kk] = pack_h8(v);
+          }
+        }
+      }
+      uint32_t wj[4][4];
+#pragma unroll
+      for (int pj = 0; pj < 4; pj++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) wj[pj][r] = s_win[pj * 16 + 4 * fg + r];
+#pragma unroll
+      for (int pi = 0; pi < 4; pi++) {
+        const uint32_t wi = s_win[pi * 16 + fr];
+        f32x4 st[4];  // S^T: lane = query pi*16 + fr, keys pj*16 + 4 fg + r
+        float m = -INFINITY;
+#pragma unroll
+        for (int pj = 0; pj < 4; pj++) {
+          st[pj] = mma(kh[pj], qh[pi], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            st[pj][r] = wj[pj][r] == wi ? st[pj][r] : -INFINITY;
+            m = fmaxf(m, st[pj][r]);
+          }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int pj = 0; pj < 4; pj++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float pexp = __expf(st[pj][r] - m);  // masked keys: exp(-inf) = 0; a query always sees itself
+            st[pj][r] = pexp;
+            l += pexp;
+          }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] = st[2 * kk + (e >> 2)][e & 3];
+          const half8 ph = pack_h8(v);
+#pragma unroll
+          for (int ct = 0; ct < 2; ct++) o[ct] = mma(vh[ct][kk], ph, o[ct]);
+        }
+        // O^T: lane = query pi*16 + fr, channels cw + 8 fg + 4 ct + r
+        const float inv = 1.0f / l;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = o[e >> 2][e & 3] * inv;
+        store_act(s_ah, s_al, hlsw(pi * 16 + fr, wave * 4 + fg), v);
+      }
+    }
+    __syncthreads();
+    {  // ---- output projection + residual
+      f32x4 a[4][2];
+      float bp[8];
+      zero(a);
+      tile_gemm_h<false, TERMS>(L.proj, cw, 0, s_ah, s_al, fr, fg, a);
+      bias8(L.proj.bias, cw + 8 * fg, bp);
+#pragma unroll
+      for (int pt = 0; pt < 4; pt++)
+#pragma unroll
+        for (int q = 0; q < 8; q++) x[pt][q] += a[pt][q >> 2][q & 3] + bp[q];
+    }
+    layer_norm(L.ln2_g, L.ln2_b, TERMS == 2);  // its barriers also fence the reuse of s_ah / s_al below
+    {  // ---- feed-forward, 256 hidden channels at a time
+      f32x4 a2[4][2];
+      zero(a2);
+      for (uint32_t c = 0; c < M.h.d_ff; c += 256) {
+        f32x4 a1[4][2];
+        float b1[8];
+        zero(a1);
+        tile_gemm_h<false, TERMS>(L.ff1, c + cw, 0, s_hh, s_hl, fr, fg, a1);
+        bias8(L.ff1.bias, c + cw + 8 * fg, b1);
+#pragma unroll
+        for (int pt = 0; pt < 4; pt++) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) v[q] = fmaxf(a1[pt][q >> 2][q & 3] + b1[q], 0.f);
+          store_act(s_ah, s_al, hlsw(pt * 16 + fr, wave * 4 + fg), v);
+        }
+        __syncthreads();
+        tile_gemm_h<false, TERMS>(L.ff2, cw, c, s_ah, s_al, fr, fg, a2);
+        __syncthreads();
+      }
+      float b2[8];
+      bias8(L.ff2.bias, cw + 8 * fg, b2);
+#pragma unroll
+      for (int pt = 0; pt < 4; pt++)
+#pragma unroll
+        for (int q = 0; q < 8; q++) x[pt][q] += a2[pt][q >> 2][q & 3] + b2[q];
+    }
+  }
+  layer_norm(M.lnf_g, M.lnf_b, true);
+  // ---- heads: 16 output channels (0 info, 1..5 bases), three terms; wave w < 4 takes token tile w
+  if (wave < 4) {
+    const uint32_t pt = wave;
+    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+    const Weight& W = M.heads;
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      const half8 wh = *reinterpret_cast<const half8*>(W.h16 + (uint64_t)fr * 256 + ks * 32 + fg * 8);
+      const half8 wl = *reinterpret_cast<const half8*>(W.l16 + (uint64_t)fr * 256 + ks * 32 + fg * 8);
+      const uint32_t o = hlsw(pt * 16 + fr, ks * 4 + fg);
+      const half8 xh = *reinterpret_cast<const half8*>(s_hh + o);
+      const half8 xl = *reinterpret_cast<const half8*>(s_hl + o);
+      a = mma(wl, xh, a);
+      a = mma(wh, xl, a);
+      a = mma(wh, xh, a);
+    }
+    // lane = token pt*16 + fr, channels 4 fg + r
+    const uint32_t tok = pt * 16 + fr;
+    if (tok < nt) {
+      const uint32_t n = t0 + tok, b = S.tok_win[n];
+      const uint64_t o = B.out_off[b] + (n - B.tok_off[b]);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t ch = 4 * fg + r;
+        const float v = a[r] + W.bias[ch];
+        if (ch == 0) B.out_info[o] = v;
+        else if (ch < 6) B.out_base[o * 5 + (ch - 1)] = v;
+      }
+    }
+  }
+}
+
+__global__ void k_build_tokens_h(BatchDev B, ModelScratch S) {
+  const uint32_t b = blockIdx.x;
+  const uint32_t t0 = B.tok_off[b], t1 = B.tok_off[b + 1];
+  for (uint32_t n = t0 + threadIdx.x; n < t1; n += blockDim.x) {
+    const uint32_t row = B.sup_row[B.sup_off[b] + (n - t0)];
+    S.tok_win[n] = b;
+    S.tok_row[n] = row;
+    TokMeta tm;
+    tm.plane_off = B.plane_off[b];
+    tm.plane_ld = B.plane_ld[b];
+    tm.tok_row = row;
+    tm.len = B.len[b];
+    tm.lmax = B.lmax[b];
+    tm.pad0 = tm.pad1 = 0;
+    S.tok_meta[n] = tm;
+  }
+}
+
+}  // namespace
+
+bool model_h_supported(const ModelDev& M) {
+  const ModelHyper& h = M.h;
+  return h.kw == 3 && h.c1 == 64 && h.c2 == HC2 && h.d_model == 256 && h.n_heads == 8 && h.d_ff % 256 == 0 && h.rows == HERRO_ROWS &&
+         M.conv2.h16 && M.fc.h16 && M.heads.h16 && M.heads.l16 && M.layer[0].qkv.ph16;
+}
+
+// B must be tileable (every window <= 64 informative rows; B.n_tiles > 0) — herro_job_infer sends larger windows through
+// the layer-by-layer kernels of model.hip.  terms: 2 (precision 4) or 1 (precision 5).
+void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S, int terms, hipStream_t st, KernelTimer* tm) {
+  const uint32_t N = B.n_tok;
+  if (N == 0 || B.n_tiles == 0) return;
+  const ModelHyper& h = M.h;
+  KT_BEGIN(tm, "build_tokens", st);
+  hipLaunchKernelGGL(k_build_tokens_h, dim3(B.n_win), dim3(64), 0, st, B, S);
+  KT_END(tm, st);
+  {
+    const uint32_t n_rows = N * HERRO_ROWS, n_tiles = (n_rows + HTP - 1) / HTP;
+    KT_BEGIN(tm, "conv_fused", st);
+    hipLaunchKernelGGL(k_conv_h, dim3(std::min<uint32_t>(n_tiles, 512u)), dim3(256), CONV_H_SHM, st, M, B, S, n_rows, n_tiles);
+    KT_END(tm, st);
+  }
+  opt_in_lds(reinterpret_cast<const void*>(k_fc_h), FC_H_SHM);
+  KT_BEGIN(tm, "fc_gemm", st);
+  hipLaunchKernelGGL(k_fc_h, dim3((N + FC_TM - 1) / FC_TM), dim3(512), FC_H_SHM, st, S.y2_hi, HERRO_ROWS * h.c2, M.fc, S.x, h.d_model, N);
+  KT_END(tm, st);
+  KT_BEGIN(tm, "layers_fused", st);
+  if (terms == 2) {
+    opt_in_lds(reinterpret_cast<const void*>(k_layers_h<2>), LAYERS_H_SHM);
+    hipLaunchKernelGGL(k_layers_h<2>, dim3(B.n_tiles), dim3(512), LAYERS_H_SHM, st, M, B, S);
+  } else {
+    opt_in_lds(reinterpret_cast<const void*>(k_layers_h<1>), LAYERS_H_SHM);
+    hipLaunchKernelGGL(k_layers_h<1>, dim3(B.n_tiles), dim3(512), LAYERS_H_SHM, st, M, B, S);
+  }
+  KT_END(tm, st);
+}
+
+}  // namespace herro

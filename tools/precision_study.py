@@ -1,0 +1,154 @@
+"""Which MFMA operand format keeps the logits inside the 1e-3 contract?  CPU emulation of the model dataflow
+(tests/model_numpy.py) with the GEMM operands rounded the way each candidate kernel would round them
+(f32 accumulation throughout, as the MFMA does).  Prints max |logit error| against an f64 evaluation.
+
+  python tools/precision_study.py [n_windows]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from herro_amd import model_io as mio  # noqa: E402
+import model_numpy as MN  # noqa: E402
+
+
+def rnd(x, dt):
+    return torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dt).to(torch.float32).numpy()
+
+
+def split(x, dt, terms):
+    """x ~= sum of `terms` values of dtype dt"""
+    out, r = [], np.asarray(x, np.float32)
+    for _ in range(terms):
+        h = rnd(r, dt)
+        out.append(h)
+        r = (r - h).astype(np.float32)
+    return out
+
+
+def make_mm(fmt):
+    """fmt: (dtype, a_terms, w_terms, cross) — products kept: all ai*wj with i + j < cross"""
+    if fmt == "f64":
+        return lambda a, wt: a.astype(np.float64) @ wt.astype(np.float64).T
+    if fmt == "f32":
+        return lambda a, wt: a.astype(np.float32) @ wt.astype(np.float32).T
+    dt, na, nw, cross = fmt
+
+    def mm(a, wt):
+        A, Wt = split(a, dt, na), split(wt, dt, nw)
+        acc = np.zeros((a.shape[0], wt.shape[0]), np.float32)
+        for i in range(na):
+            for j in range(nw):
+                if i + j < cross:
+                    acc += (A[i] @ Wt[j].T).astype(np.float32)
+        return acc
+    return mm
+
+
+def forward(F, hp, bases, quals, lens, indices, mm, mm_fc=None, mm_att=None):
+    """model_numpy.forward with pluggable matmuls (mm_fc: conv2 + FC; mm_att: QK^T and PV)."""
+    mm_fc = mm_fc or mm
+    mm_att = mm_att or mm
+    f = np.float64 if mm is make_mm("f64") else np.float32
+    B, L, R = bases.shape
+    kw, c1, c2, D = hp.kw, hp.c1, hp.c2, hp.d_model
+    h = kw // 2
+    toks, o = [], 0
+    for b in range(B):
+        for k in range(int(lens[b])):
+            toks.append((b, int(indices[o + k])))
+        o += int(lens[b])
+    N = len(toks)
+    y1 = np.zeros((N, R, kw, c1), np.float32)
+    t1, wq1, b1 = F["t1"], F["wq1"], F["b1"]
+    for n, (b, l) in enumerate(toks):
+        for dl in range(kw):
+            pos = l + dl - h
+            if pos < 0 or pos >= L:
+                continue
+            v = np.tile(b1, (R, 1)).astype(np.float32)
+            for t in range(kw):
+                q = pos + t - h
+                if q < 0 or q >= L:
+                    continue
+                v = v + t1[t][bases[b, q, :].astype(np.int64)] + wq1[t][None, :] * MN.norm_qual(quals[b, q, :])[:, None]
+            y1[n, :, dl, :] = np.maximum(v, 0)
+    y2 = np.maximum(mm_fc(y1.reshape(N * R, kw * c1), F["conv2.wt"]) + F["conv2.b"], 0).reshape(N, R * c2)
+    x = mm_fc(y2, F["fc.wt"]) + F["fc.b"]
+    rows = np.array([l for _, l in toks], np.float32)
+    ang = (rows[:, None] * F["pe_div"][None, :]).astype(np.float32)
+    x[:, 0::2] += np.sin(ang)
+    x[:, 1::2] += np.cos(ang)
+    H, dh = hp.n_heads, D // hp.n_heads
+    starts = np.concatenate([[0], np.cumsum(lens)]).astype(int)
+    for li in range(hp.n_layers):
+        p = f"L{li}."
+        hb = MN.layernorm(x, F[p + "ln1.g"], F[p + "ln1.b"], hp.ln_eps)
+        qkv = mm(hb, F[p + "qkv.wt"]) + F[p + "qkv.b"]
+        att = np.zeros_like(x)
+        for b in range(B):
+            s, e = starts[b], starts[b + 1]
+            if e == s:
+                continue
+            for hd in range(H):
+                q = qkv[s:e, hd * dh:(hd + 1) * dh] / np.sqrt(dh)
+                k = qkv[s:e, D + hd * dh:D + (hd + 1) * dh]
+                v = qkv[s:e, 2 * D + hd * dh:2 * D + (hd + 1) * dh]
+                sc = mm_att(q, k)
+                sc = np.exp(sc - sc.max(-1, keepdims=True))
+                att[s:e, hd * dh:(hd + 1) * dh] = mm_att(sc, v.T) / sc.sum(-1, keepdims=True)
+        x = x + mm(att, F[p + "proj.wt"]) + F[p + "proj.b"]
+        hb = MN.layernorm(x, F[p + "ln2.g"], F[p + "ln2.b"], hp.ln_eps)
+        ff = np.maximum(mm(hb, F[p + "ff1.wt"]) + F[p + "ff1.b"], 0)
+        x = x + mm(ff, F[p + "ff2.wt"]) + F[p + "ff2.b"]
+    hb = MN.layernorm(x, F["lnf.g"], F["lnf.b"], hp.ln_eps)
+    lg = mm(hb, F["heads.wt"]) + F["heads.b"]
+    return lg[:, :6]
+
+
+def main():
+    nwin = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    hp = mio.Hyper()
+    rng = np.random.default_rng(5)
+    L = 96
+    bases = rng.integers(0, 11, (nwin, L, 31)).astype(np.uint8)
+    quals = rng.integers(33, 90, (nwin, L, 31)).astype(np.uint8)
+    lens = rng.integers(4, 40, nwin).astype(np.int32)
+    idx = np.concatenate([np.sort(rng.choice(L, int(n), replace=False)) for n in lens]).astype(np.int32)
+    bf, hf = torch.bfloat16, torch.float16
+    fmts = {
+        "f32": "f32",
+        "bf16x3 (a1w1,a1w2,a2w1)": (bf, 2, 2, 2),
+        "bf16 x1": (bf, 1, 1, 1),
+        "f16 x1": (hf, 1, 1, 1),
+        "f16 x2 act split (a1w1,a2w1)": (hf, 2, 1, 2),
+        "f16 x2 wt split  (a1w1,a1w2)": (hf, 1, 2, 2),
+        "f16 x3": (hf, 2, 2, 2),
+    }
+    for seed in (0x48455252, 11):
+        F = mio.fold(mio.random_raw_params(hp, seed), hp)
+        ref = forward(F, hp, bases, quals, lens, idx, make_mm("f64"))
+        print(f"seed {seed:#x}: {int(lens.sum())} tokens, |logit| max {np.abs(ref).max():.3f} rms {np.sqrt((ref**2).mean()):.3f}")
+        for name, fmt in fmts.items():
+            out = forward(F, hp, bases, quals, lens, idx, make_mm(fmt))
+            e = np.abs(out - ref)
+            print(f"  {name:34s} max {e.max():.2e}  rms {np.sqrt((e**2).mean()):.2e}")
+        # mixed: conv2/FC in bf16x3 (K = 3968), transformer in a cheaper format
+        for name, fmt in (("stack f16 x1, conv/FC bf16x3", (hf, 1, 1, 1)), ("stack f16 x2 act, conv/FC bf16x3", (hf, 2, 1, 2)),
+                          ("stack f16 x2 wt, conv/FC bf16x3", (hf, 1, 2, 2))):
+            out = forward(F, hp, bases, quals, lens, idx, make_mm(fmt), mm_fc=make_mm((bf, 2, 2, 2)))
+            e = np.abs(out - ref)
+            print(f"  {name:34s} max {e.max():.2e}  rms {np.sqrt((e**2).mean()):.2e}")
+        for name, fmt in (("stack bf16x3, conv/FC f16 x1", (hf, 1, 1, 1)), ("stack bf16x3, conv/FC f16 x2 act", (hf, 2, 1, 2))):
+            out = forward(F, hp, bases, quals, lens, idx, make_mm((bf, 2, 2, 2)), mm_fc=make_mm(fmt), mm_att=make_mm((bf, 2, 2, 2)))
+            e = np.abs(out - ref)
+            print(f"  {name:34s} max {e.max():.2e}  rms {np.sqrt((e**2).mean()):.2e}")
+
+
+if __name__ == "__main__":
+    main()
