@@ -279,7 +279,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {0: "f32", 1: "bf16x3", 2: "f32-valu", 3: "bf16x3"}[args.precision],
+            "dtype": {0: "f32", 1: "bf16x3", 2: "f32-valu", 3: "bf16x3", 4: "f16 (activation hi+lo in the encoder GEMMs)", 5: "f16"}[args.precision],
             "data": "synthetic (SURVEY §8d generator, seed 0x48455252+2; random-init weights of the assumed architecture)",
             "config": {"workload": "synthetic windows, 4096 bp, 32 overlaps each, batch=128, 1xMI355X per rank "
                                    "(BASELINE configs[2])", "batch": args.batch, "window": W, "overlaps": n_ovl,

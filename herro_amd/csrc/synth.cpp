@@ -67,6 +67,7 @@ struct Params {
   uint32_t n_targets, target_len, n_overlaps, flank_min, flank_max;
   double p_sub, p_ins, p_del, p_long_indel, p_partial, p_n_base;
   uint32_t min_partial_len;
+  double p_snp;  // SNP rate between the two haplotypes (SURVEY §8 d: 2e-3); raised by tests that need many informative rows
 };
 
 struct Out {
@@ -155,7 +156,7 @@ void generate(const Params& P, Out& o) {
       const uint8_t b = (uint8_t)g.below(4);
       hap[0].base[(size_t)a] = b;
       uint8_t bb = b;
-      if (g.bern(2e-3)) bb = (uint8_t)((b + 1 + g.below(3)) & 3);
+      if (g.bern(P.p_snp)) bb = (uint8_t)((b + 1 + g.below(3)) & 3);
       if (g.bern(1e-4)) bb = DEL;
       hap[1].base[(size_t)a] = bb;
       if (g.bern(1e-4)) hap[1].ins[(size_t)a].push_back((uint8_t)g.below(4));
@@ -278,12 +279,13 @@ struct herro_synth_params {
   uint64_t seed;
   uint32_t n_targets, target_len, n_overlaps, flank_min, flank_max, min_partial_len;
   double p_sub, p_ins, p_del, p_long_indel, p_partial, p_n_base;
+  double p_snp;  // 0: the default 2e-3
 };
 
 void* herro_synth_generate(const herro_synth_params* p) {
   Params P{p->seed, p->n_targets, p->target_len, p->n_overlaps, p->flank_min, p->flank_max,
            p->p_sub, p->p_ins, p->p_del, p->p_long_indel, p->p_partial, p->p_n_base,
-           p->min_partial_len};
+           p->min_partial_len, p->p_snp > 0 ? p->p_snp : 2e-3};
   if (P.flank_max < P.flank_min) P.flank_max = P.flank_min;
   Out* o = new Out();
   generate(P, *o);

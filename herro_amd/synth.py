@@ -25,6 +25,7 @@ class _Params(C.Structure):
         ("flank_min", C.c_uint32), ("flank_max", C.c_uint32), ("min_partial_len", C.c_uint32),
         ("p_sub", C.c_double), ("p_ins", C.c_double), ("p_del", C.c_double),
         ("p_long_indel", C.c_double), ("p_partial", C.c_double), ("p_n_base", C.c_double),
+        ("p_snp", C.c_double),
     ]
 
 
@@ -77,11 +78,11 @@ class SynthBatch:
 def generate(n_targets: int, target_len: int = 4 * 4096, n_overlaps: int = 32, *, seed: int = SEED,
              flank_min: int = 500, flank_max: int = 1000, p_sub: float = 0.006, p_ins: float = 0.004,
              p_del: float = 0.006, p_long_indel: float = 0.0, p_partial: float = 0.0,
-             p_n_base: float = 0.0, min_partial_len: int = 0) -> SynthBatch:
+             p_n_base: float = 0.0, min_partial_len: int = 0, p_snp: float = 0.0) -> SynthBatch:
     lib = _lib()
     p = _Params(seed, n_targets, target_len, n_overlaps, flank_min, flank_max,
                 min_partial_len or max(1, target_len // 4), p_sub, p_ins, p_del, p_long_indel,
-                p_partial, p_n_base)
+                p_partial, p_n_base, p_snp)
     h = lib.herro_synth_generate(C.byref(p))
     try:
         sizes = np.zeros(5, np.uint64)

@@ -99,6 +99,76 @@ class HerroNet(nn.Module):
         return self.info_head(y).squeeze(-1), self.base_head(y)
 
 
+    # ---------------------------------------------------------------------------------------------------------
+    # The same function written with matmul / layer_norm / softmax only, on whatever device the parameters live
+    # on.  This is what the -m gpu end-to-end test runs ON THE GPU at the BASELINE sizes (4096-bp windows, batch
+    # 64 / 128): the dense CPU module above manages 0.4 windows/s there, and the conv / fused-attention back ends
+    # (MIOpen, SDPA) are not something a parity check should depend on.  tests/test_model_design.py pins it to
+    # forward() on the CPU.  Differences from forward(), none of them numerical beyond f32 rounding order:
+    # conv = kw shifted matmuls over a zero-padded window axis, BatchNorm(eval) applied as its affine map,
+    # the per-position linear evaluated on the gathered rows only (a row-wise op commutes with the gather).
+    @torch.no_grad()
+    def forward_gemm(self, bases, quals, lens, indices, win_chunk: int = 8):
+        hp = self.hp
+        dev = self.fc.weight.device
+        B, L, R = bases.shape
+        kw, h, D, H = hp.kw, hp.kw // 2, hp.d_model, hp.n_heads
+        dh = D // H
+
+        def bn(x, m):   # channel-last
+            return (x - m.running_mean) / torch.sqrt(m.running_var + m.eps) * m.weight + m.bias
+
+        def conv(x, m):  # x [b, L, R, cin] -> [b, L, R, cout]; Conv2d((kw, 1), padding (h, 0)) along L
+            w = m.weight[:, :, :, 0]                        # [cout, cin, kw]
+            xp = F.pad(x, (0, 0, 0, 0, h, h))               # zero rows before / after the window axis
+            acc = None
+            for t in range(kw):
+                term = xp[:, t:t + L] @ w[:, :, t].T
+                acc = term if acc is None else acc + term
+            return acc + m.bias
+
+        lens_l = [int(v) for v in lens]
+        keep = [i for i in range(B) if lens_l[i] > 0]
+        if not keep:
+            return torch.zeros(0), torch.zeros(0, 5)
+        tmax = max(lens_l)
+        toks = torch.zeros(len(keep), tmax, D, device=dev)
+        mask = torch.ones(len(keep), tmax, dtype=torch.bool, device=dev)
+        for c0 in range(0, len(keep), win_chunk):
+            sel = keep[c0:c0 + win_chunk]
+            bb = bases[sel].to(dev).long()
+            qq = quals[sel].to(dev)
+            x = torch.cat([self.embedding(bb), qq[..., None]], dim=-1)       # [b, L, R, 7]
+            x = F.relu(bn(conv(x, self.conv1), self.bn1))
+            x = F.relu(bn(conv(x, self.conv2), self.bn2))                    # [b, L, R, c2]
+            for k, i in enumerate(sel):
+                idx = indices[i].to(dev).long()
+                rows = x[k, idx].reshape(idx.shape[0], R * hp.c2)            # index = row * c2 + c, as forward()
+                ang = idx.to(torch.float32)[:, None] * self.pe_div[None, :]
+                pe = torch.zeros(idx.shape[0], D, device=dev)
+                pe[:, 0::2] = torch.sin(ang)
+                pe[:, 1::2] = torch.cos(ang)
+                toks[c0 + k, :lens_l[i]] = rows @ self.fc.weight.T + self.fc.bias + pe
+                mask[c0 + k, :lens_l[i]] = False
+            del x
+        y = toks
+        neg = mask[:, None, None, :]
+        for layer in self.encoder.layers:
+            a = layer.self_attn
+            h1 = F.layer_norm(y, (D,), layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
+            qkv = h1 @ a.in_proj_weight.T + a.in_proj_bias
+            q, k, v = (t.reshape(t.shape[0], tmax, H, dh).transpose(1, 2) for t in qkv.split(D, dim=-1))
+            sc = (q * (dh ** -0.5)) @ k.transpose(-1, -2)
+            sc = sc.masked_fill(neg, float("-inf"))
+            o = (torch.softmax(sc, dim=-1) @ v).transpose(1, 2).reshape(-1, tmax, D)
+            y = y + o @ a.out_proj.weight.T + a.out_proj.bias
+            h2 = F.layer_norm(y, (D,), layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
+            y = y + F.relu(h2 @ layer.linear1.weight.T + layer.linear1.bias) @ layer.linear2.weight.T + layer.linear2.bias
+        n = self.encoder.norm
+        y = F.layer_norm(y, (D,), n.weight, n.bias, n.eps)[~mask]
+        return (y @ self.info_head.weight.T + self.info_head.bias).squeeze(-1), y @ self.base_head.weight.T + self.base_head.bias
+
+
 def build(raw: dict, hp) -> HerroNet:
     torch.manual_seed(0)
     m = HerroNet(hp).load_raw(raw)
@@ -106,8 +176,10 @@ def build(raw: dict, hp) -> HerroNet:
     return m
 
 
-def run_batch(model: HerroNet, bases_u8: np.ndarray, quals_u8: np.ndarray, lens: np.ndarray, indices_flat: np.ndarray):
-    """Drive the twin exactly like `inference` (inference.rs:147-175): raw u8 in, logits out."""
+def run_batch(model: HerroNet, bases_u8: np.ndarray, quals_u8: np.ndarray, lens: np.ndarray, indices_flat: np.ndarray,
+              gemm: bool = False):
+    """Drive the twin exactly like `inference` (inference.rs:147-175): raw u8 in, logits out.
+    gemm=True evaluates forward_gemm (device-aware; the model may live on the GPU)."""
     b = torch.from_numpy(bases_u8.astype(np.int32))
     q = normalise_quals(torch.from_numpy(quals_u8))
     idx, o = [], 0
@@ -115,5 +187,8 @@ def run_batch(model: HerroNet, bases_u8: np.ndarray, quals_u8: np.ndarray, lens:
         idx.append(torch.from_numpy(indices_flat[o:o + int(n)].astype(np.int32)))
         o += int(n)
     with torch.no_grad():
-        info, base = model(b, q, torch.from_numpy(lens.astype(np.int32)), idx)
-    return info.numpy(), base.numpy()
+        if gemm:
+            info, base = model.forward_gemm(b, q, torch.from_numpy(lens.astype(np.int32)), idx)
+        else:
+            info, base = model(b, q, torch.from_numpy(lens.astype(np.int32)), idx)
+    return info.cpu().numpy(), base.cpu().numpy()

@@ -21,7 +21,7 @@ def _rand_batch(rng, B, L, win_len):
     return bases, quals
 
 
-@pytest.mark.parametrize("precision", [0, 1, 2, 3])
+@pytest.mark.parametrize("precision", [0, 1, 2, 3, 4, 5])
 def test_model_forward_vs_twin(precision):
     import model_ref as MR
     rng = np.random.default_rng(11)
@@ -41,7 +41,7 @@ def test_model_forward_vs_twin(precision):
     assert info.shape == ti.shape and base.shape == tb.shape
     err = max(np.abs(info - ti).max(), np.abs(base - tb).max())
     print(f"precision {precision}: max abs logit error {err:.3e}")
-    assert err <= TOL
+    assert err <= (4e-3 if precision == 5 else TOL)   # 5 = single f16 terms everywhere: measured, not shipped
     if precision == 0:
         assert err <= 1e-4
 
@@ -49,7 +49,8 @@ def test_model_forward_vs_twin(precision):
 @pytest.mark.parametrize("counts", [
     [63, 2, 64, 1, 1, 30, 34, 5],      # tiles 63 | 2 | 64 | 1+1+30 | 34+5: every packing boundary case
     [1] * 70,                          # many one-token windows: 64 + 6
-    [70, 3, 64],                       # a window above the 64-token tile: the whole launch runs layer by layer
+    [70, 3, 64],                       # a window above the 64-token tile runs layer by layer, the others stay fused
+    [5, 130, 64, 65, 1],               # several of them, interleaved
     [0, 0, 5, 0],                      # windows without informative rows in between
 ])
 def test_model_forward_tiling_edges(counts):
@@ -57,8 +58,8 @@ def test_model_forward_tiling_edges(counts):
     not fit fall back to the layer-by-layer kernels.  Both must agree with the twin."""
     import model_ref as MR
     rng = np.random.default_rng(5 + len(counts))
-    B, L = len(counts), 120
-    win_len = rng.integers(80, L + 1, B)
+    B, L = len(counts), 200
+    win_len = rng.integers(140, L + 1, B)
     win_len[0] = L
     bases, quals = _rand_batch(rng, B, L, win_len)
     idx = [np.sort(rng.choice(win_len[b], size=k, replace=False)) for b, k in enumerate(counts)]
@@ -70,6 +71,9 @@ def test_model_forward_tiling_edges(counts):
     ti, tb = MR.run_batch(G.twin(), bases, quals, lens, flat)
     assert info.shape == ti.shape and base.shape == tb.shape
     assert max(np.abs(info - ti).max(), np.abs(base - tb).max()) <= TOL
+    c.set_precision(4)   # f16 kernels: same tiles, windows above 64 rows through the layer-by-layer kernels
+    info4, base4 = c.model_forward(bases, quals, lens, flat)
+    assert max(np.abs(info4 - ti).max(), np.abs(base4 - tb).max()) <= TOL
     c.set_precision(3)
     info3, base3 = c.model_forward(bases, quals, lens, flat)
     c.set_precision(1)

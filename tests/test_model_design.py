@@ -44,6 +44,27 @@ def test_receptive_field_equals_dense_twin(kw):
     assert np.abs(ti - ni).max() < 2e-5 and np.abs(tb - nb).max() < 2e-5
 
 
+def test_gemm_formulation_of_the_twin_equals_the_module():
+    """forward_gemm (what the GPU end-to-end test runs on the device) == the nn.Module forward, incl. collate padding,
+    windows without informative rows and rows next to both window edges."""
+    import model_ref as MR
+    hp = mio.Hyper()
+    raw = mio.random_raw_params(hp, seed=9)
+    rng = np.random.default_rng(6)
+    B, L = 5, 48
+    win_len = np.array([48, 40, 48, 31, 45])
+    bases, quals = _rand_batch(rng, B, L, win_len)
+    idx = [np.array([0, 1, 2, 30, 46, 47]), np.array([39, 38, 5]), np.zeros(0, np.int64), np.arange(31), np.array([44])]
+    idx = [np.sort(i) for i in idx]
+    lens = np.array([len(i) for i in idx], np.int32)
+    flat = np.concatenate(idx).astype(np.int32)
+    twin = MR.build(raw, hp)
+    ti, tb = MR.run_batch(twin, bases, quals, lens, flat)
+    gi, gb = MR.run_batch(twin, bases, quals, lens, flat, gemm=True)
+    assert ti.shape == gi.shape and tb.shape == gb.shape
+    assert np.abs(ti - gi).max() < 2e-5 and np.abs(tb - gb).max() < 2e-5
+
+
 def test_window_without_informative_rows_is_skipped():
     import model_ref as MR
     hp = mio.Hyper(c1=32, c2=32, d_model=64, n_heads=2, d_ff=128, n_layers=1)
