@@ -81,7 +81,9 @@ def main():
     ap.add_argument("--group", type=int, default=32,
                     help="batches per launch group: the windows of GROUP consecutive steps are featurised and run "
                          "through the model in one set of kernel launches (each window keeps its own batch's padding)")
-    ap.add_argument("--precision", type=int, default=1)
+    ap.add_argument("--precision", type=int, default=None,
+                    help="GEMM operand format (herro_set_precision); default = herro_amd.api.DEFAULT_PRECISION, the mode the "
+                         "end-to-end parity test holds to the 1e-3 logits contract")
     ap.add_argument("--streams", type=int, default=2,
                     help="independent contexts (HIP streams) per GPU, each driven by its own host thread, like the "
                          "reference's concurrent feature / inference threads per device (lib.rs:154-200)")
@@ -101,6 +103,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from herro_amd import api, model_io, synth
+    if args.precision is None:
+        args.precision = api.DEFAULT_PRECISION
     W, n_ovl = 4096, 32
     targets_per_step = args.batch // 4
     path, _ = model_io.default_model_file(os.path.join(ROOT, "tests", "_cache"))

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libherro_amd.so")
 _LIB = None
 # GEMM precision used by bench.py / smoke / the end-to-end tests (herro_set_precision): 1 = bf16 hi/lo x3,
 # 4 = f16 (conv / FC / attention single, encoder GEMMs activation hi + lo), see csrc/model_h.hip
-DEFAULT_PRECISION = 1
+DEFAULT_PRECISION = 4
 
 EXPORTS = [
     "herro_version", "herro_create", "herro_destroy", "herro_last_error", "herro_set_stream", "herro_synchronize",

@@ -214,3 +214,42 @@ def test_cross_read_batching_matches_twin():
             assert np.abs(gb - tb[o:o + lens[k]]).max() <= TOL and np.abs(gi - ti[o:o + lens[k]]).max() <= TOL
             o += lens[k]
     job.close()
+
+
+def test_torchscript_archive_to_hip_logits(tmp_path):
+    """The model seam end to end (reference inference.rs:185-186 loads a TorchScript archive, :155-163 calls it):
+    archive on disk -> tools/export_weights.py -> flat file -> herro_load_model -> HIP logits, against
+    torch.jit.load(archive) executed on the CPU with the same inputs."""
+    import os, sys
+    import torch
+    sys.path.insert(0, os.path.join(G.ROOT, "tools"))
+    import export_weights as EW
+    import scripted_twin as ST
+    from herro_amd import model_io as mio
+    import model_numpy as MN
+    hp = mio.Hyper()
+    raw = mio.random_raw_params(hp, seed=4242)          # not the weights the other tests use
+    pt, flat = str(tmp_path / "model.pt"), str(tmp_path / "model.hrro")
+    ST.save_archive(pt, raw, hp)
+    EW.convert(pt, flat, do_verify=True, quiet=True)
+    rng = np.random.default_rng(12)
+    B, L = 4, 260
+    win_len = np.array([260, 200, 260, 231])
+    bases, quals = _rand_batch(rng, B, L, win_len)
+    idx = [np.sort(rng.choice(win_len[b], size=k, replace=False)) for b, k in enumerate([33, 64, 7, 50])]
+    lens = np.array([len(i) for i in idx], np.int32)
+    ts = torch.jit.load(pt, map_location="cpu").eval()
+    with torch.no_grad():
+        ti, tb = ts(torch.from_numpy(bases.astype(np.int32)), torch.from_numpy(MN.norm_qual(quals)), torch.from_numpy(lens),
+                    [torch.from_numpy(i.astype(np.int32)) for i in idx])
+    c = api.Context(0)
+    try:
+        c.load_model(flat)
+        for prec in (1, 4):
+            c.set_precision(prec)
+            info, base = c.model_forward(bases, quals, lens, np.concatenate(idx).astype(np.int32))
+            err = max(np.abs(info - ti.numpy()).max(), np.abs(base - tb.numpy()).max())
+            print(f"archive -> HIP, precision {prec}: max abs logit error {err:.3e}")
+            assert err <= TOL
+    finally:
+        c.close()
