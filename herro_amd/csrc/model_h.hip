@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <set>
 #include <type_traits>
@@ -703,6 +704,435 @@ __global__ __launch_bounds__(512) void k_layers_h(ModelDev M, BatchDev B, ModelS
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_layers_p — k_layers_h with its three exposed latencies taken off the critical path (measured on k_layers_h:
+// one MFMA term costs ~400 us per 4096 windows against a 164 us issue floor, and ~400 us are not GEMM at all):
+//   * weights run one half-call AHEAD across GEMM calls: a call enters with the fragments of its first four k-steps
+//     already in registers (loaded under the previous call's MFMAs), issues the loads of its last four at once, and
+//     under those MFMAs fetches the first four of the NEXT call (the call sequence Q, K, V, proj, [FF1, FF2] x chunks,
+//     next layer's Q ... is static).  k_layers_h paid one L2 round trip at the head of each of its 48 calls per tile,
+//     with both waves of every SIMD waiting at the same time;
+//   * LDS activation fragments are read one half k-step (8 MFMAs, >= 128 cycles) ahead of their use instead of one
+//     MFMA pair ahead;
+//   * bias vectors and LayerNorm parameters are requested before the MFMAs / reductions they follow, not after.
+// ---------------------------------------------------------------------------------------------------
+struct WStream {  // per-lane fragment pointer of one GEMM call: fragment (k, jt) at p + (jt * nks + k) * 512
+  const uint16_t* p;
+  uint32_t nks;
+};
+__device__ __forceinline__ WStream wstream(const Weight& W, uint32_t cb, uint32_t kofs, uint32_t lane) {
+  const uint32_t nks = W.K >> 5;
+  return WStream{W.ph16 + ((uint64_t)((cb >> 5) * 2 * nks + (kofs >> 5)) * 64 + lane) * 8, nks};
+}
+__device__ __forceinline__ void wload4(const WStream& s, uint32_t k0, half8 (&w)[4][2]) {
+#pragma unroll
+  for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[k][jt] = *reinterpret_cast<const half8*>(s.p + (uint64_t)(jt * s.nks + k0 + k) * 512);
+}
+
+template <bool SWAP, int TERMS>
+__device__ __forceinline__ void tile_gemm_p(const WStream& cur, half8 (&wa)[4][2], const WStream& nxt, const uint16_t* sh,
+                                            const uint16_t* sl, uint32_t fr, uint32_t fg, f32x4 (&acc)[4][2]) {
+  half8 wb[4][2];
+  wload4(cur, 4, wb);
+  half8 xh[4], xl[4], xn[4];
+  auto rd = [&](const uint16_t* plane, int k, half8 (&x)[4]) {
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++) x[pt] = *reinterpret_cast<const half8*>(plane + hlsw(pt * 16 + fr, k * 4 + fg));
+  };
+  auto mm8 = [&](const half8 (&x)[4], const half8 (&w)[2]) {
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++)
+#pragma unroll
+      for (int jt = 0; jt < 2; jt++) acc[pt][jt] = SWAP ? mma(x[pt], w[jt], acc[pt][jt]) : mma(w[jt], x[pt], acc[pt][jt]);
+  };
+  rd(sh, 0, xh);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (k == 4) {  // wa's last reader (k = 3) is behind us: refill it with the head of the next call
+      wload4(nxt, 0, wa);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (TERMS == 2) rd(sl, k, xl);
+    __builtin_amdgcn_sched_barrier(0);
+    if (k < 4) mm8(xh, wa[k]); else mm8(xh, wb[k - 4]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (k < 7) rd(sh, k + 1, xn);
+    __builtin_amdgcn_sched_barrier(0);
+    if (TERMS == 2) {
+      if (k < 4) mm8(xl, wa[k]); else mm8(xl, wb[k - 4]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++) xh[pt] = xn[pt];
+  }
+}
+
+// LDS parameter block of one layer (floats): LayerNorm 1 / 2 gain and bias, then the four bias vectors
+constexpr int PAR_LN1G = 0, PAR_LN1B = 256, PAR_LN2G = 512, PAR_LN2B = 768, PAR_BQKV = 1024, PAR_BPROJ = 1792, PAR_BFF2 = 2048, PAR_BFF1 = 2304;
+constexpr int PAR_MAX_FF = 2048;                 // d_ff supported by the parameter block
+constexpr int PAR_FLOATS = PAR_BFF1 + PAR_MAX_FF;
+
+template <int TERMS>
+__global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelScratch S) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t* s_hh = reinterpret_cast<uint16_t*>(smem);
+  uint16_t* s_hl = s_hh + HLT * 256;
+  uint16_t* s_ah = s_hl + HLT * 256;
+  uint16_t* s_al = s_ah + HLT * 256;
+  float* s_red = reinterpret_cast<float*>(s_al + HLT * 256);       // [2 passes][8 waves][64 tokens]
+  uint32_t* s_win = reinterpret_cast<uint32_t*>(s_red + 2 * 8 * HLT);
+  float* s_par = reinterpret_cast<float*>(s_win + HLT);            // this layer's LayerNorm parameters and biases
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint32_t fr = lane & 15, fg = lane >> 4;
+  const uint32_t t0 = B.tile_tok0[blockIdx.x], nt = B.tile_tok0[blockIdx.x + 1] - t0;
+  const uint32_t cw = wave * 32;
+  const float eps = M.h.ln_eps;
+  const uint32_t n_layers = M.h.n_layers, d_ff = M.h.d_ff;
+  // Everything below is address arithmetic on fr / fg (LDS swizzles, fragment pointers, parameter offsets).  Left alone, the
+  // compiler hoists ~170 such loop-invariant values out of the layer loop and then SPILLS them (168 scratch stores before the
+  // loop, ~200 scratch loads per layer, each with its own vmcnt wait).  RELAUNDER() makes fr / fg opaque at the points where
+  // it is called, so the values are recomputed (1-2 VALU each) instead of kept.
+#define RELAUNDER() asm volatile("" : "+v"(fr), "+v"(fg))
+
+  if (tid < HLT) s_win[tid] = tid < nt ? S.tok_win[t0 + tid] : 0xffffff00u + tid;
+  float x[4][8];
+  half8 wa[4][2];  // the first four k-steps of the next GEMM call, always one call ahead
+  wload4(wstream(M.layer[0].qkv, cw, 0, lane), 0, wa);
+
+  auto lds8 = [&](uint32_t o, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(s_par + o), b = *reinterpret_cast<const float4*>(s_par + o + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  };
+  // one coalesced pass over the layer's small parameter vectors -> LDS (the GEMM epilogues and LayerNorms then read
+  // them with LDS latency instead of one L2 round trip each).  Visible after the next barrier.
+  auto stage_params = [&](const LayerW& L) {
+    for (uint32_t e = tid; e < 256; e += 512) {
+      s_par[PAR_LN1G + e] = L.ln1_g[e]; s_par[PAR_LN1B + e] = L.ln1_b[e];
+      s_par[PAR_LN2G + e] = L.ln2_g[e]; s_par[PAR_LN2B + e] = L.ln2_b[e];
+      s_par[PAR_BPROJ + e] = L.proj.bias[e]; s_par[PAR_BFF2 + e] = L.ff2.bias[e];
+    }
+    for (uint32_t e = tid; e < 768; e += 512) s_par[PAR_BQKV + e] = L.qkv.bias[e];
+    for (uint32_t e = tid; e < d_ff; e += 512) s_par[PAR_BFF1 + e] = L.ff1.bias[e];
+  };
+  // x lives in registers only where it is read or updated (LayerNorms, residual adds); across the GEMM phases it is
+  // parked in the tile's own rows of S.x (L2-resident, nobody else touches them) — 32 VGPRs the weight / fragment
+  // pipeline needs.  The fetch is issued BEFORE the last GEMM call of a phase, so its latency hides under MFMAs.
+  auto park_x = [&]() {
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++) {
+      const uint32_t tok = pt * 16 + fr;
+      if (tok < nt) {
+        float* xp = S.x + (uint64_t)(t0 + tok) * 256 + cw + 8 * fg;
+        *reinterpret_cast<float4*>(xp) = make_float4(x[pt][0], x[pt][1], x[pt][2], x[pt][3]);
+        *reinterpret_cast<float4*>(xp + 4) = make_float4(x[pt][4], x[pt][5], x[pt][6], x[pt][7]);
+      }
+    }
+  };
+  auto fetch_x = [&]() {
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++) {
+      const uint32_t tok = pt * 16 + fr;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+      if (tok < nt) {
+        const float* xp = S.x + (uint64_t)(t0 + tok) * 256 + cw + 8 * fg;
+        a = *reinterpret_cast<const float4*>(xp);
+        b = *reinterpret_cast<const float4*>(xp + 4);
+      }
+      x[pt][0] = a.x; x[pt][1] = a.y; x[pt][2] = a.z; x[pt][3] = a.w;
+      x[pt][4] = b.x; x[pt][5] = b.y; x[pt][6] = b.z; x[pt][7] = b.w;
+    }
+  };
+  // LayerNorm over the 256 channels of the register-resident x, two passes (mean, then centred sum of squares)
+  auto layer_norm = [&](uint32_t og, uint32_t ob, const float* __restrict__ gp, const float* __restrict__ bp, bool want_lo) {
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      float* red = s_red + pass * 8 * HLT;   // separate arrays per pass: one barrier less per LayerNorm
+#pragma unroll
+      for (int pt = 0; pt < 4; pt++) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const float d = pass == 0 ? x[pt][q] : x[pt][q] - mean[pt];
+          s += pass == 0 ? d : d * d;
+        }
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (fg == 0) red[wave * HLT + pt * 16 + fr] = s;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int pt = 0; pt < 4; pt++) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; w++) s += red[w * HLT + pt * 16 + fr];
+        if (pass == 0) mean[pt] = s / 256.f;
+        else rstd[pt] = 1.0f / sqrtf(s / 256.f + eps);
+      }
+    }
+    float gg[8], bb[8];
+    if (gp) {  // final LayerNorm: parameters straight from global memory
+      const float4 g0 = *reinterpret_cast<const float4*>(gp + cw + 8 * fg), g1 = *reinterpret_cast<const float4*>(gp + cw + 8 * fg + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(bp + cw + 8 * fg), b1 = *reinterpret_cast<const float4*>(bp + cw + 8 * fg + 4);
+      gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
+      bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+    } else {
+      lds8(og + cw + 8 * fg, gg);
+      lds8(ob + cw + 8 * fg, bb);
+    }
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++) {
+      float y[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) y[q] = (x[pt][q] - mean[pt]) * rstd[pt] * gg[q] + bb[q];
+      const uint32_t o = hlsw(pt * 16 + fr, wave * 4 + fg);
+      if (want_lo) {
+        half8 hi, lo;
+        split_h8(y, hi, lo);
+        *reinterpret_cast<half8*>(s_hh + o) = hi;
+        *reinterpret_cast<half8*>(s_hl + o) = lo;
+      } else {
+        *reinterpret_cast<half8*>(s_hh + o) = pack_h8(y);
+      }
+    }
+    __syncthreads();  // planes complete; also: everybody is past its reads of both s_red arrays
+  };
+  auto zero = [](f32x4 (&a)[4][2]) {
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++)
+#pragma unroll
+      for (int jt = 0; jt < 2; jt++) a[pt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto store_act = [&](uint16_t* ph, uint16_t* pl, uint32_t o, const float (&v)[8]) {
+    if (TERMS == 2) {
+      half8 hi, lo;
+      split_h8(v, hi, lo);
+      *reinterpret_cast<half8*>(ph + o) = hi;
+      *reinterpret_cast<half8*>(pl + o) = lo;
+    } else {
+      *reinterpret_cast<half8*>(ph + o) = pack_h8(v);
+    }
+  };
+
+  stage_params(M.layer[0]);
+  {  // x = FC output + positional encoding (see k_layers_h)
+    const float4 pdv = *reinterpret_cast<const float4*>(M.pe_div + ((cw + 8 * fg) >> 1));
+    const float pd[4] = {pdv.x, pdv.y, pdv.z, pdv.w};
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++) {
+      const uint32_t tok = pt * 16 + fr;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+      float row = 0.f;
+      if (tok < nt) {
+        const float* xp = S.x + (uint64_t)(t0 + tok) * 256 + cw + 8 * fg;
+        a = *reinterpret_cast<const float4*>(xp);
+        b = *reinterpret_cast<const float4*>(xp + 4);
+        row = (float)S.tok_row[t0 + tok];
+      }
+      x[pt][0] = a.x; x[pt][1] = a.y; x[pt][2] = a.z; x[pt][3] = a.w;
+      x[pt][4] = b.x; x[pt][5] = b.y; x[pt][6] = b.z; x[pt][7] = b.w;
+      if (tok < nt) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float ang = __fmul_rn(row, pd[j]);
+          x[pt][2 * j] += sinf(ang);
+          x[pt][2 * j + 1] += cosf(ang);
+        }
+      }
+    }
+  }
+  __syncthreads();  // s_win, s_par
+
+  const float scale = 1.0f / sqrtf(32.f);
+  for (uint32_t li = 0; li < n_layers; li++) {
+    const LayerW& L = M.layer[li];
+    const LayerW& Ln = M.layer[li + 1 < n_layers ? li + 1 : 0];  // after the last layer: a harmless re-read of layer 0
+    RELAUNDER();
+    layer_norm(PAR_LN1G, PAR_LN1B, nullptr, nullptr, TERMS == 2);
+    park_x();
+    RELAUNDER();
+    {  // ---- attention, head = wave
+      half8 qh[4], kh[4], vh[2][2];
+      {
+        f32x4 a[4][2];
+        float bq[8];
+        zero(a);
+        tile_gemm_p<false, TERMS>(wstream(L.qkv, cw, 0, lane), wa, wstream(L.qkv, 256 + cw, 0, lane), s_hh, s_hl, fr, fg, a);
+        lds8(PAR_BQKV + cw + 8 * fg, bq);
+#pragma unroll
+        for (int pt = 0; pt < 4; pt++) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) v[q] = (a[pt][q >> 2][q & 3] + bq[q]) * scale;
+          qh[pt] = pack_h8(v);
+        }
+        zero(a);
+        tile_gemm_p<false, TERMS>(wstream(L.qkv, 256 + cw, 0, lane), wa, wstream(L.qkv, 512 + cw, 0, lane), s_hh, s_hl, fr, fg, a);
+        lds8(PAR_BQKV + 256 + cw + 8 * fg, bq);
+#pragma unroll
+        for (int pt = 0; pt < 4; pt++) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) v[q] = a[pt][q >> 2][q & 3] + bq[q];
+          kh[pt] = pack_h8(v);
+        }
+        zero(a);
+        tile_gemm_p<true, TERMS>(wstream(L.qkv, 512 + cw, 0, lane), wa, wstream(L.proj, cw, 0, lane), s_hh, s_hl, fr, fg, a);
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++) {
+          const float bv = s_par[PAR_BQKV + 512 + cw + 8 * (fr >> 2) + 4 * ct + (fr & 3)];
+#pragma unroll
+          for (int kk = 0; kk < 2; kk++) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = a[2 * kk + (e >> 2)][ct][e & 3] + bv;
+            vh[ct][kk] = pack_h8(v);
+          }
+        }
+      }
+      uint32_t wj[4][4];
+#pragma unroll
+      for (int pj = 0; pj < 4; pj++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) wj[pj][r] = s_win[pj * 16 + 4 * fg + r];
+#pragma unroll
+      for (int pi = 0; pi < 4; pi++) {
+        const uint32_t wi = s_win[pi * 16 + fr];
+        f32x4 st[4];
+        float m = -INFINITY;
+#pragma unroll
+        for (int pj = 0; pj < 4; pj++) {
+          st[pj] = mma(kh[pj], qh[pi], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            st[pj][r] = wj[pj][r] == wi ? st[pj][r] : -INFINITY;
+            m = fmaxf(m, st[pj][r]);
+          }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int pj = 0; pj < 4; pj++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float pexp = __expf(st[pj][r] - m);
+            st[pj][r] = pexp;
+            l += pexp;
+          }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] = st[2 * kk + (e >> 2)][e & 3];
+          const half8 ph = pack_h8(v);
+#pragma unroll
+          for (int ct = 0; ct < 2; ct++) o[ct] = mma(vh[ct][kk], ph, o[ct]);
+        }
+        const float inv = 1.0f / l;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = o[e >> 2][e & 3] * inv;
+        store_act(s_ah, s_al, hlsw(pi * 16 + fr, wave * 4 + fg), v);
+      }
+    }
+    __syncthreads();
+    RELAUNDER();
+    {  // ---- output projection + residual
+      f32x4 a[4][2];
+      float bp[8];
+      zero(a);
+      fetch_x();
+      tile_gemm_p<false, TERMS>(wstream(L.proj, cw, 0, lane), wa, wstream(L.ff1, cw, 0, lane), s_ah, s_al, fr, fg, a);
+      lds8(PAR_BPROJ + cw + 8 * fg, bp);
+#pragma unroll
+      for (int pt = 0; pt < 4; pt++)
+#pragma unroll
+        for (int q = 0; q < 8; q++) x[pt][q] += a[pt][q >> 2][q & 3] + bp[q];
+    }
+    RELAUNDER();
+    layer_norm(PAR_LN2G, PAR_LN2B, nullptr, nullptr, TERMS == 2);
+    park_x();
+    {  // ---- feed-forward, 256 hidden channels at a time
+      f32x4 a2[4][2];
+      {  // the FF2 accumulator starts from its bias: no parameter is read after the loop's last barrier, which is what
+         // lets the next layer's parameters be staged right behind it
+        float b2[8];
+        lds8(PAR_BFF2 + cw + 8 * fg, b2);
+#pragma unroll
+        for (int pt = 0; pt < 4; pt++)
+#pragma unroll
+          for (int jt = 0; jt < 2; jt++) a2[pt][jt] = f32x4{b2[4 * jt], b2[4 * jt + 1], b2[4 * jt + 2], b2[4 * jt + 3]};
+      }
+      for (uint32_t c = 0; c < d_ff; c += 256) {
+        RELAUNDER();
+        f32x4 a1[4][2];
+        float b1[8];
+        zero(a1);
+        tile_gemm_p<false, TERMS>(wstream(L.ff1, c + cw, 0, lane), wa, wstream(L.ff2, cw, c, lane), s_hh, s_hl, fr, fg, a1);
+        lds8(PAR_BFF1 + c + cw + 8 * fg, b1);
+#pragma unroll
+        for (int pt = 0; pt < 4; pt++) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) v[q] = fmaxf(a1[pt][q >> 2][q & 3] + b1[q], 0.f);
+          store_act(s_ah, s_al, hlsw(pt * 16 + fr, wave * 4 + fg), v);
+        }
+        __syncthreads();
+        const bool more = c + 256 < d_ff;
+        const WStream nx = more ? wstream(L.ff1, c + 256 + cw, 0, lane) : wstream(Ln.qkv, cw, 0, lane);
+        if (!more) fetch_x();
+        tile_gemm_p<false, TERMS>(wstream(L.ff2, cw, c, lane), wa, nx, s_ah, s_al, fr, fg, a2);
+        __syncthreads();
+      }
+#pragma unroll
+      for (int pt = 0; pt < 4; pt++)
+#pragma unroll
+        for (int q = 0; q < 8; q++) x[pt][q] += a2[pt][q >> 2][q & 3];
+    }
+    // every wave is past its last read of this layer's parameters (the barrier that closed the FF loop)
+    if (li + 1 < n_layers) stage_params(Ln);   // visible after the first barrier of the next LayerNorm
+  }
+  RELAUNDER();
+  layer_norm(0, 0, M.lnf_g, M.lnf_b, true);
+#undef RELAUNDER
+  if (wave < 4) {  // heads, three terms
+    const uint32_t pt = wave;
+    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+    const Weight& W = M.heads;
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      const half8 wh = *reinterpret_cast<const half8*>(W.h16 + (uint64_t)fr * 256 + ks * 32 + fg * 8);
+      const half8 wl = *reinterpret_cast<const half8*>(W.l16 + (uint64_t)fr * 256 + ks * 32 + fg * 8);
+      const uint32_t o = hlsw(pt * 16 + fr, ks * 4 + fg);
+      const half8 xh = *reinterpret_cast<const half8*>(s_hh + o);
+      const half8 xl = *reinterpret_cast<const half8*>(s_hl + o);
+      a = mma(wl, xh, a);
+      a = mma(wh, xl, a);
+      a = mma(wh, xh, a);
+    }
+    const uint32_t tok = pt * 16 + fr;
+    if (tok < nt) {
+      const uint32_t n = t0 + tok, b = S.tok_win[n];
+      const uint64_t o = B.out_off[b] + (n - B.tok_off[b]);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t ch = 4 * fg + r;
+        const float v = a[r] + W.bias[ch];
+        if (ch == 0) B.out_info[o] = v;
+        else if (ch < 6) B.out_base[o * 5 + (ch - 1)] = v;
+      }
+    }
+  }
+}
+constexpr size_t LAYERS_P_SHM = (size_t)4 * HLT * 256 * 2 + 2 * 8 * HLT * 4 + HLT * 4 + (size_t)PAR_FLOATS * 4;
+
 __global__ void k_build_tokens_h(BatchDev B, ModelScratch S) {
   const uint32_t b = blockIdx.x;
   const uint32_t t0 = B.tok_off[b], t1 = B.tok_off[b + 1];
@@ -725,7 +1155,7 @@ __global__ void k_build_tokens_h(BatchDev B, ModelScratch S) {
 
 bool model_h_supported(const ModelDev& M) {
   const ModelHyper& h = M.h;
-  return h.kw == 3 && h.c1 == 64 && h.c2 == HC2 && h.d_model == 256 && h.n_heads == 8 && h.d_ff % 256 == 0 && h.rows == HERRO_ROWS &&
+  return h.kw == 3 && h.c1 == 64 && h.c2 == HC2 && h.d_model == 256 && h.n_heads == 8 && h.d_ff % 256 == 0 && h.d_ff <= (uint32_t)PAR_MAX_FF && h.rows == HERRO_ROWS &&
          M.conv2.h16 && M.fc.h16 && M.heads.h16 && M.heads.l16 && M.layer[0].qkv.ph16;
 }
 
@@ -748,8 +1178,18 @@ void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S,
   KT_BEGIN(tm, "fc_gemm", st);
   hipLaunchKernelGGL(k_fc_h, dim3((N + FC_TM - 1) / FC_TM), dim3(512), FC_H_SHM, st, S.y2_hi, HERRO_ROWS * h.c2, M.fc, S.x, h.d_model, N);
   KT_END(tm, st);
+  // HERRO_LAYERS_V=0 selects the un-pipelined stack (k_layers_h), kept for A/B measurements
+  static const bool pipelined = !(getenv("HERRO_LAYERS_V") && atoi(getenv("HERRO_LAYERS_V")) == 0);
   KT_BEGIN(tm, "layers_fused", st);
-  if (terms == 2) {
+  if (pipelined) {
+    if (terms == 2) {
+      opt_in_lds(reinterpret_cast<const void*>(k_layers_p<2>), LAYERS_P_SHM);
+      hipLaunchKernelGGL(k_layers_p<2>, dim3(B.n_tiles), dim3(512), LAYERS_P_SHM, st, M, B, S);
+    } else {
+      opt_in_lds(reinterpret_cast<const void*>(k_layers_p<1>), LAYERS_P_SHM);
+      hipLaunchKernelGGL(k_layers_p<1>, dim3(B.n_tiles), dim3(512), LAYERS_P_SHM, st, M, B, S);
+    }
+  } else if (terms == 2) {
     opt_in_lds(reinterpret_cast<const void*>(k_layers_h<2>), LAYERS_H_SHM);
     hipLaunchKernelGGL(k_layers_h<2>, dim3(B.n_tiles), dim3(512), LAYERS_H_SHM, st, M, B, S);
   } else {
