@@ -1,15 +1,22 @@
 #!/usr/bin/env python
-"""bench.py — throughput of the HERRO hot path (pileup featurisation + correction-model forward)
+"""bench.py — throughput of the HERRO hot path (pileup featurisation + correction-model forward + consensus)
 on synthetic overlap batches, one process per GPU.
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the hot path over one batch of `--batch` (128) 4096-bp windows with 32 overlaps
-each (BASELINE.json configs[2]): featurise the windows' reads on the GPU, batch the windows with >=1
-informative position across reads, run the model.  Inputs (2-bit read store, window descriptors) are
-resident in HBM before the timed region.  Weak scaling: every rank processes its own batches; there
-is no data-path collective (windows are independent, SURVEY.md §8 e).
+A step = one pass of the hot path over one batch of `--batch` (128) 4096-bp windows with 32 overlaps each
+(BASELINE.json configs[2]): featurise the windows on the GPU, batch the windows with >= 1 informative position across
+reads, run the model, decode the corrected bases on the device.  `value` counts exactly `--steps` steps with the inputs
+(2-bit read store, window descriptors) resident in HBM before the timed region starts.  The same JSON line also carries
+  end_to_end    the same work with herro_job_create (CIGAR parse, windowing, descriptor upload) and the D2H of the
+                corrected bases INSIDE the timed region, fresh inputs every job, two feeder threads per GPU;
+  roofline      the dominant kernel against its roof, durations from HIP events on the launch stream;
+  cpu_baseline  the reference algorithm on the host cores (oracle feature generation + PyTorch-CPU twin), N = 1 only;
+  self_check    windows of a timed job compared with the oracle after the timing (features bit-exact, FASTA identical).
+Multi-GPU: the path shards by target read with no data-path collective; `--scaling weak` (default) gives every rank its
+own batches, `--scaling strong` shards ONE fixed set of `--windows` windows over the ranks (rank 0 prepares the work,
+scatters it and gathers the corrected reads — herro_amd/shard.py).
 """
 from __future__ import annotations
 
@@ -17,6 +24,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -25,50 +33,91 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_BF16_PEAK_TF = 2500.0
+MFMA_PEAK_TF = 2500.0     # dense bf16 / f16 MFMA
+W, N_OVL, WINS_PER_TARGET = 4096, 32, 4
+DTYPE = {0: "f32", 1: "bf16x3", 2: "f32-valu", 3: "bf16x3", 4: "f16 (encoder GEMMs: activation hi+lo)", 5: "f16"}
+MFMA_TERMS = {1: 3, 3: 3, 4: 2, 5: 1}   # MFMA products issued per algorithmic product in the encoder GEMMs
 
 
 def cpu_baseline(seed: int) -> dict:
-    """Reference algorithm on the host: oracle restatement (features) + PyTorch-CPU twin (model),
-    on a bounded sample of the same workload.  Checker code is used ONLY here."""
+    """Reference algorithm on the host: oracle restatement (features) + PyTorch-CPU twin (model) on a bounded sample of
+    the same workload.  The reference runs the two stages on different threads (lib.rs:154-200), so the pipeline rate is
+    the slower stage's.  Checker code is used ONLY here (and in self_check)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import concurrent.futures as cf
     import oracle_lib as O
     import model_ref as MR
     import torch
     from herro_amd import model_io, synth
-    import concurrent.futures as cf
     cores = os.cpu_count() or 1
-    # feature generation: one target read per task on all host cores, like the reference's feature threads
-    # (lib.rs:159-187); the sample is sized to keep every core busy for a few tasks
     n_tgt = max(24, min(4 * cores, 1024))
-    sb = synth.generate_parallel(n_tgt, 4 * 4096, 32, seed=seed, chunk=32)
+    sb = synth.generate_parallel(n_tgt, WINS_PER_TARGET * W, N_OVL, seed=seed, chunk=32)
     store = O.store_from_synth(sb)
     tasks = [O.target_alignments(sb, t) for t in range(sb.n_targets)]
-    workers = max(1, min(cores, len(tasks)))
 
     def feat(task):
         rid, rows, cigs = task
-        return len(store.extract_features(rid, rows, cigs, 4096))   # result released at once: its memory is recycled by the next task
-    with cf.ThreadPoolExecutor(workers) as ex:      # the oracle is a C++ library behind ctypes: the GIL is released
-        list(ex.map(feat, tasks[:2 * workers]))     # warm-up: threads started, read store paged in, allocator arenas grown
-        t0 = time.perf_counter()
-        n_win = sum(ex.map(feat, tasks))
-        t_feat = time.perf_counter() - t0
-    res = [store.extract_features(*tasks[0], 4096)]   # one read's windows for the model leg below
-    # model: dense twin on one read's windows (reference grouping), all host cores
+        return len(store.extract_features(rid, rows, cigs, W))   # released at once: the next task recycles the memory
+
+    def feat_rate(workers, sample):
+        with cf.ThreadPoolExecutor(workers) as ex:   # the oracle is a C++ library behind ctypes: the GIL is released
+            list(ex.map(feat, sample[:2 * workers]))  # warm-up: threads started, store paged in, allocator arenas grown
+            t0 = time.perf_counter()
+            n = sum(ex.map(feat, sample))
+            return n / (time.perf_counter() - t0)
+    workers = max(1, min(cores, len(tasks)))
+    feat_all = feat_rate(workers, tasks)
+    feat_t4 = feat_rate(min(4, cores), tasks[:24])           # BASELINE.md §3: the reference's `-t 4` configuration
+    # model: dense fp32 twin — what libtorch executes for the TorchScript graph — on ONE collated batch of `mb`
+    # windows of one read group (a batch of 128 such windows takes minutes on the CPU; the batch size is stated)
     torch.set_num_threads(cores)
     _, raw = model_io.default_model_file(os.path.join(ROOT, "tests", "_cache"))
     twin = MR.build(raw, model_io.Hyper())
-    nb, bt = res[0].collate(4, 0)
+    res = [store.extract_features(*tasks[k], W) for k in range(2)]
+    _, warm = res[0].collate(2, 0)
+    MR.run_batch(twin, warm["bases"], warm["quals"], warm["lens"], warm["indices"])   # warm-up: threads, allocator, oneDNN primitives
+    _, bt = res[1].collate(4, 0)
     t0 = time.perf_counter()
     MR.run_batch(twin, bt["bases"], bt["quals"], bt["lens"], bt["indices"])
-    t_model = time.perf_counter() - t0
-    n_mwin = len(bt["lens"])
-    per_win = t_feat / n_win + t_model / n_mwin
-    return {"value": 1.0 / per_win, "unit": "windows/s", "cores": cores, "kind": "port",
-            "sample": f"oracle extract_features on {n_win} windows ({workers} threads, {n_win / t_feat:.1f} win/s) + "
-                      f"dense PyTorch-CPU fp32 twin on {n_mwin} windows ({cores} threads, {n_mwin / t_model:.2f} win/s)"}
+    mb = len(bt["lens"])
+    model_rate = mb / (time.perf_counter() - t0)
+    return {"value": min(feat_all, model_rate), "unit": "windows/s", "cores": cores, "kind": "port",
+            "feature_windows_per_s": feat_all, "feature_windows_per_s_4_threads": feat_t4, "model_windows_per_s": model_rate,
+            "model_batch": mb,
+            "sample": f"pipelined stages, rate of the slower one: oracle extract_features on {sb.n_targets * WINS_PER_TARGET} windows "
+                      f"({workers} threads: {feat_all:.0f} win/s; 4 threads, the reference's -t 4: {feat_t4:.0f} win/s) | dense PyTorch-CPU fp32 "
+                      f"twin of the assumed architecture, warmed, one batch of {mb} windows ({cores} threads: {model_rate:.2f} win/s). "
+                      "The reference itself runs the model on a GPU through libtorch; this is the same algorithm on the host cores"}
+
+
+def self_check(job, sb, targets, n_check: int, seed: int) -> dict:
+    """After the timing: windows of a job that ran in the timed region against the oracle — pileup bit-exact, device FASTA
+    identical to the oracle's consensus.rs restatement decoding the job's logits."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    rng = np.random.default_rng(seed)
+    store = O.store_from_synth(sb)
+    picks = sorted(rng.choice(len(targets), size=min(n_check, len(targets)), replace=False).tolist())
+    n_win = 0
+    for k in picks:
+        t = targets[k]
+        rid, rows, cigs = O.target_alignments(sb, t)
+        res = store.extract_features(rid, rows, cigs, W)
+        lg = []
+        for wi in range(len(res)):
+            ow, gw = res.window(wi), job.window(k * WINS_PER_TARGET + wi)
+            ok = (np.array_equal(gw.bases, ow.bases) and np.array_equal(gw.quals, ow.quals) and gw.qids.tolist() == ow.qids.tolist()
+                  and gw.sup_pos.tolist() == ow.sup_pos.tolist() and gw.sup_ins.tolist() == ow.sup_ins.tolist())
+            if not ok:
+                return {"ok": False, "failed": f"pileup of target {t} window {wi}"}
+            if len(ow.sup_pos):
+                lg.append(job.logits(k * WINS_PER_TARGET + wi)[1])
+            n_win += 1
+        want = res.consensus_fasta(np.concatenate(lg) if lg else np.zeros((0, 5), np.float32))
+        if job.consensus_fasta(k, sb.read_name(rid)) != want:
+            return {"ok": False, "failed": f"FASTA of target {t}"}
+    return {"ok": True, "windows": n_win, "targets": len(picks), "what": "pileup bit-exact vs oracle, device FASTA == oracle consensus of the job's logits"}
 
 
 def main():
@@ -77,7 +126,9 @@ def main():
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=128)
-    ap.add_argument("--pool", type=int, default=2, help="distinct synthetic jobs cycled through")
+    ap.add_argument("--pool", type=int, default=2, help="distinct synthetic jobs per stream cycled through (one job touches ~0.9 GB of read "
+                                                        "store + ~1.2 GB of planes at the default group size: nothing of it survives in the 256 MB "
+                                                        "Infinity Cache until the job runs again)")
     ap.add_argument("--group", type=int, default=32,
                     help="batches per launch group: the windows of GROUP consecutive steps are featurised and run "
                          "through the model in one set of kernel launches (each window keeps its own batch's padding)")
@@ -87,6 +138,10 @@ def main():
     ap.add_argument("--streams", type=int, default=2,
                     help="independent contexts (HIP streams) per GPU, each driven by its own host thread, like the "
                          "reference's concurrent feature / inference threads per device (lib.rs:154-200)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--windows", type=int, default=0, help="--scaling strong: total windows of the fixed job (default steps * batch)")
+    ap.add_argument("--e2e-jobs", type=int, default=2, help="jobs per feeder thread in the end_to_end leg (0: skip it)")
+    ap.add_argument("--self-check", type=int, default=6, help="targets compared with the oracle after the timing (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -105,8 +160,10 @@ def main():
     from herro_amd import api, model_io, synth
     if args.precision is None:
         args.precision = api.DEFAULT_PRECISION
-    W, n_ovl = 4096, 32
-    targets_per_step = args.batch // 4
+    if args.scaling == "strong":
+        from herro_amd import shard
+        return shard.bench_strong(args, rank, world, local)
+    targets_per_step = args.batch // WINS_PER_TARGET
     path, _ = model_io.default_model_file(os.path.join(ROOT, "tests", "_cache"))
     # at least two launch groups per timed region when possible, so that featurize(k+1) can overlap infer(k)
     G = max(1, min(args.group, args.steps // 2 if args.steps >= 2 else 1))
@@ -114,11 +171,17 @@ def main():
     NS = max(1, min(args.streams, n_full)) if n_full else 1
     pool = max(1, min(args.pool, (n_full + NS - 1) // NS if n_full else 1))
     n_jobs = NS * pool
-    n_t = n_jobs * G * targets_per_step + rem * targets_per_step
+    tpj = G * targets_per_step                                  # targets per job
+    n_e2e = args.e2e_jobs * NS if (args.e2e_jobs > 0 and n_full) else 0
+    n_t = (n_jobs + n_e2e) * tpj + rem * targets_per_step
+
+    def job_targets(i):
+        return range(i * tpj, (i + 1) * tpj)
+
     def prepare(parallel: bool):
         """synthetic reads + alignments -> read stores in HBM + jobs (descriptors uploaded); outside the timed region"""
         gen = synth.generate_parallel if parallel else synth.generate   # parallel: chunks generated concurrently, merged
-        sb_ = gen(n_t, 4 * W, n_ovl, seed=synth.SEED + 2 + 1000 * rank)
+        sb_ = gen(n_t, WINS_PER_TARGET * W, N_OVL, seed=synth.SEED + 2 + 1000 * rank)
         ctxs_ = []
         for s_i in range(NS):
             c = api.Context(local)
@@ -126,28 +189,22 @@ def main():
             c.set_precision(args.precision)
             c.set_reads(sb_.seq, sb_.qual, sb_.off)
             ctxs_.append(c)
-        t0 = time.perf_counter()
-        jobs_ = [[api.job_from_synth(ctxs_[s_i], sb_, W, range((s_i * pool + i) * G * targets_per_step,
-                                                                (s_i * pool + i + 1) * G * targets_per_step))
-                  for i in range(pool)] for s_i in range(NS)]
-        dt = time.perf_counter() - t0
-        rem_ = api.job_from_synth(ctxs_[0], sb_, W, range(n_jobs * G * targets_per_step, n_t)) if rem else None
+        jobs_ = [[api.job_from_synth(ctxs_[s_i], sb_, W, job_targets(s_i * pool + i)) for i in range(pool)] for s_i in range(NS)]
+        rem_ = api.job_from_synth(ctxs_[0], sb_, W, range((n_jobs + n_e2e) * tpj, n_t)) if rem else None
         assert all(j.n_windows == G * args.batch for js in jobs_ for j in js)
-        return sb_, ctxs_, jobs_, rem_, dt
+        return sb_, ctxs_, jobs_, rem_
 
     try:
-        sb, ctxs, jobs, rem_job, host_prepare_s = prepare(True)
+        sb, ctxs, jobs, rem_job = prepare(True)
     except Exception as e:  # pragma: no cover — input preparation only; the serial generator is the tested baseline
         print(f"bench: input preparation from parallel chunks failed ({e!r}); generating serially", file=sys.stderr)
-        sb, ctxs, jobs, rem_job, host_prepare_s = prepare(False)
+        sb, ctxs, jobs, rem_job = prepare(False)
     ctx = ctxs[0]
 
     def run_job(j):
         j.featurize()
         j.infer(args.batch, 1)
         j.consensus()      # corrected bases stay in HBM (≈4 KB/window); only they would cross PCIe
-
-    import threading
 
     def run_steps(n_steps):
         """exactly n_steps batches of `batch` windows, launch groups dealt round-robin to the streams"""
@@ -208,8 +265,61 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
 
-    # ---- per-kernel durations with HIP events on the launch stream (second pass, same steps)
-    # (single stream, so that kernel durations are not inflated by the other stream's kernels)
+    # ---- end to end: job creation from host alignments + D2H of the corrected bases inside the timed region, fresh
+    # inputs for every job.  Per feeder thread: create(k+1) runs on the host while the GPU works on job k.
+    e2e = None
+    if n_e2e:
+        per = args.e2e_jobs
+        stats = [None] * NS
+
+        def feeder(s_i):
+            c = ctxs[s_i]
+            ids = [n_jobs + s_i * per + k for k in range(per)]
+            host_s = 0.0
+            bases = 0
+            t_h = time.perf_counter()
+            cur = api.job_from_synth(c, sb, W, job_targets(ids[0]))
+            host_s += time.perf_counter() - t_h
+            cur.featurize()
+            for k in range(per):
+                nxt = None
+                if k + 1 < per:
+                    t_h = time.perf_counter()
+                    nxt = api.job_from_synth(c, sb, W, job_targets(ids[k + 1]))   # host: CIGAR parse, windowing, upload enqueue
+                    host_s += time.perf_counter() - t_h
+                    nxt.featurize()
+                cur.infer(args.batch, 1)
+                cur.consensus()
+                bases += cur.consensus_fetch()                                        # D2H of the corrected bases (synchronises)
+                cur.close()
+                cur = nxt
+            stats[s_i] = (host_s, bases)
+        barrier()
+        t1 = time.perf_counter()
+        th = [threading.Thread(target=feeder, args=(s_i,)) for s_i in range(NS)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for c in ctxs:
+            c.synchronize()
+        el2 = time.perf_counter() - t1
+        barrier()
+        if world > 1:
+            tt = torch.tensor([el2], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el2 = float(tt.item())
+        n_w = n_e2e * G * args.batch
+        host_s = sum(s[0] for s in stats)
+        e2e = {"windows_per_s": n_w * world / el2, "mbases_per_s": sum(s[1] for s in stats) * world / el2 / 1e6,
+               "windows": n_w * world, "jobs_per_feeder": per, "feeders_per_gpu": NS,
+               "host_prepare_windows_per_s_per_feeder": n_w / NS / (host_s / NS) if host_s else None,
+               "note": "herro_job_create from host alignments (CIGAR parse + windowing on the context's thread pool, one pinned block, "
+                       "one async H2D) + featurize + infer + consensus + D2H of the corrected bases, all inside the timed region; "
+                       "fresh inputs per job; includes the Python-side packing of the alignment arrays"}
+
+    # ---- per-kernel durations with HIP events on the launch stream (separate pass, same jobs, single stream, so
+    # that kernel durations are not inflated by the other stream's kernels)
     st = jobs[0][0].stats()
     ctx.timing_enable(True)
     ctx.timing_reset()
@@ -223,6 +333,13 @@ def main():
     ctx.timing_enable(False)
     timed_steps = n_timed * G if n_full else rem
 
+    check = None
+    if rank == 0 and args.self_check > 0 and n_full:
+        try:
+            check = self_check(jobs[0][0], sb, list(job_targets(0)), args.self_check, 7)
+        except Exception as e:   # the checker must never take the measurement down with it
+            check = {"ok": None, "error": repr(e)}
+
     if rank == 0:
         total_windows = args.steps * args.batch * world
         kern = {k: {"ms_total": v[0], "calls": v[1], "avg_us": 1e3 * v[0] / max(v[1], 1)} for k, v in tm.items()}
@@ -231,13 +348,12 @@ def main():
         model_ms = sum(v[0] for k, v in tm.items() if k not in feat_names) / timed_steps
         # ---- algorithmic work per launch (one launch = G steps = G*batch windows); DESIGN.md §4/§5
         per_job = {k: float(v) for k, v in st.items()}
-        n_cols = 1 + n_ovl
+        n_cols = 1 + N_OVL
         tokens = per_job["sum_supported"]
-        D, FF, C1, C2, KW = 256, 1024, 64, 128, 3
+        D, FF, C1, C2, KW, NL = 256, 1024, 64, 128, 3, 4
         # SURVEY §8 d, minus what this design never moves: featurize writes the TOKEN planes only (31 L' bytes per
         # window) and reads the 2-bit bases (1/5 of bases + qualities); the qualities are touched only inside the
         # model's receptive fields (rf_quals: 5 rows x 31 columns per informative row, read + written)
-        NL = 4
         rf_bytes = tokens * 5 * 31 * 2.0
         feat_bytes = per_job["read_bytes"] / 5.0 + per_job["op_bytes"] + per_job["out_bytes"] / 2.0 + rf_bytes
         alg = {  # name -> (bound, work per launch, unit)
@@ -261,17 +377,19 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")     # written by tools/pmc_traffic.py from a --pmc run
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if dom in tj.get("kernels", {}) and tj.get("group") == G:
+            if dom in tj.get("kernels", {}) and tj.get("group") == G and tj.get("precision", 1) == args.precision:
                 traffic = tj["kernels"][dom]["hbm_bytes_corrected"]
         if bound == "hbm":
             roof = {"kernel": dom, "bound": "hbm", "achieved": work / dom_avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": work / dom_avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                     "algorithmic_bytes_per_launch": work, "launch_us": dom_avg_s * 1e6, "windows_per_launch": G * args.batch}
         else:
-            roof = {"kernel": dom, "bound": "mfma", "achieved": work / dom_avg_s / 1e12, "peak": MFMA_BF16_PEAK_TF,
-                    "unit": "TFLOP/s", "frac": work / dom_avg_s / 1e12 / MFMA_BF16_PEAK_TF, "traffic": traffic,
-                    "algorithmic_flops_per_launch": work, "launch_us": dom_avg_s * 1e6,
-                    "note": "algorithmic 2MNK flops; the bf16x3 split issues 3x that many MFMA flops"}
+            terms = MFMA_TERMS.get(args.precision, 1)
+            roof = {"kernel": dom, "bound": "mfma", "achieved": work / dom_avg_s / 1e12, "peak": MFMA_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": work / dom_avg_s / 1e12 / MFMA_PEAK_TF, "traffic": traffic,
+                    "algorithmic_flops_per_launch": work, "launch_us": dom_avg_s * 1e6, "windows_per_launch": G * args.batch,
+                    "note": f"algorithmic 2MNK flops; this precision issues {terms} MFMA product(s) per algorithmic product in the "
+                            "encoder GEMMs (issued-MFMA fraction = frac x that)"}
         out = {
             "metric": "4096-bp windows corrected/sec at batch=128",
             "value": total_windows / el,
@@ -283,13 +401,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {0: "f32", 1: "bf16x3", 2: "f32-valu", 3: "bf16x3", 4: "f16 (activation hi+lo in the encoder GEMMs)", 5: "f16"}[args.precision],
+            "dtype": DTYPE[args.precision],
             "data": "synthetic (SURVEY §8d generator, seed 0x48455252+2; random-init weights of the assumed architecture)",
             "config": {"workload": "synthetic windows, 4096 bp, 32 overlaps each, batch=128, 1xMI355X per rank "
-                                   "(BASELINE configs[2])", "batch": args.batch, "window": W, "overlaps": n_ovl,
+                                   "(BASELINE configs[2])", "batch": args.batch, "window": W, "overlaps": N_OVL,
                        "mean_len": st["sum_len"] / (G * args.batch), "mean_informative": st["sum_supported"] / (G * args.batch),
                        "model_windows_per_batch": st["n_model_windows"] / G, "batches_per_launch_group": G,
-                       "streams_per_gpu": NS},
+                       "streams_per_gpu": NS, "distinct_windows_cycled": n_jobs * G * args.batch, "precision": args.precision},
             "mbases_per_s": total_windows / el * W / 1e6,
             "roofline": roof,
             "roofline_featurize_group": {
@@ -297,9 +415,8 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": feat_bytes / G / (feat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_step": feat_bytes / G, "ms_per_step": feat_ms},
             "stage_ms_per_step": {"featurize": feat_ms, "model": model_ms},
-            "host_prepare": {"windows_per_s": n_jobs * G * args.batch / host_prepare_s,
-                             "note": "herro_job_create (CIGAR parse + windowing on a host thread pool + descriptor upload), "
-                                     "outside the timed region; includes the Python-side array packing"},
+            "end_to_end": e2e,
+            "self_check": check,
             "kernels": kern,
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is reported at N=1 only

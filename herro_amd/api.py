@@ -18,8 +18,8 @@ DEFAULT_PRECISION = 4
 EXPORTS = [
     "herro_version", "herro_create", "herro_destroy", "herro_last_error", "herro_set_stream", "herro_synchronize",
     "herro_encode_2bit", "herro_decode_2bit", "herro_set_reads", "herro_set_reads_packed", "herro_load_model",
-    "herro_set_precision", "herro_job_create", "herro_job_free", "herro_job_n_windows", "herro_job_featurize",
-    "herro_job_infer", "herro_job_consensus", "herro_job_window_info", "herro_job_window_copy", "herro_job_window_logits",
+    "herro_set_precision", "herro_job_create", "herro_job_free", "herro_job_n_windows", "herro_job_skipped", "herro_job_featurize",
+    "herro_job_infer", "herro_job_consensus", "herro_job_consensus_fetch", "herro_job_window_info", "herro_job_window_copy", "herro_job_window_logits",
     "herro_job_consensus_fasta", "herro_model_forward", "herro_timing_enable", "herro_timing_reset",
     "herro_timing_get", "herro_job_stats", "herro_debug_extract_windows",
     "herro_paf_parse", "herro_oec_read", "herro_paf_n_targets", "herro_paf_target_ids", "herro_paf_aln_off",
@@ -71,9 +71,11 @@ def lib():
         L.herro_job_free.argtypes = [vp]
         L.herro_job_n_windows.restype = u32
         L.herro_job_n_windows.argtypes = [vp]
+        L.herro_job_skipped.argtypes = [vp, vp, vp]
         L.herro_job_featurize.argtypes = [vp]
         L.herro_job_infer.argtypes = [vp, u32, i32]
         L.herro_job_consensus.argtypes = [vp]
+        L.herro_job_consensus_fetch.argtypes = [vp, vp]
         L.herro_job_window_info.argtypes = [vp, u32, vp]
         L.herro_job_window_copy.argtypes = [vp, u32, i32, vp, vp, vp, vp, vp]
         L.herro_job_window_logits.argtypes = [vp, u32, vp, vp]
@@ -278,6 +280,12 @@ class Job:
     def n_windows(self) -> int:
         return self._l.herro_job_n_windows(self.h)
 
+    def skipped(self) -> tuple[int, int]:
+        """(alignments left out, targets left without overlaps) — see herro_job_skipped"""
+        a, t = C.c_uint32(0), C.c_uint32(0)
+        self.ctx._chk(self._l.herro_job_skipped(self.h, C.byref(a), C.byref(t)))
+        return a.value, t.value
+
     def featurize(self):
         self.ctx._chk(self._l.herro_job_featurize(self.h))
 
@@ -287,6 +295,12 @@ class Job:
     def consensus(self):
         """consensus.rs:86-227 on the device; consensus_fasta() then only concatenates windows."""
         self.ctx._chk(self._l.herro_job_consensus(self.h))
+
+    def consensus_fetch(self) -> int:
+        """corrected bases of the whole job -> host; returns how many (herro_job_consensus_fetch)"""
+        n = C.c_uint64(0)
+        self.ctx._chk(self._l.herro_job_consensus_fetch(self.h, C.byref(n)))
+        return n.value
 
     def info(self, w: int) -> WindowInfo:
         wi = WindowInfo()

@@ -11,6 +11,9 @@
 #include <memory>
 #include <string>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -45,6 +48,63 @@ T* dev_alloc_copy(const std::vector<T>& v, hipStream_t st, hipError_t& err) {
 }
 }  // namespace
 
+// ---- host thread pool, one per context (created on first use).  herro_job_create used to start and join
+// min(cores, 64) std::threads twice per call; on a 256-core box that alone was ~3 of its 15 ms per 4096 windows.
+struct HostPool {
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable cv, done_cv;
+  const std::function<void(uint32_t)>* fn = nullptr;
+  std::atomic<uint32_t> next{0};
+  uint32_t n = 0, active = 0;
+  uint64_t gen = 0;
+  bool stop = false;
+  explicit HostPool(uint32_t workers) {
+    for (uint32_t i = 0; i < workers; i++) th.emplace_back([this] { loop(); });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> lk(m); stop = true; }
+    cv.notify_all();
+    for (auto& t : th) t.join();
+  }
+  void work() {
+    for (;;) {
+      const uint32_t i = next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= n) break;
+      (*fn)(i);
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return stop || gen != seen; });
+        if (stop) return;
+        seen = gen;
+      }
+      work();
+      std::lock_guard<std::mutex> lk(m);
+      if (--active == 0) done_cv.notify_one();
+    }
+  }
+  // fn(i) for i in [0, count), on the workers and the calling thread; returns when all are done
+  void run(uint32_t count, const std::function<void(uint32_t)>& f) {
+    if (count == 0) return;
+    if (th.empty() || count == 1) { for (uint32_t i = 0; i < count; i++) f(i); return; }
+    {
+      std::lock_guard<std::mutex> lk(m);
+      fn = &f; n = count; next.store(0); active = (uint32_t)th.size(); gen++;
+    }
+    cv.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(m);
+    done_cv.wait(lk, [&] { return active == 0; });
+  }
+};
+
+struct Arena { void* p = nullptr; size_t cap = 0; };
+
 struct herro_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
@@ -72,6 +132,13 @@ struct herro_ctx {
   uint32_t scratch_cap = 0;
   std::vector<void*> scratch_allocs;
   KernelTimer timer;
+  // job memory: ONE device arena and ONE pinned host arena per job, recycled through these free lists (a job used to
+  // cost 36 hipMallocs + a hipHostMalloc, ~4 ms per 4096 windows, and its descriptors went up from pageable memory)
+  std::unique_ptr<HostPool> pool;
+  std::mutex arena_mu;
+  std::vector<Arena> free_dev, free_pin;
+  uint32_t live_jobs = 0;
+  uint64_t reads_gen = 0;   // bumped by herro_set_reads: a job built on an older store refuses to run
 };
 
 struct BatchPlan {
@@ -90,16 +157,31 @@ struct dinit_alloc : std::allocator<T> {
 };
 template <class T> using uvec = std::vector<T, dinit_alloc<T>>;
 
+// array inside the job's pinned host arena
+template <class T>
+struct harr {
+  T* p = nullptr;
+  size_t n = 0;
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+  size_t size() const { return n; }
+  T* data() { return p; }
+  const T* data() const { return p; }
+};
+
 struct herro_job {
   herro_ctx* ctx = nullptr;
   uint32_t W = 0, n_targets = 0;
-  uvec<WinDesc> win;
-  uvec<OwDesc> ow;
-  uvec<uint32_t> ops;
+  harr<WinDesc> win;
+  harr<OwDesc> ow;
+  harr<uint32_t> ops;
   std::vector<uint32_t> tgt_win_off;  // [n_targets+1]
-  uvec<uint32_t> tile_win, tile_r0;
+  harr<uint32_t> tile_win, tile_r0;
   JobDev J{};
-  std::vector<void*> allocs;
+  Arena dev{}, pin{};              // device arena (descriptors + every scratch / result array), pinned host arena
+  uint64_t reads_gen = 0;
+  uint32_t n_skipped_alns = 0, n_failed_targets = 0;  // inputs the library does not support, left out (herro_job_skipped)
+  std::string first_skip;
   bool featurized = false, synced = false, inferred = false;
   uint32_t host_max_cols = 0, host_n_cls = 0;   // filled for host-only jobs (herro_debug_host_ctx)
   uint64_t host_scr_ops = 0, host_fin_bytes = 0;
@@ -130,6 +212,16 @@ struct herro_job {
 };
 
 static int job_sync(herro_job* job);
+
+static HostPool& host_pool(herro_ctx* ctx) {
+  if (!ctx->pool) {
+    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const char* env = getenv("HERRO_HOST_THREADS");
+    const uint32_t want = env ? (uint32_t)std::max(1, atoi(env)) : std::min(std::max(hw / 2u, 1u), 128u);   // two contexts per GPU are the bench default
+    ctx->pool = std::make_unique<HostPool>(want - 1);  // the calling thread works too
+  }
+  return *ctx->pool;
+}
 
 // Tiles of whole windows for the fused transformer stack: consecutive windows packed greedily into at
 // most 64 tokens.  Returns the first token of each tile (+ end).  Callers pass windows of <= FUSED_MAX_TOK
@@ -194,7 +286,7 @@ static void free_all(std::vector<void*>& v) {
 
 void herro_destroy(herro_ctx* ctx) {
   if (!ctx) return;
-  if (ctx->host_only) { delete ctx; return; }
+  if (ctx->host_only) { for (Arena& a : ctx->free_pin) std::free(a.p); delete ctx; return; }
   hipSetDevice(ctx->device);
   hipDeviceSynchronize();
   ctx->timer.reset();
@@ -203,6 +295,8 @@ void herro_destroy(herro_ctx* ctx) {
   hipFree(ctx->d_ln);
   free_all(ctx->model_allocs);
   free_all(ctx->scratch_allocs);
+  for (Arena& a : ctx->free_dev) (void)hipFree(a.p);
+  for (Arena& a : ctx->free_pin) (void)hipHostFree(a.p);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -264,16 +358,25 @@ static int upload_reads(herro_ctx* ctx, uint32_t n_reads, const std::vector<uint
   std::vector<uint64_t> wp(words);
   wp.push_back(0);  // pad word: get16() may touch one word past a read
   ctx->d_words = dev_alloc_copy(wp, ctx->stream, e); HIP_TRY(ctx, e);
-  {  // bit-plane copy of the same bases (pass 1 counts symbols bit-sliced)
+  {  // bit-plane copy of the same bases (pass 1 counts symbols bit-sliced): even / odd bits of every word, compacted
     std::vector<uint32_t> p0(words.size() + 2, 0), p1(words.size() + 2, 0);
-    for (size_t i = 0; i < words.size(); i++) {
-      const uint64_t x = words[i];
-      uint32_t a = 0, b = 0;
-      for (int k = 0; k < 32; k++) { a |= (uint32_t)((x >> (2 * k)) & 1ull) << k; b |= (uint32_t)((x >> (2 * k + 1)) & 1ull) << k; }
-      p0[i] = a; p1[i] = b;
-    }
+    auto compact = [](uint64_t t) -> uint32_t {  // bits 0, 2, 4, ... of t -> bits 0, 1, 2, ...
+      t &= 0x5555555555555555ull;
+      t = (t | (t >> 1)) & 0x3333333333333333ull;
+      t = (t | (t >> 2)) & 0x0f0f0f0f0f0f0f0full;
+      t = (t | (t >> 4)) & 0x00ff00ff00ff00ffull;
+      t = (t | (t >> 8)) & 0x0000ffff0000ffffull;
+      t = (t | (t >> 16)) & 0x00000000ffffffffull;
+      return (uint32_t)t;
+    };
+    const size_t CH = 1u << 16, nch = (words.size() + CH - 1) / CH;
+    host_pool(ctx).run((uint32_t)nch, [&](uint32_t c) {
+      const size_t a = c * CH, b = std::min(words.size(), a + CH);
+      for (size_t i = a; i < b; i++) { p0[i] = compact(words[i]); p1[i] = compact(words[i] >> 1); }
+    });
     ctx->d_p0 = dev_alloc_copy(p0, ctx->stream, e); HIP_TRY(ctx, e);
     ctx->d_p1 = dev_alloc_copy(p1, ctx->stream, e); HIP_TRY(ctx, e);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // p0 / p1 go out of scope below
   }
   ctx->d_word_off = dev_alloc_copy(word_off, ctx->stream, e); HIP_TRY(ctx, e);
   ctx->d_qual_off = dev_alloc_copy(qual_off, ctx->stream, e); HIP_TRY(ctx, e);
@@ -291,6 +394,7 @@ static int upload_reads(herro_ctx* ctx, uint32_t n_reads, const std::vector<uint
   ctx->name_class.resize(n_reads);
   for (uint32_t i = 0; i < n_reads; i++) ctx->name_class[i] = name_class ? name_class[i] : i;
   ctx->read_bytes = words.size() * 8 + nq;
+  ctx->reads_gen++;   // jobs built on the previous store hold descriptors into freed memory: they refuse to run from here on
   return HERRO_OK;
 }
 
@@ -303,10 +407,11 @@ int herro_set_reads(herro_ctx* ctx, uint32_t n_reads, const uint8_t* seq, const 
     word_off[i + 1] = word_off[i] + (off[i + 1] - off[i] + 31) / 32;
   }
   std::vector<uint64_t> words(word_off[n_reads]);
-  for (uint32_t i = 0; i < n_reads; i++) {
-    const int64_t r = herro_encode_2bit(seq + off[i], off[i + 1] - off[i], words.data() + word_off[i]);
-    if (r < 0) { ctx->err = "read " + std::to_string(i) + ": byte >= 128 in sequence"; return (int)r; }
-  }
+  std::atomic<int64_t> bad{-1};
+  host_pool(ctx).run(n_reads, [&](uint32_t i) {
+    if (herro_encode_2bit(seq + off[i], off[i + 1] - off[i], words.data() + word_off[i]) < 0) bad.store((int64_t)i);
+  });
+  if (bad.load() >= 0) { ctx->err = "read " + std::to_string(bad.load()) + ": byte >= 128 in sequence"; return HERRO_E_REFERENCE_PANIC; }
   // qualities are addressed relative to off[0]
   std::vector<uint64_t> qo(n_reads + 1);
   for (uint32_t i = 0; i <= n_reads; i++) qo[i] = off[i] - off[0];
@@ -552,6 +657,9 @@ struct TargetOut {
   std::vector<WinDesc> win;  // ow_begin target-local; device offsets filled at merge
   uint32_t n_cls = 0;
   uint64_t scr_ops = 0, alg_read_bytes = 0, alg_op_bytes = 0;
+  uint32_t n_skipped = 0;   // alignments left out (see skip() in build_target)
+  bool failed = false;      // the whole target was left without overlaps
+  std::string first_skip;
 };
 
 void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* alns, uint32_t n_aln, uint32_t W,
@@ -562,31 +670,59 @@ void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* aln
   const uint32_t n_windows = (tlen + W - 1) / W;  // features.rs:338
   if (n_windows > 65535) return fail(HERRO_E_UNSUPPORTED, "more than 65535 windows in a read (wid is u16 in the reference)");
   // collect (window, overlap) in alignment order, then bucket by window (stable)
-  struct Tmp { HostOw h; uint32_t op_base; uint32_t aln; };
+  struct Tmp { HostOw h; uint32_t op_base; uint32_t aln; uint32_t st, sq, si; };  // st / sq / si: target, query, insertion bases of the UNTRIMMED slice
   std::vector<Tmp> tmp;
-  std::vector<uint32_t> aops;
+  ParsedCigar pc;
+  std::vector<uint32_t>& aops = pc.ops;
   std::vector<HostOw> hows;
   std::unordered_map<uint32_t, uint32_t> cls_of_name;  // name class -> accumulator slot
   std::unordered_map<uint32_t, uint32_t> seen_qid;
+  // Alignments the library cannot process do not fail the job any more: they are left out and counted
+  // (herro_job_skipped).  Two kinds: what parse_paf itself would have dropped before extract_features ever saw it
+  // (self overlaps, a second alignment of a (query, target) pair — overlaps.rs:175-185), and CIGARs minimap2 never
+  // emits that the kernels' op tables do not model (a window slice starting with an insertion — the reference panics
+  // or writes into the previous position —, consecutive insertion ops).  Inputs on which the reference PANICS still
+  // fail the call: the reference would have aborted the run there (Cargo.toml:18).
+  auto skip = [&](uint32_t a, const char* why) {
+    if (!out.n_skipped++) out.first_skip = "target rid " + std::to_string(rid) + ", alignment " + std::to_string(a) + " (qid " + std::to_string(alns[a].qid) + "): " + why;
+  };
   for (uint32_t a = 0; a < n_aln; a++) {
     const herro_alignment& al = alns[a];
-    if (al.tid != rid) return fail(HERRO_E_UNSUPPORTED, "alignment tid != target rid (parse_paf groups by target, overlaps.rs:189-192)");
+    if (al.tid != rid) return fail(HERRO_E_INVALID, "alignment tid != target rid (parse_paf groups by target, overlaps.rs:189-192)");
     if (al.qid >= ctx->n_reads) return fail(HERRO_E_REFERENCE_PANIC, "alignment qid out of range");
-    if (al.qid == rid) return fail(HERRO_E_UNSUPPORTED, "self overlap (dropped by parse_paf, overlaps.rs:175-179)");
-    if (seen_qid.count(al.qid)) return fail(HERRO_E_UNSUPPORTED, "second alignment of the same (query,target) pair (dropped by parse_paf, overlaps.rs:181-185)");
+    if (al.qid == rid) { skip(a, "self overlap (dropped by parse_paf, overlaps.rs:175-179)"); continue; }
+    if (seen_qid.count(al.qid)) { skip(a, "second alignment of the same (query,target) pair (dropped by parse_paf, overlaps.rs:181-185)"); continue; }
     seen_qid[al.qid] = a;
     if (al.tlen != tlen) return fail(HERRO_E_INVALID, "alignment tlen differs from the stored read length");
     if (al.qend > ctx->read_len[al.qid] || al.tend > tlen) return fail(HERRO_E_REFERENCE_PANIC, "alignment coordinates exceed the read length");
     BuildError be;
-    aops.clear();
-    if (!parse_cigar(al.cigar, al.cigar_len, aops, be)) return fail(be.code, be.msg);
+    if (!parse_cigar_prefix(al.cigar, al.cigar_len, pc, be)) return fail(be.code, be.msg);
     hows.clear();
     if (!window_alignment(aops, al, W, n_windows, hows, be)) return fail(be.code, be.msg);
+    if (!hows.empty()) {
+      bool unsupported = false;
+      for (size_t k = 0; k < hows.size() && !unsupported; k++)
+        unsupported = hows[k].op_hi > hows[k].op_lo && (op_type(aops[hows[k].op_lo]) == OP_I || pc.ins_pair_in(hows[k].op_lo, hows[k].op_hi));
+      if (unsupported) { skip(a, "a window's CIGAR slice starts with an insertion, or consecutive insertion ops (never produced by minimap2)"); continue; }
+    }
     const uint32_t op_base = (uint32_t)out.ops.size();
     if (!hows.empty()) out.ops.insert(out.ops.end(), aops.begin(), aops.end());
-    for (auto& h : hows) tmp.push_back(Tmp{h, op_base, a});
+    for (auto& h : hows)
+      tmp.push_back(Tmp{h, op_base, a, h.op_hi >= h.op_lo ? pc.pt[h.op_hi] - pc.pt[h.op_lo] : 0u, h.op_hi >= h.op_lo ? pc.pq[h.op_hi] - pc.pq[h.op_lo] : 0u,
+                        h.op_hi >= h.op_lo ? pc.pi[h.op_hi] - pc.pi[h.op_lo] : 0u});
     const uint32_t nc = ctx->name_class[al.qid];
     if (!cls_of_name.count(nc)) cls_of_name[nc] = out.n_cls++;
+  }
+  {  // a window with more overlaps than the kernels' 12-bit symbol counters hold: the target keeps its windows, without overlaps
+    std::vector<uint32_t> per_win(n_windows, 0);
+    bool over = false;
+    for (auto& x : tmp) over |= ++per_win[x.h.win] > 4000;
+    if (over) {
+      out.failed = true;
+      out.n_skipped += (uint32_t)seen_qid.size();
+      if (out.first_skip.empty()) out.first_skip = "target rid " + std::to_string(rid) + ": more than 4000 overlaps in one window";
+      tmp.clear(); out.ops.clear(); out.n_cls = 0;
+    }
   }
   std::vector<uint32_t> cnt(n_windows + 1, 0);
   for (auto& x : tmp) cnt[x.h.win + 1]++;
@@ -627,22 +763,26 @@ void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* aln
     if (d.tstart < win_start) return fail(HERRO_E_REFERENCE_PANIC, "overlap starts before its window (usize underflow)");
     if (op_type(out.ops[d.op_begin]) == OP_I)
       return fail(HERRO_E_UNSUPPORTED, "cigar slice starts with an insertion (leading or consecutive I ops; the reference panics or writes into the previous position)");
-    uint64_t tt = 0, qq = 0;
-    for (uint32_t k = 0; k < d.op_cnt; k++) {
-      const uint32_t op = out.ops[d.op_begin + k];
-      const uint32_t l = op_len(op);
-      if (k == 0 && d.op_cnt == 1) { if (d.end_off <= d.start_off) return fail(HERRO_E_REFERENCE_PANIC, "cigar_end_offset <= cigar_start_offset"); }
-      else if (k == 0) { if (l <= d.start_off) return fail(HERRO_E_REFERENCE_PANIC, "op length <= cigar_start_offset"); }
-      const uint32_t e = eff_len(op, k, d.op_cnt, d.start_off, d.end_off);
-      if (e == 0) return fail(HERRO_E_REFERENCE_PANIC, "Operation length cannot be 0");
-      if (op_type(op) != OP_I) tt += e;
-      if (op_type(op) != OP_D) qq += e;
-      if (op_type(op) == OP_I) {
-        ins_sum[wi] += l;
-        if (k + 1 < d.op_cnt && op_type(out.ops[d.op_begin + k + 1]) == OP_I)
-          return fail(HERRO_E_UNSUPPORTED, "consecutive insertion ops in a CIGAR (never produced by minimap2)");
-      }
+    // target / query bases the TRIMMED slice consumes, from the prefix sums of the parse: the slice's first op loses
+    // start_off bases, its last op counts end_off bases (effective-op-length rule, features.rs:82-90); the insertion
+    // total stays untrimmed (get_max_ins, features.rs:64-79).  The slice never starts with I (checked per alignment).
+    const uint32_t op_f = out.ops[d.op_begin], op_l = out.ops[d.op_begin + d.op_cnt - 1];
+    uint64_t tt = x.st, qq = x.sq;
+    if (d.op_cnt == 1) {
+      if (d.end_off <= d.start_off) return fail(HERRO_E_REFERENCE_PANIC, "cigar_end_offset <= cigar_start_offset");
+      const uint32_t e1 = d.end_off - d.start_off, l1 = op_len(op_f);
+      if (op_type(op_f) != OP_I) tt = tt - l1 + e1;
+      if (op_type(op_f) != OP_D) qq = qq - l1 + e1;
+    } else {
+      if (op_len(op_f) <= d.start_off) return fail(HERRO_E_REFERENCE_PANIC, "op length <= cigar_start_offset");
+      if (d.end_off == 0) return fail(HERRO_E_REFERENCE_PANIC, "Operation length cannot be 0");
+      if (op_type(op_f) != OP_I) tt -= d.start_off;
+      if (op_type(op_f) != OP_D) qq -= d.start_off;
+      const uint32_t ll = op_len(op_l);
+      if (op_type(op_l) != OP_I) tt = tt - ll + d.end_off;
+      if (op_type(op_l) != OP_D) qq = qq - ll + d.end_off;
     }
+    ins_sum[wi] += x.si;
     if ((uint64_t)(d.tstart - win_start) + tt > win_len) return fail(HERRO_E_REFERENCE_PANIC, "cigar slice overruns the target window");
     if (qq > d.qlen) return fail(HERRO_E_REFERENCE_PANIC, "cigar slice overruns the query region");
     if ((uint64_t)d.qbeg + d.qlen > ctx->read_len[al.qid]) return fail(HERRO_E_REFERENCE_PANIC, "query region exceeds the query read");
@@ -658,7 +798,6 @@ void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* aln
     wd.win_len = (wi == n_windows - 1) ? tlen - wi * W : W;
     wd.ow_begin = cnt[wi];
     wd.ow_cnt = cnt[wi + 1] - cnt[wi];
-    if (wd.ow_cnt > 4000) return fail(HERRO_E_UNSUPPORTED, "more than 4000 overlaps in one window");
     const uint64_t lub = ((uint64_t)wd.win_len + std::min<uint64_t>(ins_sum[wi], (uint64_t)50 * wd.win_len) + 15) & ~15ull;
     wd.lub = (uint32_t)lub;
     out.alg_read_bytes += (uint64_t)wd.win_len + (wd.win_len + 3) / 4;
@@ -688,33 +827,17 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   job->W = W;
   job->n_targets = n_targets;
   job->tgt_win_off.assign(n_targets + 1, 0);
-  // ---- per-target host work (CIGAR parse, windowing, validation) is independent: run it on a pool of
-  // threads, each target into its own buffers with target-local offsets, then merge in target order.
+  // ---- per-target host work (CIGAR parse, windowing, validation) is independent: it runs on the context's thread
+  // pool, each target into its own buffers with target-local offsets, merged in target order below.
+  HostPool& hpool = host_pool(ctx);
   std::vector<TargetOut> outs(n_targets);
-  {
-    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
-    const char* env = getenv("HERRO_HOST_THREADS");
-    const uint32_t want = env ? (uint32_t)std::max(1, atoi(env)) : std::min(hw, 64u);
-    const uint32_t nthr = std::max(1u, std::min(want, n_targets));
-    std::atomic<uint32_t> next{0};
-    auto worker = [&]() {
-      for (;;) {
-        const uint32_t t = next.fetch_add(1);
-        if (t >= n_targets) break;
-        build_target(ctx, rids[t], alns + aln_off[t], (uint32_t)(aln_off[t + 1] - aln_off[t]), W, outs[t]);
-      }
-    };
-    if (nthr == 1) worker();
-    else {
-      std::vector<std::thread> th;
-      for (uint32_t i = 0; i < nthr; i++) th.emplace_back(worker);
-      for (auto& x : th) x.join();
-    }
-  }
+  hpool.run(n_targets, [&](uint32_t t) {
+    build_target(ctx, rids[t], alns + aln_off[t], (uint32_t)(aln_off[t + 1] - aln_off[t]), W, outs[t]);
+  });
   auto t_built = tnow();
-  // ---- merge in target order: a serial pass over the per-target SIZES fixes every base offset, the bytes are
-  // then copied (and the target-local indices rebased) by the thread pool.  (Appending target by target on one
-  // thread was 35 of the 45 ms herro_job_create took for 4096 windows.)
+  // ---- merge in target order: a serial pass over the per-target SIZES fixes every base offset; the bytes are then
+  // copied (and the target-local indices rebased) by the pool, straight into the job's PINNED host arena, whose
+  // layout is the layout of the head of the device arena: one asynchronous copy takes all descriptors up.
   struct Base { uint64_t op, ow, win, tile, cls, scr, fin, row, pos; };
   std::vector<Base> base(n_targets + 1);
   uint32_t n_cls = 0, max_cols = 1;
@@ -723,7 +846,12 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
     Base b{0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t t = 0; t < n_targets; t++) {
       const TargetOut& o = outs[t];
-      if (o.err.code != HERRO_OK) return fail(o.err.code, o.err.msg);
+      if (o.err.code != HERRO_OK) return fail(o.err.code, "target " + std::to_string(t) + " (rid " + std::to_string(rids[t]) + "): " + o.err.msg);
+      if (o.n_skipped) {
+        if (!job->n_skipped_alns && !job->n_failed_targets) job->first_skip = o.first_skip;
+        job->n_skipped_alns += o.n_skipped;
+        job->n_failed_targets += o.failed ? 1u : 0u;
+      }
       base[t] = b;
       b.op += o.ops.size(); b.ow += o.ow.size(); b.win += o.win.size(); b.cls += o.n_cls; b.scr += o.scr_ops;
       for (const WinDesc& wd : o.win) {
@@ -738,57 +866,81 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
     }
     base[n_targets] = b;
     n_cls = (uint32_t)b.cls; scr_ops = b.scr; fin_bytes = b.fin; row_elems = b.row; pos_elems = b.pos;
-    job->ops.resize(b.op); job->ow.resize(b.ow); job->win.resize(b.win);
-    job->tile_win.resize(b.tile); job->tile_r0.resize(b.tile);
-  }
-  {
-    std::atomic<uint32_t> next{0};
-    auto worker = [&]() {
-      for (;;) {
-        const uint32_t t = next.fetch_add(1);
-        if (t >= n_targets) break;
-        TargetOut& o = outs[t];
-        const Base& b = base[t];
-        if (!o.ops.empty()) std::memcpy(job->ops.data() + b.op, o.ops.data(), o.ops.size() * 4);
-        for (size_t i = 0; i < o.ow.size(); i++) {
-          OwDesc d = o.ow[i];
-          d.win += (uint32_t)b.win; d.cls += (uint32_t)b.cls; d.op_begin += (uint32_t)b.op; d.scr_off += (uint32_t)b.scr;
-          job->ow[b.ow + i] = d;
-        }
-        uint64_t fin = b.fin, row = b.row, pos = b.pos, tile = b.tile;
-        for (size_t i = 0; i < o.win.size(); i++) {
-          WinDesc wd = o.win[i];
-          wd.ow_begin += (uint32_t)b.ow;
-          wd.col_off = 0;
-          wd.fin_off = fin; fin += (uint64_t)HERRO_ROWS * wd.lub;
-          wd.row_off = row; row += wd.lub;
-          wd.pos_off = pos; pos += (uint64_t)W + 1;
-          for (uint32_t r0 = 0; r0 < wd.lub; r0 += HERRO_TILE) { job->tile_win[tile] = (uint32_t)(b.win + i); job->tile_r0[tile] = r0; tile++; }
-          job->win[b.win + i] = wd;
-        }
-        o = TargetOut();  // release
-      }
-    };
-    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
-    const char* env = getenv("HERRO_HOST_THREADS");
-    const uint32_t want = env ? (uint32_t)std::max(1, atoi(env)) : std::min(hw, 64u);
-    const uint32_t nthr = std::max(1u, std::min(want, n_targets));
-    if (nthr == 1) worker();
-    else {
-      std::vector<std::thread> th;
-      for (uint32_t i = 0; i < nthr; i++) th.emplace_back(worker);
-      for (auto& x : th) x.join();
-    }
   }
   if (scr_ops > 0xffffffffull) return fail(HERRO_E_UNSUPPORTED, "job too large (op scratch exceeds 2^32)");
+  if (job->n_skipped_alns) ctx->err = std::to_string(job->n_skipped_alns) + " alignment(s) left out; first: " + job->first_skip;
+  const Base& tot = base[n_targets];
+  // descriptor block (host arena == head of the device arena), 256-byte aligned pieces
+  size_t cur = 0;
+  auto take = [&](size_t bytes) { const size_t o = cur; cur = (cur + std::max<size_t>(bytes, 16) + 255) & ~size_t(255); return o; };
+  const size_t o_ops = take(tot.op * 4), o_ow = take(tot.ow * sizeof(OwDesc)), o_win = take(tot.win * sizeof(WinDesc));
+  const size_t o_tw = take(tot.tile * 4), o_tr = take(tot.tile * 4);
+  const size_t desc_bytes = cur;
+  const size_t o_counts = take(tot.win * 12);   // host arena only: pinned landing zone of the per-window counts
+  const size_t pin_bytes = cur;
+  auto acquire = [&](std::vector<Arena>& pool_, size_t need, bool device) -> Arena {
+    {
+      std::lock_guard<std::mutex> lk(ctx->arena_mu);
+      size_t best = pool_.size();
+      for (size_t i = 0; i < pool_.size(); i++)
+        if (pool_[i].cap >= need && (best == pool_.size() || pool_[i].cap < pool_[best].cap)) best = i;
+      if (best != pool_.size()) { Arena a_ = pool_[best]; pool_.erase(pool_.begin() + best); return a_; }
+    }
+    Arena a_;
+    a_.cap = need + need / 8 + 4096;
+    if (ctx->host_only) a_.p = std::malloc(a_.cap);
+    else if (device) { if (hipMalloc(&a_.p, a_.cap) != hipSuccess) a_.p = nullptr; }
+    else if (hipHostMalloc(&a_.p, a_.cap, hipHostMallocDefault) != hipSuccess) a_.p = nullptr;
+    if (!a_.p) a_.cap = 0;
+    return a_;
+  };
+  job->pin = acquire(ctx->free_pin, pin_bytes, false);
+  if (!job->pin.p) return fail(HERRO_E_NO_DEVICE, "out of pinned host memory for the job");
+  {
+    unsigned char* hb = (unsigned char*)job->pin.p;
+    job->ops.p = (uint32_t*)(hb + o_ops); job->ops.n = tot.op;
+    job->ow.p = (OwDesc*)(hb + o_ow); job->ow.n = tot.ow;
+    job->win.p = (WinDesc*)(hb + o_win); job->win.n = tot.win;
+    job->tile_win.p = (uint32_t*)(hb + o_tw); job->tile_win.n = tot.tile;
+    job->tile_r0.p = (uint32_t*)(hb + o_tr); job->tile_r0.n = tot.tile;
+    job->h_counts = (uint32_t*)(hb + o_counts);
+  }
+  hpool.run(n_targets, [&](uint32_t t) {
+    TargetOut& o = outs[t];
+    const Base& b = base[t];
+    if (!o.ops.empty()) std::memcpy(job->ops.data() + b.op, o.ops.data(), o.ops.size() * 4);
+    for (size_t i = 0; i < o.ow.size(); i++) {
+      OwDesc d = o.ow[i];
+      d.win += (uint32_t)b.win; d.cls += (uint32_t)b.cls; d.op_begin += (uint32_t)b.op; d.scr_off += (uint32_t)b.scr;
+      job->ow[b.ow + i] = d;
+    }
+    uint64_t fin = b.fin, row = b.row, pos = b.pos, tile = b.tile;
+    for (size_t i = 0; i < o.win.size(); i++) {
+      WinDesc wd = o.win[i];
+      wd.ow_begin += (uint32_t)b.ow;
+      wd.col_off = 0;
+      wd.fin_off = fin; fin += (uint64_t)HERRO_ROWS * wd.lub;
+      wd.row_off = row; row += wd.lub;
+      wd.pos_off = pos; pos += (uint64_t)W + 1;
+      for (uint32_t r0 = 0; r0 < wd.lub; r0 += HERRO_TILE) { job->tile_win[tile] = (uint32_t)(b.win + i); job->tile_r0[tile] = r0; tile++; }
+      job->win[b.win + i] = wd;
+    }
+    o = TargetOut();  // release
+  });
   job->row_elems = row_elems;
+  job->reads_gen = ctx->reads_gen;
 
   auto t_merged = tnow();
   if (ctx->host_only) {  // test hook: the host half (descriptors) only
     job->host_max_cols = max_cols; job->host_n_cls = n_cls; job->host_scr_ops = scr_ops; job->host_fin_bytes = fin_bytes;
+    ctx->live_jobs++;
+    if (prof) {
+      auto ms = [](auto a_, auto b_) { return std::chrono::duration<double, std::milli>(b_ - a_).count(); };
+      fprintf(stderr, "herro_job_create (host half): build %.2f ms, merge %.2f (%zu windows)\n", ms(t_begin, t_built), ms(t_built, t_merged), job->win.size());
+    }
     return job.release();
   }
-  // ---- device allocation + upload
+  // ---- device arena: descriptor block first (same layout as the host arena), then every scratch / result array
   const uint32_t n_ow = (uint32_t)job->ow.size(), n_win = (uint32_t)job->win.size();
   JobDev& J = job->J;
   J.read_words = ctx->d_words; J.read_word_off = ctx->d_word_off; J.read_p0 = ctx->d_p0; J.read_p1 = ctx->d_p1;
@@ -797,77 +949,94 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.n_ow = n_ow; J.n_win = n_win; J.n_cls = n_cls;
   J.n_tiles = (uint32_t)job->tile_win.size(); J.window_size = W; J.n_bw = W / 32 + 1; J.max_cols = max_cols;
   { const char* d = getenv("HERRO_DBG"); J.dbg = d ? (uint32_t)atoi(d) : 0u; }
-  hipError_t e = hipSuccess;
-  bool oom = false;
-  auto A = [&](uint64_t bytes) -> void* {
-    void* p = nullptr;
-    if (hipMalloc(&p, std::max<uint64_t>(bytes, 16)) != hipSuccess) { oom = true; return nullptr; }
-    job->allocs.push_back(p);
-    return p;
+  cur = desc_bytes;
+  const size_t o_op_t = take(scr_ops * 4), o_op_q = take(scr_ops * 4), o_ins_ev = take(scr_ops * 4), o_ins_cnt = take((uint64_t)n_ow * 4);
+  const size_t o_md = take(scr_ops * 16), o_bm = take((uint64_t)n_ow * J.n_bw * 8), o_chdr = take((uint64_t)n_ow * sizeof(ColHdr));
+  const size_t o_keep = take(n_ow), o_acc = take((uint64_t)n_ow * 4), o_ttot = take((uint64_t)n_ow * 4);
+  const size_t o_slot = take((uint64_t)n_ow * 4), o_rqid = take((uint64_t)n_ow * 4), o_sel = take((uint64_t)n_win * 32 * 4);
+  const size_t tplan_bytes = (size_t)J.n_tiles * 32 * 64;
+  const size_t o_tplan = take(tplan_bytes), o_thdr = take((size_t)J.n_tiles * 64), o_dcounts = take((uint64_t)n_win * 12);
+  const size_t o_rop = take(pos_elems * 4), o_rmap = take(row_elems * 4), o_sflag = take(row_elems);
+  const size_t o_cseq = take(row_elems), o_ctmp = take(row_elems), o_clen = take((uint64_t)n_win * 4);
+  const size_t o_srow = take(row_elems * 4), o_spi = take(row_elems * 4);
+  const size_t o_finb = take(fin_bytes), o_finq = take(fin_bytes), o_nd = take((uint64_t)n_cls * 8);
+  const size_t dev_bytes = cur;
+  job->dev = acquire(ctx->free_dev, dev_bytes, true);
+  auto give_back = [&]() {
+    std::lock_guard<std::mutex> lk(ctx->arena_mu);
+    if (job->dev.p) ctx->free_dev.push_back(job->dev);
+    if (job->pin.p) ctx->free_pin.push_back(job->pin);
+    job->dev = Arena{}; job->pin = Arena{};
   };
-  auto up = [&](const void* src, uint64_t bytes) -> void* {
-    void* p = A(bytes);
-    if (p && bytes) e = hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, ctx->stream);
-    return p;
-  };
-  J.ops = (const uint32_t*)up(job->ops.data(), job->ops.size() * 4);
-  J.ow = (const OwDesc*)up(job->ow.data(), job->ow.size() * sizeof(OwDesc));
-  J.win = (const WinDesc*)up(job->win.data(), job->win.size() * sizeof(WinDesc));
-  J.tile_win = (const uint32_t*)up(job->tile_win.data(), job->tile_win.size() * 4);
-  J.tile_r0 = (const uint32_t*)up(job->tile_r0.data(), job->tile_r0.size() * 4);
-  J.op_t = (uint32_t*)A(scr_ops * 4); J.op_q = (uint32_t*)A(scr_ops * 4); J.ins_ev = (uint32_t*)A(scr_ops * 4);
-  J.ins_cnt = (uint32_t*)A((uint64_t)n_ow * 4);
-  J.md = (uint4*)A(scr_ops * 16); J.bm = (uint2*)A((uint64_t)n_ow * J.n_bw * 8); J.chdr = (ColHdr*)A((uint64_t)n_ow * sizeof(ColHdr));
-  J.ow_keep = (uint8_t*)A(n_ow); J.ow_acc = (float*)A((uint64_t)n_ow * 4);
-  J.ow_ttotal = (uint32_t*)A((uint64_t)n_ow * 4);
-  J.slot_ow = (uint32_t*)A((uint64_t)n_ow * 4); J.rank_qid = (uint32_t*)A((uint64_t)n_ow * 4);
-  J.sel_ow = (uint32_t*)A((uint64_t)n_win * 32 * 4);
-  J.tplan = (struct herro::TPlan*)A((uint64_t)J.n_tiles * 32 * 64);
-  J.thdr = (struct herro::TileHdr*)A((uint64_t)J.n_tiles * 64);
-  if (J.tplan) hipMemsetAsync(J.tplan, 0xff, (uint64_t)J.n_tiles * 32 * 64, ctx->stream);  // records of empty tiles are loaded, never used
-  job->d_counts = (uint32_t*)A((uint64_t)n_win * 12);
+  if (!job->dev.p) { give_back(); return fail(HERRO_E_NO_DEVICE, "out of device memory for the job (" + std::to_string(dev_bytes >> 20) + " MiB)"); }
+  unsigned char* db = (unsigned char*)job->dev.p;
+  J.ops = (const uint32_t*)(db + o_ops); J.ow = (const OwDesc*)(db + o_ow); J.win = (const WinDesc*)(db + o_win);
+  J.tile_win = (const uint32_t*)(db + o_tw); J.tile_r0 = (const uint32_t*)(db + o_tr);
+  J.op_t = (uint32_t*)(db + o_op_t); J.op_q = (uint32_t*)(db + o_op_q); J.ins_ev = (uint32_t*)(db + o_ins_ev);
+  J.ins_cnt = (uint32_t*)(db + o_ins_cnt);
+  J.md = (uint4*)(db + o_md); J.bm = (uint2*)(db + o_bm); J.chdr = (ColHdr*)(db + o_chdr);
+  J.ow_keep = (uint8_t*)(db + o_keep); J.ow_acc = (float*)(db + o_acc); J.ow_ttotal = (uint32_t*)(db + o_ttot);
+  J.slot_ow = (uint32_t*)(db + o_slot); J.rank_qid = (uint32_t*)(db + o_rqid); J.sel_ow = (uint32_t*)(db + o_sel);
+  J.tplan = (struct herro::TPlan*)(db + o_tplan); J.thdr = (struct herro::TileHdr*)(db + o_thdr);
+  job->d_counts = (uint32_t*)(db + o_dcounts);
   J.win_Lf = job->d_counts; J.win_nsup = job->d_counts + n_win; J.win_nkept = job->d_counts + 2ull * n_win;
-  J.row_of_pos2 = (uint32_t*)A(pos_elems * 4);
-  J.rowmap2 = (uint32_t*)A(row_elems * 4);
-  J.sup_flag = (uint8_t*)A(row_elems);
-  J.cons_seq = (uint8_t*)A(row_elems); J.cons_tmp = (uint8_t*)A(row_elems); J.cons_len = (uint32_t*)A((uint64_t)n_win * 4);
-  J.sup_row = (uint32_t*)A(row_elems * 4); J.sup_pi = (uint32_t*)A(row_elems * 4);
-  J.fin_b = (uint8_t*)A(fin_bytes); J.fin_q = (uint8_t*)A(fin_bytes);
-  J.nd = (uint32_t*)A((uint64_t)n_cls * 8);
-  if (oom || e != hipSuccess) {
-    free_all(job->allocs);
-    return fail(HERRO_E_NO_DEVICE, oom ? "out of device memory for the job" : hipGetErrorString(e));
-  }
-  auto t_enq = tnow();
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) { free_all(job->allocs); return fail(HERRO_E_NO_DEVICE, "upload failed"); }
-  auto t_up = tnow();
-  if (hipHostMalloc((void**)&job->h_counts, std::max<uint64_t>((uint64_t)n_win * 12, 16), hipHostMallocDefault) != hipSuccess ||
-      hipEventCreateWithFlags(&job->ev_counts, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&job->ev_blob, hipEventDisableTiming) != hipSuccess) {
-    free_all(job->allocs);
-    return fail(HERRO_E_NO_DEVICE, "pinned buffer / event creation failed");
+  J.row_of_pos2 = (uint32_t*)(db + o_rop); J.rowmap2 = (uint32_t*)(db + o_rmap); J.sup_flag = (uint8_t*)(db + o_sflag);
+  J.cons_seq = (uint8_t*)(db + o_cseq); J.cons_tmp = (uint8_t*)(db + o_ctmp); J.cons_len = (uint32_t*)(db + o_clen);
+  J.sup_row = (uint32_t*)(db + o_srow); J.sup_pi = (uint32_t*)(db + o_spi);
+  J.fin_b = (uint8_t*)(db + o_finb); J.fin_q = (uint8_t*)(db + o_finq); J.nd = (uint32_t*)(db + o_nd);
+  // one copy, pinned -> device, asynchronous on the context stream: the kernels of herro_job_featurize queue behind it
+  // in stream order, nobody waits here
+  hipError_t e = hipMemcpyAsync(db, job->pin.p, desc_bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && tplan_bytes) e = hipMemsetAsync(J.tplan, 0xff, tplan_bytes, ctx->stream);  // records of empty tiles are loaded, never used
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&job->ev_counts, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&job->ev_blob, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    (void)hipStreamSynchronize(ctx->stream);
+    if (job->ev_counts) (void)hipEventDestroy(job->ev_counts);
+    if (job->ev_blob) (void)hipEventDestroy(job->ev_blob);
+    give_back();
+    return fail(HERRO_E_NO_DEVICE, std::string("descriptor upload failed: ") + hipGetErrorString(e));
   }
   if (prof) {
-    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    fprintf(stderr, "herro_job_create: build %.1f ms, merge %.1f, alloc+enqueue %.1f, upload sync %.1f, pinned+events %.1f\n", ms(t_begin, t_built),
-            ms(t_built, t_merged), ms(t_merged, t_enq), ms(t_enq, t_up), ms(t_up, tnow()));
+    auto ms = [](auto a_, auto b_) { return std::chrono::duration<double, std::milli>(b_ - a_).count(); };
+    fprintf(stderr, "herro_job_create: build %.2f ms, merge %.2f, arena + enqueue %.2f (%u windows, %zu MiB device)\n", ms(t_begin, t_built),
+            ms(t_built, t_merged), ms(t_merged, tnow()), n_win, dev_bytes >> 20);
   }
+  ctx->live_jobs++;
   return job.release();
+}
+
+int herro_job_skipped(const herro_job* job, uint32_t* n_alignments, uint32_t* n_targets) {
+  if (!job) return HERRO_E_INVALID;
+  if (n_alignments) *n_alignments = job->n_skipped_alns;
+  if (n_targets) *n_targets = job->n_failed_targets;
+  return HERRO_OK;
 }
 
 void herro_job_free(herro_job* job) {
   if (!job) return;
-  if (job->ctx->host_only) { delete job; return; }
-  hipSetDevice(job->ctx->device);
-  hipStreamSynchronize(job->ctx->stream);
-  free_all(job->allocs);
-  if (job->d_info) hipFree(job->d_info);
-  if (job->d_base) hipFree(job->d_base);
-  if (job->d_bdesc) hipFree(job->d_bdesc);
-  if (job->h_counts) hipHostFree(job->h_counts);
-  if (job->ev_counts) hipEventDestroy(job->ev_counts);
-  if (job->ev_blob) hipEventDestroy(job->ev_blob);
-  if (job->d_supoff) hipFree(job->d_supoff);
+  herro_ctx* ctx = job->ctx;
+  if (ctx->live_jobs) ctx->live_jobs--;
+  if (ctx->host_only) {
+    std::lock_guard<std::mutex> lk(ctx->arena_mu);
+    if (job->pin.p) { if (ctx->free_pin.size() < 6) ctx->free_pin.push_back(job->pin); else std::free(job->pin.p); }
+    delete job;
+    return;
+  }
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);   // nothing of this job is in flight once its memory is recycled
+  {
+    std::lock_guard<std::mutex> lk(ctx->arena_mu);
+    // keep a handful of arenas for the next jobs (the bench cycles 2-4 jobs per context); the rest goes back to HIP
+    if (job->dev.p) { if (ctx->free_dev.size() < 6) ctx->free_dev.push_back(job->dev); else (void)hipFree(job->dev.p); }
+    if (job->pin.p) { if (ctx->free_pin.size() < 6) ctx->free_pin.push_back(job->pin); else (void)hipHostFree(job->pin.p); }
+  }
+  if (job->d_info) (void)hipFree(job->d_info);
+  if (job->d_base) (void)hipFree(job->d_base);
+  if (job->d_bdesc) (void)hipFree(job->d_bdesc);
+  if (job->ev_counts) (void)hipEventDestroy(job->ev_counts);
+  if (job->ev_blob) (void)hipEventDestroy(job->ev_blob);
+  if (job->d_supoff) (void)hipFree(job->d_supoff);
   delete job;
 }
 
@@ -876,7 +1045,11 @@ uint32_t herro_job_n_windows(const herro_job* job) { return job ? (uint32_t)job-
 int herro_job_featurize(herro_job* job) {
   if (!job) return HERRO_E_INVALID;
   herro_ctx* ctx = job->ctx;
+  if (job->reads_gen != ctx->reads_gen) { ctx->err = "the read store was replaced (herro_set_reads) after this job was created"; return HERRO_E_STATE; }
   hipSetDevice(ctx->device);
+  // everything derived from a previous pass over this job is stale from here on
+  job->synced = false; job->inferred = false; job->quals_full = false;
+  job->consensus_done = false; job->consensus_on_host = false; job->logits_on_host = false;
   if (job->J.n_win == 0) { job->featurized = true; return HERRO_OK; }
   launch_featurize(job->J, ctx->stream, &ctx->timer);
   HIP_TRY(ctx, hipGetLastError());
@@ -885,9 +1058,6 @@ int herro_job_featurize(herro_job* job) {
   HIP_TRY(ctx, hipMemcpyAsync(job->h_counts, job->d_counts, (uint64_t)job->J.n_win * 12, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(job->ev_counts, ctx->stream));
   job->featurized = true;
-  job->synced = false;
-  job->inferred = false;
-  job->quals_full = false;
   return HERRO_OK;
 }
 
@@ -1178,6 +1348,36 @@ int herro_job_window_logits(herro_job* job, uint32_t w, float* info_logits, floa
   return HERRO_OK;
 }
 
+// corrected bases of every window (device consensus) -> host, once per consensus pass
+static int consensus_to_host(herro_job* job) {
+  herro_ctx* ctx = job->ctx;
+  if (job->consensus_on_host) return HERRO_OK;
+  const uint32_t n = job->J.n_win;
+  job->h_cons_len.resize(n);
+  job->h_cons_seq.resize(job->row_elems);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->timer.collect();
+  if (n) HIP_TRY(ctx, hipMemcpy(job->h_cons_len.data(), job->J.cons_len, n * 4ull, hipMemcpyDeviceToHost));
+  if (job->row_elems) HIP_TRY(ctx, hipMemcpy(job->h_cons_seq.data(), job->J.cons_seq, job->row_elems, hipMemcpyDeviceToHost));
+  job->consensus_on_host = true;
+  return HERRO_OK;
+}
+
+// Brings the corrected bases of the whole job to the host (what crosses PCIe on the way out: ~4 KB per window) and
+// returns their number; herro_job_consensus_fasta afterwards only assembles text.  Requires herro_job_consensus.
+int herro_job_consensus_fetch(herro_job* job, uint64_t* n_bases) {
+  if (!job) return HERRO_E_INVALID;
+  herro_ctx* ctx = job->ctx;
+  if (!job->consensus_done) { ctx->err = "herro_job_consensus has not run"; return HERRO_E_STATE; }
+  (void)hipSetDevice(ctx->device);
+  int rc = consensus_to_host(job);
+  if (rc) return rc;
+  uint64_t tot = 0;
+  for (uint32_t w = 0; w < job->J.n_win; w++) tot += job->h_cons_len[w];
+  if (n_bases) *n_bases = tot;
+  return HERRO_OK;
+}
+
 // consensus.rs:86-227 + lib.rs:282-317 on the host, from device results.
 int64_t herro_job_consensus_fasta(herro_job* job, uint32_t t, const char* id, const char* desc, char* out,
                                   uint64_t cap) {
@@ -1198,16 +1398,7 @@ int64_t herro_job_consensus_fasta(herro_job* job, uint32_t t, const char* id, co
   std::vector<std::string> seqs;
   std::string cur;
   if (job->consensus_done) {  // device consensus: concatenate the windows' corrected bases
-    if (!job->consensus_on_host) {
-      const uint32_t n = job->J.n_win;
-      job->h_cons_len.resize(n);
-      job->h_cons_seq.resize(job->row_elems);
-      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-      ctx->timer.collect();
-      if (n) HIP_TRY(ctx, hipMemcpy(job->h_cons_len.data(), job->J.cons_len, n * 4ull, hipMemcpyDeviceToHost));
-      if (job->row_elems) HIP_TRY(ctx, hipMemcpy(job->h_cons_seq.data(), job->J.cons_seq, job->row_elems, hipMemcpyDeviceToHost));
-      job->consensus_on_host = true;
-    }
+    if ((rc = consensus_to_host(job))) return rc;
     for (uint32_t w = (uint32_t)st; w < (uint32_t)en; w++) {
       if (std::min<uint32_t>(job->h_nkept[w], 30) < 2) {
         if (!cur.empty()) { seqs.push_back(cur); cur.clear(); }

@@ -775,7 +775,7 @@ constexpr int PAR_LN1G = 0, PAR_LN1B = 256, PAR_LN2G = 512, PAR_LN2B = 768, PAR_
 constexpr int PAR_MAX_FF = 2048;                 // d_ff supported by the parameter block
 constexpr int PAR_FLOATS = PAR_BFF1 + PAR_MAX_FF;
 
-template <int TERMS>
+template <int TERMS, bool PARK>
 __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelScratch S) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* s_hh = reinterpret_cast<uint16_t*>(smem);
@@ -821,6 +821,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
   // parked in the tile's own rows of S.x (L2-resident, nobody else touches them) — 32 VGPRs the weight / fragment
   // pipeline needs.  The fetch is issued BEFORE the last GEMM call of a phase, so its latency hides under MFMAs.
   auto park_x = [&]() {
+    if (!PARK) return;
 #pragma unroll
     for (int pt = 0; pt < 4; pt++) {
       const uint32_t tok = pt * 16 + fr;
@@ -832,6 +833,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
     }
   };
   auto fetch_x = [&]() {
+    if (!PARK) return;
 #pragma unroll
     for (int pt = 0; pt < 4; pt++) {
       const uint32_t tok = pt * 16 + fr;
@@ -1179,15 +1181,24 @@ void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S,
   hipLaunchKernelGGL(k_fc_h, dim3((N + FC_TM - 1) / FC_TM), dim3(512), FC_H_SHM, st, S.y2_hi, HERRO_ROWS * h.c2, M.fc, S.x, h.d_model, N);
   KT_END(tm, st);
   // HERRO_LAYERS_V=0 selects the un-pipelined stack (k_layers_h), kept for A/B measurements
-  static const bool pipelined = !(getenv("HERRO_LAYERS_V") && atoi(getenv("HERRO_LAYERS_V")) == 0);
+  static const int variant = getenv("HERRO_LAYERS_V") ? atoi(getenv("HERRO_LAYERS_V")) : 1;
+  const bool pipelined = variant != 0;
   KT_BEGIN(tm, "layers_fused", st);
-  if (pipelined) {
+  if (variant == 2) {  // pipelined, x kept in registers (A/B)
     if (terms == 2) {
-      opt_in_lds(reinterpret_cast<const void*>(k_layers_p<2>), LAYERS_P_SHM);
-      hipLaunchKernelGGL(k_layers_p<2>, dim3(B.n_tiles), dim3(512), LAYERS_P_SHM, st, M, B, S);
+      opt_in_lds(reinterpret_cast<const void*>(k_layers_p<2, false>), LAYERS_P_SHM);
+      hipLaunchKernelGGL((k_layers_p<2, false>), dim3(B.n_tiles), dim3(512), LAYERS_P_SHM, st, M, B, S);
     } else {
-      opt_in_lds(reinterpret_cast<const void*>(k_layers_p<1>), LAYERS_P_SHM);
-      hipLaunchKernelGGL(k_layers_p<1>, dim3(B.n_tiles), dim3(512), LAYERS_P_SHM, st, M, B, S);
+      opt_in_lds(reinterpret_cast<const void*>(k_layers_p<1, false>), LAYERS_P_SHM);
+      hipLaunchKernelGGL((k_layers_p<1, false>), dim3(B.n_tiles), dim3(512), LAYERS_P_SHM, st, M, B, S);
+    }
+  } else if (pipelined) {
+    if (terms == 2) {
+      opt_in_lds(reinterpret_cast<const void*>(k_layers_p<2, true>), LAYERS_P_SHM);
+      hipLaunchKernelGGL((k_layers_p<2, true>), dim3(B.n_tiles), dim3(512), LAYERS_P_SHM, st, M, B, S);
+    } else {
+      opt_in_lds(reinterpret_cast<const void*>(k_layers_p<1, true>), LAYERS_P_SHM);
+      hipLaunchKernelGGL((k_layers_p<1, true>), dim3(B.n_tiles), dim3(512), LAYERS_P_SHM, st, M, B, S);
     }
   } else if (terms == 2) {
     opt_in_lds(reinterpret_cast<const void*>(k_layers_h<2>), LAYERS_H_SHM);

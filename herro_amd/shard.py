@@ -43,3 +43,263 @@ def gather_counts(local: dict[str, int], group=None) -> dict[str, int]:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         t = t.cpu()
     return {k: int(v) for k, v in zip(keys, t.tolist())}
+
+
+# =====================================================================================================================
+# Strong scaling: ONE fixed set of target reads, ingested on rank 0, sharded over the ranks.
+#
+# The reference feeds its per-device replicas from one shared queue (reference lib.rs:154-200), collects per device
+# (consensus.rs:229-263) and writes through one writer (lib.rs:267-291).  Across processes that becomes (BASELINE.json
+# north_star, SURVEY.md §8 e): the read store replicated on every GPU (broadcast once), the window WORK — target ids,
+# PAF rows, CIGARs — scattered from rank 0 by the partition above, the corrected reads gathered back to rank 0 as FASTA
+# text, which rank 0 writes.  RCCL has no scatterv / gatherv: sizes go through one small collective, payloads through
+# grouped point-to-point sends (xGMI is point-to-point anyway).  Nothing is reduced: there is no all-reduce on the path.
+# The payloads are small (~15 KB of descriptors and ~4 KB of corrected bases per window), so they are aggregated: one
+# message per rank for the work, one per rank for the results.
+# =====================================================================================================================
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def _dev(group=None):
+    import torch
+    dist = _dist()
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
+def pack_work(rids, aln_off, rows, cig_off, cig) -> np.ndarray:
+    """One contiguous u8 message: the targets of one shard with their alignments (rows u32 [m, 10], CIGAR blob rebased)."""
+    rids = np.ascontiguousarray(rids, np.uint32)
+    aln_off = np.ascontiguousarray(aln_off, np.uint64)
+    rows = np.ascontiguousarray(rows, np.uint32).reshape(-1, 10)
+    cig_off = np.ascontiguousarray(cig_off, np.uint64)
+    cig = np.ascontiguousarray(cig, np.uint8)
+    hdr = np.array([len(rids), len(rows), len(cig)], np.uint64)
+    parts = [hdr.view(np.uint8), aln_off.view(np.uint8), cig_off.view(np.uint8), rids.view(np.uint8), rows.reshape(-1).view(np.uint8), cig]
+    return np.concatenate(parts)
+
+
+def unpack_work(buf: np.ndarray):
+    buf = np.ascontiguousarray(buf, np.uint8)
+    n, m, c = (int(x) for x in buf[:24].view(np.uint64))
+    o = 24
+    aln_off = buf[o:o + 8 * (n + 1)].view(np.uint64).copy(); o += 8 * (n + 1)
+    cig_off = buf[o:o + 8 * m].view(np.uint64).copy(); o += 8 * m
+    rids = buf[o:o + 4 * n].view(np.uint32).copy(); o += 4 * n
+    rows = buf[o:o + 40 * m].view(np.uint32).reshape(m, 10).copy(); o += 40 * m
+    cig = buf[o:o + c].copy()
+    return rids, aln_off, rows, cig_off, cig
+
+
+def shard_work(sb, targets) -> np.ndarray:
+    """pack_work of the given target indices of a SynthBatch-like object (tgt_rid, tgt_aln_off, aln, cig_off, cig)."""
+    targets = [int(t) for t in targets]
+    a0 = [int(sb.tgt_aln_off[t]) for t in targets]
+    a1 = [int(sb.tgt_aln_off[t + 1]) for t in targets]
+    sel = np.concatenate([np.arange(x, y) for x, y in zip(a0, a1)]).astype(np.int64) if targets else np.zeros(0, np.int64)
+    aln_off = np.zeros(len(targets) + 1, np.uint64)
+    aln_off[1:] = np.cumsum([y - x for x, y in zip(a0, a1)])
+    rows = sb.aln[sel]
+    lens = rows[:, 9].astype(np.uint64) if len(sel) else np.zeros(0, np.uint64)
+    cig_off = np.zeros(len(sel), np.uint64)
+    if len(sel):
+        cig_off[1:] = np.cumsum(lens)[:-1]
+    pieces = [sb.cig[int(sb.cig_off[a]):int(sb.cig_off[a]) + int(l)] for a, l in zip(sel, lens)]
+    cig = np.concatenate(pieces) if pieces else np.zeros(0, np.uint8)
+    return pack_work(sb.tgt_rid[targets], aln_off, rows, cig_off, cig)
+
+
+def _exchange_sizes(sizes_on_root, n_local: int, root_to_all: bool, group=None) -> list[int]:
+    """root_to_all: rank 0 tells every rank the size of its message; else every rank tells rank 0 its size."""
+    import torch
+    dist = _dist()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = _dev(group)
+    if root_to_all:
+        t = torch.tensor(sizes_on_root if rank == 0 else [0] * world, dtype=torch.int64, device=dev)
+        dist.broadcast(t, 0, group=group)
+        return [int(x) for x in t.cpu().tolist()]
+    t = torch.zeros(world, dtype=torch.int64, device=dev)
+    t[rank] = n_local
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)   # world integers: the one collective of the result path
+    return [int(x) for x in t.cpu().tolist()]
+
+
+def scatter_bytes(messages, group=None) -> np.ndarray:
+    """rank 0 holds one u8 message per rank; every rank gets its own.  Sizes by one broadcast, payloads by grouped
+    point-to-point sends (RCCL has no scatterv)."""
+    import torch
+    dist = _dist()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world == 1:
+        return np.ascontiguousarray(messages[0], np.uint8)
+    dev = _dev(group)
+    sizes = _exchange_sizes([len(m) for m in messages] if rank == 0 else None, 0, True, group)
+    if rank == 0:
+        ops, keep = [], []
+        for r in range(1, world):
+            if sizes[r]:
+                t = torch.from_numpy(np.ascontiguousarray(messages[r], np.uint8)).to(dev)
+                keep.append(t)
+                ops.append(dist.P2POp(dist.isend, t, r, group=group))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return np.ascontiguousarray(messages[0], np.uint8)
+    buf = torch.empty(sizes[rank], dtype=torch.uint8, device=dev)
+    if sizes[rank]:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf, 0, group=group)]):
+            w.wait()
+    return buf.cpu().numpy()
+
+
+def gather_bytes(message: bytes, group=None):
+    """every rank contributes one byte string; rank 0 returns the list (others None).  gatherv by grouped send / recv."""
+    import torch
+    dist = _dist()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world == 1:
+        return [bytes(message)]
+    dev = _dev(group)
+    sizes = _exchange_sizes(None, len(message), False, group)
+    if rank == 0:
+        bufs = [None] + [torch.empty(sizes[r], dtype=torch.uint8, device=dev) for r in range(1, world)]
+        ops = [dist.P2POp(dist.irecv, bufs[r], r, group=group) for r in range(1, world) if sizes[r]]
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return [bytes(message)] + [bufs[r].cpu().numpy().tobytes() for r in range(1, world)]
+    if len(message):
+        t = torch.from_numpy(np.frombuffer(message, np.uint8).copy()).to(dev)
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, t, 0, group=group)]):
+            w.wait()
+    return None
+
+
+def broadcast_reads(sb, group=None):
+    """The read store, replicated: rank 0's (seq, qual, off) to every rank (the one bulk transfer, once per data set)."""
+    import torch
+    dist = _dist()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world == 1:
+        return sb.seq, sb.qual, sb.off
+    dev = _dev(group)
+    n = torch.tensor([len(sb.seq), len(sb.off)] if rank == 0 else [0, 0], dtype=torch.int64, device=dev)
+    dist.broadcast(n, 0, group=group)
+    nb, no = (int(x) for x in n.cpu().tolist())
+    out = []
+    for arr, cnt, dt in ((sb.seq if rank == 0 else None, nb, np.uint8), (sb.qual if rank == 0 else None, nb, np.uint8),
+                         (sb.off if rank == 0 else None, no, np.uint64)):
+        t = torch.from_numpy(np.ascontiguousarray(arr, dt).view(np.uint8)).to(dev) if rank == 0 else \
+            torch.empty(cnt * np.dtype(dt).itemsize, dtype=torch.uint8, device=dev)
+        dist.broadcast(t, 0, group=group)
+        out.append(t.cpu().numpy().view(dt))
+    return tuple(out)
+
+
+def correct_sharded(sb, n_windows_per_target, correct_fn, group=None):
+    """The whole multi-GPU data path for one set of targets.  Rank 0 passes `sb` (targets + alignments) and the windows per
+    target; other ranks pass None.  correct_fn(rids, aln_off, rows, cig_off, cig) -> list of (rid, fasta bytes) runs on every
+    rank over its shard.  Returns (on rank 0) the FASTA records of all targets sorted by read id, and this rank's shard size."""
+    dist = _dist()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    msgs = None
+    if rank == 0:
+        parts = partition_targets(n_windows_per_target, world)
+        msgs = [shard_work(sb, p) for p in parts]
+    mine = scatter_bytes(msgs, group) if world > 1 else msgs[0]
+    rids, aln_off, rows, cig_off, cig = unpack_work(mine)
+    recs = correct_fn(rids, aln_off, rows, cig_off, cig)
+    blob = b"".join(int(r).to_bytes(4, "little") + len(f).to_bytes(8, "little") + f for r, f in recs)
+    gathered = gather_bytes(blob, group) if world > 1 else [blob]
+    if rank != 0:
+        return None, len(rids)
+    out = []
+    for g in gathered:
+        o = 0
+        while o < len(g):
+            r = int.from_bytes(g[o:o + 4], "little"); ln = int.from_bytes(g[o + 4:o + 12], "little")
+            out.append((r, g[o + 12:o + 12 + ln])); o += 12 + ln
+    out.sort(key=lambda x: x[0])
+    return b"".join(f for _, f in out), len(rids)
+
+
+def hip_corrector(ctx, window_size: int, batch: int, read_name, group_targets: int = 1024):
+    """correct_fn for correct_sharded on the HIP path: jobs of at most `group_targets` targets, cross-read batches of
+    `batch` windows, device consensus, FASTA text per target."""
+    def fn(rids, aln_off, rows, cig_off, cig):
+        out = []
+        for t0 in range(0, len(rids), group_targets):
+            t1 = min(t0 + group_targets, len(rids))
+            a0, a1 = int(aln_off[t0]), int(aln_off[t1])
+            job = ctx.create_job(rids[t0:t1], rows[a0:a1], aln_off[t0:t1 + 1] - aln_off[t0], None, window_size,
+                                 cig_blob=cig, cig_off=cig_off[a0:a1])
+            job.featurize()
+            job.infer(batch, 1)
+            job.consensus()
+            job.consensus_fetch()
+            for k in range(t1 - t0):
+                out.append((int(rids[t0 + k]), job.consensus_fasta(k, read_name(int(rids[t0 + k]))).encode()))
+            job.close()
+        return out
+    return fn
+
+
+def bench_strong(args, rank: int, world: int, local: int):
+    """bench.py --scaling strong: ONE fixed set of windows (BASELINE configs[3]) sharded over the ranks; rank 0 ingests,
+    scatters the work, gathers the corrected reads and holds the FASTA.  Timed: scatter -> job creation -> featurize ->
+    infer -> consensus -> D2H -> gather, i.e. the whole multi-GPU data path (max over ranks)."""
+    import json
+    import os
+    import time
+    import torch
+    import torch.distributed as dist
+    from herro_amd import api, model_io, synth
+    W, n_ovl, wpt = 4096, 32, 4
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n_windows = args.windows or args.steps * args.batch
+    n_t = max(world, n_windows // wpt)
+    path, _ = model_io.default_model_file(os.path.join(root, "tests", "_cache"))
+    sb = synth.generate_parallel(n_t, wpt * W, n_ovl, seed=synth.SEED + 3) if rank == 0 else None
+    seq, qual, off = broadcast_reads(sb) if world > 1 else (sb.seq, sb.qual, sb.off)
+    ctx = api.Context(local)
+    ctx.load_model(path)
+    ctx.set_precision(args.precision)
+    ctx.set_reads(seq, qual, off)
+    fn = hip_corrector(ctx, W, args.batch, lambda rid: f"read{rid}", group_targets=max(1, args.group * args.batch // wpt))
+    nw = np.full(n_t, wpt, np.int64) if rank == 0 else None
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(1 if args.warmup else 0):        # one untimed pass over the same fixed job
+        correct_sharded(sb, nw, fn)
+    sync()
+    t0 = time.perf_counter()
+    fasta, n_mine = correct_sharded(sb, nw, fn)
+    ctx.synchronize()
+    el = time.perf_counter() - t0
+    sync()
+    if world > 1:
+        tt = torch.tensor([el], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    if rank == 0:
+        n_rec = fasta.count(b">")
+        steps = n_t * wpt // args.batch
+        print(json.dumps({
+            "metric": "4096-bp windows corrected/sec at batch=128", "value": n_t * wpt / el, "unit": "windows/s", "n_gpus": world,
+            "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / max(steps, 1), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": {1: "bf16x3", 4: "f16 (encoder GEMMs: activation hi+lo)", 5: "f16"}.get(args.precision, str(args.precision)),
+            "data": "synthetic (SURVEY §8d generator, seed 0x48455252+3; random-init weights of the assumed architecture)",
+            "config": {"workload": f"ONE fixed job of {n_t * wpt} synthetic 4096-bp windows (32 overlaps each, batch=128) sharded by target read over "
+                                   f"{world} rank(s): rank 0 ingests, scatters the work, gathers the corrected reads (BASELINE configs[3])",
+                       "batch": args.batch, "window": W, "overlaps": n_ovl, "timed": "scatter + herro_job_create + featurize + infer + consensus + "
+                       "D2H + FASTA gather (whole multi-GPU data path, host work included)", "precision": args.precision},
+            "mbases_per_s": (len(fasta) - 16 * n_rec) / el / 1e6, "fasta_records": n_rec, "fasta_bytes": len(fasta),
+            "roofline": {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None,
+                         "note": "per-kernel roofline: run the default (weak) mode; this mode times the sharded data path end to end"}}))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()

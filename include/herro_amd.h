@@ -102,7 +102,9 @@ int herro_set_precision(herro_ctx* ctx, int mode);
 /* ---- job = a set of target reads with their alignments -------------------------------------
  * herro_job_create replaces the front half of `extract_features` (features.rs:326-361): it runs
  * `extract_windows` (windowing.rs:44-273) for every alignment on the host, converts CIGARs to a
- * binary op stream and uploads the descriptors.  Alignments of target t are
+ * binary op stream and uploads the descriptors (one pinned block, one asynchronous copy; job memory is recycled through
+ * per-context arenas, the host work runs on a per-context thread pool of HERRO_HOST_THREADS, default min(cores, 64)).
+ * Alignments of target t are
  * alns[aln_off[t] .. aln_off[t+1]); every alignment must have tid == rids[t] (overlaps.rs:189-192).
  * window_size: the `-w` flag (main.rs:69-74); 16 <= window_size <= 8192 here. */
 herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* rids,
@@ -110,6 +112,12 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
                             uint32_t window_size);
 void herro_job_free(herro_job* job);
 uint32_t herro_job_n_windows(const herro_job* job);
+/* Alignments herro_job_create left out instead of failing the call: what parse_paf itself drops before extract_features
+ * sees it (self overlaps, a second alignment of a (query, target) pair — overlaps.rs:175-185) and CIGARs minimap2 never
+ * emits that the kernels do not model (a window slice starting with an insertion, consecutive insertion ops);
+ * n_targets = targets left without any overlap (> 4000 overlaps in one window).  herro_last_error() describes the first.
+ * Inputs on which the reference panics still make herro_job_create return NULL. */
+int herro_job_skipped(const herro_job* job, uint32_t* n_alignments, uint32_t* n_targets);
 
 /* GPU feature generation for all windows of the job — features.rs:364-580 (filter, accuracy
  * ranking, max-insertion map, pileup scatter, informative positions, haplotype-ratio re-ranking,
@@ -139,6 +147,11 @@ int herro_job_window_logits(herro_job* job, uint32_t w, float* info_logits, floa
  * HBM; herro_job_consensus_fasta then only concatenates windows.  Optional: without it the FASTA call
  * decodes on the host from the planes.  Requires herro_job_infer if any window has informative rows. */
 int herro_job_consensus(herro_job* job);
+
+/* After herro_job_consensus: copy the corrected bases of every window to the host (the only result traffic of the
+ * corrected-reads path, ~4 KB per window) and return how many there are; herro_job_consensus_fasta then only assembles
+ * text.  Optional (the FASTA call fetches on demand). */
+int herro_job_consensus_fetch(herro_job* job, uint64_t* n_bases);
 
 /* Consensus + FASTA text for target t (consensus.rs:86-227, lib.rs:282-317); id/desc are the
  * read's id and optional description (NULL: none).  Returns bytes written (0: read not

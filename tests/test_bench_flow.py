@@ -34,6 +34,11 @@ class FakeJob:
         FakeJob.log.append(("C", id(self)))
         self.state = "done"
 
+    def consensus_fetch(self):
+        assert self.state == "done", "fetch before consensus"
+        FakeJob.log.append(("D", id(self)))
+        return 4000 * self.n_windows
+
     def close(self):
         pass
 
@@ -83,7 +88,7 @@ def test_bench_flow(monkeypatch, capsys, argv, steps):
     monkeypatch.setattr(synth, "generate_parallel", lambda *a, **k: fake_sb)
     monkeypatch.setattr(synth, "generate", lambda *a, **k: fake_sb)
     monkeypatch.setattr(model_io, "default_model_file", lambda d: ("model.bin", None))
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--no-cpu-baseline"] + argv)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--no-cpu-baseline", "--self-check", "0"] + argv)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
     sys.path.insert(0, ROOT)
@@ -100,6 +105,10 @@ def test_bench_flow(monkeypatch, capsys, argv, steps):
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["unit"] == "windows/s" and "workload" in d["config"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+    if d["end_to_end"] is not None:   # job creation + D2H inside the timed region: every end-to-end job fetched its bases once
+        assert d["end_to_end"]["windows_per_s"] > 0 and d["end_to_end"]["windows"] > 0
+        n_fetch = sum(1 for ev, _ in FakeJob.log if ev == "D")
+        assert n_fetch == d["end_to_end"]["jobs_per_feeder"] * d["end_to_end"]["feeders_per_gpu"]
     # every job that ran went featurize -> infer -> consensus, and the timed region covered exactly `steps` batches:
     # windows run in the timed region = steps * batch; count via the log between warm-up and the kernel-timing pass is
     # not separable here, so check the invariant the pipeline relies on instead: no job is inferred twice in a row

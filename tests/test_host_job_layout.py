@@ -115,10 +115,20 @@ def test_rejections_without_a_device():
     rows = sb.aln[int(sb.tgt_aln_off[0]):int(sb.tgt_aln_off[1])].copy()
     cigs = [sb.cigar(a) for a in range(int(sb.tgt_aln_off[0]), int(sb.tgt_aln_off[1]))]
     off = np.array([0, len(rows)], np.uint64)
-    bad = rows.copy(); bad[1, 0] = bad[0, 0]                       # same (query, target) pair twice
-    with pytest.raises(api.HerroError) as e:
-        c.create_job(sb.tgt_rid[:1], bad, off, cigs, 128)
-    assert e.value.code == -4
+    # what parse_paf would have dropped (a second alignment of the same (query, target) pair, a self overlap) is left
+    # out and counted, it no longer fails the job: the descriptors are those of the input without these alignments
+    bad = np.concatenate([rows[:2], rows[:1], rows[2:]]); bad[2, 1:5] = rows[1, 1:5]      # rows[0]'s pair again, in third place
+    selfo = rows[:1].copy(); selfo[0, 0] = selfo[0, 5]                                    # qid == tid
+    bad = np.concatenate([bad, selfo])
+    bad_cigs = cigs[:2] + [cigs[1]] + cigs[2:] + [cigs[0]]
+    off_bad = np.array([0, len(bad)], np.uint64)
+    jb = c.create_job(sb.tgt_rid[:1], bad, off_bad, bad_cigs, 128)
+    jg = c.create_job(sb.tgt_rid[:1], rows, off, cigs, 128)
+    assert jb.skipped() == (2, 0) and jg.skipped() == (0, 0)
+    ab, ag = c.job_arrays(jb), c.job_arrays(jg)
+    for k in ag:
+        assert np.array_equal(ab[k], ag[k]), k
+    jb.close(); jg.close()
     with pytest.raises(api.HerroError) as e:                       # a CIGAR op the reference panics on
         c.create_job(sb.tgt_rid[:1], rows, off, [cigs[0].replace(b"M", b"X", 1)] + cigs[1:], 128)
     assert e.value.code == -3

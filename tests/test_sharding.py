@@ -75,3 +75,74 @@ def test_two_rank_gloo(tmp_path):
         nsup += sum(len(res.window(w).sup_pos) for w in range(len(res)))
     assert got["tot"] == {"windows": nwin, "informative": nsup, "reads": sb.n_targets}
     assert sorted(got["parts"][0] + got["parts"][1]) == list(range(sb.n_targets))
+
+
+WORKER2 = textwrap.dedent("""
+    import os, sys, json, hashlib
+    sys.path.insert(0, {root!r})
+    import numpy as np, torch, torch.distributed as dist
+    from herro_amd import shard, synth
+    world = int(sys.argv[2])
+    if world > 1:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=world)
+    rank = int(sys.argv[1])
+    sb = synth.generate(9, 1400, 7, seed=11, flank_min=30, flank_max=60) if rank == 0 else None   # ONLY rank 0 ingests
+    nw = shard.windows_of((sb.off[1:] - sb.off[:-1])[sb.tgt_rid], 256) if rank == 0 else None
+    if world > 1:                                         # the read store is replicated by broadcast
+        seq, qual, off = shard.broadcast_reads(sb)
+    else:
+        seq, qual, off = sb.seq, sb.qual, sb.off
+
+    def correct(rids, aln_off, rows, cig_off, cig):       # stand-in corrector: a digest of exactly what arrived + the store
+        out = []
+        for k, rid in enumerate(rids):
+            a0, a1 = int(aln_off[k]), int(aln_off[k + 1])
+            h = hashlib.sha1()
+            h.update(rows[a0:a1].tobytes())
+            for a in range(a0, a1):
+                h.update(cig[int(cig_off[a]):int(cig_off[a]) + int(rows[a, 9])].tobytes())
+            h.update(seq[int(off[rid]):int(off[rid + 1])].tobytes()); h.update(qual[int(off[rid]):int(off[rid + 1])].tobytes())
+            out.append((int(rid), (">read%d \\n%s\\n" % (rid, h.hexdigest())).encode()))
+        return out
+    fasta, n_mine = shard.correct_sharded(sb, nw, correct)
+    if rank == 0:
+        print(json.dumps({{"fasta": fasta.decode(), "mine": n_mine}}))
+    if world > 1:
+        dist.destroy_process_group()
+""")
+
+
+def test_scatter_work_gather_fasta_two_ranks(tmp_path):
+    """north_star's only collectives: rank 0 scatters the window work, every rank corrects its shard, the corrected reads are
+    gathered to rank 0.  The gathered FASTA (id-sorted) is byte-identical to the single-rank one; rank 1 never saw the
+    alignments except through the scatter, nor the reads except through the broadcast."""
+    port = 31500 + os.getpid() % 2000
+    script = tmp_path / "worker2.py"
+    script.write_text(WORKER2.format(root=ROOT, port=port))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    import json
+    single = subprocess.run([sys.executable, str(script), "0", "1"], capture_output=True, text=True, env=env, timeout=240)
+    assert single.returncode == 0, single.stderr
+    want = json.loads(single.stdout.strip().splitlines()[-1])
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    got = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert got["fasta"] == want["fasta"] and got["fasta"].count(">") == 9
+    assert 0 < got["mine"] < 9 and want["mine"] == 9
+
+
+def test_work_message_round_trip():
+    from herro_amd import synth
+    sb = synth.generate(5, 900, 6, seed=3, flank_min=20, flank_max=40)
+    msg = shard.shard_work(sb, [4, 1, 2])
+    rids, aln_off, rows, cig_off, cig = shard.unpack_work(msg)
+    assert rids.tolist() == sb.tgt_rid[[4, 1, 2]].tolist() and len(aln_off) == 4
+    k = 0
+    for t in (4, 1, 2):
+        for a in range(int(sb.tgt_aln_off[t]), int(sb.tgt_aln_off[t + 1])):
+            assert rows[k].tolist() == sb.aln[a].tolist()
+            assert cig[int(cig_off[k]):int(cig_off[k]) + int(rows[k, 9])].tobytes() == sb.cigar(a)
+            k += 1
+    assert k == len(rows) == int(aln_off[-1])
