@@ -203,10 +203,20 @@ __global__ __launch_bounds__(NT) void k_ow_stats(JobDev J) {
     carry_m += (uint32_t)(tot_im >> 32);
   }
   const uint32_t t_total = carry_t;
-  // this wave's LDS / global writes are read back below by the same wave
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  // this wave's LDS / global writes are read back below by the same wave.  LDS operations of one wave execute in order, so
+  // for the staged tables a wavefront-scope fence (a compiler barrier, no wait) is enough; only the rare overlap whose ops
+  // did not fit the LDS slots reads op_t / op_q back from GLOBAL memory and has to wait for its stores.  (A workgroup-scope
+  // release here made every wave wait for the acknowledgement of its md / ins_ev stores — a full memory round trip in the
+  // middle of a latency-bound kernel.)
+  if (in_lds) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
   const uint32_t* po = in_lds ? s_op : ops;
   const uint32_t* pt = in_lds ? s_t : op_t;
   const uint32_t* pq = in_lds ? s_q : op_q;
@@ -1104,9 +1114,18 @@ __global__ __launch_bounds__(NT) void k_final_tiles_t(JobDev J) {
   pl0.off = 0; pl0.sbase = 0; pl0.sdir_strand = 0;
   if (sc < HERRO_ROWS - 1) pl0 = J.tplan[(uint64_t)tile * 32 + sc];
   if (th.r0 >= th.Lf || (J.dbg & 16u)) return;
+  if (J.dbg & 32u) {  // phase probe: round trip 1 only (the sink keeps the loads alive)
+    if (pl0.ow == 0x7ffffff1u && pl0.cnt == 0x7ffffff3u) J.sup_flag[th.row_off] = 1;
+    return;
+  }
   // round trip 2: row map entry, rank directory words, op entries, 2-bit words
   TileData d;
   tile_fetch(J, th, pl0, sc, l8, d);
+  if (J.dbg & 64u) {  // phase probe: both round trips, no LDS staging
+    uint32_t acc = d.rm ^ d.vb[0].x ^ d.vb[1].y ^ d.vm[0].x ^ d.vm[1].y ^ d.vm[2].z ^ (uint32_t)d.vw[0] ^ (uint32_t)(d.vw[1] >> 32);
+    if (acc == 0x7ffffff1u && pl0.ow == 0x7ffffff3u) J.sup_flag[th.row_off] = 1;
+    return;
+  }
   const unsigned char* bm_bytes = reinterpret_cast<const unsigned char*>(s_bm);
   const unsigned char* md_bytes = reinterpret_cast<const unsigned char*>(s_md);
   const uint8_t* w_bytes = reinterpret_cast<const uint8_t*>(s_words);
@@ -1207,6 +1226,7 @@ __global__ __launch_bounds__(NT) void k_final_tiles_t(JobDev J) {
           cnt += (f < 5u ? 1u : 0u) << (6u * min(f, 4u));
         }
       }
+      uint32_t sup_v = 0, cons_v = 0;   // stored after the last barrier (see below)
       if (valid) {
         uint32_t c5[5];
 #pragma unroll
@@ -1216,7 +1236,7 @@ __global__ __launch_bounds__(NT) void k_final_tiles_t(JobDev J) {
         uint32_t ns = 0;
 #pragma unroll
         for (int q = 0; q < 5; q++) ns += c5[q] >= thresh ? 1u : 0u;
-        J.sup_flag[th.row_off + r] = ns >= 2 ? 1 : 0;
+        sup_v = ns >= 2 ? 1u : 0u;
         // majority vote of the consensus decoder (consensus.rs:178-200), see k_final_tiles
         uint32_t c0 = c5[0], i0 = 0;
 #pragma unroll
@@ -1227,9 +1247,16 @@ __global__ __launch_bounds__(NT) void k_final_tiles_t(JobDev J) {
         for (uint32_t q = 0; q < 5; q++)
           if (q != i0 && (!have || c5[q] > c1)) { c1 = c5[q]; i1 = q; have = true; }
         const uint32_t tb0 = t0tok;
-        J.cons_tmp[th.row_off + r] = (uint8_t)((c0 < 2u || (c0 == c1 && (i0 == tb0 || i1 == tb0))) ? tb0 : i0);
+        cons_v = (c0 < 2u || (c0 == c1 && (i0 == tb0 || i1 == tb0))) ? tb0 : i0;
       }
       __syncthreads();
+      // the two per-row bytes go out only now: a global store issued BEFORE the barrier has to be acknowledged before the
+      // workgroup may pass it (__syncthreads drains vmcnt), which put one more memory round trip into every tile's life —
+      // the phase probes (HERRO_DBG) showed 271 us per 4096 windows between the end of the fetch and the plane stores
+      if (valid) {
+        J.sup_flag[th.row_off + r] = (uint8_t)sup_v;
+        J.cons_tmp[th.row_off + r] = (uint8_t)cons_v;
+      }
       const uint32_t nseg = (min(th.lub - th.r0, (uint32_t)HERRO_TILE) + 15) / 16;
       for (uint32_t it = threadIdx.x; it < ((J.dbg & 4u) ? 0u : HERRO_ROWS * nseg); it += NT) {
         const uint32_t c = it / nseg, sg = it % nseg;
@@ -1294,6 +1321,12 @@ __global__ __launch_bounds__(NT) void k_rf_quals(JobDev J, uint32_t half) {
   }
   const uint64_t tq_off = J.read_qual_off[wd.rid] + wd.tstart;
   const uint32_t kper = max(1u, RCAP / span);  // informative rows per pass
+  __shared__ uint32_t s_csafe;
+  if (threadIdx.x == 0) s_csafe = 0;
+  __syncthreads();
+  if (threadIdx.x >= 1 && threadIdx.x < HERRO_ROWS && s_ow[threadIdx.x] != 0xffffffffu) atomicMax(&s_csafe, threadIdx.x);
+  __syncthreads();
+  const uint32_t c_safe = s_csafe;   // 0: the window has no selected column at all
   for (uint32_t k0 = 0; k0 < nsup; k0 += kper) {
     const uint32_t nk = min(kper, nsup - k0), nrows = nk * span;
     __syncthreads();
@@ -1304,21 +1337,82 @@ __global__ __launch_bounds__(NT) void k_rf_quals(JobDev J, uint32_t half) {
       s_rm[i] = in ? rowmap[r] : 0xffffffffu;
     }
     __syncthreads();
-    // neighbouring lanes: the rows of one receptive field in one column (same header, same ops, adjacent bytes)
+    // neighbouring lanes: the rows of one receptive field in one column (same header, same ops, adjacent bytes).
+    // Four cells per thread and iteration, branch-free: a cell is a chain of four dependent loads (rank directory ->
+    // op entry -> 2-bit word / quality byte); one cell at a time, a thread paid that chain ~9 times in sequence (180 us
+    // per 4096 windows for 9.5 M cells).  Cells that do not exist (outside the window, padding columns, the target
+    // column) run the chain on a safe stand-in column and drop the result.
     const uint32_t total = nrows * HERRO_ROWS;
-    for (uint32_t idx = threadIdx.x; idx < total; idx += NT) {
-      const uint32_t k = idx / (span * HERRO_ROWS), rem = idx % (span * HERRO_ROWS), c = rem / span, d = rem % span;
-      const uint32_t rm = s_rm[k * span + d];
-      if (rm == 0xffffffffu) continue;
-      const int32_t p = (int32_t)(rm & 0xffffu);
-      const uint32_t j = rm >> 16;
-      uint32_t q = 33;
-      if (c == 0) {
-        if (j == 0) q = J.read_qual[tq_off + (uint32_t)p];
-      } else if (s_ow[c] != 0xffffffffu) {
-        q = column_cell<true>(J, s_h[c], s_ow[c], p, j).qual;
+    if (c_safe == 0) {   // block-uniform: no overlap column at all — target column from the store, '!' everywhere else
+      for (uint32_t idx = threadIdx.x; idx < total; idx += NT) {
+        const uint32_t k = idx / (span * HERRO_ROWS), rem = idx % (span * HERRO_ROWS), c = rem / span, d = rem % span;
+        const uint32_t rm = s_rm[k * span + d];
+        if (rm == 0xffffffffu) continue;
+        const uint32_t q = (c == 0 && (rm >> 16) == 0) ? (uint32_t)J.read_qual[tq_off + (rm & 0xffffu)] : 33u;
+        J.fin_q[wd.fin_off + (uint64_t)c * wd.lub + s_r[k * span + d]] = (uint8_t)q;
       }
-      J.fin_q[wd.fin_off + (uint64_t)c * wd.lub + s_r[k * span + d]] = (uint8_t)q;
+      continue;
+    }
+    for (uint32_t idx0 = threadIdx.x; idx0 < total; idx0 += NT * 4) {
+      // phase A: the four cells (LDS only)
+      bool in[4], col[4];
+      int32_t p[4];
+      uint32_t j[4], cidx[4], uu[4], ow[4];
+      bool inr[4];
+      uint64_t dst[4];
+      ColHdr h[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t idx = idx0 + u * NT;
+        const bool live = idx < total;
+        const uint32_t ic = live ? idx : 0u;
+        const uint32_t k = ic / (span * HERRO_ROWS), rem = ic % (span * HERRO_ROWS), c = rem / span, d = rem % span;
+        const uint32_t rm = s_rm[k * span + d];
+        in[u] = live && rm != 0xffffffffu;
+        p[u] = in[u] ? (int32_t)(rm & 0xffffu) : 0;
+        j[u] = in[u] ? rm >> 16 : 0u;
+        cidx[u] = c;
+        col[u] = in[u] && c != 0 && s_ow[c] != 0xffffffffu;
+        const uint32_t cc = col[u] ? c : c_safe;   // c_safe >= 1 here: a selected column of this window stands in
+        h[u] = s_h[cc];
+        ow[u] = s_ow[cc];
+        const uint32_t uu_raw = (uint32_t)(p[u] - h[u].off);
+        inr[u] = uu_raw < h[u].t_total;
+        uu[u] = inr[u] ? uu_raw : 0u;
+        dst[u] = wd.fin_off + (uint64_t)c * wd.lub + s_r[k * span + d];
+      }
+      // phase B: rank directory words — four independent loads in flight (see column_cell for the arithmetic)
+      uint2 bw[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) bw[u] = J.bm[(uint64_t)ow[u] * J.n_bw + (uu[u] >> 5)];
+      // phase C: op entries
+      uint4 e[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t rank = bw[u].y + __popc(bw[u].x & (0xffffffffu >> (31u - (uu[u] & 31u))));
+        e[u] = J.md[h[u].md_off + (inr[u] && h[u].t_total ? rank - 1u : 0u)];
+      }
+      // phase D: quality bytes (query cell) and the target's quality byte
+      uint32_t qq[4], tq[4];
+      bool isbase[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const bool is_m = (e[u].z >> 31) != 0;
+        const uint32_t len = e[u].z & 0x7fffffffu;
+        const bool last = (uu[u] + 1u == e[u].x + len);
+        isbase[u] = inr[u] && (j[u] == 0 ? is_m : (last && e[u].w >= j[u]));
+        const uint32_t q = j[u] == 0 ? e[u].y + (uu[u] - e[u].x) : e[u].y + (is_m ? len : 0u) + (j[u] - 1u);
+        const uint32_t si = isbase[u] ? (uint32_t)(h[u].sbase + h[u].sdir * (int32_t)q) : 0u;
+        qq[u] = J.read_qual[h[u].qual_off + si];
+        tq[u] = J.read_qual[tq_off + (uint32_t)p[u]];   // in range for every position of the window
+      }
+      // phase E: select and store
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        uint32_t q = (col[u] && isbase[u]) ? qq[u] : 33u;
+        if (cidx[u] == 0 && j[u] == 0) q = tq[u];
+        if (in[u]) J.fin_q[dst[u]] = (uint8_t)q;
+      }
     }
   }
 }

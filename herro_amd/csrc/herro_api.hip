@@ -136,7 +136,7 @@ struct herro_ctx {
   // cost 36 hipMallocs + a hipHostMalloc, ~4 ms per 4096 windows, and its descriptors went up from pageable memory)
   std::unique_ptr<HostPool> pool;
   std::mutex arena_mu;
-  std::vector<Arena> free_dev, free_pin;
+  std::vector<Arena> free_dev, free_pin, free_small;   // free_small: the buffers a job needs only once its counts are known (logits, batch descriptors)
   uint32_t live_jobs = 0;
   uint64_t reads_gen = 0;   // bumped by herro_set_reads: a job built on an older store refuses to run
 };
@@ -189,8 +189,9 @@ struct herro_job {
   // host copies after sync
   std::vector<uint32_t> h_Lf, h_nsup, h_nkept;
   std::vector<uint64_t> sup_off;  // [n_win+1] prefix of nsup
-  float* d_info = nullptr;
+  float* d_info = nullptr;   // inside a_logits
   float* d_base = nullptr;
+  Arena a_logits{}, a_bdesc{}, a_supoff{};
   std::vector<float> h_info, h_base;
   bool logits_on_host = false;
   std::vector<BatchPlan> batches;
@@ -221,6 +222,28 @@ static HostPool& host_pool(herro_ctx* ctx) {
     ctx->pool = std::make_unique<HostPool>(want - 1);  // the calling thread works too
   }
   return *ctx->pool;
+}
+
+// late, small device buffers of a job (sized by results): recycled per context like the arenas — hipMalloc / hipFree
+// synchronise the whole device, which would serialise the feeder threads of a GPU on every job
+static Arena small_acquire(herro_ctx* ctx, size_t need) {
+  {
+    std::lock_guard<std::mutex> lk(ctx->arena_mu);
+    size_t best = ctx->free_small.size();
+    for (size_t i = 0; i < ctx->free_small.size(); i++)
+      if (ctx->free_small[i].cap >= need && (best == ctx->free_small.size() || ctx->free_small[i].cap < ctx->free_small[best].cap)) best = i;
+    if (best != ctx->free_small.size()) { Arena a = ctx->free_small[best]; ctx->free_small.erase(ctx->free_small.begin() + best); return a; }
+  }
+  Arena a;
+  a.cap = need + need / 4 + 4096;
+  if (hipMalloc(&a.p, a.cap) != hipSuccess) { a.p = nullptr; a.cap = 0; }
+  return a;
+}
+static void small_release(herro_ctx* ctx, Arena& a) {
+  if (!a.p) return;
+  std::lock_guard<std::mutex> lk(ctx->arena_mu);
+  if (ctx->free_small.size() < 24) ctx->free_small.push_back(a); else (void)hipFree(a.p);
+  a = Arena{};
 }
 
 // Tiles of whole windows for the fused transformer stack: consecutive windows packed greedily into at
@@ -297,6 +320,7 @@ void herro_destroy(herro_ctx* ctx) {
   free_all(ctx->scratch_allocs);
   for (Arena& a : ctx->free_dev) (void)hipFree(a.p);
   for (Arena& a : ctx->free_pin) (void)hipHostFree(a.p);
+  for (Arena& a : ctx->free_small) (void)hipFree(a.p);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -1031,12 +1055,11 @@ void herro_job_free(herro_job* job) {
     if (job->dev.p) { if (ctx->free_dev.size() < 6) ctx->free_dev.push_back(job->dev); else (void)hipFree(job->dev.p); }
     if (job->pin.p) { if (ctx->free_pin.size() < 6) ctx->free_pin.push_back(job->pin); else (void)hipHostFree(job->pin.p); }
   }
-  if (job->d_info) (void)hipFree(job->d_info);
-  if (job->d_base) (void)hipFree(job->d_base);
-  if (job->d_bdesc) (void)hipFree(job->d_bdesc);
+  small_release(ctx, job->a_logits);
+  small_release(ctx, job->a_bdesc);
+  small_release(ctx, job->a_supoff);
   if (job->ev_counts) (void)hipEventDestroy(job->ev_counts);
   if (job->ev_blob) (void)hipEventDestroy(job->ev_blob);
-  if (job->d_supoff) (void)hipFree(job->d_supoff);
   delete job;
 }
 
@@ -1095,10 +1118,12 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   const uint32_t n = job->J.n_win;
   const uint64_t total_sup = job->sup_off[n];
   if (!job->d_info || job->logit_cap < total_sup) {
-    if (job->d_info) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); hipFree(job->d_info); hipFree(job->d_base); job->d_info = job->d_base = nullptr; }
+    if (job->d_info) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); small_release(ctx, job->a_logits); job->d_info = job->d_base = nullptr; }
     job->logit_cap = std::max<uint64_t>(total_sup + total_sup / 8, 1);
-    HIP_TRY(ctx, hipMalloc((void**)&job->d_info, job->logit_cap * 4));
-    HIP_TRY(ctx, hipMalloc((void**)&job->d_base, job->logit_cap * 20));
+    job->a_logits = small_acquire(ctx, job->logit_cap * 24 + 256);
+    if (!job->a_logits.p) { ctx->err = "out of device memory for the logits"; return HERRO_E_NO_DEVICE; }
+    job->d_info = (float*)job->a_logits.p;
+    job->d_base = (float*)((unsigned char*)job->a_logits.p + ((job->logit_cap * 4 + 255) & ~(uint64_t)255));
   }
   // ---- plan batches (prepare_examples, inference.rs:241-250; flush rule features.rs:884-893)
   job->batches.clear();
@@ -1190,9 +1215,11 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   }
   const size_t supoff_at = put(job->sup_off.data(), ((size_t)n + 1) * 8);  // consensus reads it from the same blob
   if (job->bdesc_cap < blob.size()) {
-    if (job->d_bdesc) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(job->d_bdesc)); job->d_bdesc = nullptr; }
-    job->bdesc_cap = blob.size() + blob.size() / 4 + 4096;
-    HIP_TRY(ctx, hipMalloc(&job->d_bdesc, job->bdesc_cap));
+    if (job->d_bdesc) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); small_release(ctx, job->a_bdesc); job->d_bdesc = nullptr; }
+    job->a_bdesc = small_acquire(ctx, blob.size() + blob.size() / 4 + 4096);
+    if (!job->a_bdesc.p) { ctx->err = "out of device memory for the batch descriptors"; return HERRO_E_NO_DEVICE; }
+    job->d_bdesc = job->a_bdesc.p;
+    job->bdesc_cap = job->a_bdesc.cap;
   }
   HIP_TRY(ctx, hipMemcpyAsync(job->d_bdesc, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(job->ev_blob, ctx->stream));
@@ -1235,10 +1262,16 @@ int herro_job_consensus(herro_job* job) {
   if (job->sup_off.back() > 0 && !job->inferred) { ctx->err = "herro_job_infer has not run"; return HERRO_E_STATE; }
   const uint64_t* d_so = job->d_supoff_blob;
   if (!job->inferred || !d_so) {  // nothing informative anywhere: infer never ran for this job
-    if (!job->d_supoff) HIP_TRY(ctx, hipMalloc((void**)&job->d_supoff, std::max<uint64_t>(n, 1) * 8));
+    if (!job->d_supoff) {
+      job->a_supoff = small_acquire(ctx, std::max<uint64_t>(n, 1) * 8);
+      if (!job->a_supoff.p) { ctx->err = "out of device memory"; return HERRO_E_NO_DEVICE; }
+      job->d_supoff = (uint64_t*)job->a_supoff.p;
+    }
     if (!job->d_base) {  // a dummy logits buffer
-      HIP_TRY(ctx, hipMalloc((void**)&job->d_info, 4));
-      HIP_TRY(ctx, hipMalloc((void**)&job->d_base, 20));
+      job->a_logits = small_acquire(ctx, 512);
+      if (!job->a_logits.p) { ctx->err = "out of device memory"; return HERRO_E_NO_DEVICE; }
+      job->d_info = (float*)job->a_logits.p;
+      job->d_base = (float*)((unsigned char*)job->a_logits.p + 256);
       job->logit_cap = 1;
     }
     if (n) HIP_TRY(ctx, hipMemcpyAsync(job->d_supoff, job->sup_off.data(), n * 8ull, hipMemcpyHostToDevice, ctx->stream));
