@@ -413,6 +413,34 @@ class Paf:
         self.close()
 
 
+class PreparedAlignments:
+    """All alignments of a data set as ONE herro_alignment array, grouped by target — what a host holds after parsing its
+    PAF / .oec.zst input (the reference's reader thread hands `(tid, Vec<Alignment>)` to the feature threads,
+    lib.rs:141-151).  Jobs over target ranges are then pure C calls: no per-job packing on the Python side."""
+
+    def __init__(self, sb):
+        n = len(sb.aln)
+        self.rids = np.ascontiguousarray(sb.tgt_rid, np.uint32)
+        self.aln_off = np.ascontiguousarray(sb.tgt_aln_off, np.uint64)
+        self._cig = np.ascontiguousarray(sb.cig, np.uint8)
+        self._arr = (Alignment * max(n, 1))()
+        view = np.frombuffer(self._arr, dtype=np.dtype([("f", np.uint32, 10), ("p", np.uint64)], align=True), count=max(n, 1))
+        if n:
+            view["f"][:n, :10] = sb.aln[:, :10]
+            view["p"][:n] = self._cig.ctypes.data + np.asarray(sb.cig_off, np.uint64)
+        self.n_targets = len(self.rids)
+
+    def job(self, ctx: "Context", t0: int, t1: int, window_size: int) -> "Job":
+        """herro_job_create over targets [t0, t1): rids / aln_off are passed as offsets into the resident arrays"""
+        h = ctx._l.herro_job_create(ctx.h, t1 - t0, self.rids.ctypes.data + 4 * t0, self.aln_off.ctypes.data + 8 * t0,
+                                    C.byref(self._arr), window_size)
+        if not h:
+            msg = ctx._l.herro_last_error(ctx.h).decode()
+            code = int(msg.rsplit("[code ", 1)[1].rstrip("]")) if "[code " in msg else -1
+            raise HerroError(code, msg)
+        return Job(ctx, h, t1 - t0)
+
+
 def job_from_synth(ctx: Context, sb, window_size: int, targets=None) -> Job:
     """Job over targets of a SynthBatch (all by default)."""
     ts = list(range(sb.n_targets)) if targets is None else list(targets)

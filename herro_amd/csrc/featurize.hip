@@ -478,8 +478,9 @@ __device__ __forceinline__ void count_sym(uint64_t& c, uint32_t folded);
 // LDS staging for k_pass1_pos: PG columns at a time, each with its rank directory, op table and the
 // bit planes of the query stretch the overlap-window covers.
 static constexpr int PG = 4;   // columns staged per pass (8 measured 1.7x slower: 42 KB of LDS, 3 workgroups per CU)
-static constexpr int MDCAP = 176;  // M/D ops per column   (typical: ~100)
-static constexpr int PWCAP = 168;  // plane words per column (typical: ~150 for a 4096-bp window)
+static constexpr int MDCAP = 168;  // M/D ops per column   (typical: ~100)
+static constexpr int PWCAP = 160;  // plane words per column (typical: ~150 for a 4096-bp window)
+static constexpr int HCAP = 32;    // column headers resident in LDS at a time (a multiple of PG; typical windows keep <= 32 overlaps)
 
 struct PCol {
   ColHdr h;
@@ -498,7 +499,8 @@ template <int NB>
 __global__ __launch_bounds__(NT) void k_pass1_pos(JobDev J) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   PCol* pc = reinterpret_cast<PCol*>(smem);
-  uint4* s_md = reinterpret_cast<uint4*>(pc + PG);
+  PCol* s_hdr = pc + PG;                       // headers of the first HCAP kept columns, fetched once per window
+  uint4* s_md = reinterpret_cast<uint4*>(s_hdr + HCAP);
   uint2* s_bm = reinterpret_cast<uint2*>(s_md + PG * MDCAP);
   uint32_t* s_p0 = reinterpret_cast<uint32_t*>(s_bm + PG * J.n_bw);
   uint32_t* s_p1 = s_p0 + PG * PWCAP;
@@ -553,41 +555,62 @@ __global__ __launch_bounds__(NT) void k_pass1_pos(JobDev J) {
     }
     return out;
   };
-  auto stage = [&](uint32_t g0, uint32_t ng) {
-    __syncthreads();
-    if (threadIdx.x < ng) {
-      PCol c;
-      c.ow = slots[g0 + threadIdx.x];
-      c.h = J.chdr[c.ow];
-      const OwDesc& d = J.ow[c.ow];
-      c.pw0 = d.qbeg >> 5;
-      const uint32_t npw = ((d.qbeg + d.qlen) >> 5) - c.pw0 + 2;  // +1 for the funnel shift's second word
-      c.fb = (c.h.n_md > MDCAP || npw > PWCAP) ? 1u : 0u;
-      c.pad = 0;
-      pc[threadIdx.x] = c;
-    }
-    __syncthreads();
-    for (uint32_t idx = threadIdx.x; idx < ng * MDCAP; idx += NT) {
-      const uint32_t ci = idx / MDCAP, i = idx % MDCAP;
-      const PCol& c = pc[ci];
-      if (!c.fb && i < c.h.n_md) s_md[idx] = J.md[c.h.md_off + i];
-    }
-    for (uint32_t idx = threadIdx.x; idx < ng * J.n_bw; idx += NT) {
-      const uint32_t ci = idx / J.n_bw, i = idx % J.n_bw;
-      s_bm[idx] = J.bm[(uint64_t)pc[ci].ow * J.n_bw + i];
-    }
-    for (uint32_t idx = threadIdx.x; idx < ng * PWCAP; idx += NT) {
-      const uint32_t ci = idx / PWCAP, i = idx % PWCAP;
-      const PCol& c = pc[ci];
-      uint32_t a = 0, b = 0;
-      if (!c.fb && c.h.q_woff + c.pw0 + i < J.read_n_words + 2) {
-        a = J.read_p0[c.h.q_woff + c.pw0 + i];
-        b = J.read_p1[c.h.q_woff + c.pw0 + i];
+  // ---- staging.  The first version fetched, for every group of PG columns, the column headers (slot -> header -> overlap
+  // descriptor: three dependent loads), then the tables, with barriers in between: four exposed memory round trips per
+  // group, eight groups per window, ~165 us in the life of a workgroup.  Now the headers of (up to HCAP) kept columns are
+  // fetched ONCE per window, and the tables of group g+1 travel global -> registers while group g is being counted; a
+  // group costs two barriers and no exposed round trip.
+  auto load_hdr = [&](uint32_t slot) -> PCol {
+    PCol c;
+    c.ow = slots[slot];
+    c.h = J.chdr[c.ow];
+    const OwDesc& d = J.ow[c.ow];
+    c.pw0 = d.qbeg >> 5;
+    const uint32_t npw = ((d.qbeg + d.qlen) >> 5) - c.pw0 + 2;  // +1 for the funnel shift's second word
+    c.fb = (c.h.n_md > MDCAP || npw > PWCAP) ? 1u : 0u;
+    c.pad = 0;
+    return c;
+  };
+  // s_hdr holds the headers of kept columns [hbase, hbase + HCAP); refilled (barriers by the caller) every HCAP columns
+  auto fill_hdr = [&](uint32_t hbase) {
+    const uint32_t n_h = min(n_kept - hbase, (uint32_t)HCAP);
+    for (uint32_t i = threadIdx.x; i < n_h; i += NT) s_hdr[i] = load_hdr(hbase + i);
+  };
+  auto hdr_of = [&](uint32_t slot) -> const PCol& { return s_hdr[slot % HCAP]; };   // slot inside the resident chunk
+  // per-thread share of a group's tables: thread t takes entry t of every table of every column of the group (the
+  // tables are shorter than the workgroup: MDCAP, PWCAP <= NT; the rank directory has W / 32 + 1 <= 2 * NT words) — no
+  // index arithmetic, the column header is uniform per load
+  struct Regs { uint4 md[PG]; uint2 bm[PG][2]; uint32_t p0[PG], p1[PG]; };
+  static_assert(MDCAP <= NT && PWCAP <= NT && HERRO_MAX_WINDOW / 32 + 1 <= 2 * NT, "one table entry per thread and column");
+  const uint32_t t_ = threadIdx.x;
+  auto prefetch = [&](uint32_t g0, uint32_t ng, Regs& r) {
+#pragma unroll
+    for (int ci = 0; ci < PG; ci++) {
+      r.md[ci] = make_uint4(0, 0, 0, 0); r.bm[ci][0] = make_uint2(0, 0); r.bm[ci][1] = make_uint2(0, 0); r.p0[ci] = 0; r.p1[ci] = 0;
+      if ((uint32_t)ci < ng) {
+        const PCol& c = hdr_of(g0 + ci);
+        if (!c.fb && t_ < c.h.n_md) r.md[ci] = J.md[c.h.md_off + t_];
+        const uint2* bmp = J.bm + (uint64_t)c.ow * J.n_bw;
+        if (t_ < J.n_bw) r.bm[ci][0] = bmp[t_];
+        if (t_ + NT < J.n_bw) r.bm[ci][1] = bmp[t_ + NT];
+        if (!c.fb && t_ < PWCAP && c.h.q_woff + c.pw0 + t_ < J.read_n_words + 2) {
+          r.p0[ci] = J.read_p0[c.h.q_woff + c.pw0 + t_];
+          r.p1[ci] = J.read_p1[c.h.q_woff + c.pw0 + t_];
+        }
       }
-      s_p0[idx] = a;
-      s_p1[idx] = b;
     }
-    __syncthreads();
+  };
+  auto commit = [&](uint32_t g0, uint32_t ng, const Regs& r) {   // registers -> LDS; barriers by the caller
+    if (t_ < ng) pc[t_] = hdr_of(g0 + t_);
+#pragma unroll
+    for (int ci = 0; ci < PG; ci++) {
+      if ((uint32_t)ci < ng) {
+        if (t_ < MDCAP) s_md[ci * MDCAP + t_] = r.md[ci];
+        if (t_ < J.n_bw) s_bm[ci * J.n_bw + t_] = r.bm[ci][0];
+        if (t_ + NT < J.n_bw) s_bm[ci * J.n_bw + t_ + NT] = r.bm[ci][1];
+        if (t_ < PWCAP) { s_p0[ci * PWCAP + t_] = r.p0[ci]; s_p1[ci * PWCAP + t_] = r.p1[ci]; }
+      }
+    }
   };
 
   for (uint32_t base = 0; base < wd.win_len; base += NT * 16u) {  // wave-uniform trip count (shuffles below)
@@ -599,9 +622,19 @@ __global__ __launch_bounds__(NT) void k_pass1_pos(JobDev J) {
     SlicedCounters<NB> cnt;
     cnt.clear();
     cnt.add(ColPlanes{vmask, tlo, thi, 0u});  // the target column: always a base on these rows
+    Regs rg;
     for (uint32_t g0 = 0; g0 < n_kept; g0 += PG) {
       const uint32_t ng = min((uint32_t)PG, n_kept - g0);
-      stage(g0, ng);
+      if (g0 % HCAP == 0) {     // first group of a header chunk (for <= 32 kept overlaps: once per window)
+        __syncthreads();        // nobody reads the previous chunk's headers any more
+        fill_hdr(g0);
+        __syncthreads();
+        prefetch(g0, ng, rg);
+      }
+      __syncthreads();          // everybody is done with the previous group's tables (and with the tally scratch below)
+      commit(g0, ng, rg);
+      __syncthreads();
+      if (g0 + PG < n_kept && (g0 + PG) % HCAP != 0) prefetch(g0 + PG, min((uint32_t)PG, n_kept - g0 - PG), rg);   // in flight under the counting
       for (uint32_t ci = 0; ci < ng; ci++) {
         ColPlanes cp = act ? staged_planes(ci, P) : ColPlanes{0u, 0u, 0u, 0u};
         cp.m &= vmask; cp.gap &= vmask;
@@ -1226,7 +1259,7 @@ __global__ __launch_bounds__(NT) void k_final_tiles_t(JobDev J) {
           cnt += (f < 5u ? 1u : 0u) << (6u * min(f, 4u));
         }
       }
-      uint32_t sup_v = 0, cons_v = 0;   // stored after the last barrier (see below)
+      uint32_t sup_v = 0, cons_v = 0;
       if (valid) {
         uint32_t c5[5];
 #pragma unroll
@@ -1249,14 +1282,13 @@ __global__ __launch_bounds__(NT) void k_final_tiles_t(JobDev J) {
         const uint32_t tb0 = t0tok;
         cons_v = (c0 < 2u || (c0 == c1 && (i0 == tb0 || i1 == tb0))) ? tb0 : i0;
       }
-      __syncthreads();
-      // the two per-row bytes go out only now: a global store issued BEFORE the barrier has to be acknowledged before the
-      // workgroup may pass it (__syncthreads drains vmcnt), which put one more memory round trip into every tile's life —
-      // the phase probes (HERRO_DBG) showed 271 us per 4096 windows between the end of the fetch and the plane stores
+      // (measured: holding these two bytes back until after the barrier below — so that the barrier does not have to wait
+      // for their acknowledgement — made the kernel 9 % SLOWER, 941 -> 1030 us per 4096 windows: early stores overlap the wait)
       if (valid) {
         J.sup_flag[th.row_off + r] = (uint8_t)sup_v;
         J.cons_tmp[th.row_off + r] = (uint8_t)cons_v;
       }
+      __syncthreads();
       const uint32_t nseg = (min(th.lub - th.r0, (uint32_t)HERRO_TILE) + 15) / 16;
       for (uint32_t it = threadIdx.x; it < ((J.dbg & 4u) ? 0u : HERRO_ROWS * nseg); it += NT) {
         const uint32_t c = it / nseg, sg = it % nseg;
@@ -1496,7 +1528,7 @@ void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm) {
   KT_END(tm, st);
   KT_BEGIN(tm, "pass1_pos", st);
   {
-    const size_t shm = PG * sizeof(PCol) + (size_t)PG * MDCAP * 16 + (size_t)PG * J.n_bw * 8 + (size_t)PG * PWCAP * 8;
+    const size_t shm = (PG + HCAP) * sizeof(PCol) + (size_t)PG * MDCAP * 16 + (size_t)PG * J.n_bw * 8 + (size_t)PG * PWCAP * 8;
     // counter width: enough bits for the largest threshold floor(0.1 * max(31, columns))
     const uint32_t tmax = (uint32_t)((double)(J.max_cols > 31 ? J.max_cols : 31) * 0.1);
     if (tmax < 4) hipLaunchKernelGGL(k_pass1_pos<2>, dim3(J.n_win), dim3(NT), shm, st, J);

@@ -84,6 +84,11 @@ def test_bench_flow(monkeypatch, capsys, argv, steps):
         made.append(j)
         return j
     monkeypatch.setattr(api, "job_from_synth", fake_job_from_synth)
+
+    class FakePrep:
+        def __init__(self, sb): pass
+        def job(self, ctx, t0, t1, W): return fake_job_from_synth(ctx, None, W, range(t0, t1))
+    monkeypatch.setattr(api, "PreparedAlignments", FakePrep)
     fake_sb = types.SimpleNamespace(seq=None, qual=None, off=None)
     monkeypatch.setattr(synth, "generate_parallel", lambda *a, **k: fake_sb)
     monkeypatch.setattr(synth, "generate", lambda *a, **k: fake_sb)

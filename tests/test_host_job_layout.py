@@ -135,3 +135,18 @@ def test_rejections_without_a_device():
     with pytest.raises(api.HerroError):
         c.create_job(sb.tgt_rid[:1], rows, off, cigs, 8)           # window size out of range
     c.close()
+
+
+def test_prepared_alignments_give_the_same_jobs():
+    """api.PreparedAlignments (one resident herro_alignment array, jobs over target ranges by pointer offset — the bench's
+    end_to_end leg) builds exactly the descriptors job_from_synth builds."""
+    sb = synth.generate(6, 2000, 8, seed=3, flank_min=30, flank_max=60)
+    lens = (sb.off[1:] - sb.off[:-1]).astype(np.uint32)
+    c = api.HostContext(lens)
+    prep = api.PreparedAlignments(sb)
+    for t0, t1 in ((0, 6), (2, 5), (5, 6)):
+        j1, j2 = prep.job(c, t0, t1, 256), api.job_from_synth(c, sb, 256, range(t0, t1))
+        a1, a2 = c.job_arrays(j1), c.job_arrays(j2)
+        assert all(np.array_equal(a1[k], a2[k]) for k in a1)
+        j1.close(); j2.close()
+    c.close()
