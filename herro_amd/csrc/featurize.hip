@@ -131,7 +131,7 @@ __host__ __device__ inline size_t ow_stats_lds_per_wave(uint32_t window_size) {
 __global__ __launch_bounds__(NT) void k_ow_stats(JobDev J) {
   // per-wave LDS, sized for the job's window size (dynamic): [tw: ntw_cap u64][qw: QWCAP u64][op, t, q: OWCAP u32 each][bm: n_bw u32]
   extern __shared__ __attribute__((aligned(16))) unsigned char ow_smem[];
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform: the descriptor arrives by scalar loads
   const uint32_t o = blockIdx.x * 4 + wave;
   if (o >= J.n_ow) return;
   const uint32_t ntw_cap = J.window_size / 32 + 2;
@@ -153,21 +153,51 @@ __global__ __launch_bounds__(NT) void k_ow_stats(JobDev J) {
   const bool in_lds = cnt <= OWCAP;
 
   for (uint32_t i = lane; i < J.n_bw; i += 64) s_bm[i] = 0;
-  // 2-bit words of the target stretch and of the query stretch, coalesced, for the accuracy pass below
+  // 2-bit words of the target stretch and of the query stretch (for the accuracy pass below) and the ops of the slice:
+  // EVERY global load of this wave is issued here, before anything waits.  (As loops with run-time trip counts —
+  // three passes over the ops with two loads each, up to five + three passes over the words — they were ~13 memory
+  // round trips in sequence, ~26 us in the life of a wave whose arithmetic takes two or three.)
   const uint64_t t_woff = d.t_woff;
   const uint64_t q_woff = d.q_woff;
   const uint32_t tw0 = d.tstart >> 5, ntw = ((d.wtstart + d.wlen) >> 5) - tw0 + 2;
   const uint32_t qw0 = d.qbeg >> 5, nqw = ((d.qbeg + d.qlen) >> 5) - qw0 + 2;
   const bool q_lds = nqw <= QWCAP;
-  for (uint32_t i = lane; i < ntw; i += 64) s_tw[i] = t_woff + tw0 + i <= J.read_n_words ? J.read_words[t_woff + tw0 + i] : 0ull;
-  if (q_lds)
-    for (uint32_t i = lane; i < nqw; i += 64) s_qw[i] = q_woff + qw0 + i <= J.read_n_words ? J.read_words[q_woff + qw0 + i] : 0ull;
+  constexpr int TWI = (TWCAP + 63) / 64, QWI = (QWCAP + 63) / 64, OPI = (OWCAP + 63) / 64;
+  uint64_t tw_r[TWI], qw_r[QWI];
+  uint32_t op_r[OPI];
+#pragma unroll
+  for (int i = 0; i < TWI; i++) {
+    const uint32_t idx = lane + 64u * i;
+    tw_r[i] = (idx < ntw && t_woff + tw0 + idx <= J.read_n_words) ? J.read_words[t_woff + tw0 + idx] : 0ull;
+  }
+#pragma unroll
+  for (int i = 0; i < QWI; i++) {
+    const uint32_t idx = lane + 64u * i;
+    qw_r[i] = (q_lds && idx < nqw && q_woff + qw0 + idx <= J.read_n_words) ? J.read_words[q_woff + qw0 + idx] : 0ull;
+  }
+#pragma unroll
+  for (int i = 0; i < OPI; i++) {
+    const uint32_t k = lane + 64u * i;
+    op_r[i] = (in_lds && k < cnt) ? ops[k] : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < TWI; i++) {
+    const uint32_t idx = lane + 64u * i;
+    if (idx < ntw) s_tw[idx] = tw_r[i];
+  }
+  if (q_lds) {
+#pragma unroll
+    for (int i = 0; i < QWI; i++) {
+      const uint32_t idx = lane + 64u * i;
+      if (idx < nqw) s_qw[idx] = qw_r[i];
+    }
+  }
   uint32_t carry_t = 0, carry_q = 0, carry_i = 0, carry_m = 0, isum = 0, dsum = 0, longindel = 0;
-  for (uint32_t base = 0; base < cnt; base += 64) {
+  auto op_step = [&](uint32_t base, uint32_t op_in, uint32_t nxt_in, bool have_regs) {
     const uint32_t k = base + lane;
     uint32_t tadv = 0, qadv = 0, is_i = 0, op = 0;
     if (k < cnt) {
-      op = ops[k];
+      op = have_regs ? op_in : ops[k];
       const uint32_t ty = op_type(op);
       const uint32_t e = eff_len(op, k, cnt, d.start_off, d.end_off);
       if (ty != OP_M && op_len(op) > 50u) longindel = 1;  // untrimmed length (features.rs:317)
@@ -191,7 +221,7 @@ __global__ __launch_bounds__(NT) void k_ow_stats(JobDev J) {
         // compact M/D op table + bitmap of op starts: the tile kernels find the op covering a target
         // position with one popcount (rank) instead of a search.  An M/D op is followed by at most one
         // insertion (the host rejects consecutive I ops); I ops are never trimmed by window offsets.
-        const uint32_t nxt = (k + 1 < cnt) ? ops[k + 1] : 0u;
+        const uint32_t nxt = (k + 1 < cnt) ? (have_regs ? nxt_in : ops[k + 1]) : 0u;
         const uint32_t ins_len = (k + 1 < cnt && op_type(nxt) == OP_I) ? op_len(nxt) : 0u;
         md[carry_m + (uint32_t)(ex_im >> 32)] = make_uint4(t, q, tadv | (op_type(op) == OP_M ? 0x80000000u : 0u), ins_len);
         atomicOr(&s_bm[t >> 5], 1u << (t & 31u));
@@ -201,6 +231,19 @@ __global__ __launch_bounds__(NT) void k_ow_stats(JobDev J) {
     carry_q += (uint32_t)(tot_tq >> 32);
     carry_i += (uint32_t)tot_im;
     carry_m += (uint32_t)(tot_im >> 32);
+  };
+  if (in_lds) {
+#pragma unroll
+    for (int i = 0; i < OPI; i++) {
+      if (64u * i < cnt) {   // wave-uniform
+        // the op after lane l's: lane l+1's, or — for the last lane — the first op of the next register
+        const uint32_t same = __shfl_down(op_r[i], 1, 64);
+        const uint32_t next0 = i + 1 < OPI ? __shfl(op_r[i + 1 < OPI ? i + 1 : i], 0, 64) : 0u;
+        op_step(64u * i, op_r[i], lane == 63 ? next0 : same, true);
+      }
+    }
+  } else {
+    for (uint32_t base = 0; base < cnt; base += 64) op_step(base, 0u, 0u, false);
   }
   const uint32_t t_total = carry_t;
   // this wave's LDS / global writes are read back below by the same wave.  LDS operations of one wave execute in order, so
@@ -662,12 +705,58 @@ __global__ __launch_bounds__(NT) void k_pass1_pos(JobDev J) {
     for (uint32_t m = sup; m; m &= m - 1u) s_list[atomicAdd(s_n, 1u)] = (uint16_t)(P + (uint32_t)__ffs(m) - 1u);
     __syncthreads();
     const uint32_t npair = *s_n * n_kept;
-    for (uint32_t pr = threadIdx.x; pr < npair; pr += NT) {
-      const uint32_t pos = s_list[pr / n_kept], o = slots[pr % n_kept];
-      const ColHdr h = J.chdr[o];
-      const CellOut co = column_cell<false>(J, h, o, (int32_t)pos, 0);
-      const uint32_t t = read_code(J.read_words, t_woff, wd.tstart + pos);
-      atomicAdd(&J.nd[2 * (uint64_t)h.cls + (tok_fold(co.tok) == t ? 0 : 1)], 1u);
+    // two (position, column) cells per thread and iteration, phase by phase: a cell is slot -> header -> rank word -> op
+    // entry -> 2-bit word, five dependent loads from global memory, and one at a time they ran in sequence at the tail of
+    // every workgroup (typically 15 positions x 32 columns = 2 cells per thread = ten round trips)
+    for (uint32_t pr0 = threadIdx.x; pr0 < npair; pr0 += 2 * NT) {
+      bool live[2], inr[2];
+      uint32_t pos[2], o[2], uu[2], tw[2];
+      ColHdr h[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const uint32_t pr = pr0 + u * NT;
+        live[u] = pr < npair;
+        const uint32_t prc = live[u] ? pr : pr0;
+        pos[u] = s_list[prc / n_kept];
+        o[u] = slots[prc % n_kept];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        h[u] = J.chdr[o[u]];
+        const uint32_t ti = wd.tstart + pos[u];
+        tw[u] = (uint32_t)(J.read_words[t_woff + (ti >> 5)] >> ((ti & 31u) << 1)) & 3u;   // read_code
+      }
+      uint2 bw[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const uint32_t uu_raw = (uint32_t)((int32_t)pos[u] - h[u].off);
+        inr[u] = uu_raw < h[u].t_total;
+        uu[u] = inr[u] ? uu_raw : 0u;
+        bw[u] = J.bm[(uint64_t)o[u] * J.n_bw + (uu[u] >> 5)];
+      }
+      uint4 e[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const uint32_t rank = bw[u].y + __popc(bw[u].x & (0xffffffffu >> (31u - (uu[u] & 31u))));
+        e[u] = J.md[h[u].md_off + (inr[u] && h[u].t_total ? rank - 1u : 0u)];
+      }
+      uint64_t word[2];
+      uint32_t si[2];
+      bool isbase[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        isbase[u] = inr[u] && (e[u].z >> 31) != 0;                               // j == 0: M -> base, D -> gap
+        const uint32_t q = e[u].y + (uu[u] - e[u].x);
+        si[u] = isbase[u] ? (uint32_t)(h[u].sbase + h[u].sdir * (int32_t)q) : 0u;
+        word[u] = J.read_words[h[u].q_woff + (si[u] >> 5)];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const uint32_t code = (uint32_t)(word[u] >> ((si[u] & 31u) << 1)) & 3u;
+        // folded symbol of the cell (tok_fold of column_cell's token): base -> its forward-strand code, gap -> 4, '.' -> 10
+        const uint32_t folded = !inr[u] ? (uint32_t)TOK_NONE : (isbase[u] ? (h[u].strand ? (code ^ 3u) : code) : 4u);
+        if (live[u]) atomicAdd(&J.nd[2 * (uint64_t)h[u].cls + (folded == tw[u] ? 0 : 1)], 1u);
+      }
     }
   }
 }
@@ -1119,15 +1208,18 @@ __device__ __forceinline__ void tile_fetch(const JobDev& J, const TileHdr& th, c
   const uint32_t nbm = live ? min(min(nspan + 1u, (uint32_t)BMW), J.n_bw - pl.w0) : 0u;
   const uint32_t nmd = live ? (pl.cnt & 0xffu) : 0u;
   const uint32_t nw = live ? ((pl.cnt >> 8) & 0xffu) : (tgt ? ((th.tstart + th.p_hi) >> 5) - tw0 + 1u : 0u);
-  const uint2* __restrict__ bm = J.bm + (uint64_t)pl.ow * J.n_bw + pl.w0;
-  const uint4* __restrict__ md = J.md + pl.md_off + pl.r0;
-  const uint64_t* __restrict__ wsrc = tgt ? J.read_words + th.tgt_woff + tw0 : J.read_words + pl.q_woff + pl.word0;
+  // every load below is UNCONDITIONAL (index clamped into the live range, base pointer of element 0 for columns that
+  // stage nothing): predicated loads compiled to one branch + wait each, i.e. seven memory round trips in sequence at the
+  // head of every tile instead of one
+  const uint2* __restrict__ bm = live ? J.bm + (uint64_t)pl.ow * J.n_bw + pl.w0 : J.bm;
+  const uint4* __restrict__ md = live ? J.md + pl.md_off + pl.r0 : J.md;
+  const uint64_t* __restrict__ wsrc = tgt ? J.read_words + th.tgt_woff + tw0 : (live ? J.read_words + pl.q_woff + pl.word0 : J.read_words);
 #pragma unroll
-  for (int k = 0; k < 2; k++) d.vb[k] = (l8 + 8 * k < nbm) ? bm[l8 + 8 * k] : make_uint2(0, 0);
+  for (int k = 0; k < 2; k++) { const uint32_t i = l8 + 8 * k; d.vb[k] = bm[nbm ? min(i, nbm - 1u) : 0u]; }
 #pragma unroll
-  for (int k = 0; k < 3; k++) d.vm[k] = (l8 + 8 * k < nmd) ? md[l8 + 8 * k] : make_uint4(0, 0, 0, 0);
+  for (int k = 0; k < 3; k++) { const uint32_t i = l8 + 8 * k; d.vm[k] = md[nmd ? min(i, nmd - 1u) : 0u]; }
 #pragma unroll
-  for (int k = 0; k < 2; k++) d.vw[k] = (l8 + 8 * k < nw) ? wsrc[l8 + 8 * k] : 0ull;
+  for (int k = 0; k < 2; k++) { const uint32_t i = l8 + 8 * k; d.vw[k] = wsrc[nw ? min(i, nw - 1u) : 0u]; }
 }
 
 __global__ __launch_bounds__(NT) void k_final_tiles_t(JobDev J) {
@@ -1147,18 +1239,9 @@ __global__ __launch_bounds__(NT) void k_final_tiles_t(JobDev J) {
   pl0.off = 0; pl0.sbase = 0; pl0.sdir_strand = 0;
   if (sc < HERRO_ROWS - 1) pl0 = J.tplan[(uint64_t)tile * 32 + sc];
   if (th.r0 >= th.Lf || (J.dbg & 16u)) return;
-  if (J.dbg & 32u) {  // phase probe: round trip 1 only (the sink keeps the loads alive)
-    if (pl0.ow == 0x7ffffff1u && pl0.cnt == 0x7ffffff3u) J.sup_flag[th.row_off] = 1;
-    return;
-  }
   // round trip 2: row map entry, rank directory words, op entries, 2-bit words
   TileData d;
   tile_fetch(J, th, pl0, sc, l8, d);
-  if (J.dbg & 64u) {  // phase probe: both round trips, no LDS staging
-    uint32_t acc = d.rm ^ d.vb[0].x ^ d.vb[1].y ^ d.vm[0].x ^ d.vm[1].y ^ d.vm[2].z ^ (uint32_t)d.vw[0] ^ (uint32_t)(d.vw[1] >> 32);
-    if (acc == 0x7ffffff1u && pl0.ow == 0x7ffffff3u) J.sup_flag[th.row_off] = 1;
-    return;
-  }
   const unsigned char* bm_bytes = reinterpret_cast<const unsigned char*>(s_bm);
   const unsigned char* md_bytes = reinterpret_cast<const unsigned char*>(s_md);
   const uint8_t* w_bytes = reinterpret_cast<const uint8_t*>(s_words);
@@ -1220,34 +1303,55 @@ __global__ __launch_bounds__(NT) void k_final_tiles_t(JobDev J) {
       }
       s_tb[threadIdx.x] = (uint8_t)t0tok;
       cnt += 1u << (6u * tok_fold(t0tok));
+      // Columns are taken CG at a time, phase by phase (descriptor + rank word -> op entry -> base byte -> token): a cell is
+      // a chain of four dependent LDS reads, and column after column that chain ran strictly in sequence (~4 x 64+ cycles
+      // per cell with nothing else of the wave in flight); in groups, CG chains overlap.
+      constexpr uint32_t CG = 5;
+      static_assert((HERRO_ROWS - 1) % CG == 0, "column groups");
       if (!(J.dbg & 1u))
 #pragma unroll
-      for (uint32_t c = 1; c < HERRO_ROWS; c++) {
-        const uint4 d0 = *reinterpret_cast<const uint4*>(&s_cd[c - 1]);
-        const uint4 d1 = *(reinterpret_cast<const uint4*>(&s_cd[c - 1]) + 1);
-        const uint32_t uu_raw = (uint32_t)(p - (int32_t)d0.x);
-        const bool inr = uu_raw < d0.y;
-        const uint32_t uu = inr ? uu_raw : d0.z;
-        const uint2 bw = *reinterpret_cast<const uint2*>(bm_bytes + (int32_t)d0.w + (int32_t)((uu >> 5) << 3));
-        const uint32_t rank = __popc(bw.x & ~(0xfffffffeu << (uu & 31u))) + bw.y;
-        const uint4 e = *reinterpret_cast<const uint4*>(md_bytes + (int32_t)d1.x + (int32_t)(rank << 4));
-        // all selects, no short-circuit: booleans are combined bitwise so that nothing here becomes a branch
-        const uint32_t m_bit = e.z >> 31;                      // 1: M op, 0: D op
-        const uint32_t len = e.z & 0x7fffffffu;
-        const uint32_t lenm = m_bit ? len : 0u;
-        const bool last = (uu + 1u == e.x + len);
-        const bool ins_ok = last & (e.w >= j);                 // insertion slot j-1 behind uu exists in this read
-        const bool isbase = inr & (j0 ? (m_bit != 0u) : ins_ok);
-        const uint32_t q = e.y + (j0 ? uu - e.x : lenm + jm1);
-        const uint32_t si = isbase ? (uint32_t)(__mul24((int32_t)d1.z, (int32_t)q) + (int32_t)d1.y) : 0u;
-        const uint32_t byte = w_bytes[(c - 1) * WW * 8 + (si >> 2)];
-        const uint32_t f = ((byte >> ((si & 3u) << 1)) & 3u) ^ (d1.w & 0xffu);
-        const uint32_t tokb = f + ((d1.w >> 8) & 0xffu);
-        const uint32_t tokg = d1.w >> 16;
-        const uint32_t tok = inr ? (isbase ? tokb : tokg) : (uint32_t)TOK_NONE;
-        s_tb[c * TLD + threadIdx.x] = (uint8_t)tok;
-        const uint32_t one = inr ? 1u : 0u;
-        cnt += one << (6u * (isbase ? f : 4u));
+      for (uint32_t c0 = 1; c0 < HERRO_ROWS; c0 += CG) {
+        uint4 d1[CG], e[CG];
+        uint2 bw[CG];
+        uint32_t uu[CG], byte[CG];
+        bool inr[CG], isb[CG];
+#pragma unroll
+        for (uint32_t g = 0; g < CG; g++) {
+          const uint4 d0 = *reinterpret_cast<const uint4*>(&s_cd[c0 + g - 1]);
+          d1[g] = *(reinterpret_cast<const uint4*>(&s_cd[c0 + g - 1]) + 1);
+          const uint32_t uu_raw = (uint32_t)(p - (int32_t)d0.x);
+          inr[g] = uu_raw < d0.y;
+          uu[g] = inr[g] ? uu_raw : d0.z;
+          bw[g] = *reinterpret_cast<const uint2*>(bm_bytes + (int32_t)d0.w + (int32_t)((uu[g] >> 5) << 3));
+        }
+#pragma unroll
+        for (uint32_t g = 0; g < CG; g++) {
+          const uint32_t rank = __popc(bw[g].x & ~(0xfffffffeu << (uu[g] & 31u))) + bw[g].y;
+          e[g] = *reinterpret_cast<const uint4*>(md_bytes + (int32_t)d1[g].x + (int32_t)(rank << 4));
+        }
+#pragma unroll
+        for (uint32_t g = 0; g < CG; g++) {
+          // all selects, no short-circuit: booleans are combined bitwise so that nothing here becomes a branch
+          const uint32_t m_bit = e[g].z >> 31;                      // 1: M op, 0: D op
+          const uint32_t len = e[g].z & 0x7fffffffu;
+          const uint32_t lenm = m_bit ? len : 0u;
+          const bool last = (uu[g] + 1u == e[g].x + len);
+          const bool ins_ok = last & (e[g].w >= j);                 // insertion slot j-1 behind uu exists in this read
+          isb[g] = inr[g] & (j0 ? (m_bit != 0u) : ins_ok);
+          const uint32_t q = e[g].y + (j0 ? uu[g] - e[g].x : lenm + jm1);
+          const uint32_t si = isb[g] ? (uint32_t)(__mul24((int32_t)d1[g].z, (int32_t)q) + (int32_t)d1[g].y) : 0u;
+          byte[g] = w_bytes[(c0 + g - 1) * WW * 8 + (si >> 2)] >> ((si & 3u) << 1);
+        }
+#pragma unroll
+        for (uint32_t g = 0; g < CG; g++) {
+          const uint32_t f = (byte[g] & 3u) ^ (d1[g].w & 0xffu);
+          const uint32_t tokb = f + ((d1[g].w >> 8) & 0xffu);
+          const uint32_t tokg = d1[g].w >> 16;
+          const uint32_t tok = inr[g] ? (isb[g] ? tokb : tokg) : (uint32_t)TOK_NONE;
+          s_tb[(c0 + g) * TLD + threadIdx.x] = (uint8_t)tok;
+          const uint32_t one = inr[g] ? 1u : 0u;
+          cnt += one << (6u * (isb[g] ? f : 4u));
+        }
       }
       if (s_anyfb) {  // block-uniform, rare: columns whose stretch did not fit the staging slots
         for (uint32_t c = 1; c < HERRO_ROWS; c++) {

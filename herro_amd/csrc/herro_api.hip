@@ -206,8 +206,8 @@ struct herro_job {
   hipEvent_t ev_counts = nullptr;    // featurize + the copy of the counts finished
   uint64_t logit_cap = 0;
   bool consensus_done = false, consensus_on_host = false;
-  std::vector<uint32_t> h_cons_len;
-  std::vector<uint8_t> h_cons_seq;
+  uint32_t* h_cons_len = nullptr;   // pinned (inside the host arena): landing zone of the corrected bases
+  uint8_t* h_cons_seq = nullptr;
   uint64_t row_elems = 0;
   uint64_t alg_read_bytes = 0, alg_op_bytes = 0;
 };
@@ -901,6 +901,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   const size_t o_tw = take(tot.tile * 4), o_tr = take(tot.tile * 4);
   const size_t desc_bytes = cur;
   const size_t o_counts = take(tot.win * 12);   // host arena only: pinned landing zone of the per-window counts
+  const size_t o_hclen = take(tot.win * 4), o_hcseq = take(row_elems);   // ... and of the corrected bases (device consensus)
   const size_t pin_bytes = cur;
   auto acquire = [&](std::vector<Arena>& pool_, size_t need, bool device) -> Arena {
     {
@@ -928,6 +929,8 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
     job->tile_win.p = (uint32_t*)(hb + o_tw); job->tile_win.n = tot.tile;
     job->tile_r0.p = (uint32_t*)(hb + o_tr); job->tile_r0.n = tot.tile;
     job->h_counts = (uint32_t*)(hb + o_counts);
+    job->h_cons_len = (uint32_t*)(hb + o_hclen);
+    job->h_cons_seq = hb + o_hcseq;
   }
   hpool.run(n_targets, [&](uint32_t t) {
     TargetOut& o = outs[t];
@@ -1386,12 +1389,13 @@ static int consensus_to_host(herro_job* job) {
   herro_ctx* ctx = job->ctx;
   if (job->consensus_on_host) return HERRO_OK;
   const uint32_t n = job->J.n_win;
-  job->h_cons_len.resize(n);
-  job->h_cons_seq.resize(job->row_elems);
+  // device -> the job's pinned arena: no staging copy, no page pinning by the runtime at call time (a pageable destination
+  // made the runtime lock user pages under the mm lock, which stalled the page faults of whoever was building the next job:
+  // 40 ms spikes in the other feeder's herro_job_create)
+  if (n) HIP_TRY(ctx, hipMemcpyAsync(job->h_cons_len, job->J.cons_len, n * 4ull, hipMemcpyDeviceToHost, ctx->stream));
+  if (job->row_elems) HIP_TRY(ctx, hipMemcpyAsync(job->h_cons_seq, job->J.cons_seq, job->row_elems, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->timer.collect();
-  if (n) HIP_TRY(ctx, hipMemcpy(job->h_cons_len.data(), job->J.cons_len, n * 4ull, hipMemcpyDeviceToHost));
-  if (job->row_elems) HIP_TRY(ctx, hipMemcpy(job->h_cons_seq.data(), job->J.cons_seq, job->row_elems, hipMemcpyDeviceToHost));
   job->consensus_on_host = true;
   return HERRO_OK;
 }
@@ -1437,7 +1441,7 @@ int64_t herro_job_consensus_fasta(herro_job* job, uint32_t t, const char* id, co
         if (!cur.empty()) { seqs.push_back(cur); cur.clear(); }
         continue;
       }
-      cur.append((const char*)job->h_cons_seq.data() + job->win[w].row_off, job->h_cons_len[w]);
+      cur.append((const char*)job->h_cons_seq + job->win[w].row_off, job->h_cons_len[w]);
     }
     if (!cur.empty()) seqs.push_back(cur);
     std::string fa;

@@ -14,6 +14,20 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session", autouse=True)
+def _torch_owns_the_gpu_first():
+    """PyTorch brings its own copy of the HIP runtime (torch/lib/libamdhip64.so); libherro_amd.so links the system one
+    (/opt/rocm/lib).  The two coexist in one process only if PyTorch initialises its runtime FIRST — a test that used the
+    library before the end-to-end test moved its twin to the GPU made torch report "No HIP GPUs are available".  bench.py
+    and __graft_entry__.smoke() start with torch as well."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
+@pytest.fixture(scope="session", autouse=True)
 def _built():
     """CPU-side artefacts (oracle + synthetic generator) are cheap: build them on demand."""
     import __graft_entry__ as g
