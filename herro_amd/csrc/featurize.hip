@@ -343,12 +343,14 @@ __global__ __launch_bounds__(NT) void k_ow_stats(JobDev J) {
 __device__ __forceinline__ void scatter_max_ins(const JobDev& J, const uint32_t* ow_list, uint32_t n,
                                                 uint32_t win_len, uint32_t* s_mi, uint32_t* s_pref,
                                                 uint32_t* s_wave) {
+  __shared__ uint32_t s_scr[EVCAP];   // first insertion event of each listed overlap (OwDesc::scr_off), staged with the counts
   for (uint32_t base = 0; base < n; base += EVCAP) {
     const uint32_t nn = min((uint32_t)EVCAP, n - base);
     uint32_t carry = 0;
     for (uint32_t b2 = 0; b2 < nn; b2 += NT) {
       const uint32_t i = b2 + threadIdx.x;
       const uint32_t c = i < nn ? J.ins_cnt[ow_list[base + i]] : 0u;
+      if (i < nn) s_scr[i] = J.ow[ow_list[base + i]].scr_off;     // same round trip as the count
       uint32_t tot;
       const uint32_t ex = block_scan(c, &tot, s_wave);
       if (i < nn) s_pref[i] = carry + ex;
@@ -356,15 +358,28 @@ __device__ __forceinline__ void scatter_max_ins(const JobDev& J, const uint32_t*
     }
     __syncthreads();
     const uint32_t E = carry;
-    for (uint32_t e = threadIdx.x; e < E; e += NT) {
-      uint32_t lo = 0, hi = nn;  // largest i with s_pref[i] <= e
-      while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (s_pref[mid] <= e) lo = mid; else hi = mid;
+    // four events per thread and iteration: indices from LDS first, then the four loads together, then the atomics
+    // (one event at a time was slot -> descriptor -> event: two dependent loads per event, ~3 events per thread in a row)
+    for (uint32_t e0 = threadIdx.x; e0 < E; e0 += 4 * NT) {
+      uint32_t ev[4];
+      bool live[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t e = e0 + u * NT;
+        live[u] = e < E;
+        const uint32_t ec = live[u] ? e : e0;
+        uint32_t lo = 0, hi = nn;  // largest i with s_pref[i] <= ec
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_pref[mid] <= ec) lo = mid; else hi = mid;
+        }
+        ev[u] = J.ins_ev[s_scr[lo] + (ec - s_pref[lo])];
       }
-      const uint32_t ev = J.ins_ev[J.ow[ow_list[base + lo]].scr_off + (e - s_pref[lo])];
-      const uint32_t p = ev & 0xffffu;
-      if (p < win_len) atomicMax(&s_mi[p], ev >> 16);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t p = ev[u] & 0xffffu;
+        if (live[u] && p < win_len) atomicMax(&s_mi[p], ev[u] >> 16);
+      }
     }
     __syncthreads();
   }
