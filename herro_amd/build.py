@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libherro_amd.so")
 HIP_SOURCES = ["featurize.hip", "model.hip", "model_h.hip", "herro_api.hip", "ingest.cpp"]
 HEADERS = ["job_dev.h", "model_dev.h", "pileup_core.h", "windowing.hpp", os.path.join("..", "..", "include", "herro_amd.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
          "-fno-gpu-rdc"]
 
 

@@ -29,7 +29,6 @@
 namespace herro {
 
 static constexpr int NT = 256;       // threads per workgroup (4 waves)
-static constexpr int OPCAP = 1024;   // ops of one overlap-window staged in LDS by k_ow_stats
 static constexpr int EVCAP = 128;    // overlaps whose insertion events are flattened through LDS
 
 // ---- block-wide exclusive scan of one u32 per thread; returns exclusive prefix, *total = sum ----

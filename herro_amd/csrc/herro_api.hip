@@ -128,6 +128,7 @@ struct herro_ctx {
   ModelDev M{};
   std::vector<void*> model_allocs;
   int precision = 1;
+  bool precision_set = false;   // herro_set_precision was called: herro_load_model keeps the caller's choice
   ModelScratch S{};
   uint32_t scratch_cap = 0;
   std::vector<void*> scratch_allocs;
@@ -297,31 +298,30 @@ herro_ctx* herro_create(int device_id) {
   for (size_t k = 0; k < ln.size(); k++) ln[k] = std::log((double)k + 1.0);
   ctx->d_ln = dev_alloc_copy(ln, ctx->stream, e);
   if (e != hipSuccess) { g_create_err = hipGetErrorString(e); return nullptr; }
-  hipStreamSynchronize(ctx->stream);
+  if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) { g_create_err = hipGetErrorString(e); return nullptr; }
   ctx->ln_n = (uint32_t)ln.size();
   return ctx.release();
 }
 
 static void free_all(std::vector<void*>& v) {
-  for (void* p : v) if (p) hipFree(p);
+  for (void* p : v) if (p) (void)hipFree(p);
   v.clear();
 }
 
 void herro_destroy(herro_ctx* ctx) {
   if (!ctx) return;
   if (ctx->host_only) { for (Arena& a : ctx->free_pin) std::free(a.p); delete ctx; return; }
-  hipSetDevice(ctx->device);
-  hipDeviceSynchronize();
+  (void)hipSetDevice(ctx->device);   // teardown: nothing to report errors to
+  (void)hipDeviceSynchronize();
   ctx->timer.reset();
-  hipFree(ctx->d_words); hipFree(ctx->d_word_off); hipFree(ctx->d_qual); hipFree(ctx->d_qual_off);
-  hipFree(ctx->d_p0); hipFree(ctx->d_p1);
-  hipFree(ctx->d_ln);
+  for (void* p : {(void*)ctx->d_words, (void*)ctx->d_word_off, (void*)ctx->d_qual, (void*)ctx->d_qual_off, (void*)ctx->d_p0, (void*)ctx->d_p1, (void*)ctx->d_ln})
+    if (p) (void)hipFree(p);
   free_all(ctx->model_allocs);
   free_all(ctx->scratch_allocs);
   for (Arena& a : ctx->free_dev) (void)hipFree(a.p);
   for (Arena& a : ctx->free_pin) (void)hipHostFree(a.p);
   for (Arena& a : ctx->free_small) (void)hipFree(a.p);
-  if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
 
@@ -374,9 +374,11 @@ int herro_decode_2bit(const uint64_t* words, uint64_t length, uint64_t start, ui
 static int upload_reads(herro_ctx* ctx, uint32_t n_reads, const std::vector<uint64_t>& words,
                         const std::vector<uint64_t>& word_off, const uint8_t* qual,
                         const std::vector<uint64_t>& qual_off, const uint32_t* name_class) {
-  hipSetDevice(ctx->device);
-  hipFree(ctx->d_words); hipFree(ctx->d_word_off); hipFree(ctx->d_qual); hipFree(ctx->d_qual_off);
-  hipFree(ctx->d_p0); hipFree(ctx->d_p1); ctx->d_p0 = nullptr; ctx->d_p1 = nullptr;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // nothing may still read the store that is about to be replaced
+  for (void* p : {(void*)ctx->d_words, (void*)ctx->d_word_off, (void*)ctx->d_qual, (void*)ctx->d_qual_off, (void*)ctx->d_p0, (void*)ctx->d_p1})
+    if (p) HIP_TRY(ctx, hipFree(p));
+  ctx->d_p0 = nullptr; ctx->d_p1 = nullptr;
   ctx->d_words = nullptr; ctx->d_word_off = nullptr; ctx->d_qual = nullptr; ctx->d_qual_off = nullptr;
   hipError_t e;
   std::vector<uint64_t> wp(words);
@@ -500,7 +502,7 @@ const float* up_f32(herro_ctx* ctx, const std::vector<float>& v, hipError_t& e) 
 
 int herro_load_model(herro_ctx* ctx, const char* path) {
   if (!ctx || !path) return HERRO_E_INVALID;
-  hipSetDevice(ctx->device);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
   FILE* f = std::fopen(path, "rb");
   if (!f) { ctx->err = std::string("cannot open model file ") + path; return HERRO_E_NO_MODEL; }
   ModelHyper h;
@@ -617,6 +619,9 @@ int herro_load_model(herro_ctx* ctx, const char* path) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->M = M;
   ctx->has_model = true;
+  // default operand format: f16 (precision 4) when the model has the shapes its kernels are written for, else bf16 hi/lo x3
+  if (!ctx->precision_set) ctx->precision = model_h_supported(M) ? 4 : 1;
+  else if (ctx->precision >= 4 && !model_h_supported(M)) ctx->precision = 1;
   return HERRO_OK;
 }
 
@@ -627,12 +632,13 @@ int herro_set_precision(herro_ctx* ctx, int mode) {
     return HERRO_E_UNSUPPORTED;
   }
   ctx->precision = mode;
+  ctx->precision_set = true;
   return HERRO_OK;
 }
 
 static int ensure_scratch(herro_ctx* ctx, uint32_t n_tok) {
   if (n_tok <= ctx->scratch_cap) return HERRO_OK;
-  hipSetDevice(ctx->device);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   free_all(ctx->scratch_allocs);
   const ModelHyper& h = ctx->M.h;
@@ -841,7 +847,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   if (!ctx->d_words && !ctx->host_only) return fail(HERRO_E_STATE, "herro_set_reads must be called first");
   if (W < 16 || W > HERRO_MAX_WINDOW) return fail(HERRO_E_UNSUPPORTED, "window_size must be in [16, 8192]");
   if (n_targets && (!rids || !aln_off)) return fail(HERRO_E_INVALID, "null argument");
-  if (!ctx->host_only) hipSetDevice(ctx->device);
+  if (!ctx->host_only && hipSetDevice(ctx->device) != hipSuccess) return fail(HERRO_E_NO_DEVICE, "hipSetDevice failed");
 
   const bool prof = getenv("HERRO_HOST_PROFILE") != nullptr;
   auto tnow = [] { return std::chrono::steady_clock::now(); };
@@ -1072,7 +1078,7 @@ int herro_job_featurize(herro_job* job) {
   if (!job) return HERRO_E_INVALID;
   herro_ctx* ctx = job->ctx;
   if (job->reads_gen != ctx->reads_gen) { ctx->err = "the read store was replaced (herro_set_reads) after this job was created"; return HERRO_E_STATE; }
-  hipSetDevice(ctx->device);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
   // everything derived from a previous pass over this job is stale from here on
   job->synced = false; job->inferred = false; job->quals_full = false;
   job->consensus_done = false; job->consensus_on_host = false; job->logits_on_host = false;
@@ -1093,7 +1099,7 @@ static int job_sync(herro_job* job) {
   herro_ctx* ctx = job->ctx;
   if (!job->featurized) { ctx->err = "herro_job_featurize has not run"; return HERRO_E_STATE; }
   if (job->synced) return HERRO_OK;
-  hipSetDevice(ctx->device);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint32_t n = job->J.n_win;
   if (n) HIP_TRY(ctx, hipEventSynchronize(job->ev_counts));
   job->h_Lf.assign(job->h_counts, job->h_counts + n);
@@ -1117,7 +1123,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   if (!ctx->has_model) { ctx->err = "no model loaded"; return HERRO_E_NO_MODEL; }
   int rc = job_sync(job);
   if (rc) return rc;
-  hipSetDevice(ctx->device);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint32_t n = job->J.n_win;
   const uint64_t total_sup = job->sup_off[n];
   if (!job->d_info || job->logit_cap < total_sup) {
@@ -1260,7 +1266,7 @@ int herro_job_consensus(herro_job* job) {
   herro_ctx* ctx = job->ctx;
   int rc = job_sync(job);
   if (rc) return rc;
-  hipSetDevice(ctx->device);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint32_t n = job->J.n_win;
   if (job->sup_off.back() > 0 && !job->inferred) { ctx->err = "herro_job_infer has not run"; return HERRO_E_STATE; }
   const uint64_t* d_so = job->d_supoff_blob;
@@ -1326,7 +1332,7 @@ int herro_job_window_copy(herro_job* job, uint32_t w, int encoded, uint8_t* base
   int rc = job_sync(job);
   if (rc) return rc;
   herro_ctx* ctx = job->ctx;
-  hipSetDevice(ctx->device);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
   const WinDesc& wd = job->win[w];
   const uint32_t L = job->h_Lf[w];
   if (bases || quals) {
@@ -1360,7 +1366,7 @@ static int logits_to_host(herro_job* job) {
   herro_ctx* ctx = job->ctx;
   if (!job->inferred) { ctx->err = "herro_job_infer has not run"; return HERRO_E_STATE; }
   if (job->logits_on_host) return HERRO_OK;
-  hipSetDevice(ctx->device);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint64_t tot = job->sup_off.back();
   job->h_info.resize(tot);
   job->h_base.resize(tot * 5);
@@ -1426,7 +1432,7 @@ int64_t herro_job_consensus_fasta(herro_job* job, uint32_t t, const char* id, co
   bool need_logits = false;
   for (uint32_t w = w0; w < w1; w++) need_logits |= job->h_nsup[w] > 0 && std::min<uint32_t>(job->h_nkept[w], 30) >= 2;
   if (need_logits && (rc = logits_to_host(job))) return rc;
-  hipSetDevice(ctx->device);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
   // first..last window with n_alns > 1 (consensus.rs:90-101)
   int64_t st = -1, en = -1;
   for (uint32_t w = w0; w < w1; w++)
@@ -1526,7 +1532,7 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
                         const int32_t* lens, const int32_t* indices, float* info_logits, float* bases_logits) {
   if (!ctx || !bases || !quals || !lens) return HERRO_E_INVALID;
   if (!ctx->has_model) { ctx->err = "no model loaded"; return HERRO_E_NO_MODEL; }
-  hipSetDevice(ctx->device);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
   uint64_t N = 0;
   std::vector<uint32_t> tok_off(B + 1, 0), srow;
   for (uint32_t b = 0; b < B; b++) {
@@ -1662,13 +1668,13 @@ int64_t herro_debug_extract_windows(const herro_alignment* a, uint32_t n_windows
 int herro_timing_enable(herro_ctx* ctx, int on) { if (!ctx) return HERRO_E_INVALID; ctx->timer.on = on != 0; return HERRO_OK; }
 int herro_timing_reset(herro_ctx* ctx) {
   if (!ctx) return HERRO_E_INVALID;
-  hipStreamSynchronize(ctx->stream);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->timer.reset();
   return HERRO_OK;
 }
 int herro_timing_get(herro_ctx* ctx, char* names, uint64_t cap, double* ms, uint64_t* calls, uint32_t* n) {
   if (!ctx || !n) return HERRO_E_INVALID;
-  hipStreamSynchronize(ctx->stream);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->timer.collect();
   std::string s;
   uint32_t k = 0;

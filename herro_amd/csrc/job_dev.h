@@ -88,17 +88,25 @@ struct KernelTimer {
   std::vector<Rec> pending;
   std::map<std::string, std::pair<double, uint64_t>> acc;  // name -> (ms, calls)
   std::vector<std::string> order;
+  // An event that cannot be created or recorded drops that one measurement; timing never fails the pipeline.
   void begin(const char* name, hipStream_t st) {
     Rec r;
     r.name = name;
-    hipEventCreate(&r.a);
-    hipEventCreate(&r.b);
-    hipEventRecord(r.a, st);
+    r.a = r.b = nullptr;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess || hipEventRecord(r.a, st) != hipSuccess) {
+      if (r.a) (void)hipEventDestroy(r.a);
+      if (r.b) (void)hipEventDestroy(r.b);
+      r.a = r.b = nullptr;
+    }
     pending.push_back(r);
   }
-  void end(hipStream_t st) { hipEventRecord(pending.back().b, st); }
+  void end(hipStream_t st) {
+    Rec& r = pending.back();
+    if (r.b && hipEventRecord(r.b, st) != hipSuccess) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); r.a = r.b = nullptr; }
+  }
   void collect() {  // caller has synchronised the stream
     for (auto& r : pending) {
+      if (!r.a) continue;
       float ms = 0;
       if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
         if (!acc.count(r.name)) order.push_back(r.name);
@@ -106,8 +114,8 @@ struct KernelTimer {
         e.first += ms;
         e.second += 1;
       }
-      hipEventDestroy(r.a);
-      hipEventDestroy(r.b);
+      (void)hipEventDestroy(r.a);
+      (void)hipEventDestroy(r.b);
     }
     pending.clear();
   }

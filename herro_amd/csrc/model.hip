@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void k_patch_conv1_s(ModelDev M, BatchDev B, M
 
 // C[M,N] = epi(A . W^T + bias) (+R) with A given as bf16 hi/lo planes and W as [N][K] hi/lo planes;
 // 3 MFMAs per k-step and tile: al*bh + ah*bl + ah*bh.
-static constexpr int GM = 128, GN = 64;
+static constexpr int GN = 64;
 // TM = 128: 4 waves x (32 rows x 64 cols); TM = 64: 4 waves x (16 rows x 64 cols) — used when the 128-row
 // grid would leave the chip under-filled.
 
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void k_gemm_g(const uint16_t* __restrict__ Ahi
       for (int i = 0; i < RI; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const uint32_t nl = j * 16 + (lane & 15), n = n0 + nl;
+          const uint32_t nl = j * 16 + (lane & 15);
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             float v = acc[i][j][r] + bs[j];

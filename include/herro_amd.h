@@ -94,9 +94,14 @@ int herro_set_reads_packed(herro_ctx* ctx, uint32_t n_reads, const uint64_t* wor
  * Flat little-endian weight file written by tools/export_weights.py (stands in for
  * tch::CModule::load_on_device, inference.rs:185). */
 int herro_load_model(herro_ctx* ctx, const char* path);
-/* precision of the model GEMMs: 0 = f32 MFMA (exact f32), 1 = bf16x3 split MFMA (default; transformer stack
- * fused into one kernel when every window has <= 64 informative rows), 2 = f32 VALU, 3 = bf16x3 with the
- * stack run layer by layer (what mode 1 falls back to). */
+/* Operand format of the model GEMMs (accumulation is f32 in every mode; the contract is |logit error| <= 1e-3):
+ *   0  f32 MFMA (exact f32)                                   2  f32 VALU (debug reference)
+ *   1  bf16 hi/lo split of both operands, 3 MFMAs per product (~1e-5), transformer stack fused into one kernel
+ *   3  the same arithmetic, layer by layer (what windows with > 64 informative rows run in modes 1, 4, 5)
+ *   4  f16: conv2 / FC / attention on single f16 operands, the four GEMMs of every encoder layer on activation hi + lo
+ *      (2 MFMAs), heads on three terms — 5.5e-4 max on 36 k rows; the DEFAULT when the model has the tuned shapes
+ *   5  f16, single terms everywhere but the heads (7.6e-4: measured, not a default)
+ * herro_load_model picks 4 (or 1 when the model's shapes have no f16 kernels) unless this was called before. */
 int herro_set_precision(herro_ctx* ctx, int mode);
 
 /* ---- job = a set of target reads with their alignments -------------------------------------

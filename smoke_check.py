@@ -1,4 +1,5 @@
-"""smoke(): one small invocation of the hot path on cuda:0, checked against the oracle."""
+"""smoke(): one small invocation of the hot path on cuda:0, checked against the oracle (oracle/ and tests/ helpers are
+checker code: this file lives next to __graft_entry__.py, outside the herro_amd package, which imports none of it)."""
 from __future__ import annotations
 
 import os
@@ -6,7 +7,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.abspath(__file__))
 
 
 def run() -> None:
@@ -22,6 +23,7 @@ def run() -> None:
     ctx = api.Context(0)
     path, raw = model_io.default_model_file(os.path.join(ROOT, "tests", "_cache"))
     ctx.load_model(path)
+    ctx.set_precision(api.DEFAULT_PRECISION)
     ctx.set_reads(sb.seq, sb.qual, sb.off)
     job = api.job_from_synth(ctx, sb, W)
     job.featurize()
