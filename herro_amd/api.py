@@ -327,7 +327,9 @@ class Job:
 
     def consensus_fasta(self, t: int, read_id: str, desc: str | None = None) -> str:
         cap = 1 << 24
-        out = C.create_string_buffer(cap)
+        out = getattr(self, "_fasta_buf", None)
+        if out is None:                     # one buffer per job: allocating (and zeroing) 16 MB per target dominated multi-target runs
+            out = self._fasta_buf = C.create_string_buffer(cap)
         n = self._l.herro_job_consensus_fasta(self.h, t, read_id.encode(), None if desc is None else desc.encode(), out, cap)
         if n < 0:
             self.ctx._chk(int(n))

@@ -20,6 +20,7 @@ def ctx():
         path, raw = model_io.default_model_file(CACHE)
         c.load_model(path)
         _CTX["c"], _CTX["raw"] = c, raw
+    _CTX["c"].set_precision(api.DEFAULT_PRECISION)   # every test starts from the shipped default, whatever the previous one selected
     return _CTX["c"]
 
 

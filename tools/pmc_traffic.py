@@ -3,7 +3,7 @@
 slots, FETCH_SIZE costs 3 and WRITE_SIZE 2).  Units: rocprofv3 reports KiB.  gfx950 correction
 (MI355X_MICROARCH.md §HBM): FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads -> doubled in
 `hbm_bytes_corrected`; WRITE_SIZE is used as reported (uncalibrated).
-usage: pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv GROUP out.json"""
+usage: pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv GROUP out.json [PRECISION]"""
 import collections
 import csv
 import json
@@ -14,7 +14,7 @@ def avg(path, counter):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("herro::", "").split("<")[0]
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("herro::", "").replace("(anonymous namespace)::", "").split("<")[0]
             agg[name].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
@@ -23,8 +23,9 @@ f, w = avg(sys.argv[1], "FETCH_SIZE"), avg(sys.argv[2], "WRITE_SIZE")
 rename = {"k_ow_stats": "ow_stats", "k_win_rank": "win_rank", "k_pass1_pos": "pass1_pos", "k_select_layout": "select_layout",
           "k_final_tiles": "final_tiles", "k_sup_compact": "sup_compact", "k_patch_conv1_s": "patch_conv1",
           "k_tile_plan": "tile_plan", "k_rf_quals": "rf_quals", "k_conv_w": "conv_fused", "k_gemm_g": "fc_gemm",
-          "k_layers": "layers_fused", "k_final_tiles_t": "final_tiles", "k_gemm_g256": "fc_gemm", "k_add_pe": "add_pe", "k_build_tokens": "build_tokens", "k_consensus": "consensus"}
-out = {"group": int(sys.argv[3]), "unit": "bytes per launch", "kernels": {}}
+          "k_layers": "layers_fused", "k_final_tiles_t": "final_tiles", "k_gemm_g256": "fc_gemm", "k_add_pe": "add_pe", "k_build_tokens": "build_tokens", "k_consensus": "consensus",
+          "k_conv_h": "conv_fused", "k_fc_h": "fc_gemm", "k_layers_h": "layers_fused", "k_layers_p": "layers_fused", "k_build_tokens_h": "build_tokens"}
+out = {"group": int(sys.argv[3]), "precision": int(sys.argv[5]) if len(sys.argv) > 5 else 4, "unit": "bytes per launch", "kernels": {}}
 for k in sorted(set(f) | set(w)):
     fb, wb = f.get(k, 0.0) * 1024, w.get(k, 0.0) * 1024
     out["kernels"][rename.get(k, k)] = {"fetch_bytes_raw": fb, "write_bytes": wb, "hbm_bytes_corrected": 2 * fb + wb}
