@@ -333,7 +333,7 @@ class Job:
         n = self._l.herro_job_consensus_fasta(self.h, t, read_id.encode(), None if desc is None else desc.encode(), out, cap)
         if n < 0:
             self.ctx._chk(int(n))
-        return out.raw[:n].decode()
+        return C.string_at(out, n).decode()   # (out.raw would copy the whole 16 MB buffer per call)
 
     def stats(self) -> dict[str, int]:
         o = np.zeros(6, np.uint64)

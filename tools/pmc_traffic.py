@@ -14,7 +14,7 @@ def avg(path, counter):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("herro::", "").replace("(anonymous namespace)::", "").split("<")[0]
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("herro::", "").split("<")[0]
             agg[name].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
