@@ -982,20 +982,6 @@ struct __attribute__((aligned(16))) TileHdr {  // 64 B
   uint64_t pad2;
 };
 
-// Per-column constants of the token kernel's cell loop, pre-digested here (one thread per tile x column) and read there
-// by SCALAR loads: the kernel used to build them in LDS and read them back per cell (two broadcast 16-byte reads out of
-// ~20 LDS cycles per cell — and the cell loop is LDS-throughput bound: 6 LDS instructions per cell x 7936 cells per tile).
-struct __attribute__((aligned(16))) CDesc {
-  int32_t off;        // uu = p - off
-  uint32_t t_total;   // 0: every cell of this column is '.' in this tile
-  uint32_t uu_clamp;  // uu used for cells outside the overlap (keeps every LDS address inside the staged data)
-  int32_t bm_base;    // byte offset into S.bm of bitmap word 0 of the overlap
-  int32_t md_base;    // byte offset into S.md of op entry with rank 0
-  int32_t sbase_rel;  // stored index of query base q, relative to the first staged base: sbase_rel + sdir * q
-  int32_t sdir;
-  uint32_t tokc;      // strand ? 3 : 0 | (strand ? 5 : 0) << 8 | gap token << 16
-};
-
 __global__ __launch_bounds__(NT) void k_tile_plan(JobDev J) {
   const uint32_t idx = blockIdx.x * NT + threadIdx.x;
   const uint32_t tile = idx >> 5, c = idx & 31u;
@@ -1057,24 +1043,6 @@ __global__ __launch_bounds__(NT) void k_tile_plan(JobDev J) {
     }
   }
   J.tplan[(uint64_t)tile * 32 + c] = t;
-  {
-    CDesc cd;
-    cd.off = 0; cd.t_total = 0; cd.uu_clamp = 0; cd.bm_base = (int32_t)(c * BMW * 8); cd.md_base = (int32_t)(c * MDS * 16);
-    cd.sbase_rel = 0; cd.sdir = 1; cd.tokc = (uint32_t)TOK_GAP_F << 16;
-    const bool live = t.ow != 0xffffffffu && !(t.cnt >> 30) && t.t_total != 0;   // staged column (not outside, not fallback)
-    if (live) {
-      const bool strand = (t.sdir_strand & 1u) != 0;
-      cd.off = t.off;
-      cd.t_total = t.t_total;
-      cd.uu_clamp = t.w0 << 5;
-      cd.bm_base = (int32_t)(c * BMW * 8) - (int32_t)(t.w0 * 8);
-      cd.md_base = (int32_t)(c * MDS * 16) - (int32_t)((t.r0 + 1u) * 16);
-      cd.sbase_rel = t.sbase - (int32_t)(t.word0 << 5);
-      cd.sdir = (t.sdir_strand & 2u) ? -1 : 1;
-      cd.tokc = strand ? (3u | (5u << 8) | ((uint32_t)TOK_GAP_R << 16)) : ((uint32_t)TOK_GAP_F << 16);
-    }
-    J.cdesc[(uint64_t)tile * 32 + c] = cd;
-  }
 }
 
 
@@ -1227,6 +1195,17 @@ __global__ __launch_bounds__(NT) void k_final_tiles(JobDev J) {
 // rare global-memory fallback columns are patched in a second loop); the 2-bit code comes from a byte read
 // instead of 64-bit shifts; the stored index is one 24-bit multiply-add; tokens go straight into the LDS
 // transpose tile with ds_write_b8 at a compile-time offset; symbol counts are 6-bit fields of one register.
+struct __attribute__((aligned(16))) CDesc {
+  int32_t off;        // uu = p - off
+  uint32_t t_total;   // 0: every cell of this column is '.' in this tile
+  uint32_t uu_clamp;  // uu used for cells outside the overlap (keeps every LDS address inside the staged data)
+  int32_t bm_base;    // byte offset into S.bm of bitmap word 0 of the overlap
+  int32_t md_base;    // byte offset into S.md of op entry with rank 0
+  int32_t sbase_rel;  // stored index of query base q, relative to the first staged base: sbase_rel + sdir * q
+  int32_t sdir;
+  uint32_t tokc;      // strand ? 3 : 0 | (strand ? 5 : 0) << 8 | gap token << 16
+};
+
 // One workgroup per tile.  (A persistent, software-pipelined variant — plan of tile i+2 and data of tile i+1
 // prefetched into registers under tile i's cell loop — was built and measured 1.7x SLOWER: 156 VGPRs, three
 // workgroups per CU and four barriers per tile cost more than the round trips it hid.)
@@ -1266,6 +1245,7 @@ __global__ __launch_bounds__(NT) void k_final_tiles_t(JobDev J) {
   __shared__ uint2 s_bm[(HERRO_ROWS - 1) * BMW];
   __shared__ uint4 s_md[(HERRO_ROWS - 1) * MDS];
   __shared__ uint64_t s_words[HERRO_ROWS * WW];  // 30 columns + the target (slot 30)
+  __shared__ CDesc s_cd[32];
   __shared__ __attribute__((aligned(16))) uint8_t s_tb[HERRO_ROWS * TLD];
   __shared__ uint32_t s_fb_ow[32];
   __shared__ uint32_t s_anyfb;
@@ -1281,7 +1261,6 @@ __global__ __launch_bounds__(NT) void k_final_tiles_t(JobDev J) {
   // round trip 2: row map entry, rank directory words, op entries, 2-bit words
   TileData d;
   tile_fetch(J, th, pl0, sc, l8, d);
-  const CDesc* __restrict__ cdp = J.cdesc + (uint64_t)tile * 32;
   const unsigned char* bm_bytes = reinterpret_cast<const unsigned char*>(s_bm);
   const unsigned char* md_bytes = reinterpret_cast<const unsigned char*>(s_md);
   const uint8_t* w_bytes = reinterpret_cast<const uint8_t*>(s_words);
@@ -1305,7 +1284,24 @@ __global__ __launch_bounds__(NT) void k_final_tiles_t(JobDev J) {
 #pragma unroll
       for (int k = 0; k < 2; k++) if (l8 + 8 * k < nw) s_words[slot * WW + l8 + 8 * k] = d.vw[k];
       if (threadIdx.x == 0) s_anyfb = 0;
-      if (l8 == 0 && sc < HERRO_ROWS - 1) s_fb_ow[sc] = (pl0.ow != 0xffffffffu && fb) ? pl0.ow : 0xffffffffu;
+      if (l8 == 0 && sc < HERRO_ROWS - 1) {
+        CDesc cd;
+        cd.off = 0; cd.t_total = 0; cd.uu_clamp = 0; cd.bm_base = (int32_t)(sc * BMW * 8); cd.md_base = (int32_t)(sc * MDS * 16);
+        cd.sbase_rel = 0; cd.sdir = 1; cd.tokc = (uint32_t)TOK_GAP_F << 16;
+        if (live) {
+          const bool strand = (pl0.sdir_strand & 1u) != 0;
+          cd.off = pl0.off;
+          cd.t_total = pl0.t_total;
+          cd.uu_clamp = pl0.w0 << 5;
+          cd.bm_base = (int32_t)(sc * BMW * 8) - (int32_t)(pl0.w0 * 8);
+          cd.md_base = (int32_t)(sc * MDS * 16) - (int32_t)((pl0.r0 + 1u) * 16);
+          cd.sbase_rel = pl0.sbase - (int32_t)(pl0.word0 << 5);
+          cd.sdir = (pl0.sdir_strand & 2u) ? -1 : 1;
+          cd.tokc = strand ? (3u | (5u << 8) | ((uint32_t)TOK_GAP_R << 16)) : ((uint32_t)TOK_GAP_F << 16);
+        }
+        s_cd[sc] = cd;
+        s_fb_ow[sc] = (pl0.ow != 0xffffffffu && fb) ? pl0.ow : 0xffffffffu;
+      }
     }
     __syncthreads();
     if (l8 == 0 && sc < HERRO_ROWS - 1 && pl0.ow != 0xffffffffu && (pl0.cnt >> 31)) s_anyfb = 1;  // after thread 0's reset
@@ -1329,6 +1325,9 @@ __global__ __launch_bounds__(NT) void k_final_tiles_t(JobDev J) {
       // Columns are taken CG at a time, phase by phase (descriptor + rank word -> op entry -> base byte -> token): a cell is
       // a chain of four dependent LDS reads, and column after column that chain ran strictly in sequence (~4 x 64+ cycles
       // per cell with nothing else of the wave in flight); in groups, CG chains overlap.
+      // (Measured and rejected: the per-column constants pre-digested by k_tile_plan and read here by scalar loads instead of
+      // two broadcast LDS reads per cell: 919 -> 1030 us — scalar-load latency inside the loop and SGPR spills cost more than
+      // the LDS cycles they saved, and k_tile_plan paid 20 us for writing them.)
       constexpr uint32_t CG = 5;
       static_assert((HERRO_ROWS - 1) % CG == 0, "column groups");
       if (!(J.dbg & 1u))
@@ -1340,8 +1339,8 @@ __global__ __launch_bounds__(NT) void k_final_tiles_t(JobDev J) {
         bool inr[CG], isb[CG];
 #pragma unroll
         for (uint32_t g = 0; g < CG; g++) {
-          const uint4 d0 = *reinterpret_cast<const uint4*>(&cdp[c0 + g - 1]);          // uniform address: scalar loads
-          d1[g] = *(reinterpret_cast<const uint4*>(&cdp[c0 + g - 1]) + 1);
+          const uint4 d0 = *reinterpret_cast<const uint4*>(&s_cd[c0 + g - 1]);
+          d1[g] = *(reinterpret_cast<const uint4*>(&s_cd[c0 + g - 1]) + 1);
           const uint32_t uu_raw = (uint32_t)(p - (int32_t)d0.x);
           inr[g] = uu_raw < d0.y;
           uu[g] = inr[g] ? uu_raw : d0.z;

@@ -988,7 +988,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   const size_t o_keep = take(n_ow), o_acc = take((uint64_t)n_ow * 4), o_ttot = take((uint64_t)n_ow * 4);
   const size_t o_slot = take((uint64_t)n_ow * 4), o_rqid = take((uint64_t)n_ow * 4), o_sel = take((uint64_t)n_win * 32 * 4);
   const size_t tplan_bytes = (size_t)J.n_tiles * 32 * 64;
-  const size_t o_tplan = take(tplan_bytes), o_thdr = take((size_t)J.n_tiles * 64), o_cdesc = take((size_t)J.n_tiles * 32 * 32), o_dcounts = take((uint64_t)n_win * 12);
+  const size_t o_tplan = take(tplan_bytes), o_thdr = take((size_t)J.n_tiles * 64), o_dcounts = take((uint64_t)n_win * 12);
   const size_t o_rop = take(pos_elems * 4), o_rmap = take(row_elems * 4), o_sflag = take(row_elems);
   const size_t o_cseq = take(row_elems), o_ctmp = take(row_elems), o_clen = take((uint64_t)n_win * 4);
   const size_t o_srow = take(row_elems * 4), o_spi = take(row_elems * 4);
@@ -1010,7 +1010,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.md = (uint4*)(db + o_md); J.bm = (uint2*)(db + o_bm); J.chdr = (ColHdr*)(db + o_chdr);
   J.ow_keep = (uint8_t*)(db + o_keep); J.ow_acc = (float*)(db + o_acc); J.ow_ttotal = (uint32_t*)(db + o_ttot);
   J.slot_ow = (uint32_t*)(db + o_slot); J.rank_qid = (uint32_t*)(db + o_rqid); J.sel_ow = (uint32_t*)(db + o_sel);
-  J.tplan = (struct herro::TPlan*)(db + o_tplan); J.thdr = (struct herro::TileHdr*)(db + o_thdr); J.cdesc = (struct herro::CDesc*)(db + o_cdesc);
+  J.tplan = (struct herro::TPlan*)(db + o_tplan); J.thdr = (struct herro::TileHdr*)(db + o_thdr);
   job->d_counts = (uint32_t*)(db + o_dcounts);
   J.win_Lf = job->d_counts; J.win_nsup = job->d_counts + n_win; J.win_nkept = job->d_counts + 2ull * n_win;
   J.row_of_pos2 = (uint32_t*)(db + o_rop); J.rowmap2 = (uint32_t*)(db + o_rmap); J.sup_flag = (uint8_t*)(db + o_sflag);

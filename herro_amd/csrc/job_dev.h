@@ -59,7 +59,6 @@ struct JobDev {
   ColHdr* chdr;          // [ow]
   struct TPlan* tplan;   // [tile * 32 + c] staging plan of final-row tile x selected column (64 B)
   struct TileHdr* thdr;  // [tile] window / row range / target words of the tile (64 B)
-  struct CDesc* cdesc;   // [tile * 32 + c] per-column constants of the tile kernel's cell loop (32 B), read by scalar loads
   uint8_t* ow_keep;      // long-indel filter verdict
   float* ow_acc;         // accuracy
   uint32_t* ow_ttotal;   // target bases consumed by the slice
