@@ -28,6 +28,16 @@ using namespace herro;
 namespace {
 std::string g_create_err;
 
+// Last-error text of a context.  Job creation may run on a second thread (herro_amd.h, "Threading"), so assignment is
+// serialised; the text read back is the most recent failure of either thread, kept in a buffer that only assignment replaces.
+struct ErrSlot {
+  std::mutex mu;
+  std::string s;
+  ErrSlot& operator=(const std::string& v) { std::lock_guard<std::mutex> lk(mu); s = v; return *this; }
+  ErrSlot& operator=(const char* v) { std::lock_guard<std::mutex> lk(mu); s = v; return *this; }
+  const char* c_str() const { return s.c_str(); }
+};
+
 #define HIP_TRY(ctx, expr)                                                              \
   do {                                                                                  \
     hipError_t _e = (expr);                                                             \
@@ -108,7 +118,7 @@ struct Arena { void* p = nullptr; size_t cap = 0; };
 struct herro_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
-  std::string err;
+  ErrSlot err;
   // read store
   uint32_t n_reads = 0;
   std::vector<uint32_t> read_len, name_class;
@@ -138,7 +148,7 @@ struct herro_ctx {
   std::unique_ptr<HostPool> pool;
   std::mutex arena_mu;
   std::vector<Arena> free_dev, free_pin, free_small;   // free_small: the buffers a job needs only once its counts are known (logits, batch descriptors)
-  uint32_t live_jobs = 0;
+  std::atomic<uint32_t> live_jobs{0};   // herro_job_create may run on another thread than the context's execution calls
   uint64_t reads_gen = 0;   // bumped by herro_set_reads: a job built on an older store refuses to run
 };
 
@@ -1049,7 +1059,7 @@ int herro_job_skipped(const herro_job* job, uint32_t* n_alignments, uint32_t* n_
 void herro_job_free(herro_job* job) {
   if (!job) return;
   herro_ctx* ctx = job->ctx;
-  if (ctx->live_jobs) ctx->live_jobs--;
+  if (ctx->live_jobs.load()) ctx->live_jobs--;
   if (ctx->host_only) {
     std::lock_guard<std::mutex> lk(ctx->arena_mu);
     if (job->pin.p) { if (ctx->free_pin.size() < 6) ctx->free_pin.push_back(job->pin); else std::free(job->pin.p); }

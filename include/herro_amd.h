@@ -109,6 +109,9 @@ int herro_set_precision(herro_ctx* ctx, int mode);
  * `extract_windows` (windowing.rs:44-273) for every alignment on the host, converts CIGARs to a
  * binary op stream and uploads the descriptors (one pinned block, one asynchronous copy; job memory is recycled through
  * per-context arenas, the host work runs on a per-context thread pool of HERRO_HOST_THREADS, default min(cores, 64)).
+ * Threading: a context's execution calls (featurize / infer / consensus / accessors) belong to one thread; herro_job_create
+ * (host work + one asynchronous upload) may run on a SECOND thread of the same context at the same time, so that the next
+ * job is built while the current one executes (bench.py end_to_end does this).
  * Alignments of target t are
  * alns[aln_off[t] .. aln_off[t+1]); every alignment must have tid == rids[t] (overlaps.rs:189-192).
  * window_size: the `-w` flag (main.rs:69-74); 16 <= window_size <= 8192 here. */
