@@ -50,7 +50,7 @@ def cpu_baseline(seed: int) -> dict:
     import model_ref as MR
     import torch
     from herro_amd import model_io, synth
-    cores = os.cpu_count() or 1
+    cores = synth.usable_cpus()   # = worker threads used below
     n_tgt = max(24, min(4 * cores, 1024))
     sb = synth.generate_parallel(n_tgt, WINS_PER_TARGET * W, N_OVL, seed=seed, chunk=32)
     store = O.store_from_synth(sb)
@@ -88,7 +88,8 @@ def cpu_baseline(seed: int) -> dict:
             "sample": f"pipelined stages, rate of the slower one: oracle extract_features on {sb.n_targets * WINS_PER_TARGET} windows "
                       f"({workers} threads: {feat_all:.0f} win/s; 4 threads, the reference's -t 4: {feat_t4:.0f} win/s) | dense PyTorch-CPU fp32 "
                       f"twin of the assumed architecture, warmed, one batch of {mb} windows ({cores} threads: {model_rate:.2f} win/s). "
-                      "The reference itself runs the model on a GPU through libtorch; this is the same algorithm on the host cores"}
+                      "The reference itself runs the model on a GPU through libtorch; this is the same algorithm on the host cores "
+                      f"(usable CPUs {cores} of {os.cpu_count()} hardware threads: affinity / cgroup quota)"}
 
 
 def self_check(job, sb, targets, n_check: int, seed: int) -> dict:
@@ -140,6 +141,9 @@ def main():
                          "reference's concurrent feature / inference threads per device (lib.rs:154-200)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--windows", type=int, default=0, help="--scaling strong: total windows of the fixed job (default steps * batch)")
+    ap.add_argument("--e2e-mode", choices=["serial", "producer"], default="serial",
+                    help="end_to_end feeders: 'serial' = one thread per context (create k+1, then execute k); 'producer' = a second "
+                         "thread per context builds jobs ahead")
     ap.add_argument("--e2e-jobs", type=int, default=3, help="jobs per feeder thread in the end_to_end leg (0: skip it)")
     ap.add_argument("--self-check", type=int, default=6, help="targets compared with the oracle after the timing (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -273,13 +277,37 @@ def main():
         stats = [None] * NS
         prep = api.PreparedAlignments(sb)   # the parsed alignments of the data set, resident on the host (outside the timed region)
 
+        def feeder_serial(s_i, ids, timed):
+            # one thread per context: create(k+1) on the host while the GPU works on job k
+            c = ctxs[s_i]
+            host, bases, prev = 0.0, 0, None
+            for i in ids:
+                t_h = time.perf_counter()
+                j = prep.job(c, i * tpj, (i + 1) * tpj, W)
+                host += time.perf_counter() - t_h
+                j.featurize()
+                if prev is not None:
+                    prev.infer(args.batch, 1)
+                    prev.consensus()
+                    bases += prev.consensus_fetch()                                   # D2H of the corrected bases (synchronises)
+                    prev.close()
+                prev = j
+            prev.infer(args.batch, 1)
+            prev.consensus()
+            bases += prev.consensus_fetch()
+            prev.close()
+            if timed:
+                stats[s_i] = (host, bases)
+
         def feeder(s_i, ids, timed):
+            if args.e2e_mode == "serial":
+                return feeder_serial(s_i, ids, timed)
             # two threads per context: a producer builds jobs from the host alignments (CIGAR parse, windowing, one async
-            # upload) up to two ahead; this thread executes them.  Creation therefore overlaps both the GPU work and this
+            # upload) ahead of time; this thread executes them.  Creation therefore overlaps both the GPU work and this
             # thread's waits (per-window counts, D2H of the corrected bases).
             import queue
             c = ctxs[s_i]
-            q = queue.Queue(maxsize=2)
+            q = queue.Queue(maxsize=1)   # at most four live jobs per context: executing, featurized, queued, being built
             host = [0.0]
 
             def producer():
@@ -315,9 +343,10 @@ def main():
                 t.join()
             for c in ctxs:
                 c.synchronize()
-        # untimed pass over two already-seen target ranges per feeder: a feeder holds two jobs at a time, and the first jobs of
-        # a context pay for their arenas (hipMalloc of ~1.2 GB, page-locking ~70 MB); a long-running host recycles them
-        run_feeders([[s_i * pool, s_i * pool + (1 % pool)] for s_i in range(NS)], False)
+        # untimed pass over already-seen target ranges: a context holds up to four jobs at a time, and the first jobs of a
+        # context pay for their arenas (hipMalloc of ~1.2 GB, page-locking ~70 MB each); a long-running host recycles them
+        n_warm = 6
+        run_feeders([[s_i * pool + (k % pool) for k in range(n_warm)] for s_i in range(NS)], False)
         barrier()
         t1 = time.perf_counter()
         run_feeders([[n_jobs + s_i * per + k for k in range(per)] for s_i in range(NS)], True)
@@ -330,12 +359,14 @@ def main():
         n_w = n_e2e * G * args.batch
         host_s = sum(s[0] for s in stats)
         e2e = {"windows_per_s": n_w * world / el2, "mbases_per_s": sum(s[1] for s in stats) * world / el2 / 1e6,
-               "windows": n_w * world, "jobs_per_feeder": per, "feeders_per_gpu": NS,
+               "windows": n_w * world, "jobs_per_feeder": per, "feeders_per_gpu": NS, "warmup_jobs_per_feeder": n_warm,
                "host_prepare_windows_per_s_per_feeder": n_w / NS / (host_s / NS) if host_s else None,
                "note": "herro_job_create from host alignments (CIGAR parse + windowing on the context's thread pool, one pinned block, "
                        "one async H2D) + featurize + infer + consensus + D2H of the corrected bases, all inside the timed region; "
                        "fresh inputs per job; the alignments are resident on the host as one parsed array (what the reference's reader thread "
-                       "hands over, lib.rs:141-151); per context one thread builds jobs (up to two ahead), one executes them"}
+                       "hands over, lib.rs:141-151); " + ("per context one thread builds jobs ahead, one executes them" if args.e2e_mode == "producer"
+                                                     else "one feeder thread per context: create(k+1) runs on the host while the GPU works on job k"),
+               "mode": args.e2e_mode}
 
     # ---- per-kernel durations with HIP events on the launch stream (separate pass, same jobs, single stream, so
     # that kernel durations are not inflated by the other stream's kernels)

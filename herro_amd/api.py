@@ -156,7 +156,7 @@ class Context:
         self._l = lib()
         self.h = self._l.herro_create(device)
         if not self.h:
-            raise HerroError(-2, self._l.herro_last_error(None).decode())
+            raise HerroError(-2, self._l.herro_last_error(None).decode(errors="replace"))
 
     def close(self):
         if getattr(self, "h", None):
@@ -167,7 +167,7 @@ class Context:
 
     def _chk(self, rc: int):
         if rc != 0:
-            raise HerroError(rc, self._l.herro_last_error(self.h).decode())
+            raise HerroError(rc, self._l.herro_last_error(self.h).decode(errors="replace"))
 
     def set_stream(self, hip_stream: int | None):
         self._chk(self._l.herro_set_stream(self.h, hip_stream))
@@ -216,7 +216,7 @@ class Context:
             view["p"][:n] = base + np.asarray(cig_off, np.uint64)
         h = self._l.herro_job_create(self.h, len(rids), rids.ctypes.data, aln_off.ctypes.data, C.byref(arr), window_size)
         if not h:
-            msg = self._l.herro_last_error(self.h).decode()
+            msg = self._l.herro_last_error(self.h).decode(errors="replace")
             code = -1
             if "[code " in msg:
                 code = int(msg.rsplit("[code ", 1)[1].rstrip("]"))
@@ -228,7 +228,7 @@ class Context:
         h = self._l.herro_job_create(self.h, len(paf.targets), paf.targets.ctypes.data, paf.aln_off.ctypes.data,
                                      paf._alns_ptr, window_size)
         if not h:
-            msg = self._l.herro_last_error(self.h).decode()
+            msg = self._l.herro_last_error(self.h).decode(errors="replace")
             code = int(msg.rsplit("[code ", 1)[1].rstrip("]")) if "[code " in msg else -1
             raise HerroError(code, msg)
         return Job(self, h, len(paf.targets))
@@ -437,7 +437,7 @@ class PreparedAlignments:
         h = ctx._l.herro_job_create(ctx.h, t1 - t0, self.rids.ctypes.data + 4 * t0, self.aln_off.ctypes.data + 8 * t0,
                                     C.byref(self._arr), window_size)
         if not h:
-            msg = ctx._l.herro_last_error(ctx.h).decode()
+            msg = ctx._l.herro_last_error(ctx.h).decode(errors="replace")
             code = int(msg.rsplit("[code ", 1)[1].rstrip("]")) if "[code " in msg else -1
             raise HerroError(code, msg)
         return Job(ctx, h, t1 - t0)

@@ -28,6 +28,15 @@ using namespace herro;
 namespace {
 std::string g_create_err;
 
+// HERRO_HOST_PROFILE=2: one stderr line per API call with its start time and duration (host-side timeline of a pipeline).
+struct ProfSpan {
+  static int level() { static const int l = [] { const char* e = getenv("HERRO_HOST_PROFILE"); return e ? atoi(e) : 0; }(); return l; }
+  static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  const void* who; const char* name; double t0;
+  ProfSpan(const void* w, const char* n) : who(w), name(n), t0(level() >= 2 ? now_ms() : 0) {}
+  ~ProfSpan() { if (level() >= 2) { const double t1 = now_ms(); fprintf(stderr, "TL %p %-14s %.3f %.3f\n", who, name, fmod(t0, 1e6), t1 - t0); } }
+};
+
 // Last-error text of a context.  Job creation may run on a second thread (herro_amd.h, "Threading"), so assignment is
 // serialised; the text read back is the most recent failure of either thread, kept in a buffer that only assignment replaces.
 struct ErrSlot {
@@ -225,11 +234,32 @@ struct herro_job {
 
 static int job_sync(herro_job* job);
 
+// CPUs the process may actually use: the hardware threads, capped by a cgroup CPU quota when there is one (v2 cpu.max,
+// v1 cpu.cfs_quota_us).  A container that shows 256 hardware threads under a 16-CPU quota must not get a 64-thread pool:
+// every woken thread reserves a bandwidth slice on its CPU, the quota is gone a quarter into each 100 ms period and the
+// whole process — GPU completion waits included — stands still for the rest of it (measured: 75 ms stalls, r2n timeline).
+static uint32_t usable_cpus() {
+  uint32_t n = std::max(1u, std::thread::hardware_concurrency());
+  long long quota = -1, period = 0;
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[32] = {0};
+    if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+    fclose(f);
+  } else {
+    if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+    if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = 0; fclose(g); }
+  }
+  if (quota > 0 && period > 0) n = std::min<uint32_t>(n, (uint32_t)std::max<long long>(1, (quota + period - 1) / period));
+  return n;
+}
+
 static HostPool& host_pool(herro_ctx* ctx) {
   if (!ctx->pool) {
-    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const uint32_t cpus = usable_cpus();
     const char* env = getenv("HERRO_HOST_THREADS");
-    const uint32_t want = env ? (uint32_t)std::max(1, atoi(env)) : std::min(std::max(hw / 4u, 1u), 64u);   // several contexts share the host: two pools of 128 on 256 hardware threads measured 50 ms builds (2-7 ms alone)
+    // several contexts share the host (one or two per GPU): a quarter of the hardware threads each, never more than the
+    // CPU quota.  Two pools of 128 on 256 hardware threads measured 50 ms builds (2-7 ms alone).
+    const uint32_t want = env ? (uint32_t)std::max(1, atoi(env)) : std::min(std::min(std::max(std::thread::hardware_concurrency() / 4u, 1u), 64u), cpus);
     ctx->pool = std::make_unique<HostPool>(want - 1);  // the calling thread works too
   }
   return *ctx->pool;
@@ -710,10 +740,9 @@ void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* aln
   const uint32_t n_windows = (tlen + W - 1) / W;  // features.rs:338
   if (n_windows > 65535) return fail(HERRO_E_UNSUPPORTED, "more than 65535 windows in a read (wid is u16 in the reference)");
   // collect (window, overlap) in alignment order, then bucket by window (stable)
-  struct Tmp { HostOw h; uint32_t op_base; uint32_t aln; uint32_t st, sq, si; };  // st / sq / si: target, query, insertion bases of the UNTRIMMED slice
+  struct Tmp { HostOw h; uint32_t op_base; uint32_t aln; };
   std::vector<Tmp> tmp;
-  ParsedCigar pc;
-  std::vector<uint32_t>& aops = pc.ops;
+  CigarScan cs;
   std::vector<HostOw> hows;
   std::unordered_map<uint32_t, uint32_t> cls_of_name;  // name class -> accumulator slot
   std::unordered_map<uint32_t, uint32_t> seen_qid;
@@ -726,6 +755,11 @@ void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* aln
   auto skip = [&](uint32_t a, const char* why) {
     if (!out.n_skipped++) out.first_skip = "target rid " + std::to_string(rid) + ", alignment " + std::to_string(a) + " (qid " + std::to_string(alns[a].qid) + "): " + why;
   };
+  {
+    size_t op_room = 0;
+    for (uint32_t a = 0; a < n_aln; a++) op_room += alns[a].cigar_len / 2 + 1;
+    out.ops.reserve(op_room);
+  }
   for (uint32_t a = 0; a < n_aln; a++) {
     const herro_alignment& al = alns[a];
     if (al.tid != rid) return fail(HERRO_E_INVALID, "alignment tid != target rid (parse_paf groups by target, overlaps.rs:189-192)");
@@ -736,20 +770,20 @@ void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* aln
     if (al.tlen != tlen) return fail(HERRO_E_INVALID, "alignment tlen differs from the stored read length");
     if (al.qend > ctx->read_len[al.qid] || al.tend > tlen) return fail(HERRO_E_REFERENCE_PANIC, "alignment coordinates exceed the read length");
     BuildError be;
-    if (!parse_cigar_prefix(al.cigar, al.cigar_len, pc, be)) return fail(be.code, be.msg);
-    hows.clear();
-    if (!window_alignment(aops, al, W, n_windows, hows, be)) return fail(be.code, be.msg);
-    if (!hows.empty()) {
-      bool unsupported = false;
-      for (size_t k = 0; k < hows.size() && !unsupported; k++)
-        unsupported = hows[k].op_hi > hows[k].op_lo && (op_type(aops[hows[k].op_lo]) == OP_I || pc.ins_pair_in(hows[k].op_lo, hows[k].op_hi));
-      if (unsupported) { skip(a, "a window's CIGAR slice starts with an insertion, or consecutive insertion ops (never produced by minimap2)"); continue; }
-    }
+    // the ops are decoded straight into the target's op array (one pass over the text, scan_cigar); they stay there
+    // only if the alignment contributes a window
     const uint32_t op_base = (uint32_t)out.ops.size();
-    if (!hows.empty()) out.ops.insert(out.ops.end(), aops.begin(), aops.end());
-    for (auto& h : hows)
-      tmp.push_back(Tmp{h, op_base, a, h.op_hi >= h.op_lo ? pc.pt[h.op_hi] - pc.pt[h.op_lo] : 0u, h.op_hi >= h.op_lo ? pc.pq[h.op_hi] - pc.pq[h.op_lo] : 0u,
-                        h.op_hi >= h.op_lo ? pc.pi[h.op_hi] - pc.pi[h.op_lo] : 0u});
+    out.ops.resize((size_t)op_base + al.cigar_len / 2 + 1);
+    const uint32_t* aops = out.ops.data() + op_base;
+    if (!scan_cigar(al.cigar, al.cigar_len, al.tstart, W, out.ops.data() + op_base, cs, be)) return fail(be.code, be.msg);
+    hows.clear();
+    if (!window_cuts(aops, cs, al, W, n_windows, hows, be)) return fail(be.code, be.msg);
+    bool unsupported = false;
+    for (size_t k = 0; k < hows.size() && !unsupported; k++)
+      unsupported = hows[k].op_hi > hows[k].op_lo && (op_type(aops[hows[k].op_lo]) == OP_I || cs.ins_pair_in(hows[k].op_lo, hows[k].op_hi));
+    out.ops.resize((size_t)op_base + (hows.empty() || unsupported ? 0u : cs.n_ops));
+    if (unsupported) { skip(a, "a window's CIGAR slice starts with an insertion, or consecutive insertion ops (never produced by minimap2)"); continue; }
+    for (auto& h : hows) tmp.push_back(Tmp{h, op_base, a});
     const uint32_t nc = ctx->name_class[al.qid];
     if (!cls_of_name.count(nc)) cls_of_name[nc] = out.n_cls++;
   }
@@ -807,7 +841,7 @@ void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* aln
     // start_off bases, its last op counts end_off bases (effective-op-length rule, features.rs:82-90); the insertion
     // total stays untrimmed (get_max_ins, features.rs:64-79).  The slice never starts with I (checked per alignment).
     const uint32_t op_f = out.ops[d.op_begin], op_l = out.ops[d.op_begin + d.op_cnt - 1];
-    uint64_t tt = x.st, qq = x.sq;
+    uint64_t tt = x.h.st, qq = x.h.sq;
     if (d.op_cnt == 1) {
       if (d.end_off <= d.start_off) return fail(HERRO_E_REFERENCE_PANIC, "cigar_end_offset <= cigar_start_offset");
       const uint32_t e1 = d.end_off - d.start_off, l1 = op_len(op_f);
@@ -822,7 +856,7 @@ void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* aln
       if (op_type(op_l) != OP_I) tt = tt - ll + d.end_off;
       if (op_type(op_l) != OP_D) qq = qq - ll + d.end_off;
     }
-    ins_sum[wi] += x.si;
+    ins_sum[wi] += x.h.si;
     if ((uint64_t)(d.tstart - win_start) + tt > win_len) return fail(HERRO_E_REFERENCE_PANIC, "cigar slice overruns the target window");
     if (qq > d.qlen) return fail(HERRO_E_REFERENCE_PANIC, "cigar slice overruns the query region");
     if ((uint64_t)d.qbeg + d.qlen > ctx->read_len[al.qid]) return fail(HERRO_E_REFERENCE_PANIC, "query region exceeds the query read");
@@ -860,6 +894,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   if (!ctx->host_only && hipSetDevice(ctx->device) != hipSuccess) return fail(HERRO_E_NO_DEVICE, "hipSetDevice failed");
 
   const bool prof = getenv("HERRO_HOST_PROFILE") != nullptr;
+  ProfSpan span_(ctx, "create");
   auto tnow = [] { return std::chrono::steady_clock::now(); };
   auto t_begin = tnow();
   auto job = std::make_unique<herro_job>();
@@ -1066,6 +1101,7 @@ void herro_job_free(herro_job* job) {
     delete job;
     return;
   }
+  ProfSpan span_(ctx, "destroy");
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);   // nothing of this job is in flight once its memory is recycled
   {
@@ -1088,6 +1124,7 @@ int herro_job_featurize(herro_job* job) {
   if (!job) return HERRO_E_INVALID;
   herro_ctx* ctx = job->ctx;
   if (job->reads_gen != ctx->reads_gen) { ctx->err = "the read store was replaced (herro_set_reads) after this job was created"; return HERRO_E_STATE; }
+  ProfSpan span_(ctx, "featurize");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   // everything derived from a previous pass over this job is stale from here on
   job->synced = false; job->inferred = false; job->quals_full = false;
@@ -1111,7 +1148,7 @@ static int job_sync(herro_job* job) {
   if (job->synced) return HERRO_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint32_t n = job->J.n_win;
-  if (n) HIP_TRY(ctx, hipEventSynchronize(job->ev_counts));
+  { ProfSpan span_(ctx, "wait_counts"); if (n) HIP_TRY(ctx, hipEventSynchronize(job->ev_counts)); }
   job->h_Lf.assign(job->h_counts, job->h_counts + n);
   job->h_nsup.assign(job->h_counts + n, job->h_counts + 2ull * n);
   job->h_nkept.assign(job->h_counts + 2ull * n, job->h_counts + 3ull * n);
@@ -1131,6 +1168,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   if (!job || batch_size == 0) return HERRO_E_INVALID;
   herro_ctx* ctx = job->ctx;
   if (!ctx->has_model) { ctx->err = "no model loaded"; return HERRO_E_NO_MODEL; }
+  ProfSpan span_(ctx, "infer");
   int rc = job_sync(job);
   if (rc) return rc;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1274,6 +1312,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
 int herro_job_consensus(herro_job* job) {
   if (!job) return HERRO_E_INVALID;
   herro_ctx* ctx = job->ctx;
+  ProfSpan span_(ctx, "consensus");
   int rc = job_sync(job);
   if (rc) return rc;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1422,6 +1461,7 @@ int herro_job_consensus_fetch(herro_job* job, uint64_t* n_bases) {
   if (!job) return HERRO_E_INVALID;
   herro_ctx* ctx = job->ctx;
   if (!job->consensus_done) { ctx->err = "herro_job_consensus has not run"; return HERRO_E_STATE; }
+  ProfSpan span_(ctx, "fetch");
   (void)hipSetDevice(ctx->device);
   int rc = consensus_to_host(job);
   if (rc) return rc;

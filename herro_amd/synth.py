@@ -124,6 +124,29 @@ def merge(batches: list[SynthBatch]) -> SynthBatch:
                       tgt_aln_off=np.concatenate(tgt_offs), tgt_rid=np.concatenate(tgt_rids))
 
 
+def usable_cpus() -> int:
+    """CPUs this process may use: hardware threads, the affinity mask and a cgroup CPU quota (a box that shows 256
+    threads may grant 16 CPUs of run time per period; starting 256 workers there only buys throttling)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, -(-q // p)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def generate_parallel(n_targets: int, target_len: int = 4 * 4096, n_overlaps: int = 32, *, seed: int = SEED,
                       chunk: int = 128, workers: int | None = None, **kw) -> SynthBatch:
     """`generate` for large batches: chunks of `chunk` targets are generated concurrently (the generator is a
@@ -134,7 +157,7 @@ def generate_parallel(n_targets: int, target_len: int = 4 * 4096, n_overlaps: in
     sizes = [min(chunk, n_targets - i) for i in range(0, n_targets, chunk)]
     if len(sizes) <= 1:
         return generate(n_targets, target_len, n_overlaps, seed=seed, **kw)
-    workers = workers or min(len(sizes), max(1, (os.cpu_count() or 1)), 64)
+    workers = workers or min(len(sizes), usable_cpus(), 64)
     with cf.ThreadPoolExecutor(workers) as ex:
         parts = list(ex.map(lambda iz: generate(iz[1], target_len, n_overlaps, seed=seed + 7919 * iz[0], **kw), enumerate(sizes)))
     return merge(parts)

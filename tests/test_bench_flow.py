@@ -112,8 +112,9 @@ def test_bench_flow(monkeypatch, capsys, argv, steps):
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
     if d["end_to_end"] is not None:   # job creation + D2H inside the timed region: every end-to-end job fetched its bases once
         assert d["end_to_end"]["windows_per_s"] > 0 and d["end_to_end"]["windows"] > 0
-        n_fetch = sum(1 for ev, _ in FakeJob.log if ev == "D")   # timed jobs + two untimed warm-up jobs per feeder
-        assert n_fetch == (d["end_to_end"]["jobs_per_feeder"] + 2) * d["end_to_end"]["feeders_per_gpu"]
+        n_fetch = sum(1 for ev, _ in FakeJob.log if ev == "D")   # timed jobs + the untimed warm-up jobs of each feeder
+        e = d["end_to_end"]
+        assert n_fetch == (e["jobs_per_feeder"] + e["warmup_jobs_per_feeder"]) * e["feeders_per_gpu"]
     # every job that ran went featurize -> infer -> consensus, and the timed region covered exactly `steps` batches:
     # windows run in the timed region = steps * batch; count via the log between warm-up and the kernel-timing pass is
     # not separable here, so check the invariant the pipeline relies on instead: no job is inferred twice in a row

@@ -150,3 +150,61 @@ def test_prepared_alignments_give_the_same_jobs():
         assert all(np.array_equal(a1[k], a2[k]) for k in a1)
         j1.close(); j2.close()
     c.close()
+
+
+def _hand_alignment(rng, tlen, widths):
+    """one '+' alignment of query 1 onto target 0 from position 0: random M / I / D ops (never two insertions in a row,
+    never a leading insertion), some matches long enough to need 5..7 digits; text written with `widths` zero padding"""
+    ops, t, q, prev = [], 0, 0, "I"
+    while t < tlen - 3000:
+        ty = "M" if prev != "M" else rng.choice(["I", "D"])
+        ln = int(rng.choice([1, 2, 7, 35, 120, 999, 1000, 9999, 10000, 12345])) if ty == "M" else int(rng.integers(1, 40))
+        if ty == "M":
+            ln = min(ln, tlen - 3000 - t + 1)
+        ops.append((ln, ty))
+        t += ln if ty != "I" else 0
+        q += ln if ty != "D" else 0
+        prev = ty
+    if ops[-1][1] == "I":
+        ops.pop(); q -= ops and 0  # (the popped insertion is re-counted below)
+    t = sum(l for l, y in ops if y != "I"); q = sum(l for l, y in ops if y != "D")
+    text = "".join(f"{l:0{int(rng.choice(widths))}d}{y}" for l, y in ops).encode()
+    canon = "".join(f"{l}{y}" for l, y in ops).encode()
+    row = np.array([[1, 40000, 0, q, 0, 0, tlen, 0, t]], np.uint32)
+    return row, text, canon
+
+
+@pytest.mark.parametrize("W", [64, 1000, 4096])
+def test_cigar_text_decoder_corner_cases(W):
+    """The two-stage text decoder of herro_job_create (windowing.hpp scan_cigar): 1..4 digit lengths (32-bit lane),
+    5..7 digits (64-bit lane), 8+ digits / zero padding / short text (byte-wise path) all give the ops a regular
+    expression reads, and the same descriptors as the canonical spelling; malformed text fails like CigarIter."""
+    rng = np.random.default_rng(5)
+    lens = np.array([40000, 40000], np.uint32)
+    c = api.HostContext(lens)
+    rid = np.array([0], np.uint32)
+    off = np.array([0, 1], np.uint64)
+    for widths in ([1], [1, 3], [1, 5, 7], [1, 8, 9], [4], [7], [12]):
+        row, text, canon = _hand_alignment(rng, 40000, widths)
+        j1 = c.create_job(rid, row, off, [text], W)
+        j2 = c.create_job(rid, row, off, [canon], W)
+        a1, a2 = c.job_arrays(j1), c.job_arrays(j2)
+        assert a1["ops"].tolist() == _ops(canon)[0]
+        assert len(a1["ow"]) > 0
+        for k in a2:
+            assert np.array_equal(a1[k], a2[k]), (widths, k)
+        j1.close(); j2.close()
+    # an alignment too short to give a window still has its text decoded (short strings take the byte-wise path)
+    short = np.array([[1, 40000, 0, 5, 0, 0, 40000, 0, 5]], np.uint32)
+    j = c.create_job(rid, short, off, [b"5M"], W)
+    assert len(c.job_arrays(j)["ow"]) == 0
+    j.close()
+    row, text, canon = _hand_alignment(rng, 40000, [1])
+    for bad, what in [(canon + b"12", "ends inside an op"), (b"M" + canon, "longer than 0"), (canon.replace(b"M", b"M0I", 1), "longer than 0"),
+                      (canon.replace(b"M", b"m", 1), "Unexpected cigar operation"), (canon.replace(b"M", b":", 1), "Unexpected cigar operation"),
+                      (canon.replace(b"M", b"\xc8", 1), "Unexpected cigar operation"), (canon.replace(b"D", b"=", 1), "Unexpected cigar operation"),
+                      (b"99999999999M" + canon, "overflows 30 bits")]:
+        with pytest.raises(api.HerroError) as e:
+            c.create_job(rid, row, off, [bad], W)
+        assert what in str(e.value), (bad[:30], str(e.value))
+    c.close()

@@ -8,7 +8,7 @@ from herro_amd import api, synth
 nt = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 sb = synth.generate_parallel(nt, 4 * 4096, 32, seed=7, chunk=32)
 lens = (sb.off[1:] - sb.off[:-1]).astype(np.uint32)
-for th in (1, 2, 4, 8):
+for th in [int(x) for x in os.environ.get("HOSTPREP_THREADS", "1,2,4,8").split(",")]:
     os.environ["HERRO_HOST_THREADS"] = str(th)   # read when a context starts its thread pool (first herro_job_create)
     c = api.HostContext(lens)
     os.environ["HERRO_HOST_PROFILE"] = "1" if th == 1 else ""
