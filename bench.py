@@ -253,6 +253,10 @@ def main():
         for c in ctxs:
             c.synchronize()
 
+    # the set-up above (data generation, job building) ran on every CPU the process may use; under a cgroup CPU quota the
+    # current bandwidth period may be spent, and a throttled feeder thread would stall the timed region for the rest of
+    # it (up to 100 ms).  Two periods of rest give the short, CPU-light timed region a fresh budget.
+    time.sleep(0.25)
     for s_i in range(NS):
         for i in range(max(1, (args.warmup + G * NS - 1) // (G * NS))):
             run_job(jobs[s_i][i % pool])
@@ -359,7 +363,7 @@ def main():
         n_w = n_e2e * G * args.batch
         host_s = sum(s[0] for s in stats)
         e2e = {"windows_per_s": n_w * world / el2, "mbases_per_s": sum(s[1] for s in stats) * world / el2 / 1e6,
-               "windows": n_w * world, "jobs_per_feeder": per, "feeders_per_gpu": NS, "warmup_jobs_per_feeder": n_warm,
+               "windows": n_w * world, "usable_cpus": synth.usable_cpus(), "jobs_per_feeder": per, "feeders_per_gpu": NS, "warmup_jobs_per_feeder": n_warm,
                "host_prepare_windows_per_s_per_feeder": n_w / NS / (host_s / NS) if host_s else None,
                "note": "herro_job_create from host alignments (CIGAR parse + windowing on the context's thread pool, one pinned block, "
                        "one async H2D) + featurize + infer + consensus + D2H of the corrected bases, all inside the timed region; "

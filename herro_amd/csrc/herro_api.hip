@@ -774,13 +774,12 @@ void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* aln
     // only if the alignment contributes a window
     const uint32_t op_base = (uint32_t)out.ops.size();
     out.ops.resize((size_t)op_base + al.cigar_len / 2 + 1);
-    const uint32_t* aops = out.ops.data() + op_base;
     if (!scan_cigar(al.cigar, al.cigar_len, al.tstart, W, out.ops.data() + op_base, cs, be)) return fail(be.code, be.msg);
     hows.clear();
-    if (!window_cuts(aops, cs, al, W, n_windows, hows, be)) return fail(be.code, be.msg);
+    if (!window_cuts(cs, al, W, n_windows, hows, be)) return fail(be.code, be.msg);
     bool unsupported = false;
     for (size_t k = 0; k < hows.size() && !unsupported; k++)
-      unsupported = hows[k].op_hi > hows[k].op_lo && (op_type(aops[hows[k].op_lo]) == OP_I || cs.ins_pair_in(hows[k].op_lo, hows[k].op_hi));
+      unsupported = hows[k].op_hi > hows[k].op_lo && (op_type(hows[k].op_first) == OP_I || cs.ins_pair_in(hows[k].op_lo, hows[k].op_hi));
     out.ops.resize((size_t)op_base + (hows.empty() || unsupported ? 0u : cs.n_ops));
     if (unsupported) { skip(a, "a window's CIGAR slice starts with an insertion, or consecutive insertion ops (never produced by minimap2)"); continue; }
     for (auto& h : hows) tmp.push_back(Tmp{h, op_base, a});
@@ -835,12 +834,12 @@ void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* aln
     // ---- validate what the reference would assert / index (features.rs:585-679, 110-237)
     if (x.h.op_hi <= x.h.op_lo) return fail(HERRO_E_REFERENCE_PANIC, "empty cigar slice");
     if (d.tstart < win_start) return fail(HERRO_E_REFERENCE_PANIC, "overlap starts before its window (usize underflow)");
-    if (op_type(out.ops[d.op_begin]) == OP_I)
+    if (op_type(x.h.op_first) == OP_I)
       return fail(HERRO_E_UNSUPPORTED, "cigar slice starts with an insertion (leading or consecutive I ops; the reference panics or writes into the previous position)");
     // target / query bases the TRIMMED slice consumes, from the prefix sums of the parse: the slice's first op loses
     // start_off bases, its last op counts end_off bases (effective-op-length rule, features.rs:82-90); the insertion
     // total stays untrimmed (get_max_ins, features.rs:64-79).  The slice never starts with I (checked per alignment).
-    const uint32_t op_f = out.ops[d.op_begin], op_l = out.ops[d.op_begin + d.op_cnt - 1];
+    const uint32_t op_f = x.h.op_first, op_l = x.h.op_last;
     uint64_t tt = x.h.st, qq = x.h.sq;
     if (d.op_cnt == 1) {
       if (d.end_off <= d.start_off) return fail(HERRO_E_REFERENCE_PANIC, "cigar_end_offset <= cigar_start_offset");

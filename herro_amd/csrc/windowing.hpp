@@ -26,6 +26,7 @@ struct HostOw {  // OverlapWindow (windowing.rs:7-16) with op-index slice
   uint32_t op_lo, op_hi;  // slice [op_lo, op_hi) of the alignment's ops
   uint32_t start_off, end_off;
   uint32_t st = 0, sq = 0, si = 0;  // target / query / insertion bases of the UNTRIMMED slice (window_cuts only)
+  uint32_t op_first = 0, op_last = 0;  // the ops at op_lo and op_hi - 1 (window_cuts only; 0 past the end)
 };
 
 struct BuildError {
@@ -71,9 +72,12 @@ inline bool parse_cigar(const uint8_t* s, uint32_t n, std::vector<uint32_t>& ops
 //      out, SWAR decimal conversion (three multiplies), op type from a 256-entry table.
 // Anything unusual — a length of 8+ digits, a byte that is neither digit nor M/I/D, text shorter than 8 bytes —
 // sends the whole CIGAR through the byte-wise path, which also produces the reference's panic messages.
-struct Cut { uint32_t k, t, q, ins; };   // op index; absolute target position, query and insertion bases consumed before it
+// A cut carries everything the windowing reads of the op array: the op itself and its two successors (0 past the end).
+// The scan may therefore run somewhere else than the windowing — on the GPU, cigar_dev.hip — and hand over cuts only.
+struct Cut { uint32_t k, t, q, ins, o0, o1, o2; };   // op index; absolute target position, query and insertion bases consumed before it; ops k, k + 1, k + 2
 struct CigarScan {
   uint32_t n_ops = 0, t_end = 0, q_end = 0, ins_end = 0;   // totals after the last op (t_end absolute)
+  uint32_t op0 = 0, opn = 0;                               // first and last op
   std::vector<Cut> cuts;
   std::vector<uint32_t> ins_pairs;   // every k with ops k and k + 1 both insertions (minimap2 never emits any)
   std::vector<uint32_t> pos;         // stage A scratch: letter positions
@@ -104,7 +108,7 @@ struct ScanState {
     const uint32_t mi = 0u - (uint32_t)(ty == OP_I), md = 0u - (uint32_t)(ty == OP_D);   // all-ones masks: insertion / deletion
     const uint32_t tnew = t + (len & ~mi);
     if (__builtin_expect((uint64_t)tnew >= wend, 0)) {   // ~once per window (never true for an insertion: t < wend always holds)
-      S.cuts.push_back(Cut{k, t, q, ins});
+      S.cuts.push_back(Cut{k, t, q, ins, ops[k], 0, 0});
       wend = ((uint64_t)(tnew / W) + 1) * W;
     }
     if (__builtin_expect(mi & prev_i, 0)) S.ins_pairs.push_back(k - 1);
@@ -114,7 +118,11 @@ struct ScanState {
     prev_i = mi;
     k++;
   }
-  void finish() { S.n_ops = k; S.t_end = t; S.q_end = q; S.ins_end = ins; }
+  void finish() {
+    S.n_ops = k; S.t_end = t; S.q_end = q; S.ins_end = ins;
+    S.op0 = k ? ops[0] : 0u; S.opn = k ? ops[k - 1] : 0u;
+    for (Cut& c : S.cuts) { c.o1 = c.k + 1 < k ? ops[c.k + 1] : 0u; c.o2 = c.k + 2 < k ? ops[c.k + 2] : 0u; }
+  }
 };
 
 // CigarIter's behaviour byte by byte (aligners.rs:252-293)
@@ -284,7 +292,7 @@ inline bool window_alignment(const std::vector<uint32_t>& ops, const herro_align
 // just advances the totals, which the scan has already done).  Produces exactly what window_alignment produces, plus
 // the untrimmed target / query / insertion bases of every slice (differences of the running totals at op_lo / op_hi),
 // so that nothing downstream walks a slice again.
-inline bool window_cuts(const uint32_t* ops, const CigarScan& S, const herro_alignment& a, uint32_t W,
+inline bool window_cuts(const CigarScan& S, const herro_alignment& a, uint32_t W,
                         uint32_t n_windows, std::vector<HostOw>& out, BuildError& e) {
   if (a.tend < a.tstart || a.qend < a.qstart) { e = {HERRO_E_INVALID, "alignment with end < start"}; return false; }
   if ((a.tend - a.tstart) < W || (a.qend - a.qstart) < W) return true;  // :53-57
@@ -299,23 +307,25 @@ inline bool window_cuts(const uint32_t* ops, const CigarScan& S, const herro_ali
   bool started = false;
   uint32_t w_t = 0, w_q = 0, w_op = 0, w_off = 0;  // pending window start
   P w_p{a.tstart, 0, 0};
+  uint32_t w_opv = S.op0;  // the op at w_op
   if (a.tstart % W == 0 || a.tstart < zthr) {  // :120-125
     started = true; w_t = a.tstart; w_q = 0; w_op = 0; w_off = 0;
   }
-  auto emit = [&](uint32_t widx_plus1, uint32_t qend, uint32_t op_hi, uint32_t end_off, const P& hi) -> bool {
+  auto emit = [&](uint32_t widx_plus1, uint32_t qend, uint32_t op_hi, uint32_t end_off, const P& hi, uint32_t last_opv) -> bool {
     if (widx_plus1 == 0 || widx_plus1 - 1 >= n_windows) {
       e = {HERRO_E_REFERENCE_PANIC, "alignment reaches past the target's windows (windows[] index out of bounds)"};
       return false;
     }
     HostOw h{widx_plus1 - 1, w_t, w_q, qend, w_op, op_hi, w_off, end_off};
     h.st = hi.t - w_p.t; h.sq = hi.q - w_p.q; h.si = hi.i - w_p.i;
+    h.op_first = w_opv; h.op_last = last_opv;
     out.push_back(h);
     return true;
   };
   const uint32_t n = S.n_ops;
   for (const Cut& c : S.cuts) {
     const uint32_t k = c.k, tpos = c.t, qpos = c.q;
-    const uint32_t ty = op_type(ops[k]), l = op_len(ops[k]);
+    const uint32_t ty = op_type(c.o0), l = op_len(c.o0);
     const bool is_m = ty == OP_M;
     const uint32_t tnew = tpos + l, qnew = is_m ? qpos + l : qpos;
     const P p_k{tpos, qpos, c.ins}, p_k1{tnew, qnew, c.ins};
@@ -323,23 +333,26 @@ inline bool window_cuts(const uint32_t* ops, const CigarScan& S, const herro_ali
     for (uint32_t i = 1; i < new_w - cur_w; i++) {  // windows fully inside this op :150-195
       const uint32_t off = (cur_w + i) * W - tpos;
       const uint32_t qcut = is_m ? qpos + off : qpos;
-      if (started && !emit(cur_w + i, qcut, k + 1, off, p_k1)) return false;
-      started = true; w_t = tpos + off; w_q = qcut; w_op = k; w_off = off; w_p = p_k;
+      if (started && !emit(cur_w + i, qcut, k + 1, off, p_k1, c.o0)) return false;
+      started = true; w_t = tpos + off; w_q = qcut; w_op = k; w_off = off; w_p = p_k; w_opv = c.o0;
     }
     const uint32_t off = new_w * W - tpos;  // :198
     uint32_t qend = is_m ? qpos + off : qpos;
     uint32_t op_hi, end_off, next_op, next_off;
     P p_hi = p_k1, p_next = p_k;
+    uint32_t last_opv = c.o0, next_opv = c.o0;
     if (tnew == new_w * W) {  // op ends exactly on the boundary :210-223
-      if (k + 1 < n && op_type(ops[k + 1]) == OP_I) {  // trailing insertion stays with this window
-        const uint32_t li = op_len(ops[k + 1]);
+      if (k + 1 < n && op_type(c.o1) == OP_I) {  // trailing insertion stays with this window
+        const uint32_t li = op_len(c.o1);
         qend += li;
         op_hi = k + 2;
         end_off = li;
         p_hi = P{tnew, qnew + li, c.ins + li};
+        last_opv = c.o1; next_opv = c.o2;
       } else {
         op_hi = k + 1;
         end_off = l;
+        next_opv = c.o1;
       }
       next_op = op_hi;
       next_off = 0;
@@ -350,14 +363,14 @@ inline bool window_cuts(const uint32_t* ops, const CigarScan& S, const herro_ali
       next_op = k;
       next_off = off;
     }
-    if (started && !emit(new_w, qend, op_hi, end_off, p_hi)) return false;
-    started = true; w_t = tpos + off; w_q = qend; w_op = next_op; w_off = next_off; w_p = p_next;
+    if (started && !emit(new_w, qend, op_hi, end_off, p_hi, last_opv)) return false;
+    started = true; w_t = tpos + off; w_q = qend; w_op = next_op; w_off = next_off; w_p = p_next; w_opv = next_opv;
   }
   const uint32_t tpos = S.t_end, qpos = S.q_end;
   if (tpos > nthr && tpos % W != 0) {  // tail window :261-272
     if (!started) { e = {HERRO_E_REFERENCE_PANIC, "tail window without a start (Option::unwrap on None)"}; return false; }
     if (n == 0) { e = {HERRO_E_REFERENCE_PANIC, "empty cigar"}; return false; }
-    if (!emit(last_window, qpos, n, op_len(ops[n - 1]), P{S.t_end, S.q_end, S.ins_end})) return false;
+    if (!emit(last_window, qpos, n, op_len(S.opn), P{S.t_end, S.q_end, S.ins_end}, S.opn)) return false;
   }
   return true;
 }
