@@ -22,6 +22,7 @@
 #include "job_dev.h"
 #include "model_dev.h"
 #include "windowing.hpp"
+#include "cigar_dev.h"
 
 using namespace herro;
 
@@ -156,6 +157,10 @@ struct herro_ctx {
   // cost 36 hipMallocs + a hipHostMalloc, ~4 ms per 4096 windows, and its descriptors went up from pageable memory)
   std::unique_ptr<HostPool> pool;
   std::mutex arena_mu;
+  std::vector<Arena> free_scan, free_stage;            // device op array + staged CIGAR text of a job; pinned staging of one herro_job_create
+  hipStream_t prep_stream = nullptr;                   // CIGAR scan of the job being created: its own (high-priority) stream, so that it does not queue behind the pileup / model kernels of earlier jobs
+  hipEvent_t prep_ev = nullptr;
+  bool dev_scan = true;                                // HERRO_HOST_SCAN=1: decode the text on the host instead (A/B, debugging)
   std::vector<Arena> free_dev, free_pin, free_small;   // free_small: the buffers a job needs only once its counts are known (logits, batch descriptors)
   std::atomic<uint32_t> live_jobs{0};   // herro_job_create may run on another thread than the context's execution calls
   uint64_t reads_gen = 0;   // bumped by herro_set_reads: a job built on an older store refuses to run
@@ -199,6 +204,9 @@ struct herro_job {
   harr<uint32_t> tile_win, tile_r0;
   JobDev J{};
   Arena dev{}, pin{};              // device arena (descriptors + every scratch / result array), pinned host arena
+  Arena scan{};                    // device: the op array written by the CIGAR scan (+ the staged text it was read from)
+  uint64_t scan_ops = 0;           // slots in it
+  std::vector<uint32_t> dbg_ops;   // herro_debug_job_array(ops) of such a job: fetched on demand
   uint64_t reads_gen = 0;
   uint32_t n_skipped_alns = 0, n_failed_targets = 0;  // inputs the library does not support, left out (herro_job_skipped)
   std::string first_skip;
@@ -287,6 +295,35 @@ static void small_release(herro_ctx* ctx, Arena& a) {
   a = Arena{};
 }
 
+// A job-sized block from one of the context's free lists (best fit), or a fresh one with 12 % slack.
+// kind: 0 pinned host, 1 device; host-only contexts get plain malloc.
+static Arena arena_acquire(herro_ctx* ctx, std::vector<Arena>& list, size_t need, int kind) {
+  {
+    std::lock_guard<std::mutex> lk(ctx->arena_mu);
+    size_t best = list.size();
+    for (size_t i = 0; i < list.size(); i++)
+      if (list[i].cap >= need && (best == list.size() || list[i].cap < list[best].cap)) best = i;
+    if (best != list.size()) { Arena a = list[best]; list.erase(list.begin() + best); return a; }
+  }
+  Arena a;
+  a.cap = need + need / 8 + 4096;
+  if (ctx->host_only) a.p = std::malloc(a.cap);
+  else if (kind == 1) { if (hipMalloc(&a.p, a.cap) != hipSuccess) a.p = nullptr; }
+  else if (hipHostMalloc(&a.p, a.cap, hipHostMallocDefault) != hipSuccess) a.p = nullptr;
+  if (!a.p) a.cap = 0;
+  return a;
+}
+// gives a block back to its list when the scope ends, unless dismissed (the job keeps it)
+struct ArenaReturn {
+  herro_ctx* ctx; std::vector<Arena>* list; Arena* a; bool armed = true;
+  ~ArenaReturn() {
+    if (!armed || !a->p) return;
+    std::lock_guard<std::mutex> lk(ctx->arena_mu);
+    list->push_back(*a);
+    *a = Arena{};
+  }
+};
+
 // Tiles of whole windows for the fused transformer stack: consecutive windows packed greedily into at
 // most 64 tokens.  Returns the first token of each tile (+ end).  Callers pass windows of <= FUSED_MAX_TOK
 // informative rows only (larger windows run layer by layer, see split_launch).
@@ -333,6 +370,17 @@ herro_ctx* herro_create(int device_id) {
     return nullptr;
   }
   ctx->stream = ctx->own_stream;
+  {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
+    if ((e = hipStreamCreateWithPriority(&ctx->prep_stream, hipStreamNonBlocking, hi)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->prep_ev, hipEventDisableTiming | hipEventBlockingSync)) != hipSuccess) {
+      g_create_err = hipGetErrorString(e);
+      return nullptr;
+    }
+    const char* hs = getenv("HERRO_HOST_SCAN");
+    ctx->dev_scan = !(hs && atoi(hs) != 0);
+  }
   // ln(k+1) table from the host libm — what Rust's f64::ln calls on Linux (features.rs:507)
   std::vector<double> ln(1u << 20);
   for (size_t k = 0; k < ln.size(); k++) ln[k] = std::log((double)k + 1.0);
@@ -361,6 +409,10 @@ void herro_destroy(herro_ctx* ctx) {
   for (Arena& a : ctx->free_dev) (void)hipFree(a.p);
   for (Arena& a : ctx->free_pin) (void)hipHostFree(a.p);
   for (Arena& a : ctx->free_small) (void)hipFree(a.p);
+  for (Arena& a : ctx->free_scan) (void)hipFree(a.p);
+  for (Arena& a : ctx->free_stage) (void)hipHostFree(a.p);
+  if (ctx->prep_ev) (void)hipEventDestroy(ctx->prep_ev);
+  if (ctx->prep_stream) (void)hipStreamDestroy(ctx->prep_stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -728,12 +780,19 @@ struct TargetOut {
   uint32_t n_cls = 0;
   uint64_t scr_ops = 0, alg_read_bytes = 0, alg_op_bytes = 0;
   uint32_t n_skipped = 0;   // alignments left out (see skip() in build_target)
+  std::vector<std::pair<uint32_t, std::vector<uint32_t>>> op_patches;   // device-scan mode: (slot, ops) of texts only the host could read (e.g. 11+ digit zero padding)
   bool failed = false;      // the whole target was left without overlaps
   std::string first_skip;
 };
 
+// Results of the device CIGAR scan of a job's alignments (pinned host copies), indexed like the job's alignment range.
+struct DevScanView { const CigIn* in; const CigOut* out; const CigCut* cuts; };
+
+// ds == nullptr: the text is decoded here (scan_cigar) and the ops collect in out.ops.  Otherwise the ops are already in
+// the job's device op array (at in[g].op_off, absolute) and only the scan's cut records are read; g0 = index of the
+// target's first alignment in the scan arrays.
 void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* alns, uint32_t n_aln, uint32_t W,
-                  TargetOut& out) {
+                  TargetOut& out, const DevScanView* ds = nullptr, uint64_t g0 = 0) {
   auto fail = [&](int code, const std::string& m) { out.err = BuildError{code, m}; };
   if (rid >= ctx->n_reads) return fail(HERRO_E_REFERENCE_PANIC, "target rid out of range (reads[rid])");
   const uint32_t tlen = ctx->read_len[rid];
@@ -755,7 +814,8 @@ void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* aln
   auto skip = [&](uint32_t a, const char* why) {
     if (!out.n_skipped++) out.first_skip = "target rid " + std::to_string(rid) + ", alignment " + std::to_string(a) + " (qid " + std::to_string(alns[a].qid) + "): " + why;
   };
-  {
+  std::vector<uint32_t> spare_ops;   // device-scan mode: ops of the rare alignment the host has to read itself
+  if (!ds) {
     size_t op_room = 0;
     for (uint32_t a = 0; a < n_aln; a++) op_room += alns[a].cigar_len / 2 + 1;
     out.ops.reserve(op_room);
@@ -770,17 +830,38 @@ void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* aln
     if (al.tlen != tlen) return fail(HERRO_E_INVALID, "alignment tlen differs from the stored read length");
     if (al.qend > ctx->read_len[al.qid] || al.tend > tlen) return fail(HERRO_E_REFERENCE_PANIC, "alignment coordinates exceed the read length");
     BuildError be;
-    // the ops are decoded straight into the target's op array (one pass over the text, scan_cigar); they stay there
-    // only if the alignment contributes a window
-    const uint32_t op_base = (uint32_t)out.ops.size();
-    out.ops.resize((size_t)op_base + al.cigar_len / 2 + 1);
-    if (!scan_cigar(al.cigar, al.cigar_len, al.tstart, W, out.ops.data() + op_base, cs, be)) return fail(be.code, be.msg);
+    uint32_t op_base;
+    if (ds) {
+      const CigIn& ci = ds->in[g0 + a];
+      const CigOut& co = ds->out[g0 + a];
+      op_base = ci.op_off;
+      if (co.flags) {   // rare: malformed text (the message comes from here), consecutive insertions (their positions), more cuts than the coordinates allow
+        spare_ops.resize((size_t)al.cigar_len / 2 + 1);
+        if (!scan_cigar(al.cigar, al.cigar_len, al.tstart, W, spare_ops.data(), cs, be)) return fail(be.code, be.msg);
+        if (co.flags & CIG_MALFORMED)   // legal text the kernel does not read (lengths padded to 11+ digits): its ops go up from here
+          out.op_patches.emplace_back(ci.op_off, std::vector<uint32_t>(spare_ops.begin(), spare_ops.begin() + cs.n_ops));
+      } else {
+        cs.n_ops = co.n_ops; cs.t_end = co.t_end; cs.q_end = co.q_end; cs.ins_end = co.ins_end; cs.op0 = co.op0; cs.opn = co.opn;
+        cs.ins_pairs.clear(); cs.cuts.clear();
+        for (uint32_t c = 0; c < co.n_cuts; c++) {
+          const CigCut& k = ds->cuts[ci.cut_off + c];
+          cs.cuts.push_back(Cut{k.k, k.t, k.q, k.ins, k.o0, k.o1, k.o2});
+        }
+        std::sort(cs.cuts.begin(), cs.cuts.end(), [](const Cut& x, const Cut& y) { return x.k < y.k; });   // discovery order on the device
+      }
+    } else {
+      // the ops are decoded straight into the target's op array (one pass over the text, scan_cigar); they stay there
+      // only if the alignment contributes a window
+      op_base = (uint32_t)out.ops.size();
+      out.ops.resize((size_t)op_base + al.cigar_len / 2 + 1);
+      if (!scan_cigar(al.cigar, al.cigar_len, al.tstart, W, out.ops.data() + op_base, cs, be)) return fail(be.code, be.msg);
+    }
     hows.clear();
     if (!window_cuts(cs, al, W, n_windows, hows, be)) return fail(be.code, be.msg);
     bool unsupported = false;
     for (size_t k = 0; k < hows.size() && !unsupported; k++)
       unsupported = hows[k].op_hi > hows[k].op_lo && (op_type(hows[k].op_first) == OP_I || cs.ins_pair_in(hows[k].op_lo, hows[k].op_hi));
-    out.ops.resize((size_t)op_base + (hows.empty() || unsupported ? 0u : cs.n_ops));
+    if (!ds) out.ops.resize((size_t)op_base + (hows.empty() || unsupported ? 0u : cs.n_ops));
     if (unsupported) { skip(a, "a window's CIGAR slice starts with an insertion, or consecutive insertion ops (never produced by minimap2)"); continue; }
     for (auto& h : hows) tmp.push_back(Tmp{h, op_base, a});
     const uint32_t nc = ctx->name_class[al.qid];
@@ -904,9 +985,84 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   // ---- per-target host work (CIGAR parse, windowing, validation) is independent: it runs on the context's thread
   // pool, each target into its own buffers with target-local offsets, merged in target order below.
   HostPool& hpool = host_pool(ctx);
+  // ---- the CIGAR text goes to the GPU first (cigar_dev.hip): the bytes are staged in pinned memory, one copy up, one
+  // kernel (a workgroup per alignment) writes the binary ops into the job's op array and returns, per alignment, the
+  // totals and the ops that reach a window boundary; the host then cuts windows from those records alone.
+  Arena stage{};
+  ArenaReturn stage_ret{ctx, &ctx->free_stage, &stage};
+  ArenaReturn scan_ret{ctx, &ctx->free_scan, &job->scan};
+  DevScanView dsv{nullptr, nullptr, nullptr};
+  const DevScanView* ds = nullptr;
+  const uint64_t a0 = n_targets ? aln_off[0] : 0, nA = n_targets ? aln_off[n_targets] - a0 : 0;
+  auto t_scanned = t_begin;
+  if (!ctx->host_only && ctx->dev_scan && nA) {
+    if (!alns) return fail(HERRO_E_INVALID, "null argument");
+    if (nA > 0x7fffffffull) return fail(HERRO_E_UNSUPPORTED, "job too large (alignments)");
+    auto up256 = [](uint64_t x) { return (x + 255) & ~uint64_t(255); };
+    std::vector<CigIn> in(nA);
+    uint64_t txt = 0, opn = 0, cutn = 0;
+    for (uint64_t g = 0; g < nA; g++) {
+      const herro_alignment& al = alns[a0 + g];
+      if (al.cigar_len && !al.cigar) return fail(HERRO_E_INVALID, "alignment without cigar");
+      const uint32_t cap = (al.tend >= al.tstart ? (al.tend - al.tstart) / W : 0u) + 3u;   // one cut per window boundary the coordinates span, + slack
+      in[g] = CigIn{txt, al.cigar_len, al.tstart, (uint32_t)opn, (uint32_t)cutn, cap, 0};
+      txt += ((uint64_t)al.cigar_len + 15) & ~uint64_t(15);
+      opn += (uint64_t)al.cigar_len / 2 + 1;
+      cutn += cap;
+    }
+    if (opn > 0xffffffffull || cutn > 0xffffffffull) return fail(HERRO_E_UNSUPPORTED, "job too large (ops exceed 2^32)");
+    const uint64_t o_in = up256(txt + 16), o_out = o_in + up256(nA * sizeof(CigIn)), o_cut = o_out + up256(nA * sizeof(CigOut));
+    const uint64_t blk_bytes = o_cut + cutn * sizeof(CigCut), ops_bytes = up256(opn * 4);
+    stage = arena_acquire(ctx, ctx->free_stage, blk_bytes, 0);
+    job->scan = arena_acquire(ctx, ctx->free_scan, ops_bytes + blk_bytes, 1);
+    if (!stage.p || !job->scan.p) return fail(HERRO_E_NO_DEVICE, "out of memory for the CIGAR scan (" + std::to_string((ops_bytes + blk_bytes) >> 20) + " MiB)");
+    unsigned char* hs = (unsigned char*)stage.p;
+    unsigned char* dsb = (unsigned char*)job->scan.p + ops_bytes;
+    const uint32_t per = 32, nblk = (uint32_t)((nA + per - 1) / per);
+    hpool.run(nblk, [&](uint32_t b) {
+      for (uint64_t g = (uint64_t)b * per; g < std::min<uint64_t>(nA, (uint64_t)(b + 1) * per); g++) {
+        const herro_alignment& al = alns[a0 + g];
+        unsigned char* d = hs + in[g].txt_off;
+        if (al.cigar_len) std::memcpy(d, al.cigar, al.cigar_len);
+        std::memset(d + al.cigar_len, 0, (size_t)((((uint64_t)al.cigar_len + 15) & ~uint64_t(15)) - al.cigar_len));
+      }
+    });
+    std::memcpy(hs + o_in, in.data(), nA * sizeof(CigIn));
+    const auto t_staged = tnow();
+    hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};   // HERRO_HOST_PROFILE: copy up / kernel / copy down on the device clock
+    if (prof) for (auto& ev : pe) (void)hipEventCreate(&ev);
+    if (pe[0]) (void)hipEventRecord(pe[0], ctx->prep_stream);
+    hipError_t e = hipMemcpyAsync(dsb, hs, o_in + nA * sizeof(CigIn), hipMemcpyHostToDevice, ctx->prep_stream);
+    if (pe[1]) (void)hipEventRecord(pe[1], ctx->prep_stream);
+    if (e == hipSuccess) {
+      launch_cigar_scan(dsb, (const CigIn*)(dsb + o_in), (CigOut*)(dsb + o_out), (CigCut*)(dsb + o_cut), (uint32_t*)job->scan.p, (uint32_t)nA, W, ctx->prep_stream);
+      e = hipGetLastError();
+    }
+    if (pe[2]) (void)hipEventRecord(pe[2], ctx->prep_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hs + o_out, dsb + o_out, blk_bytes - o_out, hipMemcpyDeviceToHost, ctx->prep_stream);
+    if (pe[3]) (void)hipEventRecord(pe[3], ctx->prep_stream);
+    if (e == hipSuccess) e = hipEventRecord(ctx->prep_ev, ctx->prep_stream);
+    if (e == hipSuccess) e = hipEventSynchronize(ctx->prep_ev);
+    if (prof && e == hipSuccess) {
+      float up = 0, kn = 0, dn = 0;
+      (void)hipEventElapsedTime(&up, pe[0], pe[1]); (void)hipEventElapsedTime(&kn, pe[1], pe[2]); (void)hipEventElapsedTime(&dn, pe[2], pe[3]);
+      fprintf(stderr, "  cigar scan: %.1f MiB text staged in %.2f ms; device: copy up %.2f ms, kernel %.2f, copy down %.2f (%.1f MiB); wall %.2f ms\n", txt / 1048576.0,
+              std::chrono::duration<double, std::milli>(t_staged - t_begin).count(), up, kn, dn, (blk_bytes - o_out) / 1048576.0,
+              std::chrono::duration<double, std::milli>(tnow() - t_staged).count());
+    }
+    for (auto& ev : pe) if (ev) (void)hipEventDestroy(ev);
+    if (e != hipSuccess) {
+      (void)hipStreamSynchronize(ctx->prep_stream);
+      return fail(HERRO_E_NO_DEVICE, std::string("CIGAR scan failed: ") + hipGetErrorString(e));
+    }
+    dsv = DevScanView{(const CigIn*)(hs + o_in), (const CigOut*)(hs + o_out), (const CigCut*)(hs + o_cut)};
+    ds = &dsv;
+    job->scan_ops = opn;
+    t_scanned = tnow();
+  }
   std::vector<TargetOut> outs(n_targets);
   hpool.run(n_targets, [&](uint32_t t) {
-    build_target(ctx, rids[t], alns + aln_off[t], (uint32_t)(aln_off[t + 1] - aln_off[t]), W, outs[t]);
+    build_target(ctx, rids[t], alns + aln_off[t], (uint32_t)(aln_off[t + 1] - aln_off[t]), W, outs[t], ds, aln_off[t] - a0);
   });
   auto t_built = tnow();
   // ---- merge in target order: a serial pass over the per-target SIZES fixes every base offset; the bytes are then
@@ -925,6 +1081,10 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
         if (!job->n_skipped_alns && !job->n_failed_targets) job->first_skip = o.first_skip;
         job->n_skipped_alns += o.n_skipped;
         job->n_failed_targets += o.failed ? 1u : 0u;
+      }
+      for (auto& pt : outs[t].op_patches) {   // rare; synchronous
+        if (hipMemcpy((uint32_t*)job->scan.p + pt.first, pt.second.data(), pt.second.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+          return fail(HERRO_E_NO_DEVICE, "op upload failed");
       }
       base[t] = b;
       b.op += o.ops.size(); b.ow += o.ow.size(); b.win += o.win.size(); b.cls += o.n_cls; b.scr += o.scr_ops;
@@ -953,23 +1113,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   const size_t o_counts = take(tot.win * 12);   // host arena only: pinned landing zone of the per-window counts
   const size_t o_hclen = take(tot.win * 4), o_hcseq = take(row_elems);   // ... and of the corrected bases (device consensus)
   const size_t pin_bytes = cur;
-  auto acquire = [&](std::vector<Arena>& pool_, size_t need, bool device) -> Arena {
-    {
-      std::lock_guard<std::mutex> lk(ctx->arena_mu);
-      size_t best = pool_.size();
-      for (size_t i = 0; i < pool_.size(); i++)
-        if (pool_[i].cap >= need && (best == pool_.size() || pool_[i].cap < pool_[best].cap)) best = i;
-      if (best != pool_.size()) { Arena a_ = pool_[best]; pool_.erase(pool_.begin() + best); return a_; }
-    }
-    Arena a_;
-    a_.cap = need + need / 8 + 4096;
-    if (ctx->host_only) a_.p = std::malloc(a_.cap);
-    else if (device) { if (hipMalloc(&a_.p, a_.cap) != hipSuccess) a_.p = nullptr; }
-    else if (hipHostMalloc(&a_.p, a_.cap, hipHostMallocDefault) != hipSuccess) a_.p = nullptr;
-    if (!a_.p) a_.cap = 0;
-    return a_;
-  };
-  job->pin = acquire(ctx->free_pin, pin_bytes, false);
+  job->pin = arena_acquire(ctx, ctx->free_pin, pin_bytes, 0);
   if (!job->pin.p) return fail(HERRO_E_NO_DEVICE, "out of pinned host memory for the job");
   {
     unsigned char* hb = (unsigned char*)job->pin.p;
@@ -1038,7 +1182,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   const size_t o_srow = take(row_elems * 4), o_spi = take(row_elems * 4);
   const size_t o_finb = take(fin_bytes), o_finq = take(fin_bytes), o_nd = take((uint64_t)n_cls * 8);
   const size_t dev_bytes = cur;
-  job->dev = acquire(ctx->free_dev, dev_bytes, true);
+  job->dev = arena_acquire(ctx, ctx->free_dev, dev_bytes, 1);
   auto give_back = [&]() {
     std::lock_guard<std::mutex> lk(ctx->arena_mu);
     if (job->dev.p) ctx->free_dev.push_back(job->dev);
@@ -1047,7 +1191,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   };
   if (!job->dev.p) { give_back(); return fail(HERRO_E_NO_DEVICE, "out of device memory for the job (" + std::to_string(dev_bytes >> 20) + " MiB)"); }
   unsigned char* db = (unsigned char*)job->dev.p;
-  J.ops = (const uint32_t*)(db + o_ops); J.ow = (const OwDesc*)(db + o_ow); J.win = (const WinDesc*)(db + o_win);
+  J.ops = ds ? (const uint32_t*)job->scan.p : (const uint32_t*)(db + o_ops); J.ow = (const OwDesc*)(db + o_ow); J.win = (const WinDesc*)(db + o_win);
   J.tile_win = (const uint32_t*)(db + o_tw); J.tile_r0 = (const uint32_t*)(db + o_tr);
   J.op_t = (uint32_t*)(db + o_op_t); J.op_q = (uint32_t*)(db + o_op_q); J.ins_ev = (uint32_t*)(db + o_ins_ev);
   J.ins_cnt = (uint32_t*)(db + o_ins_cnt);
@@ -1076,10 +1220,11 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   }
   if (prof) {
     auto ms = [](auto a_, auto b_) { return std::chrono::duration<double, std::milli>(b_ - a_).count(); };
-    fprintf(stderr, "herro_job_create: build %.2f ms, merge %.2f, arena + enqueue %.2f (%u windows, %zu MiB device)\n", ms(t_begin, t_built),
-            ms(t_built, t_merged), ms(t_merged, tnow()), n_win, dev_bytes >> 20);
+    fprintf(stderr, "herro_job_create: scan %.2f ms, build %.2f, merge %.2f, arena + enqueue %.2f (%u windows, %zu MiB device)\n", ms(t_begin, t_scanned),
+            ms(t_scanned, t_built), ms(t_built, t_merged), ms(t_merged, tnow()), n_win, dev_bytes >> 20);
   }
   ctx->live_jobs++;
+  scan_ret.armed = false;   // the job keeps its op array
   return job.release();
 }
 
@@ -1107,6 +1252,7 @@ void herro_job_free(herro_job* job) {
     std::lock_guard<std::mutex> lk(ctx->arena_mu);
     // keep a handful of arenas for the next jobs (the bench cycles 2-4 jobs per context); the rest goes back to HIP
     if (job->dev.p) { if (ctx->free_dev.size() < 6) ctx->free_dev.push_back(job->dev); else (void)hipFree(job->dev.p); }
+    if (job->scan.p) { if (ctx->free_scan.size() < 6) ctx->free_scan.push_back(job->scan); else (void)hipFree(job->scan.p); }
     if (job->pin.p) { if (ctx->free_pin.size() < 6) ctx->free_pin.push_back(job->pin); else (void)hipHostFree(job->pin.p); }
   }
   small_release(ctx, job->a_logits);
@@ -1683,7 +1829,17 @@ herro_ctx* herro_debug_host_ctx(uint32_t n_reads, const uint32_t* read_len, cons
 int64_t herro_debug_job_array(herro_job* job, int which, const void** ptr, uint32_t* elem_bytes) {
   if (!job || !ptr || !elem_bytes) return HERRO_E_INVALID;
   switch (which) {
-    case 0: *ptr = job->ops.data(); *elem_bytes = 4; return (int64_t)job->ops.size();
+    case 0:
+      *elem_bytes = 4;
+      if (job->scan.p) {   // ops written by the device scan: the whole (gapped) op array, so that OwDesc::op_begin indexes it
+        job->dbg_ops.resize(job->scan_ops);
+        if (hipSetDevice(job->ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(job->dbg_ops.data(), job->scan.p, job->scan_ops * 4, hipMemcpyDeviceToHost) != hipSuccess) return HERRO_E_NO_DEVICE;
+        *ptr = job->dbg_ops.data();
+        return (int64_t)job->dbg_ops.size();
+      }
+      *ptr = job->ops.data();
+      return (int64_t)job->ops.size();
     case 1: *ptr = job->ow.data(); *elem_bytes = sizeof(OwDesc); return (int64_t)job->ow.size();
     case 2: *ptr = job->win.data(); *elem_bytes = sizeof(WinDesc); return (int64_t)job->win.size();
     case 3: *ptr = job->tile_win.data(); *elem_bytes = 4; return (int64_t)job->tile_win.size();
