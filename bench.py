@@ -148,7 +148,8 @@ def main():
     ap.add_argument("--e2e-mode", choices=["serial", "producer"], default="serial",
                     help="end_to_end feeders: 'serial' = one thread per context (create k+1, then execute k); 'producer' = a second "
                          "thread per context builds jobs ahead")
-    ap.add_argument("--e2e-jobs", type=int, default=3, help="jobs per feeder thread in the end_to_end leg (0: skip it)")
+    ap.add_argument("--e2e-feeders", type=int, default=4, help="feeder threads (one context each) of the end_to_end leg")
+    ap.add_argument("--e2e-jobs", type=int, default=6, help="jobs per feeder thread in the end_to_end leg (0: skip it)")
     ap.add_argument("--self-check", type=int, default=6, help="targets compared with the oracle after the timing (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -180,7 +181,8 @@ def main():
     pool = max(1, min(args.pool, (n_full + NS - 1) // NS if n_full else 1))
     n_jobs = NS * pool
     tpj = G * targets_per_step                                  # targets per job
-    n_e2e = args.e2e_jobs * NS if (args.e2e_jobs > 0 and n_full) else 0
+    NF = max(NS, args.e2e_feeders)                              # feeder threads (= contexts) of the end_to_end leg
+    n_e2e = args.e2e_jobs * NF if (args.e2e_jobs > 0 and n_full) else 0
     n_t = (n_jobs + n_e2e) * tpj + rem * targets_per_step
 
     def job_targets(i):
@@ -282,7 +284,16 @@ def main():
     e2e = None
     if n_e2e:
         per = args.e2e_jobs
-        stats = [None] * NS
+        stats = [None] * NF
+        # The device-resident leg is best on two streams (every kernel fills the GPU; more streams only add contention);
+        # end to end a job also waits for its text to cross PCIe and for the scan's answer, so more jobs in flight pay:
+        # measured 0.66 M windows/s with 2 feeders, 0.76 M with 3, 0.93 M with 4.  The extra contexts are made here.
+        for _ in range(NF - len(ctxs)):
+            c = api.Context(local)
+            c.load_model(path)
+            c.set_precision(args.precision)
+            c.set_reads(sb.seq, sb.qual, sb.off)
+            ctxs.append(c)
         prep = api.PreparedAlignments(sb)   # the parsed alignments of the data set, resident on the host (outside the timed region)
 
         def feeder_serial(s_i, ids, timed):
@@ -344,7 +355,7 @@ def main():
                 stats[s_i] = (host[0], bases)
 
         def run_feeders(id_lists, timed):
-            th = [threading.Thread(target=feeder, args=(s_i, id_lists[s_i], timed)) for s_i in range(NS)]
+            th = [threading.Thread(target=feeder, args=(s_i, id_lists[s_i], timed)) for s_i in range(NF)]
             for t in th:
                 t.start()
             for t in th:
@@ -354,10 +365,10 @@ def main():
         # untimed pass over already-seen target ranges: a context holds up to four jobs at a time, and the first jobs of a
         # context pay for their arenas (hipMalloc of ~1.2 GB, page-locking ~70 MB each); a long-running host recycles them
         n_warm = 6
-        run_feeders([[s_i * pool + (k % pool) for k in range(n_warm)] for s_i in range(NS)], False)
+        run_feeders([[(s_i * pool + k) % n_jobs for k in range(n_warm)] for s_i in range(NF)], False)
         barrier()
         t1 = time.perf_counter()
-        run_feeders([[n_jobs + s_i * per + k for k in range(per)] for s_i in range(NS)], True)
+        run_feeders([[n_jobs + s_i * per + k for k in range(per)] for s_i in range(NF)], True)
         el2 = time.perf_counter() - t1
         barrier()
         if world > 1:
@@ -367,10 +378,10 @@ def main():
         n_w = n_e2e * G * args.batch
         host_s = sum(s[0] for s in stats)
         e2e = {"windows_per_s": n_w * world / el2, "mbases_per_s": sum(s[1] for s in stats) * world / el2 / 1e6,
-               "windows": n_w * world, "usable_cpus": synth.usable_cpus(), "jobs_per_feeder": per, "feeders_per_gpu": NS, "warmup_jobs_per_feeder": n_warm,
-               "host_prepare_windows_per_s_per_feeder": n_w / NS / (host_s / NS) if host_s else None,
-               "note": "herro_job_create from host alignments (CIGAR parse + windowing on the context's thread pool, one pinned block, "
-                       "one async H2D) + featurize + infer + consensus + D2H of the corrected bases, all inside the timed region; "
+               "windows": n_w * world, "usable_cpus": synth.usable_cpus(), "jobs_per_feeder": per, "feeders_per_gpu": NF, "warmup_jobs_per_feeder": n_warm,
+               "host_prepare_windows_per_s_per_feeder": n_w / NF / (host_s / NF) if host_s else None,
+               "note": "herro_job_create from host alignments (CIGAR text staged and scanned on the GPU, windows cut on the context's thread pool, "
+                       "one pinned descriptor block, one async H2D) + featurize + infer + consensus + D2H of the corrected bases, all inside the timed region; "
                        "fresh inputs per job; the alignments are resident on the host as one parsed array (what the reference's reader thread "
                        "hands over, lib.rs:141-151); " + ("per context one thread builds jobs ahead, one executes them" if args.e2e_mode == "producer"
                                                      else "one feeder thread per context: create(k+1) runs on the host while the GPU works on job k"),
