@@ -51,7 +51,7 @@ def cpu_baseline(seed: int) -> dict:
     import torch
     from herro_amd import model_io, synth
     cores = synth.usable_cpus()   # = worker threads used below
-    n_tgt = max(24, min(4 * cores, 1024))
+    n_tgt = max(256, min(64 * cores, 1024))   # 1024 targets = 4096 windows on 16+ usable CPUs: ~0.5 s per pass, ~10 CPU-seconds
     sb = synth.generate_parallel(n_tgt, WINS_PER_TARGET * W, N_OVL, seed=seed, chunk=32)
     store = O.store_from_synth(sb)
     tasks = [O.target_alignments(sb, t) for t in range(sb.n_targets)]
@@ -74,20 +74,22 @@ def cpu_baseline(seed: int) -> dict:
     torch.set_num_threads(cores)
     _, raw = model_io.default_model_file(os.path.join(ROOT, "tests", "_cache"))
     twin = MR.build(raw, model_io.Hyper())
-    res = [store.extract_features(*tasks[k], W) for k in range(2)]
-    _, warm = res[0].collate(2, 0)
+    n_model = 16                                      # reads whose windows go through the model (one batch per read, as inference.rs flushes)
+    res = [store.extract_features(*tasks[k], W) for k in range(1 + n_model)]
+    _, warm = res[0].collate(WINS_PER_TARGET, 0)
     MR.run_batch(twin, warm["bases"], warm["quals"], warm["lens"], warm["indices"])   # warm-up: threads, allocator, oneDNN primitives
-    _, bt = res[1].collate(4, 0)
+    batches = [r.collate(WINS_PER_TARGET, 0)[1] for r in res[1:]]
+    mb = sum(len(bt["lens"]) for bt in batches)
     t0 = time.perf_counter()
-    MR.run_batch(twin, bt["bases"], bt["quals"], bt["lens"], bt["indices"])
-    mb = len(bt["lens"])
+    for bt in batches:
+        MR.run_batch(twin, bt["bases"], bt["quals"], bt["lens"], bt["indices"])
     model_rate = mb / (time.perf_counter() - t0)
     return {"value": min(feat_all, model_rate), "unit": "windows/s", "cores": cores, "kind": "port",
             "feature_windows_per_s": feat_all, "feature_windows_per_s_4_threads": feat_t4, "model_windows_per_s": model_rate,
             "model_batch": mb,
             "sample": f"pipelined stages, rate of the slower one: oracle extract_features on {sb.n_targets * WINS_PER_TARGET} windows "
                       f"({workers} threads: {feat_all:.0f} win/s; 4 threads, the reference's -t 4: {feat_t4:.0f} win/s) | dense PyTorch-CPU fp32 "
-                      f"twin of the assumed architecture, warmed, one batch of {mb} windows ({cores} threads: {model_rate:.2f} win/s). "
+                      f"twin of the assumed architecture, warmed, {n_model} batches of {WINS_PER_TARGET} windows ({cores} threads: {model_rate:.2f} win/s). "
                       "The reference itself runs the model on a GPU through libtorch; this is the same algorithm on the host cores "
                       f"(usable CPUs {cores} of {os.cpu_count()} hardware threads: affinity / cgroup quota)"}
 
@@ -141,6 +143,7 @@ def main():
                          "reference's concurrent feature / inference threads per device (lib.rs:154-200)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--windows", type=int, default=0, help="--scaling strong: total windows of the fixed job (default steps * batch)")
+    ap.add_argument("--repeats", type=int, default=3, help="further timed passes of the same K steps after the measured one (spread only)")
     ap.add_argument("--min-jobs", type=int, default=1,
                     help="launch grouping for short runs (steps < 2 x group): the timed steps are split into at least this many jobs. "
                          "Measured at --steps 20: one job of 2560 windows 0.96 M windows/s, two jobs of 1280 on two streams 0.87 M "
@@ -263,17 +266,24 @@ def main():
     # current bandwidth period may be spent, and a throttled feeder thread would stall the timed region for the rest of
     # it (up to 100 ms).  Two periods of rest give the short, CPU-light timed region a fresh budget.
     time.sleep(0.25)
+    # warm-up: at least W steps, and every pooled job at least once — a job's late buffers (logits, batch descriptors) are
+    # allocated by its first herro_job_infer, which must not fall into the timed region
     for s_i in range(NS):
-        for i in range(max(1, (args.warmup + G * NS - 1) // (G * NS))):
+        for i in range(max(pool, (args.warmup + G * NS - 1) // (G * NS))):
             run_job(jobs[s_i][i % pool])
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    for c in ctxs:
-        c.synchronize()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    barrier()
+
+    def timed_pass():
+        barrier()
+        t_ = time.perf_counter()
+        run_steps(args.steps)
+        for c in ctxs:
+            c.synchronize()
+        torch.cuda.synchronize()
+        el_ = time.perf_counter() - t_
+        barrier()
+        return el_
+    el = timed_pass()                                    # THE measurement: exactly K steps
+    repeats = [timed_pass() for _ in range(max(0, args.repeats))]   # reported beside it (run-to-run spread), never used for `value`
     if world > 1:
         tt = torch.tensor([el], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -483,7 +493,7 @@ def main():
                 "kernels": feat_names, "bound": "hbm", "achieved": feat_bytes / G / (feat_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": feat_bytes / G / (feat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_step": feat_bytes / G, "ms_per_step": feat_ms},
-            "stage_ms_per_step": {"featurize": feat_ms, "model": model_ms},
+            "repeat_ms_per_step": [r * 1e3 / args.steps for r in repeats], "stage_ms_per_step": {"featurize": feat_ms, "model": model_ms},
             "end_to_end": e2e,
             "self_check": check,
             "kernels": kern,
