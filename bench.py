@@ -143,6 +143,7 @@ def main():
                          "reference's concurrent feature / inference threads per device (lib.rs:154-200)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--windows", type=int, default=0, help="--scaling strong: total windows of the fixed job (default steps * batch)")
+    ap.add_argument("--settle", type=float, default=0.2, help="seconds of untimed steps on top of --warmup before the timed pass")
     ap.add_argument("--repeats", type=int, default=3, help="further timed passes of the same K steps after the measured one (spread only)")
     ap.add_argument("--min-jobs", type=int, default=1,
                     help="launch grouping for short runs (steps < 2 x group): the timed steps are split into at least this many jobs. "
@@ -271,6 +272,13 @@ def main():
     for s_i in range(NS):
         for i in range(max(pool, (args.warmup + G * NS - 1) // (G * NS))):
             run_job(jobs[s_i][i % pool])
+    # ... and at least `--settle` seconds of the same steps: W = 5 steps is 0.7 ms of GPU work, after which clocks and
+    # caches are still moving (measured: the pass after a one-job warm-up runs 8 % slower than the following ones)
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < args.settle:
+        run_steps(args.steps)
+        for c in ctxs:
+            c.synchronize()
 
     def timed_pass():
         barrier()
