@@ -105,10 +105,14 @@ int herro_load_model(herro_ctx* ctx, const char* path);
 int herro_set_precision(herro_ctx* ctx, int mode);
 
 /* ---- job = a set of target reads with their alignments -------------------------------------
- * herro_job_create replaces the front half of `extract_features` (features.rs:326-361): it runs
- * `extract_windows` (windowing.rs:44-273) for every alignment on the host, converts CIGARs to a
- * binary op stream and uploads the descriptors (one pinned block, one asynchronous copy; job memory is recycled through
- * per-context arenas, the host work runs on a per-context thread pool of HERRO_HOST_THREADS, default min(cores, 64)).
+ * herro_job_create replaces the front half of `extract_features` (features.rs:326-361): `extract_windows`
+ * (windowing.rs:44-273) for every alignment.  The CIGAR text is staged in pinned memory and decoded ON THE DEVICE (one
+ * kernel, a workgroup per alignment: binary ops into the job's op array + the ops that reach a window boundary back to the
+ * host); the host cuts the windows from those records, validates, and uploads the descriptors (one pinned block, one
+ * asynchronous copy).  The call waits for that one short kernel on a separate high-priority stream of the context, not
+ * for the context's execution stream.  Job memory is recycled through per-context arenas; the host work runs on a
+ * per-context thread pool of HERRO_HOST_THREADS, default min(hardware threads / 4, 64, the cgroup CPU quota).
+ * HERRO_HOST_SCAN=1 decodes the text on the host instead (same results; the device-free hook below always does).
  * Threading: a context's execution calls (featurize / infer / consensus / accessors) belong to one thread; herro_job_create
  * (host work + one asynchronous upload) may run on a SECOND thread of the same context at the same time, so that the next
  * job is built while the current one executes (bench.py end_to_end does this).
