@@ -153,7 +153,7 @@ def main():
                     help="end_to_end feeders: 'serial' = one thread per context (create k+1, then execute k); 'producer' = a second "
                          "thread per context builds jobs ahead")
     ap.add_argument("--e2e-feeders", type=int, default=4, help="feeder threads (one context each) of the end_to_end leg")
-    ap.add_argument("--e2e-jobs", type=int, default=6, help="jobs per feeder thread in the end_to_end leg (0: skip it)")
+    ap.add_argument("--e2e-jobs", type=int, default=None, help="jobs per feeder thread in the end_to_end leg (default: 6 on one GPU, 0 = skipped on several)")
     ap.add_argument("--self-check", type=int, default=6, help="targets compared with the oracle after the timing (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -166,9 +166,16 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
+    # the ranks of a node share its usable CPUs (hardware threads, affinity, cgroup quota): each takes its share for the
+    # library's host pool and the input generator, so that N ranks do not throttle each other
+    from herro_amd import synth
+    cpus_rank = max(2, synth.usable_cpus() // max(1, world))
     if world > 1:
+        os.environ.setdefault("HERRO_HOST_THREADS", str(cpus_rank))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.e2e_jobs is None:   # the end_to_end leg is a single-GPU figure (4 feeder contexts per GPU would have 8 ranks fight for the host)
+        args.e2e_jobs = 6 if world == 1 else 0
 
     from herro_amd import api, model_io, synth
     if args.precision is None:
@@ -195,7 +202,8 @@ def main():
     def prepare(parallel: bool):
         """synthetic reads + alignments -> read stores in HBM + jobs (descriptors uploaded); outside the timed region"""
         gen = synth.generate_parallel if parallel else synth.generate   # parallel: chunks generated concurrently, merged
-        sb_ = gen(n_t, WINS_PER_TARGET * W, N_OVL, seed=synth.SEED + 2 + 1000 * rank)
+        kw_ = dict(workers=min(cpus_rank, 64)) if parallel else {}
+        sb_ = gen(n_t, WINS_PER_TARGET * W, N_OVL, seed=synth.SEED + 2 + 1000 * rank, **kw_)
         ctxs_ = []
         for s_i in range(NS):
             c = api.Context(local)
