@@ -110,6 +110,8 @@ def test_bench_flow(monkeypatch, capsys, argv, steps):
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["unit"] == "windows/s" and "workload" in d["config"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+    assert len(d["roofline_next_kernels"]) == 2 and all({"kernel", "bound", "frac"} <= set(r) for r in d["roofline_next_kernels"])
+    assert d["roofline"]["launch_us"] >= d["roofline_next_kernels"][0]["launch_us"] >= d["roofline_next_kernels"][1]["launch_us"]
     if d["end_to_end"] is not None:   # job creation + D2H inside the timed region: every end-to-end job fetched its bases once
         assert d["end_to_end"]["windows_per_s"] > 0 and d["end_to_end"]["windows"] > 0
         n_fetch = sum(1 for ev, _ in FakeJob.log if ev == "D")   # timed jobs + the untimed warm-up jobs of each feeder
