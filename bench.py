@@ -9,9 +9,12 @@ A step = one pass of the hot path over one batch of `--batch` (128) 4096-bp wind
 (BASELINE.json configs[2]): featurise the windows on the GPU, batch the windows with >= 1 informative position across
 reads, run the model, decode the corrected bases on the device.  `value` counts exactly `--steps` steps with the inputs
 (2-bit read store, window descriptors) resident in HBM before the timed region starts.  The same JSON line also carries
-  end_to_end    the same work with herro_job_create (CIGAR parse, windowing, descriptor upload) and the D2H of the
-                corrected bases INSIDE the timed region, fresh inputs every job, two feeder threads per GPU;
-  roofline      the dominant kernel against its roof, durations from HIP events on the launch stream;
+  end_to_end    the same work with herro_job_create (CIGAR text staged and scanned on the GPU, windowing, descriptor
+                upload) and the D2H of the corrected bases INSIDE the timed region, fresh inputs every job, four feeder
+                threads (contexts) per GPU; N = 1 only by default;
+  roofline      the dominant kernel against its roof, durations from HIP events on the launch stream
+                (roofline_next_kernels: the two behind it; roofline_featurize_group: the featurize kernels together);
+  repeat_ms_per_step   three further passes of the same K steps (spread; `value` is always the first timed pass);
   cpu_baseline  the reference algorithm on the host cores (oracle feature generation + PyTorch-CPU twin), N = 1 only;
   self_check    windows of a timed job compared with the oracle after the timing (features bit-exact, FASTA identical).
 Multi-GPU: the path shards by target read with no data-path collective; `--scaling weak` (default) gives every rank its
