@@ -1575,75 +1575,18 @@ __global__ __launch_bounds__(NT) void k_rf_quals(JobDev J, uint32_t half) {
   }
 }
 
-// =====================================================================================================
-// k_consensus — one workgroup per window: corrected bases on the device (consensus.rs:86-227)
-// =====================================================================================================
-// Per final row: informative -> argmax of the 5 base logits (the LAST maximum wins, NaN is greatest —
-// max_by_key(OrderedFloat), consensus.rs:136-141); otherwise the majority vote with the target tie-break
-// (consensus.rs:178-200) that k_final_tiles already derived from its symbol counts.  '*' is dropped.  The window's
-// bases are compacted in row order; the host only concatenates windows and splits reads at windows
-// with < 2 alignments (consensus.rs:90-111).
-__global__ __launch_bounds__(NT) void k_consensus(JobDev J, const uint64_t* sup_off, const float* base_logits) {
-  __shared__ uint32_t s_wave[NT / 64];
-  const uint32_t w = blockIdx.x;
-  const WinDesc wd = J.win[w];
-  const uint32_t Lf = J.win_Lf[w], n_kept = J.win_nkept[w];
-  const uint32_t n_alns = n_kept < 30u ? n_kept : 30u;
-  uint8_t* seq = J.cons_seq + wd.row_off;
-  if (n_alns < 2) {  // not corrected: the read is split here
-    if (threadIdx.x == 0) J.cons_len[w] = 0;
-    return;
-  }
-  const float* lg = base_logits + sup_off[w] * 5;
-  uint8_t* tmp = J.cons_tmp + wd.row_off;  // per-row majority vote, written by k_final_tiles
-  // (b) informative rows: the model decides
-  const uint32_t nsup = J.win_nsup[w];
-  for (uint32_t k = threadIdx.x; k < nsup; k += NT) {
-    const float* l5 = lg + (uint64_t)k * 5;
-    uint32_t arg = 0;
-    float mx = l5[0];
-#pragma unroll
-    for (uint32_t c = 1; c < 5; c++) {
-      const float v = l5[c];
-      const bool ge = (v != v) ? true : ((mx != mx) ? false : v >= mx);
-      if (ge) { arg = c; mx = v; }
-    }
-    tmp[J.sup_row[wd.row_off + k]] = (uint8_t)arg;
-  }
-  __syncthreads();
-  // (c) drop '*' and compact in row order
-  const uint32_t ch = (Lf + NT - 1) / NT;
-  const uint32_t a = min(threadIdx.x * ch, Lf), b = min(a + ch, Lf);
-  uint32_t nout = 0;
-  for (uint32_t r = a; r < b; r++) nout += tmp[r] != 4u ? 1u : 0u;
-  uint32_t total;
-  uint32_t o = block_scan(nout, &total, s_wave);
-  for (uint32_t r = a; r < b; r++) {
-    const uint32_t base = tmp[r];
-    if (base != 4u) seq[o++] = (uint8_t)"ACGT"[base];
-  }
-  if (threadIdx.x == 0) J.cons_len[w] = total;
-}
-
-void launch_consensus(const JobDev& J, const uint64_t* sup_off, const float* base_logits, hipStream_t st, KernelTimer* tm) {
-  if (!J.n_win) return;
-  KT_BEGIN(tm, "consensus", st);
-  hipLaunchKernelGGL(k_consensus, dim3(J.n_win), dim3(NT), 0, st, J, sup_off, base_logits);
-  KT_END(tm, st);
-}
-
-void launch_rf_quals(const JobDev& J, uint32_t half, hipStream_t st, KernelTimer* tm) {
+void launch_rf_quals_old(const JobDev& J, uint32_t half, hipStream_t st, KernelTimer* tm) {
   if (!J.n_win) return;
   KT_BEGIN(tm, "rf_quals", st);
   hipLaunchKernelGGL(k_rf_quals, dim3(J.n_win), dim3(NT), 0, st, J, half);
   KT_END(tm, st);
 }
 
-void launch_full_quals(const JobDev& J, hipStream_t st) {  // token planes are rewritten with identical contents
+void launch_full_quals_old(const JobDev& J, hipStream_t st) {  // token planes are rewritten with identical contents
   if (J.n_tiles) hipLaunchKernelGGL(k_final_tiles<true>, dim3(J.n_tiles), dim3(NT), 0, st, J);
 }
 
-void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm) {
+void launch_featurize_old(const JobDev& J, hipStream_t st, KernelTimer* tm) {
   if (J.n_ow) {
     KT_BEGIN(tm, "ow_stats", st);
     hipLaunchKernelGGL(k_ow_stats, dim3((J.n_ow + 3) / 4), dim3(NT), 4 * ow_stats_lds_per_wave(J.window_size), st, J);

@@ -160,6 +160,7 @@ struct herro_ctx {
   std::vector<Arena> free_scan, free_stage;            // device op array + staged CIGAR text of a job; pinned staging of one herro_job_create
   hipStream_t prep_stream = nullptr;                   // CIGAR scan of the job being created: its own (high-priority) stream, so that it does not queue behind the pileup / model kernels of earlier jobs
   hipEvent_t prep_ev = nullptr;
+  bool feat_old = false;                               // HERRO_FEAT_OLD=1: the round-2 tile featurizer (A/B while the bit-plane one settles)
   bool dev_scan = true;                                // HERRO_HOST_SCAN=1: decode the text on the host instead (A/B, debugging)
   std::vector<Arena> free_dev, free_pin, free_small;   // free_small: the buffers a job needs only once its counts are known (logits, batch descriptors)
   std::atomic<uint32_t> live_jobs{0};   // herro_job_create may run on another thread than the context's execution calls
@@ -380,6 +381,8 @@ herro_ctx* herro_create(int device_id) {
     }
     const char* hs = getenv("HERRO_HOST_SCAN");
     ctx->dev_scan = !(hs && atoi(hs) != 0);
+    const char* fo = getenv("HERRO_FEAT_NEW");
+    ctx->feat_old = !(fo && atoi(fo) != 0);
   }
   // ln(k+1) table from the host libm — what Rust's f64::ln calls on Linux (features.rs:507)
   std::vector<double> ln(1u << 20);
@@ -1181,6 +1184,8 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   const size_t o_cseq = take(row_elems), o_ctmp = take(row_elems), o_clen = take((uint64_t)n_win * 4);
   const size_t o_srow = take(row_elems * 4), o_spi = take(row_elems * 4);
   const size_t o_finb = take(fin_bytes), o_finq = take(fin_bytes), o_nd = take((uint64_t)n_cls * 8);
+  J.nw = (W + 31) / 32;
+  const size_t o_cpl = take((uint64_t)n_ow * 3 * J.nw * 4), o_iev = take(scr_ops * 16);
   const size_t dev_bytes = cur;
   job->dev = arena_acquire(ctx, ctx->free_dev, dev_bytes, 1);
   auto give_back = [&]() {
@@ -1205,6 +1210,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.cons_seq = (uint8_t*)(db + o_cseq); J.cons_tmp = (uint8_t*)(db + o_ctmp); J.cons_len = (uint32_t*)(db + o_clen);
   J.sup_row = (uint32_t*)(db + o_srow); J.sup_pi = (uint32_t*)(db + o_spi);
   J.fin_b = (uint8_t*)(db + o_finb); J.fin_q = (uint8_t*)(db + o_finq); J.nd = (uint32_t*)(db + o_nd);
+  J.cpl = (uint32_t*)(db + o_cpl); J.iev = (uint4*)(db + o_iev);
   // one copy, pinned -> device, asynchronous on the context stream: the kernels of herro_job_featurize queue behind it
   // in stream order, nobody waits here
   hipError_t e = hipMemcpyAsync(db, job->pin.p, desc_bytes, hipMemcpyHostToDevice, ctx->stream);
@@ -1275,7 +1281,8 @@ int herro_job_featurize(herro_job* job) {
   job->synced = false; job->inferred = false; job->quals_full = false;
   job->consensus_done = false; job->consensus_on_host = false; job->logits_on_host = false;
   if (job->J.n_win == 0) { job->featurized = true; return HERRO_OK; }
-  launch_featurize(job->J, ctx->stream, &ctx->timer);
+  if (ctx->feat_old) launch_featurize_old(job->J, ctx->stream, &ctx->timer);
+  else launch_featurize(job->J, ctx->stream, &ctx->timer);
   HIP_TRY(ctx, hipGetLastError());
   // the per-window counts follow the kernels into pinned memory; whoever needs them waits for the event,
   // not for the stream, so the next job's kernels can already be queued behind this one
@@ -1429,7 +1436,10 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   rc = ensure_scratch(ctx, max_tok);
   if (rc) return rc;
   // the qualities the model will read: rows within 2 * (kw / 2) of an informative row (two stacked convs)
-  if (!job->quals_full && !groups.empty()) launch_rf_quals(job->J, 2 * (ctx->M.h.kw / 2), ctx->stream, &ctx->timer);
+  if (!job->quals_full && !groups.empty()) {
+    if (ctx->feat_old) launch_rf_quals_old(job->J, 2 * (ctx->M.h.kw / 2), ctx->stream, &ctx->timer);
+    else launch_rf_quals(job->J, 2 * (ctx->M.h.kw / 2), ctx->stream, &ctx->timer);
+  }
   for (const Offs& o : offs) {
     const unsigned char* base = (const unsigned char*)job->d_bdesc;
     BatchDev B{};
@@ -1509,7 +1519,8 @@ static int fetch_planes(herro_job* job, uint32_t w, std::vector<uint8_t>& pb, st
   HIP_TRY(ctx, hipMemcpy(pb.data(), job->J.fin_b + wd.fin_off, bytes, hipMemcpyDeviceToHost));
   if (pq) {
     if (!job->quals_full) {  // featurize leaves the quality planes to whoever asks for them
-      launch_full_quals(job->J, ctx->stream);
+      if (ctx->feat_old) launch_full_quals_old(job->J, ctx->stream);
+      else launch_full_quals(job->J, ctx->stream);
       HIP_TRY(ctx, hipGetLastError());
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
       job->quals_full = true;

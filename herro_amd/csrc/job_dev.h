@@ -79,6 +79,10 @@ struct JobDev {
   uint8_t* cons_seq;     // [win.row_off ..] corrected bases of the window (ASCII), cons_len[w] of them
   uint8_t* cons_tmp;     // [win.row_off + row] per-row call before '*' removal
   uint32_t* cons_len;    // [win]
+  // ---- bit-plane featurizer (pileup.hip)
+  uint32_t nw;           // plane words per column: ceil(window_size / 32)
+  uint32_t* cpl;         // [ow][3][nw] column planes over the window's positions: query base present / low / high code bit (kept overlaps)
+  uint4* iev;            // per overlap (at scr_off): insertion events {pos | trimmed len << 16, query index, first 16 bases, untrimmed len}
 };
 
 // Accumulates GPU time per kernel group with HIP events recorded on the launch stream.
@@ -130,6 +134,9 @@ struct KernelTimer {
 #define KT_END(tm, st) do { if ((tm) && (tm)->on) (tm)->end(st); } while (0)
 
 void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm);
+void launch_featurize_old(const JobDev& J, hipStream_t st, KernelTimer* tm);
+void launch_rf_quals_old(const JobDev& J, uint32_t half, hipStream_t st, KernelTimer* tm);
+void launch_full_quals_old(const JobDev& J, hipStream_t st);
 // qualities inside the model's receptive fields (rows within `half` of an informative row)
 void launch_rf_quals(const JobDev& J, uint32_t half, hipStream_t st, KernelTimer* tm);
 // the complete quality planes (featurize itself only writes tokens)
