@@ -441,7 +441,7 @@ def main():
     if rank == 0:
         total_windows = args.steps * args.batch * world
         kern = {k: {"ms_total": v[0], "calls": v[1], "avg_us": 1e3 * v[0] / max(v[1], 1)} for k, v in tm.items()}
-        feat_names = ["ow_stats", "win_rank", "pass1_pos", "select_layout", "tile_plan", "final_tiles", "sup_compact", "rf_quals"]
+        feat_names = ["cols", "win", "layout", "tokens", "supgather", "rf_quals"]
         feat_ms = sum(tm[k][0] for k in feat_names if k in tm) / timed_steps
         model_ms = sum(v[0] for k, v in tm.items() if k not in feat_names) / timed_steps
         # ---- algorithmic work per launch (one launch = G steps = G*batch windows); DESIGN.md §4/§5
@@ -455,11 +455,10 @@ def main():
         rf_bytes = tokens * 5 * 31 * 2.0
         feat_bytes = per_job["read_bytes"] / 5.0 + per_job["op_bytes"] + per_job["out_bytes"] / 2.0 + rf_bytes
         alg = {  # name -> (bound, work per launch, unit)
-            "final_tiles": ("hbm", per_job["out_bytes"] / 2.0 + per_job["read_bytes"] / 5.0 * 31.0 / n_cols, "B"),
+            "tokens": ("hbm", per_job["out_bytes"] / 2.0, "B"),                                      # the token planes written
             "conv_fused": ("mfma", 2.0 * tokens * 31 * (KW * C1) * C2, "F"),
             "layers_fused": ("mfma", NL * (2.0 * tokens * D * 3 * D + 2.0 * tokens * D * D + 4.0 * tokens * D * FF), "F"),
-            "ow_stats": ("hbm", per_job["read_bytes"] / 5.0 + per_job["op_bytes"], "B"),          # 2-bit only
-            "pass1_pos": ("hbm", per_job["read_bytes"] / 5.0, "B"),
+            "cols": ("hbm", per_job["read_bytes"] / 5.0 + per_job["op_bytes"], "B"),              # 2-bit bases + ops read
             "patch_conv1": ("hbm", tokens * 31 * KW * C1 * 4, "B"),                               # y1 hi/lo written
             "conv2_gemm": ("mfma", 2.0 * tokens * 31 * (KW * C1) * C2, "F"),
             "fc_gemm": ("mfma", 2.0 * tokens * (31 * C2) * D, "F"),

@@ -160,7 +160,6 @@ struct herro_ctx {
   std::vector<Arena> free_scan, free_stage;            // device op array + staged CIGAR text of a job; pinned staging of one herro_job_create
   hipStream_t prep_stream = nullptr;                   // CIGAR scan of the job being created: its own (high-priority) stream, so that it does not queue behind the pileup / model kernels of earlier jobs
   hipEvent_t prep_ev = nullptr;
-  bool feat_old = false;                               // HERRO_FEAT_OLD=1: the round-2 tile featurizer (A/B while the bit-plane one settles)
   bool dev_scan = true;                                // HERRO_HOST_SCAN=1: decode the text on the host instead (A/B, debugging)
   std::vector<Arena> free_dev, free_pin, free_small;   // free_small: the buffers a job needs only once its counts are known (logits, batch descriptors)
   std::atomic<uint32_t> live_jobs{0};   // herro_job_create may run on another thread than the context's execution calls
@@ -381,8 +380,6 @@ herro_ctx* herro_create(int device_id) {
     }
     const char* hs = getenv("HERRO_HOST_SCAN");
     ctx->dev_scan = !(hs && atoi(hs) != 0);
-    const char* fo = getenv("HERRO_FEAT_NEW");
-    ctx->feat_old = !(fo && atoi(fo) != 0);
   }
   // ln(k+1) table from the host libm — what Rust's f64::ln calls on Linux (features.rs:507)
   std::vector<double> ln(1u << 20);
@@ -1142,7 +1139,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
     for (size_t i = 0; i < o.win.size(); i++) {
       WinDesc wd = o.win[i];
       wd.ow_begin += (uint32_t)b.ow;
-      wd.col_off = 0;
+      wd.col_off = tile;   // first tile of the window
       wd.fin_off = fin; fin += (uint64_t)HERRO_ROWS * wd.lub;
       wd.row_off = row; row += wd.lub;
       wd.pos_off = pos; pos += (uint64_t)W + 1;
@@ -1171,21 +1168,18 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.read_qual = ctx->d_qual; J.read_qual_off = ctx->d_qual_off; J.read_qual_bytes = ctx->qual_bytes; J.read_n_words = ctx->n_words;
   J.ln_table = ctx->d_ln; J.ln_table_n = ctx->ln_n;
   J.n_ow = n_ow; J.n_win = n_win; J.n_cls = n_cls;
-  J.n_tiles = (uint32_t)job->tile_win.size(); J.window_size = W; J.n_bw = W / 32 + 1; J.max_cols = max_cols;
-  { const char* d = getenv("HERRO_DBG"); J.dbg = d ? (uint32_t)atoi(d) : 0u; }
+  J.n_tiles = (uint32_t)job->tile_win.size(); J.window_size = W; J.nw = (W + 31) / 32; J.max_cols = max_cols;
   cur = desc_bytes;
-  const size_t o_op_t = take(scr_ops * 4), o_op_q = take(scr_ops * 4), o_ins_ev = take(scr_ops * 4), o_ins_cnt = take((uint64_t)n_ow * 4);
-  const size_t o_md = take(scr_ops * 16), o_bm = take((uint64_t)n_ow * J.n_bw * 8), o_chdr = take((uint64_t)n_ow * sizeof(ColHdr));
+  const size_t o_cpl = take(((uint64_t)n_ow + 1) * 3 * J.nw * 4), o_iev = take(scr_ops * 16), o_ins_cnt = take((uint64_t)n_ow * 4);
+  const size_t o_ocol = take((uint64_t)n_ow * 16);
   const size_t o_keep = take(n_ow), o_acc = take((uint64_t)n_ow * 4), o_ttot = take((uint64_t)n_ow * 4);
   const size_t o_slot = take((uint64_t)n_ow * 4), o_rqid = take((uint64_t)n_ow * 4), o_sel = take((uint64_t)n_win * 32 * 4);
-  const size_t tplan_bytes = (size_t)J.n_tiles * 32 * 64;
-  const size_t o_tplan = take(tplan_bytes), o_thdr = take((size_t)J.n_tiles * 64), o_dcounts = take((uint64_t)n_win * 12);
-  const size_t o_rop = take(pos_elems * 4), o_rmap = take(row_elems * 4), o_sflag = take(row_elems);
+  const size_t o_ctab = take((uint64_t)n_win * 32 * sizeof(CTab)), o_chdr = take((size_t)J.n_tiles * 8), o_tnsup = take((size_t)J.n_tiles * 4);
+  const size_t o_dcounts = take((uint64_t)n_win * 12);
+  const size_t o_rop = take(pos_elems * 4), o_rmap = take(row_elems * 4);
   const size_t o_cseq = take(row_elems), o_ctmp = take(row_elems), o_clen = take((uint64_t)n_win * 4);
   const size_t o_srow = take(row_elems * 4), o_spi = take(row_elems * 4);
   const size_t o_finb = take(fin_bytes), o_finq = take(fin_bytes), o_nd = take((uint64_t)n_cls * 8);
-  J.nw = (W + 31) / 32;
-  const size_t o_cpl = take((uint64_t)n_ow * 3 * J.nw * 4), o_iev = take(scr_ops * 16);
   const size_t dev_bytes = cur;
   job->dev = arena_acquire(ctx, ctx->free_dev, dev_bytes, 1);
   auto give_back = [&]() {
@@ -1198,23 +1192,19 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   unsigned char* db = (unsigned char*)job->dev.p;
   J.ops = ds ? (const uint32_t*)job->scan.p : (const uint32_t*)(db + o_ops); J.ow = (const OwDesc*)(db + o_ow); J.win = (const WinDesc*)(db + o_win);
   J.tile_win = (const uint32_t*)(db + o_tw); J.tile_r0 = (const uint32_t*)(db + o_tr);
-  J.op_t = (uint32_t*)(db + o_op_t); J.op_q = (uint32_t*)(db + o_op_q); J.ins_ev = (uint32_t*)(db + o_ins_ev);
-  J.ins_cnt = (uint32_t*)(db + o_ins_cnt);
-  J.md = (uint4*)(db + o_md); J.bm = (uint2*)(db + o_bm); J.chdr = (ColHdr*)(db + o_chdr);
+  J.cpl = (uint32_t*)(db + o_cpl); J.iev = (uint4*)(db + o_iev); J.ins_cnt = (uint32_t*)(db + o_ins_cnt); J.ocol = (uint4*)(db + o_ocol);
   J.ow_keep = (uint8_t*)(db + o_keep); J.ow_acc = (float*)(db + o_acc); J.ow_ttotal = (uint32_t*)(db + o_ttot);
   J.slot_ow = (uint32_t*)(db + o_slot); J.rank_qid = (uint32_t*)(db + o_rqid); J.sel_ow = (uint32_t*)(db + o_sel);
-  J.tplan = (struct herro::TPlan*)(db + o_tplan); J.thdr = (struct herro::TileHdr*)(db + o_thdr);
+  J.ctab = (CTab*)(db + o_ctab); J.chdr2 = (uint2*)(db + o_chdr); J.tile_nsup = (uint32_t*)(db + o_tnsup);
   job->d_counts = (uint32_t*)(db + o_dcounts);
   J.win_Lf = job->d_counts; J.win_nsup = job->d_counts + n_win; J.win_nkept = job->d_counts + 2ull * n_win;
-  J.row_of_pos2 = (uint32_t*)(db + o_rop); J.rowmap2 = (uint32_t*)(db + o_rmap); J.sup_flag = (uint8_t*)(db + o_sflag);
+  J.row_of_pos2 = (uint32_t*)(db + o_rop); J.rowmap2 = (uint32_t*)(db + o_rmap);
   J.cons_seq = (uint8_t*)(db + o_cseq); J.cons_tmp = (uint8_t*)(db + o_ctmp); J.cons_len = (uint32_t*)(db + o_clen);
   J.sup_row = (uint32_t*)(db + o_srow); J.sup_pi = (uint32_t*)(db + o_spi);
   J.fin_b = (uint8_t*)(db + o_finb); J.fin_q = (uint8_t*)(db + o_finq); J.nd = (uint32_t*)(db + o_nd);
-  J.cpl = (uint32_t*)(db + o_cpl); J.iev = (uint4*)(db + o_iev);
   // one copy, pinned -> device, asynchronous on the context stream: the kernels of herro_job_featurize queue behind it
   // in stream order, nobody waits here
   hipError_t e = hipMemcpyAsync(db, job->pin.p, desc_bytes, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess && tplan_bytes) e = hipMemsetAsync(J.tplan, 0xff, tplan_bytes, ctx->stream);  // records of empty tiles are loaded, never used
   if (e == hipSuccess) e = hipEventCreateWithFlags(&job->ev_counts, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&job->ev_blob, hipEventDisableTiming);
   if (e != hipSuccess) {
@@ -1281,8 +1271,7 @@ int herro_job_featurize(herro_job* job) {
   job->synced = false; job->inferred = false; job->quals_full = false;
   job->consensus_done = false; job->consensus_on_host = false; job->logits_on_host = false;
   if (job->J.n_win == 0) { job->featurized = true; return HERRO_OK; }
-  if (ctx->feat_old) launch_featurize_old(job->J, ctx->stream, &ctx->timer);
-  else launch_featurize(job->J, ctx->stream, &ctx->timer);
+  launch_featurize(job->J, ctx->stream, &ctx->timer);
   HIP_TRY(ctx, hipGetLastError());
   // the per-window counts follow the kernels into pinned memory; whoever needs them waits for the event,
   // not for the stream, so the next job's kernels can already be queued behind this one
@@ -1436,10 +1425,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   rc = ensure_scratch(ctx, max_tok);
   if (rc) return rc;
   // the qualities the model will read: rows within 2 * (kw / 2) of an informative row (two stacked convs)
-  if (!job->quals_full && !groups.empty()) {
-    if (ctx->feat_old) launch_rf_quals_old(job->J, 2 * (ctx->M.h.kw / 2), ctx->stream, &ctx->timer);
-    else launch_rf_quals(job->J, 2 * (ctx->M.h.kw / 2), ctx->stream, &ctx->timer);
-  }
+  if (!job->quals_full && !groups.empty()) launch_rf_quals(job->J, 2 * (ctx->M.h.kw / 2), ctx->stream, &ctx->timer);
   for (const Offs& o : offs) {
     const unsigned char* base = (const unsigned char*)job->d_bdesc;
     BatchDev B{};
@@ -1519,8 +1505,7 @@ static int fetch_planes(herro_job* job, uint32_t w, std::vector<uint8_t>& pb, st
   HIP_TRY(ctx, hipMemcpy(pb.data(), job->J.fin_b + wd.fin_off, bytes, hipMemcpyDeviceToHost));
   if (pq) {
     if (!job->quals_full) {  // featurize leaves the quality planes to whoever asks for them
-      if (ctx->feat_old) launch_full_quals_old(job->J, ctx->stream);
-      else launch_full_quals(job->J, ctx->stream);
+      launch_full_quals(job->J, ctx->stream);
       HIP_TRY(ctx, hipGetLastError());
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
       job->quals_full = true;

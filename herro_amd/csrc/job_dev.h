@@ -12,20 +12,22 @@
 
 #define HERRO_ROWS 31
 #define HERRO_MAX_WINDOW 8192
-#define HERRO_TILE 256        // pileup rows per workgroup in the tile kernels
+#define HERRO_TILE 1024       // rows of the final matrix per k_tokens workgroup (a "tile" of the job's tile list)
 
 namespace herro {
 
-// Per overlap-window column header, read through scalar loads by the tile kernels.
-struct __attribute__((aligned(16))) ColHdr {
-  int32_t off;        // window-relative position where the overlap starts
-  uint32_t t_total;   // target bases the slice consumes
-  uint32_t strand, cls;
-  int32_t sbase, sdir;  // stored index of alignment-orientation query base q = sbase + sdir*q
-  uint32_t md_off;    // first entry of the overlap's M/D op table
-  uint32_t n_md;      // entries in it
-  uint64_t q_woff;    // first 2-bit word of the query read
-  uint64_t qual_off;  // first quality byte of the query read
+// A window's column table (one entry per row of the final matrix; entry 0 = the target): what the token and quality
+// kernels need to know about a selected overlap, written by k_layout.
+struct __attribute__((aligned(16))) CTab {
+  int32_t off;         // window position where the overlap starts
+  uint32_t t_total;    // target bases it covers (0: padding column)
+  uint32_t tokc;       // token offset of a base (0 forward, 5 reverse) | gap token << 8
+  uint32_t ow;         // overlap index (0xffffffff: none)
+  uint32_t n_ev;       // insertion events
+  uint32_t ev_off;     // first of them in JobDev::iev
+  int32_t sbase, sdir; // stored index of alignment-orientation query base q = sbase + sdir * q (features.rs:97-108,128-153)
+  uint64_t qual_off;   // first quality byte of the read
+  uint64_t q_woff;     // first bit-plane word of the read
 };
 
 struct JobDev {
@@ -41,35 +43,32 @@ struct JobDev {
   const double* ln_table;         // ln(k+1) computed on the host with glibc (bit-faithful to Rust std)
   uint32_t ln_table_n;
   // ---- descriptors (uploaded by herro_job_create)
-  uint32_t n_ow, n_win, n_cls, n_tiles, window_size, n_bw;
+  uint32_t n_ow, n_win, n_cls, n_tiles, window_size;
+  uint32_t nw;        // plane words per column: ceil(window_size / 32)
   uint32_t max_cols;  // 1 + max overlaps per window (sizes the bit-sliced counters)
-  uint32_t dbg;       // HERRO_DBG phase mask (profiling experiments only; 0 in production)
   const uint32_t* ops;
   const OwDesc* ow;
   const WinDesc* win;
-  const uint32_t* tile_win;  // [n_tiles] window of each row tile
+  const uint32_t* tile_win;  // [n_tiles] window of each tile of HERRO_TILE rows (tiles cover the upper bound lub of every window)
   const uint32_t* tile_r0;   // [n_tiles] first row of the tile
   // ---- scratch / results
-  uint32_t* op_t;        // per (overlap, op): target bases consumed before the op
-  uint32_t* op_q;        // ... query bases consumed before the op
-  uint32_t* ins_ev;      // per overlap (at scr_off): insertion events, window-relative pos | len << 16
+  uint32_t* cpl;         // [ow][3][nw] column planes over the window's positions: query base present / low / high code bit (kept overlaps)
+  uint4* iev;            // per overlap (at scr_off): insertion events {pos | trimmed len << 16, query index, first 16 bases, untrimmed len}
   uint32_t* ins_cnt;     // [ow] number of insertion events
-  uint4* md;             // per overlap (at scr_off): M/D ops {t_beg, q_beg, len | isM<<31, following ins len}
-  uint2* bm;             // [ow * n_bw + i] {bitmap of M/D op starts for positions 32i.., ops before 32i}
-  ColHdr* chdr;          // [ow]
-  struct TPlan* tplan;   // [tile * 32 + c] staging plan of final-row tile x selected column (64 B)
-  struct TileHdr* thdr;  // [tile] window / row range / target words of the tile (64 B)
+  uint4* ocol;           // [ow] {window position where the overlap starts, target bases covered, kept, ratio class}
   uint8_t* ow_keep;      // long-indel filter verdict
   float* ow_acc;         // accuracy
   uint32_t* ow_ttotal;   // target bases consumed by the slice
   uint32_t* slot_ow;     // [win.ow_begin + slot] -> overlap index, slots ordered by accuracy rank
   uint32_t* sel_ow;      // [win * 32 + c], c in [1,31): overlap feeding final row c (0xffffffff: padding)
+  CTab* ctab;            // [win * 32 + c]
+  uint2* chdr2;          // [tile] {position of the tile's first row, 1 if that row is the position's base row}
+  uint32_t* tile_nsup;   // [tile] informative rows found in the tile
   uint32_t* win_nkept;
   uint32_t* win_Lf;      // rows of the final matrix (L')
   uint32_t* win_nsup;
   uint32_t* row_of_pos2; // [win.pos_off + p], p in [0, win_len]: final row of each target position
   uint32_t* rowmap2;     // [win.row_off + row] = pos | ins << 16
-  uint8_t* sup_flag;     // [win.row_off + final row] informative?
   uint32_t* sup_row;     // [win.row_off + k]   final row of informative position k
   uint32_t* sup_pi;      // [win.row_off + k]   pos | ins << 16
   uint8_t* fin_b;        // final token planes   [win.fin_off + c*lub + row], c in [0,31)
@@ -79,10 +78,6 @@ struct JobDev {
   uint8_t* cons_seq;     // [win.row_off ..] corrected bases of the window (ASCII), cons_len[w] of them
   uint8_t* cons_tmp;     // [win.row_off + row] per-row call before '*' removal
   uint32_t* cons_len;    // [win]
-  // ---- bit-plane featurizer (pileup.hip)
-  uint32_t nw;           // plane words per column: ceil(window_size / 32)
-  uint32_t* cpl;         // [ow][3][nw] column planes over the window's positions: query base present / low / high code bit (kept overlaps)
-  uint4* iev;            // per overlap (at scr_off): insertion events {pos | trimmed len << 16, query index, first 16 bases, untrimmed len}
 };
 
 // Accumulates GPU time per kernel group with HIP events recorded on the launch stream.
@@ -134,9 +129,6 @@ struct KernelTimer {
 #define KT_END(tm, st) do { if ((tm) && (tm)->on) (tm)->end(st); } while (0)
 
 void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm);
-void launch_featurize_old(const JobDev& J, hipStream_t st, KernelTimer* tm);
-void launch_rf_quals_old(const JobDev& J, uint32_t half, hipStream_t st, KernelTimer* tm);
-void launch_full_quals_old(const JobDev& J, hipStream_t st);
 // qualities inside the model's receptive fields (rows within `half` of an informative row)
 void launch_rf_quals(const JobDev& J, uint32_t half, hipStream_t st, KernelTimer* tm);
 // the complete quality planes (featurize itself only writes tokens)

@@ -1,28 +1,33 @@
 // pileup.hip — pileup feature generation on gfx950, bit-plane formulation (reference src/features.rs:326-583).
 //
-// Integer / byte work, HBM- and LDS-bound; no MFMA on purpose.  Three launches per job, one workgroup per WINDOW:
+// Integer / byte work, HBM- and latency-bound; no MFMA on purpose.  Every kernel is a swarm of small workgroups, each
+// with at most three dependent global round trips in front of its arithmetic:
 //
-//   k_pass1   per overlap (one wave each): CIGAR ops -> prefix sums -> the overlap's column as three BIT PLANES over the
-//             window's target positions (M: a query base is aligned here; lo / hi: its 2-bit code), written op by op with
-//             LDS atomics from the bit-plane copy of the read store; insertion events (position, length, first bases).
-//             From the planes: accuracy (features.rs:585-679) = popcounts of M & (query ^ target); long-indel filter
-//             (features.rs:315-324).  Per window: stable accuracy rank (features.rs:386-409), informative positions of
-//             pass 1 in bit-sliced counters (features.rs:681-722), match / mismatch tallies per query name
-//             (features.rs:461-500).  The reference's [L, 1+n] pass-1 matrix never exists.
-//   k_final   haplotype score, stable re-rank, top-30 (features.rs:502-525); row layout = prefix sum over the selected
-//             overlaps' max insertion (features.rs:44-95, 531-556); the [31][L'] token planes (features.rs:110-266) in
-//             chunks of <= 2048 rows: 16 rows x 1 column per step, bits pulled from the planes, inserted bases from a small
-//             LDS tile filled by the insertion events, one 16-byte store per step; symbol counts per row in registers ->
-//             informative rows (features.rs:558) and the decoder's majority vote (consensus.rs:178-200); ordered list of
-//             informative positions.
-//   k_quals   quality bytes (features.rs:139-152,197-198,225-226): the receptive fields of informative rows (what the model
-//             reads), or the complete planes on request.  Query index of a cell = rank in the M plane + insertion events.
+//   k_cols      one WAVE per overlap-window, no barriers: CIGAR ops -> prefix sums (DPP wave scans) -> table of M/D
+//               ops + bitmap of op starts (rank directory, one popcount finds the op covering a position) -> the
+//               overlap's column as three BIT PLANES over the window's target positions (M: a query base is aligned
+//               here; lo / hi: its 2-bit code), 32 positions per lane, from the bit-plane copy of the read store;
+//               insertion events (position, length, first bases).  From the planes: accuracy (features.rs:585-679) =
+//               popcounts of M & (query ^ target); long-indel filter (features.rs:315-324).
+//   k_win       one workgroup per window: informative positions of pass 1 in bit-sliced counters over the kept
+//               columns' planes (features.rs:681-722), match / mismatch tallies per query name (features.rs:461-500),
+//               stable accuracy rank (features.rs:386-409).  The reference's [L, 1+n] pass-1 matrix never exists.
+//   k_layout    one workgroup per window: haplotype score, stable re-rank, top-30 (features.rs:502-525); row of every
+//               position = prefix sum over the selected overlaps' max insertion (features.rs:44-95, 531-556).
+//   k_tokens    one workgroup per 1024 rows: the [31][L'] token planes (features.rs:110-266): 16 rows x 1 column per
+//               step, bits pulled from the planes, inserted bases from a small LDS tile filled by the insertion events, one
+//               16-byte store per step; symbol counts per row in registers -> informative rows (features.rs:558) and
+//               the decoder's majority vote (consensus.rs:178-200).
+//   k_supgather ordered list of informative positions of a window from its chunks' lists.
+//   k_quals     quality bytes (features.rs:139-152,197-198,225-226): the receptive fields of informative rows (what the
+//               model reads), or the complete planes on request.  Query index of a cell = rank in the M plane +
+//               insertion events.
 //
 // What the formulation buys: the work of a column is proportional to its OPS (~165), not to its 4096 positions; a cell
-// of the final matrix costs ~15 ALU operations and no search; HBM traffic is the op arrays and query bit planes in,
-// the token planes out, plus 1.5 KB of planes per kept overlap between the first two kernels.
-// Generality: any number of overlaps per window (columns in groups), insertions anywhere the reference accepts them
-// (leading insertion of an alignment that starts inside the window, consecutive insertion ops), windows of 16..8192.
+// of the final matrix costs ~20 ALU operations and no search; HBM traffic is the op arrays and query bit planes in,
+// the token planes out, plus 1.5 KB of planes per kept overlap in between.
+// Generality: any number of overlaps per window, insertions anywhere the reference accepts them (leading insertion of an
+// alignment that starts inside the window, consecutive insertion ops), windows of 16..8192.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -36,15 +41,11 @@ namespace herro {
 
 namespace {
 
-constexpr int PA_NT = 512, PA_NW = PA_NT / 64;   // k_pass1
-constexpr int PB_NT = 512;                       // k_final
-constexpr int PQ_NT = 256;                       // k_quals
 constexpr uint32_t NONE = 0xffffffffu;
-constexpr uint32_t ROWCAP = 2048;   // rows of the final matrix per chunk (k_final)
-constexpr uint32_t INSCAP = 448;    // insertion rows per chunk whose tokens fit the LDS tile
-constexpr uint32_t SCAP = 128;      // overlaps per window whose scores are cached in LDS
-constexpr uint32_t PCAP = 8;        // plane words an op-lane writes itself; longer M runs are written by the whole wave
-constexpr uint32_t QEVCAP = 1024;   // insertion events staged in LDS by k_quals
+constexpr uint32_t ROWCAP = HERRO_TILE;   // rows of the final matrix per k_tokens workgroup (1024)
+constexpr uint32_t INSCAP = 192;          // insertion rows whose tokens fit the LDS tile (more: the chunk is cut in pieces)
+constexpr uint32_t SCAP = 128;            // overlaps per window whose scores are cached in LDS
+constexpr uint32_t QEVCAP = 1024;         // insertion events staged in LDS by k_quals
 
 // ---- small helpers ---------------------------------------------------------------------------------------
 template <int NT>
@@ -161,124 +162,124 @@ struct SlicedCounters {
 };
 
 // dynamic-LDS opt-in is a per-device function attribute
-void pileup_opt_in_lds(const void* fn) {
+void pileup_opt_in_lds(const void* fn, int bytes) {
   static std::mutex mu;
   static std::set<std::pair<const void*, int>> done;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return;
   std::lock_guard<std::mutex> lk(mu);
-  if (done.insert({fn, dev}).second) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (done.insert({fn, dev}).second) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-// =====================================================================================================
-// k_pass1
-// =====================================================================================================
-struct ACol { int32_t off; uint32_t t_total, keep, pad; };
-
-__host__ __device__ inline uint32_t pass1_qcap(uint32_t nw) { return nw + 40u < 320u ? nw + 40u : 320u; }   // staged query plane words per wave
-__host__ __device__ inline uint32_t pass1_group(uint32_t nw) { return nw <= 128u ? 32u : (nw <= 256u ? 16u : 8u); }  // columns resident in LDS
-__host__ __device__ inline size_t pass1_lds(uint32_t nw) {
-  const uint32_t G = pass1_group(nw);
-  return ((size_t)(3 * G + 5) * nw + 16) * 4 + (size_t)G * sizeof(ACol) + (size_t)PA_NW * 2 * pass1_qcap(nw) * 4;
-}
-
-template <int NB>
-__global__ __launch_bounds__(PA_NT) void k_pass1(JobDev J) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t pa_smem[];
-  const uint32_t nw = J.nw, G = pass1_group(nw), qcap = pass1_qcap(nw);
-  uint32_t* s_pl = pa_smem;                              // [G][3][nw] column planes M, lo, hi
-  uint32_t* s_tp = s_pl + (size_t)G * 3 * nw;            // [2][nw]    target code planes
-  uint32_t* s_tv = s_tp + 2 * nw;                        // [nw]       positions inside the window
-  uint32_t* s_sup = s_tv + nw;                           // [nw]       informative positions (pass 1)
-  uint32_t* s_list = s_sup + nw;                         // [nw]       words with informative positions
-  uint32_t* s_misc = s_list + nw;                        // [16]       0: kept overlaps, 1: entries of s_list
-  ACol* s_col = reinterpret_cast<ACol*>(s_misc + 16);    // [G]
-  uint32_t* s_wq = reinterpret_cast<uint32_t*>(s_col + G);  // [PA_NW][2][qcap] query planes of the overlap a wave works on
-
-  const uint32_t w = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const WinDesc wd = J.win[w];
-  const uint32_t n = wd.ow_cnt;
-  const uint64_t pmax = J.read_n_words + 1;   // last word of the plane arrays
-  if (tid < nw) {
-    const uint64_t t_woff = J.read_word_off[wd.rid];
-    const int32_t P = (int32_t)(tid << 5);
-    const uint32_t vm = mask_range(0, (int32_t)wd.win_len - P);
-    s_tv[tid] = vm;
-    s_tp[tid] = glb_bits(J.read_p0, t_woff, pmax, (int32_t)wd.tstart + P) & vm;
-    s_tp[nw + tid] = glb_bits(J.read_p1, t_woff, pmax, (int32_t)wd.tstart + P) & vm;
+// ---- wave scans on the DPP network: row_shr inside rows of 16 lanes, then the two row broadcasts -----------
+__device__ __forceinline__ uint32_t wscan_incl(uint32_t v) {
+#ifdef HERRO_SCAN_SHFL
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
   }
-  if (tid < 16) s_misc[tid] = 0;
-  __syncthreads();
+#else
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+#endif
+  return v;
+}
+__device__ __forceinline__ uint32_t wlast(uint32_t incl) { return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63); }
+__device__ __forceinline__ uint32_t wsum(uint32_t v) { return wlast(wscan_incl(v)); }
 
-  SlicedCounters<NB> cnt;
-  cnt.clear();
-  if (tid < nw) cnt.add(ColPlanes{s_tv[tid], s_tp[tid], s_tp[nw + tid], 0u});  // the target column: always a base on these rows
+// =====================================================================================================
+// k_cols — one wave per overlap-window, no workgroup barriers
+// =====================================================================================================
+constexpr int CA_NT = 256, CA_NW = CA_NT / 64;
+constexpr uint32_t MDCAP = 192;   // ops per batch (three steps of 64); a slice with more ops runs several batches
+__host__ __device__ inline uint32_t cols_qcap(uint32_t nw) { return nw + 40u < 320u ? nw + 40u : 320u; }   // staged query plane words
+__host__ __device__ inline uint32_t cols_lds_words(uint32_t nw) { return 3 * MDCAP + 2 * (nw + 1) + 2 * cols_qcap(nw) + 2 * (nw + 2); }
 
-  for (uint32_t g0 = 0; g0 < n; g0 += G) {
-    const uint32_t ng = min(G, n - g0);
-    // ---- phase 1: one wave per overlap
-    for (uint32_t ci = wave; ci < ng; ci += PA_NW) {
-      const uint32_t o = wd.ow_begin + g0 + ci;
-      const OwDesc d = J.ow[o];
-      uint32_t* pl = s_pl + (size_t)ci * 3 * nw;
-      for (uint32_t i = lane; i < 3 * nw; i += 64) pl[i] = 0;
-      const uint32_t cnt_ops = d.op_cnt;
-      const uint32_t* __restrict__ ops = J.ops + d.op_begin;
-      const int32_t off = (int32_t)(d.tstart - d.wtstart);
-      const uint32_t qw0 = d.qbeg >> 5, nqw = ((d.qbeg + d.qlen) >> 5) - qw0 + 2;
-      const bool staged = nqw <= qcap;
-      uint32_t* q0 = s_wq + (size_t)wave * 2 * qcap;
-      uint32_t* q1 = q0 + qcap;
-      // every global load of the overlap is issued here, unconditionally (indices clamped), before anything waits
-      uint32_t op_r[3];
+__global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t ca_smem[];
+  const uint32_t nw = J.nw, qcap = cols_qcap(nw);
+  const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t o = blockIdx.x * CA_NW + wave;
+  if (o >= J.n_ow) return;
+  uint32_t* s_mt = ca_smem + (size_t)wave * cols_lds_words(nw);   // M/D ops of the batch: window position of the first base
+  uint32_t* s_mq = s_mt + MDCAP;                                  // ... query index of it
+  uint32_t* s_ml = s_mq + MDCAP;                                  // ... length | M << 31
+  uint32_t* s_bm = s_ml + MDCAP;                                  // [nw+1] bitmap of op starts over window positions
+  uint32_t* s_cum = s_bm + (nw + 1);                              // [nw+1] op starts in front of each word
+  uint32_t* q0 = s_cum + (nw + 1);                                // [qcap] query code planes (stored orientation)
+  uint32_t* q1 = q0 + qcap;
+  uint32_t* t0 = q1 + qcap;                                       // [nw+2] target code planes, raw words from the window's first word
+  uint32_t* t1 = t0 + (nw + 2);
+  const OwDesc d = J.ow[o];   // carries the window's and the reads' offsets: no further lookups before the data
+  const uint32_t cnt_ops = d.op_cnt;
+  const uint32_t* __restrict__ ops = J.ops + d.op_begin;
+  const int32_t off = (int32_t)(d.tstart - d.wtstart);
+  const uint64_t pmax = J.read_n_words + 1;   // last word of the plane arrays
+  const uint32_t qw0 = d.qbeg >> 5, nqw = ((d.qbeg + d.qlen) >> 5) - qw0 + 2;
+  const bool staged = nqw <= qcap;
+  // ---- every global load of the wave is issued here, unconditionally (indices clamped), before anything waits
+  uint32_t op_r[3];
 #pragma unroll
-      for (int i = 0; i < 3; i++) op_r[i] = ops[min(lane + 64u * i, cnt_ops - 1u)];
-      constexpr int QI = 5;
-      uint32_t v0[QI], v1[QI];
-      const uint64_t qbase = d.q_woff + qw0;
+  for (int i = 0; i < 3; i++) op_r[i] = ops[min(lane + 64u * i, cnt_ops - 1u)];
+  constexpr int QI = 5;
+  uint32_t v0[QI], v1[QI], u0[QI], u1[QI];
+  {
+    const uint64_t qbase = d.q_woff + qw0, tbase = d.t_woff + (d.wtstart >> 5);
 #pragma unroll
-      for (int i = 0; i < QI; i++) {
-        const uint64_t gi = min(qbase + min(lane + 64u * i, nqw - 1u), pmax);
-        v0[i] = J.read_p0[gi];
-        v1[i] = J.read_p1[gi];
-      }
-      if (staged) {
+    for (int i = 0; i < QI; i++) {
+      const uint64_t gi = min(qbase + min(lane + 64u * i, nqw - 1u), pmax);
+      v0[i] = J.read_p0[gi];
+      v1[i] = J.read_p1[gi];
+      const uint64_t ti = min(tbase + min(lane + 64u * i, nw + 1u), pmax);
+      u0[i] = J.read_p0[ti];
+      u1[i] = J.read_p1[ti];
+    }
+  }
 #pragma unroll
-        for (int i = 0; i < QI; i++) {
-          const uint32_t idx = lane + 64u * i;
-          if (idx < nqw) { q0[idx] = v0[i]; q1[idx] = v1[i]; }
-        }
-      }
-      const int32_t sbase = d.strand ? (int32_t)(d.qbeg + d.qlen - 1u) : (int32_t)d.qbeg;   // stored index of alignment-orientation base 0
-      const int32_t rel = -(int32_t)(qw0 << 5);
-      // code planes of the 32 alignment-orientation query bases qidx .. qidx + 31 (bits of bases outside the region are
-      // meaningless: callers mask).  Reverse strand: base k is the complement of stored base sbase - k (features.rs:128-153).
-      auto qbits = [&](int32_t qidx, uint32_t& b0, uint32_t& b1) {
-        if (d.strand == 0) {
-          const int32_t s = sbase + qidx;
-          if (staged) { b0 = lds_bits(q0, nqw, s + rel); b1 = lds_bits(q1, nqw, s + rel); }
-          else { b0 = glb_bits(J.read_p0, d.q_woff, pmax, s); b1 = glb_bits(J.read_p1, d.q_woff, pmax, s); }
-        } else {
-          const int32_t s = sbase - qidx - 31;
-          if (staged) { b0 = ~__brev(lds_bits(q0, nqw, s + rel)); b1 = ~__brev(lds_bits(q1, nqw, s + rel)); }
-          else { b0 = ~__brev(glb_bits(J.read_p0, d.q_woff, pmax, s)); b1 = ~__brev(glb_bits(J.read_p1, d.q_woff, pmax, s)); }
-        }
-      };
-      // one plane word of an M run that starts at window position P0 (query index q) and is e long
-      auto emit = [&](uint32_t wi, int32_t P0, uint32_t e, uint32_t q) {
-        const int32_t ws = (int32_t)(wi << 5);
-        const uint32_t seg = mask_range(P0 - ws, P0 + (int32_t)e - ws);
-        uint32_t b0, b1;
-        qbits((int32_t)q + (ws - P0), b0, b1);
-        atomicOr(&pl[wi], seg);
-        atomicOr(&pl[nw + wi], b0 & seg);
-        atomicOr(&pl[2 * nw + wi], b1 & seg);
-      };
-      uint32_t carry_t = 0, carry_q = 0, n_ev = 0, isum = 0, dsum = 0, longindel = 0;
-      uint4* __restrict__ ev = J.iev + d.scr_off;
-      auto step = [&](uint32_t base, uint32_t op) {
-        const uint32_t k = base + lane;
+  for (int i = 0; i < QI; i++) {
+    const uint32_t idx = lane + 64u * i;
+    if (staged && idx < nqw) { q0[idx] = v0[i]; q1[idx] = v1[i]; }
+    if (idx < nw + 2) { t0[idx] = u0[i]; t1[idx] = u1[i]; }
+  }
+  const int32_t sbase = d.strand ? (int32_t)(d.qbeg + d.qlen - 1u) : (int32_t)d.qbeg;   // stored index of alignment-orientation base 0
+  const int32_t rel = -(int32_t)(qw0 << 5);
+  // code planes of the 32 alignment-orientation query bases qidx .. qidx + 31 (bits of bases outside the region are
+  // meaningless: callers mask).  Reverse strand: base k is the complement of stored base sbase - k (features.rs:128-153).
+  auto qbits = [&](int32_t qidx, uint32_t& b0, uint32_t& b1) {
+    if (d.strand == 0) {
+      const int32_t s = sbase + qidx;
+      if (staged) { b0 = lds_bits(q0, nqw, s + rel); b1 = lds_bits(q1, nqw, s + rel); }
+      else { b0 = glb_bits(J.read_p0, d.q_woff, pmax, s); b1 = glb_bits(J.read_p1, d.q_woff, pmax, s); }
+    } else {
+      const int32_t s = sbase - qidx - 31;
+      if (staged) { b0 = ~__brev(lds_bits(q0, nqw, s + rel)); b1 = ~__brev(lds_bits(q1, nqw, s + rel)); }
+      else { b0 = ~__brev(glb_bits(J.read_p0, d.q_woff, pmax, s)); b1 = ~__brev(glb_bits(J.read_p1, d.q_woff, pmax, s)); }
+    }
+  };
+  uint32_t carry_t = 0, carry_q = 0, n_ev = 0, isum = 0, dsum = 0, longindel = 0;
+  uint4* __restrict__ ev = J.iev + d.scr_off;
+  constexpr int NWI = 4;   // plane words per lane (nw <= 256)
+  uint32_t pM[NWI], pL[NWI], pH[NWI];
+#pragma unroll
+  for (int i = 0; i < NWI; i++) { pM[i] = 0; pL[i] = 0; pH[i] = 0; }
+  const uint64_t lt = (1ull << lane) - 1ull;
+
+  for (uint32_t b0 = 0; b0 < cnt_ops; b0 += MDCAP) {
+    for (uint32_t i = lane; i <= nw; i += 64) s_bm[i] = 0;
+    uint32_t n_md = 0;
+    const int32_t Pb0 = off + (int32_t)carry_t;   // first window position of the batch
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      const uint32_t bs = b0 + 64u * s;
+      if (bs < cnt_ops) {   // wave-uniform
+        const uint32_t k = bs + lane;
+        const uint32_t op = b0 == 0 ? op_r[s] : ops[min(k, cnt_ops - 1u)];
         const bool valid = k < cnt_ops;
         const uint32_t ty = op_type(op), len = op_len(op);
         const uint32_t e = valid ? eff_len(op, k, cnt_ops, d.start_off, d.end_off) : 0u;
@@ -287,98 +288,165 @@ __global__ __launch_bounds__(PA_NT) void k_pass1(JobDev J) {
         if (isI) isum += e;
         if (isD) dsum += e;
         const uint32_t tadv = (isM || isD) ? e : 0u, qadv = (isM || isI) ? e : 0u;
-        uint64_t tot;
-        const uint64_t ex = wscan64((uint64_t)tadv | ((uint64_t)qadv << 32), &tot);
-        const uint32_t t = carry_t + (uint32_t)ex, q = carry_q + (uint32_t)(ex >> 32);
+        const uint32_t it = wscan_incl(tadv), iq = wscan_incl(qadv);
+        const uint32_t t = carry_t + it - tadv, q = carry_q + iq - qadv;
         // insertion behind window position off + t - 1 (features.rs:77, 219-228): position, trimmed length (bases written),
         // query index of its first base, its first 16 bases, untrimmed length (max_ins)
         const uint64_t imask = __ballot(isI);
         if (isI) {
-          const uint32_t idx = n_ev + (uint32_t)__popcll(imask & ((1ull << lane) - 1ull));
+          const uint32_t idx = n_ev + (uint32_t)__popcll(imask & lt);
           const int32_t pos = off + (int32_t)t - 1;
-          uint32_t b0, b1;
-          qbits((int32_t)q, b0, b1);
-          const uint32_t codes = spread16(b0) | (spread16(b1) << 1);
+          uint32_t c0, c1;
+          qbits((int32_t)q, c0, c1);
+          const uint32_t codes = spread16(c0) | (spread16(c1) << 1);
           ev[idx] = make_uint4(((uint32_t)pos & 0xffffu) | (min(e, 0xffffu) << 16), q, codes, min(len, 0xffffu));
         }
         n_ev += (uint32_t)__popcll(imask);
-        // plane words of an M run
-        int32_t P0 = 0;
-        uint32_t ee = 0, w0 = 0, nwords = 0;
-        if (isM) {
-          P0 = off + (int32_t)t;
-          ee = (uint32_t)P0 < d.wlen ? min(e, d.wlen - (uint32_t)P0) : 0u;
-          if (ee) { w0 = (uint32_t)P0 >> 5; nwords = (((uint32_t)P0 + ee - 1u) >> 5) - w0 + 1u; }
+        // table of M/D ops + bitmap of their first positions
+        const bool isMD = (isM || isD) && e != 0u;
+        const uint64_t mdmask = __ballot(isMD);
+        if (isMD) {
+          const uint32_t idx = n_md + (uint32_t)__popcll(mdmask & lt);
+          const uint32_t P = (uint32_t)(off + (int32_t)t);
+          s_mt[idx] = P;
+          s_mq[idx] = q;
+          s_ml[idx] = e | (isM ? 0x80000000u : 0u);
+          if (P < ((nw + 1u) << 5)) atomicOr(&s_bm[P >> 5], 1u << (P & 31u));
         }
-        const bool longop = nwords > PCAP;
-        if (!longop)
-          for (uint32_t i = 0; i < nwords; i++) emit(w0 + i, P0, ee, q);
-        uint64_t lm = __ballot(longop);
-        while (lm) {
-          const int src = __ffsll((unsigned long long)lm) - 1;
-          lm &= lm - 1;
-          const int32_t P0s = __shfl(P0, src, 64);
-          const uint32_t es = __shfl(ee, src, 64), qs = __shfl(q, src, 64), w0s = __shfl(w0, src, 64), nws = __shfl(nwords, src, 64);
-          for (uint32_t i = lane; i < nws; i += 64) emit(w0s + i, P0s, es, qs);
-        }
-        carry_t += (uint32_t)tot;
-        carry_q += (uint32_t)(tot >> 32);
-      };
+        n_md += (uint32_t)__popcll(mdmask);
+        carry_t += wlast(it);
+        carry_q += wlast(iq);
+      }
+    }
+    // the wave reads its own LDS writes back: LDS operations of one wave execute in order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {  // rank directory: op starts in front of every bitmap word
+      uint32_t carry = 0;
+      for (uint32_t bb = 0; bb <= nw; bb += 64) {
+        const uint32_t i = bb + lane;
+        const uint32_t pc = i <= nw ? (uint32_t)__popc(s_bm[i]) : 0u;
+        const uint32_t inc = wscan_incl(pc);
+        if (i <= nw) s_cum[i] = carry + inc - pc;
+        carry += wlast(inc);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // planes of the batch's positions: a lane owns 32 positions, the op covering the first one is a popcount away
+    const int32_t Pb1 = min(off + (int32_t)carry_t, (int32_t)d.wlen);
 #pragma unroll
-      for (int i = 0; i < 3; i++)
-        if (64u * i < cnt_ops) step(64u * i, op_r[i]);   // wave-uniform
-      for (uint32_t base = 192; base < cnt_ops; base += 64) step(base, ops[min(base + lane, cnt_ops - 1u)]);
-      const uint32_t t_total = carry_t;
-      // the wave reads its own LDS atomics back: LDS operations of one wave execute in order
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // accuracy: matches / mismatches over M ops (features.rs:650-665)
-      uint32_t mm = 0, ss = 0;
-      for (uint32_t i = lane; i < nw; i += 64) {
-        const uint32_t M = pl[i];
-        const uint32_t x = (pl[nw + i] ^ s_tp[i]) | (pl[2 * nw + i] ^ s_tp[nw + i]);
-        ss += __popc(M & x);
-        mm += __popc(M);
-      }
-      const uint64_t t1 = wsum64((uint64_t)mm | ((uint64_t)ss << 32));
-      const uint64_t t2 = wsum64((uint64_t)isum | ((uint64_t)dsum << 32));
-      const bool keep = __ballot(longindel != 0u) == 0ull;
-      if (lane == 0) {
-        const uint32_t s_ = (uint32_t)(t1 >> 32), m_ = (uint32_t)t1 - s_, i_ = (uint32_t)t2, d_ = (uint32_t)(t2 >> 32);
-        J.ow_keep[o] = keep ? 1 : 0;
-        J.ow_acc[o] = __fdiv_rn((float)m_, (float)(m_ + s_ + i_ + d_));   // (m as f32) / ((m+s+i+d) as f32) (features.rs:678)
-        J.ow_ttotal[o] = t_total;
-        J.ins_cnt[o] = n_ev;
-        ACol c;
-        c.off = off; c.t_total = t_total; c.keep = keep ? 1u : 0u; c.pad = 0;
-        s_col[ci] = c;
-        if (keep) atomicAdd(&s_misc[0], 1u);
-      }
-      if (keep) {
-        uint32_t* __restrict__ g = J.cpl + (uint64_t)o * 3 * nw;
-        for (uint32_t i = lane; i < 3 * nw; i += 64) g[i] = pl[i];
+    for (int wi_i = 0; wi_i < NWI; wi_i++) {
+      const uint32_t wi = lane + 64u * wi_i;
+      const int32_t ws = (int32_t)(wi << 5);
+      const int32_t lo_p = max(ws, Pb0), hi_p = min(ws + 32, Pb1);
+      if (wi < nw && lo_p < hi_p) {
+        uint32_t r = s_cum[wi] + (uint32_t)__popc(s_bm[wi] & (0xffffffffu >> (31u - ((uint32_t)lo_p & 31u)))) - 1u;
+        int32_t P = lo_p;
+        while (P < hi_p && r < n_md) {
+          const int32_t tP = (int32_t)s_mt[r];
+          const uint32_t ll = s_ml[r];
+          const int32_t se = min(hi_p, tP + (int32_t)(ll & 0x7fffffffu));
+          const uint32_t seg = mask_range(P - ws, se - ws);
+          if (ll >> 31) {
+            uint32_t c0, c1;
+            qbits((int32_t)s_mq[r] + (ws - tP), c0, c1);
+            pM[wi_i] |= seg;
+            pL[wi_i] |= c0 & seg;
+            pH[wi_i] |= c1 & seg;
+          }
+          P = se;
+          r++;
+        }
       }
     }
-    __syncthreads();
-    // ---- phase 2: symbol counts per position over the kept columns of the group
-    if (tid < nw) {
-      const int32_t ws = (int32_t)(tid << 5);
-      for (uint32_t ci = 0; ci < ng; ci++) {
-        const ACol c = s_col[ci];
-        if (!c.keep) continue;
-        const uint32_t* pl = s_pl + (size_t)ci * 3 * nw;
-        const uint32_t M = pl[tid];
-        const uint32_t inr = mask_range(c.off - ws, c.off + (int32_t)c.t_total - ws) & s_tv[tid];
-        cnt.add(ColPlanes{M, pl[nw + tid], pl[2 * nw + tid], inr & ~M});
-      }
-    }
-    if (g0 + G < n) __syncthreads();
   }
-  __syncthreads();
-  const uint32_t n_kept = s_misc[0];
+  const uint32_t t_total = carry_t;
+  const bool keep = __ballot(longindel != 0u) == 0ull;
+  // accuracy: matches / mismatches over M ops (features.rs:650-665)
+  uint32_t mm = 0, ss = 0;
+  {
+    const uint32_t tsh = d.wtstart & 31u;
+#pragma unroll
+    for (int wi_i = 0; wi_i < NWI; wi_i++) {
+      const uint32_t wi = lane + 64u * wi_i;
+      if (wi < nw) {
+        const uint32_t tl = __funnelshift_r(t0[wi], t0[wi + 1], tsh), th = __funnelshift_r(t1[wi], t1[wi + 1], tsh);
+        const uint32_t x = (pL[wi_i] ^ tl) | (pH[wi_i] ^ th);
+        ss += __popc(pM[wi_i] & x);
+        mm += __popc(pM[wi_i]);
+      }
+    }
+  }
+  mm = wsum(mm); ss = wsum(ss); isum = wsum(isum); dsum = wsum(dsum);
+  if (lane == 0) {
+    const uint32_t m_ = mm - ss;
+    J.ow_keep[o] = keep ? 1 : 0;
+    J.ow_acc[o] = __fdiv_rn((float)m_, (float)(m_ + ss + isum + dsum));   // (m as f32) / ((m+s+i+d) as f32) (features.rs:678)
+    J.ow_ttotal[o] = t_total;
+    J.ins_cnt[o] = n_ev;
+    J.ocol[o] = make_uint4((uint32_t)off, t_total, keep ? 1u : 0u, d.cls);
+  }
+  if (keep) {
+    uint32_t* __restrict__ g = J.cpl + (uint64_t)o * 3 * nw;
+#pragma unroll
+    for (int wi_i = 0; wi_i < NWI; wi_i++) {
+      const uint32_t wi = lane + 64u * wi_i;
+      if (wi < nw) { g[wi] = pM[wi_i]; g[nw + wi] = pL[wi_i]; g[2 * nw + wi] = pH[wi_i]; }
+    }
+  }
+}
+
+// =====================================================================================================
+// k_win — one workgroup per window (blockDim.x >= nw): pass-1 informative positions, tallies, accuracy rank
+// =====================================================================================================
+constexpr uint32_t RKCAP = 1024;   // overlaps per window whose accuracies are ranked out of LDS
+
+template <int NB>
+__global__ __launch_bounds__(256) void k_win(JobDev J) {
+  __shared__ float s_acc[RKCAP];
+  __shared__ uint8_t s_keep[RKCAP];
+  const uint32_t w = blockIdx.x, tid = threadIdx.x, NT = blockDim.x, nw = J.nw;
+  const WinDesc wd = J.win[w];
+  const uint32_t n = wd.ow_cnt;
+  const uint64_t pmax = J.read_n_words + 1;
+  const bool active = tid < nw;
+  const uint32_t widx = min(tid, nw - 1u);
+  const int32_t P = (int32_t)(widx << 5);
+  const uint32_t vm = active ? mask_range(0, (int32_t)wd.win_len - P) : 0u;
+  const uint64_t t_woff = J.read_word_off[wd.rid];
+  const uint32_t tlo = glb_bits(J.read_p0, t_woff, pmax, (int32_t)wd.tstart + P) & vm;
+  const uint32_t thi = glb_bits(J.read_p1, t_woff, pmax, (int32_t)wd.tstart + P) & vm;
+  SlicedCounters<NB> cnt;
+  cnt.clear();
+  cnt.add(ColPlanes{vm, tlo, thi, 0u});  // the target column: always a base on these rows
+  uint32_t n_kept = 0;
+  constexpr int UB = 8;   // columns whose loads are in flight together
+  for (uint32_t c0 = 0; c0 < n; c0 += UB) {
+    uint4 oc[UB];
+    uint32_t M[UB], L[UB], H[UB];
+#pragma unroll
+    for (int u = 0; u < UB; u++) {
+      const uint64_t o = wd.ow_begin + min(c0 + u, n - 1u);
+      const uint32_t* __restrict__ g = J.cpl + o * 3 * nw + widx;   // planes of overlaps that were not kept are never written: loaded, ignored
+      oc[u] = J.ocol[o];
+      M[u] = g[0]; L[u] = g[nw]; H[u] = g[2 * nw];
+    }
+#pragma unroll
+    for (int u = 0; u < UB; u++) {
+      if (c0 + u < n && oc[u].z) {   // uniform
+        n_kept++;
+        const int32_t off = (int32_t)oc[u].x;
+        const uint32_t inr = mask_range(off - P, off + (int32_t)oc[u].y - P) & vm;
+        cnt.add(ColPlanes{M[u] & inr, L[u] & inr, H[u] & inr, inr & ~M[u]});
+      }
+    }
+  }
   // ---- informative positions: at least two symbols reach the threshold (features.rs:681-722)
-  if (tid < nw) {
+  uint32_t sup;
+  {
     const uint32_t ncols = 1u + (n_kept > 30u ? n_kept : 30u);  // features.rs:282
     const uint32_t thresh = (uint32_t)((double)ncols * 0.1);    // features.rs:712
     uint32_t one = 0, two = 0;
@@ -388,40 +456,47 @@ __global__ __launch_bounds__(PA_NT) void k_pass1(JobDev J) {
       two |= one & g;
       one |= g;
     }
-    const uint32_t sup = (thresh == 0 ? 0xffffffffu : two) & s_tv[tid];
-    s_sup[tid] = sup;
-    if (sup) s_list[atomicAdd(&s_misc[1], 1u)] = tid;
+    sup = (thresh == 0 ? 0xffffffffu : two) & vm;
   }
-  __syncthreads();
   // ---- tallies (features.rs:478-498): every kept column is scored at every informative target position; anything but
-  // the target's base ('.', '*', '#', another base) is a mismatch.  Informative positions are rare: only the plane words
-  // that hold one are looked at.
-  {
-    const uint32_t nl = s_misc[1];
-    const bool in_lds = n <= G;
-    for (uint32_t item = tid; item < nl * n; item += PA_NT) {
-      const uint32_t li = item / n, c = item - li * n;
-      const uint32_t o = wd.ow_begin + c;
-      if (!J.ow_keep[o]) continue;
-      const uint32_t wi = s_list[li], sup = s_sup[wi];
-      const uint32_t* src = in_lds ? (const uint32_t*)(s_pl + (size_t)c * 3 * nw) : (const uint32_t*)(J.cpl + (uint64_t)o * 3 * nw);
-      const uint32_t M = src[wi], lo = src[nw + wi], hi = src[2 * nw + wi];
-      const uint32_t match = sup & M & ~((lo ^ s_tp[wi]) | (hi ^ s_tp[nw + wi]));
-      const uint32_t nm = __popc(match), cls = J.ow[o].cls;
-      if (nm) atomicAdd(&J.nd[2 * (uint64_t)cls], nm);
-      atomicAdd(&J.nd[2 * (uint64_t)cls + 1], (uint32_t)__popc(sup) - nm);
+  // the target's base ('.', '*', '#', another base) is a mismatch.  Informative positions are rare: only the lanes whose
+  // word holds one go through the columns again.
+  if (sup) {
+    const uint32_t nsup = (uint32_t)__popc(sup);
+    for (uint32_t c0 = 0; c0 < n; c0 += UB) {
+      uint4 oc[UB];
+      uint32_t M[UB], L[UB], H[UB];
+#pragma unroll
+      for (int u = 0; u < UB; u++) {
+        const uint64_t o = wd.ow_begin + min(c0 + u, n - 1u);
+        const uint32_t* __restrict__ g = J.cpl + o * 3 * nw + widx;
+        oc[u] = J.ocol[o];
+        M[u] = g[0]; L[u] = g[nw]; H[u] = g[2 * nw];
+      }
+#pragma unroll
+      for (int u = 0; u < UB; u++) {
+        if (c0 + u < n && oc[u].z) {
+          const uint32_t nm = (uint32_t)__popc(sup & M[u] & ~((L[u] ^ tlo) | (H[u] ^ thi)));
+          if (nm) atomicAdd(&J.nd[2 * (uint64_t)oc[u].w], nm);
+          if (nsup - nm) atomicAdd(&J.nd[2 * (uint64_t)oc[u].w + 1], nsup - nm);
+        }
+      }
     }
   }
   // ---- stable rank of the kept overlaps by descending accuracy: sort_by_key(-acc) (features.rs:386-409)
-  for (uint32_t i = tid; i < n; i += PA_NT) {
+  const bool in_lds = n <= RKCAP;
+  if (in_lds) {
+    for (uint32_t i = tid; i < n; i += NT) { s_acc[i] = J.ow_acc[wd.ow_begin + i]; s_keep[i] = J.ow_keep[wd.ow_begin + i]; }
+    __syncthreads();
+  }
+  for (uint32_t i = tid; i < n; i += NT) {
     const uint32_t oi = wd.ow_begin + i;
-    if (!J.ow_keep[oi]) continue;
-    const float ai = J.ow_acc[oi];
+    if (!(in_lds ? s_keep[i] : J.ow_keep[oi])) continue;
+    const float ai = in_lds ? s_acc[i] : J.ow_acc[oi];
     uint32_t rank = 0;
     for (uint32_t j = 0; j < n; j++) {
-      const uint32_t oj = wd.ow_begin + j;
-      if (!J.ow_keep[oj]) continue;
-      const float aj = J.ow_acc[oj];
+      if (!(in_lds ? s_keep[j] : J.ow_keep[wd.ow_begin + j])) continue;
+      const float aj = in_lds ? s_acc[j] : J.ow_acc[wd.ow_begin + j];
       if (aj > ai || (aj == ai && j < i)) rank++;
     }
     J.slot_ow[wd.ow_begin + rank] = oi;
@@ -430,78 +505,27 @@ __global__ __launch_bounds__(PA_NT) void k_pass1(JobDev J) {
 }
 
 // =====================================================================================================
-// k_final
+// k_layout — one workgroup per window: selection of the 30 columns, row of every position
 // =====================================================================================================
-struct __attribute__((aligned(16))) BCol {
-  int32_t off;       // window position where the overlap starts
-  uint32_t t_total;  // target bases it covers (0: padding column)
-  uint32_t tokc;     // token offset of a base (0 forward, 5 reverse) | gap token << 8
-  uint32_t ow;
-};
+constexpr int LY_NT = 256;
+__host__ __device__ inline size_t layout_lds(uint32_t W) { return (size_t)(W + 1) * 4; }
 
-struct FinalLds {   // byte offsets into the dynamic LDS block
-  uint32_t hdr, uni, pl, rbase, rop16, misc, sel, nev, pref, supbits, wave, total;
-};
-__host__ __device__ inline FinalLds final_lds(uint32_t W, uint32_t nw) {
-  FinalLds L;
-  uint32_t cur = 0;
-  auto take = [&](uint32_t bytes) { const uint32_t o = cur; cur = (cur + bytes + 15u) & ~15u; return o; };
-  L.hdr = take(32 * sizeof(BCol));
-  const uint32_t a = W * 4u, b = ROWCAP * 2u + 32u * INSCAP, c = SCAP * 8u;   // max insertion per position | row info + insertion tile | scores
-  L.uni = take(a > b ? (a > c ? a : c) : (b > c ? b : c));
-  L.pl = take(HERRO_ROWS * 3u * (nw + 1u) * 4u);
-  L.rbase = take((nw + 1u) * 4u);
-  L.rop16 = take((W + 2u) * 2u);
-  L.misc = take(32 * 4);
-  L.sel = take(32 * 4);
-  L.nev = take(32 * 4);
-  L.pref = take(32 * 4);
-  L.supbits = take((ROWCAP / 32) * 4);
-  L.wave = take((PB_NT / 64) * 4);
-  L.total = cur;
-  return L;
-}
-
-__device__ __forceinline__ uint32_t dpp_quad_add(uint32_t v) {   // sum over the 4 lanes of a quad, in every lane
-  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
-  return v;
-}
-__device__ __forceinline__ uint32_t dpp_quad_lane0(uint32_t v) {  // value of the quad's first lane
-  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x00, 0xf, 0xf, true);  // quad_perm [0,0,0,0]
-}
-
-__global__ __launch_bounds__(PB_NT) void k_final(JobDev J) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char pb_smem[];
-  const uint32_t nw = J.nw, nwp = nw + 1, W = J.window_size;
-  const FinalLds LO = final_lds(W, nw);
-  BCol* s_hdr = reinterpret_cast<BCol*>(pb_smem + LO.hdr);
-  uint32_t* s_mi = reinterpret_cast<uint32_t*>(pb_smem + LO.uni);          // phase 2-3
-  double* s_score = reinterpret_cast<double*>(pb_smem + LO.uni);           // phase 0
-  uint16_t* s_rowinfo = reinterpret_cast<uint16_t*>(pb_smem + LO.uni);     // chunks: position | first-row flag << 15
-  uint8_t* s_ins = pb_smem + LO.uni + ROWCAP * 2;                          // chunks: [32][INSCAP] tokens of inserted bases, 0xff: none
-  uint32_t* s_pl = reinterpret_cast<uint32_t*>(pb_smem + LO.pl);           // [31][3][nwp]
-  uint32_t* s_rbase = reinterpret_cast<uint32_t*>(pb_smem + LO.rbase);     // [nwp] row of position 32 i
-  uint16_t* s_rop16 = reinterpret_cast<uint16_t*>(pb_smem + LO.rop16);     // [W+1] row of position p - s_rbase[p >> 5]
-  uint32_t* s_misc = reinterpret_cast<uint32_t*>(pb_smem + LO.misc);
-  uint32_t* s_sel = reinterpret_cast<uint32_t*>(pb_smem + LO.sel);
-  uint32_t* s_nev = reinterpret_cast<uint32_t*>(pb_smem + LO.nev);
-  uint32_t* s_pref = reinterpret_cast<uint32_t*>(pb_smem + LO.pref);
-  uint32_t* s_supbits = reinterpret_cast<uint32_t*>(pb_smem + LO.supbits);
-  uint32_t* s_wave = reinterpret_cast<uint32_t*>(pb_smem + LO.wave);
-
-  const uint32_t w = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+__global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t ly_smem[];
+  uint32_t* s_mi = ly_smem;   // [W+1] max insertion behind every position, then (in place) the row of every position
+  __shared__ double s_score[SCAP];
+  __shared__ uint32_t s_sel[32], s_nev[32], s_evoff[32], s_pref[33], s_wave[LY_NT / 64];
+  const uint32_t w = blockIdx.x, tid = threadIdx.x;
   const WinDesc wd = J.win[w];
   const uint32_t n_kept = J.win_nkept[w];
   const uint32_t win_len = wd.win_len;
-  const uint64_t pmax = J.read_n_words + 1;
-  if (tid < 32) { s_sel[tid] = NONE; s_misc[tid] = 0; }
+  if (tid < 32) s_sel[tid] = NONE;
+  for (uint32_t p = tid; p <= win_len; p += LY_NT) s_mi[p] = 0;
   __syncthreads();
-
-  // ---- phase 0: score n/(n+d)*ln(n+d+1) in f64 (features.rs:505-510); stable descending rank (features.rs:512-513)
+  // ---- score n/(n+d)*ln(n+d+1) in f64 (features.rs:505-510); stable descending rank (features.rs:512-513)
   {
     auto score_of = [&](uint32_t k) -> double {
-      const uint32_t cls = J.ow[J.slot_ow[wd.ow_begin + k]].cls;
+      const uint32_t cls = J.ocol[J.slot_ow[wd.ow_begin + k]].w;
       const uint32_t nn = J.nd[2 * (uint64_t)cls], dd = J.nd[2 * (uint64_t)cls + 1];
       const uint32_t tot = nn + dd;
       if (!tot) return 0.0;
@@ -510,10 +534,10 @@ __global__ __launch_bounds__(PB_NT) void k_final(JobDev J) {
     };
     const bool cached = n_kept <= SCAP;
     if (cached) {
-      for (uint32_t k = tid; k < n_kept; k += PB_NT) s_score[k] = score_of(k);
+      for (uint32_t k = tid; k < n_kept; k += LY_NT) s_score[k] = score_of(k);
       __syncthreads();
     }
-    for (uint32_t k = tid; k < n_kept; k += PB_NT) {
+    for (uint32_t k = tid; k < n_kept; k += LY_NT) {
       const double sk = cached ? s_score[k] : score_of(k);
       uint32_t rank = 0;
       for (uint32_t i = 0; i < n_kept; i++) {
@@ -524,217 +548,330 @@ __global__ __launch_bounds__(PB_NT) void k_final(JobDev J) {
       J.rank_qid[wd.ow_begin + rank] = J.ow[o].qid;
       if (rank < 30u) s_sel[rank + 1] = o;
     }
-    __syncthreads();   // also: nobody reads s_score any more
+    __syncthreads();
   }
-  // ---- phase 1: headers and planes of the selected columns (column 0 = the target), max-insertion array cleared
+  // ---- the window's column table: everything the token and quality kernels need to know about a column
   if (tid < 32) {
-    J.sel_ow[(uint64_t)w * 32 + tid] = s_sel[tid];
-    BCol h;
-    h.off = 0; h.t_total = 0; h.tokc = (uint32_t)TOK_GAP_F << 8; h.ow = NONE;
-    uint32_t nev = 0;
-    if (tid == 0) h.t_total = win_len;
-    else if (s_sel[tid] != NONE) {
+    CTab t;
+    t.off = 0; t.t_total = 0; t.tokc = (uint32_t)TOK_GAP_F << 8; t.ow = NONE; t.n_ev = 0; t.ev_off = 0; t.sbase = 0; t.sdir = 1;
+    t.qual_off = 0; t.q_woff = 0;
+    if (tid == 0) {   // the target
+      t.t_total = win_len;
+      t.q_woff = J.read_word_off[wd.rid];
+      t.qual_off = J.read_qual_off[wd.rid];
+    } else if (s_sel[tid] != NONE) {
       const uint32_t o = s_sel[tid];
       const OwDesc& d = J.ow[o];
-      h.off = (int32_t)(d.tstart - d.wtstart);
-      h.t_total = J.ow_ttotal[o];
-      h.tokc = d.strand ? (5u | ((uint32_t)TOK_GAP_R << 8)) : ((uint32_t)TOK_GAP_F << 8);
-      h.ow = o;
-      nev = J.ins_cnt[o];
+      t.off = (int32_t)(d.tstart - d.wtstart);
+      t.t_total = J.ow_ttotal[o];
+      t.tokc = d.strand ? (5u | ((uint32_t)TOK_GAP_R << 8)) : ((uint32_t)TOK_GAP_F << 8);
+      t.ow = o;
+      t.n_ev = J.ins_cnt[o];
+      t.ev_off = d.scr_off;
+      t.sbase = d.strand ? (int32_t)(d.qbeg + d.qlen - 1u) : (int32_t)d.qbeg;
+      t.sdir = d.strand ? -1 : 1;
+      t.qual_off = d.q_qual_off;
+      t.q_woff = d.q_woff;
     }
-    s_hdr[tid] = h;
-    s_nev[tid] = nev;
-  }
-  {
-    const uint32_t per = 3 * nw, total = (HERRO_ROWS - 1) * per;
-    for (uint32_t it = tid; it < total; it += PB_NT) {
-      const uint32_t c = it / per, rem = it - c * per, pi = rem / nw, wi = rem - pi * nw;
-      const uint32_t o = s_sel[c + 1];
-      s_pl[((c + 1) * 3 + pi) * nwp + wi] = o != NONE ? J.cpl[(uint64_t)o * per + rem] : 0u;
-    }
-    if (tid < nw) {
-      const uint64_t t_woff = J.read_word_off[wd.rid];
-      const int32_t P = (int32_t)(tid << 5);
-      const uint32_t vm = mask_range(0, (int32_t)win_len - P);
-      s_pl[0 * nwp + tid] = vm;
-      s_pl[1 * nwp + tid] = glb_bits(J.read_p0, t_woff, pmax, (int32_t)wd.tstart + P) & vm;
-      s_pl[2 * nwp + tid] = glb_bits(J.read_p1, t_woff, pmax, (int32_t)wd.tstart + P) & vm;
-    }
-    if (tid < HERRO_ROWS * 3) s_pl[tid * nwp + nw] = 0;   // pad word of every plane
-    for (uint32_t p = tid; p < W; p += PB_NT) s_mi[p] = 0;
+    J.ctab[(uint64_t)w * 32 + tid] = t;
+    J.sel_ow[(uint64_t)w * 32 + tid] = s_sel[tid];
+    s_nev[tid] = t.n_ev;
+    s_evoff[tid] = t.ev_off;
   }
   __syncthreads();
-  // ---- phase 2: max insertion behind every position over the SELECTED overlaps: rows where every selected column is a
-  // gap are dropped (features.rs:531-556), i.e. the final layout is the row map of the selected overlaps alone
   if (tid == 0) {
     uint32_t acc = 0;
     for (uint32_t c = 0; c < 32; c++) { s_pref[c] = acc; acc += s_nev[c]; }
-    s_misc[1] = acc;
+    s_pref[32] = acc;
   }
   __syncthreads();
-  const uint32_t n_events = s_misc[1];
-  auto event_col = [&](uint32_t e) -> uint32_t {   // column of flattened event e: largest c with s_pref[c] <= e
-    uint32_t lo = 0, hi = 32;
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (s_pref[mid] <= e) lo = mid; else hi = mid;
-    }
-    return lo;
-  };
-  for (uint32_t e = tid; e < n_events; e += PB_NT) {
-    const uint32_t c = event_col(e);
-    const uint4 v = J.iev[J.ow[s_hdr[c].ow].scr_off + (e - s_pref[c])];
-    const uint32_t p = v.x & 0xffffu;
-    if (p < win_len) atomicMax(&s_mi[p], v.w);   // untrimmed length (features.rs:64-79)
-  }
-  __syncthreads();
-  // ---- phase 3: row of every position = exclusive prefix of (1 + max insertion)
-  uint32_t Lf;
+  // ---- max insertion behind every position over the SELECTED overlaps: rows where every selected column is a gap are
+  // dropped (features.rs:531-556), i.e. the final layout is the row map of the selected overlaps alone
   {
-    uint32_t ch = 1;
-    while (ch * PB_NT < win_len) ch <<= 1;       // consecutive positions per thread: a power of two <= 32
-    const uint32_t p0 = tid * ch, p1 = min(p0 + ch, win_len);
+    const uint32_t n_events = s_pref[32];
+    for (uint32_t e0 = tid; e0 < n_events; e0 += 4 * LY_NT) {
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t e = min(e0 + u * LY_NT, n_events - 1u);
+        uint32_t lo = 0, hi = 32;   // column of flattened event e: largest c with s_pref[c] <= e
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_pref[mid] <= e) lo = mid; else hi = mid;
+        }
+        v[u] = J.iev[(uint64_t)s_evoff[lo] + (e - s_pref[lo])];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t p = v[u].x & 0xffffu;
+        if (e0 + u * LY_NT < n_events && p < win_len) atomicMax(&s_mi[p], v[u].w);   // untrimmed length (features.rs:64-79)
+      }
+    }
+  }
+  __syncthreads();
+  // ---- row of every position = exclusive prefix of (1 + max insertion); first position of every chunk of ROWCAP rows
+  {
+    const uint32_t ch = (win_len + LY_NT - 1) / LY_NT;
+    const uint32_t p0 = min(tid * ch, win_len), p1 = min(p0 + ch, win_len);
     uint32_t local = 0;
     for (uint32_t p = p0; p < p1; p++) local += 1u + s_mi[p];
-    const uint32_t ex = blk_scan<PB_NT>(local, &Lf, s_wave);
-    const uint32_t per_blk = 32u / ch;                           // threads per block of 32 positions (same wave)
-    const uint32_t rb = __shfl(ex, (int)(lane & ~(per_blk - 1u)), 64);
-    if (p0 < win_len && (p0 & 31u) == 0) s_rbase[p0 >> 5] = ex;
-    uint32_t r = ex;
+    uint32_t Lf;
+    uint32_t r = blk_scan<LY_NT>(local, &Lf, s_wave);
+    const uint32_t tile0 = (uint32_t)wd.col_off;
     for (uint32_t p = p0; p < p1; p++) {
-      s_rop16[p] = (uint16_t)(r - rb);
-      r += 1u + s_mi[p];
+      const uint32_t rn = r + 1u + s_mi[p];
+      s_mi[p] = r;
+      const uint32_t i = (rn - 1u) / ROWCAP;          // a position has at most 51 rows: it holds at most one chunk start
+      if (i * ROWCAP >= r) J.chdr2[tile0 + i] = make_uint2(p, r == i * ROWCAP ? 1u : 0u);
+      r = rn;
     }
-    if (p0 < win_len && p1 == win_len) {   // the entry behind the last position: row count
-      if ((win_len & 31u) == 0) { s_rbase[win_len >> 5] = r; s_rop16[win_len] = 0; }
-      else s_rop16[win_len] = (uint16_t)(r - rb);
-    }
-    if (tid == 0) J.win_Lf[w] = Lf;
+    if (tid == 0) { s_mi[win_len] = Lf; J.win_Lf[w] = Lf; }
   }
-  __syncthreads();   // s_mi is dead from here on (its memory becomes the chunk buffers)
-  auto rop = [&](uint32_t p) -> uint32_t { return s_rbase[p >> 5] + s_rop16[p]; };
-  auto lower = [&](uint32_t r) -> uint32_t {   // first p in [0, win_len] with rop(p) >= r (win_len + 1: none)
-    uint32_t lo = 0, hi = win_len + 1;
+  __syncthreads();
+  for (uint32_t p = tid; p <= win_len; p += LY_NT) J.row_of_pos2[wd.pos_off + p] = s_mi[p];
+}
+
+// =====================================================================================================
+// k_tokens — one workgroup per ROWCAP rows of a window's final matrix
+// =====================================================================================================
+constexpr int TK_NT = 256;
+constexpr uint32_t WPAD = 36;    // plane words staged per column: a chunk spans <= 1025 positions
+
+__device__ __forceinline__ uint32_t dpp_quad_add(uint32_t v) {   // sum over the 4 lanes of a quad, in every lane
+  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+  return v;
+}
+__device__ __forceinline__ uint32_t dpp_quad_lane0(uint32_t v) {  // value of the quad's first lane
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x00, 0xf, 0xf, true);  // quad_perm [0,0,0,0]
+}
+
+__global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J) {
+  __shared__ __attribute__((aligned(16))) CTab s_ct[32];
+  __shared__ __attribute__((aligned(16))) uint16_t s_rowinfo[ROWCAP];   // (position - pa) | base-row flag << 15
+  __shared__ __attribute__((aligned(16))) uint8_t s_ins[INSCAP * 32];   // [insertion row][column] tokens of inserted bases, 0xff: none
+  __shared__ uint32_t s_pl[HERRO_ROWS * 3 * WPAD];                      // [column][plane][word - w_lo]
+  __shared__ uint32_t s_rop[ROWCAP + 4];                                // row of positions pa .. pb1
+  __shared__ uint32_t s_pref[33], s_supbits[ROWCAP / 32];
+  const uint32_t tile = blockIdx.x, tid = threadIdx.x, nw = J.nw;
+  // round trip 1: which rows of which window
+  const uint32_t w = J.tile_win[tile], r0 = J.tile_r0[tile];
+  // round trip 2: the window, this chunk's first position (and the next chunk's), the column table
+  const uint32_t Lf = J.win_Lf[w];
+  if (r0 >= Lf) return;
+  const WinDesc wd = J.win[w];
+  const uint2 ch0 = J.chdr2[tile];
+  const bool last = r0 + ROWCAP >= Lf;
+  const uint2 ch1 = J.chdr2[last ? tile : tile + 1];
+  if (tid < 32) s_ct[tid] = J.ctab[(uint64_t)w * 32 + tid];
+  const uint32_t win_len = wd.win_len;
+  const uint32_t r1 = min(r0 + ROWCAP, Lf);
+  const uint32_t pa = ch0.x;                                                   // position of row r0
+  const uint32_t pb1 = last ? win_len : ch1.x + (ch1.y ? 0u : 1u);            // positions whose base row lies before r1
+  const uint32_t pb = pb1 - 1;
+  const uint32_t w_lo = pa >> 5, wcnt = (pb >> 5) - w_lo + 2;
+  const uint64_t pmax = J.read_n_words + 1;
+  __syncthreads();
+  // round trip 3: rows of the chunk's positions, plane words of the chunk's positions for every column
+  {
+    const uint32_t npos = pb1 - pa + 1;   // entries pa .. pb1
+    uint32_t rv[5];
+#pragma unroll
+    for (int u = 0; u < 5; u++) rv[u] = J.row_of_pos2[wd.pos_off + pa + min(tid + u * TK_NT, npos - 1u)];
+    constexpr int PI = 12;   // 30 columns x 3 planes x <= 34 words / 256 threads
+    uint32_t pv[PI];
+    const uint32_t items = (HERRO_ROWS - 1) * 3 * wcnt;
+#pragma unroll
+    for (int u = 0; u < PI; u++) {
+      const uint32_t it = min(tid + u * TK_NT, items - 1u);
+      const uint32_t cp = it / wcnt, k = it - cp * wcnt, c = 1 + cp / 3, pi = cp - (c - 1) * 3;
+      const uint32_t o = s_ct[c].ow;
+      const uint32_t wi = min(w_lo + k, nw - 1u);
+      pv[u] = J.cpl[(o != NONE ? (uint64_t)o : 0ull) * 3 * nw + pi * nw + wi];
+    }
+    uint32_t tl = 0, th = 0;
+    if (tid < wcnt) {
+      const int32_t P = (int32_t)((w_lo + tid) << 5);
+      const uint32_t vm = mask_range(0, (int32_t)win_len - P);
+      tl = glb_bits(J.read_p0, s_ct[0].q_woff, pmax, (int32_t)wd.tstart + P) & vm;
+      th = glb_bits(J.read_p1, s_ct[0].q_woff, pmax, (int32_t)wd.tstart + P) & vm;
+      s_pl[0 * WPAD + tid] = vm;
+      s_pl[1 * WPAD + tid] = tl;
+      s_pl[2 * WPAD + tid] = th;
+    }
+#pragma unroll
+    for (int u = 0; u < 5; u++) if (tid + u * TK_NT < npos) s_rop[tid + u * TK_NT] = rv[u];
+#pragma unroll
+    for (int u = 0; u < PI; u++) {
+      const uint32_t it = tid + u * TK_NT;
+      if (it < items) {
+        const uint32_t cp = it / wcnt, k = it - cp * wcnt, c = 1 + cp / 3, pi = cp - (c - 1) * 3;
+        const bool live = s_ct[c].ow != NONE && w_lo + k < nw;
+        s_pl[(c * 3 + pi) * WPAD + k] = live ? pv[u] : 0u;
+      }
+    }
+    if (tid == 0) {
+      uint32_t acc = 0;
+      for (uint32_t c = 0; c < 32; c++) { s_pref[c] = acc; acc += s_ct[c].n_ev; }
+      s_pref[32] = acc;
+    }
+  }
+  __syncthreads();
+  const uint32_t n_events = s_pref[32];
+  auto rop = [&](uint32_t p) -> uint32_t { return s_rop[p - pa]; };   // p in [pa, pb1]
+  auto lower = [&](uint32_t r) -> uint32_t {   // first p in [pa, pb1] with rop(p) >= r (pb1 + 1: none)
+    uint32_t lo = pa, hi = pb1 + 1;
     while (lo < hi) {
       const uint32_t mid = (lo + hi) >> 1;
       if (rop(mid) < r) lo = mid + 1; else hi = mid;
     }
     return lo;
   };
-
-  // ---- phase 4: the token planes, in chunks of rows [r0, r1)
   const uint32_t seg = tid >> 2, cg = tid & 3u;
-  uint32_t n_sup_total = 0;   // meaningful in wave 0
-  for (uint32_t r0 = 0; r0 < Lf;) {
-    const uint32_t pa = lower(r0 + 1) - 1;           // position of row r0
-    const uint32_t f0 = rop(pa) == r0 ? 1u : 0u;     // its base row lies in the chunk
-    uint32_t rows = ROWCAP, r1c, pb1;
+  uint32_t n_sup_chunk = 0;   // meaningful in the first wave
+  // ---- the chunk's rows, normally in one piece [ra, rb); in several when more than INSCAP of them are insertion rows
+  for (uint32_t ra = r0; ra < r1;) {
+    const uint32_t pas = lower(ra + 1) - 1;           // position of row ra
+    const uint32_t f0 = rop(pas) == ra ? 1u : 0u;     // its base row lies in the piece
+    uint32_t rows = (r1 - ra + 15u) & ~15u, rb, pb1s;
     for (;;) {
-      r1c = min(r0 + rows, Lf);
-      pb1 = lower(r1c);                              // positions with a base row before r1c
-      const uint32_t nj0 = pb1 - (f0 ? pa : pa + 1);
-      const uint32_t nins = (r1c - r0) - nj0;
-      if (nins <= INSCAP || rows <= 16) break;
+      rb = min(ra + rows, r1);
+      pb1s = lower(rb);                                // positions with a base row before rb
+      const uint32_t nj0 = pb1s - (f0 ? pas : pas + 1);
+      if ((rb - ra) - nj0 <= INSCAP || rows <= 16) break;
       rows = max(16u, (rows >> 1) & ~15u);
     }
-    const uint32_t pb = pb1 - 1;                      // last position with a row in the chunk (>= pa)
-    const uint32_t nrows = r1c - r0, nrows16 = (nrows + 15u) & ~15u;
+    const uint32_t pbs = pb1s - 1;                     // last position with a row in the piece (>= pas)
+    const uint32_t nrows = rb - ra, nrows16 = (nrows + 15u) & ~15u;
     // -- A: row info, row map, cleared insertion tile
-    for (uint32_t p = pa + tid; p <= pb; p += PB_NT) {
+    for (uint32_t p = pas + tid; p <= pbs; p += TK_NT) {
       const uint32_t rp = rop(p), nr = rop(p + 1) - rp;
       for (uint32_t j = 0; j < nr; j++) {
         const uint32_t row = rp + j;
-        if (row >= r0 && row < r1c) {
-          s_rowinfo[row - r0] = (uint16_t)(p | (j == 0 ? 0x8000u : 0u));
+        if (row >= ra && row < rb) {
+          s_rowinfo[row - ra] = (uint16_t)((p - pa) | (j == 0 ? 0x8000u : 0u));
           J.rowmap2[wd.row_off + row] = p | (j << 16);
         }
       }
     }
-    for (uint32_t i = nrows + tid; i < nrows16; i += PB_NT) s_rowinfo[i] = (uint16_t)pb;   // rows past the window's last: unused
-    for (uint32_t i = tid; i < 32 * INSCAP / 4; i += PB_NT) reinterpret_cast<uint32_t*>(s_ins)[i] = 0xffffffffu;
+    for (uint32_t i = nrows + tid; i < nrows16; i += TK_NT) s_rowinfo[i] = (uint16_t)(pbs - pa);   // rows past the window's last: unused
+    for (uint32_t i = tid; i < INSCAP * 32 / 4; i += TK_NT) reinterpret_cast<uint32_t*>(s_ins)[i] = 0xffffffffu;
     if (tid < ROWCAP / 32) s_supbits[tid] = 0;
     __syncthreads();
     // -- B: inserted bases of the selected columns (features.rs:213-229).  A later insertion at the same position
     // overwrites an earlier one from its first row on, as the reference's sequential writes do.
-    for (uint32_t e = tid; e < n_events; e += PB_NT) {
-      const uint32_t c = event_col(e), ei = e - s_pref[c], ne = s_nev[c];
-      const uint32_t o = s_hdr[c].ow;
-      const uint4* __restrict__ evs = J.iev + J.ow[o].scr_off;
-      const uint4 v = evs[ei];
-      const uint32_t p = v.x & 0xffffu, len = v.x >> 16;
-      if (p < pa || p > pb || p >= win_len) continue;
-      const uint32_t rp = rop(p), room = rop(p + 1) - rp - 1u;
-      uint32_t hide = 0;   // rows [0, hide) are overwritten by later insertions at the same position
-      for (uint32_t e2 = ei + 1; e2 < ne; e2++) {
-        const uint4 v2 = evs[e2];
-        if ((v2.x & 0xffffu) != p) break;
-        hide = max(hide, v2.x >> 16);
-      }
-      const uint32_t s5 = s_hdr[c].tokc & 0xffu;
-      for (uint32_t k = hide; k < len && k < room; k++) {
-        const uint32_t row = rp + 1u + k;
-        if (row < r0 || row >= r1c) continue;
-        uint32_t code;
-        if (k < 16u) code = (v.z >> (2u * k)) & 3u;
-        else {   // long insertion: bases beyond the 16 carried by the event come from the read store
-          const OwDesc& d = J.ow[o];
-          const uint32_t qi = v.y + k;
-          const uint32_t si = d.strand ? d.qbeg + d.qlen - 1u - qi : d.qbeg + qi;
-          const uint64_t wi = min(d.q_woff + (si >> 5), pmax);
-          code = ((J.read_p0[wi] >> (si & 31u)) & 1u) | (((J.read_p1[wi] >> (si & 31u)) & 1u) << 1);
-          if (d.strand) code ^= 3u;
+    for (uint32_t e0 = tid; e0 < n_events; e0 += 4 * TK_NT) {
+      uint4 v[4], v2[4];
+      uint32_t cc[4], ei[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t e = min(e0 + u * TK_NT, n_events - 1u);
+        uint32_t lo = 0, hi = 32;   // column of flattened event e: largest c with s_pref[c] <= e
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_pref[mid] <= e) lo = mid; else hi = mid;
         }
-        const uint32_t idx = (row - r0) - (p - pa + f0);
-        if (idx < INSCAP) s_ins[c * INSCAP + idx] = (uint8_t)(s5 + code);
+        cc[u] = lo;
+        ei[u] = e - s_pref[lo];
+        const uint4* __restrict__ evs = J.iev + s_ct[lo].ev_off;
+        v[u] = evs[ei[u]];
+        v2[u] = evs[min(ei[u] + 1u, s_ct[lo].n_ev - 1u)];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (e0 + u * TK_NT >= n_events) continue;
+        const uint32_t c = cc[u], ne = s_ct[c].n_ev;
+        const uint32_t p = v[u].x & 0xffffu, len = v[u].x >> 16;
+        if (p < pas || p > pbs) continue;
+        const uint32_t rp = rop(p), room = rop(p + 1) - rp - 1u;
+        uint32_t hide = 0;   // rows [0, hide) are overwritten by later insertions at the same position
+        if (ei[u] + 1 < ne && (v2[u].x & 0xffffu) == p) {
+          hide = v2[u].x >> 16;
+          const uint4* __restrict__ evs = J.iev + s_ct[c].ev_off;
+          for (uint32_t e2 = ei[u] + 2; e2 < ne; e2++) {
+            const uint4 v3 = evs[e2];
+            if ((v3.x & 0xffffu) != p) break;
+            hide = max(hide, v3.x >> 16);
+          }
+        }
+        const uint32_t s5 = s_ct[c].tokc & 0xffu;
+        for (uint32_t k = hide; k < len && k < room; k++) {
+          const uint32_t row = rp + 1u + k;
+          if (row < ra || row >= rb) continue;
+          uint32_t code;
+          if (k < 16u) code = (v[u].z >> (2u * k)) & 3u;
+          else {   // long insertion: bases beyond the 16 carried by the event come from the read store
+            const int32_t si = s_ct[c].sbase + s_ct[c].sdir * (int32_t)(v[u].y + k);
+            const uint64_t wi = min(s_ct[c].q_woff + ((uint32_t)si >> 5), pmax);
+            code = ((J.read_p0[wi] >> ((uint32_t)si & 31u)) & 1u) | (((J.read_p1[wi] >> ((uint32_t)si & 31u)) & 1u) << 1);
+            if (s_ct[c].sdir < 0) code ^= 3u;
+          }
+          const uint32_t idx = (row - ra) - (p - pas + f0);
+          if (idx < INSCAP) s_ins[idx * 32 + c] = (uint8_t)(s5 + code);
+        }
       }
     }
     __syncthreads();
-    // -- C: 16 rows x 1 column per step; a quad of lanes shares a row segment, each lane a quarter of the columns
+    // -- C: 16 rows x 1 column per step; a quad of lanes shares a row segment, each lane 8 consecutive columns
     if (seg * 16u < nrows) {
       const uint4 ri0 = reinterpret_cast<const uint4*>(s_rowinfo)[seg * 2], ri1 = reinterpret_cast<const uint4*>(s_rowinfo)[seg * 2 + 1];
       const uint32_t riw[8] = {ri0.x, ri0.y, ri0.z, ri0.w, ri1.x, ri1.y, ri1.z, ri1.w};
-      const uint32_t p_first = riw[0] & 0x7fffu;
+      const uint32_t pf_rel = riw[0] & 0x7fffu;          // first position of the segment, relative to pa
+      const uint32_t p_first = pa + pf_rel;
+      const int32_t C = (int32_t)(seg * 16u) - (int32_t)(p_first - pas + f0);   // insertion-tile row of segment row i at offset k: C - k + i
       uint32_t kj[16], cnt[16];
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const uint32_t v = (riw[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
-        kj[i] = ((v & 0x7fffu) - p_first) | ((v >> 15) << 5);   // bits 0..4: position - p_first (< 16), bit 5: base row
+        const uint32_t k = (v & 0x7fffu) - pf_rel;
+        // bits 0..4: position - p_first (< 16), bit 5: base row, bits 8..: row of the insertion tile (meaningful for insertion rows)
+        kj[i] = k | ((v >> 15) << 5) | (min((uint32_t)max(C - (int32_t)k + i, 0), INSCAP - 1u) << 8);
         cnt[i] = 0;
       }
-      const int32_t C = (int32_t)(seg * 16u) - (int32_t)(p_first - pa + f0);   // insertion-tile index of row i with offset k: C - k + i
-      const uint32_t wi = p_first >> 5, sh = p_first & 31u;
-      const uint64_t gseg = wd.fin_off + r0 + seg * 16u;
+      const uint32_t wrel = (p_first >> 5) - w_lo, sh = p_first & 31u;
+      const uint64_t gseg = wd.fin_off + ra + seg * 16u;
       uint32_t tgt[4] = {0, 0, 0, 0};
-      for (uint32_t c = cg; c < HERRO_ROWS; c += 4) {
-        const BCol h = s_hdr[c];
-        const uint32_t* pl = s_pl + (size_t)c * 3 * nwp + wi;
+#pragma unroll 1
+      for (uint32_t ci = 0; ci < 8; ci++) {
+        const uint32_t c = cg * 8 + ci;   // column 31 (last lane of the quad, ci = 7) is a stand-in: '.', never stored
+        const CTab& h = s_ct[c];
+        const uint32_t* pl = s_pl + (size_t)min(c, (uint32_t)HERRO_ROWS - 1u) * 3 * WPAD + wrel;
         const uint32_t m16 = __funnelshift_r(pl[0], pl[1], sh);
-        const uint32_t l16 = __funnelshift_r(pl[nwp], pl[nwp + 1], sh);
-        const uint32_t h16 = __funnelshift_r(pl[2 * nwp], pl[2 * nwp + 1], sh);
-        const uint32_t r16 = mask_range(h.off - (int32_t)p_first, h.off + (int32_t)h.t_total - (int32_t)p_first);
+        const uint32_t l16 = __funnelshift_r(pl[WPAD], pl[WPAD + 1], sh);
+        const uint32_t h16 = __funnelshift_r(pl[2 * WPAD], pl[2 * WPAD + 1], sh);
+        const uint32_t tt = c < HERRO_ROWS ? h.t_total : 0u;
+        const uint32_t r16 = mask_range(h.off - (int32_t)p_first, h.off + (int32_t)tt - (int32_t)p_first);
         const uint32_t s5 = h.tokc & 0xffu, gapt = h.tokc >> 8;
-        const uint8_t* insrow = s_ins + c * INSCAP;
         uint32_t T[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-          const uint32_t k = kj[i];
-          const uint32_t j0 = __builtin_amdgcn_ubfe(k, 5, 1);
-          const uint32_t m = __builtin_amdgcn_ubfe(m16, k, 1) & j0;
-          const uint32_t code = __builtin_amdgcn_ubfe(l16, k, 1) | (__builtin_amdgcn_ubfe(h16, k, 1) << 1);
-          uint32_t r = __builtin_amdgcn_ubfe(r16, k, 1);
-          uint32_t fidx = m ? code : 4u;
-          uint32_t tok = m ? code + s5 : gapt;
-          tok = r ? tok : (uint32_t)TOK_NONE;
-          if (!j0) {   // insertion row: a base if this column inserts here (it counts even in front of the overlap's first base)
-            const int32_t ii = C - (int32_t)(k & 31u) + i;
-            const uint32_t b = insrow[min((uint32_t)max(ii, 0), INSCAP - 1u)];
-            if (b != 0xffu) { tok = b; fidx = b >= 5u ? b - 5u : b; r = 1u; }
+        for (int hf = 0; hf < 2; hf++) {   // two halves of eight rows, kept apart by a scheduling barrier (register pressure)
+          uint32_t ibv[8];   // this column's byte of every row's insertion-tile row: one batch of LDS reads, no branches
+#pragma unroll
+          for (int i8 = 0; i8 < 8; i8++) ibv[i8] = s_ins[(kj[hf * 8 + i8] >> 8) * 32 + c];
+#pragma unroll
+          for (int i8 = 0; i8 < 8; i8++) {
+            const int i = hf * 8 + i8;
+            const uint32_t k = kj[i];
+            const uint32_t j0 = __builtin_amdgcn_ubfe(k, 5, 1);
+            const uint32_t m = __builtin_amdgcn_ubfe(m16, k, 1) & j0;
+            const uint32_t code = __builtin_amdgcn_ubfe(l16, k, 1) | (__builtin_amdgcn_ubfe(h16, k, 1) << 1);
+            uint32_t r = __builtin_amdgcn_ubfe(r16, k, 1);
+            uint32_t fidx = m ? code : 4u;
+            uint32_t tok = m ? code + s5 : gapt;
+            tok = r ? tok : (uint32_t)TOK_NONE;
+            // insertion row: a base if this column inserts here (it counts even in front of the overlap's first base)
+            const uint32_t b = ibv[i8];
+            const bool isb = !j0 && b != 0xffu;
+            tok = isb ? b : tok;
+            fidx = isb ? (b >= 5u ? b - 5u : b) : fidx;
+            r = isb ? 1u : r;
+            T[i >> 2] |= tok << ((i & 3) * 8);
+            cnt[i] += r << (5u * fidx);
           }
-          T[i >> 2] |= tok << ((i & 3) * 8);
-          cnt[i] += r << (5u * fidx);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        *reinterpret_cast<uint4*>(J.fin_b + gseg + (uint64_t)c * wd.lub) = make_uint4(T[0], T[1], T[2], T[3]);
-        if (c == 0) { tgt[0] = T[0]; tgt[1] = T[1]; tgt[2] = T[2]; tgt[3] = T[3]; }
+        if (c < HERRO_ROWS) *reinterpret_cast<uint4*>(J.fin_b + gseg + (uint64_t)c * wd.lub) = make_uint4(T[0], T[1], T[2], T[3]);
+        if (ci == 0) { tgt[0] = T[0]; tgt[1] = T[1]; tgt[2] = T[2]; tgt[3] = T[3]; }   // column 0 in the quad's first lane
       }
       // counts of the row over all 31 columns, then each lane of the quad finishes 4 rows
 #pragma unroll
@@ -744,7 +881,6 @@ __global__ __launch_bounds__(PB_NT) void k_final(JobDev J) {
       uint32_t supb = 0, consw = 0;
 #pragma unroll
       for (int q4 = 0; q4 < 4; q4++) {
-        // row 4 cg + q4: select its counter word without indexing the register array dynamically
         const uint32_t cw = cg == 0 ? cnt[q4] : (cg == 1 ? cnt[4 + q4] : (cg == 2 ? cnt[8 + q4] : cnt[12 + q4]));
         uint32_t c5[5];
 #pragma unroll
@@ -754,8 +890,7 @@ __global__ __launch_bounds__(PB_NT) void k_final(JobDev J) {
         uint32_t ns = 0;
 #pragma unroll
         for (int q = 0; q < 5; q++) ns += c5[q] >= thresh ? 1u : 0u;
-        const uint32_t row_in_chunk = seg * 16u + cg * 4u + q4;
-        if (ns >= 2 && row_in_chunk < nrows) supb |= 1u << q4;
+        if (ns >= 2 && seg * 16u + cg * 4u + q4 < nrows) supb |= 1u << q4;
         // majority vote of the consensus decoder (consensus.rs:178-200): it looks at the first n_alns+1 rows of the pileup, and
         // every row beyond those is '.', which it skips anyway.  Two most common symbols by a stable descending sort (ties keep
         // A,C,G,T,* order), target tie-break.
@@ -771,44 +906,67 @@ __global__ __launch_bounds__(PB_NT) void k_final(JobDev J) {
         const uint32_t cons_v = (c0 < 2u || (c0 == c1 && (i0 == tb0 || i1 == tb0))) ? tb0 : i0;
         consw |= cons_v << (q4 * 8);
       }
-      *reinterpret_cast<uint32_t*>(J.cons_tmp + wd.row_off + r0 + seg * 16u + cg * 4u) = consw;
+      *reinterpret_cast<uint32_t*>(J.cons_tmp + wd.row_off + ra + seg * 16u + cg * 4u) = consw;
       if (supb) atomicOr(&s_supbits[(seg * 16u + cg * 4u) >> 5], supb << ((seg * 16u + cg * 4u) & 31u));
     }
     __syncthreads();
-    // -- D: ordered list of informative positions (SupportedPos, features.rs:896-900), by the first wave
+    // -- D: the piece's informative positions, in row order (SupportedPos, features.rs:896-900), by the first wave; the window's
+    // list is put together by k_supgather
     if (tid < 64) {
-      const uint32_t bits = s_supbits[tid];
-      uint64_t tot;
-      const uint32_t ex = (uint32_t)wscan64((uint64_t)__popc(bits), &tot);
-      uint32_t k = n_sup_total + ex;
+      const uint32_t bits = tid < ROWCAP / 32 ? s_supbits[tid] : 0u;
+      const uint32_t inc = wscan_incl((uint32_t)__popc(bits));
+      uint32_t k = n_sup_chunk + inc - (uint32_t)__popc(bits);
       for (uint32_t m = bits; m; m &= m - 1u) {
         const uint32_t ric = (tid << 5) + (uint32_t)__ffs((int)m) - 1u;
-        const uint32_t p = s_rowinfo[ric] & 0x7fffu, row = r0 + ric;
-        J.sup_row[wd.row_off + k] = row;
-        J.sup_pi[wd.row_off + k] = p | ((row - rop(p)) << 16);
+        const uint32_t p = pa + (s_rowinfo[ric] & 0x7fffu), row = ra + ric;
+        J.sup_row[wd.row_off + r0 + k] = row;
+        J.sup_pi[wd.row_off + r0 + k] = p | ((row - rop(p)) << 16);
         k++;
       }
-      n_sup_total += (uint32_t)tot;
+      n_sup_chunk += wlast(inc);
     }
     __syncthreads();
-    r0 += nrows16;   // r0 stays a multiple of 16; only the window's last chunk has nrows % 16 != 0
+    ra += nrows16;   // stays a multiple of 16; only the window's last piece has nrows % 16 != 0
   }
-  if (tid == 0) J.win_nsup[w] = n_sup_total;
+  if (tid == 0) J.tile_nsup[tile] = n_sup_chunk;
 }
 
 // =====================================================================================================
-// k_quals
+// k_supgather — one wave per window: the chunks' lists of informative positions -> one list, chunk order = row order
 // =====================================================================================================
-struct QCol {
-  int32_t off;
-  uint32_t t_total;
-  int32_t sbase, sdir;   // stored index of alignment-orientation query base q: sbase + sdir * q
-  uint32_t n_ev, ev_lds; // events: count, first slot in the LDS copy
-  uint64_t qual_off;     // first quality byte of the query read
-  uint64_t ev_glb;       // first event in J.iev
-};
+__global__ __launch_bounds__(64) void k_supgather(JobDev J) {
+  const uint32_t w = blockIdx.x, lane = threadIdx.x;
+  const WinDesc wd = J.win[w];
+  const uint32_t Lf = J.win_Lf[w], tile0 = (uint32_t)wd.col_off;
+  const uint32_t nch = (Lf + ROWCAP - 1) / ROWCAP;
+  uint32_t dst = 0;
+  for (uint32_t c0 = 0; c0 < nch; c0 += 64) {
+    const uint32_t i = c0 + lane;
+    const uint32_t cn = i < nch ? J.tile_nsup[tile0 + i] : 0u;
+    const uint32_t inc = wscan_incl(cn);
+    const uint32_t my_dst = dst + inc - cn;
+    for (uint32_t j = 0; j < 64 && c0 + j < nch; j++) {   // chunk by chunk: destinations never run ahead of unread sources
+      const uint32_t cnt_j = (uint32_t)__builtin_amdgcn_readlane((int)cn, (int)j), dst_j = (uint32_t)__builtin_amdgcn_readlane((int)my_dst, (int)j);
+      const uint32_t src = (c0 + j) * ROWCAP;
+      if (src == dst_j) continue;
+      for (uint32_t k = lane; k < cnt_j; k += 64) {
+        const uint32_t a = J.sup_row[wd.row_off + src + k], b = J.sup_pi[wd.row_off + src + k];
+        J.sup_row[wd.row_off + dst_j + k] = a;
+        J.sup_pi[wd.row_off + dst_j + k] = b;
+      }
+    }
+    dst += wlast(inc);
+  }
+  if (lane == 0) J.win_nsup[w] = dst;
+}
+
+// =====================================================================================================
+// k_quals — one workgroup per window
+// =====================================================================================================
+constexpr int PQ_NT = 256;
+constexpr uint32_t RFCAP = 1024;   // receptive-field rows per pass
 __host__ __device__ inline size_t quals_lds(uint32_t nw) {
-  return 32 * sizeof(QCol) + (size_t)(HERRO_ROWS - 1) * nw * 4 + (((size_t)(HERRO_ROWS - 1) * nw * 2 + 15) & ~(size_t)15) + (size_t)QEVCAP * 16 + 64;
+  return (size_t)(HERRO_ROWS - 1) * nw * 4 + (((size_t)(HERRO_ROWS - 1) * nw * 2 + 15) & ~(size_t)15) + (size_t)QEVCAP * 16;
 }
 
 // FULL: every cell of the window; otherwise the cells within `half` rows of an informative row (the model's receptive fields).
@@ -816,74 +974,86 @@ template <bool FULL>
 __global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pq_smem[];
   const uint32_t nw = J.nw;
-  QCol* s_col = reinterpret_cast<QCol*>(pq_smem);
-  uint32_t* s_M = reinterpret_cast<uint32_t*>(pq_smem + 32 * sizeof(QCol));          // [30][nw]
-  uint16_t* s_rk = reinterpret_cast<uint16_t*>(s_M + (size_t)(HERRO_ROWS - 1) * nw);  // [30][nw] M bits before the word
-  uint4* s_ev = reinterpret_cast<uint4*>(pq_smem + 32 * sizeof(QCol) + (size_t)(HERRO_ROWS - 1) * nw * 4 + (((size_t)(HERRO_ROWS - 1) * nw * 2 + 15) & ~(size_t)15));
-  uint32_t* s_misc = reinterpret_cast<uint32_t*>(s_ev + QEVCAP);
-
+  uint32_t* s_M = reinterpret_cast<uint32_t*>(pq_smem);                               // [30][nw] M planes of the selected columns
+  uint16_t* s_rk = reinterpret_cast<uint16_t*>(s_M + (size_t)(HERRO_ROWS - 1) * nw);  // [30][nw] M bits in front of the word
+  uint4* s_ev = reinterpret_cast<uint4*>(pq_smem + (size_t)(HERRO_ROWS - 1) * nw * 4 + (((size_t)(HERRO_ROWS - 1) * nw * 2 + 15) & ~(size_t)15));
+  __shared__ __attribute__((aligned(16))) CTab s_ct[32];
+  __shared__ uint32_t s_evl[33];      // first LDS slot of every column's events
+  __shared__ uint32_t s_rm[RFCAP];    // row-map entry of each receptive-field row (NONE: outside the window)
+  __shared__ uint32_t s_rr[RFCAP];    // its row
   const uint32_t w = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t nsup = J.win_nsup[w], Lf = J.win_Lf[w];
   if (!FULL && !nsup) return;
   const WinDesc wd = J.win[w];
+  if (tid < 32) s_ct[tid] = J.ctab[(uint64_t)w * 32 + tid];
+  __syncthreads();
   if (tid == 0) {
     uint32_t acc = 0;
-    for (uint32_t c = 1; c < HERRO_ROWS; c++) {
-      const uint32_t o = J.sel_ow[(uint64_t)w * 32 + c];
-      QCol q;
-      q.off = 0; q.t_total = 0; q.sbase = 0; q.sdir = 1; q.n_ev = 0; q.ev_lds = acc; q.qual_off = 0; q.ev_glb = 0;
-      if (o != NONE) {
-        const OwDesc& d = J.ow[o];
-        q.off = (int32_t)(d.tstart - d.wtstart);
-        q.t_total = J.ow_ttotal[o];
-        q.sbase = d.strand ? (int32_t)(d.qbeg + d.qlen - 1u) : (int32_t)d.qbeg;
-        q.sdir = d.strand ? -1 : 1;
-        q.n_ev = J.ins_cnt[o];
-        q.qual_off = d.q_qual_off;
-        q.ev_glb = d.scr_off;
+    for (uint32_t c = 0; c < 32; c++) { s_evl[c] = acc; acc += s_ct[c].n_ev; }
+    s_evl[32] = acc;
+  }
+  {  // M planes: all loads of a thread issued together
+    const uint32_t items = (HERRO_ROWS - 1) * nw;
+    for (uint32_t it0 = tid; it0 < items; it0 += 8 * PQ_NT) {
+      uint32_t mv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t it = min(it0 + u * PQ_NT, items - 1u);
+        const uint32_t c = it / nw, wi = it - c * nw;
+        const uint32_t o = s_ct[c + 1].ow;
+        mv[u] = J.cpl[(o != NONE ? (uint64_t)o : 0ull) * 3 * nw + wi];
       }
-      s_col[c] = q;
-      acc += q.n_ev;
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t it = it0 + u * PQ_NT;
+        if (it < items) s_M[it] = s_ct[it / nw + 1].ow != NONE ? mv[u] : 0u;
+      }
     }
-    s_misc[0] = acc;
   }
   __syncthreads();
-  const bool ev_in_lds = s_misc[0] <= QEVCAP;
-  // M planes of the selected columns, their rank directories, the events
-  for (uint32_t it = tid; it < (HERRO_ROWS - 1) * nw; it += PQ_NT) {
-    const uint32_t c = it / nw, wi = it - c * nw;
-    const uint32_t o = J.sel_ow[(uint64_t)w * 32 + c + 1];
-    s_M[it] = o != NONE ? J.cpl[(uint64_t)o * 3 * nw + wi] : 0u;
-  }
+  const uint32_t n_events = s_evl[32];
+  const bool ev_in_lds = n_events <= QEVCAP;
   if (ev_in_lds) {
-    for (uint32_t c = 1; c < HERRO_ROWS; c++) {
-      const QCol& q = s_col[c];
-      for (uint32_t i = tid; i < q.n_ev; i += PQ_NT) s_ev[q.ev_lds + i] = J.iev[q.ev_glb + i];
+    for (uint32_t e0 = tid; e0 < n_events; e0 += 4 * PQ_NT) {
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t e = min(e0 + u * PQ_NT, n_events - 1u);
+        uint32_t lo = 0, hi = 32;
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_evl[mid] <= e) lo = mid; else hi = mid;
+        }
+        v[u] = J.iev[(uint64_t)s_ct[lo].ev_off + (e - s_evl[lo])];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (e0 + u * PQ_NT < n_events) s_ev[e0 + u * PQ_NT] = v[u];
     }
   }
-  __syncthreads();
-  for (uint32_t c = wave; c < HERRO_ROWS - 1; c += PQ_NT / 64) {
+  for (uint32_t c = wave; c < HERRO_ROWS - 1; c += PQ_NT / 64) {   // rank directory of every M plane
     uint32_t carry = 0;
     for (uint32_t b = 0; b < nw; b += 64) {
       const uint32_t i = b + lane;
       const uint32_t pc = i < nw ? (uint32_t)__popc(s_M[c * nw + i]) : 0u;
-      uint64_t tot;
-      const uint32_t ex = (uint32_t)wscan64(pc, &tot);
-      if (i < nw) s_rk[c * nw + i] = (uint16_t)(carry + ex);
-      carry += (uint32_t)tot;
+      const uint32_t inc = wscan_incl(pc);
+      if (i < nw) s_rk[c * nw + i] = (uint16_t)(carry + inc - pc);
+      carry += wlast(inc);
     }
   }
   __syncthreads();
 
-  const uint64_t tq_off = J.read_qual_off[wd.rid] + wd.tstart;
-  // quality of cell (column c >= 1, position p, insertion ordinal j): '!' unless the cell holds a query base
-  auto cell = [&](uint32_t c, uint32_t p, uint32_t j) -> uint32_t {
-    const QCol& q = s_col[c];
-    if (q.t_total == 0 && q.n_ev == 0) return 33u;
-    const uint4* evg = J.iev + q.ev_glb;
-    auto event = [&](uint32_t i) -> uint4 { return ev_in_lds ? s_ev[q.ev_lds + i] : evg[i]; };
-    // first event with position >= bound
-    auto first_ge = [&](uint32_t bound) -> uint32_t {
+  const uint64_t tq_off = s_ct[0].qual_off + wd.tstart;
+  const uint64_t qmax = J.read_qual_bytes ? J.read_qual_bytes - 1 : 0;
+  // address of the quality byte of cell (column c, position p, insertion ordinal j); NONE64: the cell holds no base ('!')
+  constexpr uint64_t NONE64 = ~0ull;
+  auto cell_addr = [&](uint32_t c, uint32_t p, uint32_t j) -> uint64_t {
+    if (c == 0) return j == 0 ? min(tq_off + p, qmax) : NONE64;
+    const CTab& q = s_ct[c];
+    if (q.ow == NONE) return NONE64;
+    const uint4* evg = J.iev + q.ev_off;
+    const uint32_t el = s_evl[c];
+    auto event = [&](uint32_t i) -> uint4 { return ev_in_lds ? s_ev[el + i] : evg[i]; };
+    auto first_ge = [&](uint32_t bound) -> uint32_t {   // first event with position >= bound
       uint32_t lo = 0, hi = q.n_ev;
       while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -900,7 +1070,7 @@ __global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half) {
     uint32_t qi;
     if (j == 0) {
       const uint32_t uu = p - (uint32_t)q.off;
-      if (uu >= q.t_total || !((M[p >> 5] >> (p & 31u)) & 1u)) return 33u;
+      if (uu >= q.t_total || !((M[p >> 5] >> (p & 31u)) & 1u)) return NONE64;
       const uint32_t ub = first_ge(p);          // events strictly before p: [0, ub)
       if (ub == 0) qi = rank(p);
       else {
@@ -917,37 +1087,68 @@ __global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half) {
         if ((e.x >> 16) >= j) { qi = e.y + j - 1u; found = true; break; }   // the LAST insertion at p that is long enough wrote this row
         i--;
       }
-      if (!found) return 33u;
+      if (!found) return NONE64;
     }
     const int64_t si = (int64_t)q.sbase + (int64_t)q.sdir * (int64_t)qi;
-    const uint64_t gi = q.qual_off + (uint64_t)max(si, (int64_t)0);
-    return J.read_qual[min(gi, J.read_qual_bytes ? J.read_qual_bytes - 1 : 0)];
+    return min(q.qual_off + (uint64_t)max(si, (int64_t)0), qmax);
   };
   if (FULL) {
     const uint64_t total = (uint64_t)Lf * HERRO_ROWS;
-    for (uint64_t idx = tid; idx < total; idx += PQ_NT) {
-      const uint32_t c = (uint32_t)(idx / Lf), r = (uint32_t)(idx - (uint64_t)c * Lf);
-      const uint32_t rm = J.rowmap2[wd.row_off + r];
-      const uint32_t p = rm & 0xffffu, j = rm >> 16;
-      uint32_t qv;
-      if (c == 0) qv = j == 0 ? (uint32_t)J.read_qual[tq_off + p] : 33u;
-      else qv = cell(c, p, j);
-      J.fin_q[wd.fin_off + (uint64_t)c * wd.lub + r] = (uint8_t)qv;
+    for (uint64_t idx0 = tid; idx0 < total; idx0 += 4 * PQ_NT) {
+      uint32_t rm[4];
+      uint64_t dst[4], src[4];
+      uint32_t cc[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint64_t idx = min(idx0 + (uint64_t)u * PQ_NT, total - 1);
+        cc[u] = (uint32_t)(idx / Lf);
+        const uint32_t r = (uint32_t)(idx - (uint64_t)cc[u] * Lf);
+        rm[u] = J.rowmap2[wd.row_off + r];
+        dst[u] = wd.fin_off + (uint64_t)cc[u] * wd.lub + r;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) src[u] = cell_addr(cc[u], rm[u] & 0xffffu, rm[u] >> 16);
+      uint32_t qv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) qv[u] = J.read_qual[src[u] == NONE64 ? 0 : src[u]];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (idx0 + (uint64_t)u * PQ_NT < total) J.fin_q[dst[u]] = (uint8_t)(src[u] == NONE64 ? 33u : qv[u]);
     }
   } else {
     const uint32_t span = 2 * half + 1;
-    const uint64_t total = (uint64_t)nsup * span * HERRO_ROWS;
-    for (uint64_t idx = tid; idx < total; idx += PQ_NT) {
+    const uint32_t kper = max(1u, RFCAP / span);   // informative rows per pass
+    for (uint32_t k0 = 0; k0 < nsup; k0 += kper) {
+      const uint32_t nk = min(kper, nsup - k0), nrows = nk * span;
+      __syncthreads();
+      for (uint32_t i = tid; i < nrows; i += PQ_NT) {
+        const int64_t r = (int64_t)J.sup_row[wd.row_off + k0 + i / span] + (int64_t)(i % span) - (int64_t)half;
+        const bool in = r >= 0 && r < (int64_t)Lf;
+        s_rr[i] = (uint32_t)r;
+        s_rm[i] = in ? J.rowmap2[wd.row_off + (uint32_t)r] : NONE;
+      }
+      __syncthreads();
       // neighbouring lanes: the rows of one receptive field in one column
-      const uint32_t k = (uint32_t)(idx / (span * HERRO_ROWS)), rem = (uint32_t)(idx - (uint64_t)k * span * HERRO_ROWS), c = rem / span, dd = rem - c * span;
-      const int64_t r = (int64_t)J.sup_row[wd.row_off + k] + (int64_t)dd - (int64_t)half;
-      if (r < 0 || r >= (int64_t)Lf) continue;
-      const uint32_t rm = J.rowmap2[wd.row_off + (uint32_t)r];
-      const uint32_t p = rm & 0xffffu, j = rm >> 16;
-      uint32_t qv;
-      if (c == 0) qv = j == 0 ? (uint32_t)J.read_qual[tq_off + p] : 33u;
-      else qv = cell(c, p, j);
-      J.fin_q[wd.fin_off + (uint64_t)c * wd.lub + (uint32_t)r] = (uint8_t)qv;
+      const uint32_t total = nrows * HERRO_ROWS;
+      for (uint32_t idx0 = tid; idx0 < total; idx0 += 4 * PQ_NT) {
+        uint64_t dst[4], src[4];
+        bool live[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t idx = min(idx0 + u * PQ_NT, total - 1u);
+          const uint32_t k = idx / (span * HERRO_ROWS), rem = idx - k * span * HERRO_ROWS, c = rem / span, dd = rem - c * span;
+          const uint32_t rm = s_rm[k * span + dd];
+          live[u] = idx0 + u * PQ_NT < total && rm != NONE;
+          dst[u] = wd.fin_off + (uint64_t)c * wd.lub + s_rr[k * span + dd];
+          src[u] = rm != NONE ? cell_addr(c, rm & 0xffffu, rm >> 16) : NONE64;
+        }
+        uint32_t qv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) qv[u] = J.read_qual[src[u] == NONE64 ? 0 : src[u]];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (live[u]) J.fin_q[dst[u]] = (uint8_t)(src[u] == NONE64 ? 33u : qv[u]);
+      }
     }
   }
 }
@@ -1015,46 +1216,50 @@ void launch_consensus(const JobDev& J, const uint64_t* sup_off, const float* bas
 void launch_rf_quals(const JobDev& J, uint32_t half, hipStream_t st, KernelTimer* tm) {
   if (!J.n_win) return;
   KT_BEGIN(tm, "rf_quals", st);
-  pileup_opt_in_lds(reinterpret_cast<const void*>(k_quals<false>));
+  pileup_opt_in_lds(reinterpret_cast<const void*>(k_quals<false>), 96 * 1024);   // windows of 8192: 62 KB dynamic + 10 KB static
   hipLaunchKernelGGL(k_quals<false>, dim3(J.n_win), dim3(PQ_NT), quals_lds(J.nw), st, J, half);
   KT_END(tm, st);
 }
 
 void launch_full_quals(const JobDev& J, hipStream_t st) {
   if (!J.n_win) return;
-  pileup_opt_in_lds(reinterpret_cast<const void*>(k_quals<true>));
+  pileup_opt_in_lds(reinterpret_cast<const void*>(k_quals<true>), 96 * 1024);
   hipLaunchKernelGGL(k_quals<true>, dim3(J.n_win), dim3(PQ_NT), quals_lds(J.nw), st, J, 0u);
 }
 
-size_t pileup_lds_bytes(uint32_t W, int which) {   // for DESIGN / diagnostics
-  const uint32_t nw = (W + 31) / 32;
-  return which == 0 ? pass1_lds(nw) : (which == 1 ? (size_t)final_lds(W, nw).total : quals_lds(nw));
-}
-
 template <int NB>
-static void launch_pass1(const JobDev& J, hipStream_t st) {
-  pileup_opt_in_lds(reinterpret_cast<const void*>(k_pass1<NB>));
-  hipLaunchKernelGGL(k_pass1<NB>, dim3(J.n_win), dim3(PA_NT), pass1_lds(J.nw), st, J);
+static void launch_win(const JobDev& J, hipStream_t st) {
+  hipLaunchKernelGGL(k_win<NB>, dim3(J.n_win), dim3(J.nw <= 128 ? 128 : 256), 0, st, J);
 }
 
 void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm) {
   if (!J.n_win) return;
-  KT_BEGIN(tm, "pass1", st);
+  if (J.n_ow) {
+    KT_BEGIN(tm, "cols", st);
+    hipLaunchKernelGGL(k_cols, dim3((J.n_ow + CA_NW - 1) / CA_NW), dim3(CA_NT), (size_t)CA_NW * cols_lds_words(J.nw) * 4, st, J);
+    KT_END(tm, st);
+  }
+  KT_BEGIN(tm, "win", st);
   if (J.n_cls) (void)hipMemsetAsync(J.nd, 0, (size_t)J.n_cls * 8, st);   // match / mismatch tallies start from zero
   {
     // counter width: enough bits for the largest threshold floor(0.1 * max(31, columns))
     const uint32_t tmax = (uint32_t)((double)(J.max_cols > 31 ? J.max_cols : 31) * 0.1);
-    if (tmax < 4) launch_pass1<2>(J, st);
-    else if (tmax < 8) launch_pass1<3>(J, st);
-    else if (tmax < 16) launch_pass1<4>(J, st);
-    else if (tmax < 64) launch_pass1<6>(J, st);
-    else if (tmax < 512) launch_pass1<9>(J, st);
-    else launch_pass1<14>(J, st);
+    if (tmax < 4) launch_win<2>(J, st);
+    else if (tmax < 8) launch_win<3>(J, st);
+    else if (tmax < 16) launch_win<4>(J, st);
+    else if (tmax < 64) launch_win<6>(J, st);
+    else if (tmax < 512) launch_win<9>(J, st);
+    else launch_win<14>(J, st);
   }
   KT_END(tm, st);
-  KT_BEGIN(tm, "final", st);
-  pileup_opt_in_lds(reinterpret_cast<const void*>(k_final));
-  hipLaunchKernelGGL(k_final, dim3(J.n_win), dim3(PB_NT), final_lds(J.window_size, J.nw).total, st, J);
+  KT_BEGIN(tm, "layout", st);
+  hipLaunchKernelGGL(k_layout, dim3(J.n_win), dim3(LY_NT), layout_lds(J.window_size), st, J);
+  KT_END(tm, st);
+  KT_BEGIN(tm, "tokens", st);
+  if (J.n_tiles) hipLaunchKernelGGL(k_tokens, dim3(J.n_tiles), dim3(TK_NT), 0, st, J);
+  KT_END(tm, st);
+  KT_BEGIN(tm, "supgather", st);
+  hipLaunchKernelGGL(k_supgather, dim3(J.n_win), dim3(64), 0, st, J);
   KT_END(tm, st);
 }
 

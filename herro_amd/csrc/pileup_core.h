@@ -59,7 +59,7 @@ struct WinDesc {
   uint32_t ow_begin;  // first OwDesc of this window (push order == alignment order)
   uint32_t ow_cnt;
   uint32_t lub;       // upper bound on rows L (multiple of 16)
-  uint64_t col_off;   // byte offset of this window's [(ow_cnt+1), lub] pass-1 column planes
+  uint64_t col_off;   // first tile of this window in the job's tile list
   uint64_t fin_off;   // byte offset of this window's [31, lub] final planes
   uint64_t row_off;   // element offset of this window's lub-sized u32 row scratch
   uint64_t pos_off;   // element offset of this window's (window_size+1)-sized u32 position scratch

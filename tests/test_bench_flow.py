@@ -61,7 +61,7 @@ class FakeCtx:
     def close(self): pass
 
     def timing(self):
-        names = ["ow_stats", "win_rank", "pass1_pos", "select_layout", "tile_plan", "final_tiles", "sup_compact", "rf_quals",
+        names = ["cols", "win", "layout", "tokens", "supgather", "rf_quals",
                  "build_tokens", "conv_fused", "fc_gemm", "add_pe", "layers_fused", "consensus"]
         return {n: (1.0 + i, 4) for i, n in enumerate(names)}
 

@@ -58,7 +58,7 @@ def _expected(sb, W, targets):
             lub = (wl + min(ins_sum[w], 50 * wl) + 15) & ~15
             win.append(dict(rid=rid, wid=w, n_wids=nwin, tstart=w * W, win_len=wl, ow_begin=len(ow), ow_cnt=len(per_win[w]), lub=lub))
             ow.extend(per_win[w])
-            tiles.extend((len(win) - 1, r0) for r0 in range(0, lub, 256))
+            tiles.extend((len(win) - 1, r0) for r0 in range(0, lub, 1024))
         n_cls_total += len(cls_of)
         tgt_off.append(len(win))
     return ops, ow, win, tiles, tgt_off
