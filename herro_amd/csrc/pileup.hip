@@ -43,7 +43,6 @@ namespace {
 
 constexpr uint32_t NONE = 0xffffffffu;
 constexpr uint32_t ROWCAP = HERRO_TILE;   // rows of the final matrix per k_tokens workgroup (1024)
-constexpr uint32_t INSCAP = 192;          // insertion rows whose tokens fit the LDS tile (more: the chunk is cut in pieces)
 constexpr uint32_t SCAP = 128;            // overlaps per window whose scores are cached in LDS
 constexpr uint32_t QEVCAP = 1024;         // insertion events staged in LDS by k_quals
 
@@ -69,23 +68,6 @@ __device__ __forceinline__ uint32_t blk_scan(uint32_t v, uint32_t* total, uint32
   }
   *total = tot;
   return base + inc - v;
-}
-
-__device__ __forceinline__ uint64_t wscan64(uint64_t v, uint64_t* total) {  // exclusive, within the wave
-  const int lane = threadIdx.x & 63;
-  uint64_t inc = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint64_t o = __shfl_up(inc, d, 64);
-    if (lane >= d) inc += o;
-  }
-  *total = __shfl(inc, 63, 64);
-  return inc - v;
-}
-__device__ __forceinline__ uint64_t wsum64(uint64_t v) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
 }
 
 // bits [lo, hi) of a 32-bit word, clipped
@@ -649,7 +631,7 @@ __device__ __forceinline__ uint32_t dpp_quad_lane0(uint32_t v) {  // value of th
 __global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J) {
   __shared__ __attribute__((aligned(16))) CTab s_ct[32];
   __shared__ __attribute__((aligned(16))) uint16_t s_rowinfo[ROWCAP];   // (position - pa) | base-row flag << 15
-  __shared__ __attribute__((aligned(16))) uint8_t s_ins[INSCAP * 32];   // [insertion row][column] tokens of inserted bases, 0xff: none
+  __shared__ uint32_t s_adj[ROWCAP];                                    // per row: inserted A, C, G, T (5 bits each), '*' they replace (bits 20..)
   __shared__ uint32_t s_pl[HERRO_ROWS * 3 * WPAD];                      // [column][plane][word - w_lo]
   __shared__ uint32_t s_rop[ROWCAP + 4];                                // row of positions pa .. pb1
   __shared__ uint32_t s_pref[33], s_supbits[ROWCAP / 32];
@@ -671,6 +653,9 @@ __global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J) {
   const uint32_t pb = pb1 - 1;
   const uint32_t w_lo = pa >> 5, wcnt = (pb >> 5) - w_lo + 2;
   const uint64_t pmax = J.read_n_words + 1;
+  const uint32_t nrows = r1 - r0, nrows16 = (nrows + 15u) & ~15u;
+  s_adj[tid] = 0; s_adj[tid + TK_NT] = 0; s_adj[tid + 2 * TK_NT] = 0; s_adj[tid + 3 * TK_NT] = 0;
+  if (tid < ROWCAP / 32) s_supbits[tid] = 0;
   __syncthreads();
   // round trip 3: rows of the chunk's positions, plane words of the chunk's positions for every column
   {
@@ -689,15 +674,12 @@ __global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J) {
       const uint32_t wi = min(w_lo + k, nw - 1u);
       pv[u] = J.cpl[(o != NONE ? (uint64_t)o : 0ull) * 3 * nw + pi * nw + wi];
     }
-    uint32_t tl = 0, th = 0;
     if (tid < wcnt) {
       const int32_t P = (int32_t)((w_lo + tid) << 5);
       const uint32_t vm = mask_range(0, (int32_t)win_len - P);
-      tl = glb_bits(J.read_p0, s_ct[0].q_woff, pmax, (int32_t)wd.tstart + P) & vm;
-      th = glb_bits(J.read_p1, s_ct[0].q_woff, pmax, (int32_t)wd.tstart + P) & vm;
       s_pl[0 * WPAD + tid] = vm;
-      s_pl[1 * WPAD + tid] = tl;
-      s_pl[2 * WPAD + tid] = th;
+      s_pl[1 * WPAD + tid] = glb_bits(J.read_p0, s_ct[0].q_woff, pmax, (int32_t)wd.tstart + P) & vm;
+      s_pl[2 * WPAD + tid] = glb_bits(J.read_p1, s_ct[0].q_woff, pmax, (int32_t)wd.tstart + P) & vm;
     }
 #pragma unroll
     for (int u = 0; u < 5; u++) if (tid + u * TK_NT < npos) s_rop[tid + u * TK_NT] = rv[u];
@@ -719,216 +701,210 @@ __global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J) {
   __syncthreads();
   const uint32_t n_events = s_pref[32];
   auto rop = [&](uint32_t p) -> uint32_t { return s_rop[p - pa]; };   // p in [pa, pb1]
-  auto lower = [&](uint32_t r) -> uint32_t {   // first p in [pa, pb1] with rop(p) >= r (pb1 + 1: none)
-    uint32_t lo = pa, hi = pb1 + 1;
-    while (lo < hi) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (rop(mid) < r) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-  };
-  const uint32_t seg = tid >> 2, cg = tid & 3u;
-  uint32_t n_sup_chunk = 0;   // meaningful in the first wave
-  // ---- the chunk's rows, normally in one piece [ra, rb); in several when more than INSCAP of them are insertion rows
-  for (uint32_t ra = r0; ra < r1;) {
-    const uint32_t pas = lower(ra + 1) - 1;           // position of row ra
-    const uint32_t f0 = rop(pas) == ra ? 1u : 0u;     // its base row lies in the piece
-    uint32_t rows = (r1 - ra + 15u) & ~15u, rb, pb1s;
-    for (;;) {
-      rb = min(ra + rows, r1);
-      pb1s = lower(rb);                                // positions with a base row before rb
-      const uint32_t nj0 = pb1s - (f0 ? pas : pas + 1);
-      if ((rb - ra) - nj0 <= INSCAP || rows <= 16) break;
-      rows = max(16u, (rows >> 1) & ~15u);
-    }
-    const uint32_t pbs = pb1s - 1;                     // last position with a row in the piece (>= pas)
-    const uint32_t nrows = rb - ra, nrows16 = (nrows + 15u) & ~15u;
-    // -- A: row info, row map, cleared insertion tile
-    for (uint32_t p = pas + tid; p <= pbs; p += TK_NT) {
-      const uint32_t rp = rop(p), nr = rop(p + 1) - rp;
-      for (uint32_t j = 0; j < nr; j++) {
-        const uint32_t row = rp + j;
-        if (row >= ra && row < rb) {
-          s_rowinfo[row - ra] = (uint16_t)((p - pa) | (j == 0 ? 0x8000u : 0u));
-          J.rowmap2[wd.row_off + row] = p | (j << 16);
-        }
+  // -- A: position (relative to pa) and base-row flag of every row of the chunk, the window's row map
+  for (uint32_t p = pa + tid; p <= pb; p += TK_NT) {
+    const uint32_t rp = rop(p), nr = rop(p + 1) - rp;
+    for (uint32_t j = 0; j < nr; j++) {
+      const uint32_t row = rp + j;
+      if (row >= r0 && row < r1) {
+        s_rowinfo[row - r0] = (uint16_t)((p - pa) | (j == 0 ? 0x8000u : 0u));
+        J.rowmap2[wd.row_off + row] = p | (j << 16);
       }
     }
-    for (uint32_t i = nrows + tid; i < nrows16; i += TK_NT) s_rowinfo[i] = (uint16_t)(pbs - pa);   // rows past the window's last: unused
-    for (uint32_t i = tid; i < INSCAP * 32 / 4; i += TK_NT) reinterpret_cast<uint32_t*>(s_ins)[i] = 0xffffffffu;
-    if (tid < ROWCAP / 32) s_supbits[tid] = 0;
-    __syncthreads();
-    // -- B: inserted bases of the selected columns (features.rs:213-229).  A later insertion at the same position
-    // overwrites an earlier one from its first row on, as the reference's sequential writes do.
-    for (uint32_t e0 = tid; e0 < n_events; e0 += 4 * TK_NT) {
-      uint4 v[4], v2[4];
-      uint32_t cc[4], ei[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const uint32_t e = min(e0 + u * TK_NT, n_events - 1u);
-        uint32_t lo = 0, hi = 32;   // column of flattened event e: largest c with s_pref[c] <= e
-        while (hi - lo > 1) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (s_pref[mid] <= e) lo = mid; else hi = mid;
-        }
-        cc[u] = lo;
-        ei[u] = e - s_pref[lo];
-        const uint4* __restrict__ evs = J.iev + s_ct[lo].ev_off;
-        v[u] = evs[ei[u]];
-        v2[u] = evs[min(ei[u] + 1u, s_ct[lo].n_ev - 1u)];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        if (e0 + u * TK_NT >= n_events) continue;
-        const uint32_t c = cc[u], ne = s_ct[c].n_ev;
-        const uint32_t p = v[u].x & 0xffffu, len = v[u].x >> 16;
-        if (p < pas || p > pbs) continue;
-        const uint32_t rp = rop(p), room = rop(p + 1) - rp - 1u;
-        uint32_t hide = 0;   // rows [0, hide) are overwritten by later insertions at the same position
-        if (ei[u] + 1 < ne && (v2[u].x & 0xffffu) == p) {
-          hide = v2[u].x >> 16;
-          const uint4* __restrict__ evs = J.iev + s_ct[c].ev_off;
-          for (uint32_t e2 = ei[u] + 2; e2 < ne; e2++) {
-            const uint4 v3 = evs[e2];
-            if ((v3.x & 0xffffu) != p) break;
-            hide = max(hide, v3.x >> 16);
-          }
-        }
-        const uint32_t s5 = s_ct[c].tokc & 0xffu;
-        for (uint32_t k = hide; k < len && k < room; k++) {
-          const uint32_t row = rp + 1u + k;
-          if (row < ra || row >= rb) continue;
-          uint32_t code;
-          if (k < 16u) code = (v[u].z >> (2u * k)) & 3u;
-          else {   // long insertion: bases beyond the 16 carried by the event come from the read store
-            const int32_t si = s_ct[c].sbase + s_ct[c].sdir * (int32_t)(v[u].y + k);
-            const uint64_t wi = min(s_ct[c].q_woff + ((uint32_t)si >> 5), pmax);
-            code = ((J.read_p0[wi] >> ((uint32_t)si & 31u)) & 1u) | (((J.read_p1[wi] >> ((uint32_t)si & 31u)) & 1u) << 1);
-            if (s_ct[c].sdir < 0) code ^= 3u;
-          }
-          const uint32_t idx = (row - ra) - (p - pas + f0);
-          if (idx < INSCAP) s_ins[idx * 32 + c] = (uint8_t)(s5 + code);
-        }
-      }
-    }
-    __syncthreads();
-    // -- C: 16 rows x 1 column per step; a quad of lanes shares a row segment, each lane 8 consecutive columns
-    if (seg * 16u < nrows) {
-      const uint4 ri0 = reinterpret_cast<const uint4*>(s_rowinfo)[seg * 2], ri1 = reinterpret_cast<const uint4*>(s_rowinfo)[seg * 2 + 1];
-      const uint32_t riw[8] = {ri0.x, ri0.y, ri0.z, ri0.w, ri1.x, ri1.y, ri1.z, ri1.w};
-      const uint32_t pf_rel = riw[0] & 0x7fffu;          // first position of the segment, relative to pa
-      const uint32_t p_first = pa + pf_rel;
-      const int32_t C = (int32_t)(seg * 16u) - (int32_t)(p_first - pas + f0);   // insertion-tile row of segment row i at offset k: C - k + i
-      uint32_t kj[16], cnt[16];
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const uint32_t v = (riw[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
-        const uint32_t k = (v & 0x7fffu) - pf_rel;
-        // bits 0..4: position - p_first (< 16), bit 5: base row, bits 8..: row of the insertion tile (meaningful for insertion rows)
-        kj[i] = k | ((v >> 15) << 5) | (min((uint32_t)max(C - (int32_t)k + i, 0), INSCAP - 1u) << 8);
-        cnt[i] = 0;
-      }
-      const uint32_t wrel = (p_first >> 5) - w_lo, sh = p_first & 31u;
-      const uint64_t gseg = wd.fin_off + ra + seg * 16u;
-      uint32_t tgt[4] = {0, 0, 0, 0};
-#pragma unroll 1
-      for (uint32_t ci = 0; ci < 8; ci++) {
-        const uint32_t c = cg * 8 + ci;   // column 31 (last lane of the quad, ci = 7) is a stand-in: '.', never stored
-        const CTab& h = s_ct[c];
-        const uint32_t* pl = s_pl + (size_t)min(c, (uint32_t)HERRO_ROWS - 1u) * 3 * WPAD + wrel;
-        const uint32_t m16 = __funnelshift_r(pl[0], pl[1], sh);
-        const uint32_t l16 = __funnelshift_r(pl[WPAD], pl[WPAD + 1], sh);
-        const uint32_t h16 = __funnelshift_r(pl[2 * WPAD], pl[2 * WPAD + 1], sh);
-        const uint32_t tt = c < HERRO_ROWS ? h.t_total : 0u;
-        const uint32_t r16 = mask_range(h.off - (int32_t)p_first, h.off + (int32_t)tt - (int32_t)p_first);
-        const uint32_t s5 = h.tokc & 0xffu, gapt = h.tokc >> 8;
-        uint32_t T[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int hf = 0; hf < 2; hf++) {   // two halves of eight rows, kept apart by a scheduling barrier (register pressure)
-          uint32_t ibv[8];   // this column's byte of every row's insertion-tile row: one batch of LDS reads, no branches
-#pragma unroll
-          for (int i8 = 0; i8 < 8; i8++) ibv[i8] = s_ins[(kj[hf * 8 + i8] >> 8) * 32 + c];
-#pragma unroll
-          for (int i8 = 0; i8 < 8; i8++) {
-            const int i = hf * 8 + i8;
-            const uint32_t k = kj[i];
-            const uint32_t j0 = __builtin_amdgcn_ubfe(k, 5, 1);
-            const uint32_t m = __builtin_amdgcn_ubfe(m16, k, 1) & j0;
-            const uint32_t code = __builtin_amdgcn_ubfe(l16, k, 1) | (__builtin_amdgcn_ubfe(h16, k, 1) << 1);
-            uint32_t r = __builtin_amdgcn_ubfe(r16, k, 1);
-            uint32_t fidx = m ? code : 4u;
-            uint32_t tok = m ? code + s5 : gapt;
-            tok = r ? tok : (uint32_t)TOK_NONE;
-            // insertion row: a base if this column inserts here (it counts even in front of the overlap's first base)
-            const uint32_t b = ibv[i8];
-            const bool isb = !j0 && b != 0xffu;
-            tok = isb ? b : tok;
-            fidx = isb ? (b >= 5u ? b - 5u : b) : fidx;
-            r = isb ? 1u : r;
-            T[i >> 2] |= tok << ((i & 3) * 8);
-            cnt[i] += r << (5u * fidx);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (c < HERRO_ROWS) *reinterpret_cast<uint4*>(J.fin_b + gseg + (uint64_t)c * wd.lub) = make_uint4(T[0], T[1], T[2], T[3]);
-        if (ci == 0) { tgt[0] = T[0]; tgt[1] = T[1]; tgt[2] = T[2]; tgt[3] = T[3]; }   // column 0 in the quad's first lane
-      }
-      // counts of the row over all 31 columns, then each lane of the quad finishes 4 rows
-#pragma unroll
-      for (int i = 0; i < 16; i++) cnt[i] = dpp_quad_add(cnt[i]);
-      const uint32_t tg0 = dpp_quad_lane0(tgt[0]), tg1 = dpp_quad_lane0(tgt[1]), tg2 = dpp_quad_lane0(tgt[2]), tg3 = dpp_quad_lane0(tgt[3]);
-      const uint32_t tgw = cg == 0 ? tg0 : (cg == 1 ? tg1 : (cg == 2 ? tg2 : tg3));
-      uint32_t supb = 0, consw = 0;
-#pragma unroll
-      for (int q4 = 0; q4 < 4; q4++) {
-        const uint32_t cw = cg == 0 ? cnt[q4] : (cg == 1 ? cnt[4 + q4] : (cg == 2 ? cnt[8 + q4] : cnt[12 + q4]));
-        uint32_t c5[5];
-#pragma unroll
-        for (int q = 0; q < 5; q++) c5[q] = (cw >> (5 * q)) & 31u;
-        // informative rows of the final [L',31] matrix: thresh = (31 * 0.1) as usize = 3 (features.rs:558,712)
-        const uint32_t thresh = (uint32_t)((double)HERRO_ROWS * 0.1);
-        uint32_t ns = 0;
-#pragma unroll
-        for (int q = 0; q < 5; q++) ns += c5[q] >= thresh ? 1u : 0u;
-        if (ns >= 2 && seg * 16u + cg * 4u + q4 < nrows) supb |= 1u << q4;
-        // majority vote of the consensus decoder (consensus.rs:178-200): it looks at the first n_alns+1 rows of the pileup, and
-        // every row beyond those is '.', which it skips anyway.  Two most common symbols by a stable descending sort (ties keep
-        // A,C,G,T,* order), target tie-break.
-        uint32_t c0 = c5[0], i0 = 0;
-#pragma unroll
-        for (uint32_t q = 1; q < 5; q++) if (c5[q] > c0) { c0 = c5[q]; i0 = q; }
-        uint32_t c1 = 0, i1 = 5;
-        bool have = false;
-#pragma unroll
-        for (uint32_t q = 0; q < 5; q++)
-          if (q != i0 && (!have || c5[q] > c1)) { c1 = c5[q]; i1 = q; have = true; }
-        const uint32_t tb0 = (tgw >> (q4 * 8)) & 0xffu;
-        const uint32_t cons_v = (c0 < 2u || (c0 == c1 && (i0 == tb0 || i1 == tb0))) ? tb0 : i0;
-        consw |= cons_v << (q4 * 8);
-      }
-      *reinterpret_cast<uint32_t*>(J.cons_tmp + wd.row_off + ra + seg * 16u + cg * 4u) = consw;
-      if (supb) atomicOr(&s_supbits[(seg * 16u + cg * 4u) >> 5], supb << ((seg * 16u + cg * 4u) & 31u));
-    }
-    __syncthreads();
-    // -- D: the piece's informative positions, in row order (SupportedPos, features.rs:896-900), by the first wave; the window's
-    // list is put together by k_supgather
-    if (tid < 64) {
-      const uint32_t bits = tid < ROWCAP / 32 ? s_supbits[tid] : 0u;
-      const uint32_t inc = wscan_incl((uint32_t)__popc(bits));
-      uint32_t k = n_sup_chunk + inc - (uint32_t)__popc(bits);
-      for (uint32_t m = bits; m; m &= m - 1u) {
-        const uint32_t ric = (tid << 5) + (uint32_t)__ffs((int)m) - 1u;
-        const uint32_t p = pa + (s_rowinfo[ric] & 0x7fffu), row = ra + ric;
-        J.sup_row[wd.row_off + r0 + k] = row;
-        J.sup_pi[wd.row_off + r0 + k] = p | ((row - rop(p)) << 16);
-        k++;
-      }
-      n_sup_chunk += wlast(inc);
-    }
-    __syncthreads();
-    ra += nrows16;   // stays a multiple of 16; only the window's last piece has nrows % 16 != 0
   }
-  if (tid == 0) J.tile_nsup[tile] = n_sup_chunk;
+  for (uint32_t i = nrows + tid; i < nrows16; i += TK_NT) s_rowinfo[i] = (uint16_t)(pb - pa);   // rows past the window's last: unused
+  __syncthreads();
+  // -- C1: 16 rows x 1 column per step, four rows per register.  A quad of lanes shares a row segment, each lane takes 8
+  // consecutive columns.  Position space -> row space is a byte permute: a base row takes the byte of its position, an
+  // insertion row the default of its position ('*' inside the overlap, '.' outside); inserted bases are patched in by B.
+  const uint32_t seg = tid >> 2, cg = tid & 3u;
+  const bool seg_live = seg * 16u < nrows;
+  uint32_t cAC[4] = {0, 0, 0, 0}, cGT[4] = {0, 0, 0, 0}, cS[4] = {0, 0, 0, 0};   // per row (byte): A | C << 4, G | T << 4, '*' seen in this lane's columns
+  uint32_t tgt[4] = {0, 0, 0, 0};
+  if (seg_live) {
+    const uint4 ri0 = reinterpret_cast<const uint4*>(s_rowinfo)[seg * 2], ri1 = reinterpret_cast<const uint4*>(s_rowinfo)[seg * 2 + 1];
+    const uint32_t riw[8] = {ri0.x, ri0.y, ri0.z, ri0.w, ri1.x, ri1.y, ri1.z, ri1.w};
+    const uint32_t pf_rel = riw[0] & 0x7fffu;          // first position of the segment, relative to pa
+    const uint32_t p_first = pa + pf_rel;
+    uint32_t kb[4], selT[4], selS[4];   // per register of four rows: position offset of its first row, byte selectors
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      kb[d] = ((riw[2 * d] & 0x7fffu) - pf_rel);
+      selT[d] = 0; selS[d] = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const uint32_t v = (riw[(4 * d + i) >> 1] >> (((4 * d + i) & 1) * 16)) & 0xffffu;
+        const uint32_t dk = (v & 0x7fffu) - pf_rel - kb[d];   // 0..3: rows advance at most one position each
+        const uint32_t j0 = v >> 15;
+        selT[d] |= (j0 ? dk : 4u + dk) << (8 * i);            // tokens: base row <- token of its position, insertion row <- default of its position
+        selS[d] |= (j0 ? dk : 0x0cu) << (8 * i);              // base symbols: insertion rows count nothing here (0x0c selects the constant 0)
+      }
+    }
+    const uint32_t wrel = (p_first >> 5) - w_lo, sh = p_first & 31u;
+    const uint64_t gseg = wd.fin_off + r0 + seg * 16u;
+#pragma unroll 1
+    for (uint32_t ci = 0; ci < 8; ci++) {
+      const uint32_t c = cg * 8 + ci;   // column 31 (last lane of the quad, ci = 7) is a stand-in: '.', never stored
+      const CTab& h = s_ct[c];
+      const uint32_t* pl = s_pl + (size_t)min(c, (uint32_t)HERRO_ROWS - 1u) * 3 * WPAD + wrel;
+      const bool real = c < HERRO_ROWS;
+      const uint32_t m32 = real ? __funnelshift_r(pl[0], pl[1], sh) : 0u;
+      const uint32_t l32 = real ? __funnelshift_r(pl[WPAD], pl[WPAD + 1], sh) : 0u;
+      const uint32_t h32 = real ? __funnelshift_r(pl[2 * WPAD], pl[2 * WPAD + 1], sh) : 0u;
+      const uint32_t tt = real ? h.t_total : 0u;
+      const uint32_t r32 = mask_range(h.off - (int32_t)p_first, h.off + (int32_t)tt - (int32_t)p_first);
+      const uint32_t s5 = h.tokc & 0xffu, gapt = h.tokc >> 8;
+      const uint32_t lut_lo = gapt * 0x01010101u;                                   // no query base here: gap
+      const uint32_t lut_hi = (s5 * 0x01010101u) + 0x03020100u;                     // query base: its code + strand offset
+      const uint32_t tenx = (uint32_t)TOK_NONE * 0x01010101u;
+      uint32_t T[4];
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        const uint32_t k = kb[d];
+        const uint32_t m4 = __builtin_amdgcn_ubfe(m32, k, 4), l4 = __builtin_amdgcn_ubfe(l32, k, 4), h4 = __builtin_amdgcn_ubfe(h32, k, 4),
+                       r4 = __builtin_amdgcn_ubfe(r32, k, 4);
+        // four positions -> four bytes: bit j of x lands on bit 8 j of x * 0x204081 (the partial products do not overlap)
+        const uint32_t idx = ((__umul24(m4, 0x810204u) & 0x04040404u) | (__umul24(h4, 0x408102u) & 0x02020202u)) | (__umul24(l4, 0x204081u) & 0x01010101u);   // per byte: M << 2 | hi << 1 | lo
+        const uint32_t Rb = __umul24(r4, 0x204081u) & 0x01010101u;
+        const uint32_t Rm = (Rb << 8) - Rb;                                         // 0xff in the bytes inside the overlap
+        const uint32_t tokMP = __builtin_amdgcn_perm(lut_hi, lut_lo, idx);
+        const uint32_t tokP = (tokMP & Rm) | (tenx & ~Rm);                          // per position: base / gap / '.'
+        const uint32_t defP = (lut_lo & Rm) | (tenx & ~Rm);                         // ... of an insertion row behind it: gap / '.'
+        T[d] = __builtin_amdgcn_perm(defP, tokP, selT[d]);
+        const uint32_t acP = __builtin_amdgcn_perm(0x00001001u, 0u, idx);           // A -> 0x01, C -> 0x10
+        const uint32_t gtP = __builtin_amdgcn_perm(0x10010000u, 0u, idx);           // G -> 0x01, T -> 0x10
+        const uint32_t Sb = Rb & ~(idx >> 2);                                       // inside the overlap, no base: '*' (bit 0 of every byte)
+        cAC[d] += __builtin_amdgcn_perm(0u, acP, selS[d]);
+        cGT[d] += __builtin_amdgcn_perm(0u, gtP, selS[d]);
+        cS[d] += __builtin_amdgcn_perm(Rb, Sb & 0x01010101u, selT[d]);              // an insertion row shows '*' wherever the overlap covers its position
+      }
+      if (c < HERRO_ROWS) *reinterpret_cast<uint4*>(J.fin_b + gseg + (uint64_t)c * wd.lub) = make_uint4(T[0], T[1], T[2], T[3]);
+      if (ci == 0) { tgt[0] = T[0]; tgt[1] = T[1]; tgt[2] = T[2]; tgt[3] = T[3]; }   // column 0 sits in the quad's first lane
+    }
+  }
+  __threadfence_block();
+  __syncthreads();   // the default tokens are out before the inserted bases go over them
+  // -- B: inserted bases of the selected columns (features.rs:213-229): the token byte over the default, the row's symbol
+  // counts adjusted in LDS.  A later insertion at the same position overwrites an earlier one from its first row on, as the
+  // reference's sequential writes do.
+  for (uint32_t e0 = tid; e0 < n_events; e0 += 4 * TK_NT) {
+    uint4 v[4], v2[4];
+    uint32_t cc[4], ei[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t e = min(e0 + u * TK_NT, n_events - 1u);
+      uint32_t lo = 0, hi = 32;   // column of flattened event e: largest c with s_pref[c] <= e
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_pref[mid] <= e) lo = mid; else hi = mid;
+      }
+      cc[u] = lo;
+      ei[u] = e - s_pref[lo];
+      const uint4* __restrict__ evs = J.iev + s_ct[lo].ev_off;
+      v[u] = evs[ei[u]];
+      v2[u] = evs[min(ei[u] + 1u, s_ct[lo].n_ev - 1u)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (e0 + u * TK_NT >= n_events) continue;
+      const uint32_t c = cc[u], ne = s_ct[c].n_ev;
+      const uint32_t p = v[u].x & 0xffffu, len = v[u].x >> 16;
+      if (p < pa || p > pb) continue;
+      const uint32_t rp = rop(p), room = rop(p + 1) - rp - 1u;
+      uint32_t hide = 0;   // rows [0, hide) are overwritten by later insertions at the same position
+      if (ei[u] + 1 < ne && (v2[u].x & 0xffffu) == p) {
+        hide = v2[u].x >> 16;
+        const uint4* __restrict__ evs = J.iev + s_ct[c].ev_off;
+        for (uint32_t e2 = ei[u] + 2; e2 < ne; e2++) {
+          const uint4 v3 = evs[e2];
+          if ((v3.x & 0xffffu) != p) break;
+          hide = max(hide, v3.x >> 16);
+        }
+      }
+      const uint32_t s5 = s_ct[c].tokc & 0xffu;
+      const bool inr = (uint32_t)((int32_t)p - s_ct[c].off) < s_ct[c].t_total;   // the default under it was '*' (counted), not '.'
+      for (uint32_t k = hide; k < len && k < room; k++) {
+        const uint32_t row = rp + 1u + k;
+        if (row < r0 || row >= r1) continue;
+        uint32_t code;
+        if (k < 16u) code = (v[u].z >> (2u * k)) & 3u;
+        else {   // long insertion: bases beyond the 16 carried by the event come from the read store
+          const int32_t si = s_ct[c].sbase + s_ct[c].sdir * (int32_t)(v[u].y + k);
+          const uint64_t wi = min(s_ct[c].q_woff + ((uint32_t)si >> 5), pmax);
+          code = ((J.read_p0[wi] >> ((uint32_t)si & 31u)) & 1u) | (((J.read_p1[wi] >> ((uint32_t)si & 31u)) & 1u) << 1);
+          if (s_ct[c].sdir < 0) code ^= 3u;
+        }
+        J.fin_b[wd.fin_off + (uint64_t)c * wd.lub + row] = (uint8_t)(s5 + code);
+        atomicAdd(&s_adj[row - r0], (1u << (5u * code)) + (inr ? 1u << 20 : 0u));
+      }
+    }
+  }
+  __syncthreads();
+  // -- C2: counts of every row over all 31 columns; each lane of the quad finishes 4 rows
+  if (seg_live) {
+    uint32_t cnt8[5][4];   // per symbol: four registers of four row-bytes
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      cnt8[0][d] = dpp_quad_add(cAC[d] & 0x0f0f0f0fu);
+      cnt8[1][d] = dpp_quad_add((cAC[d] >> 4) & 0x0f0f0f0fu);
+      cnt8[2][d] = dpp_quad_add(cGT[d] & 0x0f0f0f0fu);
+      cnt8[3][d] = dpp_quad_add((cGT[d] >> 4) & 0x0f0f0f0fu);
+      cnt8[4][d] = dpp_quad_add(cS[d]);
+    }
+    const uint32_t tg0 = dpp_quad_lane0(tgt[0]), tg1 = dpp_quad_lane0(tgt[1]), tg2 = dpp_quad_lane0(tgt[2]), tg3 = dpp_quad_lane0(tgt[3]);
+    const uint32_t tgw = cg == 0 ? tg0 : (cg == 1 ? tg1 : (cg == 2 ? tg2 : tg3));
+    uint32_t cw[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) cw[q] = cg == 0 ? cnt8[q][0] : (cg == 1 ? cnt8[q][1] : (cg == 2 ? cnt8[q][2] : cnt8[q][3]));
+    const uint4 adj = *reinterpret_cast<const uint4*>(s_adj + seg * 16u + cg * 4u);
+    const uint32_t adjw[4] = {adj.x, adj.y, adj.z, adj.w};
+    uint32_t supb = 0, consw = 0;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; q4++) {
+      uint32_t c5[5];
+#pragma unroll
+      for (int q = 0; q < 4; q++) c5[q] = ((cw[q] >> (8 * q4)) & 0xffu) + ((adjw[q4] >> (5 * q)) & 31u);
+      c5[4] = ((cw[4] >> (8 * q4)) & 0xffu) - (adjw[q4] >> 20);
+      // informative rows of the final [L',31] matrix: thresh = (31 * 0.1) as usize = 3 (features.rs:558,712)
+      const uint32_t thresh = (uint32_t)((double)HERRO_ROWS * 0.1);
+      uint32_t ns = 0;
+#pragma unroll
+      for (int q = 0; q < 5; q++) ns += c5[q] >= thresh ? 1u : 0u;
+      if (ns >= 2 && seg * 16u + cg * 4u + q4 < nrows) supb |= 1u << q4;
+      // majority vote of the consensus decoder (consensus.rs:178-200): it looks at the first n_alns+1 rows of the pileup, and
+      // every row beyond those is '.', which it skips anyway.  Two most common symbols by a stable descending sort (ties keep
+      // A,C,G,T,* order), target tie-break.
+      uint32_t c0 = c5[0], i0 = 0;
+#pragma unroll
+      for (uint32_t q = 1; q < 5; q++) if (c5[q] > c0) { c0 = c5[q]; i0 = q; }
+      uint32_t c1 = 0, i1 = 5;
+      bool have = false;
+#pragma unroll
+      for (uint32_t q = 0; q < 5; q++)
+        if (q != i0 && (!have || c5[q] > c1)) { c1 = c5[q]; i1 = q; have = true; }
+      const uint32_t tb0 = (tgw >> (q4 * 8)) & 0xffu;
+      const uint32_t cons_v = (c0 < 2u || (c0 == c1 && (i0 == tb0 || i1 == tb0))) ? tb0 : i0;
+      consw |= cons_v << (q4 * 8);
+    }
+    *reinterpret_cast<uint32_t*>(J.cons_tmp + wd.row_off + r0 + seg * 16u + cg * 4u) = consw;
+    if (supb) atomicOr(&s_supbits[(seg * 16u + cg * 4u) >> 5], supb << ((seg * 16u + cg * 4u) & 31u));
+  }
+  __syncthreads();
+  // -- D: the chunk's informative positions, in row order (SupportedPos, features.rs:896-900), by the first wave; the window's
+  // list is put together by k_supgather
+  if (tid < 64) {
+    const uint32_t bits = tid < ROWCAP / 32 ? s_supbits[tid] : 0u;
+    const uint32_t inc = wscan_incl((uint32_t)__popc(bits));
+    uint32_t k = inc - (uint32_t)__popc(bits);
+    for (uint32_t m = bits; m; m &= m - 1u) {
+      const uint32_t ric = (tid << 5) + (uint32_t)__ffs((int)m) - 1u;
+      const uint32_t p = pa + (s_rowinfo[ric] & 0x7fffu), row = r0 + ric;
+      J.sup_row[wd.row_off + r0 + k] = row;
+      J.sup_pi[wd.row_off + r0 + k] = p | ((row - rop(p)) << 16);
+      k++;
+    }
+    if (tid == 63) J.tile_nsup[tile] = inc;
+  }
 }
 
 // =====================================================================================================
