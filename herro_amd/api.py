@@ -346,7 +346,7 @@ OW_DTYPE = np.dtype([(n, "<u4") for n in ("win", "qid", "cls", "tstart", "qbeg",
                                             "end_off", "scr_off", "strand", "wtstart", "wlen")] +
                     [(n, "<u8") for n in ("t_woff", "q_woff", "q_qual_off")], align=True)   # OwDesc (csrc/pileup_core.h)
 WIN_DTYPE = np.dtype([(n, "<u4") for n in ("rid", "wid", "n_wids", "tstart", "win_len", "ow_begin", "ow_cnt", "lub")] +
-                     [(n, "<u8") for n in ("col_off", "fin_off", "row_off", "pos_off")], align=True)   # WinDesc
+                     [(n, "<u8") for n in ("col_off", "fin_off", "row_off", "pos_off", "ev_off")], align=True)   # WinDesc
 
 
 class HostContext(Context):

@@ -160,6 +160,7 @@ struct herro_ctx {
   std::vector<Arena> free_scan, free_stage;            // device op array + staged CIGAR text of a job; pinned staging of one herro_job_create
   hipStream_t prep_stream = nullptr;                   // CIGAR scan of the job being created: its own (high-priority) stream, so that it does not queue behind the pileup / model kernels of earlier jobs
   hipEvent_t prep_ev = nullptr;
+  unsigned long long* d_prof = nullptr;                // HERRO_PROF=1: per-kernel phase cycles (job_dev.h PROF_MARK), printed by herro_destroy
   bool dev_scan = true;                                // HERRO_HOST_SCAN=1: decode the text on the host instead (A/B, debugging)
   std::vector<Arena> free_dev, free_pin, free_small;   // free_small: the buffers a job needs only once its counts are known (logits, batch descriptors)
   std::atomic<uint32_t> live_jobs{0};   // herro_job_create may run on another thread than the context's execution calls
@@ -219,6 +220,7 @@ struct herro_job {
   std::vector<uint64_t> sup_off;  // [n_win+1] prefix of nsup
   float* d_info = nullptr;   // inside a_logits
   float* d_base = nullptr;
+  uint8_t* d_rfq = nullptr;  // inside a_logits: qualities of the receptive fields, compact (BatchDev::rf_q)
   Arena a_logits{}, a_bdesc{}, a_supoff{};
   std::vector<float> h_info, h_base;
   bool logits_on_host = false;
@@ -378,6 +380,9 @@ herro_ctx* herro_create(int device_id) {
       g_create_err = hipGetErrorString(e);
       return nullptr;
     }
+    if (const char* pe = getenv("HERRO_PROF"); pe && atoi(pe)) {
+      if (hipMalloc((void**)&ctx->d_prof, 256 * 32 * 8) == hipSuccess) (void)hipMemset(ctx->d_prof, 0, 256 * 32 * 8); else ctx->d_prof = nullptr;
+    }
     const char* hs = getenv("HERRO_HOST_SCAN");
     ctx->dev_scan = !(hs && atoi(hs) != 0);
   }
@@ -401,6 +406,20 @@ void herro_destroy(herro_ctx* ctx) {
   if (ctx->host_only) { for (Arena& a : ctx->free_pin) std::free(a.p); delete ctx; return; }
   (void)hipSetDevice(ctx->device);   // teardown: nothing to report errors to
   (void)hipDeviceSynchronize();
+  if (ctx->d_prof) {
+    std::vector<unsigned long long> raw(256 * 32);
+    unsigned long long h[256] = {0};
+    if (hipMemcpy(raw.data(), ctx->d_prof, raw.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+      for (int i = 0; i < 256; i++) for (int sh = 0; sh < 32; sh++) h[i] += raw[(size_t)i * 32 + sh];
+      for (int k = 0; k < 16; k++)
+        if (h[k * 16 + 15]) {
+          fprintf(stderr, "PROF kernel %d (%llu workgroups), cycles per workgroup by phase:", k, h[k * 16 + 15]);
+          for (int ph = 0; ph < 15; ph++) if (h[k * 16 + ph]) fprintf(stderr, " %d:%.0f", ph, (double)h[k * 16 + ph] / (double)h[k * 16 + 15]);
+          fprintf(stderr, "\n");
+        }
+    }
+    (void)hipFree(ctx->d_prof);
+  }
   ctx->timer.reset();
   for (void* p : {(void*)ctx->d_words, (void*)ctx->d_word_off, (void*)ctx->d_qual, (void*)ctx->d_qual_off, (void*)ctx->d_p0, (void*)ctx->d_p1, (void*)ctx->d_ln})
     if (p) (void)hipFree(p);
@@ -1135,9 +1154,11 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
       d.win += (uint32_t)b.win; d.cls += (uint32_t)b.cls; d.op_begin += (uint32_t)b.op; d.scr_off += (uint32_t)b.scr;
       job->ow[b.ow + i] = d;
     }
-    uint64_t fin = b.fin, row = b.row, pos = b.pos, tile = b.tile;
+    uint64_t fin = b.fin, row = b.row, pos = b.pos, tile = b.tile, evo = b.scr + 2 * b.ow;
     for (size_t i = 0; i < o.win.size(); i++) {
       WinDesc wd = o.win[i];
+      wd.ev_off = evo;
+      for (uint32_t k = 0; k < wd.ow_cnt; k++) evo += o.ow[wd.ow_begin + k].op_cnt + 2u;   // target-local ow_begin here
       wd.ow_begin += (uint32_t)b.ow;
       wd.col_off = tile;   // first tile of the window
       wd.fin_off = fin; fin += (uint64_t)HERRO_ROWS * wd.lub;
@@ -1167,6 +1188,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.read_words = ctx->d_words; J.read_word_off = ctx->d_word_off; J.read_p0 = ctx->d_p0; J.read_p1 = ctx->d_p1;
   J.read_qual = ctx->d_qual; J.read_qual_off = ctx->d_qual_off; J.read_qual_bytes = ctx->qual_bytes; J.read_n_words = ctx->n_words;
   J.ln_table = ctx->d_ln; J.ln_table_n = ctx->ln_n;
+  J.prof = ctx->d_prof;
   J.n_ow = n_ow; J.n_win = n_win; J.n_cls = n_cls;
   J.n_tiles = (uint32_t)job->tile_win.size(); J.window_size = W; J.nw = (W + 31) / 32; J.max_cols = max_cols;
   cur = desc_bytes;
@@ -1175,6 +1197,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   const size_t o_keep = take(n_ow), o_acc = take((uint64_t)n_ow * 4), o_ttot = take((uint64_t)n_ow * 4);
   const size_t o_slot = take((uint64_t)n_ow * 4), o_rqid = take((uint64_t)n_ow * 4), o_sel = take((uint64_t)n_win * 32 * 4);
   const size_t o_ctab = take((uint64_t)n_win * 32 * sizeof(CTab)), o_chdr = take((size_t)J.n_tiles * 8), o_tnsup = take((size_t)J.n_tiles * 4);
+  const size_t o_sev = take((scr_ops + 2ull * n_ow) * 8), o_tev = take((scr_ops + 2ull * n_ow) * 16), o_tileev = take((size_t)J.n_tiles * 8);
   const size_t o_dcounts = take((uint64_t)n_win * 12);
   const size_t o_rop = take(pos_elems * 4), o_rmap = take(row_elems * 4);
   const size_t o_cseq = take(row_elems), o_ctmp = take(row_elems), o_clen = take((uint64_t)n_win * 4);
@@ -1196,6 +1219,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.ow_keep = (uint8_t*)(db + o_keep); J.ow_acc = (float*)(db + o_acc); J.ow_ttotal = (uint32_t*)(db + o_ttot);
   J.slot_ow = (uint32_t*)(db + o_slot); J.rank_qid = (uint32_t*)(db + o_rqid); J.sel_ow = (uint32_t*)(db + o_sel);
   J.ctab = (CTab*)(db + o_ctab); J.chdr2 = (uint2*)(db + o_chdr); J.tile_nsup = (uint32_t*)(db + o_tnsup);
+  J.sev = (uint2*)(db + o_sev); J.tev = (uint4*)(db + o_tev); J.tile_ev = (uint2*)(db + o_tileev);
   job->d_counts = (uint32_t*)(db + o_dcounts);
   J.win_Lf = job->d_counts; J.win_nsup = job->d_counts + n_win; J.win_nkept = job->d_counts + 2ull * n_win;
   J.row_of_pos2 = (uint32_t*)(db + o_rop); J.rowmap2 = (uint32_t*)(db + o_rmap);
@@ -1318,10 +1342,12 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   if (!job->d_info || job->logit_cap < total_sup) {
     if (job->d_info) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); small_release(ctx, job->a_logits); job->d_info = job->d_base = nullptr; }
     job->logit_cap = std::max<uint64_t>(total_sup + total_sup / 8, 1);
-    job->a_logits = small_acquire(ctx, job->logit_cap * 24 + 256);
+    const uint64_t o_base = (job->logit_cap * 4 + 255) & ~(uint64_t)255, o_rfq = (o_base + job->logit_cap * 20 + 255) & ~(uint64_t)255;
+    job->a_logits = small_acquire(ctx, o_rfq + job->logit_cap * HERRO_ROWS * 8 + 256);
     if (!job->a_logits.p) { ctx->err = "out of device memory for the logits"; return HERRO_E_NO_DEVICE; }
     job->d_info = (float*)job->a_logits.p;
-    job->d_base = (float*)((unsigned char*)job->a_logits.p + ((job->logit_cap * 4 + 255) & ~(uint64_t)255));
+    job->d_base = (float*)((unsigned char*)job->a_logits.p + o_base);
+    job->d_rfq = (uint8_t*)job->a_logits.p + o_rfq;
   }
   // ---- plan batches (prepare_examples, inference.rs:241-250; flush rule features.rs:884-893)
   job->batches.clear();
@@ -1425,7 +1451,10 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   rc = ensure_scratch(ctx, max_tok);
   if (rc) return rc;
   // the qualities the model will read: rows within 2 * (kw / 2) of an informative row (two stacked convs)
-  if (!job->quals_full && !groups.empty()) launch_rf_quals(job->J, 2 * (ctx->M.h.kw / 2), ctx->stream, &ctx->timer);
+  const uint32_t rf_half = 2 * (ctx->M.h.kw / 2);
+  const bool rf_compact = !job->quals_full && job->d_rfq && 2 * rf_half + 1 <= 8;   // the model reads the compact receptive fields; else the planes
+  if (!job->quals_full && !groups.empty())
+    launch_rf_quals(job->J, rf_half, job->d_supoff_blob, rf_compact ? job->d_rfq : nullptr, ctx->stream, &ctx->timer);
   for (const Offs& o : offs) {
     const unsigned char* base = (const unsigned char*)job->d_bdesc;
     BatchDev B{};
@@ -1440,6 +1469,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
     B.n_tiles = o.n_tiles;
     B.tile_tok0 = (const uint32_t*)(base + o.tiles);
     B.planes_b = job->J.fin_b; B.planes_q = job->J.fin_q; B.sup_row = job->J.sup_row;
+    B.rf_q = rf_compact ? job->d_rfq : nullptr;
     B.out_info = job->d_info; B.out_base = job->d_base;
     run_model(ctx, B, o.tiled);
   }
@@ -1784,7 +1814,7 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
     bd.sup_off = (const uint64_t*)up(P.sup_off.data(), nb * 8); bd.out_off = (const uint64_t*)up(P.out_off.data(), nb * 8);
     bd.tile_tok0 = (const uint32_t*)up(P.tiles.data(), P.tiles.size() * 4);
     bd.n_tiles = P.tiles.empty() ? 0u : (uint32_t)P.tiles.size() - 1;
-    bd.planes_b = d_pb; bd.planes_q = d_pq; bd.sup_row = d_sr; bd.out_info = d_info; bd.out_base = d_base;
+    bd.planes_b = d_pb; bd.planes_q = d_pq; bd.rf_q = nullptr; bd.sup_row = d_sr; bd.out_info = d_info; bd.out_base = d_base;
     if (!bd.plane_off || !bd.plane_ld || !bd.len || !bd.lmax || !bd.tok_off || !bd.sup_off || !bd.out_off || !bd.tile_tok0 || e != hipSuccess) {
       ctx->err = e != hipSuccess ? hipGetErrorString(e) : "out of device memory";
       (void)hipStreamSynchronize(st);

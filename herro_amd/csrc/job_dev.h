@@ -64,6 +64,9 @@ struct JobDev {
   CTab* ctab;            // [win * 32 + c]
   uint2* chdr2;          // [tile] {position of the tile's first row, 1 if that row is the position's base row}
   uint32_t* tile_nsup;   // [tile] informative rows found in the tile
+  uint2* sev;            // per window (at ctab[0].ev_off): insertion events of the selected columns, column-major {pos | len << 16, query index | column << 24}
+  uint4* tev;            // per window (same base): per tile, the inserted-base runs reaching into it {pos | len << 16, query index, first 16 bases, column | hidden rows << 8}
+  uint2* tile_ev;        // [tile] {first slot of the tile's runs relative to the window's base, count}
   uint32_t* win_nkept;
   uint32_t* win_Lf;      // rows of the final matrix (L')
   uint32_t* win_nsup;
@@ -78,7 +81,23 @@ struct JobDev {
   uint8_t* cons_seq;     // [win.row_off ..] corrected bases of the window (ASCII), cons_len[w] of them
   uint8_t* cons_tmp;     // [win.row_off + row] per-row call before '*' removal
   uint32_t* cons_len;    // [win]
+  unsigned long long* prof;  // HERRO_PROF=1: [kernel * 16 + phase] shader cycles summed over workgroups, [.. + 15] workgroups (null otherwise)
 };
+
+// phase timer for kernel development (HERRO_PROF=1): thread 0 of one workgroup in 32 adds the cycles since the previous mark
+// (sampled and sharded 32 ways: an atomic per mark from every workgroup on one address slowed the kernels 5x and drowned the signal)
+#define PROF_ON(J) ((J).prof && threadIdx.x == 0 && (blockIdx.x & 31u) == 0)
+#define PROF_BEGIN(J) unsigned long long _pt = PROF_ON(J) ? __builtin_readcyclecounter() : 0ull
+#define PROF_MARK(J, kern, phase)                                                              \
+  do {                                                                                        \
+    if (PROF_ON(J)) {                                                                         \
+      const unsigned long long _t = __builtin_readcyclecounter();                             \
+      const unsigned _sh = (blockIdx.x >> 5) & 31u;                                           \
+      atomicAdd(&(J).prof[((kern) * 16 + (phase)) * 32 + _sh], _t - _pt);                     \
+      if ((phase) == 0) atomicAdd(&(J).prof[((kern) * 16 + 15) * 32 + _sh], 1ull);            \
+      _pt = __builtin_readcyclecounter();                                                     \
+    }                                                                                         \
+  } while (0)
 
 // Accumulates GPU time per kernel group with HIP events recorded on the launch stream.
 struct KernelTimer {
@@ -130,7 +149,8 @@ struct KernelTimer {
 
 void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm);
 // qualities inside the model's receptive fields (rows within `half` of an informative row)
-void launch_rf_quals(const JobDev& J, uint32_t half, hipStream_t st, KernelTimer* tm);
+// rf_q != null: compact layout [(sup_off[w] + k) * 31 + column][8] (needs 2 * half + 1 <= 8), else into the quality planes
+void launch_rf_quals(const JobDev& J, uint32_t half, const uint64_t* sup_off, uint8_t* rf_q, hipStream_t st, KernelTimer* tm);
 // the complete quality planes (featurize itself only writes tokens)
 void launch_full_quals(const JobDev& J, hipStream_t st);
 void launch_consensus(const JobDev& J, const uint64_t* sup_off, const float* base_logits, hipStream_t st, KernelTimer* tm);

@@ -66,7 +66,8 @@ __global__ void k_build_tokens(BatchDev B, ModelScratch S) {
     tm.tok_row = row;
     tm.len = B.len[b];
     tm.lmax = B.lmax[b];
-    tm.pad0 = tm.pad1 = 0;
+    tm.rf_idx = (uint32_t)(B.out_off[b] + (n - t0));
+    tm.pad1 = 0;
     S.tok_meta[n] = tm;
   }
 }
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(256) void k_patch_conv1(ModelDev M, BatchDev B, Mod
   const uint8_t* pb = B.planes_b + B.plane_off[b];
   const uint8_t* pq = B.planes_q + B.plane_off[b];
   const uint32_t ld = B.plane_ld[b];
+  const uint8_t* rq = (B.rf_q && P <= 8) ? B.rf_q + (B.out_off[b] + (n - B.tok_off[b])) * HERRO_ROWS * 8 : nullptr;   // receptive-field qualities, compact
 
   for (uint32_t e = threadIdx.x; e < kw * 12 * c1; e += blockDim.x) s_t1[e] = M.t1[e];
   for (uint32_t e = threadIdx.x; e < kw * c1; e += blockDim.x) s_wq[e] = M.wq1[e];
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void k_patch_conv1(ModelDev M, BatchDev B, Mod
     if (q >= 0 && q < lmax) {
       if (q < len) {
         tok = pb[(uint64_t)r * ld + q];
-        qn = norm_qual(pq[(uint64_t)r * ld + q]);
+        qn = norm_qual(rq ? rq[r * 8 + e % P] : pq[(uint64_t)r * ld + q]);
       } else {  // batch padding (inference.rs:86-97)
         tok = TOK_PAD;
         qn = norm_qual(126u);
@@ -441,6 +443,7 @@ __global__ __launch_bounds__(256) void k_patch_conv1_s(ModelDev M, BatchDev B, M
     const uint8_t* pb = B.planes_b + B.plane_off[b];
     const uint8_t* pq = B.planes_q + B.plane_off[b];
     const uint32_t ld = B.plane_ld[b];
+    const uint8_t* rq = (B.rf_q && P <= 8) ? B.rf_q + (B.out_off[b] + (n - B.tok_off[b])) * HERRO_ROWS * 8 : nullptr;   // receptive-field qualities, compact
     __syncthreads();
     for (uint32_t e = threadIdx.x; e < HERRO_ROWS * P; e += blockDim.x) {
       const uint32_t r = e / P;
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(256) void k_patch_conv1_s(ModelDev M, BatchDev B, M
       if (q >= 0 && q < lmax) {
         if (q < len) {
           tok = pb[(uint64_t)r * ld + q];
-          qn = norm_qual(pq[(uint64_t)r * ld + q]);
+          qn = norm_qual(rq ? rq[r * 8 + e % P] : pq[(uint64_t)r * ld + q]);
         } else {  // batch padding (inference.rs:86-97)
           tok = TOK_PAD;
           qn = norm_qual(126u);
@@ -1016,7 +1019,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_w(ModelDev M, BatchDev B, Model
   // ---- gather: threads 0..127 fetch the 5 tokens of pair tid, threads 128..255 its 5 qualities
   const uint32_t grr = tid & 127u;
   const bool gq = tid >= 128;
-  const uint8_t* gplane = gq ? B.planes_q : B.planes_b;
+  const bool rfq = gq && B.rf_q != nullptr;   // qualities from the compact receptive-field array
+  const uint8_t* gplane = gq ? (rfq ? B.rf_q : B.planes_q) : B.planes_b;
   struct PairMeta { uint64_t rowbase; uint32_t tok_row, len, lmax; };  // lmax = 0: no such pair
   auto load_meta = [&](uint32_t tile) -> PairMeta {
     const uint32_t m = tile * CW_TP + grr;
@@ -1024,6 +1028,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_w(ModelDev M, BatchDev B, Model
     if (tile < n_tiles && m < n_rows) {
       const TokMeta tm = S.tok_meta[m / HERRO_ROWS];
       r.rowbase = tm.plane_off + (uint64_t)(m % HERRO_ROWS) * tm.plane_ld;  // byte offset of the read row
+      if (rfq) r.rowbase = ((uint64_t)tm.rf_idx * HERRO_ROWS + m % HERRO_ROWS) * 8 - (uint64_t)(int64_t)((int32_t)tm.tok_row - 2);   // + q = slot byte q - (tok_row - 2)
       r.tok_row = tm.tok_row;
       r.len = tm.len;
       r.lmax = tm.lmax;

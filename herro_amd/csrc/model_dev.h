@@ -76,7 +76,8 @@ struct BatchDev {
   const uint64_t* sup_off;    // [B] element offset of the window's informative-row list
   const uint64_t* out_off;    // [B] element offset of the window's logits in the job buffers
   const uint8_t* planes_b;    // tokens
-  const uint8_t* planes_q;    // raw qualities
+  const uint8_t* planes_q;    // raw qualities (complete planes; used when rf_q is null)
+  const uint8_t* rf_q;        // qualities of the receptive fields only: [(out_off[b] + k) * 31 + row][8], byte i = row tok_row - 2 (kw / 2) + i (k_quals); null: read planes_q
   const uint32_t* sup_row;    // informative rows
   uint32_t n_tiles;           // token tiles of whole windows (<= 64 tokens each) for the fused stack; 0: not tileable
   const uint32_t* tile_tok0;  // [n_tiles+1] first token of each tile
@@ -90,7 +91,8 @@ struct __attribute__((aligned(16))) TokMeta {
   uint32_t plane_ld;   // plane stride
   uint32_t tok_row;    // row of the token inside the window
   uint32_t len, lmax;  // L' of the window, max L' of its batch (both < 65536)
-  uint32_t pad0, pad1;
+  uint32_t rf_idx;     // job-level index of the token (slot of its receptive-field qualities in BatchDev::rf_q)
+  uint32_t pad1;
 };
 
 struct ModelScratch {  // sized for n_tok tokens

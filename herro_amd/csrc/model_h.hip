@@ -144,7 +144,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_h(ModelDev M, BatchDev B, Model
 
   const uint32_t grr = tid & 127u;
   const bool gq = tid >= 128;
-  const uint8_t* gplane = gq ? B.planes_q : B.planes_b;
+  const bool rfq = gq && B.rf_q != nullptr;   // qualities from the compact receptive-field array
+  const uint8_t* gplane = gq ? (rfq ? B.rf_q : B.planes_q) : B.planes_b;
   struct PairMeta { uint64_t rowbase; uint32_t tok_row, len, lmax; };
   auto load_meta = [&](uint32_t tile) -> PairMeta {
     const uint32_t m = tile * HTP + grr;
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_h(ModelDev M, BatchDev B, Model
     if (tile < n_tiles && m < n_rows) {
       const TokMeta tm = S.tok_meta[m / HERRO_ROWS];
       r.rowbase = tm.plane_off + (uint64_t)(m % HERRO_ROWS) * tm.plane_ld;
+      if (rfq) r.rowbase = ((uint64_t)tm.rf_idx * HERRO_ROWS + m % HERRO_ROWS) * 8 - (uint64_t)(int64_t)((int32_t)tm.tok_row - 2);   // + q = slot byte q - (tok_row - 2)
       r.tok_row = tm.tok_row;
       r.len = tm.len;
       r.lmax = tm.lmax;
@@ -1148,7 +1150,8 @@ __global__ void k_build_tokens_h(BatchDev B, ModelScratch S) {
     tm.tok_row = row;
     tm.len = B.len[b];
     tm.lmax = B.lmax[b];
-    tm.pad0 = tm.pad1 = 0;
+    tm.rf_idx = (uint32_t)(B.out_off[b] + (n - t0));
+    tm.pad1 = 0;
     S.tok_meta[n] = tm;
   }
 }

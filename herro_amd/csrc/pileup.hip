@@ -31,8 +31,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <set>
+#include <type_traits>
 
 #include "job_dev.h"
 #include "pileup_core.h"
@@ -44,7 +47,7 @@ namespace {
 constexpr uint32_t NONE = 0xffffffffu;
 constexpr uint32_t ROWCAP = HERRO_TILE;   // rows of the final matrix per k_tokens workgroup (1024)
 constexpr uint32_t SCAP = 128;            // overlaps per window whose scores are cached in LDS
-constexpr uint32_t QEVCAP = 1024;         // insertion events staged in LDS by k_quals
+constexpr uint32_t QEVCAP = 2048;         // insertion events (position | length, query index) staged in LDS by k_quals
 
 // ---- small helpers ---------------------------------------------------------------------------------------
 template <int NT>
@@ -79,11 +82,11 @@ __device__ __forceinline__ uint32_t mask_range(int32_t lo, int32_t hi) {
   return m & ~((1u << lo) - 1u);
 }
 
-// 32 consecutive plane bits starting at bit index s of a staged plane of npw words (bits outside read 0)
+// 32 consecutive plane bits starting at bit index s of a staged plane of npw words (bits outside read 0).  The staged
+// words sit between two zero words, pl[-1] and pl[npw]: no bounds branches, two clamps.
 __device__ __forceinline__ uint32_t lds_bits(const uint32_t* pl, uint32_t npw, int32_t s) {
-  if (s < 0) return s <= -32 ? 0u : (pl[0] << (uint32_t)(-s));
-  const uint32_t w = (uint32_t)s >> 5;
-  const uint32_t a = w < npw ? pl[w] : 0u, b = w + 1 < npw ? pl[w + 1] : 0u;
+  const int32_t w = s >> 5;
+  const uint32_t a = pl[min(max(w, -1), (int32_t)npw)], b = pl[min(max(w + 1, -1), (int32_t)npw)];
   return __funnelshift_r(a, b, (uint32_t)s & 31u);
 }
 // the same from the read store's plane array (word index clamped into the array: wmax = its last word)
@@ -181,7 +184,7 @@ __device__ __forceinline__ uint32_t wsum(uint32_t v) { return wlast(wscan_incl(v
 constexpr int CA_NT = 256, CA_NW = CA_NT / 64;
 constexpr uint32_t MDCAP = 192;   // ops per batch (three steps of 64); a slice with more ops runs several batches
 __host__ __device__ inline uint32_t cols_qcap(uint32_t nw) { return nw + 40u < 320u ? nw + 40u : 320u; }   // staged query plane words
-__host__ __device__ inline uint32_t cols_lds_words(uint32_t nw) { return 3 * MDCAP + 2 * (nw + 1) + 2 * cols_qcap(nw) + 2 * (nw + 2); }
+__host__ __device__ inline uint32_t cols_lds_words(uint32_t nw) { return 3 * MDCAP + 2 * (nw + 1) + 2 * (cols_qcap(nw) + 2) + 2 * (nw + 2); }
 
 __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
   extern __shared__ __attribute__((aligned(16))) uint32_t ca_smem[];
@@ -194,10 +197,11 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
   uint32_t* s_ml = s_mq + MDCAP;                                  // ... length | M << 31
   uint32_t* s_bm = s_ml + MDCAP;                                  // [nw+1] bitmap of op starts over window positions
   uint32_t* s_cum = s_bm + (nw + 1);                              // [nw+1] op starts in front of each word
-  uint32_t* q0 = s_cum + (nw + 1);                                // [qcap] query code planes (stored orientation)
-  uint32_t* q1 = q0 + qcap;
-  uint32_t* t0 = q1 + qcap;                                       // [nw+2] target code planes, raw words from the window's first word
+  uint32_t* q0 = s_cum + (nw + 1) + 1;                            // [-1 .. qcap] query code planes (stored orientation) between two zero words
+  uint32_t* q1 = q0 + qcap + 2;
+  uint32_t* t0 = q1 + qcap + 1;                                   // [nw+2] target code planes, raw words from the window's first word
   uint32_t* t1 = t0 + (nw + 2);
+  PROF_BEGIN(J);
   const OwDesc d = J.ow[o];   // carries the window's and the reads' offsets: no further lookups before the data
   const uint32_t cnt_ops = d.op_cnt;
   const uint32_t* __restrict__ ops = J.ops + d.op_begin;
@@ -227,8 +231,10 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
   for (int i = 0; i < QI; i++) {
     const uint32_t idx = lane + 64u * i;
     if (staged && idx < nqw) { q0[idx] = v0[i]; q1[idx] = v1[i]; }
+    if (staged && i == 0 && lane < 2) { q0[lane ? (int)nqw : -1] = 0; q1[lane ? (int)nqw : -1] = 0; }
     if (idx < nw + 2) { t0[idx] = u0[i]; t1[idx] = u1[i]; }
   }
+  PROF_MARK(J, 0, 0);
   const int32_t sbase = d.strand ? (int32_t)(d.qbeg + d.qlen - 1u) : (int32_t)d.qbeg;   // stored index of alignment-orientation base 0
   const int32_t rel = -(int32_t)(qw0 << 5);
   // code planes of the 32 alignment-orientation query bases qidx .. qidx + 31 (bits of bases outside the region are
@@ -304,6 +310,7 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    PROF_MARK(J, 0, 1);
     {  // rank directory: op starts in front of every bitmap word
       uint32_t carry = 0;
       for (uint32_t bb = 0; bb <= nw; bb += 64) {
@@ -317,6 +324,7 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    PROF_MARK(J, 0, 2);
     // planes of the batch's positions: a lane owns 32 positions, the op covering the first one is a popcount away
     const int32_t Pb1 = min(off + (int32_t)carry_t, (int32_t)d.wlen);
 #pragma unroll
@@ -345,6 +353,7 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
       }
     }
   }
+  PROF_MARK(J, 0, 3);
   const uint32_t t_total = carry_t;
   const bool keep = __ballot(longindel != 0u) == 0ull;
   // accuracy: matches / mismatches over M ops (features.rs:650-665)
@@ -379,6 +388,7 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
       if (wi < nw) { g[wi] = pM[wi_i]; g[nw + wi] = pL[wi_i]; g[2 * nw + wi] = pH[wi_i]; }
     }
   }
+  PROF_MARK(J, 0, 4);
 }
 
 // =====================================================================================================
@@ -391,6 +401,7 @@ __global__ __launch_bounds__(256) void k_win(JobDev J) {
   __shared__ float s_acc[RKCAP];
   __shared__ uint8_t s_keep[RKCAP];
   const uint32_t w = blockIdx.x, tid = threadIdx.x, NT = blockDim.x, nw = J.nw;
+  PROF_BEGIN(J);
   const WinDesc wd = J.win[w];
   const uint32_t n = wd.ow_cnt;
   const uint64_t pmax = J.read_n_words + 1;
@@ -404,16 +415,22 @@ __global__ __launch_bounds__(256) void k_win(JobDev J) {
   SlicedCounters<NB> cnt;
   cnt.clear();
   cnt.add(ColPlanes{vm, tlo, thi, 0u});  // the target column: always a base on these rows
+  PROF_MARK(J, 1, 0);
   uint32_t n_kept = 0;
-  constexpr int UB = 8;   // columns whose loads are in flight together
-  for (uint32_t c0 = 0; c0 < n; c0 += UB) {
+  constexpr int UB = 8;    // columns whose loads are in flight together
+  const uint4* __restrict__ ocol = J.ocol;   // read-only here: uniform addresses -> scalar loads
+  uint32_t match[4 * UB];  // first 32 columns: positions where the column shows the target's base (kept for the tallies)
+#pragma unroll
+  for (int u = 0; u < 4 * UB; u++) match[u] = 0;
+  uint32_t keepmask = 0;   // kept among the first 32 columns
+  auto batch = [&](uint32_t c0, uint32_t* keep_match) {
     uint4 oc[UB];
     uint32_t M[UB], L[UB], H[UB];
 #pragma unroll
     for (int u = 0; u < UB; u++) {
       const uint64_t o = wd.ow_begin + min(c0 + u, n - 1u);
       const uint32_t* __restrict__ g = J.cpl + o * 3 * nw + widx;   // planes of overlaps that were not kept are never written: loaded, ignored
-      oc[u] = J.ocol[o];
+      oc[u] = ocol[o];
       M[u] = g[0]; L[u] = g[nw]; H[u] = g[2 * nw];
     }
 #pragma unroll
@@ -422,10 +439,18 @@ __global__ __launch_bounds__(256) void k_win(JobDev J) {
         n_kept++;
         const int32_t off = (int32_t)oc[u].x;
         const uint32_t inr = mask_range(off - P, off + (int32_t)oc[u].y - P) & vm;
-        cnt.add(ColPlanes{M[u] & inr, L[u] & inr, H[u] & inr, inr & ~M[u]});
+        const uint32_t Mi = M[u] & inr;
+        cnt.add(ColPlanes{Mi, L[u] & inr, H[u] & inr, inr & ~M[u]});
+        if (keep_match) { keep_match[u] = Mi & ~((L[u] ^ tlo) | (H[u] ^ thi)); keepmask |= 1u << ((c0 + u) & 31u); }
       }
     }
-  }
+  };
+  if (n > 0) batch(0, match);
+  if (n > UB) batch(UB, match + UB);
+  if (n > 2 * UB) batch(2 * UB, match + 2 * UB);
+  if (n > 3 * UB) batch(3 * UB, match + 3 * UB);
+  for (uint32_t c0 = 4 * UB; c0 < n; c0 += UB) batch(c0, nullptr);
+  PROF_MARK(J, 1, 1);
   // ---- informative positions: at least two symbols reach the threshold (features.rs:681-722)
   uint32_t sup;
   {
@@ -442,29 +467,43 @@ __global__ __launch_bounds__(256) void k_win(JobDev J) {
   }
   // ---- tallies (features.rs:478-498): every kept column is scored at every informative target position; anything but
   // the target's base ('.', '*', '#', another base) is a mismatch.  Informative positions are rare: only the lanes whose
-  // word holds one go through the columns again.
+  // word holds one take part; the first 32 columns' match masks are still in registers, further columns are read again.
   if (sup) {
     const uint32_t nsup = (uint32_t)__popc(sup);
-    for (uint32_t c0 = 0; c0 < n; c0 += UB) {
-      uint4 oc[UB];
+    uint32_t cls[4 * UB];
+#pragma unroll
+    for (int u = 0; u < 4 * UB; u++) cls[u] = ocol[wd.ow_begin + min((uint32_t)u, n ? n - 1u : 0u)].w;
+#pragma unroll
+    for (int u = 0; u < 4 * UB; u++) {
+      if ((keepmask >> u) & 1u) {
+        const uint32_t nm = (uint32_t)__popc(sup & match[u]);
+        if (nm) atomicAdd(&J.nd[2 * (uint64_t)cls[u]], nm);
+        if (nsup - nm) atomicAdd(&J.nd[2 * (uint64_t)cls[u] + 1], nsup - nm);
+      }
+    }
+    for (uint32_t c0 = 4 * UB; c0 < n; c0 += UB) {
+      uint4 oc2[UB];
       uint32_t M[UB], L[UB], H[UB];
 #pragma unroll
       for (int u = 0; u < UB; u++) {
         const uint64_t o = wd.ow_begin + min(c0 + u, n - 1u);
         const uint32_t* __restrict__ g = J.cpl + o * 3 * nw + widx;
-        oc[u] = J.ocol[o];
+        oc2[u] = ocol[o];
         M[u] = g[0]; L[u] = g[nw]; H[u] = g[2 * nw];
       }
 #pragma unroll
       for (int u = 0; u < UB; u++) {
-        if (c0 + u < n && oc[u].z) {
-          const uint32_t nm = (uint32_t)__popc(sup & M[u] & ~((L[u] ^ tlo) | (H[u] ^ thi)));
-          if (nm) atomicAdd(&J.nd[2 * (uint64_t)oc[u].w], nm);
-          if (nsup - nm) atomicAdd(&J.nd[2 * (uint64_t)oc[u].w + 1], nsup - nm);
+        if (c0 + u < n && oc2[u].z) {
+          const int32_t off = (int32_t)oc2[u].x;
+          const uint32_t inr = mask_range(off - P, off + (int32_t)oc2[u].y - P) & vm;
+          const uint32_t nm = (uint32_t)__popc(sup & M[u] & inr & ~((L[u] ^ tlo) | (H[u] ^ thi)));
+          if (nm) atomicAdd(&J.nd[2 * (uint64_t)oc2[u].w], nm);
+          if (nsup - nm) atomicAdd(&J.nd[2 * (uint64_t)oc2[u].w + 1], nsup - nm);
         }
       }
     }
   }
+  PROF_MARK(J, 1, 2);
   // ---- stable rank of the kept overlaps by descending accuracy: sort_by_key(-acc) (features.rs:386-409)
   const bool in_lds = n <= RKCAP;
   if (in_lds) {
@@ -484,24 +523,30 @@ __global__ __launch_bounds__(256) void k_win(JobDev J) {
     J.slot_ow[wd.ow_begin + rank] = oi;
   }
   if (tid == 0) J.win_nkept[w] = n_kept;
+  PROF_MARK(J, 1, 3);
 }
 
 // =====================================================================================================
 // k_layout — one workgroup per window: selection of the 30 columns, row of every position
 // =====================================================================================================
 constexpr int LY_NT = 256;
+constexpr uint32_t TCAP = 2 * LY_NT;   // tiles per window (8192 positions x 51 rows / 1024 = 408)
 __host__ __device__ inline size_t layout_lds(uint32_t W) { return (size_t)(W + 1) * 4; }
 
 __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
   extern __shared__ __attribute__((aligned(16))) uint32_t ly_smem[];
   uint32_t* s_mi = ly_smem;   // [W+1] max insertion behind every position, then (in place) the row of every position
   __shared__ double s_score[SCAP];
-  __shared__ uint32_t s_sel[32], s_nev[32], s_evoff[32], s_pref[33], s_wave[LY_NT / 64];
+  __shared__ uint32_t s_sel[32], s_nev[32], s_evoff[32], s_pref[33], s_wave[LY_NT / 64], s_maxne;
+  __shared__ uint32_t s_tcnt[TCAP], s_toff[TCAP];   // insertion events per tile of the window, first slot of each tile's list
   const uint32_t w = blockIdx.x, tid = threadIdx.x;
+  PROF_BEGIN(J);
   const WinDesc wd = J.win[w];
   const uint32_t n_kept = J.win_nkept[w];
   const uint32_t win_len = wd.win_len;
   if (tid < 32) s_sel[tid] = NONE;
+  if (tid == 0) s_maxne = 0;
+  for (uint32_t t = tid; t < TCAP; t += LY_NT) s_tcnt[t] = 0;
   for (uint32_t p = tid; p <= win_len; p += LY_NT) s_mi[p] = 0;
   __syncthreads();
   // ---- score n/(n+d)*ln(n+d+1) in f64 (features.rs:505-510); stable descending rank (features.rs:512-513)
@@ -532,6 +577,7 @@ __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
     }
     __syncthreads();
   }
+  PROF_MARK(J, 2, 0);
   // ---- the window's column table: everything the token and quality kernels need to know about a column
   if (tid < 32) {
     CTab t;
@@ -555,42 +601,56 @@ __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
       t.qual_off = d.q_qual_off;
       t.q_woff = d.q_woff;
     }
+    // entry 0 (the target) also carries the window's compact event arrays: first slot (sev / tev), selected events in all
+    const uint32_t nev = tid == 0 ? 0u : t.n_ev;
+    const uint32_t inc = wscan_incl(nev);   // lanes 0..31 of the first wave
+    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 31);
+    if (tid == 0) {
+      t.ev_off = (uint32_t)wd.ev_off;
+      t.n_ev = tot;
+    }
     J.ctab[(uint64_t)w * 32 + tid] = t;
     J.sel_ow[(uint64_t)w * 32 + tid] = s_sel[tid];
-    s_nev[tid] = t.n_ev;
-    s_evoff[tid] = t.ev_off;
+    s_nev[tid] = nev;
+    s_evoff[tid] = tid == 0 ? 0u : t.ev_off;
+    s_pref[tid] = inc - nev;
+    if (tid == 0) { s_pref[32] = tot; s_evoff[0] = t.ev_off; }   // s_evoff[0]: the window's base in sev / tev
+    atomicMax(&s_maxne, nev);
   }
   __syncthreads();
-  if (tid == 0) {
-    uint32_t acc = 0;
-    for (uint32_t c = 0; c < 32; c++) { s_pref[c] = acc; acc += s_nev[c]; }
-    s_pref[32] = acc;
-  }
-  __syncthreads();
-  // ---- max insertion behind every position over the SELECTED overlaps: rows where every selected column is a gap are
-  // dropped (features.rs:531-556), i.e. the final layout is the row map of the selected overlaps alone
-  {
-    const uint32_t n_events = s_pref[32];
-    for (uint32_t e0 = tid; e0 < n_events; e0 += 4 * LY_NT) {
-      uint4 v[4];
+  PROF_MARK(J, 2, 1);
+  // ---- insertion events of the selected columns, 8 threads per column, 8 events per thread in flight (no search for an
+  // event's column).  First use: max insertion behind every position over the SELECTED overlaps — rows where every selected
+  // column is a gap are dropped (features.rs:531-556), i.e. the final layout is the row map of the selected overlaps alone —
+  // and the window's compact event list {position | length << 16, query index | column << 24} for k_rfq.
+  const uint32_t lc = tid >> 3, sub = tid & 7u;
+  const uint32_t ne = s_nev[lc], sevb = s_pref[lc];
+  const uint64_t eo = s_evoff[lc], wbase = s_evoff[0];
+  const uint32_t nbatch = (s_maxne + 63u) / 64u;
+  uint4 v[8];
+  uint32_t hx[8];   // position | length of the event behind it (a later insertion at the same position hides this one's first rows)
+  auto load = [&](uint32_t b) {
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const uint32_t e = min(e0 + u * LY_NT, n_events - 1u);
-        uint32_t lo = 0, hi = 32;   // column of flattened event e: largest c with s_pref[c] <= e
-        while (hi - lo > 1) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (s_pref[mid] <= e) lo = mid; else hi = mid;
-        }
-        v[u] = J.iev[(uint64_t)s_evoff[lo] + (e - s_pref[lo])];
-      }
+    for (int k = 0; k < 8; k++) {
+      const uint32_t i = b * 64u + sub + 8u * k;
+      v[k] = ne ? J.iev[eo + min(i, ne - 1u)] : make_uint4(0, 0, 0, 0);
+      hx[k] = ne ? J.iev[eo + min(i + 1u, ne - 1u)].x : 0u;
+    }
+  };
+  for (uint32_t b = 0; b < nbatch; b++) {
+    load(b);
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const uint32_t p = v[u].x & 0xffffu;
-        if (e0 + u * LY_NT < n_events && p < win_len) atomicMax(&s_mi[p], v[u].w);   // untrimmed length (features.rs:64-79)
+    for (int k = 0; k < 8; k++) {
+      const uint32_t i = b * 64u + sub + 8u * k;
+      if (i < ne) {
+        const uint32_t p = v[k].x & 0xffffu;
+        if (p < win_len) atomicMax(&s_mi[p], v[k].w);   // untrimmed length (features.rs:64-79)
+        J.sev[wbase + sevb + i] = make_uint2(v[k].x, (v[k].y & 0xffffffu) | (lc << 24));
       }
     }
   }
   __syncthreads();
+  PROF_MARK(J, 2, 2);
   // ---- row of every position = exclusive prefix of (1 + max insertion); first position of every chunk of ROWCAP rows
   {
     const uint32_t ch = (win_len + LY_NT - 1) / LY_NT;
@@ -610,7 +670,55 @@ __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
     if (tid == 0) { s_mi[win_len] = Lf; J.win_Lf[w] = Lf; }
   }
   __syncthreads();
+  PROF_MARK(J, 2, 3);
   for (uint32_t p = tid; p <= win_len; p += LY_NT) J.row_of_pos2[wd.pos_off + p] = s_mi[p];
+  // ---- the events once more, now that rows are known: every tile of ROWCAP rows gets the list of the inserted-base runs that
+  // reach into it {position | length << 16, query index, first 16 bases, column | hidden rows << 8} (k_tokens, phase B)
+  const uint32_t tile0 = (uint32_t)wd.col_off, n_t = (s_mi[win_len] + ROWCAP - 1) / ROWCAP;
+  auto each_run = [&](uint32_t b, auto&& fn) {   // fn(event, hidden rows, first tile, last tile) for this thread's events of batch b
+    if (nbatch > 1) load(b);                     // a single batch is still in registers
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t i = b * 64u + sub + 8u * k;
+      if (i >= ne) continue;
+      const uint32_t p = v[k].x & 0xffffu, len = v[k].x >> 16;
+      if (p >= win_len) continue;
+      const uint32_t rp = s_mi[p], room = s_mi[p + 1] - rp - 1u;
+      uint32_t hide = 0;
+      if (i + 1 < ne && (hx[k] & 0xffffu) == p) {
+        hide = hx[k] >> 16;
+        for (uint32_t e2 = i + 2; e2 < ne; e2++) {
+          const uint32_t x3 = J.iev[eo + e2].x;
+          if ((x3 & 0xffffu) != p) break;
+          hide = max(hide, x3 >> 16);
+        }
+      }
+      const uint32_t lenr = min(len, room);
+      if (hide >= lenr) continue;
+      fn(v[k], hide, (rp + 1u + hide) / ROWCAP, (rp + lenr) / ROWCAP);
+    }
+  };
+  for (uint32_t b = 0; b < nbatch; b++)
+    each_run(b, [&](const uint4&, uint32_t, uint32_t t_lo, uint32_t t_hi) {
+      for (uint32_t t = t_lo; t <= t_hi && t < TCAP; t++) atomicAdd(&s_tcnt[t], 1u);
+    });
+  __syncthreads();
+  {
+    uint32_t tot;
+    const uint32_t c0 = s_tcnt[2 * tid], c1 = s_tcnt[2 * tid + 1];
+    const uint32_t ex = blk_scan<LY_NT>(c0 + c1, &tot, s_wave);
+    s_toff[2 * tid] = ex;
+    s_toff[2 * tid + 1] = ex + c0;
+    if (2 * tid < n_t) J.tile_ev[tile0 + 2 * tid] = make_uint2(ex, c0);
+    if (2 * tid + 1 < n_t) J.tile_ev[tile0 + 2 * tid + 1] = make_uint2(ex + c0, c1);
+  }
+  __syncthreads();
+  for (uint32_t b = 0; b < nbatch; b++)
+    each_run(b, [&](const uint4& e, uint32_t hide, uint32_t t_lo, uint32_t t_hi) {
+      for (uint32_t t = t_lo; t <= t_hi && t < TCAP; t++)
+        J.tev[wbase + atomicAdd(&s_toff[t], 1u)] = make_uint4(e.x, e.y, e.z, lc | (hide << 8));
+    });
+  PROF_MARK(J, 2, 4);
 }
 
 // =====================================================================================================
@@ -634,8 +742,9 @@ __global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J) {
   __shared__ uint32_t s_adj[ROWCAP];                                    // per row: inserted A, C, G, T (5 bits each), '*' they replace (bits 20..)
   __shared__ uint32_t s_pl[HERRO_ROWS * 3 * WPAD];                      // [column][plane][word - w_lo]
   __shared__ uint32_t s_rop[ROWCAP + 4];                                // row of positions pa .. pb1
-  __shared__ uint32_t s_pref[33], s_supbits[ROWCAP / 32];
+  __shared__ uint32_t s_supbits[ROWCAP / 32];
   const uint32_t tile = blockIdx.x, tid = threadIdx.x, nw = J.nw;
+  PROF_BEGIN(J);
   // round trip 1: which rows of which window
   const uint32_t w = J.tile_win[tile], r0 = J.tile_r0[tile];
   // round trip 2: the window, this chunk's first position (and the next chunk's), the column table
@@ -645,6 +754,7 @@ __global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J) {
   const uint2 ch0 = J.chdr2[tile];
   const bool last = r0 + ROWCAP >= Lf;
   const uint2 ch1 = J.chdr2[last ? tile : tile + 1];
+  const uint2 tev_h = J.tile_ev[tile];   // the tile's inserted-base runs: first slot (relative to the window's), count
   if (tid < 32) s_ct[tid] = J.ctab[(uint64_t)w * 32 + tid];
   const uint32_t win_len = wd.win_len;
   const uint32_t r1 = min(r0 + ROWCAP, Lf);
@@ -657,6 +767,7 @@ __global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J) {
   s_adj[tid] = 0; s_adj[tid + TK_NT] = 0; s_adj[tid + 2 * TK_NT] = 0; s_adj[tid + 3 * TK_NT] = 0;
   if (tid < ROWCAP / 32) s_supbits[tid] = 0;
   __syncthreads();
+  PROF_MARK(J, 3, 0);
   // round trip 3: rows of the chunk's positions, plane words of the chunk's positions for every column
   {
     const uint32_t npos = pb1 - pa + 1;   // entries pa .. pb1
@@ -692,14 +803,9 @@ __global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J) {
         s_pl[(c * 3 + pi) * WPAD + k] = live ? pv[u] : 0u;
       }
     }
-    if (tid == 0) {
-      uint32_t acc = 0;
-      for (uint32_t c = 0; c < 32; c++) { s_pref[c] = acc; acc += s_ct[c].n_ev; }
-      s_pref[32] = acc;
-    }
   }
   __syncthreads();
-  const uint32_t n_events = s_pref[32];
+  PROF_MARK(J, 3, 1);
   auto rop = [&](uint32_t p) -> uint32_t { return s_rop[p - pa]; };   // p in [pa, pb1]
   // -- A: position (relative to pa) and base-row flag of every row of the chunk, the window's row map
   for (uint32_t p = pa + tid; p <= pb; p += TK_NT) {
@@ -714,6 +820,7 @@ __global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J) {
   }
   for (uint32_t i = nrows + tid; i < nrows16; i += TK_NT) s_rowinfo[i] = (uint16_t)(pb - pa);   // rows past the window's last: unused
   __syncthreads();
+  PROF_MARK(J, 3, 2);
   // -- C1: 16 rows x 1 column per step, four rows per register.  A quad of lanes shares a row segment, each lane takes 8
   // consecutive columns.  Position space -> row space is a byte permute: a base row takes the byte of its position, an
   // insertion row the default of its position ('*' inside the overlap, '.' outside); inserted bases are patched in by B.
@@ -784,62 +891,44 @@ __global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J) {
   }
   __threadfence_block();
   __syncthreads();   // the default tokens are out before the inserted bases go over them
+  PROF_MARK(J, 3, 3);
   // -- B: inserted bases of the selected columns (features.rs:213-229): the token byte over the default, the row's symbol
-  // counts adjusted in LDS.  A later insertion at the same position overwrites an earlier one from its first row on, as the
-  // reference's sequential writes do.
-  for (uint32_t e0 = tid; e0 < n_events; e0 += 4 * TK_NT) {
-    uint4 v[4], v2[4];
-    uint32_t cc[4], ei[4];
+  // counts adjusted in LDS.  The tile's runs were listed by k_layout (a later insertion at the same position overwrites an
+  // earlier one from its first row on, as the reference's sequential writes do: those rows are "hidden").
+  {
+    const uint4* __restrict__ tev = J.tev + s_ct[0].ev_off + tev_h.x;
+    for (uint32_t e0 = tid; e0 < tev_h.y; e0 += 2 * TK_NT) {
+      uint4 ve[2];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const uint32_t e = min(e0 + u * TK_NT, n_events - 1u);
-      uint32_t lo = 0, hi = 32;   // column of flattened event e: largest c with s_pref[c] <= e
-      while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (s_pref[mid] <= e) lo = mid; else hi = mid;
-      }
-      cc[u] = lo;
-      ei[u] = e - s_pref[lo];
-      const uint4* __restrict__ evs = J.iev + s_ct[lo].ev_off;
-      v[u] = evs[ei[u]];
-      v2[u] = evs[min(ei[u] + 1u, s_ct[lo].n_ev - 1u)];
-    }
+      for (int u = 0; u < 2; u++) ve[u] = tev[min(e0 + u * TK_NT, tev_h.y - 1u)];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      if (e0 + u * TK_NT >= n_events) continue;
-      const uint32_t c = cc[u], ne = s_ct[c].n_ev;
-      const uint32_t p = v[u].x & 0xffffu, len = v[u].x >> 16;
-      if (p < pa || p > pb) continue;
-      const uint32_t rp = rop(p), room = rop(p + 1) - rp - 1u;
-      uint32_t hide = 0;   // rows [0, hide) are overwritten by later insertions at the same position
-      if (ei[u] + 1 < ne && (v2[u].x & 0xffffu) == p) {
-        hide = v2[u].x >> 16;
-        const uint4* __restrict__ evs = J.iev + s_ct[c].ev_off;
-        for (uint32_t e2 = ei[u] + 2; e2 < ne; e2++) {
-          const uint4 v3 = evs[e2];
-          if ((v3.x & 0xffffu) != p) break;
-          hide = max(hide, v3.x >> 16);
+      for (int u = 0; u < 2; u++) {
+        if (e0 + u * TK_NT >= tev_h.y) continue;
+        const uint32_t c = ve[u].w & 0xffu, hide = ve[u].w >> 8;
+        const uint32_t p = ve[u].x & 0xffffu, len = ve[u].x >> 16;
+        if (p < pa || p > pb) continue;
+        const uint32_t rp = rop(p), room = rop(p + 1) - rp - 1u;
+        const uint32_t s5 = s_ct[c].tokc & 0xffu;
+        const bool inr = (uint32_t)((int32_t)p - s_ct[c].off) < s_ct[c].t_total;   // the default under it was '*' (counted), not '.'
+        for (uint32_t k = hide; k < len && k < room; k++) {
+          const uint32_t row = rp + 1u + k;
+          if (row < r0 || row >= r1) continue;
+          uint32_t code;
+          if (k < 16u) code = (ve[u].z >> (2u * k)) & 3u;
+          else {   // long insertion: bases beyond the 16 carried by the event come from the read store
+            const int32_t si = s_ct[c].sbase + s_ct[c].sdir * (int32_t)(ve[u].y + k);
+            const uint64_t wi = min(s_ct[c].q_woff + ((uint32_t)si >> 5), pmax);
+            code = ((J.read_p0[wi] >> ((uint32_t)si & 31u)) & 1u) | (((J.read_p1[wi] >> ((uint32_t)si & 31u)) & 1u) << 1);
+            if (s_ct[c].sdir < 0) code ^= 3u;
+          }
+          J.fin_b[wd.fin_off + (uint64_t)c * wd.lub + row] = (uint8_t)(s5 + code);
+          atomicAdd(&s_adj[row - r0], (1u << (5u * code)) + (inr ? 1u << 20 : 0u));
         }
-      }
-      const uint32_t s5 = s_ct[c].tokc & 0xffu;
-      const bool inr = (uint32_t)((int32_t)p - s_ct[c].off) < s_ct[c].t_total;   // the default under it was '*' (counted), not '.'
-      for (uint32_t k = hide; k < len && k < room; k++) {
-        const uint32_t row = rp + 1u + k;
-        if (row < r0 || row >= r1) continue;
-        uint32_t code;
-        if (k < 16u) code = (v[u].z >> (2u * k)) & 3u;
-        else {   // long insertion: bases beyond the 16 carried by the event come from the read store
-          const int32_t si = s_ct[c].sbase + s_ct[c].sdir * (int32_t)(v[u].y + k);
-          const uint64_t wi = min(s_ct[c].q_woff + ((uint32_t)si >> 5), pmax);
-          code = ((J.read_p0[wi] >> ((uint32_t)si & 31u)) & 1u) | (((J.read_p1[wi] >> ((uint32_t)si & 31u)) & 1u) << 1);
-          if (s_ct[c].sdir < 0) code ^= 3u;
-        }
-        J.fin_b[wd.fin_off + (uint64_t)c * wd.lub + row] = (uint8_t)(s5 + code);
-        atomicAdd(&s_adj[row - r0], (1u << (5u * code)) + (inr ? 1u << 20 : 0u));
       }
     }
   }
   __syncthreads();
+  PROF_MARK(J, 3, 4);
   // -- C2: counts of every row over all 31 columns; each lane of the quad finishes 4 rows
   if (seg_live) {
     uint32_t cnt8[5][4];   // per symbol: four registers of four row-bytes
@@ -890,6 +979,7 @@ __global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J) {
     if (supb) atomicOr(&s_supbits[(seg * 16u + cg * 4u) >> 5], supb << ((seg * 16u + cg * 4u) & 31u));
   }
   __syncthreads();
+  PROF_MARK(J, 3, 5);
   // -- D: the chunk's informative positions, in row order (SupportedPos, features.rs:896-900), by the first wave; the window's
   // list is put together by k_supgather
   if (tid < 64) {
@@ -905,6 +995,7 @@ __global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J) {
     }
     if (tid == 63) J.tile_nsup[tile] = inc;
   }
+  PROF_MARK(J, 3, 6);
 }
 
 // =====================================================================================================
@@ -942,68 +1033,94 @@ __global__ __launch_bounds__(64) void k_supgather(JobDev J) {
 constexpr int PQ_NT = 256;
 constexpr uint32_t RFCAP = 1024;   // receptive-field rows per pass
 __host__ __device__ inline size_t quals_lds(uint32_t nw) {
-  return (size_t)(HERRO_ROWS - 1) * nw * 4 + (((size_t)(HERRO_ROWS - 1) * nw * 2 + 15) & ~(size_t)15) + (size_t)QEVCAP * 16;
+  return (size_t)(HERRO_ROWS - 1) * nw * 4 + (((size_t)(HERRO_ROWS - 1) * nw * 2 + 15) & ~(size_t)15) + (size_t)QEVCAP * 8;
 }
 
 // FULL: every cell of the window; otherwise the cells within `half` rows of an informative row (the model's receptive fields).
+// rf_q != null (and 2 * half + 1 <= 8): the receptive fields go out compact, [(sup_off[w] + k) * 31 + column][8] with byte i = row
+// sup_row[k] - half + i — dense stores.  (Single bytes scattered over the window's 146 KB of quality planes made every store a
+// read-modify-write of its own line: 0.6 GB of traffic per 4096 windows for 10 MB of payload.)
 template <bool FULL>
-__global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half) {
+__global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half, const uint64_t* __restrict__ sup_off, uint8_t* __restrict__ rf_q, uint32_t dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pq_smem[];
   const uint32_t nw = J.nw;
   uint32_t* s_M = reinterpret_cast<uint32_t*>(pq_smem);                               // [30][nw] M planes of the selected columns
   uint16_t* s_rk = reinterpret_cast<uint16_t*>(s_M + (size_t)(HERRO_ROWS - 1) * nw);  // [30][nw] M bits in front of the word
-  uint4* s_ev = reinterpret_cast<uint4*>(pq_smem + (size_t)(HERRO_ROWS - 1) * nw * 4 + (((size_t)(HERRO_ROWS - 1) * nw * 2 + 15) & ~(size_t)15));
+  uint2* s_ev = reinterpret_cast<uint2*>(pq_smem + (size_t)(HERRO_ROWS - 1) * nw * 4 + (((size_t)(HERRO_ROWS - 1) * nw * 2 + 15) & ~(size_t)15));
   __shared__ __attribute__((aligned(16))) CTab s_ct[32];
   __shared__ uint32_t s_evl[33];      // first LDS slot of every column's events
   __shared__ uint32_t s_rm[RFCAP];    // row-map entry of each receptive-field row (NONE: outside the window)
   __shared__ uint32_t s_rr[RFCAP];    // its row
   const uint32_t w = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  // round trip 1
   const uint32_t nsup = J.win_nsup[w], Lf = J.win_Lf[w];
-  if (!FULL && !nsup) return;
   const WinDesc wd = J.win[w];
   if (tid < 32) s_ct[tid] = J.ctab[(uint64_t)w * 32 + tid];
+  if (!FULL && !nsup) return;
+  if (dbg & 16u) return;
   __syncthreads();
-  if (tid == 0) {
-    uint32_t acc = 0;
-    for (uint32_t c = 0; c < 32; c++) { s_evl[c] = acc; acc += s_ct[c].n_ev; }
-    s_evl[32] = acc;
+  if (tid < 64) {   // first LDS slot of every column's events
+    const uint32_t ne = (tid >= 1 && tid < 32) ? s_ct[tid].n_ev : 0u;   // entry 0 (the target) carries the window's totals
+    const uint32_t inc = wscan_incl(ne);
+    if (tid < 32) s_evl[tid] = inc - ne;
+    if (tid == 31) s_evl[32] = inc;
   }
-  {  // M planes: all loads of a thread issued together
+  __syncthreads();
+  const uint32_t n_events = s_evl[32];
+  const bool ev_in_lds = n_events <= QEVCAP;
+  const uint32_t span = 2 * half + 1;
+  const uint32_t kper = max(1u, RFCAP / span);   // informative rows per pass
+  // round trip 2: M planes, events, the first pass's informative rows — all loads of a thread issued together
+  {
     const uint32_t items = (HERRO_ROWS - 1) * nw;
-    for (uint32_t it0 = tid; it0 < items; it0 += 8 * PQ_NT) {
-      uint32_t mv[8];
+    constexpr int MI = 16;
+    uint32_t srow = 0;
+    if (!FULL && tid < min(kper, nsup)) srow = J.sup_row[wd.row_off + tid];   // kper <= 256 whenever span >= 4; larger passes reload below
+    constexpr int EI = QEVCAP / PQ_NT;
+    uint2 ev[EI];
+    if (ev_in_lds) {
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
+      for (int u = 0; u < EI; u++) {
+        const uint32_t e = min(tid + u * PQ_NT, n_events ? n_events - 1u : 0u);
+        uint32_t lo = 0, hi = 32;
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_evl[mid] <= e) lo = mid; else hi = mid;
+        }
+        ev[u] = n_events ? *reinterpret_cast<const uint2*>(J.iev + (uint64_t)s_ct[lo].ev_off + (e - s_evl[lo])) : make_uint2(0, 0);
+      }
+    }
+    for (uint32_t it0 = tid; it0 < items; it0 += MI * PQ_NT) {
+      uint32_t mv[MI];
+#pragma unroll
+      for (int u = 0; u < MI; u++) {
         const uint32_t it = min(it0 + u * PQ_NT, items - 1u);
         const uint32_t c = it / nw, wi = it - c * nw;
         const uint32_t o = s_ct[c + 1].ow;
         mv[u] = J.cpl[(o != NONE ? (uint64_t)o : 0ull) * 3 * nw + wi];
       }
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
+      for (int u = 0; u < MI; u++) {
         const uint32_t it = it0 + u * PQ_NT;
         if (it < items) s_M[it] = s_ct[it / nw + 1].ow != NONE ? mv[u] : 0u;
       }
     }
+    if (ev_in_lds) {
+#pragma unroll
+      for (int u = 0; u < EI; u++) if (tid + u * PQ_NT < n_events) s_ev[tid + u * PQ_NT] = ev[u];
+    }
+    if (!FULL && tid < min(kper, nsup)) s_rr[tid] = srow;   // staged through s_rr: rewritten below once the rows are expanded
   }
   __syncthreads();
-  const uint32_t n_events = s_evl[32];
-  const bool ev_in_lds = n_events <= QEVCAP;
-  if (ev_in_lds) {
-    for (uint32_t e0 = tid; e0 < n_events; e0 += 4 * PQ_NT) {
-      uint4 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const uint32_t e = min(e0 + u * PQ_NT, n_events - 1u);
-        uint32_t lo = 0, hi = 32;
-        while (hi - lo > 1) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (s_evl[mid] <= e) lo = mid; else hi = mid;
-        }
-        v[u] = J.iev[(uint64_t)s_ct[lo].ev_off + (e - s_evl[lo])];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) if (e0 + u * PQ_NT < n_events) s_ev[e0 + u * PQ_NT] = v[u];
+  if (dbg & 8u) return;
+  uint32_t pre_rm = NONE, pre_r = 0;   // first pass: row-map entries travel while the rank directories are built
+  const bool pre = !FULL && kper <= PQ_NT && min(kper, nsup) * span <= PQ_NT * 1u;
+  if (pre) {
+    const uint32_t nrows = min(kper, nsup) * span;
+    if (tid < nrows) {
+      const int64_t r = (int64_t)s_rr[tid / span] + (int64_t)(tid % span) - (int64_t)half;
+      pre_r = (uint32_t)r;
+      if (r >= 0 && r < (int64_t)Lf) pre_rm = J.rowmap2[wd.row_off + (uint32_t)r];
     }
   }
   for (uint32_t c = wave; c < HERRO_ROWS - 1; c += PQ_NT / 64) {   // rank directory of every M plane
@@ -1018,22 +1135,25 @@ __global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half) {
   }
   __syncthreads();
 
+  if (dbg & 4u) return;
   const uint64_t tq_off = s_ct[0].qual_off + wd.tstart;
   const uint64_t qmax = J.read_qual_bytes ? J.read_qual_bytes - 1 : 0;
   // address of the quality byte of cell (column c, position p, insertion ordinal j); NONE64: the cell holds no base ('!')
   constexpr uint64_t NONE64 = ~0ull;
-  auto cell_addr = [&](uint32_t c, uint32_t p, uint32_t j) -> uint64_t {
+  auto cell_addr = [&](auto evlds, uint32_t c, uint32_t p, uint32_t j) -> uint64_t {
+    constexpr bool EVL = decltype(evlds)::value;
     if (c == 0) return j == 0 ? min(tq_off + p, qmax) : NONE64;
     const CTab& q = s_ct[c];
     if (q.ow == NONE) return NONE64;
     const uint4* evg = J.iev + q.ev_off;
     const uint32_t el = s_evl[c];
-    auto event = [&](uint32_t i) -> uint4 { return ev_in_lds ? s_ev[el + i] : evg[i]; };
+    auto ev_x = [&](uint32_t i) -> uint32_t { return EVL ? s_ev[el + i].x : evg[i].x; };
+    auto ev_y = [&](uint32_t i) -> uint32_t { return EVL ? s_ev[el + i].y : evg[i].y; };
     auto first_ge = [&](uint32_t bound) -> uint32_t {   // first event with position >= bound
       uint32_t lo = 0, hi = q.n_ev;
       while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
-        if ((event(mid).x & 0xffffu) < bound) lo = mid + 1; else hi = mid;
+        if ((ev_x(mid) & 0xffffu) < bound) lo = mid + 1; else hi = mid;
       }
       return lo;
     };
@@ -1050,17 +1170,17 @@ __global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half) {
       const uint32_t ub = first_ge(p);          // events strictly before p: [0, ub)
       if (ub == 0) qi = rank(p);
       else {
-        const uint4 e = event(ub - 1);
-        qi = e.y + (e.x >> 16) + rank(p) - rank((e.x & 0xffffu) + 1u);
+        const uint32_t ex = ev_x(ub - 1);
+        qi = ev_y(ub - 1) + (ex >> 16) + rank(p) - rank((ex & 0xffffu) + 1u);
       }
     } else {
       uint32_t i = first_ge(p + 1);             // events at positions <= p: [0, i)
       bool found = false;
       qi = 0;
       while (i > 0) {
-        const uint4 e = event(i - 1);
-        if ((e.x & 0xffffu) != p) break;
-        if ((e.x >> 16) >= j) { qi = e.y + j - 1u; found = true; break; }   // the LAST insertion at p that is long enough wrote this row
+        const uint32_t ex = ev_x(i - 1);
+        if ((ex & 0xffffu) != p) break;
+        if ((ex >> 16) >= j) { qi = ev_y(i - 1) + j - 1u; found = true; break; }   // the LAST insertion at p that is long enough wrote this row
         i--;
       }
       if (!found) return NONE64;
@@ -1068,63 +1188,340 @@ __global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half) {
     const int64_t si = (int64_t)q.sbase + (int64_t)q.sdir * (int64_t)qi;
     return min(q.qual_off + (uint64_t)max(si, (int64_t)0), qmax);
   };
-  if (FULL) {
-    const uint64_t total = (uint64_t)Lf * HERRO_ROWS;
-    for (uint64_t idx0 = tid; idx0 < total; idx0 += 4 * PQ_NT) {
-      uint32_t rm[4];
-      uint64_t dst[4], src[4];
-      uint32_t cc[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const uint64_t idx = min(idx0 + (uint64_t)u * PQ_NT, total - 1);
-        cc[u] = (uint32_t)(idx / Lf);
-        const uint32_t r = (uint32_t)(idx - (uint64_t)cc[u] * Lf);
-        rm[u] = J.rowmap2[wd.row_off + r];
-        dst[u] = wd.fin_off + (uint64_t)cc[u] * wd.lub + r;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) src[u] = cell_addr(cc[u], rm[u] & 0xffffu, rm[u] >> 16);
-      uint32_t qv[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) qv[u] = J.read_qual[src[u] == NONE64 ? 0 : src[u]];
-#pragma unroll
-      for (int u = 0; u < 4; u++)
-        if (idx0 + (uint64_t)u * PQ_NT < total) J.fin_q[dst[u]] = (uint8_t)(src[u] == NONE64 ? 33u : qv[u]);
-    }
-  } else {
-    const uint32_t span = 2 * half + 1;
-    const uint32_t kper = max(1u, RFCAP / span);   // informative rows per pass
-    for (uint32_t k0 = 0; k0 < nsup; k0 += kper) {
-      const uint32_t nk = min(kper, nsup - k0), nrows = nk * span;
-      __syncthreads();
-      for (uint32_t i = tid; i < nrows; i += PQ_NT) {
-        const int64_t r = (int64_t)J.sup_row[wd.row_off + k0 + i / span] + (int64_t)(i % span) - (int64_t)half;
-        const bool in = r >= 0 && r < (int64_t)Lf;
-        s_rr[i] = (uint32_t)r;
-        s_rm[i] = in ? J.rowmap2[wd.row_off + (uint32_t)r] : NONE;
-      }
-      __syncthreads();
-      // neighbouring lanes: the rows of one receptive field in one column
-      const uint32_t total = nrows * HERRO_ROWS;
-      for (uint32_t idx0 = tid; idx0 < total; idx0 += 4 * PQ_NT) {
+  auto run = [&](auto evlds) {
+    if (FULL) {
+      const uint64_t total = (uint64_t)Lf * HERRO_ROWS;
+      for (uint64_t idx0 = tid; idx0 < total; idx0 += 4 * PQ_NT) {
+        uint32_t rm[4];
         uint64_t dst[4], src[4];
-        bool live[4];
+        uint32_t cc[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          const uint32_t idx = min(idx0 + u * PQ_NT, total - 1u);
-          const uint32_t k = idx / (span * HERRO_ROWS), rem = idx - k * span * HERRO_ROWS, c = rem / span, dd = rem - c * span;
-          const uint32_t rm = s_rm[k * span + dd];
-          live[u] = idx0 + u * PQ_NT < total && rm != NONE;
-          dst[u] = wd.fin_off + (uint64_t)c * wd.lub + s_rr[k * span + dd];
-          src[u] = rm != NONE ? cell_addr(c, rm & 0xffffu, rm >> 16) : NONE64;
+          const uint64_t idx = min(idx0 + (uint64_t)u * PQ_NT, total - 1);
+          cc[u] = (uint32_t)(idx / Lf);
+          const uint32_t r = (uint32_t)(idx - (uint64_t)cc[u] * Lf);
+          rm[u] = J.rowmap2[wd.row_off + r];
+          dst[u] = wd.fin_off + (uint64_t)cc[u] * wd.lub + r;
         }
+#pragma unroll
+        for (int u = 0; u < 4; u++) src[u] = cell_addr(evlds, cc[u], rm[u] & 0xffffu, rm[u] >> 16);
         uint32_t qv[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) qv[u] = J.read_qual[src[u] == NONE64 ? 0 : src[u]];
 #pragma unroll
         for (int u = 0; u < 4; u++)
-          if (live[u]) J.fin_q[dst[u]] = (uint8_t)(src[u] == NONE64 ? 33u : qv[u]);
+          if (idx0 + (uint64_t)u * PQ_NT < total) J.fin_q[dst[u]] = (uint8_t)(src[u] == NONE64 ? 33u : qv[u]);
       }
+    } else {
+      for (uint32_t k0 = 0; k0 < nsup; k0 += kper) {
+        const uint32_t nk = min(kper, nsup - k0), nrows = nk * span;
+        if (k0 == 0 && pre) {
+          if (tid < nrows) { s_rr[tid] = pre_r; s_rm[tid] = pre_rm; }
+        } else {
+          __syncthreads();
+          for (uint32_t i = tid; i < nrows; i += PQ_NT) {
+            const int64_t r = (int64_t)J.sup_row[wd.row_off + k0 + i / span] + (int64_t)(i % span) - (int64_t)half;
+            const bool in = r >= 0 && r < (int64_t)Lf;
+            s_rr[i] = (uint32_t)r;
+            s_rm[i] = in ? J.rowmap2[wd.row_off + (uint32_t)r] : NONE;
+          }
+        }
+        __syncthreads();
+        // a batch of cells per thread: addresses first (LDS only), then all quality bytes together, then the stores.
+        // Compact: consecutive lanes = consecutive bytes of the 8-byte slots (informative row, column); planes: the 31 columns of a row.
+        const bool compact = rf_q != nullptr && span <= 8;
+        const uint32_t total = compact ? nk * HERRO_ROWS * 8 : nrows * HERRO_ROWS;
+        const uint64_t slot0 = compact ? (sup_off[w] + k0) * HERRO_ROWS * 8 : 0;
+        uint8_t* __restrict__ outp = compact ? rf_q : J.fin_q;
+        constexpr int CB = 10;
+        for (uint32_t idx0 = tid; idx0 < total; idx0 += CB * PQ_NT) {
+          uint64_t dst[CB], src[CB];
+          bool live[CB];
+#pragma unroll
+          for (int u = 0; u < CB; u++) {
+            const uint32_t idx = min(idx0 + u * PQ_NT, total - 1u);
+            uint32_t slot, c;
+            if (compact) {
+              const uint32_t kc = idx >> 3, dd = idx & 7u, k = kc / HERRO_ROWS;
+              c = kc - k * HERRO_ROWS;
+              slot = min(k * span + dd, nrows - 1u);
+              live[u] = dd < span;
+              dst[u] = slot0 + idx;
+            } else {
+              slot = idx / HERRO_ROWS;
+              c = idx - slot * HERRO_ROWS;
+              live[u] = true;
+              dst[u] = wd.fin_off + (uint64_t)c * wd.lub + s_rr[slot];
+            }
+            const uint32_t rm = s_rm[slot];
+            live[u] = live[u] && idx0 + u * PQ_NT < total && rm != NONE;
+            src[u] = (live[u] && !(dbg & 1u)) ? cell_addr(evlds, c, rm & 0xffffu, rm >> 16) : NONE64;
+          }
+          uint32_t qv[CB];
+#pragma unroll
+          for (int u = 0; u < CB; u++) qv[u] = J.read_qual[(src[u] == NONE64 || (dbg & 2u)) ? 0 : src[u]];
+#pragma unroll
+          for (int u = 0; u < CB; u++)
+            if (live[u]) outp[dst[u]] = (uint8_t)(src[u] == NONE64 ? 33u : qv[u]);
+        }
+      }
+    }
+  };
+  if (ev_in_lds) run(std::true_type{}); else run(std::false_type{});
+}
+
+// =====================================================================================================
+// k_rfq — one workgroup per window: the qualities of the model's receptive fields, compact
+// =====================================================================================================
+// Output [(sup_off[w] + k) * 31 + column][8]: byte i = quality of row sup_row[k] - half + i of that column (span = 2 half + 1 <= 8).
+// One thread per (informative row, column) slot walks the slot's rows in order: one directory lookup finds the insertion
+// events in front of the first row, the rank in the M plane and the event cursor then advance with the rows.  Dense 8-byte
+// stores.  (Bytes scattered over the window's quality planes made every store a read-modify-write of its own line; a binary
+// search per cell over events left in global memory cost six dependent round trips per cell.)
+constexpr int RQ_NT = 256;
+constexpr uint32_t RQ_EVCAP = 1536;   // insertion events staged in LDS (more: read from global memory)
+constexpr uint32_t RQ_ROWS = 512;     // receptive-field rows per pass
+__host__ __device__ inline uint32_t rfq_es_bytes(uint32_t nw) { return ((HERRO_ROWS - 1) * (nw + 1) * 2 + 15u) & ~15u; }
+__host__ __device__ inline size_t rfq_lds(uint32_t nw) {
+  return (size_t)(HERRO_ROWS - 1) * nw * 4 + (((size_t)(HERRO_ROWS - 1) * nw * 2 + 15) & ~(size_t)15) + rfq_es_bytes(nw) + (size_t)RQ_EVCAP * 8;
+}
+
+__global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const uint64_t* __restrict__ sup_off, uint8_t* __restrict__ rf_q) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rq_smem[];
+  const uint32_t nw = J.nw;
+  uint32_t* s_M = reinterpret_cast<uint32_t*>(rq_smem);                               // [30][nw] M planes of the selected columns
+  uint16_t* s_rk = reinterpret_cast<uint16_t*>(s_M + (size_t)(HERRO_ROWS - 1) * nw);  // [30][nw] M bits in front of the word
+  unsigned char* p_es = rq_smem + (size_t)(HERRO_ROWS - 1) * nw * 4 + (((size_t)(HERRO_ROWS - 1) * nw * 2 + 15) & ~(size_t)15);
+  uint16_t* s_es = reinterpret_cast<uint16_t*>(p_es);                                 // [30][nw+1] events in front of the word
+  uint2* s_ev = reinterpret_cast<uint2*>(p_es + rfq_es_bytes(nw));                    // {position | length << 16, inserted bases up to and including this event}
+  __shared__ __attribute__((aligned(16))) CTab s_ct[32];
+  __shared__ uint32_t s_evl[33];
+  __shared__ uint32_t s_rm[RQ_ROWS];   // row-map entry of each receptive-field row (NONE: outside the window)
+  const uint32_t w = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  PROF_BEGIN(J);
+  // round trip 1
+  const uint32_t nsup = J.win_nsup[w], Lf = J.win_Lf[w];
+  const WinDesc wd = J.win[w];
+  if (tid < 32) s_ct[tid] = J.ctab[(uint64_t)w * 32 + tid];
+  if (!nsup) return;
+  for (uint32_t i = tid; i < rfq_es_bytes(nw) / 4; i += RQ_NT) reinterpret_cast<uint32_t*>(p_es)[i] = 0;
+  __syncthreads();
+  PROF_MARK(J, 5, 0);
+  if (tid < 64) {   // first LDS slot of every column's events
+    const uint32_t ne = (tid >= 1 && tid < 32) ? s_ct[tid].n_ev : 0u;   // entry 0 (the target) carries the window's totals
+    const uint32_t inc = wscan_incl(ne);
+    if (tid < 32) s_evl[tid] = inc - ne;
+    if (tid == 31) s_evl[32] = inc;
+  }
+  __syncthreads();
+  const uint32_t n_events = s_evl[32];
+  const bool ev_in_lds = n_events <= RQ_EVCAP;
+  const uint32_t span = 2 * half + 1;
+  const uint32_t kper = RQ_ROWS / span;   // informative rows per pass
+  const uint2* __restrict__ sev = J.sev + s_ct[0].ev_off;   // the window's selected events, column-major (k_layout)
+  // round trip 2: M planes, events, the first pass's informative rows — all loads of a thread issued together
+  uint32_t srow[2] = {0, 0};
+  {
+    const uint32_t nk0 = min(kper, nsup);
+#pragma unroll
+    for (int u = 0; u < 2; u++) srow[u] = J.sup_row[wd.row_off + min(tid + u * RQ_NT, nk0 * span - 1u) / span];   // informative row of receptive-field row tid + u * NT
+    constexpr int EI = RQ_EVCAP / RQ_NT;
+    uint2 ev[EI];
+    if (ev_in_lds) {
+#pragma unroll
+      for (int u = 0; u < EI; u++) ev[u] = n_events ? sev[min(tid + u * RQ_NT, n_events - 1u)] : make_uint2(0, 0);
+    }
+    // thread -> (column, word) once; the columns advance by a fixed step
+    const uint32_t cpp = max(1u, RQ_NT / nw), c_first = tid / nw, wi = tid - c_first * nw;
+    constexpr int MI = 16;
+    for (uint32_t cb = 0; cb < HERRO_ROWS - 1; cb += MI * cpp) {
+      uint32_t mv[MI];
+#pragma unroll
+      for (int u = 0; u < MI; u++) {
+        const uint32_t c = min(cb + u * cpp + c_first, (uint32_t)HERRO_ROWS - 2u);
+        const uint32_t o = s_ct[c + 1].ow;
+        mv[u] = J.cpl[(o != NONE ? (uint64_t)o : 0ull) * 3 * nw + wi];
+      }
+#pragma unroll
+      for (int u = 0; u < MI; u++) {
+        const uint32_t c = cb + u * cpp + c_first;
+        if (c_first < cpp && c < HERRO_ROWS - 1) s_M[c * nw + wi] = s_ct[c + 1].ow != NONE ? mv[u] : 0u;
+      }
+    }
+    if (ev_in_lds) {
+#pragma unroll
+      for (int u = 0; u < EI; u++) if (tid + u * RQ_NT < n_events) s_ev[tid + u * RQ_NT] = ev[u];
+    }
+  }
+  PROF_MARK(J, 5, 1);
+  // round trip 3 (in flight while the directories are built): row-map entries of the first pass's receptive-field rows
+  uint32_t rm0[2];
+  {
+    const uint32_t nrows0 = min(kper, nsup) * span;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const uint32_t i = tid + u * RQ_NT;
+      const int64_t r = (int64_t)srow[u] + (int64_t)(i % span) - (int64_t)half;
+      rm0[u] = (i < nrows0 && r >= 0 && r < (int64_t)Lf) ? J.rowmap2[wd.row_off + (uint32_t)r] : NONE;
+    }
+  }
+  __syncthreads();
+  for (uint32_t c = wave; c < HERRO_ROWS - 1; c += RQ_NT / 64) {   // rank directory of every M plane
+    uint32_t carry = 0;
+    for (uint32_t b = 0; b < nw; b += 64) {
+      const uint32_t i = b + lane;
+      const uint32_t pc = i < nw ? (uint32_t)__popc(s_M[c * nw + i]) : 0u;
+      const uint32_t inc = wscan_incl(pc);
+      if (i < nw) s_rk[c * nw + i] = (uint16_t)(carry + inc - pc);
+      carry += wlast(inc);
+    }
+  }
+  __syncthreads();
+  PROF_MARK(J, 5, 2);
+  auto Mword = [&](uint32_t c, uint32_t wi) -> uint32_t { return s_M[(c - 1) * nw + wi]; };
+  auto rank = [&](uint32_t c, uint32_t pp) -> uint32_t {   // query bases of column c aligned to positions < pp
+    const uint32_t* M = s_M + (size_t)(c - 1) * nw;
+    const uint16_t* rk = s_rk + (size_t)(c - 1) * nw;
+    if (pp >= (nw << 5)) return (uint32_t)rk[nw - 1] + (uint32_t)__popc(M[nw - 1]);
+    return (uint32_t)rk[pp >> 5] + (uint32_t)__popc(M[pp >> 5] & ((1u << (pp & 31u)) - 1u));
+  };
+  // event i of column c: {position | length << 16, inserted bases of the column up to and including it (| column << 24 in LDS)}
+  auto event = [&](uint32_t c, uint32_t i) -> uint2 {
+    if (ev_in_lds) { const uint2 v = s_ev[s_evl[c] + i]; return make_uint2(v.x, v.y & 0xffffffu); }
+    const uint2 v = sev[s_evl[c] + i];
+    return make_uint2(v.x, (v.y & 0xffffffu) + (v.x >> 16) - rank(c, (v.x & 0xffffu) + 1u));
+  };
+  // directory of the events in front of every 32 positions (events are sorted by position within a column), then, in LDS,
+  // query index -> inserted bases through the event (query index = bases aligned in front of it + bases inserted in front of it)
+  for (uint32_t e = tid; e < n_events; e += RQ_NT) {
+    const uint2 v = ev_in_lds ? s_ev[e] : sev[e];
+    const uint32_t c = v.y >> 24, i = e - s_evl[c], ne = s_ct[c].n_ev;
+    const uint32_t xp = i ? (ev_in_lds ? s_ev[e - 1].x : sev[e - 1].x) : 0u;
+    const uint32_t we = min((v.x & 0xffffu) >> 5, nw - 1u);
+    const int32_t wp = i ? (int32_t)min((xp & 0xffffu) >> 5, nw - 1u) : -1;
+    uint16_t* es = s_es + (size_t)(c - 1) * (nw + 1);
+    for (int32_t wi = wp + 1; wi <= (int32_t)we; wi++) es[wi] = (uint16_t)i;
+    if (i + 1 == ne) for (uint32_t wi = we + 1; wi <= nw; wi++) es[wi] = (uint16_t)ne;
+  }
+  __syncthreads();
+  if (ev_in_lds) {
+    for (uint32_t e = tid; e < n_events; e += RQ_NT) {
+      const uint2 v = s_ev[e];
+      const uint32_t c = v.y >> 24;
+      s_ev[e].y = (((v.y & 0xffffffu) + (v.x >> 16) - rank(c, (v.x & 0xffffu) + 1u)) & 0xffffffu) | (c << 24);
+    }
+  }
+  const uint64_t tq_off = s_ct[0].qual_off + wd.tstart;
+  const uint64_t qmax = J.read_qual_bytes ? J.read_qual_bytes - 1 : 0;
+  constexpr uint64_t NONE64 = ~0ull;
+  PROF_MARK(J, 5, 3);
+  for (uint32_t k0 = 0; k0 < nsup; k0 += kper) {
+    const uint32_t nk = min(kper, nsup - k0), nrows = nk * span;
+    __syncthreads();
+    if (k0 == 0) {
+#pragma unroll
+      for (int u = 0; u < 2; u++) if (tid + u * RQ_NT < nrows) s_rm[tid + u * RQ_NT] = rm0[u];
+    } else {
+      for (uint32_t i = tid; i < nrows; i += RQ_NT) {
+        const int64_t r = (int64_t)J.sup_row[wd.row_off + k0 + i / span] + (int64_t)(i % span) - (int64_t)half;
+        s_rm[i] = (r >= 0 && r < (int64_t)Lf) ? J.rowmap2[wd.row_off + (uint32_t)r] : NONE;
+      }
+    }
+    __syncthreads();
+    PROF_MARK(J, 5, 4);
+    // two slots per thread and iteration: addresses of both first (LDS only), then the quality bytes together, then the stores
+    const uint32_t nslots = nk * HERRO_ROWS;
+    for (uint32_t s0 = tid; s0 < nslots; s0 += 2 * RQ_NT) {
+      uint64_t addr[2][8];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+#pragma unroll
+        for (int d = 0; d < 8; d++) addr[u][d] = NONE64;
+        const uint32_t sl = s0 + u * RQ_NT;
+        if (sl >= nslots) continue;
+        const uint32_t k = sl / HERRO_ROWS, c = sl - k * HERRO_ROWS;
+        const uint32_t* rmp = s_rm + k * span;
+        if (c == 0) {
+#pragma unroll
+          for (int d = 0; d < 8; d++) {
+            if ((uint32_t)d >= span) break;
+            const uint32_t rm = rmp[d];
+            if (rm != NONE && (rm >> 16) == 0) addr[u][d] = min(tq_off + (rm & 0xffffu), qmax);
+          }
+          continue;
+        }
+        const CTab& q = s_ct[c];
+        if (q.ow == NONE) continue;
+        const uint32_t n_ev = q.n_ev;
+        bool started = false;
+        uint32_t cur = 0, rkp = 0, e = 0, mw = 0, mwi = NONE, cum_prev = 0;
+        uint2 ecur = make_uint2(0xffffffffu, 0);   // event e (position 0xffff: none left)
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+          if ((uint32_t)d >= span) break;
+          const uint32_t rm = rmp[d];
+          if (rm == NONE) continue;
+          const uint32_t p = rm & 0xffffu, j = rm >> 16;
+          if (!started) {
+            started = true;
+            cur = p;
+            rkp = rank(c, p);
+            e = s_es[(size_t)(c - 1) * (nw + 1) + (p >> 5)];
+            if (e) cum_prev = event(c, e - 1).y;
+            if (e < n_ev) ecur = event(c, e);
+          }
+          while (cur <= p) {   // rkp: bases aligned in front of cur
+            if ((cur >> 5) != mwi) { mwi = cur >> 5; mw = Mword(c, mwi); }
+            if (cur == p) break;
+            rkp += (mw >> (cur & 31u)) & 1u;
+            cur++;
+          }
+          const uint32_t mbit = (mw >> (p & 31u)) & 1u;
+          while ((ecur.x & 0xffffu) < p) {   // events in front of p: [0, e)
+            cum_prev = ecur.y;
+            e++;
+            ecur = e < n_ev ? event(c, e) : make_uint2(0xffffffffu, 0);
+          }
+          uint32_t qi = NONE;
+          if (j == 0) {
+            if (p - (uint32_t)q.off < q.t_total && mbit) qi = rkp + cum_prev;
+          } else if ((ecur.x & 0xffffu) == p) {   // the LAST insertion behind p that is long enough wrote this row
+            uint2 own = make_uint2(0, 0);
+            bool have = false;
+            uint2 x = ecur;
+            for (uint32_t i = e;;) {
+              if ((x.x >> 16) >= j) { own = x; have = true; }
+              if (++i >= n_ev) break;
+              x = event(c, i);
+              if ((x.x & 0xffffu) != p) break;
+            }
+            if (have) qi = rkp + mbit + own.y - (own.x >> 16) + j - 1u;
+          }
+          if (qi != NONE) {
+            const int64_t si = (int64_t)q.sbase + (int64_t)q.sdir * (int64_t)qi;
+            addr[u][d] = min(q.qual_off + (uint64_t)max(si, (int64_t)0), qmax);
+          }
+        }
+      }
+      PROF_MARK(J, 5, 5);
+      uint32_t qv[2][8];
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int d = 0; d < 8; d++) qv[u][d] = J.read_qual[addr[u][d] == NONE64 ? 0 : addr[u][d]];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const uint32_t sl = s0 + u * RQ_NT;
+        if (sl >= nslots) continue;
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          lo |= (addr[u][d] == NONE64 ? 33u : qv[u][d]) << (8 * d);
+          hi |= (addr[u][d + 4] == NONE64 ? 33u : qv[u][d + 4]) << (8 * d);
+        }
+        *reinterpret_cast<uint2*>(rf_q + ((sup_off[w] + k0) * HERRO_ROWS + sl) * 8) = make_uint2(lo, hi);
+      }
+      PROF_MARK(J, 5, 6);
     }
   }
 }
@@ -1189,23 +1586,37 @@ void launch_consensus(const JobDev& J, const uint64_t* sup_off, const float* bas
   KT_END(tm, st);
 }
 
-void launch_rf_quals(const JobDev& J, uint32_t half, hipStream_t st, KernelTimer* tm) {
+void launch_rf_quals(const JobDev& J, uint32_t half, const uint64_t* sup_off, uint8_t* rf_q, hipStream_t st, KernelTimer* tm) {
   if (!J.n_win) return;
   KT_BEGIN(tm, "rf_quals", st);
+  if (rf_q && 2 * half + 1 <= 8) {
+    pileup_opt_in_lds(reinterpret_cast<const void*>(k_rfq), 128 * 1024);
+    hipLaunchKernelGGL(k_rfq, dim3(J.n_win), dim3(RQ_NT), rfq_lds(J.nw), st, J, half, sup_off, rf_q);
+    KT_END(tm, st);
+    return;
+  }
   pileup_opt_in_lds(reinterpret_cast<const void*>(k_quals<false>), 96 * 1024);   // windows of 8192: 62 KB dynamic + 10 KB static
-  hipLaunchKernelGGL(k_quals<false>, dim3(J.n_win), dim3(PQ_NT), quals_lds(J.nw), st, J, half);
+  hipLaunchKernelGGL(k_quals<false>, dim3(J.n_win), dim3(PQ_NT), quals_lds(J.nw), st, J, half, sup_off, rf_q, [] { const char* e = getenv("HERRO_QDBG"); return e ? (uint32_t)atoi(e) : 0u; }());
   KT_END(tm, st);
 }
 
 void launch_full_quals(const JobDev& J, hipStream_t st) {
   if (!J.n_win) return;
   pileup_opt_in_lds(reinterpret_cast<const void*>(k_quals<true>), 96 * 1024);
-  hipLaunchKernelGGL(k_quals<true>, dim3(J.n_win), dim3(PQ_NT), quals_lds(J.nw), st, J, 0u);
+  hipLaunchKernelGGL(k_quals<true>, dim3(J.n_win), dim3(PQ_NT), quals_lds(J.nw), st, J, 0u, (const uint64_t*)nullptr, (uint8_t*)nullptr, 0u);
 }
 
 template <int NB>
 static void launch_win(const JobDev& J, hipStream_t st) {
   hipLaunchKernelGGL(k_win<NB>, dim3(J.n_win), dim3(J.nw <= 128 ? 128 : 256), 0, st, J);
+}
+
+// HERRO_TRACE=1: name every pileup launch on stderr and wait for it (which kernel faulted)
+static void trace_point(const char* name, hipStream_t st) {
+  static const bool on = [] { const char* e = getenv("HERRO_TRACE"); return e && atoi(e); }();
+  if (!on) return;
+  const hipError_t e = hipStreamSynchronize(st);
+  fprintf(stderr, "TRACE %s done: %s\n", name, hipGetErrorString(e));
 }
 
 void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm) {
@@ -1214,6 +1625,7 @@ void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm) {
     KT_BEGIN(tm, "cols", st);
     hipLaunchKernelGGL(k_cols, dim3((J.n_ow + CA_NW - 1) / CA_NW), dim3(CA_NT), (size_t)CA_NW * cols_lds_words(J.nw) * 4, st, J);
     KT_END(tm, st);
+  trace_point("cols", st);
   }
   KT_BEGIN(tm, "win", st);
   if (J.n_cls) (void)hipMemsetAsync(J.nd, 0, (size_t)J.n_cls * 8, st);   // match / mismatch tallies start from zero
@@ -1228,15 +1640,19 @@ void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm) {
     else launch_win<14>(J, st);
   }
   KT_END(tm, st);
+  trace_point("win", st);
   KT_BEGIN(tm, "layout", st);
   hipLaunchKernelGGL(k_layout, dim3(J.n_win), dim3(LY_NT), layout_lds(J.window_size), st, J);
   KT_END(tm, st);
+  trace_point("layout", st);
   KT_BEGIN(tm, "tokens", st);
   if (J.n_tiles) hipLaunchKernelGGL(k_tokens, dim3(J.n_tiles), dim3(TK_NT), 0, st, J);
   KT_END(tm, st);
+  trace_point("tokens", st);
   KT_BEGIN(tm, "supgather", st);
   hipLaunchKernelGGL(k_supgather, dim3(J.n_win), dim3(64), 0, st, J);
   KT_END(tm, st);
+  trace_point("supgather", st);
 }
 
 }  // namespace herro

@@ -63,6 +63,7 @@ struct WinDesc {
   uint64_t fin_off;   // byte offset of this window's [31, lub] final planes
   uint64_t row_off;   // element offset of this window's lub-sized u32 row scratch
   uint64_t pos_off;   // element offset of this window's (window_size+1)-sized u32 position scratch
+  uint64_t ev_off;    // first slot of this window's compact insertion-event arrays (JobDev::sev / tev); room: its overlaps' ops + 2 each
 };
 
 // Effective length of op k of a slice with cnt ops (the reference decides "first"/"last" by the
