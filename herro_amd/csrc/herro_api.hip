@@ -824,12 +824,11 @@ void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* aln
   std::vector<HostOw> hows;
   std::unordered_map<uint32_t, uint32_t> cls_of_name;  // name class -> accumulator slot
   std::unordered_map<uint32_t, uint32_t> seen_qid;
-  // Alignments the library cannot process do not fail the job any more: they are left out and counted
-  // (herro_job_skipped).  Two kinds: what parse_paf itself would have dropped before extract_features ever saw it
-  // (self overlaps, a second alignment of a (query, target) pair — overlaps.rs:175-185), and CIGARs minimap2 never
-  // emits that the kernels' op tables do not model (a window slice starting with an insertion — the reference panics
-  // or writes into the previous position —, consecutive insertion ops).  Inputs on which the reference PANICS still
-  // fail the call: the reference would have aborted the run there (Cargo.toml:18).
+  // Alignments parse_paf itself would have dropped before extract_features ever saw them (self overlaps, a second
+  // alignment of a (query, target) pair — overlaps.rs:175-185) are left out and counted (herro_job_skipped).  Everything
+  // else the reference processes is processed — consecutive insertion ops, an alignment that starts inside a window with
+  // an insertion, any number of overlaps per window.  Inputs on which the reference PANICS fail the call: the reference
+  // would have aborted the run there (Cargo.toml:18).
   auto skip = [&](uint32_t a, const char* why) {
     if (!out.n_skipped++) out.first_skip = "target rid " + std::to_string(rid) + ", alignment " + std::to_string(a) + " (qid " + std::to_string(alns[a].qid) + "): " + why;
   };
@@ -854,7 +853,7 @@ void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* aln
       const CigIn& ci = ds->in[g0 + a];
       const CigOut& co = ds->out[g0 + a];
       op_base = ci.op_off;
-      if (co.flags) {   // rare: malformed text (the message comes from here), consecutive insertions (their positions), more cuts than the coordinates allow
+      if (co.flags & ~(uint32_t)CIG_INS_PAIR) {   // rare: malformed text (the message comes from here), more cuts than the coordinates allow
         spare_ops.resize((size_t)al.cigar_len / 2 + 1);
         if (!scan_cigar(al.cigar, al.cigar_len, al.tstart, W, spare_ops.data(), cs, be)) return fail(be.code, be.msg);
         if (co.flags & CIG_MALFORMED)   // legal text the kernel does not read (lengths padded to 11+ digits): its ops go up from here
@@ -877,25 +876,10 @@ void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* aln
     }
     hows.clear();
     if (!window_cuts(cs, al, W, n_windows, hows, be)) return fail(be.code, be.msg);
-    bool unsupported = false;
-    for (size_t k = 0; k < hows.size() && !unsupported; k++)
-      unsupported = hows[k].op_hi > hows[k].op_lo && (op_type(hows[k].op_first) == OP_I || cs.ins_pair_in(hows[k].op_lo, hows[k].op_hi));
-    if (!ds) out.ops.resize((size_t)op_base + (hows.empty() || unsupported ? 0u : cs.n_ops));
-    if (unsupported) { skip(a, "a window's CIGAR slice starts with an insertion, or consecutive insertion ops (never produced by minimap2)"); continue; }
+    if (!ds) out.ops.resize((size_t)op_base + (hows.empty() ? 0u : cs.n_ops));
     for (auto& h : hows) tmp.push_back(Tmp{h, op_base, a});
     const uint32_t nc = ctx->name_class[al.qid];
     if (!cls_of_name.count(nc)) cls_of_name[nc] = out.n_cls++;
-  }
-  {  // a window with more overlaps than the kernels' 12-bit symbol counters hold: the target keeps its windows, without overlaps
-    std::vector<uint32_t> per_win(n_windows, 0);
-    bool over = false;
-    for (auto& x : tmp) over |= ++per_win[x.h.win] > 4000;
-    if (over) {
-      out.failed = true;
-      out.n_skipped += (uint32_t)seen_qid.size();
-      if (out.first_skip.empty()) out.first_skip = "target rid " + std::to_string(rid) + ": more than 4000 overlaps in one window";
-      tmp.clear(); out.ops.clear(); out.n_cls = 0;
-    }
   }
   std::vector<uint32_t> cnt(n_windows + 1, 0);
   for (auto& x : tmp) cnt[x.h.win + 1]++;
@@ -934,8 +918,10 @@ void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* aln
     // ---- validate what the reference would assert / index (features.rs:585-679, 110-237)
     if (x.h.op_hi <= x.h.op_lo) return fail(HERRO_E_REFERENCE_PANIC, "empty cigar slice");
     if (d.tstart < win_start) return fail(HERRO_E_REFERENCE_PANIC, "overlap starts before its window (usize underflow)");
-    if (op_type(x.h.op_first) == OP_I)
-      return fail(HERRO_E_UNSUPPORTED, "cigar slice starts with an insertion (leading or consecutive I ops; the reference panics or writes into the previous position)");
+    // a slice may start with an insertion (an alignment that begins inside the window with I ops): its bases go behind the position in
+    // front of the overlap's first (features.rs:219-228) — unless there is none: max_ins[tpos - 1] with tpos == 0 panics (features.rs:77)
+    if (op_type(x.h.op_first) == OP_I && d.tstart == win_start)
+      return fail(HERRO_E_REFERENCE_PANIC, "insertion in front of the window's first position (max_ins[tpos - 1], attempt to subtract with overflow)");
     // target / query bases the TRIMMED slice consumes, from the prefix sums of the parse: the slice's first op loses
     // start_off bases, its last op counts end_off bases (effective-op-length rule, features.rs:82-90); the insertion
     // total stays untrimmed (get_max_ins, features.rs:64-79).  The slice never starts with I (checked per alignment).

@@ -400,7 +400,10 @@ template <int NB>
 __global__ __launch_bounds__(256) void k_win(JobDev J) {
   __shared__ float s_acc[RKCAP];
   __shared__ uint8_t s_keep[RKCAP];
+  __shared__ uint32_t s_nm[32], s_ns;   // first 32 columns: matches at informative positions; informative positions of the window
   const uint32_t w = blockIdx.x, tid = threadIdx.x, NT = blockDim.x, nw = J.nw;
+  if (tid < 32) s_nm[tid] = 0;
+  if (tid == 0) s_ns = 0;
   PROF_BEGIN(J);
   const WinDesc wd = J.win[w];
   const uint32_t n = wd.ow_cnt;
@@ -470,15 +473,12 @@ __global__ __launch_bounds__(256) void k_win(JobDev J) {
   // word holds one take part; the first 32 columns' match masks are still in registers, further columns are read again.
   if (sup) {
     const uint32_t nsup = (uint32_t)__popc(sup);
-    uint32_t cls[4 * UB];
-#pragma unroll
-    for (int u = 0; u < 4 * UB; u++) cls[u] = ocol[wd.ow_begin + min((uint32_t)u, n ? n - 1u : 0u)].w;
+    atomicAdd(&s_ns, nsup);
 #pragma unroll
     for (int u = 0; u < 4 * UB; u++) {
       if ((keepmask >> u) & 1u) {
         const uint32_t nm = (uint32_t)__popc(sup & match[u]);
-        if (nm) atomicAdd(&J.nd[2 * (uint64_t)cls[u]], nm);
-        if (nsup - nm) atomicAdd(&J.nd[2 * (uint64_t)cls[u] + 1], nsup - nm);
+        if (nm) atomicAdd(&s_nm[u], nm);   // in LDS first: one pair of global atomics per column and window, not per lane
       }
     }
     for (uint32_t c0 = 4 * UB; c0 < n; c0 += UB) {
@@ -506,9 +506,13 @@ __global__ __launch_bounds__(256) void k_win(JobDev J) {
   PROF_MARK(J, 1, 2);
   // ---- stable rank of the kept overlaps by descending accuracy: sort_by_key(-acc) (features.rs:386-409)
   const bool in_lds = n <= RKCAP;
-  if (in_lds) {
+  if (in_lds)
     for (uint32_t i = tid; i < n; i += NT) { s_acc[i] = J.ow_acc[wd.ow_begin + i]; s_keep[i] = J.ow_keep[wd.ow_begin + i]; }
-    __syncthreads();
+  __syncthreads();
+  if (tid < 32 && tid < n && ((keepmask >> tid) & 1u) && s_ns) {   // keepmask is uniform
+    const uint32_t cls = ocol[wd.ow_begin + tid].w, nm = s_nm[tid], ns = s_ns;
+    if (nm) atomicAdd(&J.nd[2 * (uint64_t)cls], nm);
+    if (ns - nm) atomicAdd(&J.nd[2 * (uint64_t)cls + 1], ns - nm);
   }
   for (uint32_t i = tid; i < n; i += NT) {
     const uint32_t oi = wd.ow_begin + i;
@@ -774,13 +778,14 @@ __global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J) {
     uint32_t rv[5];
 #pragma unroll
     for (int u = 0; u < 5; u++) rv[u] = J.row_of_pos2[wd.pos_off + pa + min(tid + u * TK_NT, npos - 1u)];
-    constexpr int PI = 12;   // 30 columns x 3 planes x <= 34 words / 256 threads
+    constexpr int PI = 12;   // 30 columns x 3 planes x 34 words / 256 threads
+    constexpr uint32_t WST = 34;   // words staged per plane: a chunk spans <= 1025 positions (constant: the index arithmetic folds to multiplies)
     uint32_t pv[PI];
-    const uint32_t items = (HERRO_ROWS - 1) * 3 * wcnt;
+    constexpr uint32_t items = (HERRO_ROWS - 1) * 3 * WST;
 #pragma unroll
     for (int u = 0; u < PI; u++) {
       const uint32_t it = min(tid + u * TK_NT, items - 1u);
-      const uint32_t cp = it / wcnt, k = it - cp * wcnt, c = 1 + cp / 3, pi = cp - (c - 1) * 3;
+      const uint32_t cp = it / WST, k = it - cp * WST, c = 1 + cp / 3, pi = cp - (c - 1) * 3;
       const uint32_t o = s_ct[c].ow;
       const uint32_t wi = min(w_lo + k, nw - 1u);
       pv[u] = J.cpl[(o != NONE ? (uint64_t)o : 0ull) * 3 * nw + pi * nw + wi];
@@ -798,7 +803,7 @@ __global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J) {
     for (int u = 0; u < PI; u++) {
       const uint32_t it = tid + u * TK_NT;
       if (it < items) {
-        const uint32_t cp = it / wcnt, k = it - cp * wcnt, c = 1 + cp / 3, pi = cp - (c - 1) * 3;
+        const uint32_t cp = it / WST, k = it - cp * WST, c = 1 + cp / 3, pi = cp - (c - 1) * 3;
         const bool live = s_ct[c].ow != NONE && w_lo + k < nw;
         s_pl[(c * 3 + pi) * WPAD + k] = live ? pv[u] : 0u;
       }

@@ -37,6 +37,99 @@ def test_features_bit_exact(name):
     job.close()
 
 
+def _with_cigars(sb, new):
+    """SynthBatch with some alignments replaced: new = {alignment index: (row of 9 or None, cigar bytes)}."""
+    import dataclasses
+    cigs = [sb.cigar(a) for a in range(len(sb.aln))]
+    aln = sb.aln.copy()
+    for a, (row, cg) in new.items():
+        cigs[a] = cg
+        if row is not None:
+            aln[a, :9] = row
+    off = np.zeros(len(cigs), np.uint64)
+    o = 0
+    for a, cg in enumerate(cigs):
+        off[a] = o
+        aln[a, 9] = len(cg)
+        o += len(cg)
+    return dataclasses.replace(sb, aln=aln, cig=np.frombuffer(b"".join(cigs), np.uint8).copy(), cig_off=off)
+
+
+def test_consecutive_and_leading_insertions():
+    """CIGARs minimap2 never writes but the reference processes (features.rs:213-229): consecutive insertion ops (the later
+    one overwrites the earlier one's rows from the first) and an alignment that starts inside a window with an insertion
+    (its bases land behind the position in front of the overlap)."""
+    import re
+    W = 256
+    sb = synth.generate(3, 1100, 14, seed=77, flank_min=30, flank_max=60, p_ins=0.04, p_del=0.02)
+    new, n_pairs, n_lead = {}, 0, 0
+    for a in range(len(sb.aln)):
+        cg = sb.cigar(a).decode()
+        row = [int(x) for x in sb.aln[a, :9]]
+        kind = a % 4
+        if kind in (0, 1, 2):   # split insertions of length >= 2 (>= 3) into two (three) consecutive ops
+            def split(m, kind=kind):
+                n = int(m.group(1))
+                if kind == 0 and n >= 2: return f"1I{n - 1}I"          # the second, longer one hides the first completely
+                if kind == 1 and n >= 2: return f"{n - 1}I1I"          # the second hides only the first row
+                if kind == 2 and n >= 3: return f"1I1I{n - 2}I"
+                return m.group(0)
+            cg2 = re.sub(r"(\d+)I", split, cg)
+            if cg2 != cg:
+                new[a] = (None, cg2.encode()); n_pairs += 1
+        else:                   # start 5 bases into the first window, with a 2-base insertion in front
+            m = re.match(r"(\d+)M", cg)
+            if m and int(m.group(1)) >= 8 and row[7] % W == 0:
+                lead = int(m.group(1))
+                row2 = list(row)
+                row2[7] += 5                                   # tstart
+                if row[4] == 0: row2[2] += 3                   # forward: 5 bases cut, 2 inserted bases kept -> qstart + 3
+                else: row2[3] -= 3                             # reverse: the alignment's start is the query's end
+                new[a] = (row2, (f"2I{lead - 5}M" + cg[m.end():]).encode()); n_lead += 1
+    # an insertion split at a window boundary leaves its second half at the head of the next window's slice, where the
+    # reference panics (max_ins[tpos - 1], tpos == 0): such candidates are dropped here (the oracle says which) ...
+    tgt_of = np.searchsorted(sb.tgt_aln_off, np.arange(len(sb.aln)), side="right") - 1
+    kept, panicking = {}, []
+    for a, m in new.items():
+        trial = _with_cigars(sb, {**kept, a: m})
+        try:
+            rid, rows, cigs = O.target_alignments(trial, int(tgt_of[a]))
+            O.store_from_synth(trial).extract_features(rid, rows, cigs, W)
+            kept[a] = m
+        except O.OracleError:
+            panicking.append(a)
+    n_pairs = sum(1 for a in kept if kept[a][0] is None)
+    n_lead = len(kept) - n_pairs
+    assert n_pairs >= 10 and n_lead >= 1, (n_pairs, n_lead, len(panicking))
+    sb2 = _with_cigars(sb, kept)
+    c = G.ctx()
+    G.load_synth(c, sb2)
+    store = O.store_from_synth(sb2)
+    job = api.job_from_synth(c, sb2, W)
+    assert job.skipped() == (0, 0)
+    job.featurize()
+    assert G.compare_features(job, sb2, store, W) > 0
+    job.close()
+    for a in panicking[:3]:   # ... and refused by the library like every input the reference panics on
+        bad = _with_cigars(sb, {a: new[a]})
+        with pytest.raises(api.HerroError) as e:
+            api.job_from_synth(c, bad, W, targets=[int(tgt_of[a])])
+        assert e.value.code == -3, str(e.value)
+
+
+def test_thousands_of_overlaps_in_one_window():
+    """features.rs:376-409 ranks any number of overlaps: 4200 in one window (threshold of pass 1 = 420 columns)."""
+    sb = synth.generate(1, 128, 4200, seed=31, flank_min=4, flank_max=10)
+    c = G.ctx()
+    G.load_synth(c, sb)
+    store = O.store_from_synth(sb)
+    job = api.job_from_synth(c, sb, 64)
+    job.featurize()
+    assert job.info(0).n_overlaps > 4000
+    G.compare_features(job, sb, store, 64)
+    job.close()
+
+
 def test_duplicate_read_names_share_ratio():
     # the reference keys haplotype ratios by read *name* (features.rs:494): two reads with the same id
     sb = synth.generate(1, 1024, 10, seed=99, flank_min=30, flank_max=60)
