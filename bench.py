@@ -17,9 +17,11 @@ reads, run the model, decode the corrected bases on the device.  `value` counts 
   repeat_ms_per_step   three further passes of the same K steps (spread; `value` is always the first timed pass);
   cpu_baseline  the reference algorithm on the host cores (oracle feature generation + PyTorch-CPU twin), N = 1 only;
   self_check    windows of a timed job compared with the oracle after the timing (features bit-exact, FASTA identical).
-Multi-GPU: the path shards by target read with no data-path collective; `--scaling weak` (default) gives every rank its
-own batches, `--scaling strong` shards ONE fixed set of `--windows` windows over the ranks (rank 0 prepares the work,
-scatters it and gathers the corrected reads — herro_amd/shard.py).
+  strong        after the weak measurement, ONE fixed job of --strong-windows windows through the sharded data path (rank 0
+                ingests, the window work is scattered, the corrected reads are gathered: herro_amd/shard.py), with ranks_seen.
+Multi-GPU: the path shards by target read.  `value` is the weak figure (every rank its own batches; the process group only
+carries the barrier and the max-over-ranks time); the `strong` object in the same line times the scatter / gather path of
+north_star on a fixed job; `--scaling strong` prints that path as a line of its own.
 """
 from __future__ import annotations
 
@@ -146,6 +148,9 @@ def main():
                          "reference's concurrent feature / inference threads per device (lib.rs:154-200)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--windows", type=int, default=0, help="--scaling strong: total windows of the fixed job (default steps * batch)")
+    ap.add_argument("--strong-windows", type=int, default=32768,
+                    help="size of the fixed job of the 'strong' leg that follows the weak measurement (the sharded data path: rank 0 ingests, "
+                         "scatter / gather; BASELINE configs[3] uses 100000 — its read set takes ~30 GB of host memory); 0: skip")
     ap.add_argument("--settle", type=float, default=0.2, help="seconds of untimed steps on top of --warmup before the timed pass")
     ap.add_argument("--repeats", type=int, default=3, help="further timed passes of the same K steps after the measured one (spread only)")
     ap.add_argument("--min-jobs", type=int, default=1,
@@ -522,11 +527,23 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(synth.SEED + 2)
-        print(json.dumps(out))
     for j in [j for js in jobs for j in js] + ([rem_job] if rem_job else []):
         j.close()
     for c in ctxs:
         c.close()
+    # ---- the sharded data path on ONE fixed job (every rank takes part; figures on rank 0, same JSON line)
+    if args.strong_windows > 0:
+        from herro_amd import shard
+        try:
+            strong = shard.strong_leg(args, rank, world, local, args.strong_windows, model_path=path)
+        except Exception as e:   # never lose the measured line to the extra leg
+            strong = {"error": repr(e)}
+        if rank == 0:
+            out["strong"] = strong
+            if isinstance(strong, dict) and "windows_per_s" in strong and out.get("end_to_end"):
+                strong["vs_end_to_end"] = strong["windows_per_s"] / (out["end_to_end"]["windows_per_s"] or 1.0)
+    if rank == 0:
+        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 

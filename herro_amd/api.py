@@ -20,7 +20,7 @@ EXPORTS = [
     "herro_encode_2bit", "herro_decode_2bit", "herro_set_reads", "herro_set_reads_packed", "herro_load_model",
     "herro_set_precision", "herro_job_create", "herro_job_free", "herro_job_n_windows", "herro_job_skipped", "herro_job_featurize",
     "herro_job_infer", "herro_job_consensus", "herro_job_consensus_fetch", "herro_job_window_info", "herro_job_window_copy", "herro_job_window_logits",
-    "herro_job_consensus_fasta", "herro_model_forward", "herro_timing_enable", "herro_timing_reset",
+    "herro_job_consensus_fasta", "herro_job_fasta", "herro_model_forward", "herro_timing_enable", "herro_timing_reset",
     "herro_timing_get", "herro_job_stats", "herro_debug_extract_windows",
     "herro_paf_parse", "herro_oec_read", "herro_paf_n_targets", "herro_paf_target_ids", "herro_paf_aln_off",
     "herro_paf_alignments", "herro_paf_free", "herro_debug_host_ctx", "herro_debug_job_array",
@@ -81,6 +81,8 @@ def lib():
         L.herro_job_window_logits.argtypes = [vp, u32, vp, vp]
         L.herro_job_consensus_fasta.restype = C.c_int64
         L.herro_job_consensus_fasta.argtypes = [vp, u32, C.c_char_p, C.c_char_p, vp, u64]
+        L.herro_job_fasta.restype = C.c_int64
+        L.herro_job_fasta.argtypes = [vp, vp, vp, vp, u64, vp]
         L.herro_model_forward.argtypes = [vp, u32, u32, vp, vp, vp, vp, vp, vp]
         L.herro_timing_enable.argtypes = [vp, i32]
         L.herro_timing_reset.argtypes = [vp]
@@ -334,6 +336,22 @@ class Job:
         if n < 0:
             self.ctx._chk(int(n))
         return C.string_at(out, n).decode()   # (out.raw would copy the whole 16 MB buffer per call)
+
+    def fasta(self, read_ids, with_ends: bool = False):
+        """FASTA records of every target of the job, target order, as bytes (herro_job_fasta: one C call, text assembled by
+        the library's thread pool).  read_ids: one str/bytes per target.  with_ends: also the end offset of every target's records."""
+        n = len(read_ids)
+        arr = (C.c_char_p * max(n, 1))(*[r if isinstance(r, bytes) else r.encode() for r in read_ids])
+        need = self._l.herro_job_fasta(self.h, arr, None, None, 0, None)
+        if need < 0:
+            self.ctx._chk(int(need))
+        out = C.create_string_buffer(max(int(need), 1))
+        ends = np.zeros(max(n, 1), np.uint64)
+        got = self._l.herro_job_fasta(self.h, arr, None, out, int(need), ends.ctypes.data)
+        if got < 0:
+            self.ctx._chk(int(got))
+        text = C.string_at(out, got)
+        return (text, ends[:n]) if with_ends else text
 
     def stats(self) -> dict[str, int]:
         o = np.zeros(6, np.uint64)

@@ -1628,6 +1628,37 @@ int herro_job_consensus_fetch(herro_job* job, uint64_t* n_bases) {
   return HERRO_OK;
 }
 
+// FASTA records of target t from the device consensus (corrected bases of every window on the host already): windows are
+// concatenated, the read is split where a window has fewer than two alignments (consensus.rs:90-111, lib.rs:282-317).
+static void fasta_from_device_consensus(const herro_job* job, uint32_t t, const char* id, const char* desc, std::string& fa) {
+  const uint32_t w0 = job->tgt_win_off[t], w1 = job->tgt_win_off[t + 1];
+  int64_t st = -1, en = -1;   // first..last window with n_alns > 1 (consensus.rs:90-101)
+  for (uint32_t w = w0; w < w1; w++)
+    if (std::min<uint32_t>(job->h_nkept[w], 30) > 1) { if (st < 0) st = w; en = w + 1; }
+  if (st < 0) return;
+  // segments: maximal runs of corrected windows; empty segments are dropped like empty strings in the reference
+  std::vector<std::pair<uint32_t, uint32_t>> segs;   // [first window, one past last)
+  uint32_t run0 = (uint32_t)st;
+  uint64_t run_len = 0;
+  for (uint32_t w = (uint32_t)st; w < (uint32_t)en; w++) {
+    if (std::min<uint32_t>(job->h_nkept[w], 30) < 2) {
+      if (run_len) segs.emplace_back(run0, w);
+      run0 = w + 1; run_len = 0;
+      continue;
+    }
+    run_len += job->h_cons_len[w];
+  }
+  if (run_len) segs.emplace_back(run0, (uint32_t)en);
+  for (size_t i = 0; i < segs.size(); i++) {
+    fa += ">"; fa += id;
+    if (segs.size() == 1) fa += " "; else { fa += ":"; fa += std::to_string(i); fa += " "; }
+    if (desc) fa += desc;
+    fa += "\n";
+    for (uint32_t w = segs[i].first; w < segs[i].second; w++) fa.append((const char*)job->h_cons_seq + job->win[w].row_off, job->h_cons_len[w]);
+    fa += "\n";
+  }
+}
+
 // consensus.rs:86-227 + lib.rs:282-317 on the host, from device results.
 int64_t herro_job_consensus_fasta(herro_job* job, uint32_t t, const char* id, const char* desc, char* out,
                                   uint64_t cap) {
@@ -1649,21 +1680,8 @@ int64_t herro_job_consensus_fasta(herro_job* job, uint32_t t, const char* id, co
   std::string cur;
   if (job->consensus_done) {  // device consensus: concatenate the windows' corrected bases
     if ((rc = consensus_to_host(job))) return rc;
-    for (uint32_t w = (uint32_t)st; w < (uint32_t)en; w++) {
-      if (std::min<uint32_t>(job->h_nkept[w], 30) < 2) {
-        if (!cur.empty()) { seqs.push_back(cur); cur.clear(); }
-        continue;
-      }
-      cur.append((const char*)job->h_cons_seq + job->win[w].row_off, job->h_cons_len[w]);
-    }
-    if (!cur.empty()) seqs.push_back(cur);
     std::string fa;
-    for (size_t i = 0; i < seqs.size(); i++) {
-      fa += ">"; fa += id;
-      if (seqs.size() == 1) fa += " "; else fa += ":" + std::to_string(i) + " ";
-      if (desc) fa += desc;
-      fa += "\n"; fa += seqs[i]; fa += "\n";
-    }
+    fasta_from_device_consensus(job, t, id, desc, fa);
     if (fa.size() > cap) { ctx->err = "output buffer too small"; return HERRO_E_INVALID; }
     std::memcpy(out, fa.data(), fa.size());
     return (int64_t)fa.size();
@@ -1732,6 +1750,32 @@ int64_t herro_job_consensus_fasta(herro_job* job, uint32_t t, const char* id, co
   if (fa.size() > cap) { ctx->err = "output buffer too small"; return HERRO_E_INVALID; }
   std::memcpy(out, fa.data(), fa.size());
   return (int64_t)fa.size();
+}
+
+int64_t herro_job_fasta(herro_job* job, const char* const* ids, const char* const* descs, char* out, uint64_t cap,
+                        uint64_t* rec_end) {
+  if (!job || (job->n_targets && !ids)) return HERRO_E_INVALID;
+  herro_ctx* ctx = job->ctx;
+  if (!job->consensus_done) { ctx->err = "herro_job_consensus has not run"; return HERRO_E_STATE; }
+  int rc = job_sync(job);
+  if (rc) return rc;
+  (void)hipSetDevice(ctx->device);
+  if ((rc = consensus_to_host(job))) return rc;
+  const uint32_t nt = job->n_targets;
+  std::vector<std::string> recs(nt);   // per target, built by the pool (only text assembly is left on the host)
+  host_pool(ctx).run((nt + 63) / 64, [&](uint32_t b) {
+    for (uint32_t t = b * 64; t < std::min(nt, (b + 1) * 64); t++) {
+      if (!ids[t]) continue;
+      fasta_from_device_consensus(job, t, ids[t], descs ? descs[t] : nullptr, recs[t]);
+    }
+  });
+  uint64_t tot = 0;
+  for (uint32_t t = 0; t < nt; t++) { tot += recs[t].size(); if (rec_end) rec_end[t] = tot; }
+  if (!out) return (int64_t)tot;
+  if (tot > cap) { ctx->err = "output buffer too small (" + std::to_string(tot) + " bytes needed)"; return HERRO_E_INVALID; }
+  uint64_t o = 0;
+  for (uint32_t t = 0; t < nt; t++) { std::memcpy(out + o, recs[t].data(), recs[t].size()); o += recs[t].size(); }
+  return (int64_t)tot;
 }
 
 // ---- stand-alone model entry (inference.rs:147-175) ----------------------------------------------

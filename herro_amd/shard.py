@@ -4,9 +4,14 @@ The independent unit of feature generation is the TARGET READ (the haplotype re-
 windows of a read, reference features.rs:462-500; consensus needs all windows of a read on one worker,
 consensus.rs:249).  The reference runs one replica per `-d` device pulling reads from one shared queue
 (lib.rs:154-200) and never communicates between devices.  Here: one process per GPU; the read store is
-replicated; target reads are partitioned statically, balanced by window count (longest first); there is
-NO data-path collective.  torch.distributed is used only to agree on the partition's totals and to
-gather small result summaries (corrected bases per read are written by the rank that owns the read).
+replicated (one broadcast per data set); target reads are partitioned statically, balanced by window count
+(longest first).  Two modes:
+  * weak scaling (bench.py default): every rank generates / owns its own batches; torch.distributed only carries the
+    barrier and the max-over-ranks time — no data-path collective;
+  * the sharded data path of BASELINE.json's north_star (`correct_sharded`, bench.py's "strong" leg): rank 0 ingests,
+    the window work is SCATTERED (sizes by one small collective, payloads by grouped point-to-point sends — RCCL has no
+    scatterv), every rank corrects its shard with several jobs in flight, the corrected reads are GATHERED to rank 0 the
+    same way.  Nothing is reduced anywhere.
 """
 from __future__ import annotations
 
@@ -196,10 +201,50 @@ def broadcast_reads(sb, group=None):
     return tuple(out)
 
 
+def pack_records(rids, ends, text) -> np.ndarray:
+    """One u8 message: the FASTA records of a set of targets — their read ids, the end offset of every target's records in
+    `text`, the text.  No per-record Python objects anywhere on the result path."""
+    rids = np.ascontiguousarray(rids, np.uint32)
+    ends = np.ascontiguousarray(ends, np.uint64)
+    text = np.frombuffer(text, np.uint8) if isinstance(text, (bytes, bytearray, memoryview)) else np.ascontiguousarray(text, np.uint8)
+    hdr = np.array([len(rids), len(text)], np.uint64)
+    return np.concatenate([hdr.view(np.uint8), ends.view(np.uint8), rids.view(np.uint8), text])
+
+
+def unpack_records(buf):
+    buf = np.frombuffer(buf, np.uint8) if isinstance(buf, (bytes, bytearray, memoryview)) else np.ascontiguousarray(buf, np.uint8)
+    if len(buf) < 16:
+        return np.zeros(0, np.uint32), np.zeros(0, np.uint64), np.zeros(0, np.uint8)
+    n, nb = (int(x) for x in buf[:16].view(np.uint64))
+    o = 16
+    ends = buf[o:o + 8 * n].view(np.uint64); o += 8 * n
+    rids = buf[o:o + 4 * n].view(np.uint32); o += 4 * n
+    return rids, ends, buf[o:o + nb]
+
+
+def merge_records(parts):
+    """Concatenate (rids, ends, text) triples (ends rebased)."""
+    parts = [p for p in parts if len(p[0])]
+    if not parts:
+        return np.zeros(0, np.uint32), np.zeros(0, np.uint64), np.zeros(0, np.uint8)
+    base = np.cumsum([0] + [len(p[2]) for p in parts[:-1]]).astype(np.uint64)
+    return (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] + b for p, b in zip(parts, base)]),
+            np.concatenate([np.frombuffer(p[2], np.uint8) if isinstance(p[2], (bytes, bytearray)) else p[2] for p in parts]))
+
+
+def sorted_fasta(rids, ends, text) -> bytes:
+    """The records ordered by read id (the reference writes them in completion order, lib.rs:267-291: compare as sorted sets)."""
+    text = bytes(text) if not isinstance(text, bytes) else text
+    starts = np.concatenate([[0], ends[:-1]]).astype(np.int64) if len(ends) else np.zeros(0, np.int64)
+    order = np.argsort(np.asarray(rids, np.int64), kind="stable")
+    return b"".join(text[int(starts[i]):int(ends[i])] for i in order)
+
+
 def correct_sharded(sb, n_windows_per_target, correct_fn, group=None):
     """The whole multi-GPU data path for one set of targets.  Rank 0 passes `sb` (targets + alignments) and the windows per
-    target; other ranks pass None.  correct_fn(rids, aln_off, rows, cig_off, cig) -> list of (rid, fasta bytes) runs on every
-    rank over its shard.  Returns (on rank 0) the FASTA records of all targets sorted by read id, and this rank's shard size."""
+    target; other ranks pass None.  correct_fn(rids, aln_off, rows, cig_off, cig) -> (rids, ends, text): the FASTA records of
+    its targets (any order), runs on every rank over its shard.  Returns (on rank 0; None elsewhere) the (rids, ends, text)
+    of all targets in arrival order — sorted_fasta() orders them by read id — and this rank's shard size."""
     dist = _dist()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -209,47 +254,70 @@ def correct_sharded(sb, n_windows_per_target, correct_fn, group=None):
         msgs = [shard_work(sb, p) for p in parts]
     mine = scatter_bytes(msgs, group) if world > 1 else msgs[0]
     rids, aln_off, rows, cig_off, cig = unpack_work(mine)
-    recs = correct_fn(rids, aln_off, rows, cig_off, cig)
-    blob = b"".join(int(r).to_bytes(4, "little") + len(f).to_bytes(8, "little") + f for r, f in recs)
-    gathered = gather_bytes(blob, group) if world > 1 else [blob]
+    rec = correct_fn(rids, aln_off, rows, cig_off, cig) if len(rids) else (np.zeros(0, np.uint32), np.zeros(0, np.uint64), b"")
+    if world == 1:
+        return merge_records([rec]), len(rids)
+    gathered = gather_bytes(pack_records(*rec).tobytes(), group)
     if rank != 0:
         return None, len(rids)
-    out = []
-    for g in gathered:
-        o = 0
-        while o < len(g):
-            r = int.from_bytes(g[o:o + 4], "little"); ln = int.from_bytes(g[o + 4:o + 12], "little")
-            out.append((r, g[o + 12:o + 12 + ln])); o += 12 + ln
-    out.sort(key=lambda x: x[0])
-    return b"".join(f for _, f in out), len(rids)
+    return merge_records([unpack_records(g) for g in gathered]), len(rids)
 
 
-def hip_corrector(ctx, window_size: int, batch: int, read_name, group_targets: int = 1024):
-    """correct_fn for correct_sharded on the HIP path: jobs of at most `group_targets` targets, cross-read batches of
-    `batch` windows, device consensus, FASTA text per target."""
+def hip_corrector(ctxs, window_size: int, batch: int, read_name, group_targets: int = 1024):
+    """correct_fn for correct_sharded on the HIP path: jobs of at most `group_targets` targets, cross-read batches of `batch`
+    windows, device consensus, one herro_job_fasta call per job.  `ctxs`: one or more contexts of this rank's GPU; each gets a
+    feeder thread that keeps two jobs in flight (herro_job_create of job k+1 runs on the host while the GPU works on job k),
+    like the reference's feature threads ahead of its inference thread (lib.rs:159-187)."""
+    import threading
+    if not isinstance(ctxs, (list, tuple)):
+        ctxs = [ctxs]
+
     def fn(rids, aln_off, rows, cig_off, cig):
-        out = []
-        for t0 in range(0, len(rids), group_targets):
-            t1 = min(t0 + group_targets, len(rids))
-            a0, a1 = int(aln_off[t0]), int(aln_off[t1])
-            job = ctx.create_job(rids[t0:t1], rows[a0:a1], aln_off[t0:t1 + 1] - aln_off[t0], None, window_size,
-                                 cig_blob=cig, cig_off=cig_off[a0:a1])
-            job.featurize()
+        groups = [(t0, min(t0 + group_targets, len(rids))) for t0 in range(0, len(rids), group_targets)]
+        out = [None] * len(groups)
+        err = []
+
+        def finish(g, job):
+            t0, t1 = groups[g]
             job.infer(batch, 1)
             job.consensus()
             job.consensus_fetch()
-            for k in range(t1 - t0):
-                out.append((int(rids[t0 + k]), job.consensus_fasta(k, read_name(int(rids[t0 + k]))).encode()))
+            text, ends = job.fasta([read_name(int(r)) for r in rids[t0:t1]], with_ends=True)
+            out[g] = (rids[t0:t1], ends, text)
             job.close()
-        return out
+
+        def feeder(k):
+            try:
+                ctx, prev = ctxs[k], None
+                for g in range(k, len(groups), len(ctxs)):
+                    t0, t1 = groups[g]
+                    a0, a1 = int(aln_off[t0]), int(aln_off[t1])
+                    job = ctx.create_job(rids[t0:t1], rows[a0:a1], aln_off[t0:t1 + 1] - aln_off[t0], None, window_size,
+                                         cig_blob=cig, cig_off=cig_off[a0:a1])
+                    job.featurize()
+                    if prev is not None:
+                        finish(*prev)
+                    prev = (g, job)
+                if prev is not None:
+                    finish(*prev)
+            except Exception as e:   # surfaced by the caller: a thread must not die silently
+                err.append(e)
+        th = [threading.Thread(target=feeder, args=(k,)) for k in range(min(len(ctxs), max(1, len(groups))))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if err:
+            raise err[0]
+        return merge_records([o for o in out if o is not None])
     return fn
 
 
-def bench_strong(args, rank: int, world: int, local: int):
-    """bench.py --scaling strong: ONE fixed set of windows (BASELINE configs[3]) sharded over the ranks; rank 0 ingests,
-    scatters the work, gathers the corrected reads and holds the FASTA.  Timed: scatter -> job creation -> featurize ->
-    infer -> consensus -> D2H -> gather, i.e. the whole multi-GPU data path (max over ranks)."""
-    import json
+def strong_leg(args, rank: int, world: int, local: int, n_windows: int, n_ctx: int = 3, model_path: str | None = None) -> dict | None:
+    """ONE fixed set of `n_windows` synthetic windows (BASELINE configs[3]) sharded over the ranks: rank 0 ingests, scatters the
+    work, every rank corrects its shard (n_ctx contexts = feeder threads per GPU, two jobs in flight each), the corrected reads
+    are gathered to rank 0.  Timed: scatter -> herro_job_create -> featurize -> infer -> consensus -> D2H -> FASTA text ->
+    gather, i.e. the whole multi-GPU data path, host work included (max over ranks).  Returns the figures on rank 0."""
     import os
     import time
     import torch
@@ -257,49 +325,71 @@ def bench_strong(args, rank: int, world: int, local: int):
     from herro_amd import api, model_io, synth
     W, n_ovl, wpt = 4096, 32, 4
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    n_windows = args.windows or args.steps * args.batch
     n_t = max(world, n_windows // wpt)
-    path, _ = model_io.default_model_file(os.path.join(root, "tests", "_cache"))
+    path = model_path or model_io.default_model_file(os.path.join(root, "tests", "_cache"))[0]
     sb = synth.generate_parallel(n_t, wpt * W, n_ovl, seed=synth.SEED + 3) if rank == 0 else None
     seq, qual, off = broadcast_reads(sb) if world > 1 else (sb.seq, sb.qual, sb.off)
-    ctx = api.Context(local)
-    ctx.load_model(path)
-    ctx.set_precision(args.precision)
-    ctx.set_reads(seq, qual, off)
-    fn = hip_corrector(ctx, W, args.batch, lambda rid: f"read{rid}", group_targets=max(1, args.group * args.batch // wpt))
+    ctxs = []
+    for _ in range(max(1, n_ctx)):
+        c = api.Context(local)
+        c.load_model(path)
+        c.set_precision(args.precision)
+        c.set_reads(seq, qual, off)
+        ctxs.append(c)
+    fn = hip_corrector(ctxs, W, args.batch, lambda rid: f"read{rid}", group_targets=max(1, args.group * args.batch // wpt))
     nw = np.full(n_t, wpt, np.int64) if rank == 0 else None
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-    for _ in range(1 if args.warmup else 0):        # one untimed pass over the same fixed job
+    if args.warmup:                                  # one untimed pass over the same fixed job (arenas, clocks)
         correct_sharded(sb, nw, fn)
     sync()
     t0 = time.perf_counter()
-    fasta, n_mine = correct_sharded(sb, nw, fn)
-    ctx.synchronize()
+    rec, n_mine = correct_sharded(sb, nw, fn)
+    for c in ctxs:
+        c.synchronize()
     el = time.perf_counter() - t0
     sync()
+    seen = world
     if world > 1:
         tt = torch.tensor([el], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
+        one = torch.ones(1, device="cuda", dtype=torch.int64)
+        dist.all_reduce(one)
+        seen = int(one.item())
+    for c in ctxs:
+        c.close()
+    if rank != 0:
+        return None
+    rids, ends, text = rec
+    n_rec = int(np.count_nonzero(np.asarray(text) == ord(">")))
+    return {"windows_per_s": n_t * wpt / el, "windows": n_t * wpt, "seconds": el, "ranks_seen": seen, "contexts_per_gpu": len(ctxs),
+            "mbases_per_s": (len(text) - 16 * n_rec) / el / 1e6, "fasta_records": n_rec, "fasta_bytes": int(len(text)),
+            "timed": "scatter + herro_job_create + featurize + infer + consensus + D2H + herro_job_fasta + gather to rank 0 "
+                     "(whole sharded data path, host work included); rank 0 ingests"}
+
+
+def bench_strong(args, rank: int, world: int, local: int):
+    """bench.py --scaling strong: the line of the sharded data path alone (see strong_leg)."""
+    import json
+    import torch.distributed as dist
+    n_windows = args.windows or args.steps * args.batch
+    r = strong_leg(args, rank, world, local, n_windows)
     if rank == 0:
-        n_rec = fasta.count(b">")
-        steps = n_t * wpt // args.batch
+        steps = r["windows"] // args.batch
         print(json.dumps({
-            "metric": "4096-bp windows corrected/sec at batch=128", "value": n_t * wpt / el, "unit": "windows/s", "n_gpus": world,
-            "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / max(steps, 1), "higher_is_better": True, "scaling": "strong",
+            "metric": "4096-bp windows corrected/sec at batch=128", "value": r["windows_per_s"], "unit": "windows/s", "n_gpus": world,
+            "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * r["seconds"] / max(steps, 1), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": {1: "bf16x3", 4: "f16 (encoder GEMMs: activation hi+lo)", 5: "f16"}.get(args.precision, str(args.precision)),
             "data": "synthetic (SURVEY §8d generator, seed 0x48455252+3; random-init weights of the assumed architecture)",
-            "config": {"workload": f"ONE fixed job of {n_t * wpt} synthetic 4096-bp windows (32 overlaps each, batch=128) sharded by target read over "
+            "config": {"workload": f"ONE fixed job of {r['windows']} synthetic 4096-bp windows (32 overlaps each, batch=128) sharded by target read over "
                                    f"{world} rank(s): rank 0 ingests, scatters the work, gathers the corrected reads (BASELINE configs[3])",
-                       "batch": args.batch, "window": W, "overlaps": n_ovl, "timed": "scatter + herro_job_create + featurize + infer + consensus + "
-                       "D2H + FASTA gather (whole multi-GPU data path, host work included)", "precision": args.precision},
-            "mbases_per_s": (len(fasta) - 16 * n_rec) / el / 1e6, "fasta_records": n_rec, "fasta_bytes": len(fasta),
+                       "batch": args.batch, "window": 4096, "overlaps": 32, "timed": r["timed"], "precision": args.precision},
+            "strong": r,
             "roofline": {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None,
                          "note": "per-kernel roofline: run the default (weak) mode; this mode times the sharded data path end to end"}}))
-    ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -171,6 +171,14 @@ int herro_job_consensus_fetch(herro_job* job, uint64_t* n_bases);
 int64_t herro_job_consensus_fasta(herro_job* job, uint32_t t, const char* id, const char* desc,
                                   char* out, uint64_t cap);
 
+/* The FASTA records of ALL targets of the job in one call, target order (the consensus worker's output for a batch of
+ * reads, consensus.rs:229-263 + lib.rs:282-317): ids[t] / descs[t] (descs or descs[t] NULL: none) as above.  Requires
+ * herro_job_consensus.  out == NULL: returns the number of bytes the records take; otherwise writes them (at most cap
+ * bytes) and returns the bytes written, or a negative error.  rec_end, if not NULL, receives for every target the end
+ * offset of its records in out ([n_targets]; equal ends: the read was not emitted). */
+int64_t herro_job_fasta(herro_job* job, const char* const* ids, const char* const* descs, char* out, uint64_t cap,
+                        uint64_t* rec_end);
+
 /* ---- stand-alone model entry (parity checks) — mirrors `inference` (inference.rs:147-175):
  * bases u8 tokens [B,L,31], quals raw u8 [B,L,31] (normalised on device, :153), lens [B],
  * indices flat [sum(lens)].  Outputs info_logits [N], bases_logits [N,5] (host). */

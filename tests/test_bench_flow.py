@@ -93,6 +93,8 @@ def test_bench_flow(monkeypatch, capsys, argv, steps):
     monkeypatch.setattr(synth, "generate_parallel", lambda *a, **k: fake_sb)
     monkeypatch.setattr(synth, "generate", lambda *a, **k: fake_sb)
     monkeypatch.setattr(model_io, "default_model_file", lambda d: ("model.bin", None))
+    from herro_amd import shard
+    monkeypatch.setattr(shard, "strong_leg", lambda *a, **k: {"windows_per_s": 2.0, "windows": 8, "ranks_seen": 1})
     monkeypatch.setattr(sys, "argv", ["bench.py", "--no-cpu-baseline", "--self-check", "0"] + argv)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
@@ -109,6 +111,7 @@ def test_bench_flow(monkeypatch, capsys, argv, steps):
         assert d["steps"] == steps
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["unit"] == "windows/s" and "workload" in d["config"]
+    assert d["strong"]["ranks_seen"] == d["n_gpus"] and d["strong"]["windows_per_s"] > 0   # the sharded leg rides in the same line
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
     assert len(d["roofline_next_kernels"]) == 2 and all({"kernel", "bound", "frac"} <= set(r) for r in d["roofline_next_kernels"])
     assert d["roofline"]["launch_us"] >= d["roofline_next_kernels"][0]["launch_us"] >= d["roofline_next_kernels"][1]["launch_us"]

@@ -6,7 +6,7 @@ import pytest
 
 import gpu_common as G
 import oracle_lib as O
-from herro_amd import api, shard, synth
+from herro_amd import api, model_io, shard, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -18,8 +18,13 @@ def test_sharded_path_single_rank_matches_plain_job():
     c.set_precision(api.DEFAULT_PRECISION)
     G.load_synth(c, sb)
     nw = shard.windows_of((sb.off[1:] - sb.off[:-1])[sb.tgt_rid], W)
-    fasta, n_mine = shard.correct_sharded(sb, nw, shard.hip_corrector(c, W, 5, sb.read_name, group_targets=3))
-    assert n_mine == sb.n_targets
+    c2 = api.Context(0)                       # a second context of the same GPU: two feeder threads, two jobs in flight each
+    c2.load_model(model_io.default_model_file(G.CACHE)[0])
+    c2.set_precision(api.DEFAULT_PRECISION)
+    c2.set_reads(sb.seq, sb.qual, sb.off)
+    rec, n_mine = shard.correct_sharded(sb, nw, shard.hip_corrector([c, c2], W, 5, sb.read_name, group_targets=3))
+    fasta = shard.sorted_fasta(*rec)
+    assert n_mine == sb.n_targets and len(rec[0]) == sb.n_targets
     job = api.job_from_synth(c, sb, W)
     job.featurize()
     job.infer(5, 1)
@@ -30,4 +35,9 @@ def test_sharded_path_single_rank_matches_plain_job():
     # what the oracle decodes from that run's own logits, which the other tests pin; here: same records
     assert fasta.decode() == "".join(f for _, f in recs)
     assert fasta.count(b">") >= 1
+    # herro_job_fasta (all targets, one call) == the per-target entry
+    text, ends = job.fasta([sb.read_name(int(r)) for r in sb.tgt_rid], with_ends=True)
+    assert text.decode() == "".join(job.consensus_fasta(t, sb.read_name(int(sb.tgt_rid[t]))) for t in range(sb.n_targets))
+    assert int(ends[-1]) == len(text)
     job.close()
+    c2.close()

@@ -86,7 +86,8 @@ WORKER2 = textwrap.dedent("""
     if world > 1:
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=world)
     rank = int(sys.argv[1])
-    sb = synth.generate(9, 1400, 7, seed=11, flank_min=30, flank_max=60) if rank == 0 else None   # ONLY rank 0 ingests
+    n_targets = int(sys.argv[3]) if len(sys.argv) > 3 else 9
+    sb = synth.generate(n_targets, 1400, 7, seed=11, flank_min=30, flank_max=60) if rank == 0 else None   # ONLY rank 0 ingests
     nw = shard.windows_of((sb.off[1:] - sb.off[:-1])[sb.tgt_rid], 256) if rank == 0 else None
     if world > 1:                                         # the read store is replicated by broadcast
         seq, qual, off = shard.broadcast_reads(sb)
@@ -95,6 +96,7 @@ WORKER2 = textwrap.dedent("""
 
     def correct(rids, aln_off, rows, cig_off, cig):       # stand-in corrector: a digest of exactly what arrived + the store
         out = []
+        assert len(rids) > 0                              # an empty shard never reaches the corrector
         for k, rid in enumerate(rids):
             a0, a1 = int(aln_off[k]), int(aln_off[k + 1])
             h = hashlib.sha1()
@@ -103,10 +105,11 @@ WORKER2 = textwrap.dedent("""
                 h.update(cig[int(cig_off[a]):int(cig_off[a]) + int(rows[a, 9])].tobytes())
             h.update(seq[int(off[rid]):int(off[rid + 1])].tobytes()); h.update(qual[int(off[rid]):int(off[rid + 1])].tobytes())
             out.append((int(rid), (">read%d \\n%s\\n" % (rid, h.hexdigest())).encode()))
-        return out
-    fasta, n_mine = shard.correct_sharded(sb, nw, correct)
+        ends = np.cumsum([len(f) for _, f in out]).astype(np.uint64)
+        return np.array([r for r, _ in out], np.uint32), ends, b"".join(f for _, f in out)
+    rec, n_mine = shard.correct_sharded(sb, nw, correct)
     if rank == 0:
-        print(json.dumps({{"fasta": fasta.decode(), "mine": n_mine}}))
+        print(json.dumps({{"fasta": shard.sorted_fasta(*rec).decode(), "mine": n_mine, "records": int(len(rec[0]))}}))
     if world > 1:
         dist.destroy_process_group()
 """)
@@ -131,6 +134,36 @@ def test_scatter_work_gather_fasta_two_ranks(tmp_path):
     got = json.loads(outs[0][0].strip().splitlines()[-1])
     assert got["fasta"] == want["fasta"] and got["fasta"].count(">") == 9
     assert 0 < got["mine"] < 9 and want["mine"] == 9
+
+
+def test_three_ranks_with_an_empty_shard(tmp_path):
+    """Fewer target reads than ranks: one rank gets no work, sends no result, and nothing hangs; the gathered records are
+    the single-rank ones."""
+    port = 33500 + os.getpid() % 2000
+    script = tmp_path / "worker3.py"
+    script.write_text(WORKER2.format(root=ROOT, port=port))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    import json
+    single = subprocess.run([sys.executable, str(script), "0", "1", "2"], capture_output=True, text=True, env=env, timeout=240)
+    assert single.returncode == 0, single.stderr
+    want = json.loads(single.stdout.strip().splitlines()[-1])
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "3", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, env=env) for r in range(3)]
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    got = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert got["fasta"] == want["fasta"] and got["records"] == 2 and got["mine"] == 1
+
+
+def test_record_messages_round_trip():
+    a = (np.array([7, 3], np.uint32), np.array([5, 5], np.uint64), b">r7 \n")
+    b = (np.array([1], np.uint32), np.array([6], np.uint64), b">r1 \nA")
+    rids, ends, text = shard.unpack_records(shard.pack_records(*a))
+    assert rids.tolist() == [7, 3] and ends.tolist() == [5, 5] and bytes(text) == a[2]
+    m = shard.merge_records([a, (np.zeros(0, np.uint32), np.zeros(0, np.uint64), b""), b])
+    assert m[0].tolist() == [7, 3, 1] and m[1].tolist() == [5, 5, 11] and bytes(m[2]) == a[2] + b[2]
+    assert shard.sorted_fasta(*m) == b">r1 \nA>r7 \n"
+    assert len(shard.unpack_records(b"")[0]) == 0
 
 
 def test_work_message_round_trip():
