@@ -18,7 +18,7 @@ DEFAULT_PRECISION = 4
 EXPORTS = [
     "herro_version", "herro_create", "herro_destroy", "herro_last_error", "herro_set_stream", "herro_synchronize",
     "herro_encode_2bit", "herro_decode_2bit", "herro_set_reads", "herro_set_reads_packed", "herro_load_model",
-    "herro_set_precision", "herro_job_create", "herro_job_free", "herro_job_n_windows", "herro_job_skipped", "herro_job_featurize",
+    "herro_set_precision", "herro_model_describe", "herro_job_create", "herro_job_free", "herro_job_n_windows", "herro_job_skipped", "herro_job_featurize",
     "herro_job_infer", "herro_job_consensus", "herro_job_consensus_fetch", "herro_job_window_info", "herro_job_window_copy", "herro_job_window_logits",
     "herro_job_consensus_fasta", "herro_job_fasta", "herro_model_forward", "herro_timing_enable", "herro_timing_reset",
     "herro_timing_get", "herro_job_stats", "herro_debug_extract_windows",
@@ -81,6 +81,8 @@ def lib():
         L.herro_job_window_logits.argtypes = [vp, u32, vp, vp]
         L.herro_job_consensus_fasta.restype = C.c_int64
         L.herro_job_consensus_fasta.argtypes = [vp, u32, C.c_char_p, C.c_char_p, vp, u64]
+        L.herro_model_describe.restype = C.c_int64
+        L.herro_model_describe.argtypes = [vp, vp, u64]
         L.herro_job_fasta.restype = C.c_int64
         L.herro_job_fasta.argtypes = [vp, vp, vp, vp, u64, vp]
         L.herro_model_forward.argtypes = [vp, u32, u32, vp, vp, vp, vp, vp, vp]
@@ -190,6 +192,13 @@ class Context:
 
     def set_precision(self, mode: int):
         self._chk(self._l.herro_set_precision(self.h, mode))
+
+    def describe_model(self) -> str:
+        buf = C.create_string_buffer(4096)
+        n = self._l.herro_model_describe(self.h, buf, 4096)
+        if n < 0:
+            self._chk(int(n))
+        return buf.value.decode()
 
     def create_job(self, rids, aln_rows: np.ndarray, aln_off, cigars: list[bytes] | None, window_size: int,
                    cig_blob: np.ndarray | None = None, cig_off: np.ndarray | None = None) -> "Job":

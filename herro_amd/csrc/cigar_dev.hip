@@ -175,14 +175,18 @@ __global__ __launch_bounds__(CT) void k_cigar_scan(const uint8_t* __restrict__ t
   // Workgroup scope is all that is needed (the readers below are waves of this workgroup, behind the same L1), and all
   // that is affordable: an agent-scope fence writes the XCD's whole L2 back on gfx950, once per wave — measured 8.5 ms
   // per 4096 alignments instead of 0.1.
-  __threadfence_block();
+  // Release by the writers, acquire by the readers, both at workgroup scope: what the memory model asks for whatever the
+  // workgroup's placement (threadgroup-split mode included); on gfx950 in the default mode neither costs an instruction
+  // beyond the barrier's own wait.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   // ---- the two ops behind every cut, first / last op, totals
   const uint32_t n_ops = min(k_c, room);
-  auto ld = [&](uint32_t idx) { return __hip_atomic_load(o + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  auto ld = [&](uint32_t idx) { return __hip_atomic_load(o + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); };
   const uint32_t n_cut = min(s_ncut, a.cut_cap);
   for (uint32_t c = tid; c < n_cut; c += CT) {
-    const uint32_t kk = __hip_atomic_load(&cut[c].k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t kk = __hip_atomic_load(&cut[c].k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
     cut[c].o1 = kk + 1 < n_ops ? ld(kk + 1) : 0u;
     cut[c].o2 = kk + 2 < n_ops ? ld(kk + 2) : 0u;
   }

@@ -45,7 +45,13 @@ struct ErrSlot {
   std::string s;
   ErrSlot& operator=(const std::string& v) { std::lock_guard<std::mutex> lk(mu); s = v; return *this; }
   ErrSlot& operator=(const char* v) { std::lock_guard<std::mutex> lk(mu); s = v; return *this; }
-  const char* c_str() const { return s.c_str(); }
+  // the text handed out is a per-thread copy: an assignment by another thread (job creation may run beside the execution
+  // calls) cannot pull the buffer away under the reader
+  const char* c_str() const {
+    thread_local std::string snap;
+    { std::lock_guard<std::mutex> lk(const_cast<std::mutex&>(mu)); snap = s; }
+    return snap.c_str();
+  }
 };
 
 #define HIP_TRY(ctx, expr)                                                              \
@@ -149,6 +155,9 @@ struct herro_ctx {
   std::vector<void*> model_allocs;
   int precision = 1;
   bool precision_set = false;   // herro_set_precision was called: herro_load_model keeps the caller's choice
+  float wmax = 0.f;             // largest |weight| of the loaded model
+  float calib_err = -1.f;       // max |logit difference| mode 4 vs mode 1 on the calibration batch (-1: not run)
+  std::string calib_note;
   ModelScratch S{};
   uint32_t scratch_cap = 0;
   std::vector<void*> scratch_allocs;
@@ -655,11 +664,13 @@ int herro_load_model(herro_ctx* ctx, const char* path) {
     if (missing) return nullptr;
     return up_f32(ctx, v, e);
   };
+  float wmax_seen = 0.f;
   auto weight = [&](const std::string& n, uint32_t K, uint32_t N) -> Weight {
     Weight w;
     w.K = K; w.N = N;
     const auto& wt = get(n + ".wt", (size_t)K * N);
     if (missing) return w;
+    for (float x : wt) wmax_seen = std::max(wmax_seen, std::fabs(x));
     w.f32 = up_f32(ctx, wt, e);
     std::vector<uint16_t> hi(wt.size()), lo(wt.size());
     for (size_t i = 0; i < wt.size(); i++) { hi[i] = h_bf16(wt[i]); lo[i] = h_bf16(wt[i] - h_bf16f(hi[i])); }
@@ -730,14 +741,83 @@ int herro_load_model(herro_ctx* ctx, const char* path) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->M = M;
   ctx->has_model = true;
-  // default operand format: f16 (precision 4) when the model has the shapes its kernels are written for, else bf16 hi/lo x3
-  if (!ctx->precision_set) ctx->precision = model_h_supported(M) ? 4 : 1;
-  else if (ctx->precision >= 4 && !model_h_supported(M)) ctx->precision = 1;
+  ctx->wmax = wmax_seen;
+  ctx->calib_err = -1.f;
+  ctx->calib_note.clear();
+  // Operand format.  bf16 hi/lo x3 (mode 1, ~1e-5) always works.  f16 (mode 4) needs the shapes its kernels are written
+  // for, weights inside the f16 range (|w| >= 65520 rounds to inf, the remainder term to -inf: NaN logits), and — because
+  // its margin to the 1e-3 contract was measured on random-init weights only — a calibration run on THIS model.
+  const bool f16_ok = model_h_supported(M) && wmax_seen < 65504.f;
+  if (ctx->precision_set) {
+    if (ctx->precision >= 4 && !f16_ok) { ctx->precision = 1; ctx->calib_note = "f16 modes unavailable for this model (shapes or weight range): mode 1"; }
+    return HERRO_OK;
+  }
+  if (!f16_ok) {
+    ctx->precision = 1;
+    ctx->calib_note = model_h_supported(M) ? "a weight lies outside the f16 range: mode 1" : "no f16 kernels for these shapes: mode 1";
+    return HERRO_OK;
+  }
+  {  // calibration: 4 windows x 96 rows, 64 informative rows each (fused tiles), pseudo-random tokens and qualities
+    const uint32_t B = 4, L = 96, NS = 64;
+    std::vector<uint8_t> cb((size_t)B * L * HERRO_ROWS), cq(cb.size());
+    uint64_t x = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    for (size_t i = 0; i < cb.size(); i++) { cb[i] = (uint8_t)(rnd() % 11); cq[i] = (uint8_t)(33 + rnd() % 51); }
+    std::vector<int32_t> lens(B, (int32_t)NS), idx((size_t)B * NS);
+    for (uint32_t b = 0; b < B; b++) for (uint32_t k = 0; k < NS; k++) idx[(size_t)b * NS + k] = (int32_t)(16 + k);
+    std::vector<float> i1((size_t)B * NS), b1((size_t)B * NS * 5), i4(i1.size()), b4(b1.size());
+    ctx->precision = 1;
+    int rc = herro_model_forward(ctx, B, L, cb.data(), cq.data(), lens.data(), idx.data(), i1.data(), b1.data());
+    ctx->precision = 4;
+    if (rc == HERRO_OK) rc = herro_model_forward(ctx, B, L, cb.data(), cq.data(), lens.data(), idx.data(), i4.data(), b4.data());
+    if (rc != HERRO_OK) { ctx->precision = 1; ctx->calib_note = "calibration run failed: mode 1"; return HERRO_OK; }
+    float err = 0.f;
+    bool finite = true;
+    for (size_t i = 0; i < i1.size(); i++) { finite = finite && std::isfinite(i4[i]); err = std::max(err, std::fabs(i4[i] - i1[i])); }
+    for (size_t i = 0; i < b1.size(); i++) { finite = finite && std::isfinite(b4[i]); err = std::max(err, std::fabs(b4[i] - b1[i])); }
+    ctx->calib_err = finite ? err : INFINITY;
+    const bool keep4 = finite && err <= 5e-4f;
+    ctx->precision = keep4 ? 4 : 1;
+    char buf[160];
+    snprintf(buf, sizeof buf, "calibration (256 rows): max |logit(mode 4) - logit(mode 1)| = %.3g -> mode %d", (double)ctx->calib_err, ctx->precision);
+    ctx->calib_note = buf;
+  }
   return HERRO_OK;
+}
+
+int64_t herro_model_describe(const herro_ctx* ctx, char* out, uint64_t cap) {
+  if (!ctx || !out || !cap) return HERRO_E_INVALID;
+  std::string t;
+  if (!ctx->has_model) t = "no model loaded";
+  else {
+    const ModelHyper& h = ctx->M.h;
+    const uint32_t rf = 4 * (h.kw / 2) + 1;   // rows of the window the two stacked convs see around an informative row
+    const double conv = 2.0 * HERRO_ROWS * (2.0 * (h.kw / 2) + 1) * (7.0 * h.kw) * h.c1 + 2.0 * HERRO_ROWS * (double)h.kw * h.c1 * h.c2;
+    const double fc = 2.0 * HERRO_ROWS * h.c2 * (double)h.d_model;
+    const double layer = 2.0 * h.d_model * 3.0 * h.d_model + 2.0 * h.d_model * (double)h.d_model + 4.0 * h.d_model * (double)h.d_ff;
+    const double per_tok = conv + fc + h.n_layers * layer + 2.0 * h.d_model * 6.0;
+    char buf[1024];
+    snprintf(buf, sizeof buf,
+             "rows %u, conv kw %u (%u -> %u ch), d_model %u, heads %u, d_ff %u, layers %u; receptive field of an informative row: %u rows "
+             "(a dense evaluation would run the conv stack and the projection on every one of the ~4700 rows of a window); GEMM FLOP per "
+             "informative row %.3g (conv %.3g, projection %.3g, encoder %.3g), per 4096-bp window at 15 informative rows %.3g, + attention "
+             "4 * n^2 * d_model per window; max |weight| %.4g; precision mode %d%s%s",
+             h.rows, h.kw, h.c1, h.c2, h.d_model, h.n_heads, h.d_ff, h.n_layers, rf, per_tok, conv, fc, h.n_layers * layer, 15.0 * per_tok,
+             (double)ctx->wmax, ctx->precision, ctx->calib_note.empty() ? "" : "; ", ctx->calib_note.c_str());
+    t = buf;
+  }
+  const uint64_t n = std::min<uint64_t>(t.size(), cap - 1);
+  std::memcpy(out, t.data(), n);
+  out[n] = 0;
+  return (int64_t)t.size();
 }
 
 int herro_set_precision(herro_ctx* ctx, int mode) {
   if (!ctx || mode < 0 || mode > 5) return HERRO_E_INVALID;
+  if (mode >= 4 && ctx->has_model && ctx->wmax >= 65504.f) {
+    ctx->err = "precision 4 / 5 (f16 operands): a weight of this model lies outside the f16 range";
+    return HERRO_E_UNSUPPORTED;
+  }
   if (mode >= 4 && ctx->has_model && !model_h_supported(ctx->M)) {
     ctx->err = "precision 4 / 5 (f16 kernels) need kw 3, conv 64/128, d_model 256, 8 heads, d_ff % 256 == 0";
     return HERRO_E_UNSUPPORTED;
@@ -1107,7 +1187,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
     n_cls = (uint32_t)b.cls; scr_ops = b.scr; fin_bytes = b.fin; row_elems = b.row; pos_elems = b.pos;
   }
   if (scr_ops > 0xffffffffull) return fail(HERRO_E_UNSUPPORTED, "job too large (op scratch exceeds 2^32)");
-  if (job->n_skipped_alns) ctx->err = std::to_string(job->n_skipped_alns) + " alignment(s) left out; first: " + job->first_skip;
+  // (what was left out is reported by herro_job_skipped; the error slot is for errors only)
   const Base& tot = base[n_targets];
   // descriptor block (host arena == head of the device arena), 256-byte aligned pieces
   size_t cur = 0;

@@ -101,8 +101,16 @@ int herro_load_model(herro_ctx* ctx, const char* path);
  *   4  f16: conv2 / FC / attention on single f16 operands, the four GEMMs of every encoder layer on activation hi + lo
  *      (2 MFMAs), heads on three terms — 5.5e-4 max on 36 k rows; the DEFAULT when the model has the tuned shapes
  *   5  f16, single terms everywhere but the heads (7.6e-4: measured, not a default)
- * herro_load_model picks 4 (or 1 when the model's shapes have no f16 kernels) unless this was called before. */
+ * herro_load_model picks the mode itself unless this was called before: 1 when the model's shapes have no f16 kernels or
+ * a weight lies outside the f16 range; otherwise it runs a 256-row calibration batch in modes 1 and 4 and keeps 4 only
+ * if the logits are finite and differ by at most 5e-4 (half the 1e-3 contract) — the margin of the f16 formats was
+ * measured on random-init weights, a trained model decides for itself.  herro_model_describe reports the outcome. */
 int herro_set_precision(herro_ctx* ctx, int mode);
+
+/* Text description of the loaded model: hyper-parameters, receptive field of an informative row (rows the conv stack
+ * evaluates per token), GEMM FLOP per token and per 4096-bp window at 15 informative rows, the precision mode in force and
+ * the calibration result of herro_load_model.  Returns the length of the text (truncated to cap - 1 bytes + NUL). */
+int64_t herro_model_describe(const herro_ctx* ctx, char* out, uint64_t cap);
 
 /* ---- job = a set of target reads with their alignments -------------------------------------
  * herro_job_create replaces the front half of `extract_features` (features.rs:326-361): `extract_windows`

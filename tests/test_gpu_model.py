@@ -253,3 +253,28 @@ def test_torchscript_archive_to_hip_logits(tmp_path):
             assert err <= TOL
     finally:
         c.close()
+
+
+def test_load_time_precision_choice(tmp_path):
+    """herro_load_model chooses the operand format itself: f16 (mode 4) only when the calibration batch agrees with the
+    bf16x3 mode within 5e-4 and every weight fits the f16 range; herro_model_describe says what happened."""
+    c = api.Context(0)
+    path, raw = model_io.default_model_file(G.CACHE)
+    c.load_model(path)
+    d = c.describe_model()
+    assert "calibration (256 rows)" in d and "receptive field of an informative row: 5 rows" in d, d
+    assert ("-> mode 4" in d) or ("-> mode 1" in d)
+    import re
+    err = float(re.search(r"= ([0-9.eE+-]+|inf) -> mode", d).group(1))
+    assert ("-> mode 4" in d) == (err <= 5e-4)
+    big = {k: v.copy() for k, v in raw.items()}
+    k0 = "encoder.layers.0.linear1.weight"
+    big[k0].flat[0] = 1.0e5                                  # f16: inf
+    p2 = str(tmp_path / "big.hrro")
+    model_io.export(big, model_io.Hyper(), p2)
+    c.load_model(p2)
+    d2 = c.describe_model()
+    assert "outside the f16 range" in d2 and "precision mode 1" in d2, d2
+    with pytest.raises(api.HerroError):
+        c.set_precision(4)
+    c.close()

@@ -6,7 +6,7 @@ The reference loads its correction model with `tch::CModule::load_on_device(mode
 published file is `model_R10_v0.1.pt` (reference README.md:56-66), which is not part of the checkout.  This tool
 is the bridge for the day such a file is at hand:
 
-    python tools/export_weights.py model.pt model.hrro [--dump report.txt] [--verify]
+    python tools/export_weights.py model.pt model.hrro [--dump report.txt] [--no-verify]
 
 1. `torch.jit.load` the archive; print / dump its forward code, the operator histogram of the inlined graph, the
    sub-module tree and every parameter / buffer with shape and dtype.
@@ -250,8 +250,11 @@ def recover(m):
         if on == "MultiheadAttention" and hasattr(sub, "num_heads"):
             n_heads = int(sub.num_heads)
         if on == "TransformerEncoderLayer":
-            if hasattr(sub, "norm_first") and not bool(sub.norm_first):
-                raise Unsupported(f"{name}: post-LN encoder layer (norm_first = False); the kernels implement Pre-LN")
+            if hasattr(sub, "norm_first"):
+                if not bool(sub.norm_first):
+                    raise Unsupported(f"{name}: post-LN encoder layer (norm_first = False); the kernels implement Pre-LN")
+            else:
+                notes.append(f"{name}: norm_first not readable from the archive: assuming Pre-LN (the conversion check decides)")
         if on == "LayerNorm" and hasattr(sub, "eps"):
             ln_eps = float(sub.eps)
         if on == "BatchNorm2d" and hasattr(sub, "eps"):
@@ -310,7 +313,7 @@ def verify(m, hp, raw, seed: int = 0) -> float:
     return float(max(np.abs(ti.numpy() - ni).max(), np.abs(tb.numpy() - nb).max()))
 
 
-def convert(path: str, out: str, dump: str | None = None, do_verify: bool = False, quiet: bool = False):
+def convert(path: str, out: str, dump: str | None = None, do_verify: bool = True, quiet: bool = False):
     m = load_archive(path)
     report = describe(m)
     if dump:
@@ -324,7 +327,19 @@ def convert(path: str, out: str, dump: str | None = None, do_verify: bool = Fals
         kernel_limits.append("herro_load_model accepts head_dim 32, d_model % 64 == 0, kw*c1 / 31*c2 / d_ff multiples of 32, <= 16 layers")
     if kernel_limits:
         raise Unsupported("; ".join(kernel_limits) + f" — recovered {hp}")
-    model_io.export(raw, hp, out)
+    # the conversion check runs BEFORE anything is written: a file that fails it must not be left where it can be loaded
+    err = None
+    if do_verify:
+        err = verify(m, hp, raw)
+        if not quiet:
+            print(f"verify: archive vs folded tensors, max |logit diff| = {err:.2e}")
+        if not err <= 2e-5:
+            raise Unsupported(f"conversion check failed: max |logit diff| {err:.3e} > 2e-5 — the graph computes something the mapping does not")
+    elif any("not readable from the archive" in n for n in notes):
+        raise Unsupported("an attribute the shapes cannot tell (norm_first / eps / num_heads) is not readable from the archive and the "
+                          "conversion check is off (--no-verify): refusing to guess — " + "; ".join(notes))
+    model_io.export(raw, hp, out + ".tmp")
+    os.replace(out + ".tmp", out)
     if not quiet:
         print(f"recovered {hp}")
         for n in notes:
@@ -334,13 +349,6 @@ def convert(path: str, out: str, dump: str | None = None, do_verify: bool = Fals
               "generic layer-by-layer kernels only (precision 0-3): shapes differ from the tuned ones")
         print(flop_report(hp))
         print(f"wrote {out} ({os.path.getsize(out):,} bytes)")
-    err = None
-    if do_verify:
-        err = verify(m, hp, raw)
-        if not quiet:
-            print(f"verify: archive vs folded tensors, max |logit diff| = {err:.2e}")
-        if not err <= 2e-5:
-            raise Unsupported(f"conversion check failed: max |logit diff| {err:.3e} > 2e-5 — the graph computes something the mapping does not")
     return hp, raw, err
 
 
@@ -349,10 +357,11 @@ def main():
     ap.add_argument("archive")
     ap.add_argument("out")
     ap.add_argument("--dump", help="write code / graph / module tree / parameter list here")
-    ap.add_argument("--verify", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="(default) run the archive against the folded tensors before writing")
+    ap.add_argument("--no-verify", action="store_true", help="skip the conversion check")
     a = ap.parse_args()
     try:
-        convert(a.archive, a.out, a.dump, a.verify)
+        convert(a.archive, a.out, a.dump, not a.no_verify)
     except Unsupported as e:
         print(f"export_weights: cannot convert {a.archive}:\n{e}", file=sys.stderr)
         raise SystemExit(2)
