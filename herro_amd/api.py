@@ -24,6 +24,8 @@ EXPORTS = [
     "herro_timing_get", "herro_job_stats", "herro_debug_extract_windows",
     "herro_paf_parse", "herro_oec_read", "herro_paf_n_targets", "herro_paf_target_ids", "herro_paf_aln_off",
     "herro_paf_alignments", "herro_paf_free", "herro_debug_host_ctx", "herro_debug_job_array",
+    "herro_fastx_read", "herro_reads_count", "herro_reads_seq", "herro_reads_qual", "herro_reads_off", "herro_reads_ids",
+    "herro_reads_descs", "herro_reads_free", "herro_write_window_features", "herro_job_write_features",
 ]
 
 

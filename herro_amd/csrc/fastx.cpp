@@ -1,0 +1,225 @@
+// fastx.cpp — host-side file formats on either side of the hot path, behind the C ABI.
+//
+//   herro_fastx_read        what get_reads (haec_io.rs:37-75) hands to the path.  The reference reads through needletail's
+//                           parse_fastx_file: FASTA or FASTQ by the first byte, gzip by magic, sequences (and FASTQ qualities)
+//                           allowed to span lines, '\r' dropped.  get_reads then: records shorter than min_length dropped; the
+//                           header split at the first blank or tab into id / description; qualities mandatory ("Qualities should
+//                           be present." — a FASTA record is an error); the core / neighbour filter (kept if in either set).
+//   herro_write_window_features   the `herro features` sink (features.rs:724-764): <dir>/<wid>.features.npy = u8 [2, L', 31]
+//                           (ASCII bases, then qualities), <wid>.supported.npy = records {pos: <u2, ins: u1}, <wid>.ids.txt.
+//                           The reference writes NPY through the npyz crate (format 1.0, C order, default dtype strings); the
+//                           header written here is the one numpy itself writes for these arrays: magic, version 1.0, the dict
+//                           {'descr': ..., 'fortran_order': False, 'shape': (...), } padded with spaces to a multiple of 64
+//                           bytes, '\n' last.
+//
+// zlib is used through the system's libz.so.1 (stable C ABI), loaded on first use: the library keeps no link-time dependency
+// beyond the HIP runtime and libstdc++.
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/stat.h>
+
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/herro_amd.h"
+
+struct herro_reads {
+  std::vector<std::string> ids, descs;
+  std::vector<uint8_t> has_desc;
+  std::vector<uint8_t> seq, qual;
+  std::vector<uint64_t> off;
+  std::vector<const char*> id_ptr, desc_ptr;
+};
+
+namespace {
+
+struct Zlib {
+  void* h = nullptr;
+  void* (*gzopen)(const char*, const char*) = nullptr;
+  int (*gzread)(void*, void*, unsigned) = nullptr;
+  int (*gzclose)(void*) = nullptr;
+  bool ok = false;
+  Zlib() {
+    for (const char* n : {"libz.so.1", "libz.so"}) {
+      h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (h) break;
+    }
+    if (!h) return;
+    gzopen = (void* (*)(const char*, const char*))dlsym(h, "gzopen");
+    gzread = (int (*)(void*, void*, unsigned))dlsym(h, "gzread");
+    gzclose = (int (*)(void*))dlsym(h, "gzclose");
+    ok = gzopen && gzread && gzclose;
+  }
+};
+
+bool slurp(const char* path, std::string& out, std::string& why) {
+  FILE* f = fopen(path, "rb");
+  if (!f) { why = "Cannot open file containing reads."; return false; }
+  unsigned char magic[2] = {0, 0};
+  const size_t got = fread(magic, 1, 2, f);
+  const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+  if (!gz) {
+    out.assign((const char*)magic, got);
+    char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
+    fclose(f);
+    return true;
+  }
+  fclose(f);
+  static Zlib z;
+  if (!z.ok) { why = "gzip input, but libz.so.1 is not available"; return false; }
+  void* g = z.gzopen(path, "rb");
+  if (!g) { why = "Cannot open file containing reads."; return false; }
+  std::vector<char> buf(1 << 20);
+  int n;
+  while ((n = z.gzread(g, buf.data(), (unsigned)buf.size())) > 0) out.append(buf.data(), (size_t)n);
+  z.gzclose(g);
+  if (n < 0) { why = "Error parsing fastx file. (gzip stream)"; return false; }
+  return true;
+}
+
+void set_err(char* err, uint64_t cap, const std::string& m) {
+  if (err && cap) { strncpy(err, m.c_str(), cap - 1); err[cap - 1] = 0; }
+}
+
+// one line [b, e) without its terminator ('\n', and a '\r' before it); returns the start of the next line
+size_t next_line(const std::string& t, size_t pos, size_t& b, size_t& e) {
+  b = pos;
+  size_t nl = t.find('\n', pos);
+  if (nl == std::string::npos) nl = t.size();
+  e = nl;
+  if (e > b && t[e - 1] == '\r') e--;
+  return nl < t.size() ? nl + 1 : t.size();
+}
+
+std::string npy_header(const std::string& descr, const std::string& shape) {
+  std::string dict = "{'descr': " + descr + ", 'fortran_order': False, 'shape': " + shape + ", }";
+  // magic (6) + version (2) + header length (2) + dict + padding + '\n', total a multiple of 64 (numpy's format 1.0 writer)
+  size_t total = 10 + dict.size() + 1;
+  const size_t pad = (64 - total % 64) % 64;
+  dict.append(pad, ' ');
+  dict.push_back('\n');
+  std::string h("\x93NUMPY\x01\x00", 8);
+  const uint16_t hl = (uint16_t)dict.size();
+  h.push_back((char)(hl & 0xff));
+  h.push_back((char)(hl >> 8));
+  return h + dict;
+}
+
+bool mkdirs(const std::string& dir) {
+  std::string cur;
+  for (size_t i = 0; i <= dir.size(); i++) {
+    if (i == dir.size() || dir[i] == '/') {
+      if (!cur.empty() && mkdir(cur.c_str(), 0777) != 0) {
+        struct stat st;
+        if (stat(cur.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+      }
+    }
+    if (i < dir.size()) cur.push_back(dir[i]);
+  }
+  return true;
+}
+
+bool write_file(const std::string& path, const std::string& head, const void* body, size_t n) {
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) return false;
+  bool ok = fwrite(head.data(), 1, head.size(), f) == head.size();
+  if (ok && n) ok = fwrite(body, 1, n, f) == n;
+  return fclose(f) == 0 && ok;
+}
+
+}  // namespace
+
+extern "C" {
+
+herro_reads* herro_fastx_read(const char* path, uint32_t min_length, const char* const* keep_ids, uint64_t n_keep, char* err,
+                              uint64_t err_cap) {
+  if (!path) { set_err(err, err_cap, "null path"); return nullptr; }
+  std::string text, why;
+  if (!slurp(path, text, why)) { set_err(err, err_cap, why); return nullptr; }
+  std::unordered_set<std::string> keep;
+  const bool filter = keep_ids != nullptr;
+  for (uint64_t i = 0; filter && i < n_keep; i++) if (keep_ids[i]) keep.insert(keep_ids[i]);
+  auto r = new herro_reads();
+  r->off.push_back(0);
+  size_t pos = 0, b, e;
+  auto fail = [&](const char* m) -> herro_reads* { set_err(err, err_cap, m); delete r; return nullptr; };
+  std::string seq, qual;
+  while (pos < text.size()) {
+    pos = next_line(text, pos, b, e);
+    if (b == e) continue;                       // blank lines between records
+    const char kind = text[b];
+    if (kind != '@' && kind != '>') return fail("Error parsing fastx file. (record does not start with '@' or '>')");
+    const std::string head = text.substr(b + 1, e - b - 1);
+    seq.clear(); qual.clear();
+    if (kind == '>') {                          // FASTA: sequence lines up to the next header
+      while (pos < text.size() && text[pos] != '>') { pos = next_line(text, pos, b, e); seq.append(text, b, e - b); }
+      if (seq.size() < min_length) continue;    // (the length filter comes first in get_reads)
+      return fail("Qualities should be present.");
+    }
+    bool plus = false;                          // FASTQ: sequence lines up to the '+' line, then as many quality bytes
+    while (pos < text.size()) {
+      pos = next_line(text, pos, b, e);
+      if (b < e && text[b] == '+') { plus = true; break; }
+      seq.append(text, b, e - b);
+    }
+    if (!plus) return fail("Error parsing fastx file. (no '+' line)");
+    while (qual.size() < seq.size() && pos < text.size()) { pos = next_line(text, pos, b, e); qual.append(text, b, e - b); }
+    if (qual.size() != seq.size()) return fail("Error parsing fastx file. (sequence and quality lengths differ)");
+    if (seq.size() < min_length) continue;      // haec_io.rs:48-50
+    size_t cut = head.find_first_of(" \t");     // splitn(2, ' ' | '\t')
+    const std::string id = head.substr(0, cut);
+    if (filter && !keep.count(id)) continue;    // haec_io.rs:63-69 (the caller passes core u neighbour when both are given)
+    r->ids.push_back(id);
+    r->has_desc.push_back(cut != std::string::npos);
+    r->descs.push_back(cut != std::string::npos ? head.substr(cut + 1) : std::string());
+    r->seq.insert(r->seq.end(), seq.begin(), seq.end());
+    r->qual.insert(r->qual.end(), qual.begin(), qual.end());
+    r->off.push_back(r->seq.size());
+  }
+  for (size_t i = 0; i < r->ids.size(); i++) {
+    r->id_ptr.push_back(r->ids[i].c_str());
+    r->desc_ptr.push_back(r->has_desc[i] ? r->descs[i].c_str() : nullptr);
+  }
+  return r;
+}
+
+uint32_t herro_reads_count(const herro_reads* r) { return r ? (uint32_t)r->ids.size() : 0; }
+const uint8_t* herro_reads_seq(const herro_reads* r) { return r ? r->seq.data() : nullptr; }
+const uint8_t* herro_reads_qual(const herro_reads* r) { return r ? r->qual.data() : nullptr; }
+const uint64_t* herro_reads_off(const herro_reads* r) { return r ? r->off.data() : nullptr; }
+const char* const* herro_reads_ids(const herro_reads* r) { return r ? r->id_ptr.data() : nullptr; }
+const char* const* herro_reads_descs(const herro_reads* r) { return r ? r->desc_ptr.data() : nullptr; }
+void herro_reads_free(herro_reads* r) { delete r; }
+
+int herro_write_window_features(const char* dir, uint32_t wid, const char* const* ids, uint32_t n_ids, const uint8_t* bases,
+                                const uint8_t* quals, uint32_t length, const uint16_t* sup_pos, const uint8_t* sup_ins,
+                                uint32_t n_sup) {
+  if (!dir || (n_ids && !ids) || (length && (!bases || !quals)) || (n_sup && (!sup_pos || !sup_ins))) return HERRO_E_INVALID;
+  const std::string d(dir);
+  if (!mkdirs(d)) return HERRO_E_INVALID;
+  const std::string stem = d + "/" + std::to_string(wid);
+  std::string idtxt;
+  for (uint32_t i = 0; i < n_ids; i++) { idtxt += ids[i]; idtxt += "\n"; }
+  if (!write_file(stem + ".ids.txt", idtxt, nullptr, 0)) return HERRO_E_INVALID;
+  const size_t cells = (size_t)length * 31;
+  std::vector<uint8_t> feats(2 * cells);          // stack![Axis(0), bases, quals] (features.rs:742-743)
+  if (cells) { memcpy(feats.data(), bases, cells); memcpy(feats.data() + cells, quals, cells); }
+  if (!write_file(stem + ".features.npy", npy_header("'|u1'", "(2, " + std::to_string(length) + ", 31)"), feats.data(), feats.size()))
+    return HERRO_E_INVALID;
+  std::vector<uint8_t> sup((size_t)n_sup * 3);    // packed records {pos: <u2, ins: u1}
+  for (uint32_t k = 0; k < n_sup; k++) {
+    sup[3 * (size_t)k] = (uint8_t)(sup_pos[k] & 0xff);
+    sup[3 * (size_t)k + 1] = (uint8_t)(sup_pos[k] >> 8);
+    sup[3 * (size_t)k + 2] = sup_ins[k];
+  }
+  if (!write_file(stem + ".supported.npy", npy_header("[('pos', '<u2'), ('ins', '|u1')]", "(" + std::to_string(n_sup) + ",)"), sup.data(), sup.size()))
+    return HERRO_E_INVALID;
+  return HERRO_OK;
+}
+
+}  // extern "C"

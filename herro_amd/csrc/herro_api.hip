@@ -1858,6 +1858,39 @@ int64_t herro_job_fasta(herro_job* job, const char* const* ids, const char* cons
   return (int64_t)tot;
 }
 
+int64_t herro_job_write_features(herro_job* job, const char* base_dir, const char* const* read_names) {
+  if (!job || !base_dir || !read_names) return HERRO_E_INVALID;
+  herro_ctx* ctx = job->ctx;
+  int rc = job_sync(job);
+  if (rc) return rc;
+  int64_t n = 0;
+  std::vector<uint8_t> bases, quals, sins;
+  std::vector<uint16_t> spos;
+  std::vector<uint32_t> qids;
+  std::vector<const char*> ids;
+  for (uint32_t t = 0; t < job->n_targets; t++) {
+    for (uint32_t w = job->tgt_win_off[t]; w < job->tgt_win_off[t + 1]; w++) {
+      const WinDesc& wd = job->win[w];
+      const uint32_t L = job->h_Lf[w], ns = job->h_nsup[w], nk = job->h_nkept[w];
+      bases.resize((size_t)L * HERRO_ROWS); quals.resize(bases.size());
+      spos.resize(ns); sins.resize(ns); qids.resize(nk); ids.resize(nk);
+      if ((rc = herro_job_window_copy(job, w, 0, bases.data(), quals.data(), spos.data(), sins.data(), qids.data()))) return rc;
+      for (uint32_t k = 0; k < nk; k++) {
+        if (qids[k] >= ctx->n_reads || !read_names[qids[k]]) { ctx->err = "read name missing"; return HERRO_E_INVALID; }
+        ids[k] = read_names[qids[k]];
+      }
+      if (wd.rid >= ctx->n_reads || !read_names[wd.rid]) { ctx->err = "read name missing"; return HERRO_E_INVALID; }
+      const std::string dir = std::string(base_dir) + "/" + read_names[wd.rid];
+      if ((rc = herro_write_window_features(dir.c_str(), wd.wid, ids.data(), nk, bases.data(), quals.data(), L, spos.data(), sins.data(), ns))) {
+        ctx->err = "cannot write features under " + dir;
+        return rc;
+      }
+      n++;
+    }
+  }
+  return n;
+}
+
 // ---- stand-alone model entry (inference.rs:147-175) ----------------------------------------------
 int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* bases, const uint8_t* quals,
                         const int32_t* lens, const int32_t* indices, float* info_logits, float* bases_logits) {

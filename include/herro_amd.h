@@ -247,6 +247,37 @@ const uint64_t* herro_paf_aln_off(const herro_paf* p);        /* [n_targets + 1]
 const herro_alignment* herro_paf_alignments(const herro_paf* p);
 void herro_paf_free(herro_paf* p);
 
+/* ---- reads and the `herro features` sink -----------------------------------------------------
+ * herro_fastx_read = get_reads (haec_io.rs:37-75) over needletail's parse_fastx_file: FASTA or FASTQ by the first byte,
+ * gzip by magic, multi-line records, '\r' dropped; records shorter than min_length dropped; header split at the first blank
+ * or tab into id / description (NULL: none); qualities mandatory (a FASTA record fails with "Qualities should be
+ * present."); keep_ids (NULL: keep all) = the union of the reference's core and neighbour sets, which it applies only
+ * when both are given (haec_io.rs:63-69).  Returns NULL and a message in err on the inputs the reference panics on.
+ * Sequence and quality bytes of read i are [off[i], off[i+1]) of herro_reads_seq / herro_reads_qual — the arguments
+ * of herro_set_reads.  Pointers stay valid until herro_reads_free. */
+typedef struct herro_reads herro_reads;
+herro_reads* herro_fastx_read(const char* path, uint32_t min_length, const char* const* keep_ids, uint64_t n_keep, char* err,
+                              uint64_t err_cap);
+uint32_t herro_reads_count(const herro_reads* r);
+const uint8_t* herro_reads_seq(const herro_reads* r);
+const uint8_t* herro_reads_qual(const herro_reads* r);
+const uint64_t* herro_reads_off(const herro_reads* r);            /* [n + 1] */
+const char* const* herro_reads_ids(const herro_reads* r);         /* [n] */
+const char* const* herro_reads_descs(const herro_reads* r);       /* [n], NULL entries: no description */
+void herro_reads_free(herro_reads* r);
+
+/* One window of `herro features` (output_features, features.rs:724-764): <dir>/<wid>.ids.txt (one id per line),
+ * <wid>.features.npy = u8 [2, length, 31] (ASCII bases [length][31], then qualities), <wid>.supported.npy = records
+ * {pos: <u2, ins: u1}.  NPY format 1.0, C order, header as numpy writes it (dict padded with spaces to a multiple of 64
+ * bytes). */
+int herro_write_window_features(const char* dir, uint32_t wid, const char* const* ids, uint32_t n_ids, const uint8_t* bases,
+                                const uint8_t* quals, uint32_t length, const uint16_t* sup_pos, const uint8_t* sup_ins,
+                                uint32_t n_sup);
+/* `herro features` for a featurized job (FeatsGenOutput, features.rs:783-839): every window of every target into
+ * <base_dir>/<read id of the target>/, read_names[rid] for all reads of the store.  Returns the number of windows
+ * written or a negative error. */
+int64_t herro_job_write_features(herro_job* job, const char* base_dir, const char* const* read_names);
+
 #ifdef __cplusplus
 }
 #endif

@@ -208,7 +208,8 @@ def test_job_from_paf_text_equals_job_from_arrays():
 
 
 def test_features_directory_equals_oracle(tmp_path):
-    """`herro features` sink (features.rs:724-764): product files == files written from the oracle's windows."""
+    """`herro features` sink (features.rs:724-764): files written by the library (herro_job_write_features) == files written
+    from the oracle's windows by an independent writer (numpy)."""
     import os
     from herro_amd import io as hio
     sb = synth.generate(3, 900, 10, seed=21, flank_min=30, flank_max=60, p_partial=0.2)
@@ -217,21 +218,28 @@ def test_features_directory_equals_oracle(tmp_path):
     store = O.store_from_synth(sb)
     job = api.job_from_synth(c, sb, 256)
     job.featurize()
-    tw, w0 = [], 0
+    w0 = 0
     for t in range(sb.n_targets):
         rid, rows, cigs = O.target_alignments(sb, t)
         res = store.extract_features(rid, rows, cigs, 256)
-        d = str(tmp_path / "oracle" / sb.read_name(rid))
+        d = tmp_path / "oracle" / sb.read_name(rid)
+        os.makedirs(d, exist_ok=True)
         for w in range(len(res)):
             ow = res.window(w)
-            hio.write_window_features(d, w, [sb.read_name(int(q)) for q in ow.qids], ow.bases, ow.quals, ow.sup_pos, ow.sup_ins)
-        tw.append((rid, w0, len(res)))
+            np.save(d / f"{w}.features.npy", np.ascontiguousarray(np.stack([ow.bases, ow.quals], axis=0)))
+            sup = np.zeros(len(ow.sup_pos), hio.SUPPORTED_DTYPE)
+            sup["pos"], sup["ins"] = ow.sup_pos, ow.sup_ins
+            np.save(d / f"{w}.supported.npy", sup)
+            (d / f"{w}.ids.txt").write_text("".join(sb.read_name(int(q)) + "\n" for q in ow.qids))
         w0 += len(res)
-    n = hio.write_job_features(job, str(tmp_path / "product"), sb.read_name, tw)
+    n = hio.write_job_features(job, str(tmp_path / "product"), [sb.read_name(i) for i in range(sb.n_reads)])
     assert n == w0 == job.n_windows
+    n_files = 0
     for root, _, files in os.walk(tmp_path / "oracle"):
         for f in files:
             a = open(os.path.join(root, f), "rb").read()
             b = open(os.path.join(str(root).replace("/oracle/", "/product/"), f), "rb").read()
             assert a == b, (root, f)
+            n_files += 1
+    assert n_files == 3 * w0
     job.close()

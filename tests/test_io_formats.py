@@ -1,15 +1,35 @@
-"""not-gpu: the FASTQ reader (get_reads rules, haec_io.rs:37-75) and the `herro features` file layout
-(features.rs:724-764) written from the oracle's windows."""
+"""not-gpu: the reads reader (get_reads rules, haec_io.rs:37-75, needletail's record rules) and the `herro features` file
+layout (features.rs:724-764), both behind the C ABI (csrc/fastx.cpp), against independent checkers: a plain Python parser
+and numpy's own .npy writer."""
 import gzip
 import os
 
 import numpy as np
+import pytest
 
 import oracle_lib as O
 from herro_amd import io as hio, synth
 
 
-def test_read_fastq_rules(tmp_path):
+def _py_fastq(text: bytes, min_length=0, keep=None):
+    """Checker: 4-line FASTQ only, get_reads' rules restated in Python."""
+    out = []
+    lines = text.split(b"\n")
+    i = 0
+    while i + 3 < len(lines) + 1 and i < len(lines) and lines[i]:
+        h, s, q = lines[i].rstrip(b"\r")[1:], lines[i + 1].rstrip(b"\r"), lines[i + 3].rstrip(b"\r")
+        i += 4
+        if len(s) < min_length:
+            continue
+        cut = min((k for k in (h.find(b" "), h.find(b"\t")) if k >= 0), default=-1)
+        rid, desc = (h, None) if cut < 0 else (h[:cut], h[cut + 1:])
+        if keep is not None and rid.decode() not in keep:
+            continue
+        out.append((rid, desc, s, q))
+    return out
+
+
+def test_read_fastx_rules(tmp_path):
     recs = [(b"r0 some description\twith tab", b"ACGTACGT", b"IIIIIIII"), (b"r1", b"AC", b"II"),
             (b"r2\tdesc", b"ACGTN", b"!!!!!"), (b"r3", b"ACGTAAAA", b"56789:;<")]
     txt = b"".join(b"@" + h + b"\n" + s + b"\n+\n" + q + b"\n" for h, s, q in recs)
@@ -18,19 +38,39 @@ def test_read_fastq_rules(tmp_path):
     pg = tmp_path / "x.fastq.gz"
     with gzip.open(pg, "wb") as f:
         f.write(txt)
-    for path in (str(p), str(pg)):
-        r = hio.read_fastq(path, min_length=3)
-        assert r.ids == [b"r0", b"r2", b"r3"]
-        assert r.descriptions == [b"some description\twith tab", b"desc", None]
+    pc = tmp_path / "crlf.fastq"
+    pc.write_bytes(txt.replace(b"\n", b"\r\n"))
+    want = _py_fastq(txt, 3)
+    for path in (str(p), str(pg), str(pc)):
+        r = hio.read_fastx(path, min_length=3)
+        assert r.ids == [w[0] for w in want] == [b"r0", b"r2", b"r3"]
+        assert r.descriptions == [w[1] for w in want] == [b"some description\twith tab", b"desc", None]
         assert r.off.tolist() == [0, 8, 13, 21]
-        assert bytes(r.seq[8:13]) == b"ACGTN" and bytes(r.qual[13:21]) == b"56789:;<"
-    r = hio.read_fastq(str(p), core={"r0"}, neighbour={"r3"})
+        assert bytes(r.seq) == b"".join(w[2] for w in want) and bytes(r.qual) == b"".join(w[3] for w in want)
+    r = hio.read_fastx(str(p), core={"r0"}, neighbour={"r3"})
     assert r.ids == [b"r0", b"r3"]
-    r = hio.read_fastq(str(p), core={"r0"})          # filter needs both sets (haec_io.rs:63)
+    r = hio.read_fastx(str(p), core={"r0"})          # filter needs both sets (haec_io.rs:63)
     assert len(r.ids) == 4
+    # multi-line FASTQ (needletail accepts it): sequence and qualities wrapped at 3
+    ml = tmp_path / "ml.fastq"
+    ml.write_bytes(b"@m0 d\nACG\nTAC\nGT\n+m0\nIII\nIII\nII\n@m1\nAC\n+\nII\n")
+    r = hio.read_fastx(str(ml))
+    assert r.ids == [b"m0", b"m1"] and bytes(r.seq) == b"ACGTACGTAC" and bytes(r.qual) == b"IIIIIIIIII" and r.off.tolist() == [0, 8, 10]
+    # what the reference panics on
+    fa = tmp_path / "x.fasta"
+    fa.write_bytes(b">r0\nACGT\nACGT\n")
+    with pytest.raises(ValueError, match="Qualities should be present"):
+        hio.read_fastx(str(fa))
+    assert hio.read_fastx(str(fa), min_length=100).ids == []          # ... unless the length filter drops the record first
+    bad = tmp_path / "bad.fastq"
+    bad.write_bytes(b"@r0\nACGT\n+\nII\n")
+    with pytest.raises(ValueError, match="Error parsing fastx file"):
+        hio.read_fastx(str(bad))
+    with pytest.raises(ValueError, match="Cannot open"):
+        hio.read_fastx(str(tmp_path / "missing.fastq"))
 
 
-def test_features_layout_from_oracle_windows(tmp_path):
+def test_features_files_equal_numpy_written(tmp_path):
     sb = synth.generate(2, 700, 8, seed=3, flank_min=30, flank_max=50)
     store = O.store_from_synth(sb)
     rid, rows, cigs = O.target_alignments(sb, 0)
@@ -41,11 +81,18 @@ def test_features_layout_from_oracle_windows(tmp_path):
         hio.write_window_features(d, w, [sb.read_name(int(q)) for q in ow.qids], ow.bases, ow.quals, ow.sup_pos, ow.sup_ins)
     for w in range(len(res)):
         ow = res.window(w)
+        # independent writer: numpy
+        ref = tmp_path / "np"
+        os.makedirs(ref, exist_ok=True)
+        np.save(ref / f"{w}.features.npy", np.ascontiguousarray(np.stack([ow.bases, ow.quals], axis=0)))
+        sup = np.zeros(len(ow.sup_pos), hio.SUPPORTED_DTYPE)
+        sup["pos"], sup["ins"] = ow.sup_pos, ow.sup_ins
+        np.save(ref / f"{w}.supported.npy", sup)
+        for name in (f"{w}.features.npy", f"{w}.supported.npy"):
+            assert open(os.path.join(d, name), "rb").read() == open(ref / name, "rb").read(), name
         f = np.load(os.path.join(d, f"{w}.features.npy"))
         assert f.dtype == np.uint8 and f.shape == (2, ow.bases.shape[0], 31) and not np.isfortran(f)
         assert np.array_equal(f[0], ow.bases) and np.array_equal(f[1], ow.quals)
         s = np.load(os.path.join(d, f"{w}.supported.npy"))
         assert s.dtype == hio.SUPPORTED_DTYPE and s["pos"].tolist() == list(ow.sup_pos) and s["ins"].tolist() == list(ow.sup_ins)
         assert open(os.path.join(d, f"{w}.ids.txt")).read().split("\n")[:-1] == [sb.read_name(int(q)) for q in ow.qids]
-        hdr = open(os.path.join(d, f"{w}.features.npy"), "rb").read(128)
-        assert hdr[:6] == b"\x93NUMPY" and b"'descr': '|u1'" in hdr and b"'fortran_order': False" in hdr
