@@ -348,20 +348,21 @@ class Job:
             self.ctx._chk(int(n))
         return C.string_at(out, n).decode()   # (out.raw would copy the whole 16 MB buffer per call)
 
-    def fasta(self, read_ids, with_ends: bool = False):
-        """FASTA records of every target of the job, target order, as bytes (herro_job_fasta: one C call, text assembled by
-        the library's thread pool).  read_ids: one str/bytes per target.  with_ends: also the end offset of every target's records."""
+    def fasta(self, read_ids, with_ends: bool = False, as_array: bool = False):
+        """FASTA records of every target of the job, target order (herro_job_fasta: one sizing call, one call that writes the
+        text straight into a numpy buffer; the library's thread pool assembles it).  read_ids: one str/bytes per target.
+        with_ends: also the end offset of every target's records.  as_array: the text as a u8 array (no bytes copy)."""
         n = len(read_ids)
         arr = (C.c_char_p * max(n, 1))(*[r if isinstance(r, bytes) else r.encode() for r in read_ids])
-        need = self._l.herro_job_fasta(self.h, arr, None, None, 0, None)
+        ends = np.zeros(max(n, 1), np.uint64)
+        need = self._l.herro_job_fasta(self.h, arr, None, None, 0, ends.ctypes.data)
         if need < 0:
             self.ctx._chk(int(need))
-        out = C.create_string_buffer(max(int(need), 1))
-        ends = np.zeros(max(n, 1), np.uint64)
-        got = self._l.herro_job_fasta(self.h, arr, None, out, int(need), ends.ctypes.data)
+        out = np.empty(max(int(need), 1), np.uint8)
+        got = self._l.herro_job_fasta(self.h, arr, None, out.ctypes.data, int(need), None)
         if got < 0:
             self.ctx._chk(int(got))
-        text = C.string_at(out, got)
+        text = out[:got] if as_array else out[:got].tobytes()
         return (text, ends[:n]) if with_ends else text
 
     def stats(self) -> dict[str, int]:

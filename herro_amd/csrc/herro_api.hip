@@ -1710,33 +1710,60 @@ int herro_job_consensus_fetch(herro_job* job, uint64_t* n_bases) {
 
 // FASTA records of target t from the device consensus (corrected bases of every window on the host already): windows are
 // concatenated, the read is split where a window has fewer than two alignments (consensus.rs:90-111, lib.rs:282-317).
-static void fasta_from_device_consensus(const herro_job* job, uint32_t t, const char* id, const char* desc, std::string& fa) {
+// out == nullptr: only the size is computed.  Returns the bytes the records take.
+static uint64_t fasta_from_device_consensus(const herro_job* job, uint32_t t, const char* id, const char* desc, char* out) {
   const uint32_t w0 = job->tgt_win_off[t], w1 = job->tgt_win_off[t + 1];
   int64_t st = -1, en = -1;   // first..last window with n_alns > 1 (consensus.rs:90-101)
   for (uint32_t w = w0; w < w1; w++)
     if (std::min<uint32_t>(job->h_nkept[w], 30) > 1) { if (st < 0) st = w; en = w + 1; }
-  if (st < 0) return;
+  if (st < 0) return 0;
   // segments: maximal runs of corrected windows; empty segments are dropped like empty strings in the reference
-  std::vector<std::pair<uint32_t, uint32_t>> segs;   // [first window, one past last)
+  struct Seg { uint32_t a, b; uint64_t len; };
+  Seg segs_small[8];
+  std::vector<Seg> segs_big;
+  uint32_t n_seg = 0;
+  auto push = [&](uint32_t a, uint32_t b, uint64_t len) {
+    if (n_seg < 8) segs_small[n_seg] = Seg{a, b, len};
+    else { if (n_seg == 8) segs_big.assign(segs_small, segs_small + 8); segs_big.push_back(Seg{a, b, len}); }
+    n_seg++;
+  };
   uint32_t run0 = (uint32_t)st;
   uint64_t run_len = 0;
   for (uint32_t w = (uint32_t)st; w < (uint32_t)en; w++) {
     if (std::min<uint32_t>(job->h_nkept[w], 30) < 2) {
-      if (run_len) segs.emplace_back(run0, w);
+      if (run_len) push(run0, w, run_len);
       run0 = w + 1; run_len = 0;
       continue;
     }
     run_len += job->h_cons_len[w];
   }
-  if (run_len) segs.emplace_back(run0, (uint32_t)en);
-  for (size_t i = 0; i < segs.size(); i++) {
-    fa += ">"; fa += id;
-    if (segs.size() == 1) fa += " "; else { fa += ":"; fa += std::to_string(i); fa += " "; }
-    if (desc) fa += desc;
-    fa += "\n";
-    for (uint32_t w = segs[i].first; w < segs[i].second; w++) fa.append((const char*)job->h_cons_seq + job->win[w].row_off, job->h_cons_len[w]);
-    fa += "\n";
+  if (run_len) push(run0, (uint32_t)en, run_len);
+  const Seg* segs = n_seg > 8 ? segs_big.data() : segs_small;
+  const size_t id_len = strlen(id), desc_len = desc ? strlen(desc) : 0;
+  uint64_t o = 0;
+  char num[16];
+  for (uint32_t i = 0; i < n_seg; i++) {
+    int nd = 0;
+    if (n_seg > 1) nd = snprintf(num, sizeof num, ":%u", i);
+    const uint64_t head = 1 + id_len + (uint64_t)nd + 1 + desc_len + 1;   // '>' id [:i] ' ' [desc] '\n'
+    if (out) {
+      char* p = out + o;
+      *p++ = '>';
+      memcpy(p, id, id_len); p += id_len;
+      memcpy(p, num, (size_t)nd); p += nd;
+      *p++ = ' ';
+      if (desc_len) { memcpy(p, desc, desc_len); p += desc_len; }
+      *p++ = '\n';
+      for (uint32_t w = segs[i].a; w < segs[i].b; w++) {
+        if (std::min<uint32_t>(job->h_nkept[w], 30) < 2) continue;
+        memcpy(p, job->h_cons_seq + job->win[w].row_off, job->h_cons_len[w]);
+        p += job->h_cons_len[w];
+      }
+      *p++ = '\n';
+    }
+    o += head + segs[i].len + 1;
   }
+  return o;
 }
 
 // consensus.rs:86-227 + lib.rs:282-317 on the host, from device results.
@@ -1760,11 +1787,10 @@ int64_t herro_job_consensus_fasta(herro_job* job, uint32_t t, const char* id, co
   std::string cur;
   if (job->consensus_done) {  // device consensus: concatenate the windows' corrected bases
     if ((rc = consensus_to_host(job))) return rc;
-    std::string fa;
-    fasta_from_device_consensus(job, t, id, desc, fa);
-    if (fa.size() > cap) { ctx->err = "output buffer too small"; return HERRO_E_INVALID; }
-    std::memcpy(out, fa.data(), fa.size());
-    return (int64_t)fa.size();
+    const uint64_t need = fasta_from_device_consensus(job, t, id, desc, nullptr);
+    if (need > cap) { ctx->err = "output buffer too small"; return HERRO_E_INVALID; }
+    fasta_from_device_consensus(job, t, id, desc, out);
+    return (int64_t)need;
   }
   static const char UP[10] = {'A', 'C', 'G', 'T', '*', 'A', 'C', 'G', 'T', '*'};
   static const int CNT[10] = {0, 1, 2, 3, 4, 0, 1, 2, 3, 4};
@@ -1842,19 +1868,17 @@ int64_t herro_job_fasta(herro_job* job, const char* const* ids, const char* cons
   (void)hipSetDevice(ctx->device);
   if ((rc = consensus_to_host(job))) return rc;
   const uint32_t nt = job->n_targets;
-  std::vector<std::string> recs(nt);   // per target, built by the pool (only text assembly is left on the host)
-  host_pool(ctx).run((nt + 63) / 64, [&](uint32_t b) {
-    for (uint32_t t = b * 64; t < std::min(nt, (b + 1) * 64); t++) {
-      if (!ids[t]) continue;
-      fasta_from_device_consensus(job, t, ids[t], descs ? descs[t] : nullptr, recs[t]);
-    }
-  });
-  uint64_t tot = 0;
-  for (uint32_t t = 0; t < nt; t++) { tot += recs[t].size(); if (rec_end) rec_end[t] = tot; }
+  // sizes first (cheap: sums of window lengths), then every target's text straight into the caller's buffer by the pool
+  std::vector<uint64_t> end(nt + 1, 0);
+  for (uint32_t t = 0; t < nt; t++) end[t + 1] = end[t] + (ids[t] ? fasta_from_device_consensus(job, t, ids[t], descs ? descs[t] : nullptr, nullptr) : 0);
+  const uint64_t tot = end[nt];
+  if (rec_end) for (uint32_t t = 0; t < nt; t++) rec_end[t] = end[t + 1];
   if (!out) return (int64_t)tot;
   if (tot > cap) { ctx->err = "output buffer too small (" + std::to_string(tot) + " bytes needed)"; return HERRO_E_INVALID; }
-  uint64_t o = 0;
-  for (uint32_t t = 0; t < nt; t++) { std::memcpy(out + o, recs[t].data(), recs[t].size()); o += recs[t].size(); }
+  host_pool(ctx).run((nt + 63) / 64, [&](uint32_t b) {
+    for (uint32_t t = b * 64; t < std::min(nt, (b + 1) * 64); t++)
+      if (ids[t]) fasta_from_device_consensus(job, t, ids[t], descs ? descs[t] : nullptr, out + end[t]);
+  });
   return (int64_t)tot;
 }
 

@@ -21,7 +21,10 @@ import numpy as np
 def partition_targets(n_windows_per_target: np.ndarray, world_size: int) -> list[np.ndarray]:
     """Greedy longest-first partition of target indices into `world_size` shards with balanced window
     counts.  Deterministic: every rank computes the same partition from the same lengths."""
-    order = np.argsort(-np.asarray(n_windows_per_target, dtype=np.int64), kind="stable")
+    nwt = np.asarray(n_windows_per_target, dtype=np.int64)
+    if len(nwt) and (nwt == nwt[0]).all():   # equal reads: contiguous blocks are as balanced as any assignment, and cost nothing to cut
+        return [np.asarray(p, np.int64) for p in np.array_split(np.arange(len(nwt), dtype=np.int64), world_size)]
+    order = np.argsort(-nwt, kind="stable")
     load = np.zeros(world_size, np.int64)
     shards: list[list[int]] = [[] for _ in range(world_size)]
     for t in order:
@@ -89,30 +92,54 @@ def unpack_work(buf: np.ndarray):
     buf = np.ascontiguousarray(buf, np.uint8)
     n, m, c = (int(x) for x in buf[:24].view(np.uint64))
     o = 24
-    aln_off = buf[o:o + 8 * (n + 1)].view(np.uint64).copy(); o += 8 * (n + 1)
-    cig_off = buf[o:o + 8 * m].view(np.uint64).copy(); o += 8 * m
-    rids = buf[o:o + 4 * n].view(np.uint32).copy(); o += 4 * n
-    rows = buf[o:o + 40 * m].view(np.uint32).reshape(m, 10).copy(); o += 40 * m
-    cig = buf[o:o + c].copy()
+    # views, not copies (every piece is naturally aligned: 24-byte header, then the u64 arrays, then the u32 ones)
+    aln_off = buf[o:o + 8 * (n + 1)].view(np.uint64); o += 8 * (n + 1)
+    cig_off = buf[o:o + 8 * m].view(np.uint64); o += 8 * m
+    rids = buf[o:o + 4 * n].view(np.uint32); o += 4 * n
+    rows = buf[o:o + 40 * m].view(np.uint32).reshape(m, 10); o += 40 * m
+    cig = buf[o:o + c]
     return rids, aln_off, rows, cig_off, cig
 
 
-def shard_work(sb, targets) -> np.ndarray:
-    """pack_work of the given target indices of a SynthBatch-like object (tgt_rid, tgt_aln_off, aln, cig_off, cig)."""
-    targets = [int(t) for t in targets]
-    a0 = [int(sb.tgt_aln_off[t]) for t in targets]
-    a1 = [int(sb.tgt_aln_off[t + 1]) for t in targets]
-    sel = np.concatenate([np.arange(x, y) for x, y in zip(a0, a1)]).astype(np.int64) if targets else np.zeros(0, np.int64)
+def shard_arrays(sb, targets):
+    """(rids, aln_off, rows, cig_off, cig) of the given target indices of a SynthBatch-like object (tgt_rid, tgt_aln_off, aln,
+    cig_off, cig): the arguments of a corrector.  The CIGAR blob is the data set's own (offsets into it): no text is copied —
+    what rank 0 uses for its own shard."""
+    targets = np.asarray(targets, np.int64)
+    a0 = np.asarray(sb.tgt_aln_off, np.int64)[targets] if len(targets) else np.zeros(0, np.int64)
+    a1 = np.asarray(sb.tgt_aln_off, np.int64)[targets + 1] if len(targets) else np.zeros(0, np.int64)
+    cnt = a1 - a0
     aln_off = np.zeros(len(targets) + 1, np.uint64)
-    aln_off[1:] = np.cumsum([y - x for x, y in zip(a0, a1)])
-    rows = sb.aln[sel]
-    lens = rows[:, 9].astype(np.uint64) if len(sel) else np.zeros(0, np.uint64)
-    cig_off = np.zeros(len(sel), np.uint64)
-    if len(sel):
+    aln_off[1:] = np.cumsum(cnt)
+    total = int(aln_off[-1])
+    contiguous = len(targets) > 0 and total == int(a1[-1] - a0[0])            # consecutive targets: plain slices
+    if contiguous:
+        rows = sb.aln[int(a0[0]):int(a1[-1])]
+        src_off = np.asarray(sb.cig_off, np.uint64)[int(a0[0]):int(a1[-1])]
+    else:
+        sel = np.repeat(a0 - aln_off[:-1].astype(np.int64), cnt) + np.arange(total, dtype=np.int64)
+        rows = sb.aln[sel]
+        src_off = np.asarray(sb.cig_off, np.uint64)[sel] if total else np.zeros(0, np.uint64)
+    return np.asarray(sb.tgt_rid)[targets], aln_off, rows, src_off, sb.cig
+
+
+def shard_work(sb, targets) -> np.ndarray:
+    """pack_work of the given target indices: the message for another rank.  Vectorised: one slice of the CIGAR blob per run of
+    alignments whose texts lie back to back (they do in every producer here)."""
+    rids, aln_off, rows, src_off, blob = shard_arrays(sb, targets)
+    total = len(rows)
+    lens = rows[:, 9].astype(np.uint64) if total else np.zeros(0, np.uint64)
+    cig_off = np.zeros(total, np.uint64)
+    if total:
         cig_off[1:] = np.cumsum(lens)[:-1]
-    pieces = [sb.cig[int(sb.cig_off[a]):int(sb.cig_off[a]) + int(l)] for a, l in zip(sel, lens)]
+    brk = np.ones(total, bool)
+    if total > 1:
+        brk[1:] = src_off[1:] != src_off[:-1] + lens[:-1]
+    run0 = np.flatnonzero(brk)
+    run1 = np.concatenate([run0[1:], [total]]) if total else run0
+    pieces = [blob[int(src_off[i]):int(src_off[j - 1] + lens[j - 1])] for i, j in zip(run0, run1)]
     cig = np.concatenate(pieces) if pieces else np.zeros(0, np.uint8)
-    return pack_work(sb.tgt_rid[targets], aln_off, rows, cig_off, cig)
+    return pack_work(rids, aln_off, rows, cig_off, cig)
 
 
 def _exchange_sizes(sizes_on_root, n_local: int, root_to_all: bool, group=None) -> list[int]:
@@ -227,6 +254,8 @@ def merge_records(parts):
     parts = [p for p in parts if len(p[0])]
     if not parts:
         return np.zeros(0, np.uint32), np.zeros(0, np.uint64), np.zeros(0, np.uint8)
+    if len(parts) == 1:
+        return parts[0]
     base = np.cumsum([0] + [len(p[2]) for p in parts[:-1]]).astype(np.uint64)
     return (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] + b for p, b in zip(parts, base)]),
             np.concatenate([np.frombuffer(p[2], np.uint8) if isinstance(p[2], (bytes, bytearray)) else p[2] for p in parts]))
@@ -248,12 +277,13 @@ def correct_sharded(sb, n_windows_per_target, correct_fn, group=None):
     dist = _dist()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    msgs = None
-    if rank == 0:
+    if rank == 0:   # its own shard needs no message: views into the data set
         parts = partition_targets(n_windows_per_target, world)
-        msgs = [shard_work(sb, p) for p in parts]
-    mine = scatter_bytes(msgs, group) if world > 1 else msgs[0]
-    rids, aln_off, rows, cig_off, cig = unpack_work(mine)
+        if world > 1:
+            scatter_bytes([np.zeros(0, np.uint8)] + [shard_work(sb, p) for p in parts[1:]], group)
+        rids, aln_off, rows, cig_off, cig = shard_arrays(sb, parts[0])
+    else:
+        rids, aln_off, rows, cig_off, cig = unpack_work(scatter_bytes(None, group))
     rec = correct_fn(rids, aln_off, rows, cig_off, cig) if len(rids) else (np.zeros(0, np.uint32), np.zeros(0, np.uint64), b"")
     if world == 1:
         return merge_records([rec]), len(rids)
@@ -282,7 +312,7 @@ def hip_corrector(ctxs, window_size: int, batch: int, read_name, group_targets: 
             job.infer(batch, 1)
             job.consensus()
             job.consensus_fetch()
-            text, ends = job.fasta([read_name(int(r)) for r in rids[t0:t1]], with_ends=True)
+            text, ends = job.fasta([read_name(int(r)) for r in rids[t0:t1]], with_ends=True, as_array=True)
             out[g] = (rids[t0:t1], ends, text)
             job.close()
 

@@ -6,7 +6,7 @@ import pytest
 
 import gpu_common as G
 import oracle_lib as O
-from herro_amd import api, synth
+from herro_amd import api, model_io, synth
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
