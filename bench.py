@@ -476,13 +476,16 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")     # written by tools/pmc_traffic.py from a --pmc run
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("group") != G or tj.get("precision", 1) != args.precision:
-                tj = None                                           # counters of another launch size / operand format: not this run's traffic
+            if tj.get("precision", 1) != args.precision:
+                tj = None                                           # counters of another operand format: not this run's traffic
 
         def roof_of(k):
             avg_s = tm[k][0] / max(tm[k][1], 1) * 1e-3
             bound, work, _ = alg[k]
-            traffic = tj["kernels"][k]["hbm_bytes_corrected"] if tj and k in tj.get("kernels", {}) else None
+            # PMC bytes were collected per launch of tj["windows_per_launch"] windows; every kernel's traffic is proportional to
+            # the windows it processes, so it is scaled to this run's launch size
+            traffic = (tj["kernels"][k]["hbm_bytes_corrected"] / tj.get("windows_per_launch", tj["group"] * 128) * G * args.batch
+                       if tj and k in tj.get("kernels", {}) else None)
             if bound == "hbm":
                 return {"kernel": k, "bound": "hbm", "achieved": work / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": work / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,

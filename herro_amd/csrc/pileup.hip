@@ -535,7 +535,10 @@ __global__ __launch_bounds__(256) void k_win(JobDev J) {
 // =====================================================================================================
 constexpr int LY_NT = 256;
 constexpr uint32_t TCAP = 2 * LY_NT;   // tiles per window (8192 positions x 51 rows / 1024 = 408)
-__host__ __device__ inline size_t layout_lds(uint32_t W) { return (size_t)(W + 1) * 4; }
+// the per-position array is walked 16 (W / 256) consecutive positions per thread: one pad word per 16 positions makes the
+// lanes' stride 17 instead of 16 (two LDS banks for the whole wave otherwise)
+#define MI(p) ((p) + ((p) >> 4))
+__host__ __device__ inline size_t layout_lds(uint32_t W) { return (size_t)(W + 1 + ((W + 1) >> 4) + 1) * 4; }
 
 __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
   extern __shared__ __attribute__((aligned(16))) uint32_t ly_smem[];
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
   if (tid < 32) s_sel[tid] = NONE;
   if (tid == 0) s_maxne = 0;
   for (uint32_t t = tid; t < TCAP; t += LY_NT) s_tcnt[t] = 0;
-  for (uint32_t p = tid; p <= win_len; p += LY_NT) s_mi[p] = 0;
+  for (uint32_t p = tid; p <= win_len; p += LY_NT) s_mi[MI(p)] = 0;
   __syncthreads();
   // ---- score n/(n+d)*ln(n+d+1) in f64 (features.rs:505-510); stable descending rank (features.rs:512-513)
   {
@@ -648,7 +651,7 @@ __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
       const uint32_t i = b * 64u + sub + 8u * k;
       if (i < ne) {
         const uint32_t p = v[k].x & 0xffffu;
-        if (p < win_len) atomicMax(&s_mi[p], v[k].w);   // untrimmed length (features.rs:64-79)
+        if (p < win_len) atomicMax(&s_mi[MI(p)], v[k].w);   // untrimmed length (features.rs:64-79)
         J.sev[wbase + sevb + i] = make_uint2(v[k].x, (v[k].y & 0xffffffu) | (lc << 24));
       }
     }
@@ -660,25 +663,25 @@ __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
     const uint32_t ch = (win_len + LY_NT - 1) / LY_NT;
     const uint32_t p0 = min(tid * ch, win_len), p1 = min(p0 + ch, win_len);
     uint32_t local = 0;
-    for (uint32_t p = p0; p < p1; p++) local += 1u + s_mi[p];
+    for (uint32_t p = p0; p < p1; p++) local += 1u + s_mi[MI(p)];
     uint32_t Lf;
     uint32_t r = blk_scan<LY_NT>(local, &Lf, s_wave);
     const uint32_t tile0 = (uint32_t)wd.col_off;
     for (uint32_t p = p0; p < p1; p++) {
-      const uint32_t rn = r + 1u + s_mi[p];
-      s_mi[p] = r;
+      const uint32_t rn = r + 1u + s_mi[MI(p)];
+      s_mi[MI(p)] = r;
       const uint32_t i = (rn - 1u) / ROWCAP;          // a position has at most 51 rows: it holds at most one chunk start
       if (i * ROWCAP >= r) J.chdr2[tile0 + i] = make_uint2(p, r == i * ROWCAP ? 1u : 0u);
       r = rn;
     }
-    if (tid == 0) { s_mi[win_len] = Lf; J.win_Lf[w] = Lf; }
+    if (tid == 0) { s_mi[MI(win_len)] = Lf; J.win_Lf[w] = Lf; }
   }
   __syncthreads();
   PROF_MARK(J, 2, 3);
-  for (uint32_t p = tid; p <= win_len; p += LY_NT) J.row_of_pos2[wd.pos_off + p] = s_mi[p];
+  for (uint32_t p = tid; p <= win_len; p += LY_NT) J.row_of_pos2[wd.pos_off + p] = s_mi[MI(p)];
   // ---- the events once more, now that rows are known: every tile of ROWCAP rows gets the list of the inserted-base runs that
   // reach into it {position | length << 16, query index, first 16 bases, column | hidden rows << 8} (k_tokens, phase B)
-  const uint32_t tile0 = (uint32_t)wd.col_off, n_t = (s_mi[win_len] + ROWCAP - 1) / ROWCAP;
+  const uint32_t tile0 = (uint32_t)wd.col_off, n_t = (s_mi[MI(win_len)] + ROWCAP - 1) / ROWCAP;
   auto each_run = [&](uint32_t b, auto&& fn) {   // fn(event, hidden rows, first tile, last tile) for this thread's events of batch b
     if (nbatch > 1) load(b);                     // a single batch is still in registers
 #pragma unroll
@@ -687,7 +690,7 @@ __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
       if (i >= ne) continue;
       const uint32_t p = v[k].x & 0xffffu, len = v[k].x >> 16;
       if (p >= win_len) continue;
-      const uint32_t rp = s_mi[p], room = s_mi[p + 1] - rp - 1u;
+      const uint32_t rp = s_mi[MI(p)], room = s_mi[MI(p + 1)] - rp - 1u;
       uint32_t hide = 0;
       if (i + 1 < ne && (hx[k] & 0xffffu) == p) {
         hide = hx[k] >> 16;

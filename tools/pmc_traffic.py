@@ -20,14 +20,15 @@ def avg(path, counter):
 
 
 f, w = avg(sys.argv[1], "FETCH_SIZE"), avg(sys.argv[2], "WRITE_SIZE")
-rename = {"k_ow_stats": "ow_stats", "k_win_rank": "win_rank", "k_pass1_pos": "pass1_pos", "k_select_layout": "select_layout",
-          "k_final_tiles": "final_tiles", "k_sup_compact": "sup_compact", "k_patch_conv1_s": "patch_conv1",
-          "k_tile_plan": "tile_plan", "k_rf_quals": "rf_quals", "k_conv_w": "conv_fused", "k_gemm_g": "fc_gemm",
-          "k_layers": "layers_fused", "k_final_tiles_t": "final_tiles", "k_gemm_g256": "fc_gemm", "k_add_pe": "add_pe", "k_build_tokens": "build_tokens", "k_consensus": "consensus",
+rename = {"k_cols": "cols", "k_win": "win", "k_layout": "layout", "k_tokens": "tokens", "k_supgather": "supgather", "k_rfq": "rf_quals",
+          "k_quals": "rf_quals", "k_consensus": "consensus", "k_cigar_scan": "cigar_scan", "k_patch_conv1_s": "patch_conv1", "k_conv_w": "conv_fused",
+          "k_gemm_g": "fc_gemm", "k_layers": "layers_fused", "k_gemm_g256": "fc_gemm", "k_add_pe": "add_pe", "k_build_tokens": "build_tokens",
           "k_conv_h": "conv_fused", "k_fc_h": "fc_gemm", "k_layers_h": "layers_fused", "k_layers_p": "layers_fused", "k_build_tokens_h": "build_tokens"}
-out = {"group": int(sys.argv[3]), "precision": int(sys.argv[5]) if len(sys.argv) > 5 else 4, "unit": "bytes per launch", "kernels": {}}
+out = {"group": int(sys.argv[3]), "windows_per_launch": int(sys.argv[3]) * 128, "precision": int(sys.argv[5]) if len(sys.argv) > 5 else 4,
+       "unit": "bytes per launch (per_window: the same divided by windows_per_launch — what bench.py scales to its own launch size)", "kernels": {}}
 for k in sorted(set(f) | set(w)):
     fb, wb = f.get(k, 0.0) * 1024, w.get(k, 0.0) * 1024
-    out["kernels"][rename.get(k, k)] = {"fetch_bytes_raw": fb, "write_bytes": wb, "hbm_bytes_corrected": 2 * fb + wb}
+    out["kernels"][rename.get(k, k)] = {"fetch_bytes_raw": fb, "write_bytes": wb, "hbm_bytes_corrected": 2 * fb + wb,
+                                        "hbm_bytes_corrected_per_window": (2 * fb + wb) / out["windows_per_launch"]}
 json.dump(out, open(sys.argv[4], "w"), indent=1)
-print(json.dumps({k: out["kernels"][k] for k in ("final_tiles", "layers_fused") if k in out["kernels"]}, indent=1))
+print(json.dumps({k: round(v["hbm_bytes_corrected"] / 1e6, 1) for k, v in out["kernels"].items()}))
