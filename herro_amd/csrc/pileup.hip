@@ -216,15 +216,20 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
   constexpr int QI = 5;
   uint32_t v0[QI], v1[QI], u0[QI], u1[QI];
   {
-    const uint64_t qbase = d.q_woff + qw0, tbase = d.t_woff + (d.wtstart >> 5);
+    // scalar bases, 32-bit lane offsets clamped once against the end of the plane arrays
+    const uint64_t qbase = min(d.q_woff + qw0, pmax), tbase = min(d.t_woff + (d.wtstart >> 5), pmax);
+    const uint32_t qlast = (uint32_t)min((uint64_t)(nqw - 1u), pmax - qbase), tlast = (uint32_t)min((uint64_t)(nw + 1u), pmax - tbase);
+    const uint32_t* __restrict__ gq0 = J.read_p0 + qbase;
+    const uint32_t* __restrict__ gq1 = J.read_p1 + qbase;
+    const uint32_t* __restrict__ gt0 = J.read_p0 + tbase;
+    const uint32_t* __restrict__ gt1 = J.read_p1 + tbase;
 #pragma unroll
     for (int i = 0; i < QI; i++) {
-      const uint64_t gi = min(qbase + min(lane + 64u * i, nqw - 1u), pmax);
-      v0[i] = J.read_p0[gi];
-      v1[i] = J.read_p1[gi];
-      const uint64_t ti = min(tbase + min(lane + 64u * i, nw + 1u), pmax);
-      u0[i] = J.read_p0[ti];
-      u1[i] = J.read_p1[ti];
+      const uint32_t qi = min(lane + 64u * i, qlast), ti = min(lane + 64u * i, tlast);
+      v0[i] = gq0[qi];
+      v1[i] = gq1[qi];
+      u0[i] = gt0[ti];
+      u1[i] = gt1[ti];
     }
   }
 #pragma unroll
@@ -371,7 +376,11 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
       }
     }
   }
-  mm = wsum(mm); ss = wsum(ss); isum = wsum(isum); dsum = wsum(dsum);
+  {
+    const uint32_t ms = wsum(mm | (ss << 16));   // both <= 8192
+    mm = ms & 0xffffu; ss = ms >> 16;
+    isum = wsum(isum); dsum = wsum(dsum);
+  }
   if (lane == 0) {
     const uint32_t m_ = mm - ss;
     J.ow_keep[o] = keep ? 1 : 0;
@@ -420,7 +429,7 @@ __global__ __launch_bounds__(256) void k_win(JobDev J) {
   cnt.add(ColPlanes{vm, tlo, thi, 0u});  // the target column: always a base on these rows
   PROF_MARK(J, 1, 0);
   uint32_t n_kept = 0;
-  constexpr int UB = 8;    // columns whose loads are in flight together
+  constexpr int UB = 8;    // columns whose loads are in flight together (16: two round trips instead of four, but 152 VGPRs — measured no faster)
   const uint4* __restrict__ ocol = J.ocol;   // read-only here: uniform addresses -> scalar loads
   uint32_t match[4 * UB];  // first 32 columns: positions where the column shows the target's base (kept for the tallies)
 #pragma unroll
@@ -1049,7 +1058,7 @@ __host__ __device__ inline size_t quals_lds(uint32_t nw) {
 // sup_row[k] - half + i — dense stores.  (Single bytes scattered over the window's 146 KB of quality planes made every store a
 // read-modify-write of its own line: 0.6 GB of traffic per 4096 windows for 10 MB of payload.)
 template <bool FULL>
-__global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half, const uint64_t* __restrict__ sup_off, uint8_t* __restrict__ rf_q, uint32_t dbg) {
+__global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half, const uint64_t* __restrict__ sup_off, uint8_t* __restrict__ rf_q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pq_smem[];
   const uint32_t nw = J.nw;
   uint32_t* s_M = reinterpret_cast<uint32_t*>(pq_smem);                               // [30][nw] M planes of the selected columns
@@ -1065,7 +1074,6 @@ __global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half, const 
   const WinDesc wd = J.win[w];
   if (tid < 32) s_ct[tid] = J.ctab[(uint64_t)w * 32 + tid];
   if (!FULL && !nsup) return;
-  if (dbg & 16u) return;
   __syncthreads();
   if (tid < 64) {   // first LDS slot of every column's events
     const uint32_t ne = (tid >= 1 && tid < 32) ? s_ct[tid].n_ev : 0u;   // entry 0 (the target) carries the window's totals
@@ -1120,7 +1128,6 @@ __global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half, const 
     if (!FULL && tid < min(kper, nsup)) s_rr[tid] = srow;   // staged through s_rr: rewritten below once the rows are expanded
   }
   __syncthreads();
-  if (dbg & 8u) return;
   uint32_t pre_rm = NONE, pre_r = 0;   // first pass: row-map entries travel while the rank directories are built
   const bool pre = !FULL && kper <= PQ_NT && min(kper, nsup) * span <= PQ_NT * 1u;
   if (pre) {
@@ -1143,7 +1150,6 @@ __global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half, const 
   }
   __syncthreads();
 
-  if (dbg & 4u) return;
   const uint64_t tq_off = s_ct[0].qual_off + wd.tstart;
   const uint64_t qmax = J.read_qual_bytes ? J.read_qual_bytes - 1 : 0;
   // address of the quality byte of cell (column c, position p, insertion ordinal j); NONE64: the cell holds no base ('!')
@@ -1263,11 +1269,11 @@ __global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half, const 
             }
             const uint32_t rm = s_rm[slot];
             live[u] = live[u] && idx0 + u * PQ_NT < total && rm != NONE;
-            src[u] = (live[u] && !(dbg & 1u)) ? cell_addr(evlds, c, rm & 0xffffu, rm >> 16) : NONE64;
+            src[u] = live[u] ? cell_addr(evlds, c, rm & 0xffffu, rm >> 16) : NONE64;
           }
           uint32_t qv[CB];
 #pragma unroll
-          for (int u = 0; u < CB; u++) qv[u] = J.read_qual[(src[u] == NONE64 || (dbg & 2u)) ? 0 : src[u]];
+          for (int u = 0; u < CB; u++) qv[u] = J.read_qual[src[u] == NONE64 ? 0 : src[u]];
 #pragma unroll
           for (int u = 0; u < CB; u++)
             if (live[u]) outp[dst[u]] = (uint8_t)(src[u] == NONE64 ? 33u : qv[u]);
@@ -1578,10 +1584,18 @@ __global__ __launch_bounds__(PC_NT) void k_consensus(JobDev J, const uint64_t* s
   for (uint32_t r = a; r < b; r++) nout += tmp[r] != 4u ? 1u : 0u;
   uint32_t total;
   uint32_t o = blk_scan<PC_NT>(nout, &total, s_wave);
+  // the thread's bases leave in aligned 4-byte stores where they can (single bytes at the two ragged ends): a byte store per
+  // base was a write transaction per base (PMC: 170 MB written per 4096 windows for 19 MB of bases)
+  uint32_t acc = 0, nacc = 0;
   for (uint32_t r = a; r < b; r++) {
     const uint32_t base = tmp[r];
-    if (base != 4u) seq[o++] = (uint8_t)"ACGT"[base];
+    if (base == 4u) continue;
+    const uint32_t ch = (uint32_t)(uint8_t)"ACGT"[base];
+    if ((o & 3u) != 0 && nacc == 0) { seq[o++] = (uint8_t)ch; continue; }   // head: up to the next 4-byte boundary
+    acc |= ch << (8 * nacc);
+    if (++nacc == 4) { *reinterpret_cast<uint32_t*>(seq + o) = acc; o += 4; acc = 0; nacc = 0; }
   }
+  for (uint32_t k = 0; k < nacc; k++) seq[o + k] = (uint8_t)(acc >> (8 * k));   // tail
   if (threadIdx.x == 0) J.cons_len[w] = total;
 }
 
@@ -1604,14 +1618,14 @@ void launch_rf_quals(const JobDev& J, uint32_t half, const uint64_t* sup_off, ui
     return;
   }
   pileup_opt_in_lds(reinterpret_cast<const void*>(k_quals<false>), 96 * 1024);   // windows of 8192: 62 KB dynamic + 10 KB static
-  hipLaunchKernelGGL(k_quals<false>, dim3(J.n_win), dim3(PQ_NT), quals_lds(J.nw), st, J, half, sup_off, rf_q, [] { const char* e = getenv("HERRO_QDBG"); return e ? (uint32_t)atoi(e) : 0u; }());
+  hipLaunchKernelGGL(k_quals<false>, dim3(J.n_win), dim3(PQ_NT), quals_lds(J.nw), st, J, half, sup_off, rf_q);
   KT_END(tm, st);
 }
 
 void launch_full_quals(const JobDev& J, hipStream_t st) {
   if (!J.n_win) return;
   pileup_opt_in_lds(reinterpret_cast<const void*>(k_quals<true>), 96 * 1024);
-  hipLaunchKernelGGL(k_quals<true>, dim3(J.n_win), dim3(PQ_NT), quals_lds(J.nw), st, J, 0u, (const uint64_t*)nullptr, (uint8_t*)nullptr, 0u);
+  hipLaunchKernelGGL(k_quals<true>, dim3(J.n_win), dim3(PQ_NT), quals_lds(J.nw), st, J, 0u, (const uint64_t*)nullptr, (uint8_t*)nullptr);
 }
 
 template <int NB>
