@@ -872,14 +872,15 @@ __global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J) {
       const CTab& h = s_ct[c];
       const uint32_t* pl = s_pl + (size_t)min(c, (uint32_t)HERRO_ROWS - 1u) * 3 * WPAD + wrel;
       const bool real = c < HERRO_ROWS;
-      const uint32_t m32 = real ? __funnelshift_r(pl[0], pl[1], sh) : 0u;
-      const uint32_t l32 = real ? __funnelshift_r(pl[WPAD], pl[WPAD + 1], sh) : 0u;
-      const uint32_t h32 = real ? __funnelshift_r(pl[2 * WPAD], pl[2 * WPAD + 1], sh) : 0u;
-      const uint32_t tt = real ? h.t_total : 0u;
+      const uint32_t rmask = real ? 0xffffffffu : 0u;   // loads unconditional (the pointer is clamped), then masked: a predicated load is a branch and a wait each
+      const uint32_t m32 = __funnelshift_r(pl[0], pl[1], sh) & rmask;
+      const uint32_t l32 = __funnelshift_r(pl[WPAD], pl[WPAD + 1], sh) & rmask;
+      const uint32_t h32 = __funnelshift_r(pl[2 * WPAD], pl[2 * WPAD + 1], sh) & rmask;
+      const uint32_t tt = h.t_total & rmask;
       const uint32_t r32 = mask_range(h.off - (int32_t)p_first, h.off + (int32_t)tt - (int32_t)p_first);
-      const uint32_t s5 = h.tokc & 0xffu, gapt = h.tokc >> 8;
-      const uint32_t lut_lo = gapt * 0x01010101u;                                   // no query base here: gap
-      const uint32_t lut_hi = (s5 * 0x01010101u) + 0x03020100u;                     // query base: its code + strand offset
+      const bool rev = (h.tokc & 0xffu) != 0;                                       // reverse strand: tokens a c g t #
+      const uint32_t lut_lo = rev ? 0x09090909u : 0x04040404u;                      // no query base here: gap
+      const uint32_t lut_hi = rev ? 0x08070605u : 0x03020100u;                      // query base: its code + strand offset
       const uint32_t tenx = (uint32_t)TOK_NONE * 0x01010101u;
       uint32_t T[4];
 #pragma unroll
@@ -890,7 +891,9 @@ __global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J) {
         // four positions -> four bytes: bit j of x lands on bit 8 j of x * 0x204081 (the partial products do not overlap)
         const uint32_t idx = ((__umul24(m4, 0x810204u) & 0x04040404u) | (__umul24(h4, 0x408102u) & 0x02020202u)) | (__umul24(l4, 0x204081u) & 0x01010101u);   // per byte: M << 2 | hi << 1 | lo
         const uint32_t Rb = __umul24(r4, 0x204081u) & 0x01010101u;
-        const uint32_t Rm = (Rb << 8) - Rb;                                         // 0xff in the bytes inside the overlap
+        uint32_t Rm;                                                                // 0xff in the bytes inside the overlap: (Rb << 8) - Rb
+        asm("v_lshlrev_b32 %0, 8, %1" : "=v"(Rm) : "v"(Rb));                        // (kept from being folded into a quarter-rate 32-bit multiply)
+        Rm -= Rb;
         const uint32_t tokMP = __builtin_amdgcn_perm(lut_hi, lut_lo, idx);
         const uint32_t tokP = (tokMP & Rm) | (tenx & ~Rm);                          // per position: base / gap / '.'
         const uint32_t defP = (lut_lo & Rm) | (tenx & ~Rm);                         // ... of an insertion row behind it: gap / '.'
