@@ -20,6 +20,8 @@ CASES = {
     "n_bases_quirk": dict(W=256, n=3, tl=1024, ov=12, kw=dict(flank_min=30, flank_max=60, p_n_base=0.01)),
     "tiny_window": dict(W=16, n=3, tl=200, ov=8, kw=dict(flank_min=2, flank_max=5)),
     "no_overlaps": dict(W=256, n=2, tl=700, ov=0, kw=dict(flank_min=30, flank_max=60)),
+    "largest_window_w8192": dict(W=8192, n=2, tl=3 * 8192 + 100, ov=12, kw=dict(p_partial=0.3)),
+    "window_not_a_multiple_of_32": dict(W=1000, n=3, tl=3500, ov=10, kw=dict(flank_min=100, flank_max=200, p_partial=0.3)),
 }
 
 
