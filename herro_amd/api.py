@@ -23,7 +23,7 @@ EXPORTS = [
     "herro_job_consensus_fasta", "herro_job_fasta", "herro_model_forward", "herro_timing_enable", "herro_timing_reset",
     "herro_timing_get", "herro_job_stats", "herro_debug_extract_windows",
     "herro_paf_parse", "herro_oec_read", "herro_paf_n_targets", "herro_paf_target_ids", "herro_paf_aln_off",
-    "herro_paf_alignments", "herro_paf_free", "herro_debug_host_ctx", "herro_debug_job_array",
+    "herro_paf_alignments", "herro_paf_free", "herro_debug_host_ctx", "herro_debug_job_array", "herro_debug_tile_plan",
     "herro_fastx_read", "herro_reads_count", "herro_reads_seq", "herro_reads_qual", "herro_reads_off", "herro_reads_ids",
     "herro_reads_descs", "herro_reads_free", "herro_write_window_features", "herro_job_write_features",
 ]
@@ -109,6 +109,8 @@ def lib():
         L.herro_debug_host_ctx.argtypes = [u32, vp, vp]
         L.herro_debug_job_array.restype = C.c_int64
         L.herro_debug_job_array.argtypes = [vp, i32, vp, vp]
+        L.herro_debug_tile_plan.restype = C.c_int64
+        L.herro_debug_tile_plan.argtypes = [vp, u32, i32, vp]
         _LIB = L
     return _LIB
 
@@ -145,6 +147,16 @@ def debug_extract_windows(row, cigar: bytes, n_windows: int, window_size: int) -
     if n < 0:
         raise HerroError(int(n), err.value.decode())
     return out[:n].astype(np.int64)
+
+
+def debug_tile_plan(counts, packed: bool = True) -> tuple[int, np.ndarray]:
+    """(tiles, order) of one fused launch over windows of `counts` informative rows (host only, herro_debug_tile_plan)."""
+    c = np.ascontiguousarray(counts, np.uint32)
+    order = np.zeros(max(len(c), 1), np.uint32)
+    n = lib().herro_debug_tile_plan(c.ctypes.data, len(c), int(packed), order.ctypes.data)
+    if n < 0:
+        raise HerroError(int(n), "herro_debug_tile_plan")
+    return int(n), order[:len(c)]
 
 
 @dataclass

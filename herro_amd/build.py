@@ -25,7 +25,8 @@ def build_hip(force: bool = False) -> str:
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    extra = ["-DHERRO_PROF_BUILD"] if os.environ.get("HERRO_PROF_BUILD", "0") not in ("", "0") else []   # kernel phase timers (job_dev.h)
+    cmd = [hipcc] + FLAGS + extra + ["-o", LIB] + [os.path.join(CSRC, s) for s in HIP_SOURCES]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + r.stdout)

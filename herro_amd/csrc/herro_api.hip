@@ -140,6 +140,7 @@ struct herro_ctx {
   std::vector<uint32_t> read_len, name_class;
   std::vector<uint64_t> h_word_off, h_qual_off;  // host copies: overlap descriptors carry them (saves the kernel a dependent load)
   bool host_only = false;  // herro_debug_host_ctx: no device; herro_job_create stops after the host half
+  bool tile_packing = [] { const char* e = getenv("HERRO_TILE_PACK"); return !e || atoi(e) != 0; }();  // 0: windows in batch order (A/B)
   uint64_t* d_words = nullptr;
   uint32_t* d_p0 = nullptr;
   uint32_t* d_p1 = nullptr;
@@ -169,7 +170,7 @@ struct herro_ctx {
   std::vector<Arena> free_scan, free_stage;            // device op array + staged CIGAR text of a job; pinned staging of one herro_job_create
   hipStream_t prep_stream = nullptr;                   // CIGAR scan of the job being created: its own (high-priority) stream, so that it does not queue behind the pileup / model kernels of earlier jobs
   hipEvent_t prep_ev = nullptr;
-  unsigned long long* d_prof = nullptr;                // HERRO_PROF=1: per-kernel phase cycles (job_dev.h PROF_MARK), printed by herro_destroy
+  unsigned long long* d_prof = nullptr;                // HERRO_PROF_BUILD + HERRO_PROF=1: per-kernel phase cycles (job_dev.h PROF_MARK), printed by herro_destroy
   bool dev_scan = true;                                // HERRO_HOST_SCAN=1: decode the text on the host instead (A/B, debugging)
   std::vector<Arena> free_dev, free_pin, free_small;   // free_small: the buffers a job needs only once its counts are known (logits, batch descriptors)
   std::atomic<uint32_t> live_jobs{0};   // herro_job_create may run on another thread than the context's execution calls
@@ -348,6 +349,37 @@ static std::vector<uint32_t> token_tiles(const std::vector<uint32_t>& tok_off) {
   return t.size() > 1 ? t : std::vector<uint32_t>();
 }
 
+// Order in which the windows of a launch enter the token stream so that token_tiles' consecutive packing comes out as
+// best-fit-decreasing bins: every tile of the fused stack costs the same whatever it holds (the MFMAs run over all 64 token
+// slots), so the launch time is the NUMBER of tiles.  A tile is opened with the largest window left and filled with the
+// largest window that still fits, repeatedly; the window that opens the next tile is the largest one left, which did not fit
+// (or it would have been taken), so the greedy split of token_tiles falls exactly on these bins.  cnt[i] in 1..64.
+// At the bench workload (informative rows per window 4..30, mean 15.2): 999 tiles instead of 1098 for 4096 windows
+// (ideal 975), which is 4 rounds of 256 compute units instead of 5.
+static std::vector<uint32_t> tile_pack_order(const std::vector<uint32_t>& cnt) {
+  std::vector<std::vector<uint32_t>> by(FUSED_MAX_TOK + 1);
+  for (size_t i = cnt.size(); i-- > 0;) by[std::min(cnt[i], FUSED_MAX_TOK)].push_back((uint32_t)i);  // pop_back: ascending index
+  std::vector<uint32_t> order;
+  order.reserve(cnt.size());
+  for (uint32_t i : by[0]) order.push_back(i);   // (not produced by the planner: windows without informative rows are skipped)
+  size_t left = cnt.size() - by[0].size();
+  uint32_t top = FUSED_MAX_TOK;                  // no window above `top` is left
+  while (left) {
+    uint32_t room = FUSED_MAX_TOK, s = top;
+    while (room) {
+      s = std::min(s, room);
+      while (s && by[s].empty()) s--;
+      if (!s) break;
+      order.push_back(by[s].back());
+      by[s].pop_back();
+      room -= s;
+      left--;
+    }
+    while (top && by[top].empty()) top--;
+  }
+  return order;
+}
+
 // One model launch over a set of windows.  Fused stacks (precision 1, 4, 5) take tiles of whole windows of at most
 // 64 informative rows; a window above that does not make the launch group fall off the fused path any more: the
 // group is split into its small windows (tiles) and its large ones (layer-by-layer bf16x3 kernels, precision 3).
@@ -389,9 +421,11 @@ herro_ctx* herro_create(int device_id) {
       g_create_err = hipGetErrorString(e);
       return nullptr;
     }
+#ifdef HERRO_PROF_BUILD
     if (const char* pe = getenv("HERRO_PROF"); pe && atoi(pe)) {
       if (hipMalloc((void**)&ctx->d_prof, 256 * 32 * 8) == hipSuccess) (void)hipMemset(ctx->d_prof, 0, 256 * 32 * 8); else ctx->d_prof = nullptr;
     }
+#endif
     const char* hs = getenv("HERRO_HOST_SCAN");
     ctx->dev_scan = !(hs && atoi(hs) != 0);
   }
@@ -1475,21 +1509,33 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   for (auto& g : groups) {
     for (int part = 0; part < 2; part++) {  // 0: windows that fit a fused tile (all of them in the unfused modes), 1: the rest
       std::vector<uint64_t> plane_off, sup_o, out_o;
-      std::vector<uint32_t> ld, len, lmax, tok_off(1, 0);
+      std::vector<uint32_t> ld, len, lmax, tok_off(1, 0), sel, sel_lmax, sel_cnt;
       for (size_t bi = g.b0; bi < g.b1; bi++) {
         const BatchPlan& bp = job->batches[bi];
         for (uint32_t w : bp.wins) {
           const bool large = fused_mode && job->h_nsup[w] > FUSED_MAX_TOK;
           if ((int)large != part) continue;
-          const WinDesc& wd = job->win[w];
-          plane_off.push_back(wd.fin_off); ld.push_back(wd.lub); len.push_back(job->h_Lf[w]);
-          lmax.push_back(bp.lmax);   // the padding length is that of the window's BATCH, whichever launch it runs in
-          tok_off.push_back(tok_off.back() + job->h_nsup[w]);
-          sup_o.push_back(wd.row_off); out_o.push_back(job->sup_off[w]);
+          sel.push_back(w);
+          sel_lmax.push_back(bp.lmax);   // the padding length is that of the window's BATCH, whichever launch it runs in
+          sel_cnt.push_back(job->h_nsup[w]);
         }
       }
-      const size_t B = plane_off.size();
+      const size_t B = sel.size();
       if (B == 0) continue;
+      // a window's place in the launch is free (its planes, padding length and output slots travel with it): the fused
+      // stacks take them in the order that packs the fewest 64-token tiles
+      std::vector<uint32_t> order;
+      if (fused_mode && part == 0 && ctx->tile_packing) order = tile_pack_order(sel_cnt);
+      plane_off.reserve(B); sup_o.reserve(B); out_o.reserve(B); ld.reserve(B); len.reserve(B); lmax.reserve(B); tok_off.reserve(B + 1);
+      for (size_t k = 0; k < B; k++) {
+        const size_t i = order.empty() ? k : order[k];
+        const uint32_t w = sel[i];
+        const WinDesc& wd = job->win[w];
+        plane_off.push_back(wd.fin_off); ld.push_back(wd.lub); len.push_back(job->h_Lf[w]);
+        lmax.push_back(sel_lmax[i]);
+        tok_off.push_back(tok_off.back() + job->h_nsup[w]);
+        sup_o.push_back(wd.row_off); out_o.push_back(job->sup_off[w]);
+      }
       Offs o;
       o.n_win = (uint32_t)B; o.n_tok = tok_off.back(); o.tiled = fused_mode && part == 0;
       o.plane_off = put(plane_off.data(), B * 8); o.plane_ld = put(ld.data(), B * 4);
@@ -2044,6 +2090,21 @@ int64_t herro_debug_job_array(herro_job* job, int which, const void** ptr, uint3
 
 // ---- host-only test hook: the product's windowing on one alignment (no device needed) -----------
 // out rows of 8 u64: window, tstart, qstart, qend, op_lo, op_hi, start_off, end_off.
+// The token-tile plan of one fused launch over windows of cnt[i] informative rows (1..64): order[i] = index of the i-th
+// window of the token stream; returns the number of tiles (packed != 0: tile_pack_order; 0: batch order).
+int64_t herro_debug_tile_plan(const uint32_t* cnt, uint32_t n, int packed, uint32_t* order) {
+  if (!cnt || !order) return HERRO_E_INVALID;
+  std::vector<uint32_t> c(cnt, cnt + n), ord;
+  for (uint32_t v : c) if (v == 0 || v > FUSED_MAX_TOK) return HERRO_E_INVALID;
+  if (packed) ord = tile_pack_order(c);
+  else { ord.resize(n); for (uint32_t i = 0; i < n; i++) ord[i] = i; }
+  std::vector<uint32_t> tok_off(1, 0);
+  for (uint32_t i = 0; i < n; i++) { order[i] = ord[i]; tok_off.push_back(tok_off.back() + c[ord[i]]); }
+  const std::vector<uint32_t> t = token_tiles(tok_off);
+  for (size_t k = 0; k + 1 < t.size(); k++) if (t[k + 1] - t[k] > FUSED_MAX_TOK) return HERRO_E_STATE;
+  return t.empty() ? 0 : (int64_t)t.size() - 1;
+}
+
 int64_t herro_debug_extract_windows(const herro_alignment* a, uint32_t n_windows, uint32_t W, uint64_t* out,
                                     uint64_t cap, char* err, uint64_t err_cap) {
   std::vector<uint32_t> ops;

@@ -81,11 +81,15 @@ struct JobDev {
   uint8_t* cons_seq;     // [win.row_off ..] corrected bases of the window (ASCII), cons_len[w] of them
   uint8_t* cons_tmp;     // [win.row_off + row] per-row call before '*' removal
   uint32_t* cons_len;    // [win]
-  unsigned long long* prof;  // HERRO_PROF=1: [kernel * 16 + phase] shader cycles summed over workgroups, [.. + 15] workgroups (null otherwise)
+  unsigned long long* prof;  // HERRO_PROF_BUILD libraries run with HERRO_PROF=1: [kernel * 16 + phase][32 shards] shader cycles, [.. + 15] workgroups (null otherwise)
 };
 
-// phase timer for kernel development (HERRO_PROF=1): thread 0 of one workgroup in 32 adds the cycles since the previous mark
-// (sampled and sharded 32 ways: an atomic per mark from every workgroup on one address slowed the kernels 5x and drowned the signal)
+// Phase timer for kernel development.  Compiled in only when the library is built with -DHERRO_PROF_BUILD
+// (HERRO_PROF_BUILD=1 python -m herro_amd.build); such a build, run with HERRO_PROF=1, prints shader cycles per phase of the
+// pileup kernels when a context is destroyed.  Release kernels carry none of it (the marks expand to nothing).
+// Thread 0 of one workgroup in 32 adds the cycles since the previous mark, sharded 32 ways: an atomic per mark from every
+// workgroup on one address slowed the kernels 5x and drowned the signal.
+#ifdef HERRO_PROF_BUILD
 #define PROF_ON(J) ((J).prof && threadIdx.x == 0 && (blockIdx.x & 31u) == 0)
 #define PROF_BEGIN(J) unsigned long long _pt = PROF_ON(J) ? __builtin_readcyclecounter() : 0ull
 #define PROF_MARK(J, kern, phase)                                                              \
@@ -98,6 +102,10 @@ struct JobDev {
       _pt = __builtin_readcyclecounter();                                                     \
     }                                                                                         \
   } while (0)
+#else
+#define PROF_BEGIN(J) do { } while (0)
+#define PROF_MARK(J, kern, phase) do { } while (0)
+#endif
 
 // Accumulates GPU time per kernel group with HIP events recorded on the launch stream.
 struct KernelTimer {

@@ -15,9 +15,8 @@
 // Kernels (same dataflow as model.hip, re-derived for one 2-byte plane per operand):
 //   k_conv_h   embedding + quality + conv1 on the fly -> conv2 (K = 192) -> y2 as ONE f16 plane [N*31][128]
 //   k_fc_h     y2[N][3968] . Wfc -> x[N][256]; 128 x 256 tiles, LDS-DMA, three 24 KB buffers, 2 workgroups per CU
-//   k_layers_h the whole encoder stack per tile of <= 64 tokens: residual stream in registers from the FC output to
-//              the logits (positional encoding added on the way in), no parking of x in HBM, full-K weight
-//              fragments in flight per GEMM call
+//   k_layers_p the whole encoder stack per tile of <= 64 tokens: residual stream in registers from the FC output to
+//              the logits (positional encoding added on the way in), weight fragments one half GEMM call ahead
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -373,347 +372,21 @@ __global__ __launch_bounds__(512, 4) void k_fc_h(const uint16_t* __restrict__ A,
 // stream L2 -> registers in MFMA fragment order (Weight::ph16).  Differences that the smaller operands buy:
 //   * the residual stream x never leaves the registers (the bf16x3 kernel parked it in HBM around every GEMM phase
 //     to make room for 128 VGPRs of weight fragments; here a full-K weight batch is 64);
-//   * all 16 fragment loads of a GEMM call are in flight before its first MFMA (one L2 round trip per call);
 //   * Q, K, V, P are single f16 fragments (attention's error share is 4e-5 / 1.8e-4);
 //   * the positional encoding is added while x is fetched (no k_add_pe launch, no extra pass over x).
 // ---------------------------------------------------------------------------------------------------
 constexpr int HLT = 64;
-constexpr size_t LAYERS_H_SHM = (size_t)4 * HLT * 256 * 2 + 8 * HLT * 4 + HLT * 4;
 __device__ __forceinline__ uint32_t hlsw(uint32_t row, uint32_t chunk) { return row * 256 + ((chunk ^ (row & 15u)) << 3); }
 
-// acc[pt][jt] += W[32 channels at cb][K = 256 at kofs] x act[64 tokens][256] (LDS planes sh / sl).
-// SWAP = false: weights are the MFMA A operand -> lane (token fr of tile pt) x channels cb + 8 fg + 4 jt + r.
-// SWAP = true : activations are the A operand  -> lane (channel cb + 8 (fr>>2) + 4 jt + (fr&3)) x tokens 16 pt + 4 fg + r.
-template <bool SWAP, int TERMS>
-__device__ __forceinline__ void tile_gemm_h(const Weight& W, uint32_t cb, uint32_t kofs, const uint16_t* sh, const uint16_t* sl,
-                                            uint32_t fr, uint32_t fg, f32x4 (&acc)[4][2]) {
-  const uint32_t nks = W.K >> 5, lane = fg * 16 + fr;
-  half8 w[8][2];
-#pragma unroll
-  for (int jt = 0; jt < 2; jt++) {
-    const uint64_t wo = ((((uint64_t)(cb >> 5) * 2 + jt) * nks + (kofs >> 5)) * 64 + lane) * 8;
-#pragma unroll
-    for (int k = 0; k < 8; k++) w[k][jt] = *reinterpret_cast<const half8*>(W.ph16 + wo + k * 512);
-  }
-  __builtin_amdgcn_sched_barrier(0);  // all 16 loads issued together, ahead of the MFMAs (waits are then counted per use)
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    half8 xh[4], xl[4];
-#pragma unroll
-    for (int pt = 0; pt < 4; pt++) {
-      const uint32_t o = hlsw(pt * 16 + fr, k * 4 + fg);
-      xh[pt] = *reinterpret_cast<const half8*>(sh + o);
-      if (TERMS == 2) xl[pt] = *reinterpret_cast<const half8*>(sl + o);
-    }
-#pragma unroll
-    for (int pt = 0; pt < 4; pt++)
-#pragma unroll
-      for (int jt = 0; jt < 2; jt++) acc[pt][jt] = SWAP ? mma(xh[pt], w[k][jt], acc[pt][jt]) : mma(w[k][jt], xh[pt], acc[pt][jt]);
-    if (TERMS == 2) {
-#pragma unroll
-      for (int pt = 0; pt < 4; pt++)
-#pragma unroll
-        for (int jt = 0; jt < 2; jt++) acc[pt][jt] = SWAP ? mma(xl[pt], w[k][jt], acc[pt][jt]) : mma(w[k][jt], xl[pt], acc[pt][jt]);
-    }
-    __builtin_amdgcn_sched_barrier(0);  // keep the next k-step's fragment reads from being hoisted over this one's MFMAs
-  }
-}
-
-template <int TERMS>
-__global__ __launch_bounds__(512) void k_layers_h(ModelDev M, BatchDev B, ModelScratch S) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint16_t* s_hh = reinterpret_cast<uint16_t*>(smem);  // LayerNorm output, hi / lo planes [64][256]
-  uint16_t* s_hl = s_hh + HLT * 256;
-  uint16_t* s_ah = s_hl + HLT * 256;                   // attention output, then FF hidden chunk
-  uint16_t* s_al = s_ah + HLT * 256;
-  float* s_red = reinterpret_cast<float*>(s_al + HLT * 256);       // [8 waves][64 tokens]
-  uint32_t* s_win = reinterpret_cast<uint32_t*>(s_red + 8 * HLT);  // [64] window of each token
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t fr = lane & 15, fg = lane >> 4;
-  const uint32_t t0 = B.tile_tok0[blockIdx.x], nt = B.tile_tok0[blockIdx.x + 1] - t0;
-  const uint32_t cw = wave * 32;
-  const float eps = M.h.ln_eps;
-
-  if (tid < HLT) s_win[tid] = tid < nt ? S.tok_win[t0 + tid] : 0xffffff00u + tid;  // padding slots: a window of their own
-  float x[4][8];
-
-  // LayerNorm of the register-resident x over the 256 channels (8 waves x 4 lane groups x 8 registers), two passes;
-  // the result goes to the s_hh (/ s_hl) planes
-  auto layer_norm = [&](const float* __restrict__ g, const float* __restrict__ b, bool want_lo) {
-    float mean[4], rstd[4];
-#pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-#pragma unroll
-      for (int pt = 0; pt < 4; pt++) {
-        float s = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const float d = pass == 0 ? x[pt][q] : x[pt][q] - mean[pt];
-          s += pass == 0 ? d : d * d;
-        }
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        if (fg == 0) s_red[wave * HLT + pt * 16 + fr] = s;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int pt = 0; pt < 4; pt++) {
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; w++) s += s_red[w * HLT + pt * 16 + fr];
-        if (pass == 0) mean[pt] = s / 256.f;
-        else rstd[pt] = 1.0f / sqrtf(s / 256.f + eps);
-      }
-      __syncthreads();
-    }
-    const float4 g0 = *reinterpret_cast<const float4*>(g + cw + 8 * fg), g1 = *reinterpret_cast<const float4*>(g + cw + 8 * fg + 4);
-    const float4 b0 = *reinterpret_cast<const float4*>(b + cw + 8 * fg), b1 = *reinterpret_cast<const float4*>(b + cw + 8 * fg + 4);
-    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-    for (int pt = 0; pt < 4; pt++) {
-      float y[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) y[q] = (x[pt][q] - mean[pt]) * rstd[pt] * gg[q] + bb[q];
-      const uint32_t o = hlsw(pt * 16 + fr, wave * 4 + fg);
-      if (want_lo) {
-        half8 hi, lo;
-        split_h8(y, hi, lo);
-        *reinterpret_cast<half8*>(s_hh + o) = hi;
-        *reinterpret_cast<half8*>(s_hl + o) = lo;
-      } else {
-        *reinterpret_cast<half8*>(s_hh + o) = pack_h8(y);
-      }
-    }
-    __syncthreads();
-  };
-  auto zero = [](f32x4 (&a)[4][2]) {
-#pragma unroll
-    for (int pt = 0; pt < 4; pt++)
-#pragma unroll
-      for (int jt = 0; jt < 2; jt++) a[pt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  };
-  auto bias8 = [&](const float* bias, uint32_t c, float (&o)[8]) {
-    const float4 a = *reinterpret_cast<const float4*>(bias + c), b = *reinterpret_cast<const float4*>(bias + c + 4);
-    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
-  };
-  // activations that feed a TERMS-term GEMM: 8 consecutive channels of one token -> one 16-byte chunk per plane
-  auto store_act = [&](uint16_t* ph, uint16_t* pl, uint32_t o, const float (&v)[8]) {
-    if (TERMS == 2) {
-      half8 hi, lo;
-      split_h8(v, hi, lo);
-      *reinterpret_cast<half8*>(ph + o) = hi;
-      *reinterpret_cast<half8*>(pl + o) = lo;
-    } else {
-      *reinterpret_cast<half8*>(ph + o) = pack_h8(v);
-    }
-  };
-
-  // ---- x = FC output + sinusoidal positional encoding of the row index (what k_add_pe does in the other modes:
-  // x[2k] += sin(row * div[k]), x[2k+1] += cos(row * div[k]), the product rounded to f32 first)
-  {
-    const float4 pdv = *reinterpret_cast<const float4*>(M.pe_div + ((cw + 8 * fg) >> 1));
-    const float pd[4] = {pdv.x, pdv.y, pdv.z, pdv.w};
-#pragma unroll
-    for (int pt = 0; pt < 4; pt++) {
-      const uint32_t tok = pt * 16 + fr;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-      float row = 0.f;
-      if (tok < nt) {
-        const float* xp = S.x + (uint64_t)(t0 + tok) * 256 + cw + 8 * fg;
-        a = *reinterpret_cast<const float4*>(xp);
-        b = *reinterpret_cast<const float4*>(xp + 4);
-        row = (float)S.tok_row[t0 + tok];
-      }
-      x[pt][0] = a.x; x[pt][1] = a.y; x[pt][2] = a.z; x[pt][3] = a.w;
-      x[pt][4] = b.x; x[pt][5] = b.y; x[pt][6] = b.z; x[pt][7] = b.w;
-      if (tok < nt) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const float ang = __fmul_rn(row, pd[j]);
-          x[pt][2 * j] += sinf(ang);
-          x[pt][2 * j + 1] += cosf(ang);
-        }
-      }
-    }
-  }
-
-  const float scale = 1.0f / sqrtf(32.f);
-  for (uint32_t li = 0; li < M.h.n_layers; li++) {
-    const LayerW& L = M.layer[li];
-    layer_norm(L.ln1_g, L.ln1_b, TERMS == 2);
-    {  // ---- attention, head = wave; Q, K, V, P are single f16 fragments
-      half8 qh[4], kh[4], vh[2][2];
-      {
-        f32x4 a[4][2];
-        float bq[8];
-        zero(a);
-        tile_gemm_h<false, TERMS>(L.qkv, cw, 0, s_hh, s_hl, fr, fg, a);
-        bias8(L.qkv.bias, cw + 8 * fg, bq);
-#pragma unroll
-        for (int pt = 0; pt < 4; pt++) {
-          float v[8];
-#pragma unroll
-          for (int q = 0; q < 8; q++) v[q] = (a[pt][q >> 2][q & 3] + bq[q]) * scale;
-          qh[pt] = pack_h8(v);
-        }
-        zero(a);
-        tile_gemm_h<false, TERMS>(L.qkv, 256 + cw, 0, s_hh, s_hl, fr, fg, a);
-        bias8(L.qkv.bias, 256 + cw + 8 * fg, bq);
-#pragma unroll
-        for (int pt = 0; pt < 4; pt++) {
-          float v[8];
-#pragma unroll
-          for (int q = 0; q < 8; q++) v[q] = a[pt][q >> 2][q & 3] + bq[q];
-          kh[pt] = pack_h8(v);
-        }
-        zero(a);
-        tile_gemm_h<true, TERMS>(L.qkv, 512 + cw, 0, s_hh, s_hl, fr, fg, a);
-        // lane = channel 512 + cw + 8 (fr>>2) + 4 ct + (fr&3), tokens 16 pt + 4 fg + r
-#pragma unroll
-        for (int ct = 0; ct < 2; ct++) {
-          const float bv = L.qkv.bias[512 + cw + 8 * (fr >> 2) + 4 * ct + (fr & 3)];
-#pragma unroll
-          for (int kk = 0; kk < 2; kk++) {  // k-step of 32 tokens: slots e < 4 from token tile 2kk, e >= 4 from 2kk + 1
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = a[2 * kk + (e >> 2)][ct][e & 3] + bv;
-            vh[ct][kk] = pack_h8(v);
-          }
-        }
-      }
-      uint32_t wj[4][4];
-#pragma unroll
-      for (int pj = 0; pj < 4; pj++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) wj[pj][r] = s_win[pj * 16 + 4 * fg + r];
-#pragma unroll
-      for (int pi = 0; pi < 4; pi++) {
-        const uint32_t wi = s_win[pi * 16 + fr];
-        f32x4 st[4];  // S^T: lane = query pi*16 + fr, keys pj*16 + 4 fg + r
-        float m = -INFINITY;
-#pragma unroll
-        for (int pj = 0; pj < 4; pj++) {
-          st[pj] = mma(kh[pj], qh[pi], f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            st[pj][r] = wj[pj][r] == wi ? st[pj][r] : -INFINITY;
-            m = fmaxf(m, st[pj][r]);
-          }
-        }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float l = 0.f;
-#pragma unroll
-        for (int pj = 0; pj < 4; pj++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const float pexp = __expf(st[pj][r] - m);  // masked keys: exp(-inf) = 0; a query always sees itself
-            st[pj][r] = pexp;
-            l += pexp;
-          }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 8; e++) v[e] = st[2 * kk + (e >> 2)][e & 3];
-          const half8 ph = pack_h8(v);
-#pragma unroll
-          for (int ct = 0; ct < 2; ct++) o[ct] = mma(vh[ct][kk], ph, o[ct]);
-        }
-        // O^T: lane = query pi*16 + fr, channels cw + 8 fg + 4 ct + r
-        const float inv = 1.0f / l;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) v[e] = o[e >> 2][e & 3] * inv;
-        store_act(s_ah, s_al, hlsw(pi * 16 + fr, wave * 4 + fg), v);
-      }
-    }
-    __syncthreads();
-    {  // ---- output projection + residual
-      f32x4 a[4][2];
-      float bp[8];
-      zero(a);
-      tile_gemm_h<false, TERMS>(L.proj, cw, 0, s_ah, s_al, fr, fg, a);
-      bias8(L.proj.bias, cw + 8 * fg, bp);
-#pragma unroll
-      for (int pt = 0; pt < 4; pt++)
-#pragma unroll
-        for (int q = 0; q < 8; q++) x[pt][q] += a[pt][q >> 2][q & 3] + bp[q];
-    }
-    layer_norm(L.ln2_g, L.ln2_b, TERMS == 2);  // its barriers also fence the reuse of s_ah / s_al below
-    {  // ---- feed-forward, 256 hidden channels at a time
-      f32x4 a2[4][2];
-      zero(a2);
-      for (uint32_t c = 0; c < M.h.d_ff; c += 256) {
-        f32x4 a1[4][2];
-        float b1[8];
-        zero(a1);
-        tile_gemm_h<false, TERMS>(L.ff1, c + cw, 0, s_hh, s_hl, fr, fg, a1);
-        bias8(L.ff1.bias, c + cw + 8 * fg, b1);
-#pragma unroll
-        for (int pt = 0; pt < 4; pt++) {
-          float v[8];
-#pragma unroll
-          for (int q = 0; q < 8; q++) v[q] = fmaxf(a1[pt][q >> 2][q & 3] + b1[q], 0.f);
-          store_act(s_ah, s_al, hlsw(pt * 16 + fr, wave * 4 + fg), v);
-        }
-        __syncthreads();
-        tile_gemm_h<false, TERMS>(L.ff2, cw, c, s_ah, s_al, fr, fg, a2);
-        __syncthreads();
-      }
-      float b2[8];
-      bias8(L.ff2.bias, cw + 8 * fg, b2);
-#pragma unroll
-      for (int pt = 0; pt < 4; pt++)
-#pragma unroll
-        for (int q = 0; q < 8; q++) x[pt][q] += a2[pt][q >> 2][q & 3] + b2[q];
-    }
-  }
-  layer_norm(M.lnf_g, M.lnf_b, true);
-  // ---- heads: 16 output channels (0 info, 1..5 bases), three terms; wave w < 4 takes token tile w
-  if (wave < 4) {
-    const uint32_t pt = wave;
-    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-    const Weight& W = M.heads;
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++) {
-      const half8 wh = *reinterpret_cast<const half8*>(W.h16 + (uint64_t)fr * 256 + ks * 32 + fg * 8);
-      const half8 wl = *reinterpret_cast<const half8*>(W.l16 + (uint64_t)fr * 256 + ks * 32 + fg * 8);
-      const uint32_t o = hlsw(pt * 16 + fr, ks * 4 + fg);
-      const half8 xh = *reinterpret_cast<const half8*>(s_hh + o);
-      const half8 xl = *reinterpret_cast<const half8*>(s_hl + o);
-      a = mma(wl, xh, a);
-      a = mma(wh, xl, a);
-      a = mma(wh, xh, a);
-    }
-    // lane = token pt*16 + fr, channels 4 fg + r
-    const uint32_t tok = pt * 16 + fr;
-    if (tok < nt) {
-      const uint32_t n = t0 + tok, b = S.tok_win[n];
-      const uint64_t o = B.out_off[b] + (n - B.tok_off[b]);
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const uint32_t ch = 4 * fg + r;
-        const float v = a[r] + W.bias[ch];
-        if (ch == 0) B.out_info[o] = v;
-        else if (ch < 6) B.out_base[o * 5 + (ch - 1)] = v;
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------
-// k_layers_p — k_layers_h with its three exposed latencies taken off the critical path (measured on k_layers_h:
-// one MFMA term costs ~400 us per 4096 windows against a 164 us issue floor, and ~400 us are not GEMM at all):
+// k_layers_p — the stack with its three exposed latencies taken off the critical path (an un-pipelined first version,
+// all 16 fragment loads of a GEMM call issued at its head, took 1196 us per 4096 windows; this one 959; with x parked
+// in L2 across the GEMM phases instead of held in registers: 1068):
 //   * weights run one half-call AHEAD across GEMM calls: a call enters with the fragments of its first four k-steps
 //     already in registers (loaded under the previous call's MFMAs), issues the loads of its last four at once, and
 //     under those MFMAs fetches the first four of the NEXT call (the call sequence Q, K, V, proj, [FF1, FF2] x chunks,
-//     next layer's Q ... is static).  k_layers_h paid one L2 round trip at the head of each of its 48 calls per tile,
-//     with both waves of every SIMD waiting at the same time;
+//     next layer's Q ... is static) — no L2 round trip at the head of each of the 48 calls per tile, with both waves
+//     of every SIMD waiting at the same time;
 //   * LDS activation fragments are read one half k-step (8 MFMAs, >= 128 cycles) ahead of their use instead of one
 //     MFMA pair ahead;
 //   * bias vectors and LayerNorm parameters are requested before the MFMAs / reductions they follow, not after.
@@ -777,7 +450,7 @@ constexpr int PAR_LN1G = 0, PAR_LN1B = 256, PAR_LN2G = 512, PAR_LN2B = 768, PAR_
 constexpr int PAR_MAX_FF = 2048;                 // d_ff supported by the parameter block
 constexpr int PAR_FLOATS = PAR_BFF1 + PAR_MAX_FF;
 
-template <int TERMS, bool PARK>
+template <int TERMS>
 __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelScratch S) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* s_hh = reinterpret_cast<uint16_t*>(smem);
@@ -818,36 +491,6 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
     }
     for (uint32_t e = tid; e < 768; e += 512) s_par[PAR_BQKV + e] = L.qkv.bias[e];
     for (uint32_t e = tid; e < d_ff; e += 512) s_par[PAR_BFF1 + e] = L.ff1.bias[e];
-  };
-  // x lives in registers only where it is read or updated (LayerNorms, residual adds); across the GEMM phases it is
-  // parked in the tile's own rows of S.x (L2-resident, nobody else touches them) — 32 VGPRs the weight / fragment
-  // pipeline needs.  The fetch is issued BEFORE the last GEMM call of a phase, so its latency hides under MFMAs.
-  auto park_x = [&]() {
-    if (!PARK) return;
-#pragma unroll
-    for (int pt = 0; pt < 4; pt++) {
-      const uint32_t tok = pt * 16 + fr;
-      if (tok < nt) {
-        float* xp = S.x + (uint64_t)(t0 + tok) * 256 + cw + 8 * fg;
-        *reinterpret_cast<float4*>(xp) = make_float4(x[pt][0], x[pt][1], x[pt][2], x[pt][3]);
-        *reinterpret_cast<float4*>(xp + 4) = make_float4(x[pt][4], x[pt][5], x[pt][6], x[pt][7]);
-      }
-    }
-  };
-  auto fetch_x = [&]() {
-    if (!PARK) return;
-#pragma unroll
-    for (int pt = 0; pt < 4; pt++) {
-      const uint32_t tok = pt * 16 + fr;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-      if (tok < nt) {
-        const float* xp = S.x + (uint64_t)(t0 + tok) * 256 + cw + 8 * fg;
-        a = *reinterpret_cast<const float4*>(xp);
-        b = *reinterpret_cast<const float4*>(xp + 4);
-      }
-      x[pt][0] = a.x; x[pt][1] = a.y; x[pt][2] = a.z; x[pt][3] = a.w;
-      x[pt][4] = b.x; x[pt][5] = b.y; x[pt][6] = b.z; x[pt][7] = b.w;
-    }
   };
   // LayerNorm over the 256 channels of the register-resident x, two passes (mean, then centred sum of squares)
   auto layer_norm = [&](uint32_t og, uint32_t ob, const float* __restrict__ gp, const float* __restrict__ bp, bool want_lo) {
@@ -922,7 +565,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
   };
 
   stage_params(M.layer[0]);
-  {  // x = FC output + positional encoding (see k_layers_h)
+  {  // x = FC output + positional encoding: the residual stream stays in registers from here to the heads
     const float4 pdv = *reinterpret_cast<const float4*>(M.pe_div + ((cw + 8 * fg) >> 1));
     const float pd[4] = {pdv.x, pdv.y, pdv.z, pdv.w};
 #pragma unroll
@@ -956,7 +599,6 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
     const LayerW& Ln = M.layer[li + 1 < n_layers ? li + 1 : 0];  // after the last layer: a harmless re-read of layer 0
     RELAUNDER();
     layer_norm(PAR_LN1G, PAR_LN1B, nullptr, nullptr, TERMS == 2);
-    park_x();
     RELAUNDER();
     {  // ---- attention, head = wave
       half8 qh[4], kh[4], vh[2][2];
@@ -1052,7 +694,6 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
       f32x4 a[4][2];
       float bp[8];
       zero(a);
-      fetch_x();
       tile_gemm_p<false, TERMS>(wstream(L.proj, cw, 0, lane), wa, wstream(L.ff1, cw, 0, lane), s_ah, s_al, fr, fg, a);
       lds8(PAR_BPROJ + cw + 8 * fg, bp);
 #pragma unroll
@@ -1062,7 +703,6 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
     }
     RELAUNDER();
     layer_norm(PAR_LN2G, PAR_LN2B, nullptr, nullptr, TERMS == 2);
-    park_x();
     {  // ---- feed-forward, 256 hidden channels at a time
       f32x4 a2[4][2];
       {  // the FF2 accumulator starts from its bias: no parameter is read after the loop's last barrier, which is what
@@ -1091,7 +731,6 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
         __syncthreads();
         const bool more = c + 256 < d_ff;
         const WStream nx = more ? wstream(L.ff1, c + 256 + cw, 0, lane) : wstream(Ln.qkv, cw, 0, lane);
-        if (!more) fetch_x();
         tile_gemm_p<false, TERMS>(wstream(L.ff2, cw, c, lane), wa, nx, s_ah, s_al, fr, fg, a2);
         __syncthreads();
       }
@@ -1183,33 +822,13 @@ void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S,
   KT_BEGIN(tm, "fc_gemm", st);
   hipLaunchKernelGGL(k_fc_h, dim3((N + FC_TM - 1) / FC_TM), dim3(512), FC_H_SHM, st, S.y2_hi, HERRO_ROWS * h.c2, M.fc, S.x, h.d_model, N);
   KT_END(tm, st);
-  // HERRO_LAYERS_V=0 selects the un-pipelined stack (k_layers_h), 1 the pipelined one with x parked in L2 across the GEMM phases
-  // (both kept for A/B measurements)
-  static const int variant = getenv("HERRO_LAYERS_V") ? atoi(getenv("HERRO_LAYERS_V")) : 2;
-  const bool pipelined = variant != 0;
   KT_BEGIN(tm, "layers_fused", st);
-  if (variant == 2) {  // default: pipelined, x resident in registers (959 us per 4096 windows; parked in L2: 1068; un-pipelined: 1196)
-    if (terms == 2) {
-      opt_in_lds(reinterpret_cast<const void*>(k_layers_p<2, false>), LAYERS_P_SHM);
-      hipLaunchKernelGGL((k_layers_p<2, false>), dim3(B.n_tiles), dim3(512), LAYERS_P_SHM, st, M, B, S);
-    } else {
-      opt_in_lds(reinterpret_cast<const void*>(k_layers_p<1, false>), LAYERS_P_SHM);
-      hipLaunchKernelGGL((k_layers_p<1, false>), dim3(B.n_tiles), dim3(512), LAYERS_P_SHM, st, M, B, S);
-    }
-  } else if (pipelined) {
-    if (terms == 2) {
-      opt_in_lds(reinterpret_cast<const void*>(k_layers_p<2, true>), LAYERS_P_SHM);
-      hipLaunchKernelGGL((k_layers_p<2, true>), dim3(B.n_tiles), dim3(512), LAYERS_P_SHM, st, M, B, S);
-    } else {
-      opt_in_lds(reinterpret_cast<const void*>(k_layers_p<1, true>), LAYERS_P_SHM);
-      hipLaunchKernelGGL((k_layers_p<1, true>), dim3(B.n_tiles), dim3(512), LAYERS_P_SHM, st, M, B, S);
-    }
-  } else if (terms == 2) {
-    opt_in_lds(reinterpret_cast<const void*>(k_layers_h<2>), LAYERS_H_SHM);
-    hipLaunchKernelGGL(k_layers_h<2>, dim3(B.n_tiles), dim3(512), LAYERS_H_SHM, st, M, B, S);
+  if (terms == 2) {
+    opt_in_lds(reinterpret_cast<const void*>(k_layers_p<2>), LAYERS_P_SHM);
+    hipLaunchKernelGGL(k_layers_p<2>, dim3(B.n_tiles), dim3(512), LAYERS_P_SHM, st, M, B, S);
   } else {
-    opt_in_lds(reinterpret_cast<const void*>(k_layers_h<1>), LAYERS_H_SHM);
-    hipLaunchKernelGGL(k_layers_h<1>, dim3(B.n_tiles), dim3(512), LAYERS_H_SHM, st, M, B, S);
+    opt_in_lds(reinterpret_cast<const void*>(k_layers_p<1>), LAYERS_P_SHM);
+    hipLaunchKernelGGL(k_layers_p<1>, dim3(B.n_tiles), dim3(512), LAYERS_P_SHM, st, M, B, S);
   }
   KT_END(tm, st);
 }

@@ -221,6 +221,11 @@ int64_t herro_debug_extract_windows(const herro_alignment* a, uint32_t n_windows
 herro_ctx* herro_debug_host_ctx(uint32_t n_reads, const uint32_t* read_len, const uint32_t* name_class);
 int64_t herro_debug_job_array(herro_job* job, int which, const void** ptr, uint32_t* elem_bytes);
 
+/* Host-only test hook for the token-tile plan of the fused transformer stack (herro_job_infer): n windows of cnt[i]
+ * informative rows (1..64) -> order[k] = the window that is k-th in the launch's token stream; returns the number of
+ * 64-token tiles of whole windows (packed = 1: the best-fit-decreasing order herro_job_infer uses; 0: the given order). */
+int64_t herro_debug_tile_plan(const uint32_t* cnt, uint32_t n, int packed, uint32_t* order);
+
 /* ---- PAF / .oec.zst ingest on the host (needs no device) ---------------------------------------
  * herro_paf_parse replaces `parse_paf` (overlaps.rs:117-202): one overlap per line, tab separated
  *   qname qlen qstart qend strand tname tlen tstart tend ... cg:Z:<CIGAR>   (CIGAR in the LAST column),

@@ -208,3 +208,30 @@ def test_cigar_text_decoder_corner_cases(W):
             c.create_job(rid, row, off, [bad], W)
         assert what in str(e.value), (bad[:30], str(e.value))
     c.close()
+
+
+def test_token_tile_plan_packs_whole_windows_into_fewer_tiles():
+    """herro_job_infer's window order for the fused stack: a permutation, every tile <= 64 tokens of whole windows, never more
+    tiles than the batch order gives, and within 3 % of the bound ceil(tokens / 64) on the bench's row-count distribution."""
+    rng = np.random.default_rng(5)
+    for n, lo, hi in ((4096, 4, 31), (1000, 1, 65), (37, 60, 65), (1, 64, 65), (513, 1, 3)):
+        cnt = rng.integers(lo, hi, n).astype(np.uint32)
+        tiles_plain, order_plain = api.debug_tile_plan(cnt, packed=False)
+        tiles, order = api.debug_tile_plan(cnt, packed=True)
+        assert order_plain.tolist() == list(range(n))
+        assert sorted(order.tolist()) == list(range(n))
+        assert tiles <= tiles_plain
+        # the greedy consecutive split over the packed order (what the kernels get)
+        t, cur = 1, 0
+        for c in cnt[order]:
+            if cur + c > 64:
+                t, cur = t + 1, 0
+            cur += int(c)
+        assert t == tiles
+        assert tiles >= -(-int(cnt.sum()) // 64)
+        if (lo, hi) == (4, 31):
+            assert tiles <= 1.03 * cnt.sum() / 64 + 1
+    with pytest.raises(api.HerroError):
+        api.debug_tile_plan(np.array([3, 0, 2], np.uint32))
+    with pytest.raises(api.HerroError):
+        api.debug_tile_plan(np.array([65], np.uint32))
