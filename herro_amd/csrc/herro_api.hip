@@ -2008,16 +2008,23 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
   for (int part = 0; part < 2; part++) {  // 0: windows that fit a fused tile (all windows in the unfused modes), 1: larger ones
     Part& P = parts[part];
     P.tok_off.assign(1, 0);
+    const bool tiled = fused_mode && part == 0;
+    std::vector<uint32_t> sel, sel_cnt;
     for (uint32_t b = 0; b < B; b++) {
       const bool large = fused_mode && (uint32_t)lens[b] > FUSED_MAX_TOK;
       if ((int)large != part) continue;
+      sel.push_back(b);
+      sel_cnt.push_back((uint32_t)lens[b]);
+    }
+    const std::vector<uint32_t> order = tiled && ctx->tile_packing ? tile_pack_order(sel_cnt) : std::vector<uint32_t>();   // as herro_job_infer
+    for (size_t k = 0; k < sel.size(); k++) {
+      const uint32_t b = sel[order.empty() ? k : order[k]];
       P.plane_off.push_back((uint64_t)b * HERRO_ROWS * L); P.ld.push_back(L); P.len.push_back(L); P.lmax.push_back(L);
       P.sup_off.push_back(tok_off[b]); P.out_off.push_back(tok_off[b]);
       P.tok_off.push_back(P.tok_off.back() + (uint32_t)lens[b]);
     }
     const size_t nb = P.plane_off.size();
     if (nb == 0 || P.tok_off.back() == 0) continue;
-    const bool tiled = fused_mode && part == 0;
     if (tiled) P.tiles = token_tiles(P.tok_off);
     BatchDev bd{};
     bd.n_win = (uint32_t)nb; bd.n_tok = P.tok_off.back();
