@@ -1502,7 +1502,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
     std::memcpy(blob.data() + o, p, bytes);
     return o;
   };
-  struct Offs { size_t plane_off, plane_ld, len, lmax, tok_off, sup_off, out_off, tiles; uint32_t n_tiles, n_win, n_tok; bool tiled; };
+  struct Offs { size_t plane_off, plane_ld, len, lmax, tok_off, sup_off, out_off, tiles; uint32_t n_tiles, n_win, n_tok, max_win_tok; bool tiled; };
   std::vector<Offs> offs;
   uint32_t max_tok = 0;
   const bool fused_mode = ctx->precision == 1 || ctx->precision >= 4;
@@ -1538,6 +1538,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
       }
       Offs o;
       o.n_win = (uint32_t)B; o.n_tok = tok_off.back(); o.tiled = fused_mode && part == 0;
+      o.max_win_tok = *std::max_element(sel_cnt.begin(), sel_cnt.end());
       o.plane_off = put(plane_off.data(), B * 8); o.plane_ld = put(ld.data(), B * 4);
       o.len = put(len.data(), B * 4); o.lmax = put(lmax.data(), B * 4);
       o.tok_off = put(tok_off.data(), (B + 1) * 4);
@@ -1570,7 +1571,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   for (const Offs& o : offs) {
     const unsigned char* base = (const unsigned char*)job->d_bdesc;
     BatchDev B{};
-    B.n_win = o.n_win; B.n_tok = o.n_tok;
+    B.n_win = o.n_win; B.n_tok = o.n_tok; B.max_win_tok = o.max_win_tok;
     B.plane_off = (const uint64_t*)(base + o.plane_off);
     B.plane_ld = (const uint32_t*)(base + o.plane_ld);
     B.len = (const uint32_t*)(base + o.len);
@@ -2027,7 +2028,7 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
     if (nb == 0 || P.tok_off.back() == 0) continue;
     if (tiled) P.tiles = token_tiles(P.tok_off);
     BatchDev bd{};
-    bd.n_win = (uint32_t)nb; bd.n_tok = P.tok_off.back();
+    bd.n_win = (uint32_t)nb; bd.n_tok = P.tok_off.back(); bd.max_win_tok = *std::max_element(sel_cnt.begin(), sel_cnt.end());
     bd.plane_off = (const uint64_t*)up(P.plane_off.data(), nb * 8); bd.plane_ld = (const uint32_t*)up(P.ld.data(), nb * 4);
     bd.len = (const uint32_t*)up(P.len.data(), nb * 4); bd.lmax = (const uint32_t*)up(P.lmax.data(), nb * 4);
     bd.tok_off = (const uint32_t*)up(P.tok_off.data(), (nb + 1) * 4);

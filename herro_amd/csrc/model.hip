@@ -1249,6 +1249,9 @@ __global__ __launch_bounds__(256) void k_layernorm_s(const float* x, uint16_t* y
 // at a time (the window's informative positions are the sequence; typically 10-30 tokens).  K and V
 // rows are staged through LDS in chunks of KC keys with coalesced 16-byte loads; reads are broadcast
 // within a head's 16 lanes.  Softmax is kept online in registers across chunks.  Output pre-split.
+// blockIdx.y strides the blocks of 16 queries: this path is what windows above the fused stack's 64-token tile
+// take, and one workgroup walking a 100-token window alone (7 query blocks x 7 key chunks, each a serial chain
+// over 16 keys) took 330 us per layer for ten such windows.
 static constexpr int KC = 16;
 template <int DH>
 __global__ __launch_bounds__(128) void k_attention_s(BatchDev B, ModelScratch S, uint32_t D) {
@@ -1258,7 +1261,7 @@ __global__ __launch_bounds__(128) void k_attention_s(BatchDev B, ModelScratch S,
   const uint32_t b = blockIdx.x, hd = threadIdx.x >> 4, ql = threadIdx.x & 15;
   const uint32_t t0 = B.tok_off[b], len = B.tok_off[b + 1] - t0;
   const float scale = 1.0f / sqrtf((float)DH);
-  for (uint32_t i0 = 0; i0 < len; i0 += 16) {  // block-uniform trip count (barriers inside)
+  for (uint32_t i0 = blockIdx.y * 16; i0 < len; i0 += 16 * gridDim.y) {  // block-uniform trip count (barriers inside)
     const uint32_t i = i0 + ql;
     const bool act = i < len;
     float qr[DH], o[DH];
@@ -1750,7 +1753,7 @@ static void launch_model_s(const ModelDev& M, const BatchDev& B, const ModelScra
     gemm_s(S.h_hi, S.h_lo, D, L.qkv, S.qkv, nullptr, nullptr, 3 * D, nullptr, N, 0, st);
     KT_END(tm, st);
     KT_BEGIN(tm, "attention", st);
-    hipLaunchKernelGGL(k_attention_s<32>, dim3(B.n_win), dim3(16 * h.n_heads), (size_t)2 * KC * D * 4, st, B, S, D);
+    hipLaunchKernelGGL(k_attention_s<32>, dim3(B.n_win, std::max(1u, std::min((B.max_win_tok + 15) / 16, 64u))), dim3(16 * h.n_heads), (size_t)2 * KC * D * 4, st, B, S, D);
     KT_END(tm, st);
     KT_BEGIN(tm, "proj_gemm", st);
     gemm_s(S.att_hi, S.att_lo, D, L.proj, S.x, nullptr, nullptr, D, S.x, N, 0, st);

@@ -68,6 +68,7 @@ struct ModelDev {
 struct BatchDev {
   uint32_t n_win;             // B
   uint32_t n_tok;             // N = sum of informative positions
+  uint32_t max_win_tok;       // most informative positions in one window (0: unknown) — sizes the query-block dimension of k_attention_s
   const uint64_t* plane_off;  // [B] byte offset of the window's token/quality planes
   const uint32_t* plane_ld;   // [B] plane stride (lub)
   const uint32_t* len;        // [B] L' of each window

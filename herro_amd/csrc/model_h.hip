@@ -7,10 +7,14 @@
 //     conv2 7.8e-5, FC 1.0e-4, Q.K^T 4.0e-5, P.V 1.8e-4  with single f16 operands (1 MFMA per product)
 //     QKV 2.0e-4, proj 2.2e-4, FF1 1.8e-4, FF2 1.8e-4    with the activation split in two f16 terms (2 MFMAs)
 //     heads 5.7e-4 single -> kept at three terms (a 256 x 16 GEMM: nothing to gain)
-// so precision 4 runs conv2 / FC / attention on single f16 operands (v_mfma_f32_16x16x32_f16), the four big GEMMs of
-// every encoder layer on `activation hi + lo` x `weight` (2 MFMAs; the weight planes streamed from L2 halve as well),
-// and the heads on three terms.  Precision 5 drops the activation lo term too (1 MFMA everywhere but the heads);
-// it is measured and reported, not the default.  Accumulation is f32 in every mode.
+// so precision 4 runs conv2 / FC / attention on single f16 operands (v_mfma_f32_16x16x32_f16), the heads on three terms, and
+// of the four big GEMMs of an encoder layer proj / FF1 / FF2 on `activation hi + lo` x `weight` (2 MFMAs).  QKV runs on the hi
+// term alone: Q, K and V are rounded to single f16 fragments for the attention anyway, and the whole-model error does not see
+// its lo term (same emulation, 1020 tokens, three weight seeds, max | rms of the logit error:
+//     all four split 3.9e-4 | 1.02e-4, 5.6e-4 | 1.57e-4, 4.2e-4 | 0.93e-4      QKV single 4.1e-4 | 1.05e-4, 5.3e-4 | 1.58e-4, 3.3e-4 | 0.95e-4
+//     proj single 5.3e-4, 7.0e-4, 4.2e-4    FF1 + FF2 single 6.2e-4, 7.0e-4, 5.5e-4    everything single 6.1e-4, 8.4e-4, 5.7e-4)
+// — an eighth of the stack's MFMAs and the LayerNorm-1 lo plane for nothing.  Precision 5 drops the activation lo term
+// everywhere (1 MFMA everywhere but the heads); it is measured and reported, not the default.  Accumulation is f32 in every mode.
 //
 // Kernels (same dataflow as model.hip, re-derived for one 2-byte plane per operand):
 //   k_conv_h   embedding + quality + conv1 on the fly -> conv2 (K = 192) -> y2 as ONE f16 plane [N*31][128]
@@ -598,7 +602,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
     const LayerW& L = M.layer[li];
     const LayerW& Ln = M.layer[li + 1 < n_layers ? li + 1 : 0];  // after the last layer: a harmless re-read of layer 0
     RELAUNDER();
-    layer_norm(PAR_LN1G, PAR_LN1B, nullptr, nullptr, TERMS == 2);
+    layer_norm(PAR_LN1G, PAR_LN1B, nullptr, nullptr, false);   // Q, K, V read the hi plane only (see the header: QKV single)
     RELAUNDER();
     {  // ---- attention, head = wave
       half8 qh[4], kh[4], vh[2][2];
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
         f32x4 a[4][2];
         float bq[8];
         zero(a);
-        tile_gemm_p<false, TERMS>(wstream(L.qkv, cw, 0, lane), wa, wstream(L.qkv, 256 + cw, 0, lane), s_hh, s_hl, fr, fg, a);
+        tile_gemm_p<false, 1>(wstream(L.qkv, cw, 0, lane), wa, wstream(L.qkv, 256 + cw, 0, lane), s_hh, s_hl, fr, fg, a);
         lds8(PAR_BQKV + cw + 8 * fg, bq);
 #pragma unroll
         for (int pt = 0; pt < 4; pt++) {
@@ -616,7 +620,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
           qh[pt] = pack_h8(v);
         }
         zero(a);
-        tile_gemm_p<false, TERMS>(wstream(L.qkv, 256 + cw, 0, lane), wa, wstream(L.qkv, 512 + cw, 0, lane), s_hh, s_hl, fr, fg, a);
+        tile_gemm_p<false, 1>(wstream(L.qkv, 256 + cw, 0, lane), wa, wstream(L.qkv, 512 + cw, 0, lane), s_hh, s_hl, fr, fg, a);
         lds8(PAR_BQKV + 256 + cw + 8 * fg, bq);
 #pragma unroll
         for (int pt = 0; pt < 4; pt++) {
@@ -626,7 +630,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
           kh[pt] = pack_h8(v);
         }
         zero(a);
-        tile_gemm_p<true, TERMS>(wstream(L.qkv, 512 + cw, 0, lane), wa, wstream(L.proj, cw, 0, lane), s_hh, s_hl, fr, fg, a);
+        tile_gemm_p<true, 1>(wstream(L.qkv, 512 + cw, 0, lane), wa, wstream(L.proj, cw, 0, lane), s_hh, s_hl, fr, fg, a);
 #pragma unroll
         for (int ct = 0; ct < 2; ct++) {
           const float bv = s_par[PAR_BQKV + 512 + cw + 8 * (fr >> 2) + 4 * ct + (fr & 3)];

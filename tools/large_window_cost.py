@@ -1,0 +1,47 @@
+"""GPU: what windows with more than 64 informative rows cost.  The fused encoder stack takes tiles of whole windows of at
+most 64 rows; larger windows of a launch run through the layer-by-layer bf16x3 kernels (herro_api.hip run_model).  Times the
+model kernels (HIP events of the context's KernelTimer) of one collated batch of B windows, all small, against the same
+batch with 1 % of the windows enlarged to 100 rows.  usage: python tools/large_window_cost.py [B]"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from herro_amd import api, model_io  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+L = 512
+rng = np.random.default_rng(3)
+c = api.Context(0)
+path, _ = model_io.default_model_file(os.path.join(ROOT, "tests", "_cache"))
+c.load_model(path)
+c.set_precision(api.DEFAULT_PRECISION)
+bases = rng.integers(0, 11, (B, L, 31)).astype(np.uint8)
+quals = rng.integers(33, 90, (B, L, 31)).astype(np.uint8)
+
+
+def run(counts):
+    idx = [np.sort(rng.choice(L, size=int(k), replace=False)) for k in counts]
+    lens = np.array([len(i) for i in idx], np.int32)
+    flat = np.concatenate(idx).astype(np.int32)
+    c.model_forward(bases, quals, lens, flat)          # warm-up: scratch, opt-ins
+    c.timing_enable(True)
+    c.timing_reset()
+    for _ in range(5):
+        c.model_forward(bases, quals, lens, flat)
+    t = c.timing()
+    c.timing_enable(False)
+    return {k: round(v[0] / v[1] * 1e3, 1) for k, v in t.items() if v[1]}, int(lens.sum())
+
+
+small = np.clip(rng.normal(15.2, 4.5, B).round(), 4, 30).astype(int)
+mixed = small.copy()
+mixed[rng.choice(B, size=max(1, B // 100), replace=False)] = 100
+a, na = run(small)
+b, nb = run(mixed)
+out = {"windows": B, "rows_small": na, "rows_mixed": nb, "large_windows": int((mixed > 64).sum()),
+       "us_per_launch_small": a, "us_per_launch_mixed": b, "sum_small_us": round(sum(a.values()), 1), "sum_mixed_us": round(sum(b.values()), 1)}
+print(json.dumps(out))
