@@ -98,9 +98,9 @@ int herro_load_model(herro_ctx* ctx, const char* path);
  *   0  f32 MFMA (exact f32)                                   2  f32 VALU (debug reference)
  *   1  bf16 hi/lo split of both operands, 3 MFMAs per product (~1e-5), transformer stack fused into one kernel
  *   3  the same arithmetic, layer by layer (what windows with > 64 informative rows run in modes 1, 4, 5)
- *   4  f16: conv2 / FC / attention on single f16 operands, the four GEMMs of every encoder layer on activation hi + lo
- *      (2 MFMAs), heads on three terms — 5.5e-4 max on 36 k rows; the DEFAULT when the model has the tuned shapes
- *   5  f16, single terms everywhere but the heads (7.6e-4: measured, not a default)
+ *   4  f16: conv2 / FC / attention / QKV on single f16 operands, proj / FF1 / FF2 of every encoder layer on activation
+ *      hi + lo (2 MFMAs), heads on three terms — 5.9e-4 max on 36 k rows; the DEFAULT when the model has the tuned shapes
+ *   5  f16, single terms everywhere but the heads (7.3e-4: measured, not a default)
  * herro_load_model picks the mode itself unless this was called before: 1 when the model's shapes have no f16 kernels or
  * a weight lies outside the f16 range; otherwise it runs a 256-row calibration batch in modes 1 and 4 and keeps 4 only
  * if the logits are finite and differ by at most 5e-4 (half the 1e-3 contract) — the margin of the f16 formats was
