@@ -9,10 +9,13 @@
 // under oracle/.  The product (herro_amd/) never includes, links or calls this code.
 //
 // PARITY STATUS: the reference cannot be built here (no Rust toolchain, crates not
-// vendored) and holds live tests only for the 2-bit codec (haec_io.rs:185-300).  This
-// oracle is pinned against those codec vectors; for windowing / pileup / consensus the
-// reference has no live tests or fixtures, so those parts are "parity unpinned" beyond a
-// hand-traced known-answer example re-derived from the code.
+// vendored).  Pinned: the 2-bit codec against the reference's 11 codec tests
+// (haec_io.rs:185-300, tests/golden/codec_vectors.json); extract_windows against the
+// expected values of the reference's seven windowing tests (windowing.rs:309-606; they no
+// longer compile, their sequences and per-window numbers are data —
+// tests/test_oracle_ref_windowing.py).  For pileup / consensus the reference has no tests
+// or fixtures, so those parts are "parity unpinned" beyond a hand-traced known-answer
+// example re-derived from the code.
 #pragma once
 #include <algorithm>
 #include <array>

@@ -72,3 +72,18 @@ def test_hand_cases():
         api.debug_extract_windows((1, 64, 0, 35, 0, 0, 35, 0, 35), b"30M5X", 4, 10)
     with pytest.raises(api.HerroError):
         api.debug_extract_windows((1, 64, 0, 35, 0, 0, 35, 0, 35), b"0M35M", 4, 10)
+
+
+def test_reference_windowing_vectors():
+    """The target-side cases of the reference's own windowing tests (windowing.rs:309-606; the oracle is held to their expected
+    values in test_oracle_ref_windowing.py) through the PRODUCT's windowing: identical rows."""
+    import test_oracle_ref_windowing as R
+    q1, t1 = R.Q1, R.T1
+    cases = [(R.EDIT, len(q1), len(t1), 0), (R.GAP, len(q1), len(t1), 0), (R.GAP, len(q1), len(t1) + 5, 5),
+             ("2=2D20=3X2=", 27, 29, 0), ("4=20I16=", 40, 20, 0)]
+    for cig, ql, tl, ts in cases:
+        text = R._as_mid(cig)
+        row = (0, ql, 0, ql, 0, 1, tl, ts, tl)
+        nwin = (tl + R.W - 1) // R.W
+        want = O.extract_windows(row, text, nwin, R.W).tolist()
+        assert want and to_byte_rows(api.debug_extract_windows(row, text, nwin, R.W), text) == want
