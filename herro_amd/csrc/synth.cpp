@@ -12,6 +12,7 @@
 // hap-A coordinate system, so they are exact.  PRNG: splitmix64-seeded xoshiro256**; normal
 // variates by Irwin-Hall(12) so the stream is bit-reproducible on any libm.
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -40,6 +41,10 @@ struct Rng {
   double uniform() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
   uint32_t below(uint32_t n) { return (uint32_t)(((next() >> 32) * (uint64_t)n) >> 32); }
   bool bern(double p) { return uniform() < p; }
+  // uniform() < p without the conversion: uniform() is k * 2^-53 exactly (k = next() >> 11 < 2^53) and p * 2^53 is exact in a
+  // double, so k * 2^-53 < p  <=>  k < p * 2^53  <=>  k < ceil(p * 2^53) for the integer k.  Same draws, same outcomes.
+  static uint64_t threshold(double p) { return p > 0 ? (p >= 1 ? (1ull << 53) : (uint64_t)std::ceil(p * 9007199254740992.0)) : 0; }
+  bool bern_t(uint64_t thr) { return (next() >> 11) < thr; }
   double normal() {
     double a = 0;
     for (int i = 0; i < 12; i++) a += uniform();
@@ -55,11 +60,15 @@ struct Rng {
 const char ACGT[4] = {'A', 'C', 'G', 'T'};
 const uint8_t DEL = 4;
 
-// A sequence expressed in hap-A column coordinates: per column an optional base + insertions.
+// A sequence expressed in hap-A column coordinates: per column an optional base + insertions.  The insertions of all
+// columns sit in one buffer (columns are always produced left to right): column i owns idata[ioff[i] .. ioff[i + 1]).
 struct Cols {
-  int64_t a0 = 0;                          // first column
-  std::vector<uint8_t> base;               // 0..3 or DEL
-  std::vector<std::vector<uint8_t>> ins;   // bases 0..3 after the column
+  int64_t a0 = 0;                 // first column
+  std::vector<uint8_t> base;      // 0..3 or DEL
+  std::vector<uint32_t> ioff;     // base.size() + 1
+  std::vector<uint8_t> idata;     // inserted bases 0..3
+  uint32_t ins_n(size_t i) const { return ioff[i + 1] - ioff[i]; }
+  const uint8_t* ins(size_t i) const { return idata.data() + ioff[i]; }
 };
 
 struct Params {
@@ -87,36 +96,43 @@ Cols noisy_read(Rng& g, const Cols& hap, int64_t a_lo, int64_t a_hi, const Param
   r.a0 = a_lo;
   const size_t n = (size_t)(a_hi - a_lo);
   r.base.assign(n, DEL);
-  r.ins.assign(n, {});
+  r.ioff.resize(n + 1);
+  r.idata.reserve(n / 32 + 64);
+  const uint64_t t_del = Rng::threshold(P.p_del), t_sub = Rng::threshold(P.p_sub), t_ins = Rng::threshold(P.p_ins),
+                 t_long = Rng::threshold(P.p_long_indel);
   uint32_t del_left = 0;
-  auto emit = [&](uint8_t hb, std::vector<uint8_t>* dst_ins, uint8_t* dst_base) {
+  auto emit = [&](uint8_t hb, uint8_t* dst_base) {
     // one haplotype base -> maybe deleted / substituted, maybe followed by insertion
     if (del_left > 0) {
       del_left--;
-    } else if (g.bern(P.p_del)) {
-      del_left = (g.bern(P.p_long_indel) ? 55 + g.below(20) : g.geom(0.8, 10)) - 1;
+    } else if (g.bern_t(t_del)) {
+      del_left = (g.bern_t(t_long) ? 55 + g.below(20) : g.geom(0.8, 10)) - 1;
     } else {
       uint8_t b = hb;
-      if (g.bern(P.p_sub)) b = (uint8_t)((b + 1 + g.below(3)) & 3);
-      if (dst_base) *dst_base = b; else dst_ins->push_back(b);
+      if (g.bern_t(t_sub)) b = (uint8_t)((b + 1 + g.below(3)) & 3);
+      if (dst_base) *dst_base = b; else r.idata.push_back(b);
     }
-    if (g.bern(P.p_ins)) {
-      const uint32_t l = g.bern(P.p_long_indel) ? 55 + g.below(20) : g.geom(0.8, 10);
-      for (uint32_t k = 0; k < l; k++) dst_ins->push_back((uint8_t)g.below(4));
+    if (g.bern_t(t_ins)) {
+      const uint32_t l = g.bern_t(t_long) ? 55 + g.below(20) : g.geom(0.8, 10);
+      for (uint32_t k = 0; k < l; k++) r.idata.push_back((uint8_t)g.below(4));
     }
   };
+  const size_t h0 = (size_t)(a_lo - hap.a0);
   for (size_t i = 0; i < n; i++) {
-    const size_t h = (size_t)(a_lo + (int64_t)i - hap.a0);
-    if (hap.base[h] != DEL) emit(hap.base[h], &r.ins[i], &r.base[i]);
-    for (uint8_t hb : hap.ins[h]) emit(hb, &r.ins[i], nullptr);
+    const size_t h = h0 + i;
+    r.ioff[i] = (uint32_t)r.idata.size();
+    if (hap.base[h] != DEL) emit(hap.base[h], &r.base[i]);
+    for (uint32_t k = hap.ioff[h]; k < hap.ioff[h + 1]; k++) emit(hap.idata[k], nullptr);
   }
+  r.ioff[n] = (uint32_t)r.idata.size();
   return r;
 }
 
 void flatten(const Cols& c, std::vector<uint8_t>& out) {
+  out.reserve(out.size() + c.base.size() + c.idata.size());
   for (size_t i = 0; i < c.base.size(); i++) {
     if (c.base[i] != DEL) out.push_back(c.base[i]);
-    for (uint8_t b : c.ins[i]) out.push_back(b);
+    out.insert(out.end(), c.ins(i), c.ins(i) + c.ins_n(i));
   }
 }
 
@@ -130,11 +146,14 @@ struct Cig {
 };
 
 void gen_quals(Rng& g, size_t n, std::vector<uint8_t>& out) {
+  const size_t at = out.size();
+  out.resize(at + n);
+  uint8_t* d = out.data() + at;
   for (size_t i = 0; i < n; i++) {
     double q = 22.0 + 8.0 * g.normal();
     long v = (long)(q + (q >= 0 ? 0.5 : -0.5));
     v = std::max(2l, std::min(50l, v));
-    out.push_back((uint8_t)(33 + v));
+    d[i] = (uint8_t)(33 + v);
   }
 }
 
@@ -150,7 +169,7 @@ void generate(const Params& P, Out& o) {
     for (int h = 0; h < 2; h++) {
       hap[h].a0 = 0;
       hap[h].base.resize((size_t)TL);
-      hap[h].ins.assign((size_t)TL, {});
+      hap[h].ioff.assign((size_t)TL + 1, 0);   // hap A carries no insertions
     }
     for (int64_t a = 0; a < TL; a++) {
       const uint8_t b = (uint8_t)g.below(4);
@@ -159,8 +178,10 @@ void generate(const Params& P, Out& o) {
       if (g.bern(P.p_snp)) bb = (uint8_t)((b + 1 + g.below(3)) & 3);
       if (g.bern(1e-4)) bb = DEL;
       hap[1].base[(size_t)a] = bb;
-      if (g.bern(1e-4)) hap[1].ins[(size_t)a].push_back((uint8_t)g.below(4));
+      hap[1].ioff[(size_t)a] = (uint32_t)hap[1].idata.size();
+      if (g.bern(1e-4)) hap[1].idata.push_back((uint8_t)g.below(4));
     }
+    hap[1].ioff[(size_t)TL] = (uint32_t)hap[1].idata.size();
 
     // --- target read: exactly target_len bases starting at column `margin`
     const int th = (int)g.below(2);
@@ -169,16 +190,18 @@ void generate(const Params& P, Out& o) {
       size_t cnt = 0, i = 0;
       for (; i < tc.base.size() && cnt < P.target_len; i++) {
         if (tc.base[i] != DEL) cnt++;
-        if (cnt + tc.ins[i].size() > P.target_len) tc.ins[i].resize(P.target_len - cnt);
-        cnt += tc.ins[i].size();
+        uint32_t ni = tc.ins_n(i);
+        if (cnt + ni > P.target_len) {   // the last column keeps only the insertions that still fit (its successors are dropped below)
+          ni = (uint32_t)(P.target_len - cnt);
+          tc.ioff[i + 1] = tc.ioff[i] + ni;
+        }
+        cnt += ni;
       }
-      tc.base.resize(i);
-      tc.ins.resize(i);
       // drop trailing columns that contributed nothing
-      while (!tc.base.empty() && tc.base.back() == DEL && tc.ins.back().empty()) {
-        tc.base.pop_back();
-        tc.ins.pop_back();
-      }
+      while (i > 0 && tc.base[i - 1] == DEL && tc.ins_n(i - 1) == 0) i--;
+      tc.base.resize(i);
+      tc.ioff.resize(i + 1);
+      tc.idata.resize(tc.ioff[i]);
     }
     std::vector<uint8_t> tseq;
     flatten(tc, tseq);
@@ -188,8 +211,13 @@ void generate(const Params& P, Out& o) {
     // target prefix sums: bases before column i
     std::vector<uint32_t> tpre(tc.base.size() + 1, 0);
     for (size_t i = 0; i < tc.base.size(); i++)
-      tpre[i + 1] = tpre[i] + (tc.base[i] != DEL) + (uint32_t)tc.ins[i].size();
-    for (uint8_t b : tseq) o.seq.push_back((uint8_t)(g.bern(P.p_n_base) ? 'N' : ACGT[b]));
+      tpre[i + 1] = tpre[i] + (tc.base[i] != DEL) + tc.ins_n(i);
+    {
+      const uint64_t t_n = Rng::threshold(P.p_n_base);
+      const size_t at = o.seq.size();
+      o.seq.resize(at + tseq.size());
+      for (size_t i = 0; i < tseq.size(); i++) o.seq[at + i] = (uint8_t)(g.bern_t(t_n) ? 'N' : ACGT[tseq[i]]);
+    }
     gen_quals(g, tseq.size(), o.qual);
     o.off.push_back(o.seq.size());
     o.tgt_rid.push_back(tid);
@@ -220,19 +248,22 @@ void generate(const Params& P, Out& o) {
       uint32_t q_before = 0;
       for (int64_t a = lo; a < c0; a++) {
         const size_t i = (size_t)(a - lo);
-        q_before += (qc.base[i] != DEL) + (uint32_t)qc.ins[i].size();
+        q_before += (qc.base[i] != DEL) + qc.ins_n(i);
       }
       uint32_t tstart = tpre[(size_t)(c0 - ta0)], tend = tstart, qs = q_before, qe = q_before;
+      cg.ops.reserve(512);
       for (int64_t a = c0; a < c1; a++) {
         const size_t ti = (size_t)(a - ta0), qi = (size_t)(a - lo);
         const bool tb = tc.base[ti] != DEL, qb = qc.base[qi] != DEL;
         if (tb && qb) cg.add('M', 1);
         else if (tb) cg.add('D', 1);
         else if (qb) cg.add('I', 1);
-        const uint32_t x = (uint32_t)tc.ins[ti].size(), y = (uint32_t)qc.ins[qi].size();
-        cg.add('M', std::min(x, y));
-        if (x > y) cg.add('D', x - y);
-        if (y > x) cg.add('I', y - x);
+        const uint32_t x = tc.ins_n(ti), y = qc.ins_n(qi);
+        if (x | y) {
+          cg.add('M', std::min(x, y));
+          if (x > y) cg.add('D', x - y);
+          if (y > x) cg.add('I', y - x);
+        }
         tend += tb + x;
         qe += qb + y;
       }
@@ -250,12 +281,18 @@ void generate(const Params& P, Out& o) {
       const bool rev = g.bern(0.5);
       std::vector<uint8_t> qq;
       gen_quals(g, qseq.size(), qq);
-      if (rev) {
-        for (size_t i = qseq.size(); i-- > 0;) o.seq.push_back((uint8_t)ACGT[3 - qseq[i]]);
-        for (size_t i = qq.size(); i-- > 0;) o.qual.push_back(qq[i]);
-      } else {
-        for (uint8_t b : qseq) o.seq.push_back((uint8_t)ACGT[b]);
-        o.qual.insert(o.qual.end(), qq.begin(), qq.end());
+      {
+        const size_t at = o.seq.size(), n = qseq.size();
+        o.seq.resize(at + n);
+        o.qual.resize(at + n);
+        uint8_t* ds = o.seq.data() + at;
+        uint8_t* dq = o.qual.data() + at;
+        if (rev) {
+          for (size_t i = 0; i < n; i++) { ds[i] = (uint8_t)ACGT[3 - qseq[n - 1 - i]]; dq[i] = qq[n - 1 - i]; }
+        } else {
+          for (size_t i = 0; i < n; i++) ds[i] = (uint8_t)ACGT[qseq[i]];
+          memcpy(dq, qq.data(), n);
+        }
       }
       o.off.push_back(o.seq.size());
       if (cg.ops.empty()) continue;
@@ -297,6 +334,29 @@ void herro_synth_sizes(void* h, uint64_t* s) {
   Out* o = (Out*)h;
   s[0] = o->off.size() - 1; s[1] = o->seq.size(); s[2] = o->cig_off.size(); s[3] = o->cig.size();
   s[4] = o->tgt_rid.size();
+}
+// One part of a batch generated in chunks, written straight into its place in the merged arrays (herro_amd/synth.py
+// generate_parallel): read ids, base offsets, alignment and CIGAR offsets rebased by what the parts in front of it hold.
+// seq / qual / cig / aln / cig_off / tgt_rid point at the part's first element; off and tgt_aln_off at the element BEFORE it
+// (the merged arrays carry one leading 0, written by the caller).
+void herro_synth_copy_into(void* h, uint8_t* seq, uint8_t* qual, uint64_t* off, uint32_t* aln, uint64_t* cig_off, uint8_t* cig,
+                           uint64_t* tgt_aln_off, uint32_t* tgt_rid, uint64_t rbase, uint64_t bbase, uint64_t abase, uint64_t cbase) {
+  Out* o = (Out*)h;
+  memcpy(seq, o->seq.data(), o->seq.size());
+  memcpy(qual, o->qual.data(), o->qual.size());
+  for (size_t i = 1; i < o->off.size(); i++) off[i] = o->off[i] + bbase;
+  const size_t na = o->cig_off.size();
+  for (size_t a = 0; a < na; a++) {
+    const uint32_t* r = &o->aln[a * 10];
+    uint32_t* d = aln + a * 10;
+    memcpy(d, r, 40);
+    d[0] = r[0] + (uint32_t)rbase;   // qid
+    d[5] = r[5] + (uint32_t)rbase;   // tid
+    cig_off[a] = o->cig_off[a] + cbase;
+  }
+  memcpy(cig, o->cig.data(), o->cig.size());
+  for (size_t t = 1; t < o->tgt_aln_off.size(); t++) tgt_aln_off[t] = o->tgt_aln_off[t] + abase;
+  for (size_t t = 0; t < o->tgt_rid.size(); t++) tgt_rid[t] = o->tgt_rid[t] + (uint32_t)rbase;
 }
 void herro_synth_copy(void* h, uint8_t* seq, uint8_t* qual, uint64_t* off, uint32_t* aln,
                       uint64_t* cig_off, uint8_t* cig, uint64_t* tgt_aln_off, uint32_t* tgt_rid) {

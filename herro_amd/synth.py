@@ -41,6 +41,7 @@ def _lib():
         _LIB.herro_synth_free.argtypes = [C.c_void_p]
         _LIB.herro_synth_sizes.argtypes = [C.c_void_p, C.c_void_p]
         _LIB.herro_synth_copy.argtypes = [C.c_void_p] + [C.c_void_p] * 8
+        _LIB.herro_synth_copy_into.argtypes = [C.c_void_p] + [C.c_void_p] * 8 + [C.c_uint64] * 4
     return _LIB
 
 
@@ -75,19 +76,29 @@ class SynthBatch:
         return self.seq[int(self.off[rid]):int(self.off[rid + 1])].tobytes()
 
 
+def _params(n_targets, target_len, n_overlaps, seed, flank_min=500, flank_max=1000, p_sub=0.006, p_ins=0.004, p_del=0.006,
+            p_long_indel=0.0, p_partial=0.0, p_n_base=0.0, min_partial_len=0, p_snp=0.0) -> _Params:
+    return _Params(seed, n_targets, target_len, n_overlaps, flank_min, flank_max,
+                   min_partial_len or max(1, target_len // 4), p_sub, p_ins, p_del, p_long_indel,
+                   p_partial, p_n_base, p_snp)
+
+
+def _sizes(h) -> tuple[int, int, int, int, int]:
+    sizes = np.zeros(5, np.uint64)
+    _lib().herro_synth_sizes(h, sizes.ctypes.data)
+    return tuple(int(x) for x in sizes)   # n_reads, bases, alignments, cigar bytes, targets
+
+
 def generate(n_targets: int, target_len: int = 4 * 4096, n_overlaps: int = 32, *, seed: int = SEED,
              flank_min: int = 500, flank_max: int = 1000, p_sub: float = 0.006, p_ins: float = 0.004,
              p_del: float = 0.006, p_long_indel: float = 0.0, p_partial: float = 0.0,
              p_n_base: float = 0.0, min_partial_len: int = 0, p_snp: float = 0.0) -> SynthBatch:
     lib = _lib()
-    p = _Params(seed, n_targets, target_len, n_overlaps, flank_min, flank_max,
-                min_partial_len or max(1, target_len // 4), p_sub, p_ins, p_del, p_long_indel,
-                p_partial, p_n_base, p_snp)
+    p = _params(n_targets, target_len, n_overlaps, seed, flank_min, flank_max, p_sub, p_ins, p_del, p_long_indel, p_partial,
+                p_n_base, min_partial_len, p_snp)
     h = lib.herro_synth_generate(C.byref(p))
     try:
-        sizes = np.zeros(5, np.uint64)
-        lib.herro_synth_sizes(h, sizes.ctypes.data)
-        n_reads, nb, n_aln, ncig, nt = (int(x) for x in sizes)
+        n_reads, nb, n_aln, ncig, nt = _sizes(h)
         b = SynthBatch(
             seq=np.empty(nb, np.uint8), qual=np.empty(nb, np.uint8), off=np.empty(n_reads + 1, np.uint64),
             aln=np.empty((n_aln, 10), np.uint32), cig_off=np.empty(n_aln, np.uint64),
@@ -153,11 +164,41 @@ def generate_parallel(n_targets: int, target_len: int = 4 * 4096, n_overlaps: in
     single-threaded C++ call that releases the GIL; chunk i uses seed + 7919 * i) and merged.  The data differ
     from one `generate(n_targets, seed=seed)` call — same distribution, different draws."""
     import concurrent.futures as cf
-    import os
     sizes = [min(chunk, n_targets - i) for i in range(0, n_targets, chunk)]
     if len(sizes) <= 1:
         return generate(n_targets, target_len, n_overlaps, seed=seed, **kw)
     workers = workers or min(len(sizes), usable_cpus(), 64)
-    with cf.ThreadPoolExecutor(workers) as ex:
-        parts = list(ex.map(lambda iz: generate(iz[1], target_len, n_overlaps, seed=seed + 7919 * iz[0], **kw), enumerate(sizes)))
-    return merge(parts)
+    lib = _lib()
+    handles: list = [None] * len(sizes)
+
+    def make(iz):
+        p = _params(iz[1], target_len, n_overlaps, seed + 7919 * iz[0], **kw)
+        handles[iz[0]] = lib.herro_synth_generate(C.byref(p))     # (ctypes releases the GIL for the call)
+        return _sizes(handles[iz[0]])
+    try:
+        with cf.ThreadPoolExecutor(workers) as ex:
+            sz = np.array(list(ex.map(make, enumerate(sizes))), np.int64).reshape(len(sizes), 5)
+            base = np.concatenate([np.zeros((1, 5), np.int64), np.cumsum(sz, axis=0)])    # reads, bases, alignments, cigar bytes, targets in front of part i
+            n_reads, nb, n_aln, ncig, nt = (int(x) for x in base[-1])
+            # the merged arrays are allocated once and every part is written into its slice by the thread pool (the first
+            # touch of the pages included): `merge` of per-part arrays spent more time in page faults than the generator in all
+            # its arithmetic
+            b = SynthBatch(seq=np.empty(nb, np.uint8), qual=np.empty(nb, np.uint8), off=np.empty(n_reads + 1, np.uint64),
+                           aln=np.empty((n_aln, 10), np.uint32), cig_off=np.empty(n_aln, np.uint64), cig=np.empty(ncig, np.uint8),
+                           tgt_aln_off=np.empty(nt + 1, np.uint64), tgt_rid=np.empty(nt, np.uint32))
+            b.off[0] = 0
+            b.tgt_aln_off[0] = 0
+
+            def place(i):
+                r0, b0, a0, c0, t0 = (int(x) for x in base[i])
+                lib.herro_synth_copy_into(handles[i], b.seq.ctypes.data + b0, b.qual.ctypes.data + b0, b.off.ctypes.data + 8 * r0,
+                                          b.aln.ctypes.data + 40 * a0, b.cig_off.ctypes.data + 8 * a0, b.cig.ctypes.data + c0,
+                                          b.tgt_aln_off.ctypes.data + 8 * t0, b.tgt_rid.ctypes.data + 4 * t0, r0, b0, a0, c0)
+                lib.herro_synth_free(handles[i])
+                handles[i] = None
+            list(ex.map(place, range(len(sizes))))
+        return b
+    finally:
+        for h in handles:
+            if h is not None:
+                lib.herro_synth_free(h)
