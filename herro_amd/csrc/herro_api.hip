@@ -114,10 +114,13 @@ struct HostPool {
       if (--active == 0) done_cv.notify_one();
     }
   }
-  // fn(i) for i in [0, count), on the workers and the calling thread; returns when all are done
+  // fn(i) for i in [0, count), on the workers and the calling thread; returns when all are done.  One run at a time: a second
+  // caller (herro_set_reads beside a herro_job_create of another thread on the same context) waits its turn.
+  std::mutex run_mu;
   void run(uint32_t count, const std::function<void(uint32_t)>& f) {
     if (count == 0) return;
     if (th.empty() || count == 1) { for (uint32_t i = 0; i < count; i++) f(i); return; }
+    std::lock_guard<std::mutex> one_run(run_mu);
     {
       std::lock_guard<std::mutex> lk(m);
       fn = &f; n = count; next.store(0); active = (uint32_t)th.size(); gen++;

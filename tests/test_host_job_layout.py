@@ -235,3 +235,37 @@ def test_token_tile_plan_packs_whole_windows_into_fewer_tiles():
         api.debug_tile_plan(np.array([3, 0, 2], np.uint32))
     with pytest.raises(api.HerroError):
         api.debug_tile_plan(np.array([65], np.uint32))
+
+
+def test_two_threads_create_jobs_on_one_context():
+    """The context's host pool takes one parallel section at a time: two threads building jobs on the same context get the same
+    descriptors as one thread building them in turn."""
+    import threading
+    sb = synth.generate(48, 3000, 10, seed=77, flank_min=30, flank_max=60, p_partial=0.3)
+    lens = (sb.off[1:] - sb.off[:-1]).astype(np.uint32)
+    W = 512
+    c = api.HostContext(lens)
+    want = {}
+    for k in range(4):
+        j = api.job_from_synth(c, sb, W, range(12 * k, 12 * k + 12))
+        want[k] = c.job_arrays(j)
+        j.close()
+    bad, errs = [], []
+
+    def worker(ks):
+        try:
+            for _ in range(40):
+                for k in ks:
+                    j = api.job_from_synth(c, sb, W, range(12 * k, 12 * k + 12))
+                    got = c.job_arrays(j)
+                    j.close()
+                    if got.keys() != want[k].keys() or any(got[n].tobytes() != want[k][n].tobytes() for n in got):
+                        bad.append(k)
+        except Exception as e:
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(ks,)) for ks in ((0, 1), (2, 3))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs and not bad
