@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--strong-windows", type=int, default=32768,
                     help="size of the fixed job of the 'strong' leg that follows the weak measurement (the sharded data path: rank 0 ingests, "
                          "scatter / gather; BASELINE configs[3] uses 100000 — its read set takes ~30 GB of host memory); 0: skip")
+    ap.add_argument("--strong-timeout", type=float, default=420.0, help="seconds the 'strong' leg may take before the line goes out without it")
     ap.add_argument("--settle", type=float, default=0.2, help="seconds of untimed steps on top of --warmup before the timed pass")
     ap.add_argument("--repeats", type=int, default=3, help="further timed passes of the same K steps after the measured one (spread only)")
     ap.add_argument("--min-jobs", type=int, default=1,
@@ -535,18 +536,38 @@ def main():
     for c in ctxs:
         c.close()
     # ---- the sharded data path on ONE fixed job (every rank takes part; figures on rank 0, same JSON line)
+    strong_failed = False
     if args.strong_windows > 0:
         from herro_amd import shard
-        try:
-            strong = shard.strong_leg(args, rank, world, local, args.strong_windows, model_path=path)
-        except Exception as e:   # never lose the measured line to the extra leg
-            strong = {"error": repr(e)}
+        # The measured line must not be lost to the extra leg — neither to an exception nor to a hang (a rank that fails before a
+        # send leaves its peers waiting in a receive for ever).  The leg runs on a worker thread under a deadline; a rank on which
+        # it failed or ran out of time reports that (rank 0: in the line) and leaves without the collective shutdown.
+        box = {}
+
+        def leg():
+            try:
+                torch.cuda.set_device(local)   # the current device is per thread
+                box["r"] = shard.strong_leg(args, rank, world, local, args.strong_windows, model_path=path)
+            except BaseException as e:
+                box["e"] = repr(e)
+        th = threading.Thread(target=leg, daemon=True)
+        th.start()
+        th.join(args.strong_timeout)
+        if th.is_alive():
+            strong, strong_failed = {"error": f"no result within --strong-timeout {args.strong_timeout:.0f} s"}, True
+        elif "e" in box:
+            strong, strong_failed = {"error": box["e"]}, True
+        else:
+            strong = box.get("r")
         if rank == 0:
             out["strong"] = strong
             if isinstance(strong, dict) and "windows_per_s" in strong and out.get("end_to_end"):
                 strong["vs_end_to_end"] = strong["windows_per_s"] / (out["end_to_end"]["windows_per_s"] or 1.0)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if strong_failed and world > 1:
+        sys.stderr.flush()
+        os._exit(0)     # peers may be stuck in a collective of the failed leg: no destroy_process_group, no atexit handlers
     if world > 1:
         dist.destroy_process_group()
 

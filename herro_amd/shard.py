@@ -123,23 +123,65 @@ def shard_arrays(sb, targets):
     return np.asarray(sb.tgt_rid)[targets], aln_off, rows, src_off, sb.cig
 
 
-def shard_work(sb, targets) -> np.ndarray:
-    """pack_work of the given target indices: the message for another rank.  Vectorised: one slice of the CIGAR blob per run of
-    alignments whose texts lie back to back (they do in every producer here)."""
+def work_size(sb, targets) -> int:
+    """len(shard_work(sb, targets)) without building the message (rank 0 announces all sizes before it packs anything)."""
+    targets = np.asarray(targets, np.int64)
+    n = len(targets)
+    if n == 0:
+        return 24 + 8
+    off = np.asarray(sb.tgt_aln_off, np.int64)
+    a0, a1 = off[targets], off[targets + 1]
+    m = int((a1 - a0).sum())
+    if m == int(a1[-1] - a0[0]):     # consecutive targets
+        c = int(np.asarray(sb.aln[int(a0[0]):int(a1[-1]), 9], np.int64).sum())
+    else:
+        c = int(sum(int(np.asarray(sb.aln[int(x):int(y), 9], np.int64).sum()) for x, y in zip(a0, a1)))
+    return 24 + 8 * (n + 1) + 8 * m + 4 * n + 40 * m + c
+
+
+_SCRATCH: dict = {}
+
+
+def _scratch(slot, nbytes: int) -> np.ndarray:
+    """A reusable message buffer per destination (grow-only): the pages of a fresh 50 MB array are touched for the first time
+    while it is filled, which costs more than the copy itself; the second job through the path finds them mapped."""
+    b = _SCRATCH.get(slot)
+    if b is None or len(b) < nbytes:
+        b = _SCRATCH[slot] = np.empty(int(nbytes * 1.25) + 4096, np.uint8)
+    return b[:nbytes]
+
+
+def shard_work(sb, targets, slot=None) -> np.ndarray:
+    """pack_work of the given target indices: the message for another rank, written ONCE into one buffer (header, offsets, read
+    ids, PAF rows, then one slice of the CIGAR blob per run of alignments whose texts lie back to back — they do in every
+    producer here)."""
     rids, aln_off, rows, src_off, blob = shard_arrays(sb, targets)
-    total = len(rows)
+    n, total = len(rids), len(rows)
     lens = rows[:, 9].astype(np.uint64) if total else np.zeros(0, np.uint64)
-    cig_off = np.zeros(total, np.uint64)
+    c = int(lens.sum()) if total else 0
+    nbytes = 24 + 8 * (n + 1) + 8 * total + 4 * n + 40 * total + c
+    buf = np.empty(nbytes, np.uint8) if slot is None else _scratch(slot, nbytes)   # slot: reuse this destination's buffer
+    buf[:24].view(np.uint64)[:] = (n, total, c)
+    o = 24
+    buf[o:o + 8 * (n + 1)].view(np.uint64)[:] = aln_off; o += 8 * (n + 1)
+    cig_off = buf[o:o + 8 * total].view(np.uint64); o += 8 * total
     if total:
-        cig_off[1:] = np.cumsum(lens)[:-1]
-    brk = np.ones(total, bool)
-    if total > 1:
-        brk[1:] = src_off[1:] != src_off[:-1] + lens[:-1]
-    run0 = np.flatnonzero(brk)
-    run1 = np.concatenate([run0[1:], [total]]) if total else run0
-    pieces = [blob[int(src_off[i]):int(src_off[j - 1] + lens[j - 1])] for i, j in zip(run0, run1)]
-    cig = np.concatenate(pieces) if pieces else np.zeros(0, np.uint8)
-    return pack_work(rids, aln_off, rows, cig_off, cig)
+        cig_off[0] = 0
+        np.cumsum(lens[:-1], out=cig_off[1:])
+    buf[o:o + 4 * n].view(np.uint32)[:] = rids; o += 4 * n
+    buf[o:o + 40 * total].view(np.uint32).reshape(total, 10)[:] = rows; o += 40 * total
+    if total:
+        brk = np.ones(total, bool)
+        if total > 1:
+            brk[1:] = src_off[1:] != src_off[:-1] + lens[:-1]
+        run0 = np.flatnonzero(brk)
+        run1 = np.concatenate([run0[1:], [total]])
+        for i, j in zip(run0, run1):
+            b0, b1 = int(src_off[i]), int(src_off[j - 1] + lens[j - 1])
+            buf[o:o + b1 - b0] = blob[b0:b1]
+            o += b1 - b0
+    assert o == len(buf)
+    return buf
 
 
 def _exchange_sizes(sizes_on_root, n_local: int, root_to_all: bool, group=None) -> list[int]:
@@ -158,26 +200,36 @@ def _exchange_sizes(sizes_on_root, n_local: int, root_to_all: bool, group=None) 
     return [int(x) for x in t.cpu().tolist()]
 
 
-def scatter_bytes(messages, group=None) -> np.ndarray:
-    """rank 0 holds one u8 message per rank; every rank gets its own.  Sizes by one broadcast, payloads by grouped
-    point-to-point sends (RCCL has no scatterv)."""
+def scatter_bytes(messages, group=None, sizes=None) -> np.ndarray:
+    """rank 0 holds one u8 message per rank (or a callable that builds it, with `sizes` = their lengths); every rank gets its
+    own.  Sizes by one broadcast, payloads by grouped point-to-point sends (RCCL has no scatterv)."""
     import torch
     dist = _dist()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if world == 1:
         return np.ascontiguousarray(messages[0], np.uint8)
     dev = _dev(group)
-    sizes = _exchange_sizes([len(m) for m in messages] if rank == 0 else None, 0, True, group)
+    if rank == 0 and sizes is None:
+        sizes = [len(m) for m in messages]
+    sizes = _exchange_sizes(sizes if rank == 0 else None, 0, True, group)
     if rank == 0:
-        ops, keep = [], []
-        for r in range(1, world):
-            if sizes[r]:
-                t = torch.from_numpy(np.ascontiguousarray(messages[r], np.uint8)).to(dev)
-                keep.append(t)
-                ops.append(dist.P2POp(dist.isend, t, r, group=group))
+        # a message may be a callable that builds it (sizes given by the caller): the peers' messages are packed and staged on
+        # the transport's device by a few threads at once (numpy copies and torch's H2D release the GIL), then sent in one group
+        import concurrent.futures as cf
+
+        def stage(r):
+            m = messages[r]() if callable(messages[r]) else messages[r]
+            m = np.ascontiguousarray(m, np.uint8)
+            assert len(m) == sizes[r], (r, len(m), sizes[r])
+            return torch.from_numpy(m).to(dev)
+        todo = [r for r in range(1, world) if sizes[r]]
+        with cf.ThreadPoolExecutor(max(1, min(len(todo), 8))) as ex:
+            keep = dict(zip(todo, ex.map(stage, todo)))
+        ops = [dist.P2POp(dist.isend, keep[r], r, group=group) for r in todo]
         for w in (dist.batch_isend_irecv(ops) if ops else []):
             w.wait()
-        return np.ascontiguousarray(messages[0], np.uint8)
+        m0 = messages[0]() if callable(messages[0]) else messages[0]
+        return np.ascontiguousarray(m0, np.uint8)
     buf = torch.empty(sizes[rank], dtype=torch.uint8, device=dev)
     if sizes[rank]:
         for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf, 0, group=group)]):
@@ -185,23 +237,25 @@ def scatter_bytes(messages, group=None) -> np.ndarray:
     return buf.cpu().numpy()
 
 
-def gather_bytes(message: bytes, group=None):
-    """every rank contributes one byte string; rank 0 returns the list (others None).  gatherv by grouped send / recv."""
+def gather_bytes(message, group=None):
+    """every rank contributes one message (bytes or a u8 array); rank 0 returns the list of u8 arrays in rank order (others
+    None).  gatherv by grouped send / recv; nothing is copied on the way except by the transport."""
     import torch
     dist = _dist()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    mine = np.frombuffer(message, np.uint8) if isinstance(message, (bytes, bytearray, memoryview)) else np.ascontiguousarray(message, np.uint8)
     if world == 1:
-        return [bytes(message)]
+        return [mine]
     dev = _dev(group)
-    sizes = _exchange_sizes(None, len(message), False, group)
+    sizes = _exchange_sizes(None, len(mine), False, group)
     if rank == 0:
         bufs = [None] + [torch.empty(sizes[r], dtype=torch.uint8, device=dev) for r in range(1, world)]
         ops = [dist.P2POp(dist.irecv, bufs[r], r, group=group) for r in range(1, world) if sizes[r]]
         for w in (dist.batch_isend_irecv(ops) if ops else []):
             w.wait()
-        return [bytes(message)] + [bufs[r].cpu().numpy().tobytes() for r in range(1, world)]
-    if len(message):
-        t = torch.from_numpy(np.frombuffer(message, np.uint8).copy()).to(dev)
+        return [mine] + [bufs[r].cpu().numpy() for r in range(1, world)]
+    if len(mine):
+        t = torch.from_numpy(mine if mine.flags.writeable else mine.copy()).to(dev)   # (torch wants a writeable array to wrap)
         for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, t, 0, group=group)]):
             w.wait()
     return None
@@ -234,8 +288,13 @@ def pack_records(rids, ends, text) -> np.ndarray:
     rids = np.ascontiguousarray(rids, np.uint32)
     ends = np.ascontiguousarray(ends, np.uint64)
     text = np.frombuffer(text, np.uint8) if isinstance(text, (bytes, bytearray, memoryview)) else np.ascontiguousarray(text, np.uint8)
-    hdr = np.array([len(rids), len(text)], np.uint64)
-    return np.concatenate([hdr.view(np.uint8), ends.view(np.uint8), rids.view(np.uint8), text])
+    n, nb = len(rids), len(text)
+    buf = np.empty(16 + 12 * n + nb, np.uint8)
+    buf[:16].view(np.uint64)[:] = (n, nb)
+    buf[16:16 + 8 * n].view(np.uint64)[:] = ends
+    buf[16 + 8 * n:16 + 12 * n].view(np.uint32)[:] = rids
+    buf[16 + 12 * n:] = text
+    return buf
 
 
 def unpack_records(buf):
@@ -280,14 +339,15 @@ def correct_sharded(sb, n_windows_per_target, correct_fn, group=None):
     if rank == 0:   # its own shard needs no message: views into the data set
         parts = partition_targets(n_windows_per_target, world)
         if world > 1:
-            scatter_bytes([np.zeros(0, np.uint8)] + [shard_work(sb, p) for p in parts[1:]], group)
+            scatter_bytes([np.zeros(0, np.uint8)] + [(lambda p=p, r=r: shard_work(sb, p, slot=("work", r))) for r, p in enumerate(parts[1:], 1)], group,
+                          sizes=[0] + [work_size(sb, p) for p in parts[1:]])
         rids, aln_off, rows, cig_off, cig = shard_arrays(sb, parts[0])
     else:
         rids, aln_off, rows, cig_off, cig = unpack_work(scatter_bytes(None, group))
     rec = correct_fn(rids, aln_off, rows, cig_off, cig) if len(rids) else (np.zeros(0, np.uint32), np.zeros(0, np.uint64), b"")
     if world == 1:
         return merge_records([rec]), len(rids)
-    gathered = gather_bytes(pack_records(*rec).tobytes(), group)
+    gathered = gather_bytes(pack_records(*rec), group)
     if rank != 0:
         return None, len(rids)
     return merge_records([unpack_records(g) for g in gathered]), len(rids)

@@ -66,11 +66,13 @@ class FakeCtx:
         return {n: (1.0 + i, 4) for i, n in enumerate(names)}
 
 
-@pytest.mark.parametrize("argv,steps", [(["--steps", "12", "--warmup", "4", "--group", "3", "--streams", "2"], 12),
-                                        (["--steps", "7", "--warmup", "1", "--group", "32", "--streams", "2"], 7),
-                                        (["--steps", "1", "--warmup", "0"], 1),
-                                        ([], None)])
-def test_bench_flow(monkeypatch, capsys, argv, steps):
+@pytest.mark.parametrize("argv,steps,strong_mode", [(["--steps", "12", "--warmup", "4", "--group", "3", "--streams", "2"], 12, "ok"),
+                                                    (["--steps", "7", "--warmup", "1", "--group", "32", "--streams", "2"], 7, "ok"),
+                                                    (["--steps", "1", "--warmup", "0"], 1, "ok"),
+                                                    ([], None, "ok"),
+                                                    (["--steps", "2", "--warmup", "0"], 2, "raises"),
+                                                    (["--steps", "2", "--warmup", "0", "--strong-timeout", "0.3"], 2, "hangs")])
+def test_bench_flow(monkeypatch, capsys, argv, steps, strong_mode):
     import torch
     from herro_amd import api, synth, model_io
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
@@ -94,7 +96,15 @@ def test_bench_flow(monkeypatch, capsys, argv, steps):
     monkeypatch.setattr(synth, "generate", lambda *a, **k: fake_sb)
     monkeypatch.setattr(model_io, "default_model_file", lambda d: ("model.bin", None))
     from herro_amd import shard
-    monkeypatch.setattr(shard, "strong_leg", lambda *a, **k: {"windows_per_s": 2.0, "windows": 8, "ranks_seen": 1})
+    hang = __import__("threading").Event()
+
+    def fake_strong(*a, **k):
+        if strong_mode == "raises":
+            raise RuntimeError("a peer went away")
+        if strong_mode == "hangs":
+            hang.wait(30)          # a rank stuck in a receive: the line must go out without the leg
+        return {"windows_per_s": 2.0, "windows": 8, "ranks_seen": 1}
+    monkeypatch.setattr(shard, "strong_leg", fake_strong)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--no-cpu-baseline", "--self-check", "0"] + argv)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
@@ -102,6 +112,7 @@ def test_bench_flow(monkeypatch, capsys, argv, steps):
     bench = importlib.import_module("bench")
     FakeJob.log = []
     bench.main()
+    hang.set()
     out = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
     assert len(out) == 1, out
     d = json.loads(out[0])
@@ -111,7 +122,11 @@ def test_bench_flow(monkeypatch, capsys, argv, steps):
         assert d["steps"] == steps
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["unit"] == "windows/s" and "workload" in d["config"]
-    assert d["strong"]["ranks_seen"] == d["n_gpus"] and d["strong"]["windows_per_s"] > 0   # the sharded leg rides in the same line
+    if strong_mode == "ok":
+        assert d["strong"]["ranks_seen"] == d["n_gpus"] and d["strong"]["windows_per_s"] > 0   # the sharded leg rides in the same line
+    else:   # the measured line survives a leg that fails or never comes back
+        assert "error" in d["strong"] and d["value"] > 0
+        assert ("peer went away" in d["strong"]["error"]) if strong_mode == "raises" else ("strong-timeout" in d["strong"]["error"])
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
     assert len(d["roofline_next_kernels"]) == 2 and all({"kernel", "bound", "frac"} <= set(r) for r in d["roofline_next_kernels"])
     assert d["roofline"]["launch_us"] >= d["roofline_next_kernels"][0]["launch_us"] >= d["roofline_next_kernels"][1]["launch_us"]
