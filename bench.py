@@ -536,7 +536,7 @@ def main():
     for c in ctxs:
         c.close()
     # ---- the sharded data path on ONE fixed job (every rank takes part; figures on rank 0, same JSON line)
-    strong_failed = False
+    strong_failed = strong_hung = False
     if args.strong_windows > 0:
         from herro_amd import shard
         # The measured line must not be lost to the extra leg — neither to an exception nor to a hang (a rank that fails before a
@@ -554,7 +554,7 @@ def main():
         th.start()
         th.join(args.strong_timeout)
         if th.is_alive():
-            strong, strong_failed = {"error": f"no result within --strong-timeout {args.strong_timeout:.0f} s"}, True
+            strong, strong_failed, strong_hung = {"error": f"no result within --strong-timeout {args.strong_timeout:.0f} s"}, True, True
         elif "e" in box:
             strong, strong_failed = {"error": box["e"]}, True
         else:
@@ -565,9 +565,12 @@ def main():
                 strong["vs_end_to_end"] = strong["windows_per_s"] / (out["end_to_end"]["windows_per_s"] or 1.0)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if strong_failed and world > 1:
+    if strong_failed and (world > 1 or strong_hung):
+        # peers may be stuck in a collective of the failed leg, or this process's own worker thread inside a HIP call: leave
+        # without destroy_process_group and without tearing the runtime down under it
+        sys.stdout.flush()
         sys.stderr.flush()
-        os._exit(0)     # peers may be stuck in a collective of the failed leg: no destroy_process_group, no atexit handlers
+        os._exit(0)
     if world > 1:
         dist.destroy_process_group()
 

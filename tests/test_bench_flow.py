@@ -111,8 +111,14 @@ def test_bench_flow(monkeypatch, capsys, argv, steps, strong_mode):
     sys.path.insert(0, ROOT)
     bench = importlib.import_module("bench")
     FakeJob.log = []
-    bench.main()
+    left = []
+    monkeypatch.setattr(os, "_exit", lambda code: (left.append(code), (_ for _ in ()).throw(SystemExit(code))))
+    try:
+        bench.main()
+    except SystemExit:
+        assert strong_mode == "hangs" and left == [0]     # a stuck leg: the process leaves without tearing the runtime down under it
     hang.set()
+    assert (strong_mode == "hangs") == bool(left)
     out = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
     assert len(out) == 1, out
     d = json.loads(out[0])
