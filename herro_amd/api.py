@@ -23,7 +23,8 @@ EXPORTS = [
     "herro_job_consensus_fasta", "herro_job_fasta", "herro_model_forward", "herro_timing_enable", "herro_timing_reset",
     "herro_timing_get", "herro_job_stats", "herro_debug_extract_windows",
     "herro_paf_parse", "herro_oec_read", "herro_paf_n_targets", "herro_paf_target_ids", "herro_paf_aln_off",
-    "herro_paf_alignments", "herro_paf_free", "herro_debug_host_ctx", "herro_debug_job_array", "herro_debug_tile_plan",
+    "herro_paf_alignments", "herro_paf_free", "herro_name_index_create", "herro_name_index_free", "herro_paf_parse_indexed",
+    "herro_oec_read_indexed", "herro_debug_host_ctx", "herro_debug_job_array", "herro_debug_tile_plan",
     "herro_fastx_read", "herro_reads_count", "herro_reads_seq", "herro_reads_qual", "herro_reads_off", "herro_reads_ids",
     "herro_reads_descs", "herro_reads_free", "herro_write_window_features", "herro_job_write_features",
 ]
@@ -105,6 +106,14 @@ def lib():
             f.argtypes = [vp]
         L.herro_paf_free.restype = None
         L.herro_paf_free.argtypes = [vp]
+        L.herro_name_index_create.restype = vp
+        L.herro_name_index_create.argtypes = [u32, C.c_char_p, vp]
+        L.herro_name_index_free.restype = None
+        L.herro_name_index_free.argtypes = [vp]
+        L.herro_paf_parse_indexed.restype = vp
+        L.herro_paf_parse_indexed.argtypes = [C.c_char_p, u64, vp, vp, i32, vp, u64]
+        L.herro_oec_read_indexed.restype = vp
+        L.herro_oec_read_indexed.argtypes = [C.c_char_p, vp, vp, i32, vp, u64]
         L.herro_debug_host_ctx.restype = vp
         L.herro_debug_host_ctx.argtypes = [u32, vp, vp]
         L.herro_debug_job_array.restype = C.c_int64
@@ -411,24 +420,53 @@ class HostContext(Context):
         return out
 
 
-class Paf:
-    """Parsed PAF / .oec.zst batch (host only; overlaps.rs:117-202, 292-323): targets in order of first
-    appearance, their alignments in file order.  `targets`, `aln_off`, `alns` are what herro_job_create takes;
-    the CIGAR pointers inside `alns` stay valid while this object lives."""
+class NameIndex:
+    """read name -> read id, built once per read set (herro_name_index_create; the reference's `name_to_id`, lib.rs:136-140)."""
 
-    def __init__(self, names: list[bytes], text: bytes | None = None, path: str | None = None, core=None, threads: int = 0):
+    def __init__(self, names: list[bytes]):
         self.h = None
         L = lib()
         blob = b"".join(names)
         off = np.zeros(len(names) + 1, np.uint64)
         off[1:] = np.cumsum([len(n) for n in names])
+        self._l, self.n = L, len(names)
+        self.h = L.herro_name_index_create(len(names), blob, off.ctypes.data)
+        if not self.h:
+            raise HerroError(-1, "herro_name_index_create")
+
+    def close(self):
+        if self.h:
+            self._l.herro_name_index_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Paf:
+    """Parsed PAF / .oec.zst batch (host only; overlaps.rs:117-202, 292-323): targets in order of first
+    appearance, their alignments in file order.  `targets`, `aln_off`, `alns` are what herro_job_create takes;
+    the CIGAR pointers inside `alns` stay valid while this object lives.  `names`: the read ids, or a NameIndex built once."""
+
+    def __init__(self, names, text: bytes | None = None, path: str | None = None, core=None, threads: int = 0):
+        self.h = None
+        L = lib()
         core_a = None if core is None else np.ascontiguousarray(core, np.uint8)
         err = C.create_string_buffer(512)
         cptr = None if core_a is None else core_a.ctypes.data
-        if text is not None:
-            h = L.herro_paf_parse(text, len(text), len(names), blob, off.ctypes.data, cptr, threads, err, 512)
+        if isinstance(names, NameIndex):
+            if text is not None:
+                h = L.herro_paf_parse_indexed(text, len(text), names.h, cptr, threads, err, 512)
+            else:
+                h = L.herro_oec_read_indexed(path.encode(), names.h, cptr, threads, err, 512)
         else:
-            h = L.herro_oec_read(path.encode(), len(names), blob, off.ctypes.data, cptr, threads, err, 512)
+            blob = b"".join(names)
+            off = np.zeros(len(names) + 1, np.uint64)
+            off[1:] = np.cumsum([len(n) for n in names])
+            if text is not None:
+                h = L.herro_paf_parse(text, len(text), len(names), blob, off.ctypes.data, cptr, threads, err, 512)
+            else:
+                h = L.herro_oec_read(path.encode(), len(names), blob, off.ctypes.data, cptr, threads, err, 512)
         if not h:
             raise HerroError(-3, err.value.decode())
         self._l, self.h = L, h

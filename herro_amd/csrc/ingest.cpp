@@ -27,6 +27,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
+#include <memory>
 #include <string>
 #include <string_view>
 #include <thread>
@@ -106,7 +108,10 @@ void parse_line(std::string_view ln, const NameMap& names, const uint8_t* core, 
     if (!parse_u32(f, *p)) return panic("Character is not a valid digit");
   }
   if (exhausted) return panic("called `Option::unwrap()` on a `None` value");  // data.last() on an empty iterator
-  const size_t lt = ln.rfind('\t');
+  // (memrchr, not string_view::rfind: the last field is the CIGAR, ~1.6 KB per line, and rfind walks it a byte at a time —
+  // that walk was two thirds of the whole parse)
+  const void* ltp = memrchr(ln.data(), '\t', ln.size());
+  const size_t lt = ltp ? (size_t)((const char*)ltp - ln.data()) : std::string_view::npos;
   const std::string_view last = ln.substr(lt + 1);
   if (last.size() < 5) return panic("range start index 5 out of range for slice");
   r.a.cigar = reinterpret_cast<const uint8_t*>(last.data() + 5);
@@ -118,10 +123,20 @@ void parse_line(std::string_view ln, const NameMap& names, const uint8_t* core, 
 }  // namespace
 
 struct herro_paf {
-  std::string text;  // owns the bytes the cigar pointers refer to
+  // the bytes the cigar pointers refer to: either a buffer filled by the parser's threads (herro_paf_parse; not a std::string —
+  // resize() would zero 50 MB on one thread first) or the string the zstd decoder produced (herro_oec_read)
+  std::unique_ptr<char[]> buf;
+  std::string text;
   std::vector<uint32_t> tids;
   std::vector<uint64_t> aln_off;
   std::vector<herro_alignment> alns;
+};
+
+// read name -> read id, built once per read set (the reference's `name_to_id`, lib.rs:136-140) and shared by every parse
+struct herro_name_index {
+  std::string blob;      // the names, owned: the map's keys point into it
+  NameMap map;
+  uint32_t n_reads = 0;
 };
 
 namespace {
@@ -134,34 +149,66 @@ void set_err(char* err, uint64_t cap, const std::string& m) {
   }
 }
 
-herro_paf* parse_owned(std::string&& text, size_t body, uint32_t n_reads, const char* names, const uint64_t* name_off,
-                       const uint8_t* core, int n_threads, char* err, uint64_t err_cap) {
-  auto out = new herro_paf();
-  out->text = std::move(text);
-  const char* base = out->text.data();
-  const size_t len = out->text.size();
-  NameMap map;
+// `src` != nullptr: the caller's bytes, copied into a buffer the result owns (by the same threads that look for the line
+// ends); else `owned` holds them already.
+void fill_map(NameMap& map, uint32_t n_reads, const char* names, const uint64_t* name_off) {
   map.reserve((size_t)n_reads * 2);
   for (uint32_t i = 0; i < n_reads; i++) map[std::string_view(names + name_off[i], (size_t)(name_off[i + 1] - name_off[i]))] = i;
+}
 
-  // line starts
+herro_paf* parse_owned(const char* src, size_t src_len, std::string&& owned, size_t body, uint32_t n_reads, const NameMap& map,
+                       const uint8_t* core, int n_threads, char* err, uint64_t err_cap) {
+  auto out = new herro_paf();
+  size_t len;
+  if (src) { len = src_len; out->buf.reset(new char[std::max<size_t>(len, 1)]); }
+  else { out->text = std::move(owned); len = out->text.size(); }
+  char* base = src ? out->buf.get() : out->text.data();
+
+  const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+  const uint32_t want = n_threads > 0 ? (uint32_t)n_threads : std::min(hw, 32u);
+  auto run = [&](uint32_t nthr, const std::function<void(uint32_t)>& f) {
+    if (nthr <= 1) { f(0); return; }
+    std::vector<std::thread> th;
+    for (uint32_t i = 1; i < nthr; i++) th.emplace_back(f, i);
+    f(0);
+    for (auto& x : th) x.join();
+  };
+  // ---- pass 1, byte ranges: copy (if the bytes are the caller's) and note every '\n'
+  const size_t span = len > body ? len - body : 0;
+  const uint32_t nt1 = (uint32_t)std::max<size_t>(1, std::min<size_t>(want, (span + (1u << 20) - 1) >> 20));
+  std::vector<std::vector<size_t>> nls(nt1);
+  if (src && body) memcpy(base, src, std::min(body, len));
+  run(nt1, [&](uint32_t k) {
+    const size_t b = body + span * k / nt1, e = body + span * (k + 1) / nt1;
+    if (src && e > b) memcpy(base + b, src + b, e - b);
+    std::vector<size_t>& v = nls[k];
+    v.reserve((e - b) / 512 + 16);
+    for (size_t p = b; p < e;) {
+      const void* nl = memchr(base + p, '\n', e - p);
+      if (!nl) break;
+      p = (size_t)((const char*)nl - base) + 1;
+      v.push_back(p);                      // start of the next line
+    }
+  });
+  // line starts: `body`, then the byte after every newline (a newline at the very end starts no line)
   std::vector<size_t> ls;
-  for (size_t p = body; p < len;) {
-    ls.push_back(p);
-    const void* nl = memchr(base + p, '\n', len - p);
-    p = nl ? (size_t)((const char*)nl - base) + 1 : len;
+  {
+    size_t total = 1;
+    for (auto& v : nls) total += v.size();
+    ls.reserve(total + 1);
+    if (body < len) ls.push_back(body);
+    for (auto& v : nls) for (size_t p : v) if (p < len) ls.push_back(p);
   }
   const size_t nl = ls.size();
   ls.push_back(len);
   std::vector<Rec> recs(nl);
-  const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
-  const uint32_t nthr = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_threads > 0 ? (size_t)n_threads : std::min(hw, 32u), (nl + 4095) / 4096));
+  const uint32_t nthr = (uint32_t)std::max<size_t>(1, std::min<size_t>(want, (nl + 1023) / 1024));
   std::atomic<size_t> next{0};
-  auto worker = [&]() {
+  run(nthr, [&](uint32_t) {
     for (;;) {
-      const size_t b = next.fetch_add(4096);
+      const size_t b = next.fetch_add(1024);
       if (b >= nl) break;
-      const size_t e = std::min(nl, b + 4096);
+      const size_t e = std::min(nl, b + 1024);
       for (size_t i = b; i < e; i++) {
         const size_t l0 = ls[i], l1 = ls[i + 1];  // read_until: bytes l0..l1 incl. the delimiter if present
         recs[i].line = i;
@@ -169,17 +216,10 @@ herro_paf* parse_owned(std::string&& text, size_t body, uint32_t n_reads, const 
         parse_line(std::string_view(base + l0, l1 - l0 - 1), map, core, recs[i]);  // `buffer[..len - 1]`
       }
     }
-  };
-  if (nthr == 1) worker();
-  else {
-    std::vector<std::thread> th;
-    for (uint32_t i = 0; i < nthr; i++) th.emplace_back(worker);
-    for (auto& x : th) x.join();
-  }
-  // duplicates + grouping, in file order
-  std::unordered_set<uint64_t> seen;
-  std::unordered_map<uint32_t, uint32_t> slot;
-  std::vector<std::vector<uint32_t>> groups;
+  });
+  // duplicates + grouping, in file order.  (query, target) pairs go through an open-addressing table (a node-based set cost
+  // 70 ns per overlap, as much as parsing its line on eight threads); a target's group is found by direct index.
+  size_t n_keep = 0;
   for (size_t i = 0; i < nl; i++) {
     const Rec& r = recs[i];
     if (r.status < 0) {
@@ -187,16 +227,34 @@ herro_paf* parse_owned(std::string&& text, size_t body, uint32_t n_reads, const 
       delete out;
       return nullptr;
     }
+    n_keep += r.status == 0;
+  }
+  size_t cap = 16;
+  while (cap < 2 * n_keep) cap <<= 1;
+  std::vector<uint64_t> seen(cap, 0);                       // key + 1 (0 = empty); a pair of read ids is never 2^64 - 1
+  std::vector<uint32_t> slot(n_reads, 0);                   // group + 1 of a target (tid < n_reads: it came out of the name index)
+  std::vector<std::vector<uint32_t>> groups;
+  for (size_t i = 0; i < nl; i++) {
+    const Rec& r = recs[i];
     if (r.status) continue;
-    if (!seen.insert(((uint64_t)r.a.qid << 32) | r.a.tid).second) continue;  // the first overlap of a pair is kept
-    auto it = slot.find(r.a.tid);
-    if (it == slot.end()) {
-      it = slot.emplace(r.a.tid, (uint32_t)groups.size()).first;
+    const uint64_t key = (((uint64_t)r.a.qid << 32) | r.a.tid) + 1;
+    size_t h = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 17) & (cap - 1);
+    bool dup = false;
+    while (seen[h]) {
+      if (seen[h] == key) { dup = true; break; }
+      h = (h + 1) & (cap - 1);
+    }
+    if (dup) continue;                                        // the first overlap of a pair is kept
+    seen[h] = key;
+    uint32_t& g = slot[r.a.tid];
+    if (!g) {
       groups.emplace_back();
+      g = (uint32_t)groups.size();
       out->tids.push_back(r.a.tid);
     }
-    groups[it->second].push_back((uint32_t)i);
+    groups[g - 1].push_back((uint32_t)i);
   }
+  out->alns.reserve(n_keep);
   out->aln_off.assign(1, 0);
   for (auto& g : groups) {
     for (uint32_t i : g) out->alns.push_back(recs[i].a);
@@ -263,18 +321,9 @@ bool zstd_decode_file(const char* path, std::string& out, std::string& why) {
 
 extern "C" {
 
-herro_paf* herro_paf_parse(const char* text, uint64_t len, uint32_t n_reads, const char* names, const uint64_t* name_off,
-                           const uint8_t* core, int n_threads, char* err, uint64_t err_cap) {
-  if ((!text && len) || (n_reads && (!names || !name_off))) { set_err(err, err_cap, "invalid argument"); return nullptr; }
-  return parse_owned(std::string(text ? text : "", (size_t)len), 0, n_reads, names, name_off, core, n_threads, err, err_cap);
-}
-
-herro_paf* herro_oec_read(const char* path, uint32_t n_reads, const char* names, const uint64_t* name_off, const uint8_t* core,
-                          int n_threads, char* err, uint64_t err_cap) {
-  if (!path || (n_reads && (!names || !name_off))) { set_err(err, err_cap, "invalid argument"); return nullptr; }
-  std::string text, why;
-  if (!zstd_decode_file(path, text, why)) { set_err(err, err_cap, why); return nullptr; }
-  // header (overlaps.rs:304-320): "<n_targets>\n" then n_targets id lines (read and ignored by the reference too)
+// header of an .oec.zst stream (overlaps.rs:304-320): "<n_targets>\n" then n_targets id lines (read and ignored by the
+// reference too); returns where the PAF lines start
+static size_t oec_body(const std::string& text) {
   size_t p = 0;
   uint32_t n_targets = 0;
   {
@@ -287,7 +336,55 @@ herro_paf* herro_oec_read(const char* path, uint32_t n_reads, const char* names,
     const size_t e = text.find('\n', p);
     p = e == std::string::npos ? text.size() : e + 1;
   }
-  return parse_owned(std::move(text), p, n_reads, names, name_off, core, n_threads, err, err_cap);
+  return p;
+}
+
+herro_name_index* herro_name_index_create(uint32_t n_reads, const char* names, const uint64_t* name_off) {
+  if (n_reads && (!names || !name_off)) return nullptr;
+  auto ix = new herro_name_index();
+  ix->n_reads = n_reads;
+  if (n_reads) {
+    ix->blob.assign(names + name_off[0], (size_t)(name_off[n_reads] - name_off[0]));
+    std::vector<uint64_t> off(n_reads + 1);
+    for (uint32_t i = 0; i <= n_reads; i++) off[i] = name_off[i] - name_off[0];
+    fill_map(ix->map, n_reads, ix->blob.data(), off.data());
+  }
+  return ix;
+}
+void herro_name_index_free(herro_name_index* ix) { delete ix; }
+
+herro_paf* herro_paf_parse_indexed(const char* text, uint64_t len, const herro_name_index* ix, const uint8_t* core, int n_threads,
+                                   char* err, uint64_t err_cap) {
+  if ((!text && len) || !ix) { set_err(err, err_cap, "invalid argument"); return nullptr; }
+  return parse_owned(text ? text : "", (size_t)len, std::string(), 0, ix->n_reads, ix->map, core, n_threads, err, err_cap);
+}
+
+herro_paf* herro_oec_read_indexed(const char* path, const herro_name_index* ix, const uint8_t* core, int n_threads, char* err,
+                                  uint64_t err_cap) {
+  if (!path || !ix) { set_err(err, err_cap, "invalid argument"); return nullptr; }
+  std::string text, why;
+  if (!zstd_decode_file(path, text, why)) { set_err(err, err_cap, why); return nullptr; }
+  const size_t p = oec_body(text);
+  return parse_owned(nullptr, 0, std::move(text), p, ix->n_reads, ix->map, core, n_threads, err, err_cap);
+}
+
+herro_paf* herro_paf_parse(const char* text, uint64_t len, uint32_t n_reads, const char* names, const uint64_t* name_off,
+                           const uint8_t* core, int n_threads, char* err, uint64_t err_cap) {
+  if ((!text && len) || (n_reads && (!names || !name_off))) { set_err(err, err_cap, "invalid argument"); return nullptr; }
+  NameMap map;                                   // keys point into the caller's names: valid for the call
+  fill_map(map, n_reads, names, name_off);
+  return parse_owned(text ? text : "", (size_t)len, std::string(), 0, n_reads, map, core, n_threads, err, err_cap);
+}
+
+herro_paf* herro_oec_read(const char* path, uint32_t n_reads, const char* names, const uint64_t* name_off, const uint8_t* core,
+                          int n_threads, char* err, uint64_t err_cap) {
+  if (!path || (n_reads && (!names || !name_off))) { set_err(err, err_cap, "invalid argument"); return nullptr; }
+  std::string text, why;
+  if (!zstd_decode_file(path, text, why)) { set_err(err, err_cap, why); return nullptr; }
+  NameMap map;
+  fill_map(map, n_reads, names, name_off);
+  const size_t p = oec_body(text);
+  return parse_owned(nullptr, 0, std::move(text), p, n_reads, map, core, n_threads, err, err_cap);
 }
 
 uint32_t herro_paf_n_targets(const herro_paf* p) { return p ? (uint32_t)p->tids.size() : 0; }

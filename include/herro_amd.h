@@ -241,6 +241,16 @@ int64_t herro_debug_tile_plan(const uint32_t* cnt, uint32_t n, int packed, uint3
  * The result feeds herro_job_create directly: rids = herro_paf_target_ids, aln_off, alns.  The CIGAR
  * pointers stay valid until herro_paf_free. */
 typedef struct herro_paf herro_paf;
+/* The name -> read id index of a read set, built once (the reference's `name_to_id`, lib.rs:136-140) and shared by any number
+ * of parses, also concurrent ones; herro_paf_parse / herro_oec_read build a temporary one per call (fine for one batch,
+ * wasteful for a thousand batch files over millions of reads). */
+typedef struct herro_name_index herro_name_index;
+herro_name_index* herro_name_index_create(uint32_t n_reads, const char* names, const uint64_t* name_off);
+void herro_name_index_free(herro_name_index* index);
+herro_paf* herro_paf_parse_indexed(const char* text, uint64_t len, const herro_name_index* index, const uint8_t* core,
+                                   int n_threads, char* err, uint64_t err_cap);
+herro_paf* herro_oec_read_indexed(const char* path, const herro_name_index* index, const uint8_t* core, int n_threads,
+                                  char* err, uint64_t err_cap);
 herro_paf* herro_paf_parse(const char* text, uint64_t len, uint32_t n_reads, const char* names,
                            const uint64_t* name_off, const uint8_t* core, int n_threads, char* err,
                            uint64_t err_cap);

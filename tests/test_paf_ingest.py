@@ -21,17 +21,20 @@ def _line(q, ql, qs, qe, st, t, tl, ts, te, cig, extra=(b"60", b"100", b"255")):
 def _check(text, names, core_names=None, threads=0):
     core = None if core_names is None else np.array([1 if n in core_names else 0 for n in names], np.uint8)
     want_order, want = R.parse_paf(text, names, None if core_names is None else set(core_names))
-    p = api.Paf(names, text=text, core=core, threads=threads)
-    assert p.targets.tolist() == want_order
-    rows = p.rows()
-    k = 0
-    for ti, t in enumerate(want_order):
-        assert int(p.aln_off[ti + 1] - p.aln_off[ti]) == len(want[t])
-        for w in want[t]:
-            assert rows[k] == w
-            k += 1
-    assert k == p.n_alns
-    p.close()
+    ix = api.NameIndex(names)           # the same parse through an index built once
+    for who in (names, ix):
+        p = api.Paf(who, text=text, core=core, threads=threads)
+        assert p.targets.tolist() == want_order
+        rows = p.rows()
+        k = 0
+        for ti, t in enumerate(want_order):
+            assert int(p.aln_off[ti + 1] - p.aln_off[ti]) == len(want[t])
+            for w in want[t]:
+                assert rows[k] == w
+                k += 1
+        assert k == p.n_alns
+        p.close()
+    ix.close()
 
 
 NAMES = [b"r0", b"r1", b"r2", b"r3", b"dup", b"r5", b"dup"]  # "dup" -> index 6 (last one wins)
@@ -113,10 +116,12 @@ def test_oec_zst_file(tmp_path):
     f = tmp_path / "0.oec.zst"
     f.write_bytes(comp)
     want_order, want = R.read_batch(body, NAMES)
-    p = api.Paf(NAMES, path=str(f))
-    assert p.targets.tolist() == want_order
-    assert p.rows() == [w for t in want_order for w in want[t]]
-    p.close()
+    ix = api.NameIndex(NAMES)
+    for who in (NAMES, ix):
+        p = api.Paf(who, path=str(f))
+        assert p.targets.tolist() == want_order
+        assert p.rows() == [w for t in want_order for w in want[t]]
+        p.close()
     with pytest.raises(api.HerroError):
         api.Paf(NAMES, path=str(tmp_path / "missing.oec.zst"))
 
