@@ -176,3 +176,28 @@ def test_randomised_differential():
         assert p.targets.tolist() == want_order, trial
         assert p.rows() == [w for t in want_order for w in want[t]], trial
         p.close()
+
+
+def test_job_from_paf_equals_job_from_arrays_host_half():
+    """PAF text -> herro_paf_parse -> herro_job_create: the same descriptors as the array entry (device-free context)."""
+    from herro_amd import synth
+    sb = synth.generate(4, 1500, 12, seed=9, flank_min=40, flank_max=80, p_partial=0.3)
+    lens = (sb.off[1:] - sb.off[:-1]).astype(np.uint32)
+    c = api.HostContext(lens)
+    names = [sb.read_name(i).encode() for i in range(sb.n_reads)]
+    lines = []
+    for a in range(len(sb.aln)):
+        r = sb.aln[a]
+        lines.append(b"\t".join([names[r[0]], b"%d" % r[1], b"%d" % r[2], b"%d" % r[3], b"-" if r[4] else b"+", names[r[5]],
+                                 b"%d" % r[6], b"%d" % r[7], b"%d" % r[8], b"60", b"60", b"255", b"cg:Z:" + sb.cigar(a)]))
+    ix = api.NameIndex(names)
+    for who in (names, ix):
+        paf = api.Paf(who, text=b"\n".join(lines) + b"\n")
+        assert paf.targets.tolist() == sb.tgt_rid.tolist()
+        ja, jp = api.job_from_synth(c, sb, 512), c.create_job_from_paf(paf, 512)
+        A, B = c.job_arrays(ja), c.job_arrays(jp)
+        for k in A:
+            assert np.array_equal(A[k], B[k]), k
+        ja.close(); jp.close(); paf.close()
+    ix.close()
+    c.close()
