@@ -1,7 +1,8 @@
 // pileup.hip — pileup feature generation on gfx950, bit-plane formulation (reference src/features.rs:326-583).
 //
-// Integer / byte work, HBM- and latency-bound; no MFMA on purpose.  Every kernel is a swarm of small workgroups, each
-// with at most three dependent global round trips in front of its arithmetic:
+// Integer / byte work; no MFMA on purpose.  Every kernel is a swarm of small workgroups, each with at most three dependent
+// global round trips in front of its arithmetic; k_cols and k_tokens end up bound by VALU issue (a wave64 instruction holds
+// its SIMD four cycles on gfx950), the rest by latency (DESIGN.md §4 has the counters).
 //
 //   k_cols      one WAVE per overlap-window, no barriers: CIGAR ops -> prefix sums (DPP wave scans) -> table of M/D
 //               ops + bitmap of op starts (rank directory, one popcount finds the op covering a position) -> the
@@ -13,15 +14,19 @@
 //               columns' planes (features.rs:681-722), match / mismatch tallies per query name (features.rs:461-500),
 //               stable accuracy rank (features.rs:386-409).  The reference's [L, 1+n] pass-1 matrix never exists.
 //   k_layout    one workgroup per window: haplotype score, stable re-rank, top-30 (features.rs:502-525); row of every
-//               position = prefix sum over the selected overlaps' max insertion (features.rs:44-95, 531-556).
+//               position = prefix sum over the selected overlaps' max insertion (features.rs:44-95, 531-556); the column
+//               table and the compact event lists its consumers walk (per window for k_rfq, per tile for k_tokens).
 //   k_tokens    one workgroup per 1024 rows: the [31][L'] token planes (features.rs:110-266): 16 rows x 1 column per
-//               step, bits pulled from the planes, inserted bases from a small LDS tile filled by the insertion events, one
-//               16-byte store per step; symbol counts per row in registers -> informative rows (features.rs:558) and
-//               the decoder's majority vote (consensus.rs:178-200).
-//   k_supgather ordered list of informative positions of a window from its chunks' lists.
-//   k_quals     quality bytes (features.rs:139-152,197-198,225-226): the receptive fields of informative rows (what the
-//               model reads), or the complete planes on request.  Query index of a cell = rank in the M plane +
-//               insertion events.
+//               step, four rows per register — bits pulled from the planes, spread to bytes by one multiply, tokens and the
+//               position -> row expansion by v_perm_b32; inserted bases patched in from the tile's event list; symbol counts
+//               per row -> informative rows (features.rs:558) and the decoder's majority vote (consensus.rs:178-200).
+//   k_supgather ordered list of informative positions of a window from its tiles' lists.
+//   k_rfq       at infer time: the qualities of the model's receptive fields (five rows around every informative row),
+//               compact, 8 bytes per (informative row, column) (features.rs:139-152,197-198,225-226).  Query index of a cell
+//               = rank in the M plane + insertion events.
+//   k_quals     the same bytes as complete quality planes, on request (herro_job_window_copy with a quality buffer), and the
+//               receptive fields of models whose field is wider than 8 rows.
+//   k_consensus corrected bases of a window from the logits and the votes (consensus.rs:86-227).
 //
 // What the formulation buys: the work of a column is proportional to its OPS (~165), not to its 4096 positions; a cell
 // of the final matrix costs ~20 ALU operations and no search; HBM traffic is the op arrays and query bit planes in,
