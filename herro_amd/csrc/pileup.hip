@@ -1553,7 +1553,7 @@ __global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const ui
 // =====================================================================================================
 // Per final row: informative -> argmax of the 5 base logits (the LAST maximum wins, NaN is greatest —
 // max_by_key(OrderedFloat), consensus.rs:136-141); otherwise the majority vote with the target tie-break
-// (consensus.rs:178-200) that k_final already derived from its symbol counts.  '*' is dropped.  The window's
+// (consensus.rs:178-200) that k_tokens already derived from its symbol counts.  '*' is dropped.  The window's
 // bases are compacted in row order; the host only concatenates windows and splits reads at windows
 // with < 2 alignments (consensus.rs:90-111).
 constexpr int PC_NT = 256;
@@ -1569,7 +1569,7 @@ __global__ __launch_bounds__(PC_NT) void k_consensus(JobDev J, const uint64_t* s
     return;
   }
   const float* lg = base_logits + sup_off[w] * 5;
-  uint8_t* tmp = J.cons_tmp + wd.row_off;  // per-row majority vote, written by k_final
+  uint8_t* tmp = J.cons_tmp + wd.row_off;  // per-row majority vote, written by k_tokens
   // informative rows: the model decides
   const uint32_t nsup = J.win_nsup[w];
   for (uint32_t k = threadIdx.x; k < nsup; k += PC_NT) {

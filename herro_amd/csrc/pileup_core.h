@@ -1,5 +1,5 @@
 // pileup_core.h — data layout + the small pieces of integer logic shared by the HIP kernels
-// (featurize.hip) and the host-side descriptor builder (windowing.cpp).  Everything here is
+// (pileup.hip, cigar_dev.hip) and the host-side descriptor builder (herro_api.hip, windowing.hpp).  Everything here is
 // `__host__ __device__` so the exact device logic can also be unit-tested on the CPU.
 //
 // Reference semantics restated here (lbcb-sci/herro v0.1.1, src/):
