@@ -179,3 +179,25 @@ def test_work_message_round_trip():
             assert cig[int(cig_off[k]):int(cig_off[k]) + int(rows[k, 9])].tobytes() == sb.cigar(a)
             k += 1
     assert k == len(rows) == int(aln_off[-1])
+
+
+def test_work_messages_are_packed_once_and_sized_ahead():
+    """shard_work writes a shard's message straight into one buffer; work_size announces its length before anything is packed
+    (rank 0 broadcasts the sizes first); unpack_work hands back views equal to the zero-copy arrays rank 0 uses for itself."""
+    from herro_amd import shard, synth
+    sb = synth.generate(40, 2048 + 77, 12, seed=5, p_partial=0.3, flank_min=60, flank_max=90)
+    rng = np.random.default_rng(1)
+    for k, tg in enumerate((np.arange(0, 40), np.arange(7, 19), np.array([3, 4, 5, 9, 10, 30]), rng.permutation(40)[:17],
+                            np.zeros(0, np.int64), np.array([39]))):
+        for slot in (None, ("t", k)):                       # fresh buffer / the destination's reusable one
+            m = shard.shard_work(sb, tg, slot=slot)
+            assert len(m) == shard.work_size(sb, tg)
+            rids, aln_off, rows, cig_off, cig = shard.unpack_work(m)
+            r2, a2, rw2, so2, blob = shard.shard_arrays(sb, tg)
+            assert np.array_equal(rids, r2) and np.array_equal(aln_off, a2) and np.array_equal(rows, rw2)
+            for a in range(len(rows)):
+                n = int(rows[a, 9])
+                assert cig[int(cig_off[a]):int(cig_off[a]) + n].tobytes() == blob[int(so2[a]):int(so2[a]) + n].tobytes()
+    rec = shard.pack_records(np.array([5, 9], np.uint32), np.array([4, 9], np.uint64), b">a\nAC>b\nG")
+    r, e, t = shard.unpack_records(rec)
+    assert r.tolist() == [5, 9] and e.tolist() == [4, 9] and t.tobytes() == b">a\nAC>b\nG"
