@@ -465,6 +465,9 @@ void herro_destroy(herro_ctx* ctx) {
         }
     }
     (void)hipFree(ctx->d_prof);
+#ifdef HERRO_PROF_BUILD
+    model_h_prof_dump();
+#endif
   }
   ctx->timer.reset();
   for (void* p : {(void*)ctx->d_words, (void*)ctx->d_word_off, (void*)ctx->d_qual, (void*)ctx->d_qual_off, (void*)ctx->d_p0, (void*)ctx->d_p1, (void*)ctx->d_ln})

@@ -122,6 +122,9 @@ void launch_model(const ModelDev& M, const BatchDev& B, const ModelScratch& S, i
 // f16-operand kernels (model_h.hip): terms = 2 -> precision 4, terms = 1 -> precision 5.  B must be tiled (n_tiles > 0).
 bool model_h_supported(const ModelDev& M);
 void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S, int terms, hipStream_t st, KernelTimer* tm);
+#ifdef HERRO_PROF_BUILD
+void model_h_prof_dump();   // phase cycles of k_layers_p (model_h.hip LP_MARK), printed by herro_destroy when HERRO_PROF=1
+#endif
 // [B,L,31] -> [B][31][L] planes (stand-alone entry only)
 void launch_transpose_blr(const uint8_t* src, uint8_t* dst, uint32_t B, uint32_t L, hipStream_t st);
 

@@ -454,6 +454,27 @@ constexpr int PAR_LN1G = 0, PAR_LN1B = 256, PAR_LN2G = 512, PAR_LN2B = 768, PAR_
 constexpr int PAR_MAX_FF = 2048;                 // d_ff supported by the parameter block
 constexpr int PAR_FLOATS = PAR_BFF1 + PAR_MAX_FF;
 
+// Phase timer of the stack, compiled only into HERRO_PROF_BUILD libraries (HERRO_PROF_BUILD=1 python -m herro_amd.build; run with
+// HERRO_PROF=1): thread 0 of one tile in 16 adds the shader cycles since its previous mark to its phase's counter
+// (0 prologue, 1 LayerNorm 1, 2 QKV, 3 attention, 4 proj, 5 LayerNorm 2, 6 FF1 + epilogue, 7 FF2, 8 final LayerNorm + heads; 15 tiles
+// sampled).  Release kernels carry nothing of it.
+#ifdef HERRO_PROF_BUILD
+__device__ unsigned long long g_lp_prof[16];
+#define LP_BEGIN() unsigned long long _lp_t = (tid == 0 && (blockIdx.x & 15u) == 0) ? __builtin_readcyclecounter() : 0ull
+#define LP_MARK(ph)                                                                      \
+  do {                                                                                   \
+    if (tid == 0 && (blockIdx.x & 15u) == 0) {                                           \
+      const unsigned long long _n = __builtin_readcyclecounter();                        \
+      atomicAdd(&g_lp_prof[ph], _n - _lp_t);                                             \
+      if ((ph) == 0) atomicAdd(&g_lp_prof[15], 1ull);                                    \
+      _lp_t = __builtin_readcyclecounter();                                              \
+    }                                                                                    \
+  } while (0)
+#else
+#define LP_BEGIN() do { } while (0)
+#define LP_MARK(ph) do { } while (0)
+#endif
+
 template <int TERMS>
 __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelScratch S) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -465,6 +486,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
   uint32_t* s_win = reinterpret_cast<uint32_t*>(s_red + 2 * 8 * HLT);
   float* s_par = reinterpret_cast<float*>(s_win + HLT);            // this layer's LayerNorm parameters and biases
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  LP_BEGIN();
   uint32_t fr = lane & 15, fg = lane >> 4;
   const uint32_t t0 = B.tile_tok0[blockIdx.x], nt = B.tile_tok0[blockIdx.x + 1] - t0;
   const uint32_t cw = wave * 32;
@@ -602,7 +624,9 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
     const LayerW& L = M.layer[li];
     const LayerW& Ln = M.layer[li + 1 < n_layers ? li + 1 : 0];  // after the last layer: a harmless re-read of layer 0
     RELAUNDER();
+    LP_MARK(li ? 7 : 0);
     layer_norm(PAR_LN1G, PAR_LN1B, nullptr, nullptr, false);   // Q, K, V read the hi plane only (see the header: QKV single)
+    LP_MARK(1);
     RELAUNDER();
     {  // ---- attention, head = wave
       half8 qh[4], kh[4], vh[2][2];
@@ -643,6 +667,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
           }
         }
       }
+      LP_MARK(2);
       uint32_t wj[4][4];
 #pragma unroll
       for (int pj = 0; pj < 4; pj++)
@@ -693,6 +718,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
       }
     }
     __syncthreads();
+    LP_MARK(3);
     RELAUNDER();
     {  // ---- output projection + residual
       f32x4 a[4][2];
@@ -706,7 +732,9 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
         for (int q = 0; q < 8; q++) x[pt][q] += a[pt][q >> 2][q & 3] + bp[q];
     }
     RELAUNDER();
+    LP_MARK(4);
     layer_norm(PAR_LN2G, PAR_LN2B, nullptr, nullptr, TERMS == 2);
+    LP_MARK(5);
     {  // ---- feed-forward, 256 hidden channels at a time
       f32x4 a2[4][2];
       {  // the FF2 accumulator starts from its bias: no parameter is read after the loop's last barrier, which is what
@@ -733,10 +761,12 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
           store_act(s_ah, s_al, hlsw(pt * 16 + fr, wave * 4 + fg), v);
         }
         __syncthreads();
+        LP_MARK(6);
         const bool more = c + 256 < d_ff;
         const WStream nx = more ? wstream(L.ff1, c + 256 + cw, 0, lane) : wstream(Ln.qkv, cw, 0, lane);
         tile_gemm_p<false, TERMS>(wstream(L.ff2, cw, c, lane), wa, nx, s_ah, s_al, fr, fg, a2);
         __syncthreads();
+        LP_MARK(7);
       }
 #pragma unroll
       for (int pt = 0; pt < 4; pt++)
@@ -777,6 +807,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
       }
     }
   }
+  LP_MARK(8);
 }
 constexpr size_t LAYERS_P_SHM = (size_t)4 * HLT * 256 * 2 + 2 * 8 * HLT * 4 + HLT * 4 + (size_t)PAR_FLOATS * 4;
 
@@ -836,5 +867,16 @@ void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S,
   }
   KT_END(tm, st);
 }
+
+#ifdef HERRO_PROF_BUILD
+void model_h_prof_dump() {
+  unsigned long long h[16] = {0};
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lp_prof), sizeof h) != hipSuccess || !h[15]) return;
+  static const char* name[9] = {"prologue", "LN1", "QKV", "attention", "proj", "LN2", "FF1+epilogue", "FF2", "final LN + heads"};
+  fprintf(stderr, "PROF k_layers_p (%llu tiles sampled), shader cycles per tile by phase:", h[15]);
+  for (int p = 0; p < 9; p++) fprintf(stderr, " %s %.0f", name[p], (double)h[p] / (double)h[15]);
+  fprintf(stderr, "\n");
+}
+#endif
 
 }  // namespace herro

@@ -1,5 +1,6 @@
 #!/bin/bash
-# in-kernel phase cycles of the device-resident bench leg: rebuilds the library with the phase timers (HERRO_PROF_BUILD, job_dev.h),
+# in-kernel phase cycles of the device-resident bench leg (pileup kernels: job_dev.h PROF_MARK; encoder stack: model_h.hip LP_MARK):
+# rebuilds the library with the phase timers (HERRO_PROF_BUILD),
 # runs with HERRO_PROF=1, and puts the release build back
 HERRO_PROF_BUILD=1 python -c "from herro_amd import build; build.build_hip(force=True)"
 trap 'python -c "from herro_amd import build; build.build_hip(force=True)"' EXIT
