@@ -80,6 +80,25 @@ def test_many_lines_parallel_matches_serial():
     _check(text, names, threads=8)
 
 
+def test_text_of_several_megabytes_crosses_the_byte_ranges_of_the_threads():
+    """The copy and the search for line ends run over byte ranges of >= 1 MiB per thread: long lines (CIGARs of kilobytes) that
+    straddle the range boundaries, with and without a final newline, against the restatement."""
+    rng = np.random.default_rng(8)
+    names = [f"read{i}".encode() for i in range(64)]
+    L = []
+    for _ in range(2500):
+        q, t = rng.integers(0, 70, 2)
+        qn = names[q] if q < 64 else b"unknown%d" % q
+        tn = names[t] if t < 64 else b"unknown%d" % t
+        cig = b"".join(b"%d%s" % (int(rng.integers(1, 60)), [b"M", b"I", b"M", b"D"][k % 4]) for k in range(int(rng.integers(1, 1500)))) + b"7M"
+        L.append(_line(qn, 50000, 0, 40000, b"+" if rng.integers(0, 2) else b"-", tn, 50000, 3, 40003, cig))
+    text = b"\n".join(L)
+    assert len(text) > 5 << 20
+    for tail in (b"\n", b""):
+        for th in (1, 3, 8):
+            _check(text + tail, names, threads=th)
+
+
 @pytest.mark.parametrize("bad,msg", [
     (_line(b"r1", "1x0", 0, 90, b"+", b"r0", 120, 5, 95, b"90M"), "valid digit"),
     (_line(b"r1", 100, 0, 90, b"*", b"r0", 120, 5, 95, b"90M"), "Invalid strand"),
