@@ -473,7 +473,7 @@ def bench_strong(args, rank: int, world: int, local: int):
         print(json.dumps({
             "metric": "4096-bp windows corrected/sec at batch=128", "value": r["windows_per_s"], "unit": "windows/s", "n_gpus": world,
             "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * r["seconds"] / max(steps, 1), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": {1: "bf16x3", 4: "f16 (encoder GEMMs: activation hi+lo)", 5: "f16"}.get(args.precision, str(args.precision)),
+            "vs_baseline": None, "dtype": {1: "bf16x3", 4: "f16 (encoder proj / FF GEMMs: activation hi+lo)", 5: "f16"}.get(args.precision, str(args.precision)),
             "data": "synthetic (SURVEY §8d generator, seed 0x48455252+3; random-init weights of the assumed architecture)",
             "config": {"workload": f"ONE fixed job of {r['windows']} synthetic 4096-bp windows (32 overlaps each, batch=128) sharded by target read over "
                                    f"{world} rank(s): rank 0 ingests, scatters the work, gathers the corrected reads (BASELINE configs[3])",

@@ -149,3 +149,26 @@ def test_bench_flow(monkeypatch, capsys, argv, steps, strong_mode):
         if ev == "I":
             assert last.get(jid) == "F"
         last[jid] = ev
+
+
+def test_bench_strong_mode_line(monkeypatch, capsys):
+    """`bench.py --scaling strong`: the sharded data path as a line of its own, same contract keys (the leg itself is stubbed)."""
+    import torch
+    from herro_amd import shard
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setattr(shard, "strong_leg", lambda args, rank, world, local, n, **k: {
+        "windows_per_s": 5.0e5, "windows": n, "seconds": n / 5.0e5, "ranks_seen": 1, "timed": "scatter + ... + gather"})
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--scaling", "strong", "--steps", "16", "--warmup", "1"])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    bench.main()
+    out = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
+    assert len(out) == 1
+    d = json.loads(out[0])
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["scaling"] == "strong" and d["steps"] == 16 and d["n_gpus"] == 1 and d["value"] == 5.0e5
+    assert d["strong"]["windows"] == 16 * 128 and abs(d["ms_per_step"] - 1e3 * d["strong"]["seconds"] / 16) < 1e-9
