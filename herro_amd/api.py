@@ -24,7 +24,7 @@ EXPORTS = [
     "herro_timing_get", "herro_job_stats", "herro_debug_extract_windows",
     "herro_paf_parse", "herro_oec_read", "herro_paf_n_targets", "herro_paf_target_ids", "herro_paf_aln_off",
     "herro_paf_alignments", "herro_paf_free", "herro_name_index_create", "herro_name_index_free", "herro_paf_parse_indexed",
-    "herro_oec_read_indexed", "herro_debug_host_ctx", "herro_debug_job_array", "herro_debug_tile_plan",
+    "herro_oec_read_indexed", "herro_paf_parse_view", "herro_debug_host_ctx", "herro_debug_job_array", "herro_debug_tile_plan",
     "herro_fastx_read", "herro_reads_count", "herro_reads_seq", "herro_reads_qual", "herro_reads_off", "herro_reads_ids",
     "herro_reads_descs", "herro_reads_free", "herro_write_window_features", "herro_job_write_features",
 ]
@@ -114,6 +114,8 @@ def lib():
         L.herro_paf_parse_indexed.argtypes = [C.c_char_p, u64, vp, vp, i32, vp, u64]
         L.herro_oec_read_indexed.restype = vp
         L.herro_oec_read_indexed.argtypes = [C.c_char_p, vp, vp, i32, vp, u64]
+        L.herro_paf_parse_view.restype = vp
+        L.herro_paf_parse_view.argtypes = [C.c_char_p, u64, vp, vp, i32, vp, u64]
         L.herro_debug_host_ctx.restype = vp
         L.herro_debug_host_ctx.argtypes = [u32, vp, vp]
         L.herro_debug_job_array.restype = C.c_int64
@@ -448,14 +450,18 @@ class Paf:
     appearance, their alignments in file order.  `targets`, `aln_off`, `alns` are what herro_job_create takes;
     the CIGAR pointers inside `alns` stay valid while this object lives.  `names`: the read ids, or a NameIndex built once."""
 
-    def __init__(self, names, text: bytes | None = None, path: str | None = None, core=None, threads: int = 0):
+    def __init__(self, names, text: bytes | None = None, path: str | None = None, core=None, threads: int = 0, view: bool = False):
+        """view=True (with a NameIndex and `text`): no copy of the text — this object keeps `text` alive instead."""
         self.h = None
+        self._text = text if view else None
         L = lib()
         core_a = None if core is None else np.ascontiguousarray(core, np.uint8)
         err = C.create_string_buffer(512)
         cptr = None if core_a is None else core_a.ctypes.data
         if isinstance(names, NameIndex):
-            if text is not None:
+            if text is not None and view:
+                h = L.herro_paf_parse_view(text, len(text), names.h, cptr, threads, err, 512)
+            elif text is not None:
                 h = L.herro_paf_parse_indexed(text, len(text), names.h, cptr, threads, err, 512)
             else:
                 h = L.herro_oec_read_indexed(path.encode(), names.h, cptr, threads, err, 512)

@@ -157,12 +157,14 @@ void fill_map(NameMap& map, uint32_t n_reads, const char* names, const uint64_t*
 }
 
 herro_paf* parse_owned(const char* src, size_t src_len, std::string&& owned, size_t body, uint32_t n_reads, const NameMap& map,
-                       const uint8_t* core, int n_threads, char* err, uint64_t err_cap) {
+                       const uint8_t* core, int n_threads, char* err, uint64_t err_cap, bool borrow = false) {
   auto out = new herro_paf();
   size_t len;
-  if (src) { len = src_len; out->buf.reset(new char[std::max<size_t>(len, 1)]); }
+  if (src && borrow) len = src_len;   // the caller keeps the bytes alive (herro_paf_parse_view): nothing is copied
+  else if (src) { len = src_len; out->buf.reset(new char[std::max<size_t>(len, 1)]); }
   else { out->text = std::move(owned); len = out->text.size(); }
-  char* base = src ? out->buf.get() : out->text.data();
+  const char* base = src ? (borrow ? src : out->buf.get()) : out->text.data();
+  char* wbase = (src && !borrow) ? out->buf.get() : nullptr;   // where the caller's bytes are copied to, if they are
 
   const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
   const uint32_t want = n_threads > 0 ? (uint32_t)n_threads : std::min(hw, 32u);
@@ -177,10 +179,10 @@ herro_paf* parse_owned(const char* src, size_t src_len, std::string&& owned, siz
   const size_t span = len > body ? len - body : 0;
   const uint32_t nt1 = (uint32_t)std::max<size_t>(1, std::min<size_t>(want, (span + (1u << 20) - 1) >> 20));
   std::vector<std::vector<size_t>> nls(nt1);
-  if (src && body) memcpy(base, src, std::min(body, len));
+  if (wbase && body) memcpy(wbase, src, std::min(body, len));
   run(nt1, [&](uint32_t k) {
     const size_t b = body + span * k / nt1, e = body + span * (k + 1) / nt1;
-    if (src && e > b) memcpy(base + b, src + b, e - b);
+    if (wbase && e > b) memcpy(wbase + b, src + b, e - b);
     std::vector<size_t>& v = nls[k];
     v.reserve((e - b) / 512 + 16);
     for (size_t p = b; p < e;) {
@@ -357,6 +359,12 @@ herro_paf* herro_paf_parse_indexed(const char* text, uint64_t len, const herro_n
                                    char* err, uint64_t err_cap) {
   if ((!text && len) || !ix) { set_err(err, err_cap, "invalid argument"); return nullptr; }
   return parse_owned(text ? text : "", (size_t)len, std::string(), 0, ix->n_reads, ix->map, core, n_threads, err, err_cap);
+}
+
+herro_paf* herro_paf_parse_view(const char* text, uint64_t len, const herro_name_index* ix, const uint8_t* core, int n_threads,
+                                char* err, uint64_t err_cap) {
+  if ((!text && len) || !ix) { set_err(err, err_cap, "invalid argument"); return nullptr; }
+  return parse_owned(text ? text : "", (size_t)len, std::string(), 0, ix->n_reads, ix->map, core, n_threads, err, err_cap, true);
 }
 
 herro_paf* herro_oec_read_indexed(const char* path, const herro_name_index* ix, const uint8_t* core, int n_threads, char* err,

@@ -251,6 +251,10 @@ herro_paf* herro_paf_parse_indexed(const char* text, uint64_t len, const herro_n
                                    int n_threads, char* err, uint64_t err_cap);
 herro_paf* herro_oec_read_indexed(const char* path, const herro_name_index* index, const uint8_t* core, int n_threads,
                                   char* err, uint64_t err_cap);
+/* herro_paf_parse_indexed without the copy: the result (its CIGAR pointers) refers to `text` itself — a buffer or file mapping
+ * the caller keeps alive and unchanged until herro_paf_free. */
+herro_paf* herro_paf_parse_view(const char* text, uint64_t len, const herro_name_index* index, const uint8_t* core,
+                                int n_threads, char* err, uint64_t err_cap);
 herro_paf* herro_paf_parse(const char* text, uint64_t len, uint32_t n_reads, const char* names,
                            const uint64_t* name_off, const uint8_t* core, int n_threads, char* err,
                            uint64_t err_cap);

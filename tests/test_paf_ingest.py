@@ -21,9 +21,9 @@ def _line(q, ql, qs, qe, st, t, tl, ts, te, cig, extra=(b"60", b"100", b"255")):
 def _check(text, names, core_names=None, threads=0):
     core = None if core_names is None else np.array([1 if n in core_names else 0 for n in names], np.uint8)
     want_order, want = R.parse_paf(text, names, None if core_names is None else set(core_names))
-    ix = api.NameIndex(names)           # the same parse through an index built once
-    for who in (names, ix):
-        p = api.Paf(who, text=text, core=core, threads=threads)
+    ix = api.NameIndex(names)           # the same parse through an index built once, and without copying the text
+    for who, view in ((names, False), (ix, False), (ix, True)):
+        p = api.Paf(who, text=text, core=core, threads=threads, view=view)
         assert p.targets.tolist() == want_order
         rows = p.rows()
         k = 0
