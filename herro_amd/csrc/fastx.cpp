@@ -62,10 +62,28 @@ bool slurp(const char* path, std::string& out, std::string& why) {
   const size_t got = fread(magic, 1, 2, f);
   const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
   if (!gz) {
-    out.assign((const char*)magic, got);
-    char buf[1 << 16];
-    size_t n;
-    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
+    // plain file: its size is known, so the bytes land in their final place (an appending loop re-copied the text at every
+    // growth of the string)
+    struct stat st;
+    if (fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+      out.resize((size_t)st.st_size);
+      memcpy(&out[0], magic, got);
+      size_t have = got;
+      while (have < out.size()) {
+        const size_t n = fread(&out[have], 1, out.size() - have, f);
+        if (!n) break;
+        have += n;
+      }
+      out.resize(have);
+      char buf[1 << 16];       // (a file that grew meanwhile)
+      size_t n;
+      while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
+    } else {
+      out.assign((const char*)magic, got);
+      char buf[1 << 16];
+      size_t n;
+      while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
+    }
     fclose(f);
     return true;
   }
@@ -146,6 +164,8 @@ herro_reads* herro_fastx_read(const char* path, uint32_t min_length, const char*
   for (uint64_t i = 0; filter && i < n_keep; i++) if (keep_ids[i]) keep.insert(keep_ids[i]);
   auto r = new herro_reads();
   r->off.push_back(0);
+  r->seq.reserve(text.size() / 2);      // a FASTQ file is half bases, half qualities: one allocation instead of a doubling series
+  r->qual.reserve(text.size() / 2);
   size_t pos = 0, b, e;
   auto fail = [&](const char* m) -> herro_reads* { set_err(err, err_cap, m); delete r; return nullptr; };
   std::string seq, qual;
@@ -162,23 +182,34 @@ herro_reads* herro_fastx_read(const char* path, uint32_t min_length, const char*
       return fail("Qualities should be present.");
     }
     bool plus = false;                          // FASTQ: sequence lines up to the '+' line, then as many quality bytes
+    size_t sb = 0, se = 0, qb = 0, qe = 0, n_seq_lines = 0, n_qual_lines = 0;   // the record's only sequence / quality line, if single-line
     while (pos < text.size()) {
       pos = next_line(text, pos, b, e);
       if (b < e && text[b] == '+') { plus = true; break; }
-      seq.append(text, b, e - b);
+      if (n_seq_lines++ == 0) { sb = b; se = e; }
+      else { if (n_seq_lines == 2) seq.assign(text, sb, se - sb); seq.append(text, b, e - b); }
     }
     if (!plus) return fail("Error parsing fastx file. (no '+' line)");
-    while (qual.size() < seq.size() && pos < text.size()) { pos = next_line(text, pos, b, e); qual.append(text, b, e - b); }
-    if (qual.size() != seq.size()) return fail("Error parsing fastx file. (sequence and quality lengths differ)");
-    if (seq.size() < min_length) continue;      // haec_io.rs:48-50
+    const size_t seq_len = n_seq_lines <= 1 ? se - sb : seq.size();
+    size_t qual_len = 0;
+    while (qual_len < seq_len && pos < text.size()) {
+      pos = next_line(text, pos, b, e);
+      if (n_qual_lines++ == 0) { qb = b; qe = e; }
+      else { if (n_qual_lines == 2) qual.assign(text, qb, qe - qb); qual.append(text, b, e - b); }
+      qual_len = n_qual_lines <= 1 ? qe - qb : qual.size();
+    }
+    if (qual_len != seq_len) return fail("Error parsing fastx file. (sequence and quality lengths differ)");
+    if (seq_len < min_length) continue;         // haec_io.rs:48-50
+    const char* seq_p = n_seq_lines <= 1 ? text.data() + sb : seq.data();      // four-line records are copied once, from the text
+    const char* qual_p = n_qual_lines <= 1 ? text.data() + qb : qual.data();
     size_t cut = head.find_first_of(" \t");     // splitn(2, ' ' | '\t')
     const std::string id = head.substr(0, cut);
     if (filter && !keep.count(id)) continue;    // haec_io.rs:63-69 (the caller passes core u neighbour when both are given)
     r->ids.push_back(id);
     r->has_desc.push_back(cut != std::string::npos);
     r->descs.push_back(cut != std::string::npos ? head.substr(cut + 1) : std::string());
-    r->seq.insert(r->seq.end(), seq.begin(), seq.end());
-    r->qual.insert(r->qual.end(), qual.begin(), qual.end());
+    r->seq.insert(r->seq.end(), seq_p, seq_p + seq_len);
+    r->qual.insert(r->qual.end(), qual_p, qual_p + seq_len);
     r->off.push_back(r->seq.size());
   }
   for (size_t i = 0; i < r->ids.size(); i++) {

@@ -56,6 +56,12 @@ def test_read_fastx_rules(tmp_path):
     ml.write_bytes(b"@m0 d\nACG\nTAC\nGT\n+m0\nIII\nIII\nII\n@m1\nAC\n+\nII\n")
     r = hio.read_fastx(str(ml))
     assert r.ids == [b"m0", b"m1"] and bytes(r.seq) == b"ACGTACGTAC" and bytes(r.qual) == b"IIIIIIIIII" and r.off.tolist() == [0, 8, 10]
+    # sequence on one line, qualities wrapped (and the reverse); an empty record; no newline at the end of the file
+    mx = tmp_path / "mixed.fastq"
+    mx.write_bytes(b"@a\nACGTAC\n+\nIII\nJJJ\n@b\nAC\nGT\n+\nKKKK\n@e\n\n+\n\n@z\nTT\n+\nLL")
+    r = hio.read_fastx(str(mx))
+    assert r.ids == [b"a", b"b", b"e", b"z"] and bytes(r.seq) == b"ACGTACACGTTT" and bytes(r.qual) == b"IIIJJJKKKKLL"
+    assert r.off.tolist() == [0, 6, 10, 10, 12]
     # what the reference panics on
     fa = tmp_path / "x.fasta"
     fa.write_bytes(b">r0\nACGT\nACGT\n")
