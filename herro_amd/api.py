@@ -9,7 +9,8 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libherro_amd.so")
+# HERRO_LIB: another build of the same library (e.g. the HERRO_PROF_BUILD one of tools/prof.sh), for A/B runs on one GPU box
+LIB_PATH = os.environ.get("HERRO_LIB") or os.path.join(_HERE, "libherro_amd.so")
 _LIB = None
 # GEMM precision used by bench.py / smoke / the end-to-end tests (herro_set_precision): 1 = bf16 hi/lo x3,
 # 4 = f16 (conv / FC / attention single, encoder GEMMs activation hi + lo), see csrc/model_h.hip
@@ -121,7 +122,7 @@ def lib():
         L.herro_debug_job_array.restype = C.c_int64
         L.herro_debug_job_array.argtypes = [vp, i32, vp, vp]
         L.herro_debug_tile_plan.restype = C.c_int64
-        L.herro_debug_tile_plan.argtypes = [vp, u32, i32, vp]
+        L.herro_debug_tile_plan.argtypes = [vp, u32, i32, u32, vp, vp, vp]
         _LIB = L
     return _LIB
 
@@ -160,14 +161,19 @@ def debug_extract_windows(row, cigar: bytes, n_windows: int, window_size: int) -
     return out[:n].astype(np.int64)
 
 
-def debug_tile_plan(counts, packed: bool = True) -> tuple[int, np.ndarray]:
-    """(tiles, order) of one fused launch over windows of `counts` informative rows (host only, herro_debug_tile_plan)."""
+def debug_tile_plan(counts, packed: bool = True, qmode: int = 0, n_cu: int = 256, bounds: bool = False):
+    """(tiles, order) of one fused launch over windows of `counts` informative rows (host only, herro_debug_tile_plan).
+    qmode 1 / 2: the plans with 32-token tiles (short last round / every small window) -> (tiles of 64, tiles of 32, order);
+    bounds: append the first token of every tile (+ end)."""
     c = np.ascontiguousarray(counts, np.uint32)
     order = np.zeros(max(len(c), 1), np.uint32)
-    n = lib().herro_debug_tile_plan(c.ctypes.data, len(c), int(packed), order.ctypes.data)
+    n_half = C.c_uint32(0)
+    tok = np.zeros(len(c) + 2, np.uint32)
+    n = lib().herro_debug_tile_plan(c.ctypes.data, len(c), int(packed) | (qmode << 1), n_cu, order.ctypes.data, C.byref(n_half), tok.ctypes.data)
     if n < 0:
         raise HerroError(int(n), "herro_debug_tile_plan")
-    return int(n), order[:len(c)]
+    out = (int(n), int(n_half.value), order[:len(c)]) if qmode else (int(n), order[:len(c)])
+    return out + (tok[:int(n) + int(n_half.value) + 1],) if bounds else out
 
 
 @dataclass

@@ -21,16 +21,20 @@ def _stale() -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build_hip(force: bool = False) -> str:
+def build_hip(force: bool = False, out: str | None = None, defines: tuple = ()) -> str:
+    """out / defines: a second library next to the release one (phase timers, A/B variants), selected at run time by HERRO_LIB."""
+    if out is not None:
+        force = True
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = ["-DHERRO_PROF_BUILD"] if os.environ.get("HERRO_PROF_BUILD", "0") not in ("", "0") else []   # kernel phase timers (job_dev.h)
-    cmd = [hipcc] + FLAGS + extra + ["-o", LIB] + [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    extra += ["-D" + d for d in defines]
+    cmd = [hipcc] + FLAGS + extra + ["-o", out or LIB] + [os.path.join(CSRC, s) for s in HIP_SOURCES]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + r.stdout)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":

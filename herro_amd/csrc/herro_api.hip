@@ -136,6 +136,7 @@ struct Arena { void* p = nullptr; size_t cap = 0; };
 
 struct herro_ctx {
   int device = 0;
+  uint32_t n_cu = 256;   // compute units of the device: one round of the fused stack (plan_tiles)
   hipStream_t own_stream = nullptr, stream = nullptr;
   ErrSlot err;
   // read store
@@ -340,35 +341,34 @@ struct ArenaReturn {
 };
 
 // Tiles of whole windows for the fused transformer stack: consecutive windows packed greedily into at
-// most 64 tokens.  Returns the first token of each tile (+ end).  Callers pass windows of <= FUSED_MAX_TOK
-// informative rows only (larger windows run layer by layer, see split_launch).
+// most `cap` tokens.  Returns the first token of each tile (+ end) for windows [w0, w1) of the token stream.  Callers pass
+// windows of <= FUSED_MAX_TOK informative rows only (larger windows run layer by layer, see split_launch).
 static constexpr uint32_t FUSED_MAX_TOK = 64;
-static std::vector<uint32_t> token_tiles(const std::vector<uint32_t>& tok_off) {
-  std::vector<uint32_t> t(1, 0);
-  for (size_t w = 0; w + 1 < tok_off.size(); w++) {
-    if (tok_off[w + 1] - t.back() > FUSED_MAX_TOK) t.push_back(tok_off[w]);
+static constexpr uint32_t FUSED_HALF_TOK = 32;   // tile of k_layers_q (two workgroups per compute unit)
+static std::vector<uint32_t> token_tiles(const std::vector<uint32_t>& tok_off, size_t w0 = 0, size_t w1 = ~size_t(0), uint32_t cap = FUSED_MAX_TOK) {
+  w1 = std::min(w1, tok_off.size() - 1);
+  if (w0 >= w1) return std::vector<uint32_t>();
+  std::vector<uint32_t> t(1, tok_off[w0]);
+  for (size_t w = w0; w < w1; w++) {
+    if (tok_off[w + 1] - t.back() > cap) t.push_back(tok_off[w]);
   }
-  if (tok_off.back() > t.back()) t.push_back(tok_off.back());
+  if (tok_off[w1] > t.back()) t.push_back(tok_off[w1]);
   return t.size() > 1 ? t : std::vector<uint32_t>();
 }
 
 // Order in which the windows of a launch enter the token stream so that token_tiles' consecutive packing comes out as
-// best-fit-decreasing bins: every tile of the fused stack costs the same whatever it holds (the MFMAs run over all 64 token
+// best-fit-decreasing bins: every tile of the fused stack costs the same whatever it holds (the MFMAs run over all its token
 // slots), so the launch time is the NUMBER of tiles.  A tile is opened with the largest window left and filled with the
 // largest window that still fits, repeatedly; the window that opens the next tile is the largest one left, which did not fit
-// (or it would have been taken), so the greedy split of token_tiles falls exactly on these bins.  cnt[i] in 1..64.
-// At the bench workload (informative rows per window 4..30, mean 15.2): 999 tiles instead of 1098 for 4096 windows
+// (or it would have been taken), so the greedy split of token_tiles falls exactly on these bins.  cnt[i] in 1..cap; the indices
+// appended to `order` are those of `idx` (all windows when idx is null).
+// At the bench workload (informative rows per window 4..30, mean 15.2): 999 tiles of 64 instead of 1098 for 4096 windows
 // (ideal 975), which is 4 rounds of 256 compute units instead of 5.
-static std::vector<uint32_t> tile_pack_order(const std::vector<uint32_t>& cnt) {
-  std::vector<std::vector<uint32_t>> by(FUSED_MAX_TOK + 1);
-  for (size_t i = cnt.size(); i-- > 0;) by[std::min(cnt[i], FUSED_MAX_TOK)].push_back((uint32_t)i);  // pop_back: ascending index
-  std::vector<uint32_t> order;
-  order.reserve(cnt.size());
-  for (uint32_t i : by[0]) order.push_back(i);   // (not produced by the planner: windows without informative rows are skipped)
-  size_t left = cnt.size() - by[0].size();
-  uint32_t top = FUSED_MAX_TOK;                  // no window above `top` is left
-  while (left) {
-    uint32_t room = FUSED_MAX_TOK, s = top;
+static void tile_pack_bins(const std::vector<uint32_t>& cnt, std::vector<std::vector<uint32_t>>& by, size_t left, uint32_t cap, std::vector<uint32_t>& order) {
+  uint32_t top = cap;                  // no window above `top` is left
+  while (top && by[top].empty()) top--;
+  while (left && top) {
+    uint32_t room = cap, s = top;
     while (room) {
       s = std::min(s, room);
       while (s && by[s].empty()) s--;
@@ -380,7 +380,98 @@ static std::vector<uint32_t> tile_pack_order(const std::vector<uint32_t>& cnt) {
     }
     while (top && by[top].empty()) top--;
   }
+}
+static std::vector<uint32_t> tile_pack_order(const std::vector<uint32_t>& cnt) {
+  std::vector<std::vector<uint32_t>> by(FUSED_MAX_TOK + 1);
+  for (size_t i = cnt.size(); i-- > 0;) by[std::min(cnt[i], FUSED_MAX_TOK)].push_back((uint32_t)i);  // pop_back: ascending index
+  std::vector<uint32_t> order;
+  order.reserve(cnt.size());
+  for (uint32_t i : by[0]) order.push_back(i);   // (not produced by the planner: windows without informative rows are skipped)
+  tile_pack_bins(cnt, by, cnt.size() - by[0].size(), FUSED_MAX_TOK, order);
   return order;
+}
+
+// The token stream of one fused launch: `order[k]` = index (into cnt) of its k-th window, `tiles` the 64-token tiles at its
+// head (first tokens + end), `tiles_q` the 32-token tiles behind them (k_layers_q; empty when qmode = 0).
+// A launch of the fused stack runs in rounds of one 64-token tile per compute unit; a 32-token tile costs about half a round
+// when it has its compute unit to itself (two of them sharing one are bound by the weight stream: no gain, measured).
+// qmode 1 (default with the f16 stack): when the LAST round would fill at most half of the compute units, the windows of its
+// tiles go into 32-token tiles instead, one per compute unit (2560 windows of the bench: 625 tiles = 2 rounds + 113 -> 2 rounds
+// + 226 half tiles).  qmode 2 (A/B): every window of <= 32 rows goes into 32-token tiles; a window of 33..64 opens a 64-token
+// tile and takes the best-fitting small windows along.  Without `pack` the windows keep their batch order inside each class.
+struct TilePlan { std::vector<uint32_t> order, tiles, tiles_q; };
+static TilePlan plan_tiles(const std::vector<uint32_t>& cnt, bool pack, int qmode, uint32_t n_cu) {
+  TilePlan P;
+  const size_t n = cnt.size();
+  std::vector<uint32_t> tok_off(1, 0);
+  auto finish = [&](size_t n_head) {   // n_head windows in 64-token tiles
+    tok_off.assign(1, 0);
+    for (size_t k = 0; k < n; k++) tok_off.push_back(tok_off.back() + cnt[P.order[k]]);
+    P.tiles = token_tiles(tok_off, 0, n_head, FUSED_MAX_TOK);
+    P.tiles_q.clear();
+    if (n_head < n) P.tiles_q = token_tiles(tok_off, n_head, n, FUSED_HALF_TOK);
+  };
+  if (qmode != 2) {
+    if (pack) P.order = tile_pack_order(cnt);
+    else { P.order.resize(n); for (size_t i = 0; i < n; i++) P.order[i] = (uint32_t)i; }
+    finish(n);
+    const size_t n64 = P.tiles.empty() ? 0 : P.tiles.size() - 1;
+    const size_t r = n_cu ? n64 % n_cu : 0;
+    if (qmode == 0 || r == 0 || 2 * r > n_cu) return P;
+    // windows of the last r tiles: the small ones leave for 32-token tiles, a large one stays (in front of them)
+    const uint32_t cut_tok = P.tiles[n64 - r];
+    size_t k0 = 0;
+    while (tok_off[k0] < cut_tok) k0++;
+    std::vector<uint32_t> keep, tail;
+    for (size_t k = k0; k < n; k++) (cnt[P.order[k]] > FUSED_HALF_TOK ? keep : tail).push_back(P.order[k]);
+    if (tail.empty()) return P;
+    if (pack) {  // best-fit-decreasing into bins of 32
+      std::vector<std::vector<uint32_t>> by(FUSED_HALF_TOK + 1);
+      for (size_t i = tail.size(); i-- > 0;) by[cnt[tail[i]]].push_back(tail[i]);
+      std::vector<uint32_t> t2;
+      for (uint32_t i : by[0]) t2.push_back(i);
+      tile_pack_bins(cnt, by, tail.size() - by[0].size(), FUSED_HALF_TOK, t2);
+      tail.swap(t2);
+    }
+    P.order.resize(k0);
+    P.order.insert(P.order.end(), keep.begin(), keep.end());
+    const size_t n_head = P.order.size();
+    P.order.insert(P.order.end(), tail.begin(), tail.end());
+    finish(n_head);
+    return P;
+  }
+  P.order.reserve(n);
+  if (!pack) {
+    for (size_t i = 0; i < n; i++) if (cnt[i] > FUSED_HALF_TOK) P.order.push_back((uint32_t)i);
+    const size_t n_head = P.order.size();
+    for (size_t i = 0; i < n; i++) if (cnt[i] <= FUSED_HALF_TOK) P.order.push_back((uint32_t)i);
+    finish(n_head);
+    return P;
+  }
+  std::vector<std::vector<uint32_t>> by(FUSED_MAX_TOK + 1);
+  for (size_t i = n; i-- > 0;) by[std::min(cnt[i], FUSED_MAX_TOK)].push_back((uint32_t)i);
+  size_t small_left = 0;
+  for (uint32_t s = 0; s <= FUSED_HALF_TOK; s++) small_left += by[s].size();
+  for (uint32_t s = FUSED_MAX_TOK; s > FUSED_HALF_TOK; s--)
+    while (!by[s].empty()) {   // a 64-token tile: one large window + the small ones that fit best
+      P.order.push_back(by[s].back());
+      by[s].pop_back();
+      uint32_t room = FUSED_MAX_TOK - s, f = room;
+      while (room) {
+        f = std::min(f, room);
+        while (f && by[f].empty()) f--;
+        if (!f) break;
+        P.order.push_back(by[f].back());
+        by[f].pop_back();
+        room -= f;
+        small_left--;
+      }
+    }
+  const size_t n_head = P.order.size();
+  for (uint32_t i : by[0]) { P.order.push_back(i); small_left--; }
+  tile_pack_bins(cnt, by, small_left, FUSED_HALF_TOK, P.order);
+  finish(n_head);
+  return P;
 }
 
 // One model launch over a set of windows.  Fused stacks (precision 1, 4, 5) take tiles of whole windows of at most
@@ -417,6 +508,8 @@ herro_ctx* herro_create(int device_id) {
   }
   ctx->stream = ctx->own_stream;
   {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) ctx->n_cu = (uint32_t)cus;
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
     if ((e = hipStreamCreateWithPriority(&ctx->prep_stream, hipStreamNonBlocking, hi)) != hipSuccess ||
@@ -1508,10 +1601,11 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
     std::memcpy(blob.data() + o, p, bytes);
     return o;
   };
-  struct Offs { size_t plane_off, plane_ld, len, lmax, tok_off, sup_off, out_off, tiles; uint32_t n_tiles, n_win, n_tok, max_win_tok; bool tiled; };
+  struct Offs { size_t plane_off, plane_ld, len, lmax, tok_off, sup_off, out_off, tiles, tiles_q; uint32_t n_tiles, n_tiles_q, n_win, n_tok, max_win_tok; bool tiled; };
   std::vector<Offs> offs;
   uint32_t max_tok = 0;
   const bool fused_mode = ctx->precision == 1 || ctx->precision >= 4;
+  const int qmode = ctx->precision >= 4 ? model_h_half_tiles(ctx->M) : 0;
   for (auto& g : groups) {
     for (int part = 0; part < 2; part++) {  // 0: windows that fit a fused tile (all of them in the unfused modes), 1: the rest
       std::vector<uint64_t> plane_off, sup_o, out_o;
@@ -1530,8 +1624,9 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
       if (B == 0) continue;
       // a window's place in the launch is free (its planes, padding length and output slots travel with it): the fused
       // stacks take them in the order that packs the fewest 64-token tiles
-      std::vector<uint32_t> order;
-      if (fused_mode && part == 0 && ctx->tile_packing) order = tile_pack_order(sel_cnt);
+      TilePlan plan;
+      if (fused_mode && part == 0) plan = plan_tiles(sel_cnt, ctx->tile_packing, qmode, ctx->n_cu);
+      const std::vector<uint32_t>& order = plan.order;
       plane_off.reserve(B); sup_o.reserve(B); out_o.reserve(B); ld.reserve(B); len.reserve(B); lmax.reserve(B); tok_off.reserve(B + 1);
       for (size_t k = 0; k < B; k++) {
         const size_t i = order.empty() ? k : order[k];
@@ -1549,9 +1644,10 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
       o.len = put(len.data(), B * 4); o.lmax = put(lmax.data(), B * 4);
       o.tok_off = put(tok_off.data(), (B + 1) * 4);
       o.sup_off = put(sup_o.data(), B * 8); o.out_off = put(out_o.data(), B * 8);
-      const std::vector<uint32_t> tiles = o.tiled ? token_tiles(tok_off) : std::vector<uint32_t>();
-      o.n_tiles = tiles.empty() ? 0u : (uint32_t)tiles.size() - 1;
-      o.tiles = put(tiles.data(), tiles.size() * 4);
+      o.n_tiles = plan.tiles.empty() ? 0u : (uint32_t)plan.tiles.size() - 1;
+      o.tiles = put(plan.tiles.data(), plan.tiles.size() * 4);
+      o.n_tiles_q = plan.tiles_q.empty() ? 0u : (uint32_t)plan.tiles_q.size() - 1;
+      o.tiles_q = put(plan.tiles_q.data(), plan.tiles_q.size() * 4);
       offs.push_back(o);
       max_tok = std::max(max_tok, o.n_tok);
     }
@@ -1587,6 +1683,8 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
     B.out_off = (const uint64_t*)(base + o.out_off);
     B.n_tiles = o.n_tiles;
     B.tile_tok0 = (const uint32_t*)(base + o.tiles);
+    B.n_tiles_q = o.n_tiles_q;
+    B.tile_tok0_q = (const uint32_t*)(base + o.tiles_q);
     B.planes_b = job->J.fin_b; B.planes_q = job->J.fin_q; B.sup_row = job->J.sup_row;
     B.rf_q = rf_compact ? job->d_rfq : nullptr;
     B.out_info = job->d_info; B.out_base = job->d_base;
@@ -2009,7 +2107,7 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
   int rc = HERRO_OK;
   if ((rc = ensure_scratch(ctx, (uint32_t)N))) return done(rc);
   // the host arrays of both parts must outlive their asynchronous uploads
-  struct Part { std::vector<uint64_t> plane_off, sup_off, out_off; std::vector<uint32_t> ld, len, lmax, tok_off, tiles; };
+  struct Part { std::vector<uint64_t> plane_off, sup_off, out_off; std::vector<uint32_t> ld, len, lmax, tok_off; TilePlan plan; };
   Part parts[2];
   const bool fused_mode = ctx->precision == 1 || ctx->precision >= 4;
   for (int part = 0; part < 2; part++) {  // 0: windows that fit a fused tile (all windows in the unfused modes), 1: larger ones
@@ -2023,7 +2121,8 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
       sel.push_back(b);
       sel_cnt.push_back((uint32_t)lens[b]);
     }
-    const std::vector<uint32_t> order = tiled && ctx->tile_packing ? tile_pack_order(sel_cnt) : std::vector<uint32_t>();   // as herro_job_infer
+    if (tiled) P.plan = plan_tiles(sel_cnt, ctx->tile_packing, ctx->precision >= 4 ? model_h_half_tiles(ctx->M) : 0, ctx->n_cu);   // as herro_job_infer
+    const std::vector<uint32_t>& order = P.plan.order;
     for (size_t k = 0; k < sel.size(); k++) {
       const uint32_t b = sel[order.empty() ? k : order[k]];
       P.plane_off.push_back((uint64_t)b * HERRO_ROWS * L); P.ld.push_back(L); P.len.push_back(L); P.lmax.push_back(L);
@@ -2032,17 +2131,18 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
     }
     const size_t nb = P.plane_off.size();
     if (nb == 0 || P.tok_off.back() == 0) continue;
-    if (tiled) P.tiles = token_tiles(P.tok_off);
     BatchDev bd{};
     bd.n_win = (uint32_t)nb; bd.n_tok = P.tok_off.back(); bd.max_win_tok = *std::max_element(sel_cnt.begin(), sel_cnt.end());
     bd.plane_off = (const uint64_t*)up(P.plane_off.data(), nb * 8); bd.plane_ld = (const uint32_t*)up(P.ld.data(), nb * 4);
     bd.len = (const uint32_t*)up(P.len.data(), nb * 4); bd.lmax = (const uint32_t*)up(P.lmax.data(), nb * 4);
     bd.tok_off = (const uint32_t*)up(P.tok_off.data(), (nb + 1) * 4);
     bd.sup_off = (const uint64_t*)up(P.sup_off.data(), nb * 8); bd.out_off = (const uint64_t*)up(P.out_off.data(), nb * 8);
-    bd.tile_tok0 = (const uint32_t*)up(P.tiles.data(), P.tiles.size() * 4);
-    bd.n_tiles = P.tiles.empty() ? 0u : (uint32_t)P.tiles.size() - 1;
+    bd.tile_tok0 = (const uint32_t*)up(P.plan.tiles.data(), P.plan.tiles.size() * 4);
+    bd.n_tiles = P.plan.tiles.empty() ? 0u : (uint32_t)P.plan.tiles.size() - 1;
+    bd.tile_tok0_q = (const uint32_t*)up(P.plan.tiles_q.data(), P.plan.tiles_q.size() * 4);
+    bd.n_tiles_q = P.plan.tiles_q.empty() ? 0u : (uint32_t)P.plan.tiles_q.size() - 1;
     bd.planes_b = d_pb; bd.planes_q = d_pq; bd.rf_q = nullptr; bd.sup_row = d_sr; bd.out_info = d_info; bd.out_base = d_base;
-    if (!bd.plane_off || !bd.plane_ld || !bd.len || !bd.lmax || !bd.tok_off || !bd.sup_off || !bd.out_off || !bd.tile_tok0 || e != hipSuccess) {
+    if (!bd.plane_off || !bd.plane_ld || !bd.len || !bd.lmax || !bd.tok_off || !bd.sup_off || !bd.out_off || !bd.tile_tok0 || !bd.tile_tok0_q || e != hipSuccess) {
       ctx->err = e != hipSuccess ? hipGetErrorString(e) : "out of device memory";
       (void)hipStreamSynchronize(st);
       return done(HERRO_E_NO_DEVICE);
@@ -2106,17 +2206,27 @@ int64_t herro_debug_job_array(herro_job* job, int which, const void** ptr, uint3
 // out rows of 8 u64: window, tstart, qstart, qend, op_lo, op_hi, start_off, end_off.
 // The token-tile plan of one fused launch over windows of cnt[i] informative rows (1..64): order[i] = index of the i-th
 // window of the token stream; returns the number of tiles (packed != 0: tile_pack_order; 0: batch order).
-int64_t herro_debug_tile_plan(const uint32_t* cnt, uint32_t n, int packed, uint32_t* order) {
+// (packed >> 1) & 3: qmode of plan_tiles — 1 the f16 stack's default (32-token tiles for a short last round of n_cu compute
+// units), 2 every small window in 32-token tiles (*n_half receives their number; the return value counts the 64-token tiles
+// at the head of the stream); tile_tok (capacity n + 2, may be null) receives the first tokens of all tiles, 64-token ones first, + end.
+int64_t herro_debug_tile_plan(const uint32_t* cnt, uint32_t n, int packed, uint32_t n_cu, uint32_t* order, uint32_t* n_half, uint32_t* tile_tok) {
   if (!cnt || !order) return HERRO_E_INVALID;
-  std::vector<uint32_t> c(cnt, cnt + n), ord;
+  std::vector<uint32_t> c(cnt, cnt + n);
   for (uint32_t v : c) if (v == 0 || v > FUSED_MAX_TOK) return HERRO_E_INVALID;
-  if (packed) ord = tile_pack_order(c);
-  else { ord.resize(n); for (uint32_t i = 0; i < n; i++) ord[i] = i; }
-  std::vector<uint32_t> tok_off(1, 0);
-  for (uint32_t i = 0; i < n; i++) { order[i] = ord[i]; tok_off.push_back(tok_off.back() + c[ord[i]]); }
-  const std::vector<uint32_t> t = token_tiles(tok_off);
-  for (size_t k = 0; k + 1 < t.size(); k++) if (t[k + 1] - t[k] > FUSED_MAX_TOK) return HERRO_E_STATE;
-  return t.empty() ? 0 : (int64_t)t.size() - 1;
+  const TilePlan P = plan_tiles(c, (packed & 1) != 0, (packed >> 1) & 3, n_cu);
+  for (uint32_t i = 0; i < n; i++) order[i] = P.order[i];
+  for (size_t k = 0; k + 1 < P.tiles.size(); k++) if (P.tiles[k + 1] - P.tiles[k] > FUSED_MAX_TOK) return HERRO_E_STATE;
+  for (size_t k = 0; k + 1 < P.tiles_q.size(); k++) if (P.tiles_q[k + 1] - P.tiles_q[k] > FUSED_HALF_TOK) return HERRO_E_STATE;
+  if (!P.tiles.empty() && !P.tiles_q.empty() && P.tiles.back() != P.tiles_q.front()) return HERRO_E_STATE;
+  const size_t n64 = P.tiles.empty() ? 0 : P.tiles.size() - 1, n32 = P.tiles_q.empty() ? 0 : P.tiles_q.size() - 1;
+  if (n_half) *n_half = (uint32_t)n32;
+  if (tile_tok) {
+    size_t k = 0;
+    for (size_t i = 0; i < n64; i++) tile_tok[k++] = P.tiles[i];
+    for (size_t i = 0; i < n32; i++) tile_tok[k++] = P.tiles_q[i];
+    tile_tok[k] = n32 ? P.tiles_q.back() : (n64 ? P.tiles.back() : 0);
+  }
+  return (int64_t)n64;
 }
 
 int64_t herro_debug_extract_windows(const herro_alignment* a, uint32_t n_windows, uint32_t W, uint64_t* out,

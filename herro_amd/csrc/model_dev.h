@@ -82,6 +82,8 @@ struct BatchDev {
   const uint32_t* sup_row;    // informative rows
   uint32_t n_tiles;           // token tiles of whole windows (<= 64 tokens each) for the fused stack; 0: not tileable
   const uint32_t* tile_tok0;  // [n_tiles+1] first token of each tile
+  uint32_t n_tiles_q;         // tiles of <= 32 tokens behind them in the token stream (k_layers_q: two workgroups per compute unit); 0: none
+  const uint32_t* tile_tok0_q;  // [n_tiles_q+1]
   float* out_info;            // job-level [sum nsup]
   float* out_base;            // job-level [sum nsup][5]
 };
@@ -121,6 +123,7 @@ void launch_model(const ModelDev& M, const BatchDev& B, const ModelScratch& S, i
                   hipStream_t st, KernelTimer* tm);
 // f16-operand kernels (model_h.hip): terms = 2 -> precision 4, terms = 1 -> precision 5.  B must be tiled (n_tiles > 0).
 bool model_h_supported(const ModelDev& M);
+int model_h_half_tiles(const ModelDev& M);   // qmode of plan_tiles: 0 no 32-token tiles, 1 for a short last round (default), 2 for every small window (HERRO_LAYERS_Q)
 void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S, int terms, hipStream_t st, KernelTimer* tm);
 #ifdef HERRO_PROF_BUILD
 void model_h_prof_dump();   // phase cycles of k_layers_p (model_h.hip LP_MARK), printed by herro_destroy when HERRO_PROF=1

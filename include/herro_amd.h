@@ -223,8 +223,13 @@ int64_t herro_debug_job_array(herro_job* job, int which, const void** ptr, uint3
 
 /* Host-only test hook for the token-tile plan of the fused transformer stack (herro_job_infer): n windows of cnt[i]
  * informative rows (1..64) -> order[k] = the window that is k-th in the launch's token stream; returns the number of
- * 64-token tiles of whole windows (packed = 1: the best-fit-decreasing order herro_job_infer uses; 0: the given order). */
-int64_t herro_debug_tile_plan(const uint32_t* cnt, uint32_t n, int packed, uint32_t* order);
+ * 64-token tiles of whole windows at the head of the stream.  packed bit 0: the best-fit-decreasing order herro_job_infer
+ * uses (0: the given order); bits 1-2: 0 = 64-token tiles only; 1 = the f16 stack's default: when the last round of n_cu
+ * tiles (one per compute unit) would be at most half full, its windows go into 32-token tiles instead (half the cost each);
+ * 2 = every window of <= 32 rows in 32-token tiles, a window of 33..64 rows opens a 64-token tile and takes the best-fitting
+ * small windows along.  *n_half (may be null) receives the number of 32-token tiles; tile_tok (capacity n + 1, may be null)
+ * the first token of every tile, the 64-token ones first, then the end of the stream. */
+int64_t herro_debug_tile_plan(const uint32_t* cnt, uint32_t n, int packed, uint32_t n_cu, uint32_t* order, uint32_t* n_half, uint32_t* tile_tok);
 
 /* ---- PAF / .oec.zst ingest on the host (needs no device) ---------------------------------------
  * herro_paf_parse replaces `parse_paf` (overlaps.rs:117-202): one overlap per line, tab separated

@@ -52,6 +52,8 @@ def test_model_forward_vs_twin(precision):
     [70, 3, 64],                       # a window above the 64-token tile runs layer by layer, the others stay fused
     [5, 130, 64, 65, 1],               # several of them, interleaved
     [0, 0, 5, 0],                      # windows without informative rows in between
+    [32, 33, 31, 1, 16, 16, 17, 15, 2],  # the 32-token tiles of the f16 stack: 33 opens a 64-token tile and takes 31 along; 32 | 17+15 | 16+16 | 2+1
+    [40, 20, 4, 30, 2, 64, 9],         # 64-token tiles 64 | 40+20+4, 32-token tiles 30+2 | 9
 ])
 def test_model_forward_tiling_edges(counts):
     """precision 1 = the fused transformer stack over tiles of whole windows (<= 64 tokens); windows that do
@@ -74,6 +76,9 @@ def test_model_forward_tiling_edges(counts):
     c.set_precision(4)   # f16 kernels: same tiles, windows above 64 rows through the layer-by-layer kernels
     info4, base4 = c.model_forward(bases, quals, lens, flat)
     assert max(np.abs(info4 - ti).max(), np.abs(base4 - tb).max()) <= TOL
+    c.set_precision(5)   # the single-term instances of the same kernels
+    info5, base5 = c.model_forward(bases, quals, lens, flat)
+    assert max(np.abs(info5 - ti).max(), np.abs(base5 - tb).max()) <= TOL
     c.set_precision(3)
     info3, base3 = c.model_forward(bases, quals, lens, flat)
     c.set_precision(1)

@@ -237,6 +237,66 @@ def test_token_tile_plan_packs_whole_windows_into_fewer_tiles():
         api.debug_tile_plan(np.array([65], np.uint32))
 
 
+def _check_plan(cnt, n64, n32, order, tok):
+    n = len(cnt)
+    assert sorted(order.tolist()) == list(range(n))
+    c = cnt[order].astype(np.int64)
+    win_tok = np.concatenate([[0], np.cumsum(c)])
+    assert tok[0] == 0 and tok[-1] == win_tok[-1] and len(tok) == n64 + n32 + 1
+    assert np.all(np.isin(tok, win_tok)), "a tile boundary inside a window"
+    size = np.diff(tok.astype(np.int64))
+    assert np.all(size[:n64] <= 64) and np.all(size[n64:] <= 32) and np.all(size > 0)
+    in_head = np.arange(n) < (np.searchsorted(win_tok, tok[n64]) if n64 + n32 else 0)
+    assert np.all(c[~in_head] <= 32)
+    return c, win_tok
+
+
+def test_token_tile_plan_all_small_windows_in_half_tiles():
+    """qmode 2 (the A/B plan of k_layers_q): a permutation; tiles are runs of WHOLE windows; the 64-token tiles come first, each
+    opened by a window of 33..64 rows; every other window sits in a tile of <= 32 tokens; the 32-token tiles are within 4 % of
+    ceil(tokens / 32) on the bench's distribution; the cost (a 64-token tile = two 32-token ones) never exceeds that of the
+    64-token-only plan by more than a few percent."""
+    rng = np.random.default_rng(6)
+    for n, lo, hi, packed in ((4096, 4, 31, True), (2560, 4, 31, True), (1000, 1, 65, True), (1000, 1, 65, False), (37, 60, 65, True),
+                              (64, 33, 34, True), (1, 64, 65, True), (1, 7, 8, True), (513, 1, 3, True), (300, 20, 45, True)):
+        cnt = rng.integers(lo, hi, n).astype(np.uint32)
+        n64, n32, order, tok = api.debug_tile_plan(cnt, packed=packed, qmode=2, bounds=True)
+        c, win_tok = _check_plan(cnt, n64, n32, order, tok)
+        first_win = np.searchsorted(win_tok, tok[:-1])
+        assert np.all(c[first_win[:n64]] > 32), "a 64-token tile is opened by a large window"
+        assert int((c > 32).sum()) == n64
+        if (lo, hi) == (4, 31):
+            assert n64 == 0 and n32 <= 1.04 * cnt.sum() / 32 + 1
+        if packed:
+            full, _ = api.debug_tile_plan(cnt, packed=True)
+            assert 2 * n64 + n32 <= 1.04 * 2 * full + 1 + n64   # never materially worse than 64-token tiles only (smaller bins pack ~2 % looser)
+    assert api.debug_tile_plan(np.array([], np.uint32), qmode=2)[:2] == (0, 0)
+
+
+def test_token_tile_plan_short_last_round_in_half_tiles():
+    """qmode 1 (herro_job_infer's default for the f16 stack): the 64-token plan, except that a last round filling at most half of
+    the compute units is re-packed into 32-token tiles (one per compute unit, half the cost)."""
+    rng = np.random.default_rng(7)
+    for n, lo, hi, n_cu in ((2560, 4, 31, 256), (4096, 4, 31, 256), (700, 4, 31, 256), (100, 4, 31, 256), (3000, 4, 31, 304), (900, 20, 60, 64), (50, 40, 64, 8)):
+        cnt = rng.integers(lo, hi, n).astype(np.uint32)
+        full, _ = api.debug_tile_plan(cnt, packed=True)
+        n64, n32, order, tok = api.debug_tile_plan(cnt, packed=True, qmode=1, n_cu=n_cu, bounds=True)
+        _check_plan(cnt, n64, n32, order, tok)
+        r = full % n_cu
+        if r == 0 or 2 * r > n_cu:
+            assert (n64, n32) == (full, 0)
+        elif lo < 32:
+            assert n64 % n_cu <= (cnt > 32).sum() and n64 <= full and n32 > 0
+            assert n32 <= 2 * r + 2 + r // 8, (full, r, n64, n32)      # about two half tiles per tile of the short round
+            rounds = lambda t64, t32: -(-t64 // n_cu) + 0.5 * -(-t32 // n_cu)
+            assert rounds(n64, n32) < rounds(full, 0)
+    # a launch like the bench's 2560 windows (625 tiles): 2 full rounds + a short one
+    cnt = np.random.default_rng(1).integers(4, 27, 2560).astype(np.uint32)
+    assert 600 <= api.debug_tile_plan(cnt, packed=True)[0] <= 640
+    n64, n32, _ = api.debug_tile_plan(cnt, packed=True, qmode=1, n_cu=256)
+    assert n64 == 512 and 150 <= n32 <= 256
+
+
 def test_two_threads_create_jobs_on_one_context():
     """The context's host pool takes one parallel section at a time: two threads building jobs on the same context get the same
     descriptors as one thread building them in turn."""
