@@ -1396,7 +1396,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   const size_t o_keep = take(n_ow), o_acc = take((uint64_t)n_ow * 4), o_ttot = take((uint64_t)n_ow * 4);
   const size_t o_slot = take((uint64_t)n_ow * 4), o_rqid = take((uint64_t)n_ow * 4), o_sel = take((uint64_t)n_win * 32 * 4);
   const size_t o_ctab = take((uint64_t)n_win * 32 * sizeof(CTab)), o_chdr = take((size_t)J.n_tiles * 8), o_tnsup = take((size_t)J.n_tiles * 4);
-  const size_t o_sev = take((scr_ops + 2ull * n_ow) * 8), o_tev = take((scr_ops + 2ull * n_ow) * 16), o_tileev = take((size_t)J.n_tiles * 8);
+  const size_t o_cdir = take(((uint64_t)n_ow + 1) * J.nw * 8), o_tev = take((scr_ops + 2ull * n_ow) * 16), o_tileev = take((size_t)J.n_tiles * 8);
   const size_t o_dcounts = take((uint64_t)n_win * 12);
   const size_t o_rop = take(pos_elems * 4), o_rmap = take(row_elems * 4);
   const size_t o_cseq = take(row_elems), o_ctmp = take(row_elems), o_clen = take((uint64_t)n_win * 4);
@@ -1418,7 +1418,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.ow_keep = (uint8_t*)(db + o_keep); J.ow_acc = (float*)(db + o_acc); J.ow_ttotal = (uint32_t*)(db + o_ttot);
   J.slot_ow = (uint32_t*)(db + o_slot); J.rank_qid = (uint32_t*)(db + o_rqid); J.sel_ow = (uint32_t*)(db + o_sel);
   J.ctab = (CTab*)(db + o_ctab); J.chdr2 = (uint2*)(db + o_chdr); J.tile_nsup = (uint32_t*)(db + o_tnsup);
-  J.sev = (uint2*)(db + o_sev); J.tev = (uint4*)(db + o_tev); J.tile_ev = (uint2*)(db + o_tileev);
+  J.cdir = (uint2*)(db + o_cdir); J.tev = (uint4*)(db + o_tev); J.tile_ev = (uint2*)(db + o_tileev);
   job->d_counts = (uint32_t*)(db + o_dcounts);
   J.win_Lf = job->d_counts; J.win_nsup = job->d_counts + n_win; J.win_nkept = job->d_counts + 2ull * n_win;
   J.row_of_pos2 = (uint32_t*)(db + o_rop); J.rowmap2 = (uint32_t*)(db + o_rmap);

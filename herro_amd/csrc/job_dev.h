@@ -53,6 +53,8 @@ struct JobDev {
   const uint32_t* tile_r0;   // [n_tiles] first row of the tile
   // ---- scratch / results
   uint32_t* cpl;         // [ow][3][nw] column planes over the window's positions: query base present / low / high code bit (kept overlaps)
+  uint2* cdir;           // [ow][nw] per word of 32 positions (kept overlaps; k_rfq): {M word, alignment-orientation query index of the first base at or
+                         // behind position 32 * word | insertion events of the overlap in front of that position << 20} (0xffffffff: does not fit)
   uint4* iev;            // per overlap (at scr_off): insertion events {pos | trimmed len << 16, query index, first 16 bases, untrimmed len}
   uint32_t* ins_cnt;     // [ow] number of insertion events
   uint4* ocol;           // [ow] {window position where the overlap starts, target bases covered, kept, ratio class}
@@ -64,8 +66,7 @@ struct JobDev {
   CTab* ctab;            // [win * 32 + c]
   uint2* chdr2;          // [tile] {position of the tile's first row, 1 if that row is the position's base row}
   uint32_t* tile_nsup;   // [tile] informative rows found in the tile
-  uint2* sev;            // per window (at ctab[0].ev_off): insertion events of the selected columns, column-major {pos | len << 16, query index | column << 24}
-  uint4* tev;            // per window (same base): per tile, the inserted-base runs reaching into it {pos | len << 16, query index, first 16 bases, column | hidden rows << 8}
+  uint4* tev;            // per window (at ctab[0].ev_off): per tile, the inserted-base runs reaching into it {pos | len << 16, query index, first 16 bases, column | hidden rows << 8}
   uint2* tile_ev;        // [tile] {first slot of the tile's runs relative to the window's base, count}
   uint32_t* win_nkept;
   uint32_t* win_Lf;      // rows of the final matrix (L')

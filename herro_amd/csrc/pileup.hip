@@ -199,7 +199,7 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
   if (o >= J.n_ow) return;
   uint32_t* s_mt = ca_smem + (size_t)wave * cols_lds_words(nw);   // M/D ops of the batch: window position of the first base
   uint32_t* s_mq = s_mt + MDCAP;                                  // ... query index of it
-  uint32_t* s_ml = s_mq + MDCAP;                                  // ... length | M << 31
+  uint32_t* s_ml = s_mq + MDCAP;                                  // ... length | insertion events in front of it << 14 | M << 31
   uint32_t* s_bm = s_ml + MDCAP;                                  // [nw+1] bitmap of op starts over window positions
   uint32_t* s_cum = s_bm + (nw + 1);                              // [nw+1] op starts in front of each word
   uint32_t* q0 = s_cum + (nw + 1) + 1;                            // [-1 .. qcap] query code planes (stored orientation) between two zero words
@@ -264,8 +264,12 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
   uint4* __restrict__ ev = J.iev + d.scr_off;
   constexpr int NWI = 4;   // plane words per lane (nw <= 256)
   uint32_t pM[NWI], pL[NWI], pH[NWI];
+  // directories for k_rfq, per word of 32 positions: alignment-orientation query index of the first base at or behind the word's
+  // first position (= M bits + inserted bases in front of it), insertion events in front of it — read off the op that covers
+  // the word's first position (no events inside an M / D op); 0 / 0 in front of the overlap, 0 / all events behind it
+  uint32_t dQ[NWI], dE[NWI];
 #pragma unroll
-  for (int i = 0; i < NWI; i++) { pM[i] = 0; pL[i] = 0; pH[i] = 0; }
+  for (int i = 0; i < NWI; i++) { pM[i] = 0; pL[i] = 0; pH[i] = 0; dQ[i] = 0; dE[i] = 0xffffffffu; }
   const uint64_t lt = (1ull << lane) - 1ull;
 
   for (uint32_t b0 = 0; b0 < cnt_ops; b0 += MDCAP) {
@@ -299,6 +303,7 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
           const uint32_t codes = spread16(c0) | (spread16(c1) << 1);
           ev[idx] = make_uint4(((uint32_t)pos & 0xffffu) | (min(e, 0xffffu) << 16), q, codes, min(len, 0xffffu));
         }
+        const uint32_t ev_before = n_ev + (uint32_t)__popcll(imask & lt);   // insertion events of the slice in front of this op
         n_ev += (uint32_t)__popcll(imask);
         // table of M/D ops + bitmap of their first positions
         const bool isMD = (isM || isD) && e != 0u;
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
           const uint32_t P = (uint32_t)(off + (int32_t)t);
           s_mt[idx] = P;
           s_mq[idx] = q;
-          s_ml[idx] = e | (isM ? 0x80000000u : 0u);
+          s_ml[idx] = e | (min(ev_before, 0x1ffffu) << 14) | (isM ? 0x80000000u : 0u);   // e <= 8192
           if (P < ((nw + 1u) << 5)) atomicOr(&s_bm[P >> 5], 1u << (P & 31u));
         }
         n_md += (uint32_t)__popcll(mdmask);
@@ -345,10 +350,17 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
       if (wi < nw && lo_p < hi_p) {
         uint32_t r = s_cum[wi] + (uint32_t)__popc(s_bm[wi] & (0xffffffffu >> (31u - ((uint32_t)lo_p & 31u)))) - 1u;
         int32_t P = lo_p;
+        if (lo_p == ws && r < n_md) {
+          const uint32_t ll = s_ml[r];
+          dQ[wi_i] = s_mq[r] + ((ll >> 31) ? (uint32_t)(ws - (int32_t)s_mt[r]) : 0u);
+          dE[wi_i] = (ll >> 14) & 0x1ffffu;
+        } else if (b0 == 0 && ws < Pb0) {
+          dE[wi_i] = 0;
+        }
         while (P < hi_p && r < n_md) {
           const int32_t tP = (int32_t)s_mt[r];
           const uint32_t ll = s_ml[r];
-          const int32_t se = min(hi_p, tP + (int32_t)(ll & 0x7fffffffu));
+          const int32_t se = min(hi_p, tP + (int32_t)(ll & 0x3fffu));
           const uint32_t seg = mask_range(P - ws, se - ws);
           if (ll >> 31) {
             uint32_t c0, c1;
@@ -399,7 +411,13 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
 #pragma unroll
     for (int wi_i = 0; wi_i < NWI; wi_i++) {
       const uint32_t wi = lane + 64u * wi_i;
-      if (wi < nw) { g[wi] = pM[wi_i]; g[nw + wi] = pL[wi_i]; g[2 * nw + wi] = pH[wi_i]; }
+      if (wi < nw) {
+        g[wi] = pM[wi_i]; g[nw + wi] = pL[wi_i]; g[2 * nw + wi] = pH[wi_i];
+        const uint32_t de = dE[wi_i] == 0xffffffffu ? (((int32_t)(wi << 5) < off) ? 0u : n_ev) : dE[wi_i];
+        // one 8-byte record per word {M word, query index | events << 20}: a slot of k_rfq reads this word's and the next one's
+        // from one sector.  Indices that do not fit (2^20 bases / 2^12 events in one overlap-window) are flagged; k_rfq then counts
+        J.cdir[(uint64_t)o * nw + wi] = make_uint2(pM[wi_i], (dQ[wi_i] < (1u << 20) && de < 0xfffu) ? (dQ[wi_i] | (de << 20)) : 0xffffffffu);
+      }
     }
   }
   PROF_MARK(J, 0, 4);
@@ -558,7 +576,7 @@ __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
   extern __shared__ __attribute__((aligned(16))) uint32_t ly_smem[];
   uint32_t* s_mi = ly_smem;   // [W+1] max insertion behind every position, then (in place) the row of every position
   __shared__ double s_score[SCAP];
-  __shared__ uint32_t s_sel[32], s_nev[32], s_evoff[32], s_pref[33], s_wave[LY_NT / 64], s_maxne;
+  __shared__ uint32_t s_sel[32], s_nev[32], s_evoff[32], s_wave[LY_NT / 64], s_maxne;
   __shared__ uint32_t s_tcnt[TCAP], s_toff[TCAP];   // insertion events per tile of the window, first slot of each tile's list
   const uint32_t w = blockIdx.x, tid = threadIdx.x;
   PROF_BEGIN(J);
@@ -622,7 +640,7 @@ __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
       t.qual_off = d.q_qual_off;
       t.q_woff = d.q_woff;
     }
-    // entry 0 (the target) also carries the window's compact event arrays: first slot (sev / tev), selected events in all
+    // entry 0 (the target) also carries the window's compact event array: first slot (tev), selected events in all
     const uint32_t nev = tid == 0 ? 0u : t.n_ev;
     const uint32_t inc = wscan_incl(nev);   // lanes 0..31 of the first wave
     const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 31);
@@ -634,18 +652,16 @@ __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
     J.sel_ow[(uint64_t)w * 32 + tid] = s_sel[tid];
     s_nev[tid] = nev;
     s_evoff[tid] = tid == 0 ? 0u : t.ev_off;
-    s_pref[tid] = inc - nev;
-    if (tid == 0) { s_pref[32] = tot; s_evoff[0] = t.ev_off; }   // s_evoff[0]: the window's base in sev / tev
+    if (tid == 0) s_evoff[0] = t.ev_off;   // s_evoff[0]: the window's base in tev
     atomicMax(&s_maxne, nev);
   }
   __syncthreads();
   PROF_MARK(J, 2, 1);
   // ---- insertion events of the selected columns, 8 threads per column, 8 events per thread in flight (no search for an
   // event's column).  First use: max insertion behind every position over the SELECTED overlaps — rows where every selected
-  // column is a gap are dropped (features.rs:531-556), i.e. the final layout is the row map of the selected overlaps alone —
-  // and the window's compact event list {position | length << 16, query index | column << 24} for k_rfq.
+  // column is a gap are dropped (features.rs:531-556), i.e. the final layout is the row map of the selected overlaps alone.
   const uint32_t lc = tid >> 3, sub = tid & 7u;
-  const uint32_t ne = s_nev[lc], sevb = s_pref[lc];
+  const uint32_t ne = s_nev[lc];
   const uint64_t eo = s_evoff[lc], wbase = s_evoff[0];
   const uint32_t nbatch = (s_maxne + 63u) / 64u;
   uint4 v[8];
@@ -666,7 +682,6 @@ __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
       if (i < ne) {
         const uint32_t p = v[k].x & 0xffffu;
         if (p < win_len) atomicMax(&s_mi[MI(p)], v[k].w);   // untrimmed length (features.rs:64-79)
-        J.sev[wbase + sevb + i] = make_uint2(v[k].x, (v[k].y & 0xffffffu) | (lc << 24));
       }
     }
   }
@@ -1296,255 +1311,119 @@ __global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half, const 
 // k_rfq — one workgroup per window: the qualities of the model's receptive fields, compact
 // =====================================================================================================
 // Output [(sup_off[w] + k) * 31 + column][8]: byte i = quality of row sup_row[k] - half + i of that column (span = 2 half + 1 <= 8).
-// One thread per (informative row, column) slot walks the slot's rows in order: one directory lookup finds the insertion
-// events in front of the first row, the rank in the M plane and the event cursor then advance with the rows.  Dense 8-byte
-// stores.  (Bytes scattered over the window's quality planes made every store a read-modify-write of its own line; a binary
-// search per cell over events left in global memory cost six dependent round trips per cell.)
+// One thread per (informative row, column) slot.  A cell's quality is the read's byte at the query index of the cell's base
+// (features.rs:139-152, 197-198, 225-226): for a base row at position p, the index of the first base at or behind the start of
+// p's word (k_cols' directory, which also carries the word of the M plane) + the M bits of the word in front of p + the bases
+// inserted between the word's start and p (events from the directory's cursor; skipped when the next word's cursor says none); for row j of an insertion behind p, the event's own query index
+// + j - 1 — the LAST event at p that is long enough wrote the row (the reference's sequential writes).  Everything is a gather
+// of a few words per slot with three dependent steps; nothing is staged.  (r3's version staged the 30 M planes of the window,
+// built rank and event directories for all 4096 positions in LDS — 60 k cycles and 43 KB of LDS per window for ~470 slots,
+// 17.7 x the output in HBM traffic; r2 scattered single bytes over the quality planes.)
 constexpr int RQ_NT = 256;
-constexpr uint32_t RQ_EVCAP = 1536;   // insertion events staged in LDS (more: read from global memory)
-constexpr uint32_t RQ_ROWS = 512;     // receptive-field rows per pass
-__host__ __device__ inline uint32_t rfq_es_bytes(uint32_t nw) { return ((HERRO_ROWS - 1) * (nw + 1) * 2 + 15u) & ~15u; }
-__host__ __device__ inline size_t rfq_lds(uint32_t nw) {
-  return (size_t)(HERRO_ROWS - 1) * nw * 4 + (((size_t)(HERRO_ROWS - 1) * nw * 2 + 15) & ~(size_t)15) + rfq_es_bytes(nw) + (size_t)RQ_EVCAP * 8;
-}
 
 __global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const uint64_t* __restrict__ sup_off, uint8_t* __restrict__ rf_q) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char rq_smem[];
-  const uint32_t nw = J.nw;
-  uint32_t* s_M = reinterpret_cast<uint32_t*>(rq_smem);                               // [30][nw] M planes of the selected columns
-  uint16_t* s_rk = reinterpret_cast<uint16_t*>(s_M + (size_t)(HERRO_ROWS - 1) * nw);  // [30][nw] M bits in front of the word
-  unsigned char* p_es = rq_smem + (size_t)(HERRO_ROWS - 1) * nw * 4 + (((size_t)(HERRO_ROWS - 1) * nw * 2 + 15) & ~(size_t)15);
-  uint16_t* s_es = reinterpret_cast<uint16_t*>(p_es);                                 // [30][nw+1] events in front of the word
-  uint2* s_ev = reinterpret_cast<uint2*>(p_es + rfq_es_bytes(nw));                    // {position | length << 16, inserted bases up to and including this event}
   __shared__ __attribute__((aligned(16))) CTab s_ct[32];
-  __shared__ uint32_t s_evl[33];
-  __shared__ uint32_t s_rm[RQ_ROWS];   // row-map entry of each receptive-field row (NONE: outside the window)
-  const uint32_t w = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t w = blockIdx.x, tid = threadIdx.x, nw = J.nw;
   PROF_BEGIN(J);
-  // round trip 1
   const uint32_t nsup = J.win_nsup[w], Lf = J.win_Lf[w];
+  if (!nsup) return;
   const WinDesc wd = J.win[w];
   if (tid < 32) s_ct[tid] = J.ctab[(uint64_t)w * 32 + tid];
-  if (!nsup) return;
-  for (uint32_t i = tid; i < rfq_es_bytes(nw) / 4; i += RQ_NT) reinterpret_cast<uint32_t*>(p_es)[i] = 0;
   __syncthreads();
   PROF_MARK(J, 5, 0);
-  if (tid < 64) {   // first LDS slot of every column's events
-    const uint32_t ne = (tid >= 1 && tid < 32) ? s_ct[tid].n_ev : 0u;   // entry 0 (the target) carries the window's totals
-    const uint32_t inc = wscan_incl(ne);
-    if (tid < 32) s_evl[tid] = inc - ne;
-    if (tid == 31) s_evl[32] = inc;
-  }
-  __syncthreads();
-  const uint32_t n_events = s_evl[32];
-  const bool ev_in_lds = n_events <= RQ_EVCAP;
   const uint32_t span = 2 * half + 1;
-  const uint32_t kper = RQ_ROWS / span;   // informative rows per pass
-  const uint2* __restrict__ sev = J.sev + s_ct[0].ev_off;   // the window's selected events, column-major (k_layout)
-  // round trip 2: M planes, events, the first pass's informative rows — all loads of a thread issued together
-  uint32_t srow[2] = {0, 0};
-  {
-    const uint32_t nk0 = min(kper, nsup);
-#pragma unroll
-    for (int u = 0; u < 2; u++) srow[u] = J.sup_row[wd.row_off + min(tid + u * RQ_NT, nk0 * span - 1u) / span];   // informative row of receptive-field row tid + u * NT
-    constexpr int EI = RQ_EVCAP / RQ_NT;
-    uint2 ev[EI];
-    if (ev_in_lds) {
-#pragma unroll
-      for (int u = 0; u < EI; u++) ev[u] = n_events ? sev[min(tid + u * RQ_NT, n_events - 1u)] : make_uint2(0, 0);
-    }
-    // thread -> (column, word) once; the columns advance by a fixed step
-    const uint32_t cpp = max(1u, RQ_NT / nw), c_first = tid / nw, wi = tid - c_first * nw;
-    constexpr int MI = 16;
-    for (uint32_t cb = 0; cb < HERRO_ROWS - 1; cb += MI * cpp) {
-      uint32_t mv[MI];
-#pragma unroll
-      for (int u = 0; u < MI; u++) {
-        const uint32_t c = min(cb + u * cpp + c_first, (uint32_t)HERRO_ROWS - 2u);
-        const uint32_t o = s_ct[c + 1].ow;
-        mv[u] = J.cpl[(o != NONE ? (uint64_t)o : 0ull) * 3 * nw + wi];
-      }
-#pragma unroll
-      for (int u = 0; u < MI; u++) {
-        const uint32_t c = cb + u * cpp + c_first;
-        if (c_first < cpp && c < HERRO_ROWS - 1) s_M[c * nw + wi] = s_ct[c + 1].ow != NONE ? mv[u] : 0u;
-      }
-    }
-    if (ev_in_lds) {
-#pragma unroll
-      for (int u = 0; u < EI; u++) if (tid + u * RQ_NT < n_events) s_ev[tid + u * RQ_NT] = ev[u];
-    }
-  }
-  PROF_MARK(J, 5, 1);
-  // round trip 3 (in flight while the directories are built): row-map entries of the first pass's receptive-field rows
-  uint32_t rm0[2];
-  {
-    const uint32_t nrows0 = min(kper, nsup) * span;
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-      const uint32_t i = tid + u * RQ_NT;
-      const int64_t r = (int64_t)srow[u] + (int64_t)(i % span) - (int64_t)half;
-      rm0[u] = (i < nrows0 && r >= 0 && r < (int64_t)Lf) ? J.rowmap2[wd.row_off + (uint32_t)r] : NONE;
-    }
-  }
-  __syncthreads();
-  for (uint32_t c = wave; c < HERRO_ROWS - 1; c += RQ_NT / 64) {   // rank directory of every M plane
-    uint32_t carry = 0;
-    for (uint32_t b = 0; b < nw; b += 64) {
-      const uint32_t i = b + lane;
-      const uint32_t pc = i < nw ? (uint32_t)__popc(s_M[c * nw + i]) : 0u;
-      const uint32_t inc = wscan_incl(pc);
-      if (i < nw) s_rk[c * nw + i] = (uint16_t)(carry + inc - pc);
-      carry += wlast(inc);
-    }
-  }
-  __syncthreads();
-  PROF_MARK(J, 5, 2);
-  auto Mword = [&](uint32_t c, uint32_t wi) -> uint32_t { return s_M[(c - 1) * nw + wi]; };
-  auto rank = [&](uint32_t c, uint32_t pp) -> uint32_t {   // query bases of column c aligned to positions < pp
-    const uint32_t* M = s_M + (size_t)(c - 1) * nw;
-    const uint16_t* rk = s_rk + (size_t)(c - 1) * nw;
-    if (pp >= (nw << 5)) return (uint32_t)rk[nw - 1] + (uint32_t)__popc(M[nw - 1]);
-    return (uint32_t)rk[pp >> 5] + (uint32_t)__popc(M[pp >> 5] & ((1u << (pp & 31u)) - 1u));
-  };
-  // event i of column c: {position | length << 16, inserted bases of the column up to and including it (| column << 24 in LDS)}
-  auto event = [&](uint32_t c, uint32_t i) -> uint2 {
-    if (ev_in_lds) { const uint2 v = s_ev[s_evl[c] + i]; return make_uint2(v.x, v.y & 0xffffffu); }
-    const uint2 v = sev[s_evl[c] + i];
-    return make_uint2(v.x, (v.y & 0xffffffu) + (v.x >> 16) - rank(c, (v.x & 0xffffu) + 1u));
-  };
-  // directory of the events in front of every 32 positions (events are sorted by position within a column), then, in LDS,
-  // query index -> inserted bases through the event (query index = bases aligned in front of it + bases inserted in front of it)
-  for (uint32_t e = tid; e < n_events; e += RQ_NT) {
-    const uint2 v = ev_in_lds ? s_ev[e] : sev[e];
-    const uint32_t c = v.y >> 24, i = e - s_evl[c], ne = s_ct[c].n_ev;
-    const uint32_t xp = i ? (ev_in_lds ? s_ev[e - 1].x : sev[e - 1].x) : 0u;
-    const uint32_t we = min((v.x & 0xffffu) >> 5, nw - 1u);
-    const int32_t wp = i ? (int32_t)min((xp & 0xffffu) >> 5, nw - 1u) : -1;
-    uint16_t* es = s_es + (size_t)(c - 1) * (nw + 1);
-    for (int32_t wi = wp + 1; wi <= (int32_t)we; wi++) es[wi] = (uint16_t)i;
-    if (i + 1 == ne) for (uint32_t wi = we + 1; wi <= nw; wi++) es[wi] = (uint16_t)ne;
-  }
-  __syncthreads();
-  if (ev_in_lds) {
-    for (uint32_t e = tid; e < n_events; e += RQ_NT) {
-      const uint2 v = s_ev[e];
-      const uint32_t c = v.y >> 24;
-      s_ev[e].y = (((v.y & 0xffffffu) + (v.x >> 16) - rank(c, (v.x & 0xffffu) + 1u)) & 0xffffffu) | (c << 24);
-    }
-  }
   const uint64_t tq_off = s_ct[0].qual_off + wd.tstart;
   const uint64_t qmax = J.read_qual_bytes ? J.read_qual_bytes - 1 : 0;
   constexpr uint64_t NONE64 = ~0ull;
-  PROF_MARK(J, 5, 3);
-  for (uint32_t k0 = 0; k0 < nsup; k0 += kper) {
-    const uint32_t nk = min(kper, nsup - k0), nrows = nk * span;
-    __syncthreads();
-    if (k0 == 0) {
+  const uint32_t nslots = nsup * HERRO_ROWS;
+  const uint64_t out0 = sup_off[w] * HERRO_ROWS;
+  for (uint32_t sl = tid; sl < nslots; sl += RQ_NT) {
+    const uint32_t k = sl / HERRO_ROWS, c = sl - k * HERRO_ROWS;
+    const int64_t row0 = (int64_t)J.sup_row[wd.row_off + k] - (int64_t)half;
+    uint32_t rm[8];
 #pragma unroll
-      for (int u = 0; u < 2; u++) if (tid + u * RQ_NT < nrows) s_rm[tid + u * RQ_NT] = rm0[u];
-    } else {
-      for (uint32_t i = tid; i < nrows; i += RQ_NT) {
-        const int64_t r = (int64_t)J.sup_row[wd.row_off + k0 + i / span] + (int64_t)(i % span) - (int64_t)half;
-        s_rm[i] = (r >= 0 && r < (int64_t)Lf) ? J.rowmap2[wd.row_off + (uint32_t)r] : NONE;
-      }
+    for (int d = 0; d < 8; d++) {
+      const int64_t r = row0 + d;
+      rm[d] = ((uint32_t)d < span && r >= 0 && r < (int64_t)Lf) ? J.rowmap2[wd.row_off + (uint32_t)r] : NONE;
     }
-    __syncthreads();
-    PROF_MARK(J, 5, 4);
-    // two slots per thread and iteration: addresses of both first (LDS only), then the quality bytes together, then the stores
-    const uint32_t nslots = nk * HERRO_ROWS;
-    for (uint32_t s0 = tid; s0 < nslots; s0 += 2 * RQ_NT) {
-      uint64_t addr[2][8];
+    uint64_t addr[8];
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
+    for (int d = 0; d < 8; d++) addr[d] = NONE64;
+    const CTab& q = s_ct[c];
+    if (c == 0) {
 #pragma unroll
-        for (int d = 0; d < 8; d++) addr[u][d] = NONE64;
-        const uint32_t sl = s0 + u * RQ_NT;
-        if (sl >= nslots) continue;
-        const uint32_t k = sl / HERRO_ROWS, c = sl - k * HERRO_ROWS;
-        const uint32_t* rmp = s_rm + k * span;
-        if (c == 0) {
+      for (int d = 0; d < 8; d++)
+        if (rm[d] != NONE && (rm[d] >> 16) == 0) addr[d] = min(tq_off + (rm[d] & 0xffffu), qmax);
+    } else if (q.ow != NONE) {
+      uint32_t p0 = NONE;   // position of the slot's first row inside the window
 #pragma unroll
-          for (int d = 0; d < 8; d++) {
-            if ((uint32_t)d >= span) break;
-            const uint32_t rm = rmp[d];
-            if (rm != NONE && (rm >> 16) == 0) addr[u][d] = min(tq_off + (rm & 0xffffu), qmax);
-          }
-          continue;
-        }
-        const CTab& q = s_ct[c];
-        if (q.ow == NONE) continue;
+      for (int d = 7; d >= 0; d--) if (rm[d] != NONE) p0 = rm[d] & 0xffffu;
+      if (p0 != NONE) {
+        const uint32_t w0 = min(p0 >> 5, nw - 1u), w1 = min(w0 + 1u, nw - 1u);
+        const uint2* __restrict__ dir = J.cdir + (uint64_t)q.ow * nw;
+        const uint2 d0 = dir[w0], d1 = dir[w1];
+        const uint32_t m0 = d0.x, m1 = d1.x;
         const uint32_t n_ev = q.n_ev;
-        bool started = false;
-        uint32_t cur = 0, rkp = 0, e = 0, mw = 0, mwi = NONE, cum_prev = 0;
-        uint2 ecur = make_uint2(0xffffffffu, 0);   // event e (position 0xffff: none left)
+        const uint4* __restrict__ iev = J.iev + q.ev_off;
+        uint32_t qw = d0.y & 0xfffffu, e = d0.y >> 20;
+        if (d0.y == 0xffffffffu) {   // indices beyond the record's fields: count (M bits and events in front of the word)
+          const uint32_t* __restrict__ M = J.cpl + (uint64_t)q.ow * 3 * nw;
+          qw = 0; e = 0;
+          for (uint32_t i = 0; i < w0; i++) qw += (uint32_t)__popc(M[i]);
+          while (e < n_ev && (iev[e].x & 0xffffu) < (w0 << 5)) { qw += iev[e].x >> 16; e++; }
+        }
+        // no insertion event between the two words' first positions and no row beyond: the event list is not needed
+        uint32_t pl = p0;
+        bool ins_row = false;
+#pragma unroll
+        for (int d = 0; d < 8; d++) if (rm[d] != NONE) { pl = rm[d] & 0xffffu; ins_row = ins_row || (rm[d] >> 16) != 0; }
+        const bool quiet = d0.y != 0xffffffffu && d1.y != 0xffffffffu && w1 != w0 && (d1.y >> 20) == e && (pl >> 5) == w0 && !ins_row;
+        uint4 ecur = (!quiet && e < n_ev) ? iev[e] : make_uint4(0xffffffffu, 0, 0, 0);   // event e (position 0xffff: none left)
+        uint32_t cum = 0;   // bases inserted behind positions [32 w0, p)
 #pragma unroll
         for (int d = 0; d < 8; d++) {
-          if ((uint32_t)d >= span) break;
-          const uint32_t rm = rmp[d];
-          if (rm == NONE) continue;
-          const uint32_t p = rm & 0xffffu, j = rm >> 16;
-          if (!started) {
-            started = true;
-            cur = p;
-            rkp = rank(c, p);
-            e = s_es[(size_t)(c - 1) * (nw + 1) + (p >> 5)];
-            if (e) cum_prev = event(c, e - 1).y;
-            if (e < n_ev) ecur = event(c, e);
-          }
-          while (cur <= p) {   // rkp: bases aligned in front of cur
-            if ((cur >> 5) != mwi) { mwi = cur >> 5; mw = Mword(c, mwi); }
-            if (cur == p) break;
-            rkp += (mw >> (cur & 31u)) & 1u;
-            cur++;
-          }
-          const uint32_t mbit = (mw >> (p & 31u)) & 1u;
-          while ((ecur.x & 0xffffu) < p) {   // events in front of p: [0, e)
-            cum_prev = ecur.y;
+          if (rm[d] == NONE) continue;
+          const uint32_t p = rm[d] & 0xffffu, j = rm[d] >> 16;
+          while ((ecur.x & 0xffffu) < p) {   // events in front of p: [.., e)
+            cum += ecur.x >> 16;
             e++;
-            ecur = e < n_ev ? event(c, e) : make_uint2(0xffffffffu, 0);
+            ecur = e < n_ev ? iev[e] : make_uint4(0xffffffffu, 0, 0, 0);
           }
+          const bool second = (p >> 5) != w0;   // the span is at most 8 rows: two words at most
+          const uint32_t mw = second ? m1 : m0;
+          const uint32_t below = (uint32_t)__popc(mw & ((1u << (p & 31u)) - 1u)) + (second ? (uint32_t)__popc(m0) : 0u);
+          const uint32_t mbit = (mw >> (p & 31u)) & 1u;
           uint32_t qi = NONE;
           if (j == 0) {
-            if (p - (uint32_t)q.off < q.t_total && mbit) qi = rkp + cum_prev;
-          } else if ((ecur.x & 0xffffu) == p) {   // the LAST insertion behind p that is long enough wrote this row
-            uint2 own = make_uint2(0, 0);
-            bool have = false;
-            uint2 x = ecur;
+            if (p - (uint32_t)q.off < q.t_total && mbit) qi = qw + below + cum;
+          } else if ((ecur.x & 0xffffu) == p) {
+            uint4 x = ecur;
             for (uint32_t i = e;;) {
-              if ((x.x >> 16) >= j) { own = x; have = true; }
+              if ((x.x >> 16) >= j) qi = x.y + j - 1u;
               if (++i >= n_ev) break;
-              x = event(c, i);
+              x = iev[i];
               if ((x.x & 0xffffu) != p) break;
             }
-            if (have) qi = rkp + mbit + own.y - (own.x >> 16) + j - 1u;
           }
           if (qi != NONE) {
             const int64_t si = (int64_t)q.sbase + (int64_t)q.sdir * (int64_t)qi;
-            addr[u][d] = min(q.qual_off + (uint64_t)max(si, (int64_t)0), qmax);
+            addr[d] = min(q.qual_off + (uint64_t)max(si, (int64_t)0), qmax);
           }
         }
       }
-      PROF_MARK(J, 5, 5);
-      uint32_t qv[2][8];
-#pragma unroll
-      for (int u = 0; u < 2; u++)
-#pragma unroll
-        for (int d = 0; d < 8; d++) qv[u][d] = J.read_qual[addr[u][d] == NONE64 ? 0 : addr[u][d]];
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const uint32_t sl = s0 + u * RQ_NT;
-        if (sl >= nslots) continue;
-        uint32_t lo = 0, hi = 0;
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-          lo |= (addr[u][d] == NONE64 ? 33u : qv[u][d]) << (8 * d);
-          hi |= (addr[u][d + 4] == NONE64 ? 33u : qv[u][d + 4]) << (8 * d);
-        }
-        *reinterpret_cast<uint2*>(rf_q + ((sup_off[w] + k0) * HERRO_ROWS + sl) * 8) = make_uint2(lo, hi);
-      }
-      PROF_MARK(J, 5, 6);
     }
+    PROF_MARK(J, 5, 1);
+    uint32_t qv[8];
+#pragma unroll
+    for (int d = 0; d < 8; d++) qv[d] = J.read_qual[addr[d] == NONE64 ? 0 : addr[d]];
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      lo |= (addr[d] == NONE64 ? 33u : qv[d]) << (8 * d);
+      hi |= (addr[d + 4] == NONE64 ? 33u : qv[d + 4]) << (8 * d);
+    }
+    *reinterpret_cast<uint2*>(rf_q + (out0 + sl) * 8) = make_uint2(lo, hi);
+    PROF_MARK(J, 5, 2);
   }
 }
 
@@ -1620,8 +1499,7 @@ void launch_rf_quals(const JobDev& J, uint32_t half, const uint64_t* sup_off, ui
   if (!J.n_win) return;
   KT_BEGIN(tm, "rf_quals", st);
   if (rf_q && 2 * half + 1 <= 8) {
-    pileup_opt_in_lds(reinterpret_cast<const void*>(k_rfq), 128 * 1024);
-    hipLaunchKernelGGL(k_rfq, dim3(J.n_win), dim3(RQ_NT), rfq_lds(J.nw), st, J, half, sup_off, rf_q);
+    hipLaunchKernelGGL(k_rfq, dim3(J.n_win), dim3(RQ_NT), 0, st, J, half, sup_off, rf_q);
     KT_END(tm, st);
     return;
   }
