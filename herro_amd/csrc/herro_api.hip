@@ -855,6 +855,34 @@ int herro_load_model(herro_ctx* ctx, const char* path) {
   M.t1 = vec("t1", (size_t)h.kw * 12 * h.c1);
   M.wq1 = vec("wq1", (size_t)h.kw * h.c1);
   M.b1 = vec("b1", h.c1);
+  if (!missing && h.kw == 3 && h.c1 == 64) {   // conv1 as a GEMM (k_conv_m): W1g[c][tap * 32 + slot], slots as listed in model_h.hip
+    const auto& t1 = get("t1", (size_t)h.kw * 12 * h.c1);
+    const auto& wq = get("wq1", (size_t)h.kw * h.c1);
+    const auto& b1 = get("b1", h.c1);
+    const uint32_t K = 96, N = 64, nks = 3;
+    std::vector<uint16_t> g((size_t)N * K, 0), ph((size_t)N * K);
+    for (uint32_t c = 0; c < N && !missing; c++)
+      for (uint32_t tp = 0; tp < 3; tp++) {
+        uint16_t* row = g.data() + (size_t)c * K + tp * 32;
+        auto hl = [&](float v, uint16_t& hi, uint16_t& lo) { hi = h_f16(v); lo = h_f16(v - h_f16f(hi)); };
+        for (uint32_t tok = 0; tok < 12; tok++) hl(t1[((size_t)tp * 12 + tok) * N + c], row[tok], row[16 + tok]);
+        uint16_t qh, ql;
+        hl(wq[(size_t)tp * N + c], qh, ql);
+        row[13] = qh; row[14] = qh; row[29] = ql;
+        if (tp == 0) hl(b1[c], row[15], row[31]);
+      }
+    for (uint32_t n32 = 0; n32 < N / 32; n32++)
+      for (uint32_t jt = 0; jt < 2; jt++)
+        for (uint32_t ks = 0; ks < nks; ks++)
+          for (uint32_t lane = 0; lane < 64; lane++) {
+            const uint32_t fr = lane & 15, fg = lane >> 4;
+            const size_t src = (size_t)(n32 * 32 + 8 * (fr >> 2) + 4 * jt + (fr & 3)) * K + ks * 32 + fg * 8;
+            const size_t dst = ((((size_t)n32 * 2 + jt) * nks + ks) * 64 + lane) * 8;
+            for (uint32_t e8 = 0; e8 < 8; e8++) ph[dst + e8] = g[src + e8];
+          }
+    uint16_t* dg = dev_alloc_copy(ph, ctx->stream, e); ctx->model_allocs.push_back(dg);
+    M.conv1g.ph16 = dg; M.conv1g.K = K; M.conv1g.N = N;
+  }
   M.conv2 = weight("conv2", h.kw * h.c1, h.c2);
   M.fc = weight("fc", h.rows * h.c2, D);
   M.pe_div = vec("pe_div", D / 2);

@@ -54,6 +54,7 @@ struct ModelDev {
   const float* t1;      // [kw][12][c1] embedding folded through conv1 (+BN), tap-major
   const float* wq1;     // [kw][c1]     conv1 weights of the quality channel
   const float* b1;      // [c1]
+  Weight conv1g;        // conv1 as a GEMM for k_conv_m (model_h.hip): [kw*32, c1] f16 hi / lo slots of table, quality weight and bias; ph16 only
   Weight conv2;         // [kw*c1, c2]  (BN folded), k = tap*c1 + c
   Weight fc;            // [rows*c2, d_model], k = row*c2 + c
   const float* pe_div;  // [d_model/2]

@@ -76,6 +76,14 @@ __device__ __forceinline__ void split_h8(const float (&v)[8], half8& hi, half8& 
   hi = __builtin_bit_cast(half8, h);
   lo = __builtin_bit_cast(half8, l);
 }
+// max(x, 0) on eight packed halves, then a lane mask
+__device__ __forceinline__ half8 relu_mask_h8(half8 x, uint32_t mask) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  uint4 u = __builtin_bit_cast(uint4, x);
+  const h2 z = {(_Float16)0, (_Float16)0};
+  auto mx = [&](uint32_t v) -> uint32_t { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h2, v), z)) & mask; };
+  return __builtin_bit_cast(half8, make_uint4(mx(u.x), mx(u.y), mx(u.z), mx(u.w)));
+}
 __device__ __forceinline__ f32x4 mma(half8 a, half8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 __device__ __forceinline__ void glds16_h(const void* gsrc, uint32_t lds_dst) {  // 16 B per lane, global -> LDS, no VGPR staging
@@ -274,6 +282,218 @@ __global__ __launch_bounds__(256, 2) void k_conv_h(ModelDev M, BatchDev B, Model
             make_uint4(pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7]));
     }
     __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_conv_m — conv1 AND conv2 on the MFMA pipe, chained through registers (round 4).
+// k_conv_h generates conv1 on the vector unit: 1400 VALU instructions per thread and tile for 96 MFMAs (MFMA pipe 14 %
+// busy).  But conv1 of a (token, read row) pair is a tiny GEMM: y1[j][c] = relu(b1[c] + sum_tap T1[tap][tok(j + tap)][c] +
+// wq[tap][c] q(j + tap)) = W1g . a, with a = per tap a one-hot of the cell's token (13 values: 12 tokens + "outside"), the
+// normalised quality and a constant 1 for the bias.  To keep conv1 as exact as the f32 VALU version (the table is not
+// rounded to f16 anywhere today), table, quality weight and bias enter as f16 hi + lo in separate K slots — the one-hot is
+// exact, so hi and lo rows simply add up — and the quality as hi + lo too: 32 slots per tap, K = 96, 3 k-steps:
+//     slots 0..12 one-hot -> T1 hi | 13 q_hi -> wq hi | 14 q_lo -> wq hi | 15 one -> b1 hi (tap 0) | 16..28 one-hot -> T1 lo |
+//     29 q_hi -> wq lo | 30 unused | 31 one -> b1 lo (tap 0)                       (Weight M.conv1g, built at load)
+// The MFMA's result layout (channel rows, pair columns; two row-interleaved MFMAs give a lane 8 consecutive channels of its
+// pair) IS the B-operand layout of conv2's k-step, so y1 never leaves the registers: a wave takes 32 pairs (two blocks of
+// 16) through conv1 (36 MFMAs per block) and conv2 (48 per block, W2 fragments read once from LDS for both blocks) and
+// stores y2 as 16-byte pieces.  No activation in LDS, no barrier in the loop; the waves of a workgroup only share the 48 KB
+// of conv2 fragments.
+// ---------------------------------------------------------------------------------------------------
+constexpr int CM_NT = 256;
+constexpr size_t CONV_M_SHM = (size_t)48 * 1024 + 128 * 4 + 32 * 16;
+
+__global__ __launch_bounds__(CM_NT, 2) void k_conv_m(ModelDev M, BatchDev B, ModelScratch S, uint32_t n_rows, uint32_t n_units) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* s_w2 = reinterpret_cast<uint4*>(smem);                     // conv2 weights in fragment order: fragment f, lane l at [f * 64 + l]
+  float* s_b2 = reinterpret_cast<float*>(smem + 48 * 1024);
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t fr = lane & 15, fg = lane >> 4;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(M.conv2.ph16);
+    for (uint32_t i = tid; i < 48 * 64; i += CM_NT) s_w2[i] = src[i];
+    for (uint32_t i = tid; i < 128; i += CM_NT) s_b2[i] = M.conv2.bias[i];
+  }
+  half8 w1[3][2][2];   // [tap][slab][jt]
+  {
+    const uint16_t* p = M.conv1g.ph16 + (uint64_t)lane * 8;
+#pragma unroll
+    for (int sl = 0; sl < 2; sl++)
+#pragma unroll
+      for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+        for (int tp = 0; tp < 3; tp++) w1[tp][sl][jt] = *reinterpret_cast<const half8*>(p + (uint64_t)(((sl * 2 + jt) * 3 + tp) * 64) * 8);
+  }
+  const bool rfq = B.rf_q != nullptr;
+  // The receptive field of pair m: rows tok_row - 2 .. + 2 of read row (m % 31) of the token's window; outside [0, lmax): token 12
+  // (zero table row) and no quality; inside the batch padding [len, lmax): pad token and quality 126 (inference.rs:86-97).
+  // Two dependent loads (the token's record, then its cells) run two and one unit ahead of the arithmetic.
+  struct Raw { uint32_t t[5], q[5]; uint2 q8; };
+  struct Cells { uint32_t tok[2], q[2], ok; };   // five token bytes, five quality bytes (0xff: none), validity of the three conv1 positions
+  auto load_meta = [&](uint32_t m) -> TokMeta {
+    return S.tok_meta[min(m, n_rows - 1u) / HERRO_ROWS];
+  };
+  auto load_raw = [&](const TokMeta& tm, uint32_t m) -> Raw {
+    Raw r;
+    const uint32_t rr = min(m, n_rows - 1u) % HERRO_ROWS;
+    const uint8_t* pb = B.planes_b + tm.plane_off + (uint64_t)rr * tm.plane_ld;
+    r.q8 = make_uint2(0, 0);
+    if (rfq) r.q8 = *reinterpret_cast<const uint2*>(B.rf_q + ((uint64_t)tm.rf_idx * HERRO_ROWS + rr) * 8);
+    const uint8_t* pq = B.planes_q + tm.plane_off + (uint64_t)rr * tm.plane_ld;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      const int32_t row = min(max((int32_t)tm.tok_row - 2 + i, 0), (int32_t)tm.len - 1);   // clamped: the value is dropped below when the cell is not real
+      r.t[i] = pb[row];
+      r.q[i] = rfq ? 0u : (uint32_t)pq[row];
+    }
+    return r;
+  };
+  auto finish = [&](const Raw& r, const TokMeta& tm, uint32_t m) -> Cells {
+    Cells c;
+    uint32_t tk[5], qq[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      const int32_t row = (int32_t)tm.tok_row - 2 + i;
+      const bool in = m < n_rows && row >= 0 && row < (int32_t)tm.lmax, real = in && row < (int32_t)tm.len;
+      const uint32_t qv = rfq ? ((i < 4 ? r.q8.x >> (8 * i) : r.q8.y) & 0xffu) : r.q[i];
+      tk[i] = real ? r.t[i] : (in ? (uint32_t)TOK_PAD : 12u);
+      qq[i] = real ? qv : (in ? 126u : 0xffu);
+    }
+    c.tok[0] = tk[0] | (tk[1] << 8) | (tk[2] << 16) | (tk[3] << 24); c.tok[1] = tk[4];
+    c.q[0] = qq[0] | (qq[1] << 8) | (qq[2] << 16) | (qq[3] << 24); c.q[1] = qq[4];
+    c.ok = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int32_t pos = (int32_t)tm.tok_row + j - 1;
+      if (m < n_rows && pos >= 0 && pos < (int32_t)tm.lmax) c.ok |= 1u << j;
+    }
+    return c;
+  };
+  // one-hot operand fragments by (token, lane parity): lanes fg 0 / 2 hold slots 0..7, lanes fg 1 / 3 slots 8..15 (+ one in slot 15)
+  uint4* s_oh = reinterpret_cast<uint4*>(s_b2 + 128);
+  if (tid < 32) {
+    const uint32_t tok = tid >> 1, od = tid & 1u, t = tok - 8u * od;
+    uint32_t r[4] = {0, 0, 0, od ? 0x3c000000u : 0u};
+    if (tok < 13 && (od ? t < 5u : t < 8u)) r[t >> 1] |= 0x3c00u << ((t & 1u) * 16u);
+    s_oh[tid] = make_uint4(r[0], r[1], r[2], r[3]);
+  }
+  __syncthreads();
+
+  const uint32_t odd = fg & 1u;
+  const uint32_t stride = gridDim.x * (CM_NT / 64);
+  uint32_t unit = blockIdx.x * (CM_NT / 64) + wave;
+  TokMeta mt1[2], mt2[2];   // records of the pairs of unit + stride, unit + 2 stride
+  Cells cur[2];
+  Raw raw[2];
+#pragma unroll
+  for (int b = 0; b < 2; b++) {
+    const TokMeta m0 = load_meta(unit * 32 + b * 16 + fr);
+    cur[b] = finish(load_raw(m0, unit * 32 + b * 16 + fr), m0, unit * 32 + b * 16 + fr);
+    mt1[b] = load_meta((unit + stride) * 32 + b * 16 + fr);
+  }
+  for (; unit < n_units; unit += stride) {
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      mt2[b] = load_meta((unit + 2 * stride) * 32 + b * 16 + fr);
+      raw[b] = load_raw(mt1[b], (unit + stride) * 32 + b * 16 + fr);
+    }
+    half8 y1f[2][6];   // [block][conv2 k-step = position * 2 + slab]
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      // operand fragments of the five receptive-field rows: lanes fg 0 / 2 slots 0..7 (one-hot of tokens 0..7), lanes fg 1 / 3
+      // slots 8..15 (tokens 8..12, q_hi, q_lo | 0, one)
+      half8 rf[5];
+#pragma unroll
+      for (int i = 0; i < 5; i++) {
+        const uint32_t tok = ((i < 4 ? cur[b].tok[0] >> (8 * i) : cur[b].tok[1]) & 0xffu);
+        const uint32_t qb = ((i < 4 ? cur[b].q[0] >> (8 * i) : cur[b].q[1]) & 0xffu);
+        uint4 r = s_oh[tok * 2u + odd];
+        const float qn = qb != 0xffu ? norm_qual_h(qb) : 0.f;
+        uint32_t qh, ql;
+        split_h2(qn, 0.f, qh, ql);
+        r.z |= odd ? qh << 16 : 0u;                               // slot 13 (29): q_hi
+        r.w |= fg == 1u ? (ql & 0xffffu) : 0u;                    // slot 14: q_lo (30: unused)
+        rf[i] = as_half8(r.x, r.y, r.z, r.w);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        f32x4 a[2][2];
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++)
+#pragma unroll
+          for (int jt = 0; jt < 2; jt++) a[sl][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tp = 0; tp < 3; tp++)
+#pragma unroll
+          for (int sl = 0; sl < 2; sl++)
+#pragma unroll
+            for (int jt = 0; jt < 2; jt++) a[sl][jt] = mma(w1[tp][sl][jt], rf[j + tp], a[sl][jt]);
+        const uint32_t okm = ((cur[b].ok >> j) & 1u) ? 0xffffffffu : 0u;   // conv2 sees zeros beyond the (padded) sequence ends
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) v[q] = a[sl][q >> 2][q & 3];
+          y1f[b][j * 2 + sl] = relu_mask_h8(pack_h8(v), okm);   // ReLU after the rounding: the same number
+        }
+      }
+    }
+    // conv2: 64 output channels at a time, both blocks against one read of every weight fragment
+    uint16_t* y2 = S.y2_hi;
+#pragma unroll
+    for (int hs = 0; hs < 2; hs++) {
+      f32x4 a2[2][2][2];   // [block][slab][jt]
+#pragma unroll
+      for (int sl = 0; sl < 2; sl++)
+#pragma unroll
+        for (int jt = 0; jt < 2; jt++) {
+          const float4 bv = *reinterpret_cast<const float4*>(s_b2 + (hs * 2 + sl) * 32 + 8 * fg + 4 * jt);
+#pragma unroll
+          for (int b = 0; b < 2; b++) a2[b][sl][jt] = f32x4{bv.x, bv.y, bv.z, bv.w};
+        }
+      half8 wf[2][2], wn[2][2];   // the fragments of one k-step, read one k-step ahead of their MFMAs
+      auto rdw = [&](int ks, half8 (&w)[2][2]) {
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++)
+#pragma unroll
+          for (int jt = 0; jt < 2; jt++) w[sl][jt] = __builtin_bit_cast(half8, s_w2[((((hs * 2 + sl) * 2 + jt) * 6 + ks) * 64) + lane]);
+      };
+      rdw(0, wf);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 6; ks++) {
+        if (ks < 5) rdw(ks + 1, wn);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++)
+#pragma unroll
+          for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) a2[b][sl][jt] = mma(wf[sl][jt], y1f[b][ks], a2[b][sl][jt]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++)
+#pragma unroll
+          for (int jt = 0; jt < 2; jt++) wf[sl][jt] = wn[sl][jt];
+      }
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const uint32_t m = unit * 32 + b * 16 + fr;
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) v[q] = a2[b][sl][q >> 2][q & 3];
+          if (m < n_rows) *reinterpret_cast<half8*>(y2 + (uint64_t)m * HC2 + (hs * 2 + sl) * 32 + 8 * fg) = relu_mask_h8(pack_h8(v), 0xffffffffu);
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      cur[b] = finish(raw[b], mt1[b], (unit + stride) * 32 + b * 16 + fr);
+      mt1[b] = mt2[b];
+    }
   }
 }
 
@@ -1273,9 +1493,16 @@ void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S,
   hipLaunchKernelGGL(k_build_tokens_h, dim3(B.n_win), dim3(64), 0, st, B, S);
   KT_END(tm, st);
   {
+    static const bool conv_m = [] { const char* e = getenv("HERRO_CONV_M"); return !e || atoi(e) != 0; }();   // 0: conv1 on the vector unit (k_conv_h), for the A/B
     const uint32_t n_rows = N * HERRO_ROWS, n_tiles = (n_rows + HTP - 1) / HTP;
     KT_BEGIN(tm, "conv_fused", st);
-    hipLaunchKernelGGL(k_conv_h, dim3(std::min<uint32_t>(n_tiles, 512u)), dim3(256), CONV_H_SHM, st, M, B, S, n_rows, n_tiles);
+    if (conv_m && M.conv1g.ph16) {
+      const uint32_t n_units = (n_rows + 31) / 32;
+      opt_in_lds(reinterpret_cast<const void*>(k_conv_m), CONV_M_SHM);
+      hipLaunchKernelGGL(k_conv_m, dim3(std::min<uint32_t>((n_units + 3) / 4, 512u)), dim3(CM_NT), CONV_M_SHM, st, M, B, S, n_rows, n_units);
+    } else {
+      hipLaunchKernelGGL(k_conv_h, dim3(std::min<uint32_t>(n_tiles, 512u)), dim3(256), CONV_H_SHM, st, M, B, S, n_rows, n_tiles);
+    }
     KT_END(tm, st);
   }
   opt_in_lds(reinterpret_cast<const void*>(k_fc_h), FC_H_SHM);
