@@ -1005,6 +1005,7 @@ static int ensure_scratch(herro_ctx* ctx, uint32_t n_tok) {
   S.tok_win = (uint32_t*)A(cap * 4);
   S.tok_row = (uint32_t*)A(cap * 4);
   S.tok_meta = (TokMeta*)A(cap * sizeof(TokMeta));
+  S.tok_cv = (TokCv*)A(cap * sizeof(TokCv));
   S.y1 = (float*)A(cap * HERRO_ROWS * h.kw * h.c1 * 4);
   S.y2 = (float*)A(cap * HERRO_ROWS * h.c2 * 4);
   S.x = (float*)A(cap * h.d_model * 4);
@@ -1018,7 +1019,7 @@ static int ensure_scratch(herro_ctx* ctx, uint32_t n_tok) {
   S.h_hi = (uint16_t*)A(cap * h.d_model * 2); S.h_lo = (uint16_t*)A(cap * h.d_model * 2);
   S.att_hi = (uint16_t*)A(cap * h.d_model * 2); S.att_lo = (uint16_t*)A(cap * h.d_model * 2);
   S.ff_hi = (uint16_t*)A(cap * h.d_ff * 2); S.ff_lo = (uint16_t*)A(cap * h.d_ff * 2);
-  if (!S.y1_hi || !S.y1_lo || !S.y2_hi || !S.y2_lo || !S.h_hi || !S.h_lo || !S.att_hi || !S.att_lo || !S.ff_hi || !S.ff_lo ||!S.tok_win || !S.tok_row || !S.tok_meta || !S.y1 || !S.y2 || !S.x || !S.hbuf || !S.qkv || !S.att || !S.ff || !S.logits) {
+  if (!S.y1_hi || !S.y1_lo || !S.y2_hi || !S.y2_lo || !S.h_hi || !S.h_lo || !S.att_hi || !S.att_lo || !S.ff_hi || !S.ff_lo ||!S.tok_win || !S.tok_row || !S.tok_meta || !S.tok_cv || !S.y1 || !S.y2 || !S.x || !S.hbuf || !S.qkv || !S.att || !S.ff || !S.logits) {
     free_all(ctx->scratch_allocs);
     ctx->scratch_cap = 0;
     ctx->err = "out of device memory for model scratch (" + std::to_string(cap) + " tokens)";
@@ -2126,7 +2127,7 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
     return p;
   };
   uint8_t* d_src_b = (uint8_t*)up(bases, cells); uint8_t* d_src_q = (uint8_t*)up(quals, cells);
-  uint8_t* d_pb = (uint8_t*)A(cells); uint8_t* d_pq = (uint8_t*)A(cells);
+  uint8_t* d_pb = (uint8_t*)A(cells + 16); uint8_t* d_pq = (uint8_t*)A(cells + 16);   // + slack: k_conv_m reads up to 2 bytes behind a plane row (masked)
   uint32_t* d_sr = (uint32_t*)up(srow.data(), N * 4);
   float* d_info = (float*)A(N * 4); float* d_base = (float*)A(N * 20);
   if (!d_src_b || !d_src_q || !d_pb || !d_pq || !d_sr || !d_info || !d_base) { ctx->err = "out of device memory"; return done(HERRO_E_NO_DEVICE); }

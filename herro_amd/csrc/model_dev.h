@@ -99,10 +99,23 @@ struct __attribute__((aligned(16))) TokMeta {
   uint32_t pad1;
 };
 
+// The same for k_conv_m (model_h.hip), with the token's five receptive-field rows tok_row - 2 .. + 2 resolved once per token instead
+// of once per (read row, lane): byte masks of the rows inside the window's real rows, default bytes of the others — pad token /
+// quality 126 inside the batch padding [len, lmax) (inference.rs:86-97), token 12 (zero table row) / no quality (0xff) outside
+// [0, lmax).  Rows 0..3 in the 32-bit words, row 4 in the packed bytes.
+struct __attribute__((aligned(16))) TokCv {
+  uint64_t plane_off;
+  uint32_t ld_d1;      // plane stride | default token of row 4 << 16 | default quality of row 4 << 24
+  uint32_t row_ok;     // tok_row | validity of conv1 positions tok_row - 1 .. + 1 (inside [0, lmax)) << 16 | mask of row 4 << 24
+  uint32_t rf_idx;
+  uint32_t mk0, dt0, dq0;
+};
+
 struct ModelScratch {  // sized for n_tok tokens
   uint32_t* tok_win;  // [N] window (batch-local) of each token
   uint32_t* tok_row;  // [N] row of each token
   TokMeta* tok_meta;  // [N]
+  TokCv* tok_cv;      // [N]
   float* y1;          // [N][31][kw][c1]
   float* y2;          // [N][31*c2]
   float* x;           // [N][d_model] residual stream

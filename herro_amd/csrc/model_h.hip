@@ -17,7 +17,7 @@
 // everywhere (1 MFMA everywhere but the heads); it is measured and reported, not the default.  Accumulation is f32 in every mode.
 //
 // Kernels (same dataflow as model.hip, re-derived for one 2-byte plane per operand):
-//   k_conv_h   embedding + quality + conv1 on the fly -> conv2 (K = 192) -> y2 as ONE f16 plane [N*31][128]
+//   k_conv_m   embedding + quality + conv1 as a K = 96 GEMM -> (registers) -> conv2 (K = 192) -> y2 as ONE f16 plane [N*31][128]
 //   k_fc_h     y2[N][3968] . Wfc -> x[N][256]; 128 x 256 tiles, LDS-DMA, three 24 KB buffers, 2 workgroups per CU
 //   k_layers_p the whole encoder stack per tile of <= 64 tokens: residual stream in registers from the FC output to
 //              the logits (positional encoding added on the way in), weight fragments one half GEMM call ahead
@@ -108,203 +108,37 @@ void opt_in_lds(const void* fn, size_t bytes) {
   if (done.insert({fn, dev}).second) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// conv1 (on the fly) -> conv2, single f16 operands.  Same organisation as k_conv_w (model.hip): persistent
-// workgroups walk tiles of 128 (token, read row) pairs, conv2 weights resident in VGPRs (wave = 32 output
-// channels, 48 registers), MFMA roles swapped so y2 leaves as 16-byte stores straight from the accumulators,
-// activation tile double-buffered (one barrier per k-step), next tile's cells prefetched into registers.
-// ---------------------------------------------------------------------------------------------------
 constexpr int HC2 = 128;
-constexpr int HLD = 32;  // 64-byte LDS rows, 16-byte chunks XOR-swizzled by (row >> 1) & 3
-__device__ __forceinline__ uint32_t hswz(uint32_t row, uint32_t chunk) { return chunk ^ ((row >> 1) & 3u); }
-constexpr int HTP = 128;
-constexpr int HT1R = 13;
-constexpr size_t CONV_H_SHM = (size_t)2 * HTP * HLD * 2 + (size_t)(3 * HT1R * 64 + 3 * 64 + 64) * 4 + (size_t)HTP * 8 * 4 + (size_t)HTP * 8 +
-                              (size_t)HTP * 4;
-
-__global__ __launch_bounds__(256, 2) void k_conv_h(ModelDev M, BatchDev B, ModelScratch S, uint32_t n_rows, uint32_t n_tiles) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint16_t* s_x = reinterpret_cast<uint16_t*>(smem);               // [2 buffers][128][32] f16
-  float* s_t1 = reinterpret_cast<float*>(s_x + 2 * HTP * HLD);      // [3][13][64]
-  float* s_wq = s_t1 + 3 * HT1R * 64;                               // [3][64]
-  float* s_b1 = s_wq + 3 * 64;                                      // [64]
-  float* s_qn = s_b1 + 64;                                          // [128][8]
-  uint8_t* s_tok = reinterpret_cast<uint8_t*>(s_qn + HTP * 8);      // [128][8]
-  uint8_t* s_val = s_tok + HTP * 8;                                 // [128][4]
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t fr = lane & 15, fg = lane >> 4;
-
-  for (uint32_t e = tid; e < 3 * HT1R * 64; e += 256) {
-    const uint32_t t = e / (HT1R * 64), rem = e % (HT1R * 64), tok = rem / 64, c = rem % 64;
-    s_t1[e] = tok < 12 ? M.t1[(t * 12 + tok) * 64 + c] : 0.f;
-  }
-  for (uint32_t e = tid; e < 3 * 64; e += 256) s_wq[e] = M.wq1[e];
-  for (uint32_t e = tid; e < 64; e += 256) s_b1[e] = M.b1[e];
-  const Weight& W = M.conv2;
-  const uint32_t c0 = wave * 32;
-  half8 wh[6][2];
-#pragma unroll
-  for (int jt = 0; jt < 2; jt++) {
-    const uint32_t ch = c0 + 8 * (fr >> 2) + 4 * jt + (fr & 3);  // lane group g ends up with channels c0 + 8g .. + 7
-#pragma unroll
-    for (int ks = 0; ks < 6; ks++) wh[ks][jt] = *reinterpret_cast<const half8*>(W.h16 + (uint64_t)ch * 192 + ks * 32 + fg * 8);
-  }
-  float bias8[8];
-#pragma unroll
-  for (int q = 0; q < 8; q++) bias8[q] = W.bias[c0 + 8 * fg + q];
-
-  const uint32_t grr = tid & 127u;
-  const bool gq = tid >= 128;
-  const bool rfq = gq && B.rf_q != nullptr;   // qualities from the compact receptive-field array
-  const uint8_t* gplane = gq ? (rfq ? B.rf_q : B.planes_q) : B.planes_b;
-  struct PairMeta { uint64_t rowbase; uint32_t tok_row, len, lmax; };
-  auto load_meta = [&](uint32_t tile) -> PairMeta {
-    const uint32_t m = tile * HTP + grr;
-    PairMeta r{0, 0, 0, 0};
-    if (tile < n_tiles && m < n_rows) {
-      const TokMeta tm = S.tok_meta[m / HERRO_ROWS];
-      r.rowbase = tm.plane_off + (uint64_t)(m % HERRO_ROWS) * tm.plane_ld;
-      if (rfq) r.rowbase = ((uint64_t)tm.rf_idx * HERRO_ROWS + m % HERRO_ROWS) * 8 - (uint64_t)(int64_t)((int32_t)tm.tok_row - 2);   // + q = slot byte q - (tok_row - 2)
-      r.tok_row = tm.tok_row;
-      r.len = tm.len;
-      r.lmax = tm.lmax;
-    }
-    return r;
-  };
-  auto load_cells = [&](const PairMeta& mt, uint32_t (&g)[5]) {
-#pragma unroll
-    for (int pi = 0; pi < 5; pi++) {
-      const int32_t q = (int32_t)mt.tok_row - 2 + pi;
-      uint32_t v = gq ? 0xffffffffu : 12u;
-      if (q >= 0 && q < (int32_t)mt.lmax) v = q < (int32_t)mt.len ? (uint32_t)gplane[mt.rowbase + (uint32_t)q] : (gq ? 126u : (uint32_t)TOK_PAD);
-      g[pi] = v;
-    }
-  };
-  uint32_t g[5];
-  PairMeta mcur = load_meta(blockIdx.x);
-  load_cells(mcur, g);
-  PairMeta mnext = load_meta(blockIdx.x + gridDim.x);
-
-  f32x4 acc[8][2];
-  const uint32_t arow = tid >> 3, kk = (tid & 7) * 4;
-  uint16_t* y2 = S.y2_hi;  // one f16 plane in this mode
-  __syncthreads();
-
-  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const uint32_t m0 = tile * HTP;
-    if (!gq) {
-      *reinterpret_cast<uint2*>(s_tok + grr * 8) = make_uint2(g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24), g[4]);
-      uint32_t vb = 0;
-#pragma unroll
-      for (int dl = 0; dl < 3; dl++) {
-        const int32_t pos = (int32_t)mcur.tok_row + dl - 1;
-        if (pos >= 0 && pos < (int32_t)mcur.lmax) vb |= 1u << (8 * dl);
-      }
-      *reinterpret_cast<uint32_t*>(s_val + grr * 4) = vb;
-    } else {
-      float qn[5];
-#pragma unroll
-      for (int pi = 0; pi < 5; pi++) qn[pi] = g[pi] != 0xffffffffu ? norm_qual_h(g[pi]) : 0.f;
-      *reinterpret_cast<float4*>(s_qn + grr * 8) = make_float4(qn[0], qn[1], qn[2], qn[3]);
-      s_qn[grr * 8 + 4] = qn[4];
-    }
-    __syncthreads();
-    mcur = mnext;
-    load_cells(mcur, g);
-    mnext = load_meta(tile + 2 * gridDim.x);
-
-#pragma unroll
-    for (int pt = 0; pt < 8; pt++)
-#pragma unroll
-      for (int jt = 0; jt < 2; jt++) acc[pt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    auto gen = [&](auto ksc) {
-      constexpr int ks = decltype(ksc)::value;
-      constexpr int dl = ks >> 1, cb = (ks & 1) * 32;
-      uint16_t* xh = s_x + (ks & 1) * (HTP * HLD);
-      const uint32_t c = cb + kk;
-      const float4 b1v = *reinterpret_cast<const float4*>(s_b1 + c);
-      float4 wq[3];
-#pragma unroll
-      for (int t = 0; t < 3; t++) wq[t] = *reinterpret_cast<const float4*>(s_wq + t * 64 + c);
-#pragma unroll
-      for (int it = 0; it < 4; it++) {
-        const uint32_t rr = arow + it * 32;
-        const uint2 tk = *reinterpret_cast<const uint2*>(s_tok + rr * 8);
-        const uint64_t tk64 = (uint64_t)tk.x | ((uint64_t)tk.y << 32);
-        float4 v = b1v;
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-          const uint32_t tok = (uint32_t)(tk64 >> (8 * (dl + t))) & 0xffu;
-          const float4 tv = *reinterpret_cast<const float4*>(s_t1 + (t * HT1R + tok) * 64 + c);
-          const float qn = s_qn[rr * 8 + dl + t];
-          v.x += tv.x + wq[t].x * qn; v.y += tv.y + wq[t].y * qn; v.z += tv.z + wq[t].z * qn; v.w += tv.w + wq[t].w * qn;
-        }
-        const bool ok = s_val[rr * 4 + dl] != 0;
-        v.x = ok ? fmaxf(v.x, 0.f) : 0.f; v.y = ok ? fmaxf(v.y, 0.f) : 0.f;
-        v.z = ok ? fmaxf(v.z, 0.f) : 0.f; v.w = ok ? fmaxf(v.w, 0.f) : 0.f;
-        const uint32_t o = rr * HLD + hswz(rr, kk >> 3) * 8 + (kk & 7);
-        *reinterpret_cast<uint2*>(xh + o) = make_uint2(pack_h2(v.x, v.y), pack_h2(v.z, v.w));
-      }
-    };
-    auto mm = [&](auto ksc) {
-      constexpr int ks = decltype(ksc)::value;
-      const uint16_t* xh = s_x + (ks & 1) * (HTP * HLD);
-#pragma unroll
-      for (int pt = 0; pt < 8; pt++) {
-        const uint32_t pr = pt * 16 + fr;
-        const half8 bh = *reinterpret_cast<const half8*>(xh + pr * HLD + hswz(pr, fg) * 8);
-#pragma unroll
-        for (int jt = 0; jt < 2; jt++) acc[pt][jt] = mma(wh[ks][jt], bh, acc[pt][jt]);
-      }
-    };
-    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
-    using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
-    using K4 = std::integral_constant<int, 4>; using K5 = std::integral_constant<int, 5>;
-    gen(K0{});
-    __syncthreads();
-    gen(K1{}); mm(K0{}); __syncthreads();
-    gen(K2{}); mm(K1{}); __syncthreads();
-    gen(K3{}); mm(K2{}); __syncthreads();
-    gen(K4{}); mm(K3{}); __syncthreads();
-    gen(K5{}); mm(K4{}); __syncthreads();
-    mm(K5{});
-#pragma unroll
-    for (int pt = 0; pt < 8; pt++) {
-      const uint32_t m = m0 + pt * 16 + fr;
-      float v[8];
-#pragma unroll
-      for (int jt = 0; jt < 2; jt++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) v[jt * 4 + r] = fmaxf(acc[pt][jt][r] + bias8[jt * 4 + r], 0.f);
-      if (m < n_rows)
-        *reinterpret_cast<uint4*>(y2 + (uint64_t)m * HC2 + c0 + 8 * fg) =
-            make_uint4(pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7]));
-    }
-    __syncthreads();
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------
 // k_conv_m — conv1 AND conv2 on the MFMA pipe, chained through registers (round 4).
-// k_conv_h generates conv1 on the vector unit: 1400 VALU instructions per thread and tile for 96 MFMAs (MFMA pipe 14 %
-// busy).  But conv1 of a (token, read row) pair is a tiny GEMM: y1[j][c] = relu(b1[c] + sum_tap T1[tap][tok(j + tap)][c] +
-// wq[tap][c] q(j + tap)) = W1g . a, with a = per tap a one-hot of the cell's token (13 values: 12 tokens + "outside"), the
-// normalised quality and a constant 1 for the bias.  To keep conv1 as exact as the f32 VALU version (the table is not
-// rounded to f16 anywhere today), table, quality weight and bias enter as f16 hi + lo in separate K slots — the one-hot is
-// exact, so hi and lo rows simply add up — and the quality as hi + lo too: 32 slots per tap, K = 96, 3 k-steps:
+// Rounds 2-3 (k_conv_h, deleted) generated conv1 on the vector unit: 1400 VALU instructions per thread and tile of 128 pairs
+// for 96 MFMAs (MFMA pipe 14 % busy, 282 us per 4096 windows; this kernel 198).  But conv1 of a (token, read row) pair is a
+// tiny GEMM: y1[j][c] = relu(b1[c] + sum_tap T1[tap][tok(j + tap)][c] + wq[tap][c] q(j + tap)) = W1g . a, with a = per tap a
+// one-hot of the cell's token (13 values: 12 tokens + "outside"), the normalised quality and a constant 1 for the bias.  To
+// keep conv1 as exact as the f32 VALU version (the table was not rounded to f16 anywhere), table, quality weight and bias
+// enter as f16 hi + lo in separate K slots — the one-hot is exact, so hi and lo rows simply add up — and the quality as
+// hi + lo too: 32 slots per tap, K = 96, 3 k-steps:
 //     slots 0..12 one-hot -> T1 hi | 13 q_hi -> wq hi | 14 q_lo -> wq hi | 15 one -> b1 hi (tap 0) | 16..28 one-hot -> T1 lo |
 //     29 q_hi -> wq lo | 30 unused | 31 one -> b1 lo (tap 0)                       (Weight M.conv1g, built at load)
 // The MFMA's result layout (channel rows, pair columns; two row-interleaved MFMAs give a lane 8 consecutive channels of its
-// pair) IS the B-operand layout of conv2's k-step, so y1 never leaves the registers: a wave takes 32 pairs (two blocks of
-// 16) through conv1 (36 MFMAs per block) and conv2 (48 per block, W2 fragments read once from LDS for both blocks) and
-// stores y2 as 16-byte pieces.  No activation in LDS, no barrier in the loop; the waves of a workgroup only share the 48 KB
-// of conv2 fragments.
+// pair) IS the B-operand layout of conv2's k-step, so y1 never leaves the registers: a wave takes a block of 16 pairs through
+// conv1 (36 MFMAs) and conv2 (48, W2 fragments from LDS) and stores y2 as 16-byte pieces.  No activation in LDS, no barrier in
+// the loop; the waves of a workgroup only share the 48 KB of conv2 fragments and three small tables (one-hot fragments by
+// token, normalised quality by byte).  The five receptive-field rows of a token are resolved once per token (TokCv, written by
+// k_build_tokens_h) and fetched two steps (record) / one step (cells) ahead.  What bounds it (r4 counters, timing variants with
+// cache-hot cells / one fragment, profiles/r4_conv_*): instruction issue — 84 MFMAs against ~340 other instructions per block
+// (a 16-cycle MFMA hides three) — and, for a fifth of the time, the latency of the scattered cell loads; NOT the LDS (28 % busy).
+// A spill of even a few registers triples the time (scratch behind every load): check ScratchSize after any change.
 // ---------------------------------------------------------------------------------------------------
 constexpr int CM_NT = 256;
-constexpr size_t CONV_M_SHM = (size_t)48 * 1024 + 128 * 4 + 32 * 16;
+#ifndef HERRO_CONV_DBG
+#define HERRO_CONV_DBG 0   // timing experiments (wrong results): 1 every wave fetches the same cells, 2 one conv2 fragment for all
+#endif
+constexpr size_t CONV_M_SHM = (size_t)48 * 1024 + 128 * 4 + 32 * 16 + 256 * 4;
 
-__global__ __launch_bounds__(CM_NT, 2) void k_conv_m(ModelDev M, BatchDev B, ModelScratch S, uint32_t n_rows, uint32_t n_units) {
+template <int NB, int WPS>
+__global__ __launch_bounds__(CM_NT, WPS) void k_conv_m(ModelDev M, BatchDev B, ModelScratch S, uint32_t n_rows, uint32_t n_units) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4* s_w2 = reinterpret_cast<uint4*>(smem);                     // conv2 weights in fragment order: fragment f, lane l at [f * 64 + l]
   float* s_b2 = reinterpret_cast<float*>(smem + 48 * 1024);
@@ -331,47 +165,48 @@ __global__ __launch_bounds__(CM_NT, 2) void k_conv_m(ModelDev M, BatchDev B, Mod
   // Two dependent loads (the token's record, then its cells) run two and one unit ahead of the arithmetic.
   struct Raw { uint32_t t[5], q[5]; uint2 q8; };
   struct Cells { uint32_t tok[2], q[2], ok; };   // five token bytes, five quality bytes (0xff: none), validity of the three conv1 positions
-  auto load_meta = [&](uint32_t m) -> TokMeta {
-    return S.tok_meta[min(m, n_rows - 1u) / HERRO_ROWS];
+  auto load_meta = [&](uint32_t m) -> TokCv {
+#if HERRO_CONV_DBG & 1
+    m = lane;   // timing experiment: every wave fetches the same few cells (cache hits)
+#endif
+    return S.tok_cv[min(m, n_rows - 1u) / HERRO_ROWS];
   };
-  auto load_raw = [&](const TokMeta& tm, uint32_t m) -> Raw {
+  auto load_raw = [&](const TokCv& tm, uint32_t m) -> Raw {
     Raw r;
-    const uint32_t rr = min(m, n_rows - 1u) % HERRO_ROWS;
-    const uint8_t* pb = B.planes_b + tm.plane_off + (uint64_t)rr * tm.plane_ld;
+#if HERRO_CONV_DBG & 1
+    m = lane;
+#endif
+    const uint32_t rr = min(m, n_rows - 1u) % HERRO_ROWS, ld = tm.ld_d1 & 0xffffu, trow = tm.row_ok & 0xffffu;
+    const uint8_t* pb = B.planes_b + tm.plane_off + (uint64_t)rr * ld;
     r.q8 = make_uint2(0, 0);
     if (rfq) r.q8 = *reinterpret_cast<const uint2*>(B.rf_q + ((uint64_t)tm.rf_idx * HERRO_ROWS + rr) * 8);
-    const uint8_t* pq = B.planes_q + tm.plane_off + (uint64_t)rr * tm.plane_ld;
+    const uint8_t* pq = B.planes_q + tm.plane_off + (uint64_t)rr * ld;
 #pragma unroll
     for (int i = 0; i < 5; i++) {
-      const int32_t row = min(max((int32_t)tm.tok_row - 2 + i, 0), (int32_t)tm.len - 1);   // clamped: the value is dropped below when the cell is not real
+      const uint32_t row = i < 2 ? (uint32_t)max((int32_t)trow - 2 + i, 0) : trow - 2 + i;   // a row behind the plane's last is read (valid memory) and masked out
       r.t[i] = pb[row];
       r.q[i] = rfq ? 0u : (uint32_t)pq[row];
     }
     return r;
   };
-  auto finish = [&](const Raw& r, const TokMeta& tm, uint32_t m) -> Cells {
+  auto finish = [&](const Raw& r, const TokCv& tm) -> Cells {
     Cells c;
-    uint32_t tk[5], qq[5];
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-      const int32_t row = (int32_t)tm.tok_row - 2 + i;
-      const bool in = m < n_rows && row >= 0 && row < (int32_t)tm.lmax, real = in && row < (int32_t)tm.len;
-      const uint32_t qv = rfq ? ((i < 4 ? r.q8.x >> (8 * i) : r.q8.y) & 0xffu) : r.q[i];
-      tk[i] = real ? r.t[i] : (in ? (uint32_t)TOK_PAD : 12u);
-      qq[i] = real ? qv : (in ? 126u : 0xffu);
-    }
-    c.tok[0] = tk[0] | (tk[1] << 8) | (tk[2] << 16) | (tk[3] << 24); c.tok[1] = tk[4];
-    c.q[0] = qq[0] | (qq[1] << 8) | (qq[2] << 16) | (qq[3] << 24); c.q[1] = qq[4];
-    c.ok = 0;
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      const int32_t pos = (int32_t)tm.tok_row + j - 1;
-      if (m < n_rows && pos >= 0 && pos < (int32_t)tm.lmax) c.ok |= 1u << j;
-    }
+    const uint32_t t0 = r.t[0] | (r.t[1] << 8) | (r.t[2] << 16) | (r.t[3] << 24);
+    const uint32_t q0 = rfq ? r.q8.x : (r.q[0] | (r.q[1] << 8) | (r.q[2] << 16) | (r.q[3] << 24)), q1 = rfq ? r.q8.y : r.q[4];
+    const uint32_t mk1 = tm.row_ok >> 24;
+    c.tok[0] = (t0 & tm.mk0) | tm.dt0; c.tok[1] = (r.t[4] & mk1) | ((tm.ld_d1 >> 16) & 0xffu);
+    c.q[0] = (q0 & tm.mk0) | tm.dq0; c.q[1] = (q1 & mk1) | (tm.ld_d1 >> 24);
+    c.ok = (tm.row_ok >> 16) & 7u;
     return c;
   };
   // one-hot operand fragments by (token, lane parity): lanes fg 0 / 2 hold slots 0..7, lanes fg 1 / 3 slots 8..15 (+ one in slot 15)
   uint4* s_oh = reinterpret_cast<uint4*>(s_b2 + 128);
+  uint32_t* s_ql = reinterpret_cast<uint32_t*>(s_oh + 32);   // quality byte -> normalised quality as f16 hi | lo << 16 (255: no cell -> 0)
+  {
+    uint32_t qh = 0, ql = 0;
+    if (tid < 255) split_h2(norm_qual_h(tid), 0.f, qh, ql);
+    s_ql[tid] = (qh & 0xffffu) | (ql << 16);
+  }
   if (tid < 32) {
     const uint32_t tok = tid >> 1, od = tid & 1u, t = tok - 8u * od;
     uint32_t r[4] = {0, 0, 0, od ? 0x3c000000u : 0u};
@@ -380,27 +215,27 @@ __global__ __launch_bounds__(CM_NT, 2) void k_conv_m(ModelDev M, BatchDev B, Mod
   }
   __syncthreads();
 
-  const uint32_t odd = fg & 1u;
+  const uint32_t odd = fg & 1u, mq_hi = odd ? 0xffffu : 0u, mq_lo = fg == 1u ? 0xffffu : 0u;
   const uint32_t stride = gridDim.x * (CM_NT / 64);
   uint32_t unit = blockIdx.x * (CM_NT / 64) + wave;
-  TokMeta mt1[2], mt2[2];   // records of the pairs of unit + stride, unit + 2 stride
-  Cells cur[2];
-  Raw raw[2];
+  TokCv mt1[NB], mt2[NB];   // records of the pairs of unit + stride, unit + 2 stride
+  Cells cur[NB];
+  Raw raw[NB];
 #pragma unroll
-  for (int b = 0; b < 2; b++) {
-    const TokMeta m0 = load_meta(unit * 32 + b * 16 + fr);
-    cur[b] = finish(load_raw(m0, unit * 32 + b * 16 + fr), m0, unit * 32 + b * 16 + fr);
-    mt1[b] = load_meta((unit + stride) * 32 + b * 16 + fr);
+  for (int b = 0; b < NB; b++) {
+    const TokCv m0 = load_meta(unit * (16 * NB) + b * 16 + fr);
+    cur[b] = finish(load_raw(m0, unit * (16 * NB) + b * 16 + fr), m0);
+    mt1[b] = load_meta((unit + stride) * (16 * NB) + b * 16 + fr);
   }
   for (; unit < n_units; unit += stride) {
 #pragma unroll
-    for (int b = 0; b < 2; b++) {
-      mt2[b] = load_meta((unit + 2 * stride) * 32 + b * 16 + fr);
-      raw[b] = load_raw(mt1[b], (unit + stride) * 32 + b * 16 + fr);
+    for (int b = 0; b < NB; b++) {
+      mt2[b] = load_meta((unit + 2 * stride) * (16 * NB) + b * 16 + fr);
+      raw[b] = load_raw(mt1[b], (unit + stride) * (16 * NB) + b * 16 + fr);
     }
-    half8 y1f[2][6];   // [block][conv2 k-step = position * 2 + slab]
+    half8 y1f[NB][6];   // [block][conv2 k-step = position * 2 + slab]
 #pragma unroll
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < NB; b++) {
       // operand fragments of the five receptive-field rows: lanes fg 0 / 2 slots 0..7 (one-hot of tokens 0..7), lanes fg 1 / 3
       // slots 8..15 (tokens 8..12, q_hi, q_lo | 0, one)
       half8 rf[5];
@@ -409,11 +244,9 @@ __global__ __launch_bounds__(CM_NT, 2) void k_conv_m(ModelDev M, BatchDev B, Mod
         const uint32_t tok = ((i < 4 ? cur[b].tok[0] >> (8 * i) : cur[b].tok[1]) & 0xffu);
         const uint32_t qb = ((i < 4 ? cur[b].q[0] >> (8 * i) : cur[b].q[1]) & 0xffu);
         uint4 r = s_oh[tok * 2u + odd];
-        const float qn = qb != 0xffu ? norm_qual_h(qb) : 0.f;
-        uint32_t qh, ql;
-        split_h2(qn, 0.f, qh, ql);
-        r.z |= odd ? qh << 16 : 0u;                               // slot 13 (29): q_hi
-        r.w |= fg == 1u ? (ql & 0xffffu) : 0u;                    // slot 14: q_lo (30: unused)
+        const uint32_t qhl = s_ql[qb];
+        r.z |= (qhl & mq_hi) << 16;                               // slot 13 (29): q_hi
+        r.w |= (qhl >> 16) & mq_lo;                               // slot 14: q_lo (30: unused)
         rf[i] = as_half8(r.x, r.y, r.z, r.w);
       }
 #pragma unroll
@@ -443,21 +276,21 @@ __global__ __launch_bounds__(CM_NT, 2) void k_conv_m(ModelDev M, BatchDev B, Mod
     uint16_t* y2 = S.y2_hi;
 #pragma unroll
     for (int hs = 0; hs < 2; hs++) {
-      f32x4 a2[2][2][2];   // [block][slab][jt]
+      f32x4 a2[NB][2][2];   // [block][slab][jt]
 #pragma unroll
       for (int sl = 0; sl < 2; sl++)
 #pragma unroll
         for (int jt = 0; jt < 2; jt++) {
           const float4 bv = *reinterpret_cast<const float4*>(s_b2 + (hs * 2 + sl) * 32 + 8 * fg + 4 * jt);
 #pragma unroll
-          for (int b = 0; b < 2; b++) a2[b][sl][jt] = f32x4{bv.x, bv.y, bv.z, bv.w};
+          for (int b = 0; b < NB; b++) a2[b][sl][jt] = f32x4{bv.x, bv.y, bv.z, bv.w};
         }
       half8 wf[2][2], wn[2][2];   // the fragments of one k-step, read one k-step ahead of their MFMAs
       auto rdw = [&](int ks, half8 (&w)[2][2]) {
 #pragma unroll
         for (int sl = 0; sl < 2; sl++)
 #pragma unroll
-          for (int jt = 0; jt < 2; jt++) w[sl][jt] = __builtin_bit_cast(half8, s_w2[((((hs * 2 + sl) * 2 + jt) * 6 + ks) * 64) + lane]);
+          for (int jt = 0; jt < 2; jt++) w[sl][jt] = __builtin_bit_cast(half8, s_w2[(HERRO_CONV_DBG & 2) ? lane : ((((hs * 2 + sl) * 2 + jt) * 6 + ks) * 64) + lane]);
       };
       rdw(0, wf);
       __builtin_amdgcn_sched_barrier(0);
@@ -470,7 +303,7 @@ __global__ __launch_bounds__(CM_NT, 2) void k_conv_m(ModelDev M, BatchDev B, Mod
 #pragma unroll
           for (int jt = 0; jt < 2; jt++)
 #pragma unroll
-            for (int b = 0; b < 2; b++) a2[b][sl][jt] = mma(wf[sl][jt], y1f[b][ks], a2[b][sl][jt]);
+            for (int b = 0; b < NB; b++) a2[b][sl][jt] = mma(wf[sl][jt], y1f[b][ks], a2[b][sl][jt]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int sl = 0; sl < 2; sl++)
@@ -478,8 +311,8 @@ __global__ __launch_bounds__(CM_NT, 2) void k_conv_m(ModelDev M, BatchDev B, Mod
           for (int jt = 0; jt < 2; jt++) wf[sl][jt] = wn[sl][jt];
       }
 #pragma unroll
-      for (int b = 0; b < 2; b++) {
-        const uint32_t m = unit * 32 + b * 16 + fr;
+      for (int b = 0; b < NB; b++) {
+        const uint32_t m = unit * (16 * NB) + b * 16 + fr;
 #pragma unroll
         for (int sl = 0; sl < 2; sl++) {
           float v[8];
@@ -490,8 +323,8 @@ __global__ __launch_bounds__(CM_NT, 2) void k_conv_m(ModelDev M, BatchDev B, Mod
       }
     }
 #pragma unroll
-    for (int b = 0; b < 2; b++) {
-      cur[b] = finish(raw[b], mt1[b], (unit + stride) * 32 + b * 16 + fr);
+    for (int b = 0; b < NB; b++) {
+      cur[b] = finish(raw[b], mt1[b]);
       mt1[b] = mt2[b];
     }
   }
@@ -1465,6 +1298,25 @@ __global__ void k_build_tokens_h(BatchDev B, ModelScratch S) {
     tm.rf_idx = (uint32_t)(B.out_off[b] + (n - t0));
     tm.pad1 = 0;
     S.tok_meta[n] = tm;
+    uint32_t mk[2] = {0, 0}, dt[2] = {0, 0}, dq[2] = {0, 0}, ok = 0;
+    for (int i = 0; i < 5; i++) {
+      const int32_t r = (int32_t)row - 2 + i;
+      const bool in = r >= 0 && r < (int32_t)tm.lmax, real = in && r < (int32_t)tm.len;
+      const uint32_t sh = 8u * (i & 3);
+      if (real) mk[i >> 2] |= 0xffu << sh;
+      else { dt[i >> 2] |= (in ? (uint32_t)TOK_PAD : 12u) << sh; dq[i >> 2] |= (in ? 126u : 0xffu) << sh; }
+    }
+    for (int j = 0; j < 3; j++) {
+      const int32_t pos = (int32_t)row + j - 1;
+      if (pos >= 0 && pos < (int32_t)tm.lmax) ok |= 1u << j;
+    }
+    TokCv cv;
+    cv.plane_off = tm.plane_off;
+    cv.ld_d1 = tm.plane_ld | (dt[1] << 16) | (dq[1] << 24);
+    cv.row_ok = row | (ok << 16) | (mk[1] << 24);
+    cv.rf_idx = tm.rf_idx;
+    cv.mk0 = mk[0]; cv.dt0 = dt[0]; cv.dq0 = dq[0];
+    S.tok_cv[n] = cv;
   }
 }
 
@@ -1473,7 +1325,7 @@ __global__ void k_build_tokens_h(BatchDev B, ModelScratch S) {
 bool model_h_supported(const ModelDev& M) {
   const ModelHyper& h = M.h;
   return h.kw == 3 && h.c1 == 64 && h.c2 == HC2 && h.d_model == 256 && h.n_heads == 8 && h.d_ff % 256 == 0 && h.d_ff <= (uint32_t)PAR_MAX_FF && h.rows == HERRO_ROWS &&
-         M.conv2.h16 && M.fc.h16 && M.heads.h16 && M.heads.l16 && M.layer[0].qkv.ph16;
+         M.conv1g.ph16 && M.conv2.ph16 && M.fc.h16 && M.heads.h16 && M.heads.l16 && M.layer[0].qkv.ph16;
 }
 
 // HERRO_LAYERS_Q: 0 keeps every tile on the 64-token kernel, 2 sends every window of <= 32 rows to k_layers_q (both for A/B);
@@ -1493,15 +1345,17 @@ void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S,
   hipLaunchKernelGGL(k_build_tokens_h, dim3(B.n_win), dim3(64), 0, st, B, S);
   KT_END(tm, st);
   {
-    static const bool conv_m = [] { const char* e = getenv("HERRO_CONV_M"); return !e || atoi(e) != 0; }();   // 0: conv1 on the vector unit (k_conv_h), for the A/B
-    const uint32_t n_rows = N * HERRO_ROWS, n_tiles = (n_rows + HTP - 1) / HTP;
+    const uint32_t n_rows = N * HERRO_ROWS;
     KT_BEGIN(tm, "conv_fused", st);
-    if (conv_m && M.conv1g.ph16) {
+    static const int nb = [] { const char* e = getenv("HERRO_CONV_NB"); return e ? atoi(e) : 1; }();
+    if (nb != 2) {   // one block of 16 pairs per step, three workgroups per compute unit
+      const uint32_t n_units = (n_rows + 15) / 16;
+      opt_in_lds(reinterpret_cast<const void*>(k_conv_m<1, 3>), CONV_M_SHM);
+      hipLaunchKernelGGL((k_conv_m<1, 3>), dim3(std::min<uint32_t>((n_units + 3) / 4, 768u)), dim3(CM_NT), CONV_M_SHM, st, M, B, S, n_rows, n_units);
+    } else {         // HERRO_CONV_NB=2 (A/B): two blocks per step share every read of a conv2 fragment; 226 VGPRs, two workgroups per compute unit
       const uint32_t n_units = (n_rows + 31) / 32;
-      opt_in_lds(reinterpret_cast<const void*>(k_conv_m), CONV_M_SHM);
-      hipLaunchKernelGGL(k_conv_m, dim3(std::min<uint32_t>((n_units + 3) / 4, 512u)), dim3(CM_NT), CONV_M_SHM, st, M, B, S, n_rows, n_units);
-    } else {
-      hipLaunchKernelGGL(k_conv_h, dim3(std::min<uint32_t>(n_tiles, 512u)), dim3(256), CONV_H_SHM, st, M, B, S, n_rows, n_tiles);
+      opt_in_lds(reinterpret_cast<const void*>(k_conv_m<2, 2>), CONV_M_SHM);
+      hipLaunchKernelGGL((k_conv_m<2, 2>), dim3(std::min<uint32_t>((n_units + 3) / 4, 512u)), dim3(CM_NT), CONV_M_SHM, st, M, B, S, n_rows, n_units);
     }
     KT_END(tm, st);
   }
