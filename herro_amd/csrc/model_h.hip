@@ -84,6 +84,24 @@ __device__ __forceinline__ half8 relu_mask_h8(half8 x, uint32_t mask) {
   auto mx = [&](uint32_t v) -> uint32_t { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h2, v), z)) & mask; };
   return __builtin_bit_cast(half8, make_uint4(mx(u.x), mx(u.y), mx(u.z), mx(u.w)));
 }
+// v + (v of lane ^ 16) + (v of lane ^ 32) + (v of lane ^ 48) in every lane, on the vector unit: v_permlane16_swap / v_permlane32_swap
+// (gfx950) exchange rows of 16 / halves of 32 lanes between two registers; with both holding v, their sum is v + shfl_xor(v, 16 / 32).
+// (__shfl_xor compiles to ds_bpermute_b32: a round trip through the LDS crossbar per step, 48 of them per layer in the LayerNorms and
+// the softmax.  The clang builtin of this LLVM returns the same register for both results, hence the asm; tools/probes/permlane_check.hip.)
+__device__ __forceinline__ float fg_sum(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  a += b; b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float fg_max(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  a = fmaxf(a, b); b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
 __device__ __forceinline__ f32x4 mma(half8 a, half8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 __device__ __forceinline__ void glds16_h(const void* gsrc, uint32_t lds_dst) {  // 16 B per lane, global -> LDS, no VGPR staging
@@ -571,7 +589,8 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
     for (uint32_t e = tid; e < 768; e += 512) s_par[PAR_BQKV + e] = L.qkv.bias[e];
     for (uint32_t e = tid; e < d_ff; e += 512) s_par[PAR_BFF1 + e] = L.ff1.bias[e];
   };
-  // LayerNorm over the 256 channels of the register-resident x, two passes (mean, then centred sum of squares)
+  // LayerNorm over the 256 channels of the register-resident x, two passes (mean, then centred sum of squares).  (The one-barrier
+  // form of k_layers_q — per-wave mean and M2 merged exactly — measured no faster here: 726 vs 726 us per 4096 windows.)
   auto layer_norm = [&](uint32_t og, uint32_t ob, const float* __restrict__ gp, const float* __restrict__ bp, bool want_lo) {
     float mean[4], rstd[4];
 #pragma unroll
@@ -579,24 +598,23 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
       float* red = s_red + pass * 8 * HLT;   // separate arrays per pass: one barrier less per LayerNorm
 #pragma unroll
       for (int pt = 0; pt < 4; pt++) {
-        float s = 0.f;
+        float sm = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
           const float d = pass == 0 ? x[pt][q] : x[pt][q] - mean[pt];
-          s += pass == 0 ? d : d * d;
+          sm += pass == 0 ? d : d * d;
         }
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        if (fg == 0) red[wave * HLT + pt * 16 + fr] = s;
+        sm = fg_sum(sm);
+        if (fg == 0) red[wave * HLT + pt * 16 + fr] = sm;
       }
       __syncthreads();
 #pragma unroll
       for (int pt = 0; pt < 4; pt++) {
-        float s = 0.f;
+        float sm = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; w++) s += red[w * HLT + pt * 16 + fr];
-        if (pass == 0) mean[pt] = s / 256.f;
-        else rstd[pt] = 1.0f / sqrtf(s / 256.f + eps);
+        for (int w = 0; w < 8; w++) sm += red[w * HLT + pt * 16 + fr];
+        if (pass == 0) mean[pt] = sm / 256.f;
+        else rstd[pt] = 1.0f / sqrtf(sm / 256.f + eps);
       }
     }
     float gg[8], bb[8];
@@ -664,8 +682,10 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const float ang = __fmul_rn(row, pd[j]);
-          x[pt][2 * j] += sinf(ang);
-          x[pt][2 * j + 1] += cosf(ang);
+          float sn, cs;
+          sincosf(ang, &sn, &cs);   // one range reduction for both
+          x[pt][2 * j] += sn;
+          x[pt][2 * j + 1] += cs;
         }
       }
     }
@@ -740,8 +760,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
             m = fmaxf(m, st[pj][r]);
           }
         }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = fg_max(m);
         float l = 0.f;
 #pragma unroll
         for (int pj = 0; pj < 4; pj++)
@@ -751,8 +770,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
             st[pj][r] = pexp;
             l += pexp;
           }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l = fg_sum(l);
         f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
@@ -802,15 +820,20 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
       for (uint32_t c = 0; c < d_ff; c += 256) {
         RELAUNDER();
         f32x4 a1[4][2];
-        float b1[8];
-        zero(a1);
+        {  // the accumulators start from the bias (the moves that would zero them carry it)
+          float b1[8];
+          lds8(PAR_BFF1 + c + cw + 8 * fg, b1);
+#pragma unroll
+          for (int pt = 0; pt < 4; pt++)
+#pragma unroll
+            for (int jt = 0; jt < 2; jt++) a1[pt][jt] = f32x4{b1[4 * jt], b1[4 * jt + 1], b1[4 * jt + 2], b1[4 * jt + 3]};
+        }
         tile_gemm_p<false, TERMS>(wstream(L.ff1, c + cw, 0, lane), wa, wstream(L.ff2, cw, c, lane), s_hh, s_hl, fr, fg, a1);
-        lds8(PAR_BFF1 + c + cw + 8 * fg, b1);
 #pragma unroll
         for (int pt = 0; pt < 4; pt++) {
           float v[8];
 #pragma unroll
-          for (int q = 0; q < 8; q++) v[q] = fmaxf(a1[pt][q >> 2][q & 3] + b1[q], 0.f);
+          for (int q = 0; q < 8; q++) v[q] = fmaxf(a1[pt][q >> 2][q & 3], 0.f);
           store_act(s_ah, s_al, hlsw(pt * 16 + fr, wave * 4 + fg), v);
         }
         __syncthreads();
@@ -977,16 +1000,13 @@ __global__ __launch_bounds__(256, 2) void k_layers_q(ModelDev M, BatchDev B, Mod
       for (int sl = 0; sl < 2; sl++)
 #pragma unroll
         for (int q = 0; q < 8; q++) s += x[pt][sl][q];
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      const float mw = s * (1.0f / 64.f);
+      const float mw = fg_sum(s) * (1.0f / 64.f);
       float d2 = 0.f;
 #pragma unroll
       for (int sl = 0; sl < 2; sl++)
 #pragma unroll
         for (int q = 0; q < 8; q++) { const float d = x[pt][sl][q] - mw; d2 += d * d; }
-      d2 += __shfl_xor(d2, 16, 64);
-      d2 += __shfl_xor(d2, 32, 64);
+      d2 = fg_sum(d2);
       if (fg == 0) s_red[wave * QLT + pt * 16 + fr] = make_float2(mw, d2);
     }
     __syncthreads();
@@ -1073,8 +1093,10 @@ __global__ __launch_bounds__(256, 2) void k_layers_q(ModelDev M, BatchDev B, Mod
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const float ang = __fmul_rn(row, pd[j]);
-          x[pt][sl][2 * j] += sinf(ang);
-          x[pt][sl][2 * j + 1] += cosf(ang);
+          float sn, cs;
+          sincosf(ang, &sn, &cs);
+          x[pt][sl][2 * j] += sn;
+          x[pt][sl][2 * j + 1] += cs;
         }
       }
     }
@@ -1158,8 +1180,7 @@ __global__ __launch_bounds__(256, 2) void k_layers_q(ModelDev M, BatchDev B, Mod
               m = fmaxf(m, st[pj][r]);
             }
           }
-          m = fmaxf(m, __shfl_xor(m, 16, 64));
-          m = fmaxf(m, __shfl_xor(m, 32, 64));
+          m = fg_max(m);
           float l = 0.f;
           float v[8];
 #pragma unroll
@@ -1168,8 +1189,7 @@ __global__ __launch_bounds__(256, 2) void k_layers_q(ModelDev M, BatchDev B, Mod
             v[e] = pexp;
             l += pexp;
           }
-          l += __shfl_xor(l, 16, 64);
-          l += __shfl_xor(l, 32, 64);
+          l = fg_sum(l);
           const half8 ph = pack_h8(v);
           const float inv = 1.0f / l;
           float ov[8];
