@@ -164,6 +164,9 @@ def main():
     ap.add_argument("--e2e-feeders", type=int, default=4, help="feeder threads (one context each) of the end_to_end leg")
     ap.add_argument("--e2e-jobs", type=int, default=None, help="jobs per feeder thread in the end_to_end leg (default: 6 on one GPU, 0 = skipped on several)")
     ap.add_argument("--self-check", type=int, default=6, help="targets compared with the oracle after the timing (0: skip)")
+    ap.add_argument("--long-run-steps", type=int, default=None,
+                    help="after a SHORT measurement (steps < 64, one GPU) the same device-resident leg is run once more with this many steps in a "
+                         "child process and reported as 'long_run' in the same line (default 256; 0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -198,7 +201,9 @@ def main():
     G = max(1, min(args.group, args.steps // max(1, args.min_jobs)))
     n_full, rem = divmod(args.steps, G)
     NS = max(1, min(args.streams, n_full)) if n_full else 1
-    pool = max(1, min(args.pool, (n_full + NS - 1) // NS if n_full else 1))
+    # distinct jobs per stream, cycled: never fewer than two, so that a short run (the driver's --steps 20 is ONE launch group)
+    # does not time a re-run of the very job that warmed it up — successive passes rotate through the pool
+    pool = max(2 if n_full else 1, min(args.pool, (n_full + NS - 1) // NS if n_full else 1))
     n_jobs = NS * pool
     tpj = G * targets_per_step                                  # targets per job
     NF = max(NS, args.e2e_feeders)                              # feeder threads (= contexts) of the end_to_end leg
@@ -237,12 +242,16 @@ def main():
         j.infer(args.batch, 1)
         j.consensus()      # corrected bases stay in HBM (≈4 KB/window); only they would cross PCIe
 
+    rot = [0]   # launch groups issued so far per stream: the pool is walked on across passes
+
     def run_steps(n_steps):
         """exactly n_steps batches of `batch` windows, launch groups dealt round-robin to the streams"""
         nf, r = divmod(n_steps, G)
+        base = rot[0]
+        rot[0] += (nf + NS - 1) // NS
 
         def worker(s_i):
-            seq = [jobs[s_i][(i // NS) % pool] for i in range(s_i, nf, NS)]
+            seq = [jobs[s_i][(base + i // NS) % pool] for i in range(s_i, nf, NS)]
             if pool < 2:
                 for j in seq:
                     run_job(j)
@@ -508,6 +517,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * el / args.steps,
+            "timed_region_s": el,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -563,14 +573,30 @@ def main():
             out["strong"] = strong
             if isinstance(strong, dict) and "windows_per_s" in strong and out.get("end_to_end"):
                 strong["vs_end_to_end"] = strong["windows_per_s"] / (out["end_to_end"]["windows_per_s"] or 1.0)
+    # ---- a short run's timed region is a millisecond or two: the default-size figure of the same leg goes into the same line
+    lr_steps = 256 if args.long_run_steps is None else args.long_run_steps
+    if rank == 0 and world == 1 and lr_steps > 0 and args.steps < 64:
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(lr_steps), "--warmup", "8", "--no-cpu-baseline", "--self-check", "0", "--e2e-jobs", "0",
+               "--strong-windows", "0", "--repeats", "1", "--long-run-steps", "0", "--precision", str(args.precision), "--batch", str(args.batch)]
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=240)
+            d = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+            out["long_run"] = {k: d[k] for k in ("steps", "warmup", "value", "ms_per_step", "timed_region_s", "repeat_ms_per_step")}
+            out["long_run"]["roofline_frac"] = d["roofline"]["frac"]
+            out["long_run"]["streams_per_gpu"] = d["config"]["streams_per_gpu"]
+        except Exception as e:   # never the measured line
+            out["long_run"] = {"error": repr(e)}
     if rank == 0:
+        out["strong_ok"] = (not strong_failed) if args.strong_windows > 0 else None
         print(json.dumps(out), flush=True)
-    if strong_failed and (world > 1 or strong_hung):
-        # peers may be stuck in a collective of the failed leg, or this process's own worker thread inside a HIP call: leave
-        # without destroy_process_group and without tearing the runtime down under it
+    if strong_failed:
+        # The measured line is out; a broken sharded path must still show in the exit status (3).  Peers may be stuck in a collective of
+        # the failed leg, or this process's own worker thread inside a HIP call: leave without destroy_process_group and without
+        # tearing the runtime down under it.
         sys.stdout.flush()
         sys.stderr.flush()
-        os._exit(0)
+        os._exit(3)
     if world > 1:
         dist.destroy_process_group()
 

@@ -382,6 +382,8 @@ class Job:
         text straight into a numpy buffer; the library's thread pool assembles it).  read_ids: one str/bytes per target.
         with_ends: also the end offset of every target's records.  as_array: the text as a u8 array (no bytes copy)."""
         n = len(read_ids)
+        if n != self.n_targets:   # the library reads one id and writes one end offset per target of the job
+            raise ValueError(f"read_ids has {n} entries, the job has {self.n_targets} targets")
         arr = (C.c_char_p * max(n, 1))(*[r if isinstance(r, bytes) else r.encode() for r in read_ids])
         ends = np.zeros(max(n, 1), np.uint64)
         need = self._l.herro_job_fasta(self.h, arr, None, None, 0, ends.ctypes.data)

@@ -23,6 +23,9 @@
 #include <string.h>
 #include <sys/stat.h>
 
+#include <memory>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <unordered_set>
 #include <vector>
@@ -44,6 +47,7 @@ struct Zlib {
   void* (*gzopen)(const char*, const char*) = nullptr;
   int (*gzread)(void*, void*, unsigned) = nullptr;
   int (*gzclose)(void*) = nullptr;
+  const char* (*gzerror)(void*, int*) = nullptr;
   bool ok = false;
   Zlib() {
     for (const char* n : {"libz.so.1", "libz.so"}) {
@@ -54,7 +58,8 @@ struct Zlib {
     gzopen = (void* (*)(const char*, const char*))dlsym(h, "gzopen");
     gzread = (int (*)(void*, void*, unsigned))dlsym(h, "gzread");
     gzclose = (int (*)(void*))dlsym(h, "gzclose");
-    ok = gzopen && gzread && gzclose;
+    gzerror = (const char* (*)(void*, int*))dlsym(h, "gzerror");
+    ok = gzopen && gzread && gzclose && gzerror;
   }
 };
 
@@ -100,7 +105,12 @@ struct Source {
       } else {
         const int n = zl->gzread(g, &buf[at + have], (unsigned)std::min<size_t>(want - have, 1u << 30));
         if (n < 0) { why = "Error parsing fastx file. (gzip stream)"; buf.resize(at + have); return false; }
-        if (n == 0) eof = true;
+        if (n == 0) {   // end of the stream — or a stream cut short (at a record boundary it would otherwise pass for a clean end: gzread
+          int zerr = 0;  // returns 0 there too, and only gzerror tells: Z_BUF_ERROR = -5, "unexpected end of file")
+          (void)zl->gzerror(g, &zerr);
+          if (zerr != 0 && zerr != 1 /* Z_STREAM_END */) { why = "Error parsing fastx file. (truncated or damaged gzip stream)"; buf.resize(at + have); return false; }
+          eof = true;
+        }
         have += (size_t)n;
       }
     }
@@ -168,21 +178,38 @@ bool write_file(const std::string& path, const std::string& head, const void* bo
 
 extern "C" {
 
+static herro_reads* fastx_read_impl(const char* path, uint32_t min_length, const char* const* keep_ids, uint64_t n_keep, char* err,
+                                    uint64_t err_cap, std::unique_ptr<herro_reads>& guard);
+
 herro_reads* herro_fastx_read(const char* path, uint32_t min_length, const char* const* keep_ids, uint64_t n_keep, char* err,
                               uint64_t err_cap) {
+  std::unique_ptr<herro_reads> guard;   // no exception crosses the C ABI: an allocation failure is an error return
+  try {
+    return fastx_read_impl(path, min_length, keep_ids, n_keep, err, err_cap, guard);
+  } catch (const std::bad_alloc&) {
+    set_err(err, err_cap, "out of memory while reading the reads file");
+  } catch (const std::exception& e) {
+    set_err(err, err_cap, std::string("reads reader: ") + e.what());
+  }
+  return nullptr;
+}
+
+static herro_reads* fastx_read_impl(const char* path, uint32_t min_length, const char* const* keep_ids, uint64_t n_keep, char* err,
+                                    uint64_t err_cap, std::unique_ptr<herro_reads>& guard) {
   if (!path) { set_err(err, err_cap, "null path"); return nullptr; }
   Source src;
   if (!src.open(path)) { set_err(err, err_cap, src.why); return nullptr; }
   std::unordered_set<std::string> keep;
   const bool filter = keep_ids != nullptr;
   for (uint64_t i = 0; filter && i < n_keep; i++) if (keep_ids[i]) keep.insert(keep_ids[i]);
-  auto r = new herro_reads();
+  guard.reset(new herro_reads());
+  herro_reads* r = guard.get();
   r->off.push_back(0);
-  if (src.plain_size) {                   // a FASTQ file is half bases, half qualities: one allocation instead of a doubling series
-    r->seq.reserve(src.plain_size / 2);
+  if (src.plain_size && !filter && min_length <= 1) {   // a FASTQ file is half bases, half qualities: one allocation instead of a doubling series
+    r->seq.reserve(src.plain_size / 2);                  // (not when a filter may drop most of the file: the vectors then grow with what is kept)
     r->qual.reserve(src.plain_size / 2);
   }
-  auto fail = [&](const std::string& m) -> herro_reads* { set_err(err, err_cap, m); delete r; return nullptr; };
+  auto fail = [&](const std::string& m) -> herro_reads* { set_err(err, err_cap, m); guard.reset(); return nullptr; };
   size_t chunk = 32u << 20;
   if (const char* e = getenv("HERRO_FASTX_CHUNK")) chunk = std::max<size_t>(1, (size_t)strtoull(e, nullptr, 10));   // (tests: tiny chunks)
   std::string text, seq, qual;
@@ -263,7 +290,7 @@ herro_reads* herro_fastx_read(const char* path, uint32_t min_length, const char*
     r->id_ptr.push_back(r->ids[i].c_str());
     r->desc_ptr.push_back(r->has_desc[i] ? r->descs[i].c_str() : nullptr);
   }
-  return r;
+  return guard.release();
 }
 
 uint32_t herro_reads_count(const herro_reads* r) { return r ? (uint32_t)r->ids.size() : 0; }

@@ -105,6 +105,15 @@ def test_bench_flow(monkeypatch, capsys, argv, steps, strong_mode):
             hang.wait(30)          # a rank stuck in a receive: the line must go out without the leg
         return {"windows_per_s": 2.0, "windows": 8, "ranks_seen": 1}
     monkeypatch.setattr(shard, "strong_leg", fake_strong)
+    import subprocess
+    spawned = []
+
+    def fake_run(cmd, **kw):   # the default-size leg a short run appends ('long_run'): a child process of the same script
+        spawned.append(cmd)
+        line = json.dumps({"steps": 256, "warmup": 8, "value": 2.0e6, "ms_per_step": 0.064, "timed_region_s": 0.016, "repeat_ms_per_step": [0.064],
+                           "roofline": {"frac": 0.22}, "config": {"streams_per_gpu": 2}})
+        return types.SimpleNamespace(stdout="noise\n" + line + "\n", returncode=0)
+    monkeypatch.setattr(subprocess, "run", fake_run)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--no-cpu-baseline", "--self-check", "0"] + argv)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
@@ -116,9 +125,9 @@ def test_bench_flow(monkeypatch, capsys, argv, steps, strong_mode):
     try:
         bench.main()
     except SystemExit:
-        assert strong_mode == "hangs" and left == [0]     # a stuck leg: the process leaves without tearing the runtime down under it
+        assert strong_mode != "ok" and left == [3]     # a failed or stuck leg: the line is out, the exit status says so, the runtime is not torn down
     hang.set()
-    assert (strong_mode == "hangs") == bool(left)
+    assert (strong_mode != "ok") == bool(left)
     out = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
     assert len(out) == 1, out
     d = json.loads(out[0])
@@ -126,6 +135,11 @@ def test_bench_flow(monkeypatch, capsys, argv, steps, strong_mode):
         assert k in d, k
     if steps is not None:
         assert d["steps"] == steps
+    assert d["timed_region_s"] > 0 and d["strong_ok"] == (strong_mode == "ok")
+    if d["steps"] < 64:   # a short run carries the default-size figure of the same leg
+        assert len(spawned) == 1 and "--long-run-steps" in spawned[0] and d["long_run"]["value"] == 2.0e6 and d["long_run"]["steps"] == 256
+    else:
+        assert not spawned and "long_run" not in d
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["unit"] == "windows/s" and "workload" in d["config"]
     if strong_mode == "ok":
@@ -149,6 +163,11 @@ def test_bench_flow(monkeypatch, capsys, argv, steps, strong_mode):
         if ev == "I":
             assert last.get(jid) == "F"
         last[jid] = ev
+    # a run of at least one full launch group cycles two or more DISTINCT jobs (the timed job is not the one that was just warmed)
+    inferred = [jid for ev, jid in FakeJob.log if ev == "I"]
+    if d["steps"] >= d["config"]["batches_per_launch_group"]:
+        assert len(set(inferred)) >= 2 and d["config"]["distinct_windows_cycled"] >= 2 * d["config"]["batches_per_launch_group"] * 128
+        assert all(a != b for a, b in zip(inferred, inferred[1:])) or d["config"]["streams_per_gpu"] > 1
 
 
 def test_bench_strong_mode_line(monkeypatch, capsys):

@@ -261,13 +261,14 @@ def test_torchscript_archive_to_hip_logits(tmp_path):
 
 
 def test_load_time_precision_choice(tmp_path):
-    """herro_load_model chooses the operand format itself: f16 (mode 4) only when the calibration batch agrees with the
-    bf16x3 mode within 5e-4 and every weight fits the f16 range; herro_model_describe says what happened."""
+    """herro_load_model chooses the operand format itself: f16 (mode 4) only when a pileup-shaped calibration batch agrees with the
+    f32 mode within 5e-4 and every weight fits the f16 range; herro_model_describe says what happened; a model that failed the
+    calibration cannot be put into the f16 modes afterwards (herro_set_precision refuses)."""
     c = api.Context(0)
     path, raw = model_io.default_model_file(G.CACHE)
     c.load_model(path)
     d = c.describe_model()
-    assert "calibration (256 rows)" in d and "receptive field of an informative row: 5 rows" in d, d
+    assert "calibration (256 pileup-shaped rows)" in d and "mode 0, f32" in d and "receptive field of an informative row: 5 rows" in d, d
     assert ("-> mode 4" in d) or ("-> mode 1" in d)
     import re
     err = float(re.search(r"= ([0-9.eE+-]+|inf) -> mode", d).group(1))
@@ -282,4 +283,18 @@ def test_load_time_precision_choice(tmp_path):
     assert "outside the f16 range" in d2 and "precision mode 1" in d2, d2
     with pytest.raises(api.HerroError):
         c.set_precision(4)
+    # a model whose f16 logits drift: weights inside the f16 range, but a final LayerNorm gain that blows the logit scale (and with it
+    # the absolute error) up -> the calibration keeps mode 1, and an explicit request for mode 4 is refused
+    loud = {k: v.copy() for k, v in raw.items()}
+    for k in loud:
+        if k in ("info_head.weight", "base_head.weight"):
+            loud[k] *= 64.0
+    p3 = str(tmp_path / "loud.hrro")
+    model_io.export(loud, model_io.Hyper(), p3)
+    c.load_model(p3)
+    d3 = c.describe_model()
+    if "-> mode 1" in d3:
+        with pytest.raises(api.HerroError, match="refused"):
+            c.set_precision(4)
+        c.set_precision(1)
     c.close()

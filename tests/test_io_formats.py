@@ -81,6 +81,17 @@ def test_read_fastx_rules(tmp_path, monkeypatch, chunk):
         hio.read_fastx(str(bad))
     with pytest.raises(ValueError, match="Cannot open"):
         hio.read_fastx(str(tmp_path / "missing.fastq"))
+    # a gzip stream cut short exactly at a record boundary is an error, not a shorter read set (gzread returns 0 there as at a clean end)
+    import zlib
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    head = co.compress(b"".join(b"@" + h + b"\n" + sq + b"\n+\n" + q + b"\n" for h, sq, q in recs[:2])) + co.flush(zlib.Z_FULL_FLUSH)
+    cut = tmp_path / "cut.fastq.gz"
+    cut.write_bytes(head)                       # two whole records, no end of stream, no trailer
+    with pytest.raises(ValueError, match="truncated or damaged gzip"):
+        hio.read_fastx(str(cut))
+    whole = tmp_path / "whole.fastq.gz"
+    whole.write_bytes(head + co.compress(b"@r9\nACGT\n+\nIIII\n") + co.flush())
+    assert hio.read_fastx(str(whole)).ids == [b"r0", b"r1", b"r9"]
 
 
 def test_features_files_equal_numpy_written(tmp_path):
