@@ -204,6 +204,9 @@ class Context:
         if rc != 0:
             raise HerroError(rc, self._l.herro_last_error(self.h).decode(errors="replace"))
 
+    def last_error(self) -> str:
+        return self._l.herro_last_error(self.h).decode(errors="replace")
+
     def set_stream(self, hip_stream: int | None):
         self._chk(self._l.herro_set_stream(self.h, hip_stream))
 

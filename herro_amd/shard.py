@@ -384,6 +384,10 @@ def hip_corrector(ctxs, window_size: int, batch: int, read_name, group_targets: 
                     a0, a1 = int(aln_off[t0]), int(aln_off[t1])
                     job = ctx.create_job(rids[t0:t1], rows[a0:a1], aln_off[t0:t1 + 1] - aln_off[t0], None, window_size,
                                          cig_blob=cig, cig_off=cig_off[a0:a1])
+                    left_out = job.skipped()   # alignments parse_paf would have dropped: an ingest that hands them over is broken
+                    if left_out != (0, 0):
+                        raise RuntimeError(f"herro_job_create left out {left_out[0]} alignment(s) / {left_out[1]} target(s) of targets "
+                                           f"{int(rids[t0])}..{int(rids[t1 - 1])}: {ctx.last_error()}")
                     job.featurize()
                     if prev is not None:
                         finish(*prev)

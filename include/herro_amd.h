@@ -132,11 +132,13 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
                             uint32_t window_size);
 void herro_job_free(herro_job* job);
 uint32_t herro_job_n_windows(const herro_job* job);
-/* Alignments herro_job_create left out instead of failing the call: what parse_paf itself drops before extract_features
- * sees it (self overlaps, a second alignment of a (query, target) pair — overlaps.rs:175-185) and CIGARs minimap2 never
- * emits that the kernels do not model (a window slice starting with an insertion, consecutive insertion ops);
- * n_targets = targets left without any overlap (> 4000 overlaps in one window).  herro_last_error() describes the first.
- * Inputs on which the reference panics still make herro_job_create return NULL. */
+/* Alignments herro_job_create left out instead of failing the call: exactly what parse_paf itself drops before extract_features
+ * sees it — self overlaps and a second alignment of a (query, target) pair (overlaps.rs:175-185).  Everything else the reference
+ * processes is processed (consecutive insertion ops, an alignment starting inside window 0 with an insertion, any number of
+ * overlaps per window); *n_targets is always 0 since round 3 (no target is dropped any more) and kept for the binding.
+ * herro_last_error() describes the first alignment left out.  Inputs on which the reference panics make herro_job_create
+ * return NULL with the reference's message.  Callers that feed alignments straight from parse_paf / herro_paf_parse never see a
+ * non-zero count; herro_amd/shard.py treats one as an error. */
 int herro_job_skipped(const herro_job* job, uint32_t* n_alignments, uint32_t* n_targets);
 
 /* GPU feature generation for all windows of the job — features.rs:364-580 (filter, accuracy
