@@ -354,11 +354,15 @@ __global__ __launch_bounds__(CM_NT, WPS) void k_conv_m(ModelDev M, BatchDev B, M
 // A and B tiles go global -> LDS by LDS-DMA (3 pieces of 1 KiB per wave and k-step), three 24 KB buffers, counted
 // vmcnt, one barrier per k-step; 72 KB of LDS and <= 128 VGPRs leave room for two workgroups per CU.
 // ---------------------------------------------------------------------------------------------------
-constexpr int FC_TM = 128, FC_TN = 256, FC_NBUF = 3, FC_NP = 3;
+#ifndef HERRO_FC_NBUF
+#define HERRO_FC_NBUF 3
+#endif
+constexpr int FC_TM = 128, FC_TN = 256, FC_NBUF = HERRO_FC_NBUF, FC_NP = 3;
+static_assert(FC_NBUF >= 2 && FC_NBUF <= 5, "wait_vmcnt ladder covers up to three younger tiles");
 constexpr int FC_BS = (FC_TM + FC_TN) * 32;  // u16 elements per buffer
 constexpr size_t FC_H_SHM = (size_t)FC_NBUF * FC_BS * 2;
 
-__global__ __launch_bounds__(512, 4) void k_fc_h(const uint16_t* __restrict__ A, uint32_t lda, Weight W, float* C, uint32_t ldc, uint32_t M) {
+__global__ __launch_bounds__(512, FC_NBUF <= 3 ? 4 : 2) void k_fc_h(const uint16_t* __restrict__ A, uint32_t lda, Weight W, float* C, uint32_t ldc, uint32_t M) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem_fc[];
   uint16_t* s_raw = reinterpret_cast<uint16_t*>(smem_fc);
   const uint32_t K = W.K;
@@ -416,13 +420,16 @@ __global__ __launch_bounds__(512, 4) void k_fc_h(const uint16_t* __restrict__ A,
     }
   };
   const uint32_t nk = K / 32;
-  stage(0, 0);
-  if (nk > 1) stage(1, 1);
-  uint32_t buf = 0, nbuf = 2;
+  // tiles run FC_NBUF - 1 k-steps ahead of the MFMAs that read them
+#pragma unroll
+  for (int d = 0; d < FC_NBUF - 1; d++) if ((uint32_t)d < nk) stage(d, d);
+  uint32_t buf = 0, nbuf = FC_NBUF - 1;
   for (uint32_t k = 0; k < nk; k++) {
-    if (k + 1 < nk) wait_vmcnt_h<FC_NP>(); else wait_vmcnt_h<0>();  // this wave's pieces of tile k have landed ...
+    // this wave's pieces of tile k have landed: at most the younger tiles' pieces are still in flight
+    const uint32_t younger = min(nk - 1 - k, (uint32_t)FC_NBUF - 2);
+    if (younger >= 3) wait_vmcnt_h<3 * FC_NP>(); else if (younger == 2) wait_vmcnt_h<2 * FC_NP>(); else if (younger == 1) wait_vmcnt_h<FC_NP>(); else wait_vmcnt_h<0>();
     __builtin_amdgcn_s_barrier();                                   // ... everybody's have; tile k-1 is no longer read
-    if (k + 2 < nk) stage(k + 2, nbuf);
+    if (k + FC_NBUF - 1 < nk) stage(k + FC_NBUF - 1, nbuf);
     compute(buf);
     buf = buf == FC_NBUF - 1 ? 0 : buf + 1;
     nbuf = nbuf == FC_NBUF - 1 ? 0 : nbuf + 1;
@@ -438,6 +445,126 @@ __global__ __launch_bounds__(512, 4) void k_fc_h(const uint16_t* __restrict__ A,
         if (m < M) C[(uint64_t)m * ldc + n] = acc[i][j][r] + bs[j];
       }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_fc_r — the same GEMM with the weights streamed L2 -> registers in fragment order (round 4).
+// What k_fc_h's counters and depth experiments said (r4): a k-step costs ~1.4 us where its MFMAs need 0.25; deeper LDS-DMA prefetch
+// with one workgroup per CU is SLOWER (208 / 201 us against 182 with three buffers and two workgroups): the time is the fixed
+// cost of a k-step — three LDS-DMA pieces per wave (100-185 cycles of issue each beside MFMAs and ds_reads), eight ds_reads, the
+// barrier.  Here the weights (the same for every workgroup, L2-resident) never touch the LDS: a wave owns 32 output columns of all
+// 128 rows, its two fragments per k-step come straight from Weight::ph16 into registers one macro-step ahead; only the
+// activation tile goes through the LDS, by plain loads (one macro-step ahead, in registers) and ds_write_b128 — one barrier
+// per 64 k.  Per 64 k and wave: 32 MFMAs, 16 ds_read_b128, 4 fragment loads, 2 row loads + 2 ds_writes.
+// ---------------------------------------------------------------------------------------------------
+constexpr int FR_TM = 128;
+constexpr size_t FC_R_SHM = (size_t)2 * FR_TM * 64 * 2;   // two buffers [128 rows][64 k] f16
+
+__global__ __launch_bounds__(512, 4) void k_fc_r(const uint16_t* __restrict__ A, uint32_t lda, Weight W, float* C, uint32_t ldc, uint32_t M) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_fc[];
+  uint16_t* s_a = reinterpret_cast<uint16_t*>(smem_fc);   // [2][128][64]: row r at r * 128 B, 16-byte chunk c at (c ^ (r & 7))
+  const uint32_t nks = W.K >> 5, nms = W.K >> 6;
+  const uint32_t m0 = blockIdx.x * FR_TM;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t fr = lane & 15, fg = lane >> 4;
+  f32x4 acc[8][2];
+#pragma unroll
+  for (int pt = 0; pt < 8; pt++)
+#pragma unroll
+    for (int jt = 0; jt < 2; jt++) acc[pt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // activation rows: thread t stages row (t >> 2), 16-byte chunks (t & 3) and (t & 3) + 4 of every 64-k tile
+  const uint32_t srow = tid >> 2, sch = tid & 3;
+  const uint16_t* ga = A + (uint64_t)min(m0 + srow, M - 1) * lda + sch * 8;
+  const uint32_t sdst0 = srow * 64 + ((sch ^ (srow & 7u)) << 3), sdst1 = srow * 64 + (((sch + 4) ^ (srow & 7u)) << 3);
+  // weights: fragment (jt, ks) of this wave's 32-column slab
+  const uint16_t* gw = W.ph16 + ((uint64_t)(wave * 2) * nks * 64 + lane) * 8;
+  auto wfrag = [&](uint32_t jt, uint32_t ks) -> half8 { return *reinterpret_cast<const half8*>(gw + (uint64_t)(jt * nks + ks) * 512); };
+  half8 wr[2][2];       // ring: k-step & 1 (a slot is refilled with the k-step 2 ahead as soon as its MFMAs are issued)
+  uint4 as0, as1;       // the activation tile of the next macro-step, in flight
+  auto load_a = [&](uint32_t ms, uint4& r0, uint4& r1) {
+    r0 = *reinterpret_cast<const uint4*>(ga + (uint64_t)ms * 64);
+    r1 = *reinterpret_cast<const uint4*>(ga + (uint64_t)ms * 64 + 32);
+  };
+  auto put_a = [&](uint32_t buf, const uint4& r0, const uint4& r1) {
+    *reinterpret_cast<uint4*>(s_a + buf * (FR_TM * 64) + sdst0) = r0;
+    *reinterpret_cast<uint4*>(s_a + buf * (FR_TM * 64) + sdst1) = r1;
+  };
+  // a quarter k-step = 2 row blocks x 2 column blocks = 4 MFMAs; the fragments of the next quarter are read under them
+  auto rd = [&](uint32_t buf, uint32_t kk, uint32_t g, half8 (&x)[2]) {
+    const uint16_t* t = s_a + buf * (FR_TM * 64);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const uint32_t r = (g * 2 + i) * 16 + fr;
+      x[i] = *reinterpret_cast<const half8*>(t + r * 64 + (((kk * 4 + fg) ^ (r & 7u)) << 3));
+    }
+  };
+  auto mm = [&](uint32_t g, const half8 (&x)[2], const half8 (&w)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int jt = 0; jt < 2; jt++) acc[g * 2 + i][jt] = mma(w[jt], x[i], acc[g * 2 + i][jt]);
+  };
+  // prologue: tile 0 into LDS, tile 1 in flight, weights of k-steps 0, 1
+  {
+    uint4 t0, t1;
+    load_a(0, t0, t1);
+    load_a(min(1u, nms - 1), as0, as1);
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+      for (int jt = 0; jt < 2; jt++) wr[k][jt] = wfrag(jt, min((uint32_t)k, nks - 1));
+    put_a(0, t0, t1);
+  }
+  for (uint32_t ms = 0; ms < nms; ms += 2) {   // nms is even (K % 128 == 0)
+#pragma unroll
+    for (int u = 0; u < 2; u++) {   // macro-step ms + u reads buffer u; its successor's tile arrives in as0 / as1
+      const uint32_t s_ = ms + u;
+      // tile s_ is complete, buffer (u + 1) & 1 is no longer read.  NOT __syncthreads(): its fence waits for vmcnt(0) — every
+      // weight fragment and activation row in flight — at each of the 62 barriers, which is the latency the prefetch is there to hide.
+      // Everything below is unconditional (indices clamped; the last tile is written once more into the buffer nobody reads): with
+      // branches in the loop the compiler's wait-count bookkeeping falls back to vmcnt(0) in front of the first use of a load.
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      half8 x[2], xn[2];
+      rd(u, 0, 0, x);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 8; q++) {   // q = 4 kk + g
+        if (q < 7) rd(u, (q + 1) >> 2, (q + 1) & 3, xn);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(q & 3, x, wr[q >> 2]);
+        __builtin_amdgcn_sched_barrier(0);
+        if ((q & 3) == 3) {   // the k-step's fragments have been issued: the slot takes the k-step 2 ahead
+          const uint32_t kn = min(s_ * 2 + (q >> 2) + 2, nks - 1);
+#pragma unroll
+          for (int jt = 0; jt < 2; jt++) wr[q >> 2][jt] = wfrag(jt, kn);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (q == 5) {   // the next tile (in flight since the previous macro-step) goes into the other buffer; its successor is requested
+          put_a((u + 1) & 1, as0, as1);
+          __builtin_amdgcn_sched_barrier(0);
+          load_a(min(s_ + 2, nms - 1), as0, as1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) x[i] = xn[i];
+      }
+    }
+  }
+  float bs[8];
+  {
+    const float* bp = W.bias + wave * 32 + 8 * fg;
+#pragma unroll
+    for (int q = 0; q < 8; q++) bs[q] = W.bias ? bp[q] : 0.f;
+  }
+#pragma unroll
+  for (int pt = 0; pt < 8; pt++) {
+    const uint32_t m = m0 + pt * 16 + fr;
+    if (m < M) {
+      float* cp = C + (uint64_t)m * ldc + wave * 32 + 8 * fg;
+      *reinterpret_cast<float4*>(cp) = make_float4(acc[pt][0][0] + bs[0], acc[pt][0][1] + bs[1], acc[pt][0][2] + bs[2], acc[pt][0][3] + bs[3]);
+      *reinterpret_cast<float4*>(cp + 4) = make_float4(acc[pt][1][0] + bs[4], acc[pt][1][1] + bs[5], acc[pt][1][2] + bs[6], acc[pt][1][3] + bs[7]);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1379,9 +1506,14 @@ void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S,
     }
     KT_END(tm, st);
   }
-  opt_in_lds(reinterpret_cast<const void*>(k_fc_h), FC_H_SHM);
   KT_BEGIN(tm, "fc_gemm", st);
-  hipLaunchKernelGGL(k_fc_h, dim3((N + FC_TM - 1) / FC_TM), dim3(512), FC_H_SHM, st, S.y2_hi, HERRO_ROWS * h.c2, M.fc, S.x, h.d_model, N);
+  static const bool fc_r = [] { const char* e = getenv("HERRO_FC_R"); return !e || atoi(e) != 0; }();   // 0: weights through the LDS by LDS-DMA (k_fc_h), for the A/B
+  if (fc_r && M.fc.ph16 && M.fc.K % 128 == 0 && h.d_model == 256) {
+    hipLaunchKernelGGL(k_fc_r, dim3((N + FR_TM - 1) / FR_TM), dim3(512), FC_R_SHM, st, S.y2_hi, HERRO_ROWS * h.c2, M.fc, S.x, h.d_model, N);
+  } else {
+    opt_in_lds(reinterpret_cast<const void*>(k_fc_h), FC_H_SHM);
+    hipLaunchKernelGGL(k_fc_h, dim3((N + FC_TM - 1) / FC_TM), dim3(512), FC_H_SHM, st, S.y2_hi, HERRO_ROWS * h.c2, M.fc, S.x, h.d_model, N);
+  }
   KT_END(tm, st);
   KT_BEGIN(tm, "layers_fused", st);   // one span: the 64-token tiles (windows of 33..64 informative rows and what shares their tiles), then the 32-token ones
   if (B.n_tiles) {
