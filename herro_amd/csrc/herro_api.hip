@@ -249,6 +249,12 @@ struct herro_job {
   uint32_t* h_counts = nullptr;      // pinned
   hipEvent_t ev_counts = nullptr;    // featurize + the copy of the counts finished
   uint64_t logit_cap = 0;
+  // herro_job_featurize gathers the receptive-field qualities right behind its kernels, in front of the host's count of the informative
+  // rows (device prefix, buffer sized by an estimate): the host then plans the batches while k_rfq runs, instead of the GPU idling
+  bool rfq_spec = false;            // ... done for this pass, with rf_half = rfq_spec_half and room for rfq_spec_cap rows
+  uint32_t rfq_spec_half = 0;
+  uint64_t rfq_spec_cap = 0;
+  Arena a_supoff_dev{};             // u64[n_win + 1] written by k_supoff
   bool consensus_done = false, consensus_on_host = false;
   uint32_t* h_cons_len = nullptr;   // pinned (inside the host arena): landing zone of the corrected bases
   uint8_t* h_cons_seq = nullptr;
@@ -257,6 +263,7 @@ struct herro_job {
 };
 
 static int job_sync(herro_job* job);
+static int ensure_logits(herro_job* job, uint64_t rows);
 
 // CPUs the process may actually use: the hardware threads, capped by a cgroup CPU quota when there is one (v2 cpu.max,
 // v1 cpu.cfs_quota_us).  A container that shows 256 hardware threads under a 16-CPU quota must not get a 64-thread pool:
@@ -1540,6 +1547,7 @@ void herro_job_free(herro_job* job) {
   small_release(ctx, job->a_logits);
   small_release(ctx, job->a_bdesc);
   small_release(ctx, job->a_supoff);
+  small_release(ctx, job->a_supoff_dev);
   if (job->ev_counts) (void)hipEventDestroy(job->ev_counts);
   if (job->ev_blob) (void)hipEventDestroy(job->ev_blob);
   delete job;
@@ -1564,6 +1572,24 @@ int herro_job_featurize(herro_job* job) {
   HIP_TRY(ctx, hipMemcpyAsync(job->h_counts, job->d_counts, (uint64_t)job->J.n_win * 12, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(job->ev_counts, ctx->stream));
   job->featurized = true;
+  // The model's receptive-field qualities, gathered NOW (k_rfq needs the informative rows and their job-level slots — a device
+  // prefix — not the batch plan): by the time the host has the counts and has planned the batches, the GPU is through this
+  // kernel instead of having waited for the plan.  The buffer is sized by the job's previous pass or by an estimate; if the
+  // count turns out larger, herro_job_infer gathers again.  HERRO_RFQ_EARLY=0: gather in herro_job_infer (A/B).
+  job->rfq_spec = false;
+  static const bool early = [] { const char* e = getenv("HERRO_RFQ_EARLY"); return !e || atoi(e) != 0; }();
+  const uint32_t rf_half = ctx->has_model ? 2 * (ctx->M.h.kw / 2) : 0;
+  if (early && ctx->has_model && 2 * rf_half + 1 <= 8) {
+    const uint32_t n = job->J.n_win;
+    if (!job->a_supoff_dev.p) job->a_supoff_dev = small_acquire(ctx, ((uint64_t)n + 1) * 8);
+    const uint64_t want = job->logit_cap > 1 ? job->logit_cap : (uint64_t)n * 24;   // ~15 informative rows per window at the bench workload
+    if (job->a_supoff_dev.p && ensure_logits(job, want) == HERRO_OK) {
+      launch_supoff(job->J, (uint64_t*)job->a_supoff_dev.p, ctx->stream);
+      launch_rf_quals(job->J, rf_half, (const uint64_t*)job->a_supoff_dev.p, job->d_rfq, job->logit_cap, ctx->stream, &ctx->timer);
+      HIP_TRY(ctx, hipGetLastError());
+      job->rfq_spec = true; job->rfq_spec_half = rf_half; job->rfq_spec_cap = job->logit_cap;
+    }
+  }
   return HERRO_OK;
 }
 
@@ -1589,6 +1615,22 @@ static int job_sync(herro_job* job) {
   return HERRO_OK;
 }
 
+// logits + compact receptive-field qualities of the job: room for `rows` informative rows (grow-only; a change waits for the stream)
+static int ensure_logits(herro_job* job, uint64_t rows) {
+  herro_ctx* ctx = job->ctx;
+  if (job->d_info && job->logit_cap >= rows) return HERRO_OK;
+  if (job->d_info) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); small_release(ctx, job->a_logits); job->d_info = job->d_base = nullptr; }
+  job->logit_cap = std::max<uint64_t>(rows + rows / 8, 1);
+  const uint64_t o_base = (job->logit_cap * 4 + 255) & ~(uint64_t)255, o_rfq = (o_base + job->logit_cap * 20 + 255) & ~(uint64_t)255;
+  job->a_logits = small_acquire(ctx, o_rfq + job->logit_cap * HERRO_ROWS * 8 + 256);
+  if (!job->a_logits.p) { ctx->err = "out of device memory for the logits"; return HERRO_E_NO_DEVICE; }
+  job->d_info = (float*)job->a_logits.p;
+  job->d_base = (float*)((unsigned char*)job->a_logits.p + o_base);
+  job->d_rfq = (uint8_t*)job->a_logits.p + o_rfq;
+  job->rfq_spec = false;   // whatever was gathered lived in the old block
+  return HERRO_OK;
+}
+
 extern "C" {
 
 int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
@@ -1602,16 +1644,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   const uint32_t n = job->J.n_win;
   const uint64_t total_sup = job->sup_off[n];
   if (total_sup > 0xffffffffull / HERRO_ROWS) { ctx->err = "job too large (informative rows x 31 exceed 2^32: TokMeta::rf_idx is a 32-bit job-level index)"; return HERRO_E_UNSUPPORTED; }
-  if (!job->d_info || job->logit_cap < total_sup) {
-    if (job->d_info) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); small_release(ctx, job->a_logits); job->d_info = job->d_base = nullptr; }
-    job->logit_cap = std::max<uint64_t>(total_sup + total_sup / 8, 1);
-    const uint64_t o_base = (job->logit_cap * 4 + 255) & ~(uint64_t)255, o_rfq = (o_base + job->logit_cap * 20 + 255) & ~(uint64_t)255;
-    job->a_logits = small_acquire(ctx, o_rfq + job->logit_cap * HERRO_ROWS * 8 + 256);
-    if (!job->a_logits.p) { ctx->err = "out of device memory for the logits"; return HERRO_E_NO_DEVICE; }
-    job->d_info = (float*)job->a_logits.p;
-    job->d_base = (float*)((unsigned char*)job->a_logits.p + o_base);
-    job->d_rfq = (uint8_t*)job->a_logits.p + o_rfq;
-  }
+  if ((rc = ensure_logits(job, total_sup))) return rc;
   // ---- plan batches (prepare_examples, inference.rs:241-250; flush rule features.rs:884-893)
   job->batches.clear();
   auto flush = [&](std::vector<uint32_t>& cur) {
@@ -1732,8 +1765,9 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   // the qualities the model will read: rows within 2 * (kw / 2) of an informative row (two stacked convs)
   const uint32_t rf_half = 2 * (ctx->M.h.kw / 2);
   const bool rf_compact = !job->quals_full && job->d_rfq && 2 * rf_half + 1 <= 8;   // the model reads the compact receptive fields; else the planes
-  if (!job->quals_full && !groups.empty())
-    launch_rf_quals(job->J, rf_half, job->d_supoff_blob, rf_compact ? job->d_rfq : nullptr, ctx->stream, &ctx->timer);
+  const bool rfq_there = job->rfq_spec && rf_compact && job->rfq_spec_half == rf_half && job->rfq_spec_cap >= total_sup;   // gathered behind featurize
+  if (!job->quals_full && !groups.empty() && !rfq_there)
+    launch_rf_quals(job->J, rf_half, job->d_supoff_blob, rf_compact ? job->d_rfq : nullptr, job->logit_cap, ctx->stream, &ctx->timer);
   for (const Offs& o : offs) {
     const unsigned char* base = (const unsigned char*)job->d_bdesc;
     BatchDev B{};

@@ -159,7 +159,9 @@ struct KernelTimer {
 void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm);
 // qualities inside the model's receptive fields (rows within `half` of an informative row)
 // rf_q != null: compact layout [(sup_off[w] + k) * 31 + column][8] (needs 2 * half + 1 <= 8), else into the quality planes
-void launch_rf_quals(const JobDev& J, uint32_t half, const uint64_t* sup_off, uint8_t* rf_q, hipStream_t st, KernelTimer* tm);
+// cap: informative rows rf_q has room for (a window whose slots would lie beyond it is left out: launches in front of the host's count)
+void launch_rf_quals(const JobDev& J, uint32_t half, const uint64_t* sup_off, uint8_t* rf_q, uint64_t cap, hipStream_t st, KernelTimer* tm);
+void launch_supoff(const JobDev& J, uint64_t* sup_off, hipStream_t st);   // sup_off[0 .. n_win]: prefix of win_nsup
 // the complete quality planes (featurize itself only writes tokens)
 void launch_full_quals(const JobDev& J, hipStream_t st);
 void launch_consensus(const JobDev& J, const uint64_t* sup_off, const float* base_logits, hipStream_t st, KernelTimer* tm);

@@ -1321,12 +1321,12 @@ __global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half, const 
 // 17.7 x the output in HBM traffic; r2 scattered single bytes over the quality planes.)
 constexpr int RQ_NT = 256;
 
-__global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const uint64_t* __restrict__ sup_off, uint8_t* __restrict__ rf_q) {
+__global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const uint64_t* __restrict__ sup_off, uint8_t* __restrict__ rf_q, uint64_t cap) {
   __shared__ __attribute__((aligned(16))) CTab s_ct[32];
   const uint32_t w = blockIdx.x, tid = threadIdx.x, nw = J.nw;
   PROF_BEGIN(J);
   const uint32_t nsup = J.win_nsup[w], Lf = J.win_Lf[w];
-  if (!nsup) return;
+  if (!nsup || sup_off[w] + nsup > cap) return;   // (a launch in front of the host's count of the informative rows: the buffer was sized by an estimate)
   const WinDesc wd = J.win[w];
   if (tid < 32) s_ct[tid] = J.ctab[(uint64_t)w * 32 + tid];
   __syncthreads();
@@ -1495,11 +1495,27 @@ void launch_consensus(const JobDev& J, const uint64_t* sup_off, const float* bas
   KT_END(tm, st);
 }
 
-void launch_rf_quals(const JobDev& J, uint32_t half, const uint64_t* sup_off, uint8_t* rf_q, hipStream_t st, KernelTimer* tm) {
+// sup_off[w] = informative rows of the windows in front of w (n_win + 1 entries): the job-level slot of a window's first row
+__global__ __launch_bounds__(256) void k_supoff(JobDev J, uint64_t* __restrict__ sup_off) {
+  __shared__ uint32_t s_wave[4];
+  const uint32_t n = J.n_win, tid = threadIdx.x, ch = (n + 255) / 256;
+  const uint32_t w0 = min(tid * ch, n), w1 = min(w0 + ch, n);
+  uint32_t local = 0;
+  for (uint32_t w = w0; w < w1; w++) local += J.win_nsup[w];
+  uint32_t tot;
+  uint64_t run = blk_scan<256>(local, &tot, s_wave);
+  for (uint32_t w = w0; w < w1; w++) { sup_off[w] = run; run += J.win_nsup[w]; }
+  if (tid == 0) sup_off[n] = tot;
+}
+void launch_supoff(const JobDev& J, uint64_t* sup_off, hipStream_t st) {
+  if (J.n_win) hipLaunchKernelGGL(k_supoff, dim3(1), dim3(256), 0, st, J, sup_off);
+}
+
+void launch_rf_quals(const JobDev& J, uint32_t half, const uint64_t* sup_off, uint8_t* rf_q, uint64_t cap, hipStream_t st, KernelTimer* tm) {
   if (!J.n_win) return;
   KT_BEGIN(tm, "rf_quals", st);
   if (rf_q && 2 * half + 1 <= 8) {
-    hipLaunchKernelGGL(k_rfq, dim3(J.n_win), dim3(RQ_NT), 0, st, J, half, sup_off, rf_q);
+    hipLaunchKernelGGL(k_rfq, dim3(J.n_win), dim3(RQ_NT), 0, st, J, half, sup_off, rf_q, cap);
     KT_END(tm, st);
     return;
   }
