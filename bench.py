@@ -151,6 +151,9 @@ def main():
     ap.add_argument("--strong-windows", type=int, default=32768,
                     help="size of the fixed job of the 'strong' leg that follows the weak measurement (the sharded data path: rank 0 ingests, "
                          "scatter / gather; BASELINE configs[3] uses 100000 — its read set takes ~30 GB of host memory); 0: skip")
+    ap.add_argument("--strong-ingest", choices=["local", "rank0"], default="local",
+                    help="'local': every rank holds its own share of the parsed alignments and one all-to-all takes targets to their owners "
+                         "(scales); 'rank0': rank 0 ingests everything and scatters the work (the literal north_star path)")
     ap.add_argument("--strong-timeout", type=float, default=420.0, help="seconds the 'strong' leg may take before the line goes out without it")
     ap.add_argument("--settle", type=float, default=0.2, help="seconds of untimed steps on top of --warmup before the timed pass")
     ap.add_argument("--repeats", type=int, default=3, help="further timed passes of the same K steps after the measured one (spread only)")

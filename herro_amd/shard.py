@@ -15,7 +15,12 @@ replicated (one broadcast per data set); target reads are partitioned statically
 """
 from __future__ import annotations
 
+import ctypes
+import os
+
 import numpy as np
+
+ctypes_u8 = ctypes.c_uint8
 
 
 def partition_targets(n_windows_per_target: np.ndarray, world_size: int) -> list[np.ndarray]:
@@ -353,6 +358,184 @@ def correct_sharded(sb, n_windows_per_target, correct_fn, group=None):
     return merge_records([unpack_records(g) for g in gathered]), len(rids)
 
 
+# =====================================================================================================================
+# Per-rank ingestion (round 4): no rank parses or ships the whole alignment set.
+#
+# correct_sharded above is the literal north_star path (rank 0 ingests, scatters) and cannot scale: 13 KB of CIGAR text per
+# window leave one process.  Here every rank INGESTS ITS OWN SHARE of the alignments — a line-aligned byte range of the PAF
+# (paf_byte_range + ingest_paf_range), or its own batch files — and keeps what it owns: a target read belongs to rank
+# owner_of(rid) (a hash of its id; all windows of a read must meet on one rank: features.rs:462-500, consensus.rs:249).  What a rank has read of
+# targets it does not own goes to their owners in ONE all-to-all of packed work messages (the path's only real exchange step:
+# a share of the file is not a share of the targets); the owner merges the pieces in file order and applies parse_paf's rule
+# for a second alignment of a (query, target) pair across pieces (overlaps.rs:175-185: the first one stays).  Rank 0 sends
+# (world - 1) / world of ITS OWN share and nothing else; the read store is still replicated by one broadcast.
+# =====================================================================================================================
+def owner_of(rids, world: int) -> np.ndarray:
+    """The rank a target read belongs to: a multiplicative hash of its id (read ids often come in strides — every k-th read a
+    target — which a plain `rid % world` would send to one rank)."""
+    h = (np.asarray(rids, np.uint64) * np.uint64(0x9E3779B1)) & np.uint64(0xffffffff)
+    return ((h >> np.uint64(8)) % np.uint64(max(world, 1))).astype(np.int64)
+
+
+class _Share:
+    """The arrays shard_arrays / shard_work / work_size read from a data set: tgt_rid, tgt_aln_off, aln, cig_off, cig."""
+
+    def __init__(self, rids, aln_off, rows, cig_off, cig):
+        self.tgt_rid = np.asarray(rids, np.uint32)
+        self.tgt_aln_off = np.asarray(aln_off, np.uint64)
+        self.aln = np.asarray(rows, np.uint32).reshape(-1, 10)
+        self.cig_off = np.asarray(cig_off, np.uint64)
+        self.cig = np.asarray(cig, np.uint8)
+
+
+def paf_byte_range(path: str, rank: int, world: int) -> np.ndarray:
+    """This rank's line-aligned share of a PAF file: from the first line that starts at or behind size * rank / world up to the
+    first line that starts at or behind size * (rank + 1) / world.  Every line belongs to exactly one rank."""
+    size = os.path.getsize(path)
+
+    def line_start(pos):   # first line start >= pos
+        if pos <= 0:
+            return 0
+        if pos >= size:
+            return size
+        with open(path, "rb") as f:
+            f.seek(pos - 1)
+            while True:
+                b = f.read(1 << 16)
+                if not b:
+                    return size
+                k = b.find(b"\n")
+                if k >= 0:
+                    return f.tell() - len(b) + k + 1
+    lo, hi = line_start(size * rank // world), line_start(size * (rank + 1) // world)
+    return np.fromfile(path, np.uint8, count=hi - lo, offset=lo)
+
+
+def ingest_paf_range(text: np.ndarray, names) -> _Share:
+    """herro_paf_parse_view over this rank's bytes (no copy of the text: the CIGARs stay where they are) -> the share's arrays.
+    `names`: api.NameIndex (built once per read set) or the list of read ids."""
+    from herro_amd import api
+    own = None
+    if not isinstance(names, api.NameIndex):
+        names = own = api.NameIndex(names)
+    buf = np.ascontiguousarray(text, np.uint8)
+    paf = api.Paf(names, text=bytes(buf), view=True) if len(buf) else None   # (ctypes wants a bytes object to point into; Paf keeps it alive)
+    if paf is None or paf.n_alns == 0:
+        if own is not None:
+            own.close()
+        return _Share(np.zeros(0, np.uint32), np.zeros(1, np.uint64), np.zeros((0, 10), np.uint32), np.zeros(0, np.uint64), np.zeros(0, np.uint8))
+    m = paf.n_alns
+    raw = np.ctypeslib.as_array((ctypes_u8 * (m * 48)).from_address(paf._alns_ptr)).view(np.uint32).reshape(m, 12)   # herro_alignment: 10 u32 + a pointer
+    rows = raw[:, :10].copy()
+    ptr = raw[:, 10:12].copy().view(np.uint64).reshape(m)
+    base = ptr.min()
+    lens = rows[:, 9].astype(np.uint64)
+    end = int((ptr + lens).max() - base)
+    blob = np.ctypeslib.as_array((ctypes_u8 * end).from_address(int(base))).copy()   # the stretch of text the CIGARs lie in
+    sh = _Share(paf.targets, paf.aln_off, rows, ptr - base, blob)
+    paf.close()
+    if own is not None:
+        own.close()
+    return sh
+
+
+def exchange_bytes(messages, group=None):
+    """All-to-all of one u8 message per destination rank (empty ones cost nothing); returns the messages received, by source
+    rank.  Sizes by one all_gather of `world` integers, payloads by one group of point-to-point transfers."""
+    import torch
+    dist = _dist()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world == 1:
+        return [np.ascontiguousarray(messages[0], np.uint8)]
+    dev = _dev(group)
+    mine = torch.tensor([len(m) for m in messages], dtype=torch.int64, device=dev)
+    allsz = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(allsz, mine, group=group)
+    sizes = [[int(x) for x in t.cpu().tolist()] for t in allsz]          # sizes[src][dst]
+    send = {d: torch.from_numpy(np.ascontiguousarray(messages[d], np.uint8)).to(dev) for d in range(world) if d != rank and sizes[rank][d]}
+    recv = {r: torch.empty(sizes[r][rank], dtype=torch.uint8, device=dev) for r in range(world) if r != rank and sizes[r][rank]}
+    ops = [dist.P2POp(dist.isend, t, d, group=group) for d, t in send.items()] + [dist.P2POp(dist.irecv, t, r, group=group) for r, t in recv.items()]
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+    out = []
+    for r in range(world):
+        out.append(np.ascontiguousarray(messages[rank], np.uint8) if r == rank else (recv[r].cpu().numpy() if r in recv else np.zeros(0, np.uint8)))
+    return out
+
+
+def merge_pieces(pieces):
+    """Pieces of work (rids, aln_off, rows, cig_off, cig) in FILE ORDER (source rank order) -> one: the alignments of a target
+    from all pieces back to back in that order, targets by first appearance, a second alignment of a (query, target) pair
+    dropped (overlaps.rs:175-185 across pieces; inside a piece the parser has done it)."""
+    pieces = [p for p in pieces if len(p[0])]
+    if not pieces:
+        return np.zeros(0, np.uint32), np.zeros(1, np.uint64), np.zeros((0, 10), np.uint32), np.zeros(0, np.uint64), np.zeros(0, np.uint8)
+    rows = np.concatenate([p[2] for p in pieces])
+    base = np.cumsum([0] + [len(p[4]) for p in pieces[:-1]]).astype(np.uint64)
+    cig_off = np.concatenate([p[3] + b for p, b in zip(pieces, base)])
+    cig = np.concatenate([p[4] for p in pieces])
+    tid = rows[:, 5].astype(np.int64)
+    uniq, first = np.unique(tid, return_index=True)
+    order_t = uniq[np.argsort(first, kind="stable")]                     # targets by first appearance
+    gi = np.searchsorted(uniq, tid)
+    grank = np.empty(len(uniq), np.int64); grank[np.searchsorted(uniq, order_t)] = np.arange(len(uniq))
+    g = grank[gi]
+    key = (g << 32) | rows[:, 0].astype(np.int64)                        # (target group, query id)
+    _, keep_first = np.unique(key, return_index=True)
+    keep = np.zeros(len(rows), bool); keep[keep_first] = True
+    sel = np.flatnonzero(keep)
+    sel = sel[np.argsort(g[sel], kind="stable")]
+    cnt = np.bincount(g[sel], minlength=len(uniq))
+    aln_off = np.zeros(len(uniq) + 1, np.uint64); aln_off[1:] = np.cumsum(cnt)
+    return order_t.astype(np.uint32), aln_off, rows[sel], cig_off[sel], cig
+
+
+def route_to_owners(share: _Share, group=None):
+    """One all-to-all: every rank packs, per destination, the targets of its share that the destination owns (owner_of), and
+    gets back the pieces of its own targets from every rank, merged.  Returns (work arrays, bytes this rank sent)."""
+    dist = _dist()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    owner = owner_of(share.tgt_rid, world)
+    mine = np.flatnonzero(owner == rank)
+    msgs = [np.zeros(0, np.uint8)] * world
+    sent = 0
+    for d in range(world):
+        if d == rank:
+            continue
+        tg = np.flatnonzero(owner == d)
+        if len(tg):
+            msgs[d] = shard_work(share, tg, slot=("route", d))
+            sent += len(msgs[d])
+    got = exchange_bytes(msgs, group) if world > 1 else [msgs[0]]
+    pieces = []
+    for r in range(world):
+        if r == rank:
+            if len(mine):
+                rids, aln_off, rows, src_off, blob = shard_arrays(share, mine)
+                pieces.append((rids, aln_off, rows, src_off, blob))
+        elif len(got[r]):
+            pieces.append(unpack_work(got[r]))
+    return merge_pieces(pieces), sent
+
+
+def correct_sharded_local(share: _Share, correct_fn, group=None):
+    """The sharded data path with per-rank ingestion: `share` = what THIS rank has read (ingest_paf_range of its byte range, or
+    its own batch files); one all-to-all routes every target to its owner; correct_fn runs on the owned targets; the FASTA
+    records are gathered to rank 0.  Returns ((rids, ends, text) on rank 0 else None, owned targets, bytes sent while routing)."""
+    dist = _dist()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    (rids, aln_off, rows, cig_off, cig), sent = route_to_owners(share, group)
+    rec = correct_fn(rids, aln_off, rows, cig_off, cig) if len(rids) else (np.zeros(0, np.uint32), np.zeros(0, np.uint64), b"")
+    if world == 1:
+        return merge_records([rec]), len(rids), sent
+    gathered = gather_bytes(pack_records(*rec), group)
+    if rank != 0:
+        return None, len(rids), sent
+    return merge_records([unpack_records(g) for g in gathered]), len(rids), sent
+
+
 def hip_corrector(ctxs, window_size: int, batch: int, read_name, group_targets: int = 1024):
     """correct_fn for correct_sharded on the HIP path: jobs of at most `group_targets` targets, cross-read batches of `batch`
     windows, device consensus, one herro_job_fasta call per job.  `ctxs`: one or more contexts of this rank's GPU; each gets a
@@ -432,28 +615,48 @@ def strong_leg(args, rank: int, world: int, local: int, n_windows: int, n_ctx: i
         ctxs.append(c)
     fn = hip_corrector(ctxs, W, args.batch, lambda rid: f"read{rid}", group_targets=max(1, args.group * args.batch // wpt))
     nw = np.full(n_t, wpt, np.int64) if rank == 0 else None
+    local_ingest = getattr(args, "strong_ingest", "local") != "rank0"
+    share = None
+    if local_ingest:
+        # every rank's own share of the parsed alignments (what it would have read from its own byte range / batch files): handed
+        # out once, OUTSIDE the timed region — a contiguous block of targets per rank, which is NOT the ownership (owner_of)
+        if rank == 0:
+            blocks = np.array_split(np.arange(n_t, dtype=np.int64), world)
+            msgs = [np.zeros(0, np.uint8)] + [(lambda p=p, r=r: shard_work(sb, p, slot=("share", r))) for r, p in enumerate(blocks[1:], 1)]
+            if world > 1:
+                scatter_bytes(msgs, None, sizes=[0] + [work_size(sb, p) for p in blocks[1:]])
+            share = _Share(*shard_arrays(sb, blocks[0]))
+        else:
+            share = _Share(*unpack_work(scatter_bytes(None, None)))
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def one_pass():
+        if local_ingest:
+            return correct_sharded_local(share, fn)
+        rec_, n_ = correct_sharded(sb, nw, fn)
+        return rec_, n_, None
     if args.warmup:                                  # one untimed pass over the same fixed job (arenas, clocks)
-        correct_sharded(sb, nw, fn)
+        one_pass()
     sync()
     t0 = time.perf_counter()
-    rec, n_mine = correct_sharded(sb, nw, fn)
+    rec, n_mine, sent = one_pass()
     for c in ctxs:
         c.synchronize()
     el = time.perf_counter() - t0
     sync()
     seen = world
+    sent_all = sent
     if world > 1:
         tt = torch.tensor([el], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
-        one = torch.ones(1, device="cuda", dtype=torch.int64)
+        one = torch.tensor([1, int(sent or 0)], device="cuda", dtype=torch.int64)
         dist.all_reduce(one)
-        seen = int(one.item())
+        seen, sent_all = int(one[0].item()), int(one[1].item())
     for c in ctxs:
         c.close()
     if rank != 0:
@@ -462,8 +665,14 @@ def strong_leg(args, rank: int, world: int, local: int, n_windows: int, n_ctx: i
     n_rec = int(np.count_nonzero(np.asarray(text) == ord(">")))
     return {"windows_per_s": n_t * wpt / el, "windows": n_t * wpt, "seconds": el, "ranks_seen": seen, "contexts_per_gpu": len(ctxs),
             "mbases_per_s": (len(text) - 16 * n_rec) / el / 1e6, "fasta_records": n_rec, "fasta_bytes": int(len(text)),
-            "timed": "scatter + herro_job_create + featurize + infer + consensus + D2H + herro_job_fasta + gather to rank 0 "
-                     "(whole sharded data path, host work included); rank 0 ingests"}
+            "ingest": "local" if local_ingest else "rank0",
+            "routing_bytes_sent_by_rank0": sent, "routing_bytes_sent_all_ranks": sent_all,
+            "routing_bytes_per_window_rank0": (sent or 0) / (n_t * wpt),
+            "timed": ("all-to-all of the targets a rank read but does not own + herro_job_create + featurize + infer + consensus + D2H + herro_job_fasta "
+                      "+ gather to rank 0 (whole sharded data path, host work included); every rank holds its own share of the parsed alignments "
+                      "(per-rank ingestion), rank 0 ships nothing but part of its share") if local_ingest else
+                     ("scatter + herro_job_create + featurize + infer + consensus + D2H + herro_job_fasta + gather to rank 0 "
+                      "(whole sharded data path, host work included); rank 0 ingests")}
 
 
 def bench_strong(args, rank: int, world: int, local: int):

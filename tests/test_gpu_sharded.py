@@ -35,6 +35,10 @@ def test_sharded_path_single_rank_matches_plain_job():
     # what the oracle decodes from that run's own logits, which the other tests pin; here: same records
     assert fasta.decode() == "".join(f for _, f in recs)
     assert fasta.count(b">") >= 1
+    # the same through the per-rank-ingestion path (one rank: its share is everything, nothing to route)
+    share = shard._Share(*shard.shard_arrays(sb, np.arange(sb.n_targets)))
+    rec2, n2, sent = shard.correct_sharded_local(share, shard.hip_corrector([c, c2], W, 5, sb.read_name, group_targets=3))
+    assert n2 == sb.n_targets and sent == 0 and shard.sorted_fasta(*rec2) == fasta
     # herro_job_fasta (all targets, one call) == the per-target entry
     text, ends = job.fasta([sb.read_name(int(r)) for r in sb.tgt_rid], with_ends=True)
     assert text.decode() == "".join(job.consensus_fasta(t, sb.read_name(int(sb.tgt_rid[t]))) for t in range(sb.n_targets))

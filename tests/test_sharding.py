@@ -155,6 +155,88 @@ def test_three_ranks_with_an_empty_shard(tmp_path):
     assert got["fasta"] == want["fasta"] and got["records"] == 2 and got["mine"] == 1
 
 
+WORKER3 = textwrap.dedent("""
+    import os, sys, json, hashlib
+    sys.path.insert(0, {root!r})
+    import numpy as np, torch, torch.distributed as dist
+    from herro_amd import shard, synth, api
+    rank, world, path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    if world > 1:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    sb = synth.generate(7, 1300, 8, seed=13, flank_min=30, flank_max=60)      # the READS (every rank has the read set); alignments come from the file
+    names = [sb.read_name(i).encode() for i in range(sb.n_reads)]
+    seq, qual, off = sb.seq, sb.qual, sb.off
+
+    def correct(rids, aln_off, rows, cig_off, cig):       # stand-in corrector: a digest of exactly what arrived
+        out = []
+        for k, rid in enumerate(rids):
+            assert int(shard.owner_of([rid], world)[0]) == rank   # only targets this rank owns
+            a0, a1 = int(aln_off[k]), int(aln_off[k + 1])
+            h = hashlib.sha1()
+            h.update(np.ascontiguousarray(rows[a0:a1]).tobytes())
+            for a in range(a0, a1):
+                h.update(cig[int(cig_off[a]):int(cig_off[a]) + int(rows[a, 9])].tobytes())
+            h.update(seq[int(off[rid]):int(off[rid + 1])].tobytes())
+            out.append((int(rid), (">read%d \\n%s\\n" % (rid, h.hexdigest())).encode()))
+        ends = np.cumsum([len(f) for _, f in out]).astype(np.uint64)
+        return np.array([r for r, _ in out], np.uint32), ends, b"".join(f for _, f in out)
+    share = shard.ingest_paf_range(shard.paf_byte_range(path, rank, world), names)     # THIS rank's bytes only
+    rec, n_mine, sent = shard.correct_sharded_local(share, correct)
+    tot = shard.gather_counts({{"sent": sent, "alns_read": len(share.aln), "owned": n_mine}}) if world > 1 else {{"sent": sent, "alns_read": len(share.aln), "owned": n_mine}}
+    if rank == 0:
+        print(json.dumps({{"fasta": shard.sorted_fasta(*rec).decode(), "records": int(len(rec[0])), "tot": tot, "sent0": sent, "read0": len(share.aln)}}))
+    if world > 1:
+        dist.destroy_process_group()
+""")
+
+
+def test_per_rank_ingestion_three_ranks(tmp_path):
+    """Round 4: no rank reads or ships the whole alignment set.  Every rank parses its own byte range of the PAF, one all-to-all
+    takes every target to its owner (a hash of the read id), the owner merges the pieces in file order and drops a second alignment of a
+    (query, target) pair ACROSS pieces as parse_paf does inside one file; the gathered FASTA equals the single-rank one, and the
+    one the whole-file parser gives."""
+    import json
+    from herro_amd import synth, api
+    sb = synth.generate(7, 1300, 8, seed=13, flank_min=30, flank_max=60)
+    names = [sb.read_name(i).encode() for i in range(sb.n_reads)]
+
+    def line(a):
+        r = sb.aln[a]
+        return b"\t".join([names[r[0]], b"%d" % r[1], b"%d" % r[2], b"%d" % r[3], b"-" if r[4] else b"+", names[r[5]],
+                            b"%d" % r[6], b"%d" % r[7], b"%d" % r[8], b"60", b"60", b"255", b"cg:Z:" + sb.cigar(a)])
+    order = np.random.default_rng(3).permutation(len(sb.aln))        # a PAF sorted by nothing: every target's alignments all over the file
+    lines = [line(int(a)) for a in order]
+    lines.append(line(int(order[0])))                                # the same (query, target) pair again, at the far end of the file: dropped
+    lines.insert(len(lines) // 2, b"\t".join([names[3], b"1300", b"0", b"100", b"+", names[3], b"1300", b"0", b"100", b"60", b"60", b"255", b"cg:Z:100M"]))  # self overlap
+    path = tmp_path / "all.paf"
+    path.write_bytes(b"\n".join(lines) + b"\n")
+    port = 35500 + os.getpid() % 2000
+    script = tmp_path / "worker_local.py"
+    script.write_text(WORKER3.format(root=ROOT, port=port))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    single = subprocess.run([sys.executable, str(script), "0", "1", str(path)], capture_output=True, text=True, env=env, timeout=240)
+    assert single.returncode == 0, single.stderr
+    want = json.loads(single.stdout.strip().splitlines()[-1])
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "3", str(path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(3)]
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    got = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert got["fasta"] == want["fasta"] and got["records"] == want["records"] == sb.n_targets
+    assert got["tot"]["alns_read"] == len(sb.aln) + 1 - 0 and got["tot"]["owned"] == sb.n_targets   # every line read once (the duplicate is read, then dropped by the owner; the self overlap by the parser)
+    assert want["tot"]["sent"] == 0 and 0 < got["sent0"] < got["tot"]["sent"]          # rank 0 ships part of ITS share, nothing else
+    assert got["read0"] < 0.6 * len(sb.aln)
+    # the whole-file parser sees the same work: per target the same alignments in the same order
+    paf = api.Paf(names, text=path.read_bytes())
+    rows = paf.rows()
+    merged = shard.merge_pieces([shard.shard_arrays(sh, np.arange(len(sh.tgt_rid))) for sh in
+                                 (shard.ingest_paf_range(shard.paf_byte_range(str(path), r, 3), names) for r in range(3))])
+    assert merged[0].tolist() == paf.targets.tolist() and merged[1].tolist() == paf.aln_off.tolist()
+    for a in range(len(rows)):
+        assert merged[2][a, :9].tolist() == list(rows[a][:9]) and merged[4][int(merged[3][a]):int(merged[3][a]) + int(merged[2][a, 9])].tobytes() == rows[a][9]
+    paf.close()
+
+
 def test_record_messages_round_trip():
     a = (np.array([7, 3], np.uint32), np.array([5, 5], np.uint64), b">r7 \n")
     b = (np.array([1], np.uint32), np.array([6], np.uint64), b">r1 \nA")
