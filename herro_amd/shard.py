@@ -470,6 +470,8 @@ def merge_pieces(pieces):
     pieces = [p for p in pieces if len(p[0])]
     if not pieces:
         return np.zeros(0, np.uint32), np.zeros(1, np.uint64), np.zeros((0, 10), np.uint32), np.zeros(0, np.uint64), np.zeros(0, np.uint8)
+    if len(pieces) == 1:   # one source (a single rank, or nobody else read anything of ours): the parser's own output, untouched — no copy
+        return pieces[0]
     rows = np.concatenate([p[2] for p in pieces])
     base = np.cumsum([0] + [len(p[4]) for p in pieces[:-1]]).astype(np.uint64)
     cig_off = np.concatenate([p[3] + b for p, b in zip(pieces, base)])
