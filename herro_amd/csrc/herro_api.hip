@@ -351,7 +351,7 @@ struct ArenaReturn {
 // most `cap` tokens.  Returns the first token of each tile (+ end) for windows [w0, w1) of the token stream.  Callers pass
 // windows of <= FUSED_MAX_TOK informative rows only (larger windows run layer by layer, see split_launch).
 static constexpr uint32_t FUSED_MAX_TOK = 64;
-static constexpr uint32_t FUSED_HALF_TOK = 32;   // tile of k_layers_q (two workgroups per compute unit)
+static constexpr uint32_t FUSED_HALF_TOK = 32;   // tile of k_layers_p<., 2> (the short last round of a launch)
 static std::vector<uint32_t> token_tiles(const std::vector<uint32_t>& tok_off, size_t w0 = 0, size_t w1 = ~size_t(0), uint32_t cap = FUSED_MAX_TOK) {
   w1 = std::min(w1, tok_off.size() - 1);
   if (w0 >= w1) return std::vector<uint32_t>();
@@ -399,9 +399,9 @@ static std::vector<uint32_t> tile_pack_order(const std::vector<uint32_t>& cnt) {
 }
 
 // The token stream of one fused launch: `order[k]` = index (into cnt) of its k-th window, `tiles` the 64-token tiles at its
-// head (first tokens + end), `tiles_q` the 32-token tiles behind them (k_layers_q; empty when qmode = 0).
+// head (first tokens + end), `tiles_q` the 32-token tiles behind them (k_layers_p<., 2>; empty when qmode = 0).
 // A launch of the fused stack runs in rounds of one 64-token tile per compute unit; a 32-token tile costs about half a round
-// when it has its compute unit to itself (two of them sharing one are bound by the weight stream: no gain, measured).
+// (half the MFMAs and LDS traffic for the same weight stream).
 // qmode 1 (default with the f16 stack): when the LAST round would fill at most half of the compute units, the windows of its
 // tiles go into 32-token tiles instead, one per compute unit (2560 windows of the bench: 625 tiles = 2 rounds + 113 -> 2 rounds
 // + 226 half tiles).  qmode 2 (A/B): every window of <= 32 rows goes into 32-token tiles; a window of 33..64 opens a 64-token

@@ -83,7 +83,7 @@ struct BatchDev {
   const uint32_t* sup_row;    // informative rows
   uint32_t n_tiles;           // token tiles of whole windows (<= 64 tokens each) for the fused stack; 0: not tileable
   const uint32_t* tile_tok0;  // [n_tiles+1] first token of each tile
-  uint32_t n_tiles_q;         // tiles of <= 32 tokens behind them in the token stream (k_layers_q: two workgroups per compute unit); 0: none
+  uint32_t n_tiles_q;         // tiles of <= 32 tokens behind them in the token stream (k_layers_p<., 2>: the short last round of a launch); 0: none
   const uint32_t* tile_tok0_q;  // [n_tiles_q+1]
   float* out_info;            // job-level [sum nsup]
   float* out_base;            // job-level [sum nsup][5]

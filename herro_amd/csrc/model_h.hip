@@ -19,7 +19,7 @@
 // Kernels (same dataflow as model.hip, re-derived for one 2-byte plane per operand):
 //   k_conv_m   embedding + quality + conv1 as a K = 96 GEMM -> (registers) -> conv2 (K = 192) -> y2 as ONE f16 plane [N*31][128]
 //   k_fc_h     y2[N][3968] . Wfc -> x[N][256]; 128 x 256 tiles, LDS-DMA, three 24 KB buffers, 2 workgroups per CU
-//   k_layers_p the whole encoder stack per tile of <= 64 tokens: residual stream in registers from the FC output to
+//   k_layers_p the whole encoder stack per tile of <= 64 (or 32) tokens: residual stream in registers from the FC output to
 //              the logits (positional encoding added on the way in), weight fragments one half GEMM call ahead
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -577,7 +577,6 @@ __global__ __launch_bounds__(512, 4) void k_fc_r(const uint16_t* __restrict__ A,
 //   * Q, K, V, P are single f16 fragments (attention's error share is 4e-5 / 1.8e-4);
 //   * the positional encoding is added while x is fetched (no k_add_pe launch, no extra pass over x).
 // ---------------------------------------------------------------------------------------------------
-constexpr int HLT = 64;
 __device__ __forceinline__ uint32_t hlsw(uint32_t row, uint32_t chunk) { return row * 256 + ((chunk ^ (row & 15u)) << 3); }
 
 // ---------------------------------------------------------------------------------------------------
@@ -608,19 +607,19 @@ __device__ __forceinline__ void wload4(const WStream& s, uint32_t k0, half8 (&w)
     for (int k = 0; k < 4; k++) w[k][jt] = *reinterpret_cast<const half8*>(s.p + (uint64_t)(jt * s.nks + k0 + k) * 512);
 }
 
-template <bool SWAP, int TERMS>
+template <bool SWAP, int TERMS, int PT>
 __device__ __forceinline__ void tile_gemm_p(const WStream& cur, half8 (&wa)[4][2], const WStream& nxt, const uint16_t* sh,
-                                            const uint16_t* sl, uint32_t fr, uint32_t fg, f32x4 (&acc)[4][2]) {
+                                            const uint16_t* sl, uint32_t fr, uint32_t fg, f32x4 (&acc)[PT][2]) {
   half8 wb[4][2];
   wload4(cur, 4, wb);
-  half8 xh[4], xl[4], xn[4];
-  auto rd = [&](const uint16_t* plane, int k, half8 (&x)[4]) {
+  half8 xh[PT], xl[PT], xn[PT];
+  auto rd = [&](const uint16_t* plane, int k, half8 (&x)[PT]) {
 #pragma unroll
-    for (int pt = 0; pt < 4; pt++) x[pt] = *reinterpret_cast<const half8*>(plane + hlsw(pt * 16 + fr, k * 4 + fg));
+    for (int pt = 0; pt < PT; pt++) x[pt] = *reinterpret_cast<const half8*>(plane + hlsw(pt * 16 + fr, k * 4 + fg));
   };
-  auto mm8 = [&](const half8 (&x)[4], const half8 (&w)[2]) {
+  auto mm8 = [&](const half8 (&x)[PT], const half8 (&w)[2]) {
 #pragma unroll
-    for (int pt = 0; pt < 4; pt++)
+    for (int pt = 0; pt < PT; pt++)
 #pragma unroll
       for (int jt = 0; jt < 2; jt++) acc[pt][jt] = SWAP ? mma(x[pt], w[jt], acc[pt][jt]) : mma(w[jt], x[pt], acc[pt][jt]);
   };
@@ -643,7 +642,7 @@ __device__ __forceinline__ void tile_gemm_p(const WStream& cur, half8 (&wa)[4][2
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int pt = 0; pt < 4; pt++) xh[pt] = xn[pt];
+    for (int pt = 0; pt < PT; pt++) xh[pt] = xn[pt];
   }
 }
 
@@ -673,20 +672,22 @@ __device__ unsigned long long g_lp_prof[16];
 #define LP_MARK(ph) do { } while (0)
 #endif
 
-template <int TERMS>
+template <int TERMS, int PT>
 __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelScratch S) {
+  constexpr int HLT = 16 * PT;   // tokens per tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* s_hh = reinterpret_cast<uint16_t*>(smem);
   uint16_t* s_hl = s_hh + HLT * 256;
   uint16_t* s_ah = s_hl + HLT * 256;
   uint16_t* s_al = s_ah + HLT * 256;
-  float* s_red = reinterpret_cast<float*>(s_al + HLT * 256);       // [2 passes][8 waves][64 tokens]
+  float* s_red = reinterpret_cast<float*>(s_al + HLT * 256);       // [2 passes][8 waves][tokens]
   uint32_t* s_win = reinterpret_cast<uint32_t*>(s_red + 2 * 8 * HLT);
   float* s_par = reinterpret_cast<float*>(s_win + HLT);            // this layer's LayerNorm parameters and biases
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   LP_BEGIN();
   uint32_t fr = lane & 15, fg = lane >> 4;
-  const uint32_t t0 = B.tile_tok0[blockIdx.x], nt = B.tile_tok0[blockIdx.x + 1] - t0;
+  const uint32_t* tile_tok0 = PT == 4 ? B.tile_tok0 : B.tile_tok0_q;
+  const uint32_t t0 = tile_tok0[blockIdx.x], nt = tile_tok0[blockIdx.x + 1] - t0;
   const uint32_t cw = wave * 32;
   const float eps = M.h.ln_eps;
   const uint32_t n_layers = M.h.n_layers, d_ff = M.h.d_ff;
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
 #define RELAUNDER() asm volatile("" : "+v"(fr), "+v"(fg))
 
   if (tid < HLT) s_win[tid] = tid < nt ? S.tok_win[t0 + tid] : 0xffffff00u + tid;
-  float x[4][8];
+  float x[PT][8];
   half8 wa[4][2];  // the first four k-steps of the next GEMM call, always one call ahead
   wload4(wstream(M.layer[0].qkv, cw, 0, lane), 0, wa);
 
@@ -719,12 +720,12 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
   // LayerNorm over the 256 channels of the register-resident x, two passes (mean, then centred sum of squares).  (The one-barrier
   // form of k_layers_q — per-wave mean and M2 merged exactly — measured no faster here: 726 vs 726 us per 4096 windows.)
   auto layer_norm = [&](uint32_t og, uint32_t ob, const float* __restrict__ gp, const float* __restrict__ bp, bool want_lo) {
-    float mean[4], rstd[4];
+    float mean[PT], rstd[PT];
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
       float* red = s_red + pass * 8 * HLT;   // separate arrays per pass: one barrier less per LayerNorm
 #pragma unroll
-      for (int pt = 0; pt < 4; pt++) {
+      for (int pt = 0; pt < PT; pt++) {
         float sm = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
@@ -736,7 +737,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
       }
       __syncthreads();
 #pragma unroll
-      for (int pt = 0; pt < 4; pt++) {
+      for (int pt = 0; pt < PT; pt++) {
         float sm = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; w++) sm += red[w * HLT + pt * 16 + fr];
@@ -755,7 +756,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
       lds8(ob + cw + 8 * fg, bb);
     }
 #pragma unroll
-    for (int pt = 0; pt < 4; pt++) {
+    for (int pt = 0; pt < PT; pt++) {
       float y[8];
 #pragma unroll
       for (int q = 0; q < 8; q++) y[q] = (x[pt][q] - mean[pt]) * rstd[pt] * gg[q] + bb[q];
@@ -771,9 +772,9 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
     }
     __syncthreads();  // planes complete; also: everybody is past its reads of both s_red arrays
   };
-  auto zero = [](f32x4 (&a)[4][2]) {
+  auto zero = [](f32x4 (&a)[PT][2]) {
 #pragma unroll
-    for (int pt = 0; pt < 4; pt++)
+    for (int pt = 0; pt < PT; pt++)
 #pragma unroll
       for (int jt = 0; jt < 2; jt++) a[pt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
@@ -793,7 +794,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
     const float4 pdv = *reinterpret_cast<const float4*>(M.pe_div + ((cw + 8 * fg) >> 1));
     const float pd[4] = {pdv.x, pdv.y, pdv.z, pdv.w};
 #pragma unroll
-    for (int pt = 0; pt < 4; pt++) {
+    for (int pt = 0; pt < PT; pt++) {
       const uint32_t tok = pt * 16 + fr;
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
       float row = 0.f;
@@ -829,37 +830,37 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
     LP_MARK(1);
     RELAUNDER();
     {  // ---- attention, head = wave
-      half8 qh[4], kh[4], vh[2][2];
+      half8 qh[PT], kh[PT], vh[2][PT / 2];
       {
-        f32x4 a[4][2];
+        f32x4 a[PT][2];
         float bq[8];
         zero(a);
-        tile_gemm_p<false, 1>(wstream(L.qkv, cw, 0, lane), wa, wstream(L.qkv, 256 + cw, 0, lane), s_hh, s_hl, fr, fg, a);
+        tile_gemm_p<false, 1, PT>(wstream(L.qkv, cw, 0, lane), wa, wstream(L.qkv, 256 + cw, 0, lane), s_hh, s_hl, fr, fg, a);
         lds8(PAR_BQKV + cw + 8 * fg, bq);
 #pragma unroll
-        for (int pt = 0; pt < 4; pt++) {
+        for (int pt = 0; pt < PT; pt++) {
           float v[8];
 #pragma unroll
           for (int q = 0; q < 8; q++) v[q] = (a[pt][q >> 2][q & 3] + bq[q]) * scale;
           qh[pt] = pack_h8(v);
         }
         zero(a);
-        tile_gemm_p<false, 1>(wstream(L.qkv, 256 + cw, 0, lane), wa, wstream(L.qkv, 512 + cw, 0, lane), s_hh, s_hl, fr, fg, a);
+        tile_gemm_p<false, 1, PT>(wstream(L.qkv, 256 + cw, 0, lane), wa, wstream(L.qkv, 512 + cw, 0, lane), s_hh, s_hl, fr, fg, a);
         lds8(PAR_BQKV + 256 + cw + 8 * fg, bq);
 #pragma unroll
-        for (int pt = 0; pt < 4; pt++) {
+        for (int pt = 0; pt < PT; pt++) {
           float v[8];
 #pragma unroll
           for (int q = 0; q < 8; q++) v[q] = a[pt][q >> 2][q & 3] + bq[q];
           kh[pt] = pack_h8(v);
         }
         zero(a);
-        tile_gemm_p<true, 1>(wstream(L.qkv, 512 + cw, 0, lane), wa, wstream(L.proj, cw, 0, lane), s_hh, s_hl, fr, fg, a);
+        tile_gemm_p<true, 1, PT>(wstream(L.qkv, 512 + cw, 0, lane), wa, wstream(L.proj, cw, 0, lane), s_hh, s_hl, fr, fg, a);
 #pragma unroll
         for (int ct = 0; ct < 2; ct++) {
           const float bv = s_par[PAR_BQKV + 512 + cw + 8 * (fr >> 2) + 4 * ct + (fr & 3)];
 #pragma unroll
-          for (int kk = 0; kk < 2; kk++) {
+          for (int kk = 0; kk < PT / 2; kk++) {
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = a[2 * kk + (e >> 2)][ct][e & 3] + bv;
@@ -868,18 +869,18 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
         }
       }
       LP_MARK(2);
-      uint32_t wj[4][4];
+      uint32_t wj[PT][4];
 #pragma unroll
-      for (int pj = 0; pj < 4; pj++)
+      for (int pj = 0; pj < PT; pj++)
 #pragma unroll
         for (int r = 0; r < 4; r++) wj[pj][r] = s_win[pj * 16 + 4 * fg + r];
 #pragma unroll
-      for (int pi = 0; pi < 4; pi++) {
+      for (int pi = 0; pi < PT; pi++) {
         const uint32_t wi = s_win[pi * 16 + fr];
-        f32x4 st[4];
+        f32x4 st[PT];
         float m = -INFINITY;
 #pragma unroll
-        for (int pj = 0; pj < 4; pj++) {
+        for (int pj = 0; pj < PT; pj++) {
           st[pj] = mma(kh[pj], qh[pi], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
           for (int r = 0; r < 4; r++) {
@@ -890,7 +891,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
         m = fg_max(m);
         float l = 0.f;
 #pragma unroll
-        for (int pj = 0; pj < 4; pj++)
+        for (int pj = 0; pj < PT; pj++)
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const float pexp = __expf(st[pj][r] - m);
@@ -900,7 +901,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
         l = fg_sum(l);
         f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
+        for (int kk = 0; kk < PT / 2; kk++) {
           float v[8];
 #pragma unroll
           for (int e = 0; e < 8; e++) v[e] = st[2 * kk + (e >> 2)][e & 3];
@@ -919,13 +920,13 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
     LP_MARK(3);
     RELAUNDER();
     {  // ---- output projection + residual
-      f32x4 a[4][2];
+      f32x4 a[PT][2];
       float bp[8];
       zero(a);
-      tile_gemm_p<false, TERMS>(wstream(L.proj, cw, 0, lane), wa, wstream(L.ff1, cw, 0, lane), s_ah, s_al, fr, fg, a);
+      tile_gemm_p<false, TERMS, PT>(wstream(L.proj, cw, 0, lane), wa, wstream(L.ff1, cw, 0, lane), s_ah, s_al, fr, fg, a);
       lds8(PAR_BPROJ + cw + 8 * fg, bp);
 #pragma unroll
-      for (int pt = 0; pt < 4; pt++)
+      for (int pt = 0; pt < PT; pt++)
 #pragma unroll
         for (int q = 0; q < 8; q++) x[pt][q] += a[pt][q >> 2][q & 3] + bp[q];
     }
@@ -934,30 +935,30 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
     layer_norm(PAR_LN2G, PAR_LN2B, nullptr, nullptr, TERMS == 2);
     LP_MARK(5);
     {  // ---- feed-forward, 256 hidden channels at a time
-      f32x4 a2[4][2];
+      f32x4 a2[PT][2];
       {  // the FF2 accumulator starts from its bias: no parameter is read after the loop's last barrier, which is what
          // lets the next layer's parameters be staged right behind it
         float b2[8];
         lds8(PAR_BFF2 + cw + 8 * fg, b2);
 #pragma unroll
-        for (int pt = 0; pt < 4; pt++)
+        for (int pt = 0; pt < PT; pt++)
 #pragma unroll
           for (int jt = 0; jt < 2; jt++) a2[pt][jt] = f32x4{b2[4 * jt], b2[4 * jt + 1], b2[4 * jt + 2], b2[4 * jt + 3]};
       }
       for (uint32_t c = 0; c < d_ff; c += 256) {
         RELAUNDER();
-        f32x4 a1[4][2];
+        f32x4 a1[PT][2];
         {  // the accumulators start from the bias (the moves that would zero them carry it)
           float b1[8];
           lds8(PAR_BFF1 + c + cw + 8 * fg, b1);
 #pragma unroll
-          for (int pt = 0; pt < 4; pt++)
+          for (int pt = 0; pt < PT; pt++)
 #pragma unroll
             for (int jt = 0; jt < 2; jt++) a1[pt][jt] = f32x4{b1[4 * jt], b1[4 * jt + 1], b1[4 * jt + 2], b1[4 * jt + 3]};
         }
-        tile_gemm_p<false, TERMS>(wstream(L.ff1, c + cw, 0, lane), wa, wstream(L.ff2, cw, c, lane), s_hh, s_hl, fr, fg, a1);
+        tile_gemm_p<false, TERMS, PT>(wstream(L.ff1, c + cw, 0, lane), wa, wstream(L.ff2, cw, c, lane), s_hh, s_hl, fr, fg, a1);
 #pragma unroll
-        for (int pt = 0; pt < 4; pt++) {
+        for (int pt = 0; pt < PT; pt++) {
           float v[8];
 #pragma unroll
           for (int q = 0; q < 8; q++) v[q] = fmaxf(a1[pt][q >> 2][q & 3], 0.f);
@@ -967,12 +968,12 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
         LP_MARK(6);
         const bool more = c + 256 < d_ff;
         const WStream nx = more ? wstream(L.ff1, c + 256 + cw, 0, lane) : wstream(Ln.qkv, cw, 0, lane);
-        tile_gemm_p<false, TERMS>(wstream(L.ff2, cw, c, lane), wa, nx, s_ah, s_al, fr, fg, a2);
+        tile_gemm_p<false, TERMS, PT>(wstream(L.ff2, cw, c, lane), wa, nx, s_ah, s_al, fr, fg, a2);
         __syncthreads();
         LP_MARK(7);
       }
 #pragma unroll
-      for (int pt = 0; pt < 4; pt++)
+      for (int pt = 0; pt < PT; pt++)
 #pragma unroll
         for (int q = 0; q < 8; q++) x[pt][q] += a2[pt][q >> 2][q & 3];
     }
@@ -982,7 +983,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
   RELAUNDER();
   layer_norm(0, 0, M.lnf_g, M.lnf_b, true);
 #undef RELAUNDER
-  if (wave < 4) {  // heads, three terms
+  if (wave < PT) {  // heads, three terms
     const uint32_t pt = wave;
     f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
     const Weight& W = M.heads;
@@ -1012,423 +1013,25 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
   }
   LP_MARK(8);
 }
-constexpr size_t LAYERS_P_SHM = (size_t)4 * HLT * 256 * 2 + 2 * 8 * HLT * 4 + HLT * 4 + (size_t)PAR_FLOATS * 4;
+constexpr size_t layers_p_shm(int tokens) { return (size_t)4 * tokens * 256 * 2 + 2 * 8 * tokens * 4 + tokens * 4 + (size_t)PAR_FLOATS * 4; }
 
 // ---------------------------------------------------------------------------------------------------
-// k_layers_q — the same stack for tiles of <= 32 tokens, organised so that TWO workgroups share a compute unit (round 4).
-// Why: k_layers_p puts one 512-thread workgroup on a CU and all 8 waves are in the same phase at the same time, so the
-// VALU phases (LayerNorms, softmax, FF epilogues, prologue) and the 15 barriers of a layer leave the MFMA pipe idle:
-// phase timers, cycles per 64-token tile: 176 k of MFMA issue in 375 k (QKV / proj alone run at 86-95 %).  Here a
-// workgroup is 4 waves (one per SIMD), a wave owns 64 output channels (two 32-channel slabs = two heads) of 32 tokens,
-// LDS is 4 planes x 32 tokens = 64 KB + 15 KB -> two independent workgroups per CU: one's VALU phases and barrier waits
-// sit under the other's MFMAs.  Against k_layers_p per token: the same MFMAs, half the LDS operand reads (an activation
-// fragment feeds 4 MFMAs instead of 2), twice the weight stream from L2 (a fragment feeds 2 MFMAs per term instead of
-// 4).  Tiles are half the size, so a launch's last round quantises at half the cost, and softmax walks 32 x 32 scores
-// per head instead of 64 x 64.  Differences in the plumbing: weights sit in a ring of four k-step slots (16 VGPRs each;
-// a slot is refilled with the k-step 4 ahead — of the next call for the last four — as soon as its MFMAs are issued);
-// LayerNorm statistics take ONE barrier (per-wave mean and centred sum of squares, merged exactly as Chan et al.).
+// Tiles of 32 tokens (k_layers_p<TERMS, 2>): the same organisation — 8 waves, wave = head and 32-channel slab, weights one half
+// call ahead — over two row blocks instead of four: half the MFMAs and half the LDS traffic for the same weight stream.  A launch
+// runs in rounds of one 64-token tile per compute unit; when its last round would fill at most half of the chip, the windows of
+// that round go into 32-token tiles instead (plan_tiles, herro_api.hip).
+//
+// What round 4 measured before settling on this (profiles/r4_layers_*): a SEPARATE design for 32-token tiles, k_layers_q — four
+// waves per workgroup, wave = 64 channels (two heads), a ring of four weight k-steps, one-barrier LayerNorm, 80 KB of LDS so that
+// TWO workgroups share a compute unit and one's LayerNorm / softmax / epilogue phases sit under the other's MFMAs — the
+// restructuring VERDICT r3 asked for.  Parity was green and both workgroups were resident (7.5 waves per CU, L2 hit rate 97 %),
+// but it was SLOWER: 780 us per 4096 windows against 710.  Every weight fragment then feeds two MFMAs per term instead of four,
+// i.e. the 6.3 MB weight pass of a tile goes through the CU's vector-memory path (64 B/clk) once per 32 tokens: 98 k cycles per
+// workgroup, 197 k for the pair, against 176 k cycles of MFMA issue — QKV (one term) ran at exactly that bound (46.6 k cycles vs
+// 49 k), and the denser body clocked ~10 % lower (1.79 vs 1.98 GHz).  The phase overlap is real (339 k cycles per 64 tokens
+// instead of 375 k) but the path it needs is the one this kernel already uses at 50 % when its MFMAs run at full rate.  Alone on
+// a CU a k_layers_q tile took 0.8 of a 64-token tile's time (one wave per SIMD hides nothing); this variant takes ~0.45.
 // ---------------------------------------------------------------------------------------------------
-constexpr int QLT = 32;                          // tokens per tile
-constexpr int PARQ_MAX_FF = 1024;                // d_ff supported by the parameter block (80 KB per workgroup)
-constexpr int PARQ_FLOATS = PAR_BFF1 + PARQ_MAX_FF;
-constexpr size_t LAYERS_Q_SHM = (size_t)4 * QLT * 256 * 2 + 4 * QLT * 8 + QLT * 4 + (size_t)PARQ_FLOATS * 4;
-
-struct WRing { half8 s[4][4]; };  // [k-step & 3][2 * slab + jt]
-__device__ __forceinline__ void wloadk(const WStream& st, uint32_t k, half8 (&slot)[4]) {
-#pragma unroll
-  for (int f = 0; f < 4; f++) slot[f] = *reinterpret_cast<const half8*>(st.p + (uint64_t)(f * st.nks + k) * 512);
-}
-
-// acc[pt][2 * slab + jt] += W(call `cur`)^T . planes, K = 256; the ring enters holding k-steps 0..3 of `cur` and leaves holding 0..3 of `nxt`
-template <bool SWAP, int TERMS>
-__device__ __forceinline__ void tile_gemm_q(const WStream& cur, const WStream& nxt, WRing& w, const uint16_t* sh, const uint16_t* sl,
-                                            uint32_t fr, uint32_t fg, f32x4 (&acc)[2][4]) {
-  half8 xh[2], xl[2], xn[2];
-  auto rd = [&](const uint16_t* plane, int k, half8 (&x)[2]) {
-#pragma unroll
-    for (int pt = 0; pt < 2; pt++) x[pt] = *reinterpret_cast<const half8*>(plane + hlsw(pt * 16 + fr, k * 4 + fg));
-  };
-  auto mm8 = [&](const half8 (&x)[2], const half8 (&wk)[4]) {
-#pragma unroll
-    for (int pt = 0; pt < 2; pt++)
-#pragma unroll
-      for (int f = 0; f < 4; f++) acc[pt][f] = SWAP ? mma(x[pt], wk[f], acc[pt][f]) : mma(wk[f], x[pt], acc[pt][f]);
-  };
-  rd(sh, 0, xh);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    if (TERMS == 2) rd(sl, k, xl);
-    __builtin_amdgcn_sched_barrier(0);
-    mm8(xh, w.s[k & 3]);
-    __builtin_amdgcn_sched_barrier(0);
-    if (k < 7) rd(sh, k + 1, xn);
-    __builtin_amdgcn_sched_barrier(0);
-    if (TERMS == 2) {
-      mm8(xl, w.s[k & 3]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (k < 4) wloadk(cur, k + 4, w.s[k & 3]); else wloadk(nxt, k - 4, w.s[k & 3]);   // the slot's last reader is behind us
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int pt = 0; pt < 2; pt++) xh[pt] = xn[pt];
-  }
-}
-
-template <int TERMS>
-__global__ __launch_bounds__(256, 2) void k_layers_q(ModelDev M, BatchDev B, ModelScratch S) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint16_t* s_hh = reinterpret_cast<uint16_t*>(smem);
-  uint16_t* s_hl = s_hh + QLT * 256;
-  uint16_t* s_ah = s_hl + QLT * 256;
-  uint16_t* s_al = s_ah + QLT * 256;
-  float2* s_red = reinterpret_cast<float2*>(s_al + QLT * 256);     // [4 waves][32 tokens] {mean, centred sum of squares} over the wave's 64 channels
-  uint32_t* s_win = reinterpret_cast<uint32_t*>(s_red + 4 * QLT);
-  float* s_par = reinterpret_cast<float*>(s_win + QLT);
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  LP_BEGIN();
-  uint32_t fr = lane & 15, fg = lane >> 4;
-  const uint32_t t0 = B.tile_tok0_q[blockIdx.x], nt = B.tile_tok0_q[blockIdx.x + 1] - t0;
-  const uint32_t cw = wave * 64;   // channel of x[pt][s][q]: cw + 32 s + 8 fg + q  (16-byte chunk 8 wave + 4 s + fg of a plane row)
-  const float eps = M.h.ln_eps;
-  const uint32_t n_layers = M.h.n_layers, d_ff = M.h.d_ff;
-#define RELAUNDER() asm volatile("" : "+v"(fr), "+v"(fg))   // see k_layers_p
-
-  if (tid < QLT) s_win[tid] = tid < nt ? S.tok_win[t0 + tid] : 0xffffff00u + tid;
-  float x[2][2][8];
-  WRing w;
-  {
-    const WStream q0 = wstream(M.layer[0].qkv, cw, 0, lane);
-#pragma unroll
-    for (int k = 0; k < 4; k++) wloadk(q0, k, w.s[k]);
-  }
-  auto lds8 = [&](uint32_t o, float (&v)[8]) {
-    const float4 a = *reinterpret_cast<const float4*>(s_par + o), b = *reinterpret_cast<const float4*>(s_par + o + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-  };
-  auto stage_params = [&](const LayerW& L) {
-    {
-      const uint32_t e = tid;
-      s_par[PAR_LN1G + e] = L.ln1_g[e]; s_par[PAR_LN1B + e] = L.ln1_b[e];
-      s_par[PAR_LN2G + e] = L.ln2_g[e]; s_par[PAR_LN2B + e] = L.ln2_b[e];
-      s_par[PAR_BPROJ + e] = L.proj.bias[e]; s_par[PAR_BFF2 + e] = L.ff2.bias[e];
-    }
-    for (uint32_t e = tid; e < 768; e += 256) s_par[PAR_BQKV + e] = L.qkv.bias[e];
-    for (uint32_t e = tid; e < d_ff; e += 256) s_par[PAR_BFF1 + e] = L.ff1.bias[e];
-  };
-  // LayerNorm over the 256 channels of the register-resident x.  Statistics in one barrier: every wave reduces its 64 channels
-  // to {mean, sum of squares about that mean}; the four pairs merge exactly (mean of means; M2 = sum M2_w + 64 sum (m_w - mean)^2).
-  auto layer_norm = [&](uint32_t og, uint32_t ob, const float* __restrict__ gp, const float* __restrict__ bp, bool want_lo) {
-    float mean[2], rstd[2];
-#pragma unroll
-    for (int pt = 0; pt < 2; pt++) {
-      float s = 0.f;
-#pragma unroll
-      for (int sl = 0; sl < 2; sl++)
-#pragma unroll
-        for (int q = 0; q < 8; q++) s += x[pt][sl][q];
-      const float mw = fg_sum(s) * (1.0f / 64.f);
-      float d2 = 0.f;
-#pragma unroll
-      for (int sl = 0; sl < 2; sl++)
-#pragma unroll
-        for (int q = 0; q < 8; q++) { const float d = x[pt][sl][q] - mw; d2 += d * d; }
-      d2 = fg_sum(d2);
-      if (fg == 0) s_red[wave * QLT + pt * 16 + fr] = make_float2(mw, d2);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int pt = 0; pt < 2; pt++) {
-      float2 r[4];
-#pragma unroll
-      for (int wv = 0; wv < 4; wv++) r[wv] = s_red[wv * QLT + pt * 16 + fr];
-      const float m = (r[0].x + r[1].x + r[2].x + r[3].x) * 0.25f;
-      float m2 = r[0].y + r[1].y + r[2].y + r[3].y;
-#pragma unroll
-      for (int wv = 0; wv < 4; wv++) { const float d = r[wv].x - m; m2 += 64.f * d * d; }
-      mean[pt] = m;
-      rstd[pt] = 1.0f / sqrtf(m2 / 256.f + eps);
-    }
-#pragma unroll
-    for (int sl = 0; sl < 2; sl++) {
-      float gg[8], bb[8];
-      const uint32_t c = cw + 32 * sl + 8 * fg;
-      if (gp) {  // final LayerNorm: parameters straight from global memory
-        const float4 g0 = *reinterpret_cast<const float4*>(gp + c), g1 = *reinterpret_cast<const float4*>(gp + c + 4);
-        const float4 b0 = *reinterpret_cast<const float4*>(bp + c), b1 = *reinterpret_cast<const float4*>(bp + c + 4);
-        gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
-        bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
-      } else {
-        lds8(og + c, gg);
-        lds8(ob + c, bb);
-      }
-#pragma unroll
-      for (int pt = 0; pt < 2; pt++) {
-        float y[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) y[q] = (x[pt][sl][q] - mean[pt]) * rstd[pt] * gg[q] + bb[q];
-        const uint32_t o = hlsw(pt * 16 + fr, wave * 8 + sl * 4 + fg);
-        if (want_lo) {
-          half8 hi, lo;
-          split_h8(y, hi, lo);
-          *reinterpret_cast<half8*>(s_hh + o) = hi;
-          *reinterpret_cast<half8*>(s_hl + o) = lo;
-        } else {
-          *reinterpret_cast<half8*>(s_hh + o) = pack_h8(y);
-        }
-      }
-    }
-    __syncthreads();  // planes complete; everybody is past its reads of s_red
-  };
-  auto zero = [](f32x4 (&a)[2][4]) {
-#pragma unroll
-    for (int pt = 0; pt < 2; pt++)
-#pragma unroll
-      for (int f = 0; f < 4; f++) a[pt][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-  };
-  auto store_act = [&](uint16_t* ph, uint16_t* pl, uint32_t o, const float (&v)[8]) {
-    if (TERMS == 2) {
-      half8 hi, lo;
-      split_h8(v, hi, lo);
-      *reinterpret_cast<half8*>(ph + o) = hi;
-      *reinterpret_cast<half8*>(pl + o) = lo;
-    } else {
-      *reinterpret_cast<half8*>(ph + o) = pack_h8(v);
-    }
-  };
-
-  stage_params(M.layer[0]);
-#pragma unroll
-  for (int sl = 0; sl < 2; sl++) {  // x = FC output + positional encoding
-    const uint32_t c = cw + 32 * sl + 8 * fg;
-    const float4 pdv = *reinterpret_cast<const float4*>(M.pe_div + (c >> 1));
-    const float pd[4] = {pdv.x, pdv.y, pdv.z, pdv.w};
-#pragma unroll
-    for (int pt = 0; pt < 2; pt++) {
-      const uint32_t tok = pt * 16 + fr;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-      float row = 0.f;
-      if (tok < nt) {
-        const float* xp = S.x + (uint64_t)(t0 + tok) * 256 + c;
-        a = *reinterpret_cast<const float4*>(xp);
-        b = *reinterpret_cast<const float4*>(xp + 4);
-        row = (float)S.tok_row[t0 + tok];
-      }
-      x[pt][sl][0] = a.x; x[pt][sl][1] = a.y; x[pt][sl][2] = a.z; x[pt][sl][3] = a.w;
-      x[pt][sl][4] = b.x; x[pt][sl][5] = b.y; x[pt][sl][6] = b.z; x[pt][sl][7] = b.w;
-      if (tok < nt) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const float ang = __fmul_rn(row, pd[j]);
-          float sn, cs;
-          sincosf(ang, &sn, &cs);
-          x[pt][sl][2 * j] += sn;
-          x[pt][sl][2 * j + 1] += cs;
-        }
-      }
-    }
-  }
-  __syncthreads();  // s_win, s_par
-
-  const float scale = 1.0f / sqrtf(32.f);
-  for (uint32_t li = 0; li < n_layers; li++) {
-    const LayerW& L = M.layer[li];
-    const LayerW& Ln = M.layer[li + 1 < n_layers ? li + 1 : 0];  // after the last layer: a harmless re-read of layer 0
-    RELAUNDER();
-    LP_MARK(li ? 7 : 0);
-    layer_norm(PAR_LN1G, PAR_LN1B, nullptr, nullptr, false);   // QKV reads the hi plane only
-    LP_MARK(1);
-    RELAUNDER();
-    {  // ---- attention: heads 2 wave and 2 wave + 1
-      half8 qh[2][2], kh[2][2], vh[2][2];   // [head][pt] / [head][ct]
-      {
-        f32x4 a[2][4];
-        zero(a);
-        tile_gemm_q<false, 1>(wstream(L.qkv, cw, 0, lane), wstream(L.qkv, 256 + cw, 0, lane), w, s_hh, s_hl, fr, fg, a);
-#pragma unroll
-        for (int sl = 0; sl < 2; sl++) {
-          float bq[8];
-          lds8(PAR_BQKV + cw + 32 * sl + 8 * fg, bq);
-#pragma unroll
-          for (int pt = 0; pt < 2; pt++) {
-            float v[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) v[q] = (a[pt][2 * sl + (q >> 2)][q & 3] + bq[q]) * scale;
-            qh[sl][pt] = pack_h8(v);
-          }
-        }
-        zero(a);
-        tile_gemm_q<false, 1>(wstream(L.qkv, 256 + cw, 0, lane), wstream(L.qkv, 512 + cw, 0, lane), w, s_hh, s_hl, fr, fg, a);
-#pragma unroll
-        for (int sl = 0; sl < 2; sl++) {
-          float bq[8];
-          lds8(PAR_BQKV + 256 + cw + 32 * sl + 8 * fg, bq);
-#pragma unroll
-          for (int pt = 0; pt < 2; pt++) {
-            float v[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) v[q] = a[pt][2 * sl + (q >> 2)][q & 3] + bq[q];
-            kh[sl][pt] = pack_h8(v);
-          }
-        }
-        zero(a);
-        tile_gemm_q<true, 1>(wstream(L.qkv, 512 + cw, 0, lane), wstream(L.proj, cw, 0, lane), w, s_hh, s_hl, fr, fg, a);
-#pragma unroll
-        for (int sl = 0; sl < 2; sl++)
-#pragma unroll
-          for (int ct = 0; ct < 2; ct++) {
-            const float bv = s_par[PAR_BQKV + 512 + cw + 32 * sl + 8 * (fr >> 2) + 4 * ct + (fr & 3)];
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = a[e >> 2][2 * sl + ct][e & 3] + bv;
-            vh[sl][ct] = pack_h8(v);
-          }
-      }
-      LP_MARK(2);
-      uint32_t wj[2][4], wi[2];
-#pragma unroll
-      for (int pj = 0; pj < 2; pj++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) wj[pj][r] = s_win[pj * 16 + 4 * fg + r];
-#pragma unroll
-      for (int pi = 0; pi < 2; pi++) wi[pi] = s_win[pi * 16 + fr];
-#pragma unroll
-      for (int sl = 0; sl < 2; sl++)
-#pragma unroll
-        for (int pi = 0; pi < 2; pi++) {
-          f32x4 st[2];
-          float m = -INFINITY;
-#pragma unroll
-          for (int pj = 0; pj < 2; pj++) {
-            st[pj] = mma(kh[sl][pj], qh[sl][pi], f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-              st[pj][r] = wj[pj][r] == wi[pi] ? st[pj][r] : -INFINITY;
-              m = fmaxf(m, st[pj][r]);
-            }
-          }
-          m = fg_max(m);
-          float l = 0.f;
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 8; e++) {
-            const float pexp = __expf(st[e >> 2][e & 3] - m);
-            v[e] = pexp;
-            l += pexp;
-          }
-          l = fg_sum(l);
-          const half8 ph = pack_h8(v);
-          const float inv = 1.0f / l;
-          float ov[8];
-#pragma unroll
-          for (int ct = 0; ct < 2; ct++) {
-            const f32x4 o = mma(vh[sl][ct], ph, f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-            for (int r = 0; r < 4; r++) ov[4 * ct + r] = o[r] * inv;
-          }
-          store_act(s_ah, s_al, hlsw(pi * 16 + fr, wave * 8 + sl * 4 + fg), ov);
-        }
-    }
-    __syncthreads();
-    LP_MARK(3);
-    RELAUNDER();
-    {  // ---- output projection + residual
-      f32x4 a[2][4];
-      zero(a);
-      tile_gemm_q<false, TERMS>(wstream(L.proj, cw, 0, lane), wstream(L.ff1, cw, 0, lane), w, s_ah, s_al, fr, fg, a);
-#pragma unroll
-      for (int sl = 0; sl < 2; sl++) {
-        float bp[8];
-        lds8(PAR_BPROJ + cw + 32 * sl + 8 * fg, bp);
-#pragma unroll
-        for (int pt = 0; pt < 2; pt++)
-#pragma unroll
-          for (int q = 0; q < 8; q++) x[pt][sl][q] += a[pt][2 * sl + (q >> 2)][q & 3] + bp[q];
-      }
-    }
-    RELAUNDER();
-    LP_MARK(4);
-    layer_norm(PAR_LN2G, PAR_LN2B, nullptr, nullptr, TERMS == 2);
-    LP_MARK(5);
-    {  // ---- feed-forward, 256 hidden channels at a time
-      f32x4 a2[2][4];
-#pragma unroll
-      for (int sl = 0; sl < 2; sl++) {  // the FF2 accumulator starts from its bias (no parameter read after the loop's last barrier)
-        float b2[8];
-        lds8(PAR_BFF2 + cw + 32 * sl + 8 * fg, b2);
-#pragma unroll
-        for (int pt = 0; pt < 2; pt++)
-#pragma unroll
-          for (int jt = 0; jt < 2; jt++) a2[pt][2 * sl + jt] = f32x4{b2[4 * jt], b2[4 * jt + 1], b2[4 * jt + 2], b2[4 * jt + 3]};
-      }
-      for (uint32_t c = 0; c < d_ff; c += 256) {
-        RELAUNDER();
-        f32x4 a1[2][4];
-        zero(a1);
-        tile_gemm_q<false, TERMS>(wstream(L.ff1, c + cw, 0, lane), wstream(L.ff2, cw, c, lane), w, s_hh, s_hl, fr, fg, a1);
-#pragma unroll
-        for (int sl = 0; sl < 2; sl++) {
-          float b1[8];
-          lds8(PAR_BFF1 + c + cw + 32 * sl + 8 * fg, b1);
-#pragma unroll
-          for (int pt = 0; pt < 2; pt++) {
-            float v[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) v[q] = fmaxf(a1[pt][2 * sl + (q >> 2)][q & 3] + b1[q], 0.f);
-            store_act(s_ah, s_al, hlsw(pt * 16 + fr, wave * 8 + sl * 4 + fg), v);
-          }
-        }
-        __syncthreads();
-        LP_MARK(6);
-        const bool more = c + 256 < d_ff;
-        const WStream nx = more ? wstream(L.ff1, c + 256 + cw, 0, lane) : wstream(Ln.qkv, cw, 0, lane);
-        tile_gemm_q<false, TERMS>(wstream(L.ff2, cw, c, lane), nx, w, s_ah, s_al, fr, fg, a2);
-        __syncthreads();
-        LP_MARK(7);
-      }
-#pragma unroll
-      for (int sl = 0; sl < 2; sl++)
-#pragma unroll
-        for (int pt = 0; pt < 2; pt++)
-#pragma unroll
-          for (int q = 0; q < 8; q++) x[pt][sl][q] += a2[pt][2 * sl + (q >> 2)][q & 3];
-    }
-    if (li + 1 < n_layers) stage_params(Ln);   // visible after the first barrier of the next LayerNorm
-  }
-  RELAUNDER();
-  layer_norm(0, 0, M.lnf_g, M.lnf_b, true);
-#undef RELAUNDER
-  if (wave < 2) {  // heads, three terms
-    const uint32_t pt = wave;
-    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-    const Weight& W = M.heads;
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++) {
-      const half8 wh = *reinterpret_cast<const half8*>(W.h16 + (uint64_t)fr * 256 + ks * 32 + fg * 8);
-      const half8 wl = *reinterpret_cast<const half8*>(W.l16 + (uint64_t)fr * 256 + ks * 32 + fg * 8);
-      const uint32_t o = hlsw(pt * 16 + fr, ks * 4 + fg);
-      const half8 xh = *reinterpret_cast<const half8*>(s_hh + o);
-      const half8 xl = *reinterpret_cast<const half8*>(s_hl + o);
-      a = mma(wl, xh, a);
-      a = mma(wh, xl, a);
-      a = mma(wh, xh, a);
-    }
-    const uint32_t tok = pt * 16 + fr;
-    if (tok < nt) {
-      const uint32_t n = t0 + tok, b = S.tok_win[n];
-      const uint64_t o = B.out_off[b] + (n - B.tok_off[b]);
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const uint32_t ch = 4 * fg + r;
-        const float v = a[r] + W.bias[ch];
-        if (ch == 0) B.out_info[o] = v;
-        else if (ch < 6) B.out_base[o * 5 + (ch - 1)] = v;
-      }
-    }
-  }
-  LP_MARK(8);
-}
-
 __global__ void k_build_tokens_h(BatchDev B, ModelScratch S) {
   const uint32_t b = blockIdx.x;
   const uint32_t t0 = B.tok_off[b], t1 = B.tok_off[b + 1];
@@ -1475,11 +1078,11 @@ bool model_h_supported(const ModelDev& M) {
          M.conv1g.ph16 && M.conv2.ph16 && M.fc.h16 && M.heads.h16 && M.heads.l16 && M.layer[0].qkv.ph16;
 }
 
-// HERRO_LAYERS_Q: 0 keeps every tile on the 64-token kernel, 2 sends every window of <= 32 rows to k_layers_q (both for A/B);
-// default 1: k_layers_q takes the short last round of a launch (plan_tiles, herro_api.hip)
+// HERRO_LAYERS_Q: 0 keeps every tile at 64 tokens, 2 puts every window of <= 32 rows into 32-token tiles (both for A/B);
+// default 1: 32-token tiles take the short last round of a launch (plan_tiles, herro_api.hip)
 int model_h_half_tiles(const ModelDev& M) {
   static const int mode = [] { const char* e = getenv("HERRO_LAYERS_Q"); return e ? std::max(0, std::min(2, atoi(e))) : 1; }();
-  return model_h_supported(M) && M.h.d_ff <= (uint32_t)PARQ_MAX_FF ? mode : 0;
+  return model_h_supported(M) ? mode : 0;
 }
 
 // B must be tileable (every window <= 64 informative rows; B.n_tiles + B.n_tiles_q > 0) — herro_job_infer sends larger windows
@@ -1516,24 +1119,12 @@ void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S,
   }
   KT_END(tm, st);
   KT_BEGIN(tm, "layers_fused", st);   // one span: the 64-token tiles (windows of 33..64 informative rows and what shares their tiles), then the 32-token ones
-  if (B.n_tiles) {
-    if (terms == 2) {
-      opt_in_lds(reinterpret_cast<const void*>(k_layers_p<2>), LAYERS_P_SHM);
-      hipLaunchKernelGGL(k_layers_p<2>, dim3(B.n_tiles), dim3(512), LAYERS_P_SHM, st, M, B, S);
-    } else {
-      opt_in_lds(reinterpret_cast<const void*>(k_layers_p<1>), LAYERS_P_SHM);
-      hipLaunchKernelGGL(k_layers_p<1>, dim3(B.n_tiles), dim3(512), LAYERS_P_SHM, st, M, B, S);
-    }
-  }
-  if (B.n_tiles_q) {
-    if (terms == 2) {
-      opt_in_lds(reinterpret_cast<const void*>(k_layers_q<2>), LAYERS_Q_SHM);
-      hipLaunchKernelGGL(k_layers_q<2>, dim3(B.n_tiles_q), dim3(256), LAYERS_Q_SHM, st, M, B, S);
-    } else {
-      opt_in_lds(reinterpret_cast<const void*>(k_layers_q<1>), LAYERS_Q_SHM);
-      hipLaunchKernelGGL(k_layers_q<1>, dim3(B.n_tiles_q), dim3(256), LAYERS_Q_SHM, st, M, B, S);
-    }
-  }
+  auto launch = [&](auto kern, uint32_t n_tiles, int tokens) {
+    opt_in_lds(reinterpret_cast<const void*>(kern), layers_p_shm(tokens));
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(512), layers_p_shm(tokens), st, M, B, S);
+  };
+  if (B.n_tiles) { if (terms == 2) launch(k_layers_p<2, 4>, B.n_tiles, 64); else launch(k_layers_p<1, 4>, B.n_tiles, 64); }
+  if (B.n_tiles_q) { if (terms == 2) launch(k_layers_p<2, 2>, B.n_tiles_q, 32); else launch(k_layers_p<1, 2>, B.n_tiles_q, 32); }
   KT_END(tm, st);
 }
 
