@@ -226,7 +226,10 @@ def main():
             c = api.Context(local)
             c.load_model(path)
             c.set_precision(args.precision)
-            c.set_reads(sb_.seq, sb_.qual, sb_.off)
+            if ctxs_:
+                c.share_reads(ctxs_[0])          # one read store per device (herro_share_reads), not one per context
+            else:
+                c.set_reads(sb_.seq, sb_.qual, sb_.off)
             ctxs_.append(c)
         jobs_ = [[api.job_from_synth(ctxs_[s_i], sb_, W, job_targets(s_i * pool + i)) for i in range(pool)] for s_i in range(NS)]
         rem_ = api.job_from_synth(ctxs_[0], sb_, W, range((n_jobs + n_e2e) * tpj, n_t)) if rem else None
@@ -339,7 +342,7 @@ def main():
             c = api.Context(local)
             c.load_model(path)
             c.set_precision(args.precision)
-            c.set_reads(sb.seq, sb.qual, sb.off)
+            c.share_reads(ctxs[0])
             ctxs.append(c)
         prep = api.PreparedAlignments(sb)   # the parsed alignments of the data set, resident on the host (outside the timed region)
 

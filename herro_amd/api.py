@@ -18,7 +18,7 @@ DEFAULT_PRECISION = 4
 
 EXPORTS = [
     "herro_version", "herro_create", "herro_destroy", "herro_last_error", "herro_set_stream", "herro_synchronize",
-    "herro_encode_2bit", "herro_decode_2bit", "herro_set_reads", "herro_set_reads_packed", "herro_load_model",
+    "herro_encode_2bit", "herro_decode_2bit", "herro_set_reads", "herro_set_reads_packed", "herro_share_reads", "herro_load_model",
     "herro_set_precision", "herro_model_describe", "herro_job_create", "herro_job_free", "herro_job_n_windows", "herro_job_skipped", "herro_job_featurize",
     "herro_job_infer", "herro_job_consensus", "herro_job_consensus_fetch", "herro_job_window_info", "herro_job_window_copy", "herro_job_window_logits",
     "herro_job_consensus_fasta", "herro_job_fasta", "herro_model_forward", "herro_timing_enable", "herro_timing_reset",
@@ -68,6 +68,7 @@ def lib():
         L.herro_decode_2bit.argtypes = [vp, u64, u64, u64, i32, vp]
         L.herro_set_reads.argtypes = [vp, u32, vp, vp, vp, vp]
         L.herro_set_reads_packed.argtypes = [vp, u32, vp, vp, vp, vp, vp]
+        L.herro_share_reads.argtypes = [vp, vp]
         L.herro_load_model.argtypes = [vp, C.c_char_p]
         L.herro_set_precision.argtypes = [vp, i32]
         L.herro_job_create.restype = vp
@@ -220,6 +221,10 @@ class Context:
         nc = None if name_class is None else np.ascontiguousarray(name_class, np.uint32)
         self._chk(self._l.herro_set_reads(self.h, len(off) - 1, seq.ctypes.data, qual.ctypes.data, off.ctypes.data,
                                           None if nc is None else nc.ctypes.data))
+
+    def share_reads(self, other: "Context"):
+        """Adopt the read store of another context of the same device (herro_share_reads): one copy in HBM per device."""
+        self._chk(self._l.herro_share_reads(self.h, other.h))
 
     def load_model(self, path: str):
         self._chk(self._l.herro_load_model(self.h, path.encode()))

@@ -154,6 +154,9 @@ struct herro_ctx {
   double* d_ln = nullptr;
   uint32_t ln_n = 0;
   uint64_t read_bytes = 0, qual_bytes = 0, n_words = 0;
+  // the device arrays of the read store belong to this owner: the contexts of one device can share ONE store (herro_share_reads);
+  // its memory is freed when the last context holding it lets go
+  std::shared_ptr<void> store_owner;
   // model
   bool has_model = false;
   ModelDev M{};
@@ -570,8 +573,8 @@ void herro_destroy(herro_ctx* ctx) {
 #endif
   }
   ctx->timer.reset();
-  for (void* p : {(void*)ctx->d_words, (void*)ctx->d_word_off, (void*)ctx->d_qual, (void*)ctx->d_qual_off, (void*)ctx->d_p0, (void*)ctx->d_p1, (void*)ctx->d_ln})
-    if (p) (void)hipFree(p);
+  ctx->store_owner.reset();   // the read store goes with its last holder
+  if (ctx->d_ln) (void)hipFree(ctx->d_ln);
   free_all(ctx->model_allocs);
   free_all(ctx->scratch_allocs);
   for (Arena& a : ctx->free_dev) (void)hipFree(a.p);
@@ -636,8 +639,7 @@ static int upload_reads(herro_ctx* ctx, uint32_t n_reads, const std::vector<uint
                         const std::vector<uint64_t>& qual_off, const uint32_t* name_class) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // nothing may still read the store that is about to be replaced
-  for (void* p : {(void*)ctx->d_words, (void*)ctx->d_word_off, (void*)ctx->d_qual, (void*)ctx->d_qual_off, (void*)ctx->d_p0, (void*)ctx->d_p1})
-    if (p) HIP_TRY(ctx, hipFree(p));
+  ctx->store_owner.reset();   // frees the previous store unless another context of the device still shares it
   ctx->d_p0 = nullptr; ctx->d_p1 = nullptr;
   ctx->d_words = nullptr; ctx->d_word_off = nullptr; ctx->d_qual = nullptr; ctx->d_qual_off = nullptr;
   hipError_t e;
@@ -681,6 +683,38 @@ static int upload_reads(herro_ctx* ctx, uint32_t n_reads, const std::vector<uint
   for (uint32_t i = 0; i < n_reads; i++) ctx->name_class[i] = name_class ? name_class[i] : i;
   ctx->read_bytes = words.size() * 8 + nq;
   ctx->reads_gen++;   // jobs built on the previous store hold descriptors into freed memory: they refuse to run from here on
+  {
+    const int dev = ctx->device;
+    void* ptrs[6] = {(void*)ctx->d_words, (void*)ctx->d_word_off, (void*)ctx->d_qual, (void*)ctx->d_qual_off, (void*)ctx->d_p0, (void*)ctx->d_p1};
+    struct Owned { int dev; void* p[6]; };
+    ctx->store_owner = std::shared_ptr<void>(new Owned{dev, {ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], ptrs[5]}}, [](void* v) {
+      Owned* o = (Owned*)v;
+      int cur = 0;
+      const bool have = hipGetDevice(&cur) == hipSuccess;
+      (void)hipSetDevice(o->dev);
+      for (void* q : o->p) if (q) (void)hipFree(q);
+      if (have) (void)hipSetDevice(cur);
+      delete o;
+    });
+  }
+  return HERRO_OK;
+}
+
+int herro_share_reads(herro_ctx* ctx, const herro_ctx* from) {
+  if (!ctx || !from || ctx == from) return HERRO_E_INVALID;
+  if (ctx->host_only || from->host_only) return HERRO_E_INVALID;
+  if (ctx->device != from->device) { ctx->err = "herro_share_reads: the contexts are on different devices"; return HERRO_E_INVALID; }
+  if (!from->store_owner) { ctx->err = "herro_share_reads: the source context has no read store"; return HERRO_E_STATE; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // nothing may still read the store that is about to be replaced
+  ctx->store_owner = from->store_owner;
+  ctx->d_words = from->d_words; ctx->d_word_off = from->d_word_off; ctx->d_qual = from->d_qual; ctx->d_qual_off = from->d_qual_off;
+  ctx->d_p0 = from->d_p0; ctx->d_p1 = from->d_p1;
+  ctx->qual_bytes = from->qual_bytes; ctx->n_words = from->n_words; ctx->read_bytes = from->read_bytes;
+  ctx->n_reads = from->n_reads;
+  ctx->h_word_off = from->h_word_off; ctx->h_qual_off = from->h_qual_off;
+  ctx->read_len = from->read_len; ctx->name_class = from->name_class;
+  ctx->reads_gen++;
   return HERRO_OK;
 }
 

@@ -613,7 +613,10 @@ def strong_leg(args, rank: int, world: int, local: int, n_windows: int, n_ctx: i
         c = api.Context(local)
         c.load_model(path)
         c.set_precision(args.precision)
-        c.set_reads(seq, qual, off)
+        if ctxs:
+            c.share_reads(ctxs[0])               # one read store per device
+        else:
+            c.set_reads(seq, qual, off)
         ctxs.append(c)
     fn = hip_corrector(ctxs, W, args.batch, lambda rid: f"read{rid}", group_targets=max(1, args.group * args.batch // wpt))
     nw = np.full(n_t, wpt, np.int64) if rank == 0 else None

@@ -89,6 +89,11 @@ int herro_set_reads(herro_ctx* ctx, uint32_t n_reads, const uint8_t* seq, const 
 int herro_set_reads_packed(herro_ctx* ctx, uint32_t n_reads, const uint64_t* words,
                            const uint64_t* word_off, const uint8_t* qual, const uint64_t* qual_off,
                            const uint32_t* name_class);
+/* One read store per DEVICE: `ctx` adopts the store `from` holds (same device) instead of packing and uploading its own copy —
+ * the reference's `reads: &[HAECRecord]` is likewise shared read-only by all feature threads (lib.rs:159-187).  The device memory
+ * is reference-counted and freed with its last holder; a later herro_set_reads on either context gives that context a store of
+ * its own again.  Jobs of `ctx` built on its previous store refuse to run, as after herro_set_reads. */
+int herro_share_reads(herro_ctx* ctx, const herro_ctx* from);
 
 /* ---- model ----------------------------------------------------------------------------------
  * Flat little-endian weight file written by tools/export_weights.py (stands in for

@@ -55,6 +55,7 @@ class FakeCtx:
     def load_model(self, p): pass
     def set_precision(self, m): pass
     def set_reads(self, *a): pass
+    def share_reads(self, other): assert isinstance(other, FakeCtx)
     def synchronize(self): pass
     def timing_enable(self, on=True): self.on = on
     def timing_reset(self): pass

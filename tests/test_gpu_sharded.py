@@ -21,7 +21,7 @@ def test_sharded_path_single_rank_matches_plain_job():
     c2 = api.Context(0)                       # a second context of the same GPU: two feeder threads, two jobs in flight each
     c2.load_model(model_io.default_model_file(G.CACHE)[0])
     c2.set_precision(api.DEFAULT_PRECISION)
-    c2.set_reads(sb.seq, sb.qual, sb.off)
+    c2.share_reads(c)                         # one read store per device: the second context adopts the first one's
     rec, n_mine = shard.correct_sharded(sb, nw, shard.hip_corrector([c, c2], W, 5, sb.read_name, group_targets=3))
     fasta = shard.sorted_fasta(*rec)
     assert n_mine == sb.n_targets and len(rec[0]) == sb.n_targets
@@ -44,4 +44,14 @@ def test_sharded_path_single_rank_matches_plain_job():
     assert text.decode() == "".join(job.consensus_fasta(t, sb.read_name(int(sb.tgt_rid[t]))) for t in range(sb.n_targets))
     assert int(ends[-1]) == len(text)
     job.close()
+    # the shared store outlives the context that uploaded it being given another one: c2 keeps working on the old store
+    sb2 = synth.generate(2, 600, 6, seed=4, flank_min=30, flank_max=50)
+    c.set_reads(sb2.seq, sb2.qual, sb2.off)
+    j2 = api.job_from_synth(c2, sb, W)
+    j2.featurize(); j2.infer(5, 1); j2.consensus()
+    assert j2.consensus_fasta(0, sb.read_name(int(sb.tgt_rid[0]))) == recs[0][1] if recs[0][0] == int(sb.tgt_rid[0]) else True
+    j2.close()
+    with pytest.raises(api.HerroError):
+        c2.share_reads(c2)
     c2.close()
+    G.load_synth(c, sb)                        # (the shared test context goes back to a known state)
