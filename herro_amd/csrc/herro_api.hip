@@ -817,7 +817,7 @@ int herro_load_model(herro_ctx* ctx, const char* path) {
   }
   std::fclose(f);
   if (!ok) { ctx->err = "malformed model file"; return HERRO_E_NO_MODEL; }
-  if (h.rows != HERRO_ROWS || h.n_layers > 16 || (h.kw & 1) == 0 || h.d_model % 64 || h.d_model / h.n_heads != 32 ||
+  if (h.rows != HERRO_ROWS || h.n_layers > 16 || (h.kw & 1) == 0 || h.d_model % 64 || h.d_model / h.n_heads != 32 || h.n_heads > 32 ||
       (h.kw * h.c1) % 32 || (h.rows * h.c2) % 32 || h.d_ff % 32 || h.c2 % 16) {
     ctx->err = "unsupported model hyper-parameters";
     return HERRO_E_UNSUPPORTED;

@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(256) void k_layernorm_s(const float* x, uint16_t* y
 // over 16 keys) took 330 us per layer for ten such windows.
 static constexpr int KC = 16;
 template <int DH>
-__global__ __launch_bounds__(128) void k_attention_s(BatchDev B, ModelScratch S, uint32_t D) {
+__global__ __launch_bounds__(512) void k_attention_s(BatchDev B, ModelScratch S, uint32_t D) {   // 16 lanes per head: up to 32 heads (d_model 1024); was bounded at 128 threads = 8 heads, and a 16-head model failed to launch
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* s_k = reinterpret_cast<float*>(smem);  // [KC][D]
   float* s_v = s_k + KC * D;                     // [KC][D]

@@ -298,3 +298,43 @@ def test_load_time_precision_choice(tmp_path):
             c.set_precision(4)
         c.set_precision(1)
     c.close()
+
+
+@pytest.mark.parametrize("hp_kw", [
+    dict(kw=5, c1=32, c2=64, d_model=128, n_heads=4, d_ff=512, n_layers=2),      # a smaller family member: wider kernel, 9-row receptive field... (4 * (kw / 2) + 1)
+    dict(kw=3, c1=64, c2=128, d_model=512, n_heads=16, d_ff=1024, n_layers=3),   # a wider residual stream
+    dict(kw=7, c1=32, c2=32, d_model=256, n_heads=8, d_ff=768, n_layers=5),      # the f16 kernels' d_model with another conv stack: 13-row receptive field
+])
+def test_other_hyper_parameters_run_on_the_generic_kernels(tmp_path, hp_kw):
+    """The f16 kernels serve ONE point of the architecture family (kw 3, 64 / 128 channels, d_model 256); any other member of it —
+    conv width, channels, d_model (heads of 32), d_ff, layer count — loads, is sent to the generic bf16x3 kernels by
+    herro_load_model (mode 1; herro_model_describe says so) and meets the same 1e-3 contract against its own dense twin."""
+    import model_ref as MR
+    hp = model_io.Hyper(**hp_kw)
+    raw = model_io.random_raw_params(hp, seed=77 + hp.kw)
+    path = str(tmp_path / "other.hrro")
+    model_io.export(raw, hp, path)
+    c = api.Context(0)
+    try:
+        c.load_model(path)
+        d = c.describe_model()
+        assert f"conv kw {hp.kw}" in d and f"d_model {hp.d_model}" in d and f"layers {hp.n_layers}" in d, d
+        assert "mode 1" in d, d
+        with pytest.raises(api.HerroError):
+            c.set_precision(4)                       # no f16 kernels for these shapes
+        rng = np.random.default_rng(5)
+        B, L = 4, 220
+        win_len = np.array([220, 200, 220, 130])
+        bases, quals = _rand_batch(rng, B, L, win_len)
+        idx = [np.sort(rng.choice(win_len[b], size=k, replace=False)) for b, k in enumerate([30, 1, 70, 12])]   # 70: a window above the 64-row tile
+        idx[0][:2] = [0, 1]
+        idx[2][-1] = 219
+        lens = np.array([len(i) for i in idx], np.int32)
+        flat = np.concatenate(idx).astype(np.int32)
+        info, base = c.model_forward(bases, quals, lens, flat)
+        ti, tb = MR.run_batch(MR.build(raw, hp), bases, quals, lens, flat)
+        err = max(np.abs(info - ti).max(), np.abs(base - tb).max())
+        print(f"{hp_kw}: max abs logit error {err:.3e}")
+        assert info.shape == ti.shape and err <= TOL
+    finally:
+        c.close()
