@@ -385,10 +385,12 @@ class Job:
             self.ctx._chk(int(n))
         return C.string_at(out, n).decode()   # (out.raw would copy the whole 16 MB buffer per call)
 
-    def fasta(self, read_ids, with_ends: bool = False, as_array: bool = False):
+    def fasta(self, read_ids, with_ends: bool = False, as_array: bool = False, out_alloc=None):
         """FASTA records of every target of the job, target order (herro_job_fasta: one sizing call, one call that writes the
         text straight into a numpy buffer; the library's thread pool assembles it).  read_ids: one str/bytes per target.
-        with_ends: also the end offset of every target's records.  as_array: the text as a u8 array (no bytes copy)."""
+        with_ends: also the end offset of every target's records.  as_array: the text as a u8 array (no bytes copy).
+        out_alloc(nbytes) -> u8 array: where the text goes (a reusable buffer: a fresh 16 MB array costs more in page faults than
+        the library needs to fill it)."""
         n = len(read_ids)
         if n != self.n_targets:   # the library reads one id and writes one end offset per target of the job
             raise ValueError(f"read_ids has {n} entries, the job has {self.n_targets} targets")
@@ -397,7 +399,7 @@ class Job:
         need = self._l.herro_job_fasta(self.h, arr, None, None, 0, ends.ctypes.data)
         if need < 0:
             self.ctx._chk(int(need))
-        out = np.empty(max(int(need), 1), np.uint8)
+        out = np.empty(max(int(need), 1), np.uint8) if out_alloc is None else out_alloc(max(int(need), 1))
         got = self._l.herro_job_fasta(self.h, arr, None, out.ctypes.data, int(need), None)
         if got < 0:
             self.ctx._chk(int(got))

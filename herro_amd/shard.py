@@ -313,6 +313,24 @@ def unpack_records(buf):
     return rids, ends, buf[o:o + nb]
 
 
+def _concat_u8(arrays) -> np.ndarray:
+    """np.concatenate for a few large u8 arrays, copied by several threads (numpy releases the GIL in the copy): the FASTA text of a
+    32768-window job set is 130 MB — one thread takes 30 ms over it, which was half of what the whole sharded leg took."""
+    arrays = [np.frombuffer(a, np.uint8) if isinstance(a, (bytes, bytearray, memoryview)) else a for a in arrays]
+    total = sum(len(a) for a in arrays)
+    if total < (8 << 20) or len(arrays) < 2:
+        return np.concatenate(arrays) if len(arrays) > 1 else arrays[0]
+    out = _scratch("concat", total)   # grow-only, reused: fresh pages cost more than the copy (the result is valid until the next call)
+    offs = np.cumsum([0] + [len(a) for a in arrays])
+    import concurrent.futures as cf
+
+    def put(i):
+        out[offs[i]:offs[i + 1]] = arrays[i]
+    with cf.ThreadPoolExecutor(min(8, len(arrays))) as ex:
+        list(ex.map(put, range(len(arrays))))
+    return out
+
+
 def merge_records(parts):
     """Concatenate (rids, ends, text) triples (ends rebased)."""
     parts = [p for p in parts if len(p[0])]
@@ -321,8 +339,7 @@ def merge_records(parts):
     if len(parts) == 1:
         return parts[0]
     base = np.cumsum([0] + [len(p[2]) for p in parts[:-1]]).astype(np.uint64)
-    return (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] + b for p, b in zip(parts, base)]),
-            np.concatenate([np.frombuffer(p[2], np.uint8) if isinstance(p[2], (bytes, bytearray)) else p[2] for p in parts]))
+    return (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] + b for p, b in zip(parts, base)]), _concat_u8([p[2] for p in parts]))
 
 
 def sorted_fasta(rids, ends, text) -> bytes:
@@ -557,7 +574,8 @@ def hip_corrector(ctxs, window_size: int, batch: int, read_name, group_targets: 
             job.infer(batch, 1)
             job.consensus()
             job.consensus_fetch()
-            text, ends = job.fasta([read_name(int(r)) for r in rids[t0:t1]], with_ends=True, as_array=True)
+            text, ends = job.fasta([read_name(int(r)) for r in rids[t0:t1]], with_ends=True, as_array=True,
+                                   out_alloc=lambda nb: _scratch(("fasta", g), nb))   # per group a reusable buffer (valid until the next pass)
             out[g] = (rids[t0:t1], ends, text)
             job.close()
 
