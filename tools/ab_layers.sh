@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of the encoder stack: 32-token tiles, two workgroups per compute unit (k_layers_q, default) against 64-token tiles only
+# A/B of the encoder stack: HERRO_LAYERS_Q=1 (32-token tiles for the short last round; during round 4 also k_layers_q) against 64-token tiles only
 # (HERRO_LAYERS_Q=0), device-resident bench leg, default launch size and the driver's.  usage: gpurun -- bash tools/ab_layers.sh tag
 tag=${1:-ab}
 mkdir -p gpurun_out/$tag
