@@ -26,6 +26,8 @@ EXPORTS = [
     "herro_paf_parse", "herro_oec_read", "herro_paf_n_targets", "herro_paf_target_ids", "herro_paf_aln_off",
     "herro_paf_alignments", "herro_paf_free", "herro_name_index_create", "herro_name_index_free", "herro_paf_parse_indexed",
     "herro_oec_read_indexed", "herro_paf_parse_view", "herro_debug_host_ctx", "herro_debug_job_array", "herro_debug_tile_plan",
+    "herro_pool_create", "herro_pool_destroy", "herro_pool_last_error", "herro_pool_size", "herro_pool_ctx", "herro_pool_set_reads", "herro_pool_load_model",
+    "herro_pool_correct", "herro_pool_result", "herro_pool_groups_taken",
     "herro_fastx_read", "herro_reads_count", "herro_reads_seq", "herro_reads_qual", "herro_reads_off", "herro_reads_ids",
     "herro_reads_descs", "herro_reads_free", "herro_write_window_features", "herro_job_write_features",
 ]
@@ -69,6 +71,23 @@ def lib():
         L.herro_set_reads.argtypes = [vp, u32, vp, vp, vp, vp]
         L.herro_set_reads_packed.argtypes = [vp, u32, vp, vp, vp, vp, vp]
         L.herro_share_reads.argtypes = [vp, vp]
+        L.herro_pool_create.restype = vp
+        L.herro_pool_create.argtypes = [vp, u32]
+        L.herro_pool_destroy.argtypes = [vp]
+        L.herro_pool_last_error.restype = C.c_char_p
+        L.herro_pool_last_error.argtypes = [vp]
+        L.herro_pool_size.restype = u32
+        L.herro_pool_size.argtypes = [vp]
+        L.herro_pool_ctx.restype = vp
+        L.herro_pool_ctx.argtypes = [vp, u32]
+        L.herro_pool_set_reads.argtypes = [vp, u32, vp, vp, vp, vp]
+        L.herro_pool_load_model.argtypes = [vp, C.c_char_p]
+        L.herro_pool_correct.restype = C.c_int64
+        L.herro_pool_correct.argtypes = [vp, u32, vp, vp, vp, u32, u32, i32, u32, vp, vp]
+        L.herro_pool_result.restype = vp
+        L.herro_pool_result.argtypes = [vp, vp]
+        L.herro_pool_groups_taken.restype = u32
+        L.herro_pool_groups_taken.argtypes = [vp, u32]
         L.herro_load_model.argtypes = [vp, C.c_char_p]
         L.herro_set_precision.argtypes = [vp, i32]
         L.herro_job_create.restype = vp
@@ -175,6 +194,68 @@ def debug_tile_plan(counts, packed: bool = True, qmode: int = 0, n_cu: int = 256
         raise HerroError(int(n), "herro_debug_tile_plan")
     out = (int(n), int(n_half.value), order[:len(c)]) if qmode else (int(n), order[:len(c)])
     return out + (tok[:int(n) + int(n_half.value) + 1],) if bounds else out
+
+
+class Pool:
+    """herro_pool (csrc/pool.cpp): several contexts of one process fed from one queue of target groups — the in-process layout of
+    lib.rs:154-200.  device_ids: one entry per context (several may name the same GPU: they share its read store)."""
+
+    def __init__(self, device_ids):
+        self._l = lib()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        self.h = self._l.herro_pool_create(ids, len(device_ids))
+        if not self.h:
+            raise HerroError(-1, self._l.herro_last_error(None).decode(errors="replace"))
+        self.n = len(device_ids)
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise HerroError(int(rc), self._l.herro_pool_last_error(self.h).decode(errors="replace"))
+        return rc
+
+    def set_reads(self, seq, qual, off, name_class=None):
+        seq, qual, off = np.ascontiguousarray(seq, np.uint8), np.ascontiguousarray(qual, np.uint8), np.ascontiguousarray(off, np.uint64)
+        nc = None if name_class is None else np.ascontiguousarray(name_class, np.uint32)
+        self._chk(self._l.herro_pool_set_reads(self.h, len(off) - 1, seq.ctypes.data, qual.ctypes.data, off.ctypes.data, None if nc is None else nc.ctypes.data))
+
+    def load_model(self, path: str):
+        self._chk(self._l.herro_pool_load_model(self.h, path.encode()))
+
+    def set_precision(self, mode: int):
+        for i in range(self.n):
+            rc = self._l.herro_set_precision(self._l.herro_pool_ctx(self.h, i), mode)
+            if rc:
+                raise HerroError(rc, self._l.herro_last_error(self._l.herro_pool_ctx(self.h, i)).decode(errors="replace"))
+
+    def correct(self, rids, rows, aln_off, cig_blob, cig_off, window_size: int, batch: int, read_ids, batch_mode: int = 1, group_targets: int = 1024):
+        """FASTA text (u8 array) of all targets in target order + the end offset of every target's records."""
+        rids = np.ascontiguousarray(rids, np.uint32)
+        aln_off = np.ascontiguousarray(aln_off, np.uint64)
+        rows = np.ascontiguousarray(rows, np.uint32).reshape(-1, 10)
+        blob = np.ascontiguousarray(cig_blob, np.uint8)
+        m = len(rows)
+        raw = np.zeros((max(m, 1), 12), np.uint32)            # herro_alignment: 10 u32 + the CIGAR pointer
+        if m:
+            raw[:m, :10] = rows
+            raw[:m, 10:12] = (np.asarray(cig_off, np.uint64) + np.uint64(blob.ctypes.data)).view(np.uint32).reshape(m, 2)
+        names = (C.c_char_p * max(len(read_ids), 1))(*[r if isinstance(r, bytes) else r.encode() for r in read_ids])
+        if len(read_ids) != len(rids):
+            raise ValueError("one read id per target")
+        n = self._chk(self._l.herro_pool_correct(self.h, len(rids), rids.ctypes.data, aln_off.ctypes.data, raw.ctypes.data, window_size, batch, batch_mode,
+                                                 group_targets, names, None))
+        ends_p = C.c_void_p()
+        tp = self._l.herro_pool_result(self.h, C.byref(ends_p))
+        text = np.ctypeslib.as_array((C.c_uint8 * n).from_address(tp)).copy() if n else np.zeros(0, np.uint8)
+        ends = np.ctypeslib.as_array((C.c_uint64 * len(rids)).from_address(ends_p.value)).copy() if len(rids) else np.zeros(0, np.uint64)
+        return text, ends
+
+    def groups_taken(self):
+        return [int(self._l.herro_pool_groups_taken(self.h, i)) for i in range(self.n)]
+
+    def close(self):
+        if self.h:
+            self._l.herro_pool_destroy(self.h)
+            self.h = None
 
 
 @dataclass

@@ -309,6 +309,31 @@ int herro_write_window_features(const char* dir, uint32_t wid, const char* const
  * written or a negative error. */
 int64_t herro_job_write_features(herro_job* job, const char* base_dir, const char* const* read_names);
 
+/* ---- several contexts (GPUs) of ONE process fed from one queue (csrc/pool.cpp) --------------------------------------------------
+ * Replaces the thread layout of lib.rs:154-200 (per device: `t` feature threads + one inference thread pulling from one MPMC
+ * channel; one writer, lib.rs:267-291): herro_pool_create makes one context per entry of device_ids (several entries may name the
+ * same device: its contexts share one read store) with a worker thread each; herro_pool_correct cuts the targets into groups of
+ * `group_targets` reads and the workers PULL groups from one shared counter — whoever is free takes the next one — keeping two
+ * jobs in flight per context (the next group is created while the GPU works on the current one).  The FASTA records of all
+ * targets, in target order, stay with the pool until the next call: herro_pool_result returns the text and (via *rec_end) the
+ * end offset of every target's records; the return value of herro_pool_correct is the text's length (< 0: HERRO_E_*, message in
+ * herro_pool_last_error).  ids / descs: one C string per target (descs or its entries may be NULL), as for herro_job_fasta.
+ * herro_pool_ctx exposes a context (e.g. for herro_set_precision, herro_model_describe); herro_pool_groups_taken says how many
+ * groups context i took in the last call.  A client of this header only: every result is what the per-job calls give. */
+typedef struct herro_pool herro_pool;
+herro_pool* herro_pool_create(const int* device_ids, uint32_t n_ctx);
+void herro_pool_destroy(herro_pool* pool);
+const char* herro_pool_last_error(const herro_pool* pool);
+uint32_t herro_pool_size(const herro_pool* pool);
+herro_ctx* herro_pool_ctx(herro_pool* pool, uint32_t i);
+int herro_pool_set_reads(herro_pool* pool, uint32_t n_reads, const uint8_t* seq, const uint8_t* qual, const uint64_t* off, const uint32_t* name_class);
+int herro_pool_load_model(herro_pool* pool, const char* path);
+int64_t herro_pool_correct(herro_pool* pool, uint32_t n_targets, const uint32_t* rids, const uint64_t* aln_off, const herro_alignment* alns,
+                           uint32_t window_size, uint32_t batch_size, int batch_mode, uint32_t group_targets, const char* const* ids,
+                           const char* const* descs);
+const char* herro_pool_result(const herro_pool* pool, const uint64_t** rec_end);
+uint32_t herro_pool_groups_taken(const herro_pool* pool, uint32_t i);
+
 #ifdef __cplusplus
 }
 #endif

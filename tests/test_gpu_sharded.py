@@ -55,3 +55,37 @@ def test_sharded_path_single_rank_matches_plain_job():
         c2.share_reads(c2)
     c2.close()
     G.load_synth(c, sb)                        # (the shared test context goes back to a known state)
+
+
+def test_pool_of_contexts_fed_from_one_queue_matches_plain_job():
+    """herro_pool (csrc/pool.cpp, the in-process layout of lib.rs:154-200): three contexts of the GPU pull groups of two targets from
+    one shared counter; the FASTA of all targets, in target order, equals what one plain job gives; every group was taken once."""
+    W = 512
+    sb = synth.generate(9, 4 * 512 + 33, 12, seed=92, flank_min=60, flank_max=90, p_partial=0.2)
+    pool = api.Pool([0, 0, 0])
+    try:
+        pool.load_model(model_io.default_model_file(G.CACHE)[0])
+        pool.set_precision(api.DEFAULT_PRECISION)
+        pool.set_reads(sb.seq, sb.qual, sb.off)
+        names = [sb.read_name(int(r)) for r in sb.tgt_rid]
+        text, ends = pool.correct(sb.tgt_rid, sb.aln, sb.tgt_aln_off, sb.cig, sb.cig_off, W, 5, names, group_targets=2)
+        taken = pool.groups_taken()
+        assert sum(taken) == 5 and len(taken) == 3
+        c = G.ctx()
+        c.set_precision(api.DEFAULT_PRECISION)
+        G.load_synth(c, sb)
+        want = []
+        for t0 in range(0, sb.n_targets, 2):      # the same grouping: cross-read batches of 5 windows inside groups of two targets
+            job = api.job_from_synth(c, sb, W, range(t0, min(t0 + 2, sb.n_targets)))
+            job.featurize(); job.infer(5, 1); job.consensus()
+            want.append(job.fasta(names[t0:t0 + 2]))
+            job.close()
+        assert text.tobytes() == b"".join(want)
+        assert int(ends[-1]) == len(text) and np.all(np.diff(ends.astype(np.int64)) >= 0)
+        # an input the reference panics on: the pool reports it with the reference's message
+        bad = sb.aln.copy()
+        bad[0, 5] = bad[0, 5] + 1                 # tid != rid of its group
+        with pytest.raises(api.HerroError):
+            pool.correct(sb.tgt_rid, bad, sb.tgt_aln_off, sb.cig, sb.cig_off, W, 5, names, group_targets=2)
+    finally:
+        pool.close()
