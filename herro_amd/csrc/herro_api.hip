@@ -1494,6 +1494,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.prof = ctx->d_prof;
   J.n_ow = n_ow; J.n_win = n_win; J.n_cls = n_cls;
   J.n_tiles = (uint32_t)job->tile_win.size(); J.window_size = W; J.nw = (W + 31) / 32; J.max_cols = max_cols;
+  { const char* e = getenv("HERRO_DEBUG_CDIR_OVERFLOW"); J.dbg_flags = (e && atoi(e)) ? 1u : 0u; }
   cur = desc_bytes;
   const size_t o_cpl = take(((uint64_t)n_ow + 1) * 3 * J.nw * 4), o_iev = take(scr_ops * 16), o_ins_cnt = take((uint64_t)n_ow * 4);
   const size_t o_ocol = take((uint64_t)n_ow * 16);

@@ -44,6 +44,7 @@ struct JobDev {
   uint32_t ln_table_n;
   // ---- descriptors (uploaded by herro_job_create)
   uint32_t n_ow, n_win, n_cls, n_tiles, window_size;
+  uint32_t dbg_flags;  // bit 0 (HERRO_DEBUG_CDIR_OVERFLOW=1 at job creation): k_cols marks every directory record as not fitting, so that k_rfq's counting path runs (tests)
   uint32_t nw;        // plane words per column: ceil(window_size / 32)
   uint32_t max_cols;  // 1 + max overlaps per window (sizes the bit-sliced counters)
   const uint32_t* ops;

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
         const uint32_t de = dE[wi_i] == 0xffffffffu ? (((int32_t)(wi << 5) < off) ? 0u : n_ev) : dE[wi_i];
         // one 8-byte record per word {M word, query index | events << 20}: a slot of k_rfq reads this word's and the next one's
         // from one sector.  Indices that do not fit (2^20 bases / 2^12 events in one overlap-window) are flagged; k_rfq then counts
-        J.cdir[(uint64_t)o * nw + wi] = make_uint2(pM[wi_i], (dQ[wi_i] < (1u << 20) && de < 0xfffu) ? (dQ[wi_i] | (de << 20)) : 0xffffffffu);
+        J.cdir[(uint64_t)o * nw + wi] = make_uint2(pM[wi_i], (dQ[wi_i] < (1u << 20) && de < 0xfffu && !(J.dbg_flags & 1u)) ? (dQ[wi_i] | (de << 20)) : 0xffffffffu);
       }
     }
   }

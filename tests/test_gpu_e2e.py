@@ -150,3 +150,29 @@ def test_baseline_workload_end_to_end():
     assert n_rec == sb.n_targets
     c.set_precision(api.DEFAULT_PRECISION)
     job.close()
+
+
+def test_rfq_counting_path_equals_directory_path(monkeypatch):
+    """k_rfq reads a cell's query index from k_cols' per-word directory; a record whose fields do not fit (2^20 bases / 2^12 events in
+    one overlap-window) is flagged and k_rfq COUNTS instead (M bits and events in front of the word).  HERRO_DEBUG_CDIR_OVERFLOW=1 flags
+    every record: the receptive-field qualities — seen through the logits — must not change by a bit."""
+    sb = synth.generate(16, 3 * 1024 + 50, 14, seed=31, flank_min=60, flank_max=90, p_partial=0.25)
+    c = G.ctx()
+    c.set_precision(api.DEFAULT_PRECISION)
+    G.load_synth(c, sb)
+
+    def logits():
+        job = api.job_from_synth(c, sb, 1024)
+        job.featurize(); job.infer(16, 1)
+        out = [job.logits(w) for w in range(job.n_windows)]
+        job.close()
+        return out
+    ref = logits()
+    monkeypatch.setenv("HERRO_DEBUG_CDIR_OVERFLOW", "1")
+    got = logits()
+    monkeypatch.delenv("HERRO_DEBUG_CDIR_OVERFLOW")
+    n = 0
+    for a, b in zip(ref, got):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        n += len(a[0])
+    assert n >= 20, n   # informative rows compared
