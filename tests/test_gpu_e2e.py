@@ -123,6 +123,10 @@ def test_baseline_workload_end_to_end():
                 gi, gb = job.logits(wv)
                 e_info = max(e_info, float(np.abs(gi - ref[wv][0]).max()))
                 e_base = max(e_base, float(np.abs(gb - ref[wv][1]).max()))
+                if bs == 128 and prec == api.DEFAULT_PRECISION:
+                    # this pass reads the COMPLETE quality planes (materialised by the window copies above, bit-exact against the oracle);
+                    # the first pass read k_rfq's compact receptive fields: same bytes -> the same logits to the bit, every window
+                    assert np.array_equal(gi, first[wv][0]) and np.array_equal(gb, first[wv][1]), f"receptive-field qualities differ from the planes, window {wv}"
             errs[f"bs{bs}_p{prec}"] = {"info": e_info, "base": e_base, "windows": len(sel), "tokens": int(nsup[sel].sum())}
     try:
         os.makedirs(os.path.join(G.ROOT, "gpurun_out"), exist_ok=True)
