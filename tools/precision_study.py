@@ -50,10 +50,39 @@ def make_mm(fmt):
     return mm
 
 
-def forward(F, hp, bases, quals, lens, indices, mm, mm_fc=None, mm_att=None):
-    """model_numpy.forward with pluggable matmuls (mm_fc: conv2 + FC; mm_att: QK^T and PV)."""
+def mx_fp8(x, dt, block=32):
+    """x rounded to an MX-style fp8: blocks of 32 along the last axis share a power-of-two scale (e8m0), elements in `dt`."""
+    x = np.asarray(x, np.float32)
+    K = x.shape[-1]
+    pad = (-K) % block
+    xp = np.pad(x, [(0, 0)] * (x.ndim - 1) + [(0, pad)]).reshape(x.shape[:-1] + ((K + pad) // block, block))
+    amax = np.abs(xp).max(-1, keepdims=True)
+    top = 448.0 if dt == torch.float8_e4m3fn else 57344.0
+    sc = np.where(amax > 0, 2.0 ** np.floor(np.log2(np.maximum(amax, 1e-38) / top) + 1), 1.0).astype(np.float32)   # block max lands in (top / 2, top]
+    q = torch.from_numpy(np.ascontiguousarray(xp / sc)).to(dt).to(torch.float32).numpy() * sc
+    return q.reshape(x.shape[:-1] + (K + pad,))[..., :K].astype(np.float32)
+
+
+def make_mm_f16_lo8(dt8):
+    """activation hi (f16) x weight (f16)  +  activation remainder (MX fp8) x weight (MX fp8): the lo term on the fp8 matrix pipe"""
+    hf = torch.float16
+
+    def mm(a, wt):
+        a = np.asarray(a, np.float32)
+        ah = rnd(a, hf)
+        wh = rnd(wt, hf)
+        al8 = mx_fp8(a - ah, dt8)
+        w8 = mx_fp8(wt, dt8)
+        return (ah @ wh.T).astype(np.float32) + (al8 @ w8.T).astype(np.float32)
+    return mm
+
+
+def forward(F, hp, bases, quals, lens, indices, mm, mm_fc=None, mm_att=None, by=None):
+    """model_numpy.forward with pluggable matmuls (mm_fc: conv2 + FC; mm_att: QK^T and PV; by: {'qkv' | 'proj' | 'ff1' | 'ff2' | 'heads': matmul})."""
     mm_fc = mm_fc or mm
     mm_att = mm_att or mm
+    by = by or {}
+    g = lambda name: by.get(name, mm)
     f = np.float64 if mm is make_mm("f64") else np.float32
     B, L, R = bases.shape
     kw, c1, c2, D = hp.kw, hp.c1, hp.c2, hp.d_model
@@ -89,7 +118,7 @@ def forward(F, hp, bases, quals, lens, indices, mm, mm_fc=None, mm_att=None):
     for li in range(hp.n_layers):
         p = f"L{li}."
         hb = MN.layernorm(x, F[p + "ln1.g"], F[p + "ln1.b"], hp.ln_eps)
-        qkv = mm(hb, F[p + "qkv.wt"]) + F[p + "qkv.b"]
+        qkv = g("qkv")(hb, F[p + "qkv.wt"]) + F[p + "qkv.b"]
         att = np.zeros_like(x)
         for b in range(B):
             s, e = starts[b], starts[b + 1]
@@ -102,12 +131,12 @@ def forward(F, hp, bases, quals, lens, indices, mm, mm_fc=None, mm_att=None):
                 sc = mm_att(q, k)
                 sc = np.exp(sc - sc.max(-1, keepdims=True))
                 att[s:e, hd * dh:(hd + 1) * dh] = mm_att(sc, v.T) / sc.sum(-1, keepdims=True)
-        x = x + mm(att, F[p + "proj.wt"]) + F[p + "proj.b"]
+        x = x + g("proj")(att, F[p + "proj.wt"]) + F[p + "proj.b"]
         hb = MN.layernorm(x, F[p + "ln2.g"], F[p + "ln2.b"], hp.ln_eps)
-        ff = np.maximum(mm(hb, F[p + "ff1.wt"]) + F[p + "ff1.b"], 0)
-        x = x + mm(ff, F[p + "ff2.wt"]) + F[p + "ff2.b"]
+        ff = np.maximum(g("ff1")(hb, F[p + "ff1.wt"]) + F[p + "ff1.b"], 0)
+        x = x + g("ff2")(ff, F[p + "ff2.wt"]) + F[p + "ff2.b"]
     hb = MN.layernorm(x, F["lnf.g"], F["lnf.b"], hp.ln_eps)
-    lg = mm(hb, F["heads.wt"]) + F["heads.b"]
+    lg = g("heads")(hb, F["heads.wt"]) + F["heads.b"]
     return lg[:, :6]
 
 
@@ -142,6 +171,14 @@ def main():
         for name, fmt in (("stack f16 x1, conv/FC bf16x3", (hf, 1, 1, 1)), ("stack f16 x2 act, conv/FC bf16x3", (hf, 2, 1, 2)),
                           ("stack f16 x2 wt, conv/FC bf16x3", (hf, 1, 2, 2))):
             out = forward(F, hp, bases, quals, lens, idx, make_mm(fmt), mm_fc=make_mm((bf, 2, 2, 2)))
+            e = np.abs(out - ref)
+            print(f"  {name:34s} max {e.max():.2e}  rms {np.sqrt((e**2).mean()):.2e}")
+        # precision 4 as shipped (conv2 / FC / attention / QKV single f16, proj / FF1 / FF2 activation hi + lo, heads three terms) and the same
+        # with the lo term of proj / FF1 / FF2 on MX fp8 operands (round 4 study for the next step: the lo MFMAs are 58 % of the stack's issue)
+        one, two, three = make_mm((hf, 1, 1, 1)), make_mm((hf, 2, 1, 2)), make_mm((hf, 2, 2, 2))
+        for name, lo in (("p4: proj/FF lo term f16", two), ("p4': lo term MX e4m3", make_mm_f16_lo8(torch.float8_e4m3fn)),
+                         ("p4'': lo term MX e5m2", make_mm_f16_lo8(torch.float8_e5m2)), ("p5: no lo term", one)):
+            out = forward(F, hp, bases, quals, lens, idx, one, by={"proj": lo, "ff1": lo, "ff2": lo, "heads": three})
             e = np.abs(out - ref)
             print(f"  {name:34s} max {e.max():.2e}  rms {np.sqrt((e**2).mean()):.2e}")
         for name, fmt in (("stack bf16x3, conv/FC f16 x1", (hf, 1, 1, 1)), ("stack bf16x3, conv/FC f16 x2 act", (hf, 2, 1, 2))):
