@@ -25,7 +25,7 @@ EXPORTS = [
     "herro_timing_get", "herro_job_stats", "herro_debug_extract_windows",
     "herro_paf_parse", "herro_oec_read", "herro_paf_n_targets", "herro_paf_target_ids", "herro_paf_aln_off",
     "herro_paf_alignments", "herro_paf_free", "herro_name_index_create", "herro_name_index_free", "herro_paf_parse_indexed",
-    "herro_oec_read_indexed", "herro_paf_parse_view", "herro_debug_host_ctx", "herro_debug_job_array", "herro_debug_tile_plan",
+    "herro_oec_read_indexed", "herro_paf_parse_view", "herro_debug_host_ctx", "herro_debug_job_array", "herro_debug_tile_plan", "herro_debug_tile_plan_sib",
     "herro_pool_create", "herro_pool_destroy", "herro_pool_last_error", "herro_pool_size", "herro_pool_ctx", "herro_pool_set_reads", "herro_pool_load_model",
     "herro_pool_correct", "herro_pool_result", "herro_pool_groups_taken",
     "herro_fastx_read", "herro_reads_count", "herro_reads_seq", "herro_reads_qual", "herro_reads_off", "herro_reads_ids",
@@ -143,6 +143,8 @@ def lib():
         L.herro_debug_job_array.argtypes = [vp, i32, vp, vp]
         L.herro_debug_tile_plan.restype = C.c_int64
         L.herro_debug_tile_plan.argtypes = [vp, u32, i32, u32, vp, vp, vp]
+        L.herro_debug_tile_plan_sib.restype = i32
+        L.herro_debug_tile_plan_sib.argtypes = [vp, u32, i32, u32, vp, vp, vp, vp]
         _LIB = L
     return _LIB
 
@@ -194,6 +196,21 @@ def debug_tile_plan(counts, packed: bool = True, qmode: int = 0, n_cu: int = 256
         raise HerroError(int(n), "herro_debug_tile_plan")
     out = (int(n), int(n_half.value), order[:len(c)]) if qmode else (int(n), order[:len(c)])
     return out + (tok[:int(n) + int(n_half.value) + 1],) if bounds else out
+
+
+def debug_tile_plan_sib(counts, packed: bool = True, qmode: int = 1, n_cu: int = 256):
+    """Token-tile plan with windows above 64 rows admitted (herro_debug_tile_plan_sib): (n_sibling, n64, n32, order, tile bounds, grp)."""
+    c = np.ascontiguousarray(counts, np.uint32)
+    order = np.zeros(max(len(c), 1), np.uint32)
+    cap = int(((c.astype(np.int64) + 63) // 64).sum()) + 2
+    n_tiles = np.zeros(3, np.uint32)
+    tok = np.zeros(cap, np.uint32)
+    grp = np.zeros(cap, np.uint32)
+    rc = lib().herro_debug_tile_plan_sib(c.ctypes.data, len(c), int(packed) | (qmode << 1), n_cu, order.ctypes.data, n_tiles.ctypes.data, tok.ctypes.data, grp.ctypes.data)
+    if rc < 0:
+        raise HerroError(int(rc), "herro_debug_tile_plan_sib")
+    nb, n64, n32 = (int(x) for x in n_tiles)
+    return nb, n64, n32, order[:len(c)], tok[:nb + n64 + n32 + 1], grp[:nb]
 
 
 class Pool:

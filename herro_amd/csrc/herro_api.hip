@@ -168,6 +168,9 @@ struct herro_ctx {
   std::string calib_note;
   ModelScratch S{};
   uint32_t scratch_cap = 0;
+  void* sib_kv = nullptr;       // sibling tiles of the f16 stack (ensure_sib): K / V exchange, flags + error word
+  void* sib_flag = nullptr;
+  uint32_t sib_cap = 0;
   std::vector<void*> scratch_allocs;
   KernelTimer timer;
   // job memory: ONE device arena and ONE pinned host arena per job, recycled through these free lists (a job used to
@@ -355,6 +358,7 @@ struct ArenaReturn {
 // windows of <= FUSED_MAX_TOK informative rows only (larger windows run layer by layer, see split_launch).
 static constexpr uint32_t FUSED_MAX_TOK = 64;
 static constexpr uint32_t FUSED_HALF_TOK = 32;   // tile of k_layers_p<., 2> (the short last round of a launch)
+static constexpr uint32_t FUSED_MAX_SIB = 8;     // sibling tiles of one window in the f16 stack (k_layers_p<., 4, true>): windows of up to 512 informative rows stay fused
 static std::vector<uint32_t> token_tiles(const std::vector<uint32_t>& tok_off, size_t w0 = 0, size_t w1 = ~size_t(0), uint32_t cap = FUSED_MAX_TOK) {
   w1 = std::min(w1, tok_off.size() - 1);
   if (w0 >= w1) return std::vector<uint32_t>();
@@ -409,8 +413,35 @@ static std::vector<uint32_t> tile_pack_order(const std::vector<uint32_t>& cnt) {
 // tiles go into 32-token tiles instead, one per compute unit (2560 windows of the bench: 625 tiles = 2 rounds + 113 -> 2 rounds
 // + 226 half tiles).  qmode 2 (A/B): every window of <= 32 rows goes into 32-token tiles; a window of 33..64 opens a 64-token
 // tile and takes the best-fitting small windows along.  Without `pack` the windows keep their batch order inside each class.
-struct TilePlan { std::vector<uint32_t> order, tiles, tiles_q; };
+// Windows above 64 rows (the caller admits them up to 64 * FUSED_MAX_SIB, f16 stack only) come FIRST in the stream, each one alone
+// on ceil(rows / 64) consecutive tiles (`tiles_b`; grp[t] = first tile of the window's group | tiles in it << 24).
+struct TilePlan { std::vector<uint32_t> order, tiles, tiles_q, tiles_b, grp; };
+static TilePlan plan_tiles_small(const std::vector<uint32_t>& cnt, bool pack, int qmode, uint32_t n_cu, uint32_t n_busy = 0);
 static TilePlan plan_tiles(const std::vector<uint32_t>& cnt, bool pack, int qmode, uint32_t n_cu) {
+  std::vector<uint32_t> big, small, small_cnt;
+  for (size_t i = 0; i < cnt.size(); i++) (cnt[i] > FUSED_MAX_TOK ? big : small).push_back((uint32_t)i);
+  if (big.empty()) return plan_tiles_small(cnt, pack, qmode, n_cu);
+  for (uint32_t i : small) small_cnt.push_back(cnt[i]);
+  uint32_t n_sib = 0;
+  for (uint32_t i : big) n_sib += (cnt[i] + FUSED_MAX_TOK - 1) / FUSED_MAX_TOK;
+  TilePlan P = plan_tiles_small(small_cnt, pack, qmode, n_cu, n_sib);   // the sibling tiles share the grid of the 64-token tiles: they count in its rounds
+  for (uint32_t& o : P.order) o = small[o];
+  uint32_t tok = 0;
+  P.tiles_b.push_back(0);
+  for (uint32_t i : big) {
+    const uint32_t k = (cnt[i] + FUSED_MAX_TOK - 1) / FUSED_MAX_TOK, g0 = (uint32_t)P.grp.size();
+    for (uint32_t j = 0; j < k; j++) {
+      P.grp.push_back(g0 | (k << 24));
+      P.tiles_b.push_back(tok + std::min(cnt[i], (j + 1) * FUSED_MAX_TOK));
+    }
+    tok += cnt[i];
+  }
+  for (uint32_t& t : P.tiles) t += tok;
+  for (uint32_t& t : P.tiles_q) t += tok;
+  P.order.insert(P.order.begin(), big.begin(), big.end());
+  return P;
+}
+static TilePlan plan_tiles_small(const std::vector<uint32_t>& cnt, bool pack, int qmode, uint32_t n_cu, uint32_t n_busy) {
   TilePlan P;
   const size_t n = cnt.size();
   std::vector<uint32_t> tok_off(1, 0);
@@ -426,8 +457,10 @@ static TilePlan plan_tiles(const std::vector<uint32_t>& cnt, bool pack, int qmod
     else { P.order.resize(n); for (size_t i = 0; i < n; i++) P.order[i] = (uint32_t)i; }
     finish(n);
     const size_t n64 = P.tiles.empty() ? 0 : P.tiles.size() - 1;
-    const size_t r = n_cu ? n64 % n_cu : 0;
-    if (qmode == 0 || r == 0 || 2 * r > n_cu) return P;
+    const size_t rr = n_cu ? (n64 + n_busy) % n_cu : 0;   // tiles of the last round (n_busy: sibling tiles at the head of the same grid)
+    if (qmode == 0 || rr == 0 || 2 * rr > n_cu) return P;
+    const size_t r = std::min(rr, n64);
+    if (r == 0) return P;
     // windows of the last r tiles: the small ones leave for 32-token tiles, a large one stays (in front of them)
     const uint32_t cut_tok = P.tiles[n64 - r];
     size_t k0 = 0;
@@ -487,6 +520,44 @@ static TilePlan plan_tiles(const std::vector<uint32_t>& cnt, bool pack, int qmod
 // One model launch over a set of windows.  Fused stacks (precision 1, 4, 5) take tiles of whole windows of at most
 // 64 informative rows; a window above that does not make the launch group fall off the fused path any more: the
 // group is split into its small windows (tiles) and its large ones (layer-by-layer bf16x3 kernels, precision 3).
+// Most informative rows of a window that stays on the fused stack: 64 (one tile), or 64 * FUSED_MAX_SIB with the f16 stack, which
+// spreads a larger window over sibling tiles (HERRO_FUSED_BIG=0: such windows go layer by layer as before, for A/B).
+static uint32_t fused_tok_cap(const herro_ctx* ctx) {
+  static const bool big = [] { const char* e = getenv("HERRO_FUSED_BIG"); return !e || atoi(e) != 0; }();
+  return (big && ctx->precision >= 4 && model_h_supported(ctx->M)) ? FUSED_MAX_TOK * FUSED_MAX_SIB : FUSED_MAX_TOK;
+}
+// K / V exchange buffers and flags of `n_tiles_b` sibling tiles (128 KB per tile)
+static int ensure_sib(herro_ctx* ctx, uint32_t n_tiles_b) {
+  if (n_tiles_b <= ctx->sib_cap) return HERRO_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->sib_kv) (void)hipFree(ctx->sib_kv);
+  if (ctx->sib_flag) (void)hipFree(ctx->sib_flag);
+  ctx->sib_kv = nullptr; ctx->sib_flag = nullptr; ctx->sib_cap = 0;
+  const uint32_t cap = n_tiles_b + n_tiles_b / 2 + 8;
+  if (hipMalloc(&ctx->sib_kv, (size_t)cap * 2 * 8 * 8 * 64 * 16) != hipSuccess || hipMalloc(&ctx->sib_flag, ((size_t)cap + 1) * 4) != hipSuccess ||
+      hipMemset(ctx->sib_flag, 0, ((size_t)cap + 1) * 4) != hipSuccess) {
+    if (ctx->sib_kv) (void)hipFree(ctx->sib_kv);
+    ctx->sib_kv = nullptr;
+    ctx->err = "out of device memory for the sibling-tile buffers";
+    return HERRO_E_NO_DEVICE;
+  }
+  ctx->sib_cap = cap;
+  ctx->S.sib_kv = (uint16_t*)ctx->sib_kv;
+  ctx->S.sib_flag = (uint32_t*)ctx->sib_flag;
+  ctx->S.sib_err = (uint32_t*)ctx->sib_flag + cap;
+  return HERRO_OK;
+}
+// the sticky error word of the sibling tiles (checked where the logits come back to the host)
+static int check_sib(herro_ctx* ctx) {
+  if (!ctx->sib_flag) return HERRO_OK;
+  uint32_t e = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&e, (uint32_t*)ctx->sib_flag + ctx->sib_cap, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (!e) return HERRO_OK;
+  ctx->err = "fused stack: a sibling tile of a window above 64 informative rows never published its keys (layer " + std::to_string(e - 1) + "); logits invalid";
+  return HERRO_E_STATE;
+}
 static void run_model(herro_ctx* ctx, const BatchDev& B, bool tiled) {
   if (B.n_tok == 0) return;
   const int p = ctx->precision;
@@ -577,6 +648,8 @@ void herro_destroy(herro_ctx* ctx) {
   if (ctx->d_ln) (void)hipFree(ctx->d_ln);
   free_all(ctx->model_allocs);
   free_all(ctx->scratch_allocs);
+  if (ctx->sib_kv) (void)hipFree(ctx->sib_kv);
+  if (ctx->sib_flag) (void)hipFree(ctx->sib_flag);
   for (Arena& a : ctx->free_dev) (void)hipFree(a.p);
   for (Arena& a : ctx->free_pin) (void)hipHostFree(a.p);
   for (Arena& a : ctx->free_small) (void)hipFree(a.p);
@@ -1099,6 +1172,7 @@ static int ensure_scratch(herro_ctx* ctx, uint32_t n_tok) {
     ctx->err = "out of device memory for model scratch (" + std::to_string(cap) + " tokens)";
     return HERRO_E_NO_DEVICE;
   }
+  S.sib_kv = ctx->S.sib_kv; S.sib_flag = ctx->S.sib_flag; S.sib_err = ctx->S.sib_err;   // ensure_sib's, sized on their own
   ctx->S = S;
   ctx->scratch_cap = (uint32_t)cap;
   return HERRO_OK;
@@ -1733,10 +1807,11 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
     std::memcpy(blob.data() + o, p, bytes);
     return o;
   };
-  struct Offs { size_t plane_off, plane_ld, len, lmax, tok_off, sup_off, out_off, tiles, tiles_q; uint32_t n_tiles, n_tiles_q, n_win, n_tok, max_win_tok; bool tiled; };
+  struct Offs { size_t plane_off, plane_ld, len, lmax, tok_off, sup_off, out_off, tiles, tiles_q, tiles_b, grp; uint32_t n_tiles, n_tiles_q, n_tiles_b, n_win, n_tok, max_win_tok; bool tiled; };
   std::vector<Offs> offs;
-  uint32_t max_tok = 0;
+  uint32_t max_tok = 0, max_tiles_b = 0;
   const bool fused_mode = ctx->precision == 1 || ctx->precision >= 4;
+  const uint32_t tok_cap = fused_tok_cap(ctx);   // most informative rows of a window on the fused stack
   const int qmode = ctx->precision >= 4 ? model_h_half_tiles(ctx->M) : 0;
   for (auto& g : groups) {
     for (int part = 0; part < 2; part++) {  // 0: windows that fit a fused tile (all of them in the unfused modes), 1: the rest
@@ -1745,7 +1820,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
       for (size_t bi = g.b0; bi < g.b1; bi++) {
         const BatchPlan& bp = job->batches[bi];
         for (uint32_t w : bp.wins) {
-          const bool large = fused_mode && job->h_nsup[w] > FUSED_MAX_TOK;
+          const bool large = fused_mode && job->h_nsup[w] > tok_cap;
           if ((int)large != part) continue;
           sel.push_back(w);
           sel_lmax.push_back(bp.lmax);   // the padding length is that of the window's BATCH, whichever launch it runs in
@@ -1780,8 +1855,12 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
       o.tiles = put(plan.tiles.data(), plan.tiles.size() * 4);
       o.n_tiles_q = plan.tiles_q.empty() ? 0u : (uint32_t)plan.tiles_q.size() - 1;
       o.tiles_q = put(plan.tiles_q.data(), plan.tiles_q.size() * 4);
+      o.n_tiles_b = (uint32_t)plan.grp.size();
+      o.tiles_b = put(plan.tiles_b.data(), plan.tiles_b.size() * 4);
+      o.grp = put(plan.grp.data(), plan.grp.size() * 4);
       offs.push_back(o);
       max_tok = std::max(max_tok, o.n_tok);
+      max_tiles_b = std::max(max_tiles_b, o.n_tiles_b);
     }
   }
   const size_t supoff_at = put(job->sup_off.data(), ((size_t)n + 1) * 8);  // consensus reads it from the same blob
@@ -1797,6 +1876,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   job->d_supoff_blob = (const uint64_t*)((const unsigned char*)job->d_bdesc + supoff_at);
   rc = ensure_scratch(ctx, max_tok);
   if (rc) return rc;
+  if (max_tiles_b && (rc = ensure_sib(ctx, max_tiles_b))) return rc;
   // the qualities the model will read: rows within 2 * (kw / 2) of an informative row (two stacked convs)
   const uint32_t rf_half = 2 * (ctx->M.h.kw / 2);
   const bool rf_compact = !job->quals_full && job->d_rfq && 2 * rf_half + 1 <= 8;   // the model reads the compact receptive fields; else the planes
@@ -1818,6 +1898,9 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
     B.tile_tok0 = (const uint32_t*)(base + o.tiles);
     B.n_tiles_q = o.n_tiles_q;
     B.tile_tok0_q = (const uint32_t*)(base + o.tiles_q);
+    B.n_tiles_b = o.n_tiles_b;
+    B.tile_tok0_b = (const uint32_t*)(base + o.tiles_b);
+    B.tile_grp = (const uint32_t*)(base + o.grp);
     B.planes_b = job->J.fin_b; B.planes_q = job->J.fin_q; B.sup_row = job->J.sup_row;
     B.rf_q = rf_compact ? job->d_rfq : nullptr;
     B.out_info = job->d_info; B.out_base = job->d_base;
@@ -1942,6 +2025,7 @@ static int logits_to_host(herro_job* job) {
   job->h_base.resize(tot * 5);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->timer.collect();
+  if (int rc = check_sib(ctx)) return rc;
   if (tot) {
     HIP_TRY(ctx, hipMemcpy(job->h_info.data(), job->d_info, tot * 4, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(job->h_base.data(), job->d_base, tot * 20, hipMemcpyDeviceToHost));
@@ -1972,6 +2056,7 @@ static int consensus_to_host(herro_job* job) {
   if (job->row_elems) HIP_TRY(ctx, hipMemcpyAsync(job->h_cons_seq, job->J.cons_seq, job->row_elems, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->timer.collect();
+  if (int rc = check_sib(ctx)) return rc;
   job->consensus_on_host = true;
   return HERRO_OK;
 }
@@ -2249,7 +2334,7 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
     const bool tiled = fused_mode && part == 0;
     std::vector<uint32_t> sel, sel_cnt;
     for (uint32_t b = 0; b < B; b++) {
-      const bool large = fused_mode && (uint32_t)lens[b] > FUSED_MAX_TOK;
+      const bool large = fused_mode && (uint32_t)lens[b] > fused_tok_cap(ctx);
       if ((int)large != part) continue;
       sel.push_back(b);
       sel_cnt.push_back((uint32_t)lens[b]);
@@ -2274,8 +2359,12 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
     bd.n_tiles = P.plan.tiles.empty() ? 0u : (uint32_t)P.plan.tiles.size() - 1;
     bd.tile_tok0_q = (const uint32_t*)up(P.plan.tiles_q.data(), P.plan.tiles_q.size() * 4);
     bd.n_tiles_q = P.plan.tiles_q.empty() ? 0u : (uint32_t)P.plan.tiles_q.size() - 1;
+    bd.tile_tok0_b = (const uint32_t*)up(P.plan.tiles_b.data(), P.plan.tiles_b.size() * 4);
+    bd.tile_grp = (const uint32_t*)up(P.plan.grp.data(), P.plan.grp.size() * 4);
+    bd.n_tiles_b = (uint32_t)P.plan.grp.size();
+    if (bd.n_tiles_b && (rc = ensure_sib(ctx, bd.n_tiles_b))) { (void)hipStreamSynchronize(st); return done(rc); }
     bd.planes_b = d_pb; bd.planes_q = d_pq; bd.rf_q = nullptr; bd.sup_row = d_sr; bd.out_info = d_info; bd.out_base = d_base;
-    if (!bd.plane_off || !bd.plane_ld || !bd.len || !bd.lmax || !bd.tok_off || !bd.sup_off || !bd.out_off || !bd.tile_tok0 || !bd.tile_tok0_q || e != hipSuccess) {
+    if (!bd.plane_off || !bd.plane_ld || !bd.len || !bd.lmax || !bd.tok_off || !bd.sup_off || !bd.out_off || !bd.tile_tok0 || !bd.tile_tok0_q || !bd.tile_tok0_b || !bd.tile_grp || e != hipSuccess) {
       ctx->err = e != hipSuccess ? hipGetErrorString(e) : "out of device memory";
       (void)hipStreamSynchronize(st);
       return done(HERRO_E_NO_DEVICE);
@@ -2286,6 +2375,7 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return done(HERRO_E_NO_DEVICE); }
   ctx->timer.collect();
+  if ((rc = check_sib(ctx))) return done(rc);
   HIP_TRY(ctx, hipMemcpy(info_logits, d_info, N * 4, hipMemcpyDeviceToHost));
   HIP_TRY(ctx, hipMemcpy(bases_logits, d_base, N * 20, hipMemcpyDeviceToHost));
   return done(HERRO_OK);
@@ -2360,6 +2450,33 @@ int64_t herro_debug_tile_plan(const uint32_t* cnt, uint32_t n, int packed, uint3
     tile_tok[k] = n32 ? P.tiles_q.back() : (n64 ? P.tiles.back() : 0);
   }
   return (int64_t)n64;
+}
+
+// The same with windows above 64 rows admitted (up to 64 * 8: the f16 stack's sibling tiles, plan_tiles): n_tiles[3] = sibling tiles,
+// 64-token tiles, 32-token tiles; tile_tok (capacity sum(ceil(cnt / 64)) + 2) the first tokens of all tiles in stream order
+// (sibling tiles first) + end; grp (capacity = the sibling tiles) first tile of the window's group | tiles in it << 24.
+int herro_debug_tile_plan_sib(const uint32_t* cnt, uint32_t n, int packed, uint32_t n_cu, uint32_t* order, uint32_t* n_tiles, uint32_t* tile_tok, uint32_t* grp) {
+  if (!cnt || !order || !n_tiles) return HERRO_E_INVALID;
+  std::vector<uint32_t> c(cnt, cnt + n);
+  for (uint32_t v : c) if (v == 0 || v > FUSED_MAX_TOK * FUSED_MAX_SIB) return HERRO_E_INVALID;
+  const TilePlan P = plan_tiles(c, (packed & 1) != 0, (packed >> 1) & 3, n_cu);
+  for (uint32_t i = 0; i < n; i++) order[i] = P.order[i];
+  const size_t nb = P.grp.size(), n64 = P.tiles.empty() ? 0 : P.tiles.size() - 1, n32 = P.tiles_q.empty() ? 0 : P.tiles_q.size() - 1;
+  if (nb && P.tiles_b.size() != nb + 1) return HERRO_E_STATE;
+  n_tiles[0] = (uint32_t)nb; n_tiles[1] = (uint32_t)n64; n_tiles[2] = (uint32_t)n32;
+  if (tile_tok) {
+    size_t k = 0;
+    uint32_t end = 0;
+    for (size_t i = 0; i < nb; i++) tile_tok[k++] = P.tiles_b[i];
+    if (nb) end = P.tiles_b.back();
+    for (size_t i = 0; i < n64; i++) tile_tok[k++] = P.tiles[i];
+    if (n64) end = P.tiles.back();
+    for (size_t i = 0; i < n32; i++) tile_tok[k++] = P.tiles_q[i];
+    if (n32) end = P.tiles_q.back();
+    tile_tok[k] = end;
+  }
+  if (grp) for (size_t i = 0; i < nb; i++) grp[i] = P.grp[i];
+  return HERRO_OK;
 }
 
 int64_t herro_debug_extract_windows(const herro_alignment* a, uint32_t n_windows, uint32_t W, uint64_t* out,

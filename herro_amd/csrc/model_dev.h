@@ -85,6 +85,11 @@ struct BatchDev {
   const uint32_t* tile_tok0;  // [n_tiles+1] first token of each tile
   uint32_t n_tiles_q;         // tiles of <= 32 tokens behind them in the token stream (k_layers_p<., 2>: the short last round of a launch); 0: none
   const uint32_t* tile_tok0_q;  // [n_tiles_q+1]
+  // windows of 65 .. 64 * FUSED_MAX_SIB informative rows (f16 stack): each one alone on ceil(rows / 64) consecutive 64-token
+  // tiles at the HEAD of the token stream and of the 64-token grid — sibling tiles, which exchange their K / V fragments layer by layer (k_layers_p<., 4, true>)
+  uint32_t n_tiles_b;
+  const uint32_t* tile_tok0_b;  // [n_tiles_b+1]
+  const uint32_t* tile_grp;     // [n_tiles_b] first tile of the window's group | tiles in the group << 24
   float* out_info;            // job-level [sum nsup]
   float* out_base;            // job-level [sum nsup][5]
 };
@@ -131,6 +136,11 @@ struct ModelScratch {  // sized for n_tok tokens
   uint16_t *h_hi, *h_lo;      // [N][d_model]
   uint16_t *att_hi, *att_lo;  // [N][d_model]
   uint16_t *ff_hi, *ff_lo;    // [N][d_ff]
+  // sibling tiles of the f16 stack (windows above 64 informative rows): K / V fragments [tile][layer parity][wave = head][8 fragments][64 lanes] x 16 B,
+  // flags [tile] = layers published so far (zeroed before every launch), one sticky error word (a sibling never showed up)
+  uint16_t* sib_kv;
+  uint32_t* sib_flag;
+  uint32_t* sib_err;
 };
 
 void launch_model(const ModelDev& M, const BatchDev& B, const ModelScratch& S, int precision,

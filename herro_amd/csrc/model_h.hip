@@ -672,8 +672,12 @@ __device__ unsigned long long g_lp_prof[16];
 #define LP_MARK(ph) do { } while (0)
 #endif
 
-template <int TERMS, int PT>
+template <int TERMS, int PT, bool SIB = false>
 __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelScratch S) {
+  static_assert(!SIB || PT == 4, "sibling tiles are 64-token tiles");
+  // SIB: the grid starts with the batch's B.n_tiles_b sibling tiles (windows above 64 informative rows), the ordinary tiles follow
+  const bool big = SIB && blockIdx.x < B.n_tiles_b;
+  const uint32_t bt = SIB ? (big ? blockIdx.x : blockIdx.x - B.n_tiles_b) : blockIdx.x;
   constexpr int HLT = 16 * PT;   // tokens per tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* s_hh = reinterpret_cast<uint16_t*>(smem);
@@ -686,8 +690,9 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   LP_BEGIN();
   uint32_t fr = lane & 15, fg = lane >> 4;
-  const uint32_t* tile_tok0 = PT == 4 ? B.tile_tok0 : B.tile_tok0_q;
-  const uint32_t t0 = tile_tok0[blockIdx.x], nt = tile_tok0[blockIdx.x + 1] - t0;
+  const uint32_t* tile_tok0 = PT == 4 ? (big ? B.tile_tok0_b : B.tile_tok0) : B.tile_tok0_q;
+  const uint32_t t0 = tile_tok0[bt], nt = tile_tok0[bt + 1] - t0;
+  const uint32_t grp = big ? B.tile_grp[bt] : 0u;   // the window's sibling tiles: first | count << 24
   const uint32_t cw = wave * 32;
   const float eps = M.h.ln_eps;
   const uint32_t n_layers = M.h.n_layers, d_ff = M.h.d_ff;
@@ -874,6 +879,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
       for (int pj = 0; pj < PT; pj++)
 #pragma unroll
         for (int r = 0; r < 4; r++) wj[pj][r] = s_win[pj * 16 + 4 * fg + r];
+      if (!SIB || !big) {
 #pragma unroll
       for (int pi = 0; pi < PT; pi++) {
         const uint32_t wi = s_win[pi * 16 + fr];
@@ -914,6 +920,139 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] = o[e >> 2][e & 3] * inv;
         store_act(s_ah, s_al, hlsw(pi * 16 + fr, wave * 4 + fg), v);
+      }
+      } else {
+        // ---- a window above 64 informative rows: its tiles (siblings) hold 64 of its tokens each.  Every tile publishes the K / V
+        // fragments of its heads in REGISTER layout (a sibling's wave loads them straight into MFMA operands), attends to its own
+        // keys from registers, then walks the siblings' blocks with a running maximum / sum (the softmax over all keys of the window,
+        // accumulated block by block).  Two buffers by layer parity: a sibling is at most one layer ahead (it needs OUR keys of its
+        // layer before it can finish it).  Co-residency: the siblings are consecutive workgroups at the HEAD of the grid and workgroups
+        // are dispatched in index order, so the lowest unfinished group always has all its tiles on the chip (and in a batch's first
+        // round they all start together: no sibling waits for a compute unit while the others hold theirs).
+        {
+          uint16_t* mine = S.sib_kv + ((((uint64_t)bt * 2 + (li & 1u)) * 8 + wave) * 8 * 64 + lane) * 8;
+#pragma unroll
+          for (int pt = 0; pt < PT; pt++) *reinterpret_cast<half8*>(mine + pt * 512) = kh[pt];
+#pragma unroll
+          for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+            for (int kk = 0; kk < PT / 2; kk++) *reinterpret_cast<half8*>(mine + (PT + ct * (PT / 2) + kk) * 512) = vh[ct][kk];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the siblings run on other XCDs, behind their own L2: write back, once per wave
+          __syncthreads();
+          if (tid == 0) __hip_atomic_store(S.sib_flag + bt, li + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        float mrun[PT], lrun[PT];
+        f32x4 orun[PT][2];
+#pragma unroll
+        for (int pi = 0; pi < PT; pi++) {   // own keys first: every query finds itself there, the running maximum is finite from here on
+          const uint32_t wi = s_win[pi * 16 + fr];
+          f32x4 st[PT];
+          float m = -INFINITY;
+#pragma unroll
+          for (int pj = 0; pj < PT; pj++) {
+            st[pj] = mma(kh[pj], qh[pi], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              st[pj][r] = wj[pj][r] == wi ? st[pj][r] : -INFINITY;
+              m = fmaxf(m, st[pj][r]);
+            }
+          }
+          m = fg_max(m);
+          float l = 0.f;
+#pragma unroll
+          for (int pj = 0; pj < PT; pj++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const float pexp = __expf(st[pj][r] - m);
+              st[pj][r] = pexp;
+              l += pexp;
+            }
+          mrun[pi] = m;
+          lrun[pi] = fg_sum(l);
+          orun[pi][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+          orun[pi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < PT / 2; kk++) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = st[2 * kk + (e >> 2)][e & 3];
+            const half8 ph = pack_h8(v);
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++) orun[pi][ct] = mma(vh[ct][kk], ph, orun[pi][ct]);
+          }
+        }
+        const uint32_t g0 = grp & 0xffffffu, gk = grp >> 24;
+#pragma unroll 1
+        for (uint32_t sb = g0; sb < g0 + gk; sb++) {
+          if (sb == bt) continue;
+          uint32_t spins = 0;
+          // poll without cache maintenance (an acquiring load invalidates caches on every turn, for the whole XCD); ONE acquire when the flag is up
+          while (__hip_atomic_load(S.sib_flag + sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= li) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > (1u << 21)) {   // ~ seconds: the sibling is not coming (it would be a planner bug) — give up LOUDLY instead of hanging the device
+              if (lane == 0) atomicExch(S.sib_err, 1u + li);
+              break;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          const uint32_t nts = tile_tok0[sb + 1] - tile_tok0[sb];
+          const uint16_t* src = S.sib_kv + ((((uint64_t)sb * 2 + (li & 1u)) * 8 + wave) * 8 * 64 + lane) * 8;
+          half8 kf[PT], vf[2][PT / 2];
+#pragma unroll
+          for (int pt = 0; pt < PT; pt++) kf[pt] = *reinterpret_cast<const half8*>(src + pt * 512);
+#pragma unroll
+          for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+            for (int kk = 0; kk < PT / 2; kk++) vf[ct][kk] = *reinterpret_cast<const half8*>(src + (PT + ct * (PT / 2) + kk) * 512);
+#pragma unroll
+          for (int pi = 0; pi < PT; pi++) {
+            f32x4 st[PT];
+            float bm = -INFINITY;
+#pragma unroll
+            for (int pj = 0; pj < PT; pj++) {
+              st[pj] = mma(kf[pj], qh[pi], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+              for (int r = 0; r < 4; r++) {
+                st[pj][r] = (uint32_t)(pj * 16 + 4 * fg + r) < nts ? st[pj][r] : -INFINITY;   // the sibling's real tokens: all of them are this window's
+                bm = fmaxf(bm, st[pj][r]);
+              }
+            }
+            const float mn = fmaxf(mrun[pi], fg_max(bm));
+            const float alpha = __expf(mrun[pi] - mn);
+            float l = 0.f;
+#pragma unroll
+            for (int pj = 0; pj < PT; pj++)
+#pragma unroll
+              for (int r = 0; r < 4; r++) {
+                const float pexp = __expf(st[pj][r] - mn);
+                st[pj][r] = pexp;
+                l += pexp;
+              }
+            lrun[pi] = lrun[pi] * alpha + fg_sum(l);
+            mrun[pi] = mn;
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+              for (int r = 0; r < 4; r++) orun[pi][ct][r] *= alpha;
+#pragma unroll
+            for (int kk = 0; kk < PT / 2; kk++) {
+              float v[8];
+#pragma unroll
+              for (int e = 0; e < 8; e++) v[e] = st[2 * kk + (e >> 2)][e & 3];
+              const half8 ph = pack_h8(v);
+#pragma unroll
+              for (int ct = 0; ct < 2; ct++) orun[pi][ct] = mma(vf[ct][kk], ph, orun[pi][ct]);
+            }
+          }
+        }
+#pragma unroll
+        for (int pi = 0; pi < PT; pi++) {
+          const float inv = 1.0f / lrun[pi];
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] = orun[pi][e >> 2][e & 3] * inv;
+          store_act(s_ah, s_al, hlsw(pi * 16 + fr, wave * 4 + fg), v);
+        }
       }
     }
     __syncthreads();
@@ -1085,11 +1224,11 @@ int model_h_half_tiles(const ModelDev& M) {
   return model_h_supported(M) ? mode : 0;
 }
 
-// B must be tileable (every window <= 64 informative rows; B.n_tiles + B.n_tiles_q > 0) — herro_job_infer sends larger windows
-// through the layer-by-layer kernels of model.hip.  terms: 2 (precision 4) or 1 (precision 5).
+// B must be tileable (windows of <= 64 informative rows in B.tile_tok0 / _q, windows of 65 .. 64 * 8 rows on sibling tiles, B.tile_tok0_b) —
+// herro_job_infer sends still larger windows through the layer-by-layer kernels of model.hip.  terms: 2 (precision 4) or 1 (precision 5).
 void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S, int terms, hipStream_t st, KernelTimer* tm) {
   const uint32_t N = B.n_tok;
-  if (N == 0 || B.n_tiles + B.n_tiles_q == 0) return;
+  if (N == 0 || B.n_tiles + B.n_tiles_q + B.n_tiles_b == 0) return;
   const ModelHyper& h = M.h;
   KT_BEGIN(tm, "build_tokens", st);
   hipLaunchKernelGGL(k_build_tokens_h, dim3(B.n_win), dim3(64), 0, st, B, S);
@@ -1123,7 +1262,10 @@ void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S,
     opt_in_lds(reinterpret_cast<const void*>(kern), layers_p_shm(tokens));
     hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(512), layers_p_shm(tokens), st, M, B, S);
   };
-  if (B.n_tiles) { if (terms == 2) launch(k_layers_p<2, 4>, B.n_tiles, 64); else launch(k_layers_p<1, 4>, B.n_tiles, 64); }
+  if (B.n_tiles_b) {   // sibling tiles of the windows above 64 informative rows at the head of ONE grid with the ordinary 64-token tiles
+    (void)hipMemsetAsync(S.sib_flag, 0, (size_t)B.n_tiles_b * 4, st);
+    if (terms == 2) launch(k_layers_p<2, 4, true>, B.n_tiles_b + B.n_tiles, 64); else launch(k_layers_p<1, 4, true>, B.n_tiles_b + B.n_tiles, 64);
+  } else if (B.n_tiles) { if (terms == 2) launch(k_layers_p<2, 4>, B.n_tiles, 64); else launch(k_layers_p<1, 4>, B.n_tiles, 64); }
   if (B.n_tiles_q) { if (terms == 2) launch(k_layers_p<2, 2>, B.n_tiles_q, 32); else launch(k_layers_p<1, 2>, B.n_tiles_q, 32); }
   KT_END(tm, st);
 }

@@ -73,7 +73,7 @@ def test_model_forward_tiling_edges(counts):
     ti, tb = MR.run_batch(G.twin(), bases, quals, lens, flat)
     assert info.shape == ti.shape and base.shape == tb.shape
     assert max(np.abs(info - ti).max(), np.abs(base - tb).max()) <= TOL
-    c.set_precision(4)   # f16 kernels: same tiles, windows above 64 rows through the layer-by-layer kernels
+    c.set_precision(4)   # f16 kernels: same tiles; windows above 64 rows on sibling tiles of the same stack (next test)
     info4, base4 = c.model_forward(bases, quals, lens, flat)
     assert max(np.abs(info4 - ti).max(), np.abs(base4 - tb).max()) <= TOL
     c.set_precision(5)   # the single-term instances of the same kernels
@@ -83,6 +83,40 @@ def test_model_forward_tiling_edges(counts):
     info3, base3 = c.model_forward(bases, quals, lens, flat)
     c.set_precision(1)
     assert max(np.abs(info3 - info).max(), np.abs(base3 - base).max()) <= 1e-4   # same arithmetic, different kernels
+
+
+@pytest.mark.parametrize("counts", [
+    [65],                                        # two sibling tiles, 64 + 1
+    [200, 7],                                    # four siblings (64 64 64 8) next to an ordinary tile
+    [128, 129, 64, 3],                           # exact multiples and one over; 64 stays a single tile
+    [512, 513, 10, 257, 1, 300],                 # 8 siblings = the limit; 513 rows leave for the layer-by-layer kernels
+    [70] * 40,                                   # 80 sibling tiles in one launch
+])
+def test_windows_above_64_rows_on_sibling_tiles(counts):
+    """f16 stack (precision 4 / 5): a window of 65 .. 512 informative rows is spread over ceil(rows / 64) sibling tiles of
+    k_layers_p<., 4, true>, which exchange the K / V fragments of their heads layer by layer and accumulate the softmax over all
+    the window's keys block by block (inference.rs:134-141 takes any `lens`).  Against the dense twin, same 1e-3 contract."""
+    import model_ref as MR
+    rng = np.random.default_rng(11 + len(counts))
+    B, L = len(counts), max(220, max(counts) + 40)
+    win_len = rng.integers(max(counts), L + 1, B)
+    win_len[0] = L
+    bases, quals = _rand_batch(rng, B, L, win_len)
+    idx = [np.sort(rng.choice(win_len[b], size=k, replace=False)) for b, k in enumerate(counts)]
+    lens = np.array([len(i) for i in idx], np.int32)
+    flat = np.concatenate(idx).astype(np.int32)
+    ti, tb = MR.run_batch(G.twin(), bases, quals, lens, flat)
+    c = G.ctx()
+    try:
+        for prec in (4, 5):
+            c.set_precision(prec)
+            info, base = c.model_forward(bases, quals, lens, flat)
+            assert info.shape == ti.shape and base.shape == tb.shape
+            err = max(np.abs(info - ti).max(), np.abs(base - tb).max())
+            print(f"precision {prec}, windows of {counts[:6]} rows: max abs logit error {err:.3e}")
+            assert err <= (TOL if prec == 4 else 4e-3), (prec, err)
+    finally:
+        c.set_precision(api.DEFAULT_PRECISION)
 
 
 def test_full_width_fc_kernel_matches():

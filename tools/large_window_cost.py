@@ -1,7 +1,9 @@
 """GPU: what windows with more than 64 informative rows cost.  The fused encoder stack takes tiles of whole windows of at
-most 64 rows; larger windows of a launch run through the layer-by-layer bf16x3 kernels (herro_api.hip run_model).  Times the
-model kernels (HIP events of the context's KernelTimer) of one collated batch of B windows, all small, against the same
-batch with 1 % of the windows enlarged to 100 rows.  usage: python tools/large_window_cost.py [B]"""
+most 64 rows; a larger window (up to 512 rows) is spread over sibling tiles of the same stack, which run beside the ordinary
+tiles (HERRO_FUSED_BIG=0: through the layer-by-layer bf16x3 kernels as in round 3; HERRO_SIB_STREAM=0: sibling tiles in front of
+the ordinary ones instead of beside them).  Times the model kernels (HIP events of the context's KernelTimer) of one collated
+batch of B windows, all small, against the same batch with 1 % of the windows enlarged to 100 rows.
+usage: python tools/large_window_cost.py [B]"""
 import json
 import os
 import sys
