@@ -164,7 +164,7 @@ struct herro_ctx {
   int precision = 1;
   bool precision_set = false;   // herro_set_precision was called: herro_load_model keeps the caller's choice
   float wmax = 0.f;             // largest |weight| of the loaded model
-  float calib_err = -1.f;       // max |logit difference| mode 4 vs mode 1 on the calibration batch (-1: not run)
+  float calib_err = -1.f;       // max |logit difference| mode 4 vs mode 0 (f32 MFMA) on the calibration batch (-1: not run)
   std::string calib_note;
   ModelScratch S{};
   uint32_t scratch_cap = 0;

@@ -20,7 +20,9 @@
 //   k_conv_m   embedding + quality + conv1 as a K = 96 GEMM -> (registers) -> conv2 (K = 192) -> y2 as ONE f16 plane [N*31][128]
 //   k_fc_h     y2[N][3968] . Wfc -> x[N][256]; 128 x 256 tiles, LDS-DMA, three 24 KB buffers, 2 workgroups per CU
 //   k_layers_p the whole encoder stack per tile of <= 64 (or 32) tokens: residual stream in registers from the FC output to
-//              the logits (positional encoding added on the way in), weight fragments one half GEMM call ahead
+//              the logits (positional encoding added on the way in), weight fragments one half GEMM call ahead;
+//              <., 4, true>: the same grid headed by SIBLING tiles — a window of 65 .. 512 informative rows on ceil(rows / 64) tiles
+//              that exchange the K / V fragments of their heads through L2 / HBM layer by layer (softmax accumulated block by block)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -102,14 +102,17 @@ int herro_load_model(herro_ctx* ctx, const char* path);
 /* Operand format of the model GEMMs (accumulation is f32 in every mode; the contract is |logit error| <= 1e-3):
  *   0  f32 MFMA (exact f32)                                   2  f32 VALU (debug reference)
  *   1  bf16 hi/lo split of both operands, 3 MFMAs per product (~1e-5), transformer stack fused into one kernel
- *   3  the same arithmetic, layer by layer (what windows with > 64 informative rows run in modes 1, 4, 5)
+ *   3  the same arithmetic, layer by layer (what windows with > 64 informative rows run in mode 1, and windows with > 512 in modes 4, 5)
  *   4  f16: conv2 / FC / attention / QKV on single f16 operands, proj / FF1 / FF2 of every encoder layer on activation
- *      hi + lo (2 MFMAs), heads on three terms — 5.9e-4 max on 36 k rows; the DEFAULT when the model has the tuned shapes
+ *      hi + lo (2 MFMAs), heads on three terms — 6.3e-4 max on 36 k rows; the DEFAULT when the model has the tuned shapes.
+ *      Windows of 65 .. 512 informative rows stay on the fused stack (sibling tiles of 64 rows that exchange their K / V).
  *   5  f16, single terms everywhere but the heads (7.3e-4: measured, not a default)
  * herro_load_model picks the mode itself unless this was called before: 1 when the model's shapes have no f16 kernels or
- * a weight lies outside the f16 range; otherwise it runs a 256-row calibration batch in modes 1 and 4 and keeps 4 only
- * if the logits are finite and differ by at most 5e-4 (half the 1e-3 contract) — the margin of the f16 formats was
- * measured on random-init weights, a trained model decides for itself.  herro_model_describe reports the outcome. */
+ * a weight lies outside the f16 range; otherwise it runs a calibration batch of 256 pileup-shaped rows in mode 4 and in
+ * mode 0 (f32 MFMA) and keeps 4 only if the logits are finite and differ by at most 5e-4 (half the 1e-3 contract) — the
+ * margin of the f16 formats was measured on random-init weights, a trained model decides for itself.  A later
+ * herro_set_precision(4 / 5) on a model that failed this calibration is refused (HERRO_E_UNSUPPORTED; HERRO_FORCE_PRECISION=1
+ * overrides).  herro_model_describe reports the outcome. */
 int herro_set_precision(herro_ctx* ctx, int mode);
 
 /* Text description of the loaded model: hyper-parameters, receptive field of an informative row (rows the conv stack
