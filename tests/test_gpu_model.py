@@ -335,6 +335,46 @@ def test_load_time_precision_choice(tmp_path):
 
 
 @pytest.mark.parametrize("hp_kw", [
+    dict(n_layers=1, d_ff=256),
+    dict(n_layers=2, d_ff=512),
+    dict(n_layers=6, d_ff=2048),
+    dict(n_layers=9, d_ff=768),
+])
+def test_f16_kernels_serve_other_depths_and_ff_widths(tmp_path, hp_kw):
+    """The f16 kernels are a family along two axes: any layer count up to 16 and any d_ff that is a multiple of 256 up to 2048 (the
+    conv stack, d_model 256 and heads of 32 are fixed).  Such an archive loads, passes the load-time calibration into mode 4
+    (herro_model_describe says so) and meets the 1e-3 contract against its own dense twin — sibling tiles included."""
+    import model_ref as MR
+    hp = model_io.Hyper(**hp_kw)
+    raw = model_io.random_raw_params(hp, seed=91 + hp.n_layers)
+    path = str(tmp_path / "depth.hrro")
+    model_io.export(raw, hp, path)
+    c = api.Context(0)
+    try:
+        c.load_model(path)
+        d = c.describe_model()
+        assert f"layers {hp.n_layers}" in d and f"d_ff {hp.d_ff}" in d, d
+        mode = 4 if "-> mode 4" in d else 1
+        assert f"-> mode {mode}" in d, d
+        if hp.n_layers <= 6:
+            assert mode == 4, d                    # deeper stacks may fail the 5e-4 calibration on random weights: then mode 1 serves them (and is checked below)
+        rng = np.random.default_rng(6)
+        B, L = 5, 260
+        win_len = np.array([260, 200, 260, 130, 240])
+        bases, quals = _rand_batch(rng, B, L, win_len)
+        idx = [np.sort(rng.choice(win_len[b], size=k, replace=False)) for b, k in enumerate([30, 1, 150, 12, 64])]   # 150: three sibling tiles
+        lens = np.array([len(i) for i in idx], np.int32)
+        flat = np.concatenate(idx).astype(np.int32)
+        info, base = c.model_forward(bases, quals, lens, flat)
+        ti, tb = MR.run_batch(MR.build(raw, hp), bases, quals, lens, flat)
+        err = max(np.abs(info - ti).max(), np.abs(base - tb).max())
+        print(f"{hp_kw}: mode {mode}, max abs logit error {err:.3e}; {d[d.find('calibration'):][:120]}")
+        assert info.shape == ti.shape and err <= TOL
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("hp_kw", [
     dict(kw=5, c1=32, c2=64, d_model=128, n_heads=4, d_ff=512, n_layers=2),      # a smaller family member: wider kernel, 9-row receptive field... (4 * (kw / 2) + 1)
     dict(kw=3, c1=64, c2=128, d_model=512, n_heads=16, d_ff=1024, n_layers=3),   # a wider residual stream
     dict(kw=7, c1=32, c2=32, d_model=256, n_heads=8, d_ff=768, n_layers=5),      # the f16 kernels' d_model with another conv stack: 13-row receptive field
