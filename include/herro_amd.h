@@ -104,7 +104,7 @@ int herro_load_model(herro_ctx* ctx, const char* path);
  *   1  bf16 hi/lo split of both operands, 3 MFMAs per product (~1e-5), transformer stack fused into one kernel
  *   3  the same arithmetic, layer by layer (what windows with > 64 informative rows run in mode 1, and windows with > 512 in modes 4, 5)
  *   4  f16: conv2 / FC / attention / QKV on single f16 operands, proj / FF1 / FF2 of every encoder layer on activation
- *      hi + lo (2 MFMAs), heads on three terms — 6.3e-4 max on 36 k rows; the DEFAULT when the model has the tuned shapes.
+ *      hi + lo (2 MFMAs), heads on three terms — 5.9e-4 max on 36 k rows; the DEFAULT when the model has the tuned shapes.
  *      Windows of 65 .. 512 informative rows stay on the fused stack (sibling tiles of 64 rows that exchange their K / V).
  *   5  f16, single terms everywhere but the heads (7.3e-4: measured, not a default)
  * herro_load_model picks the mode itself unless this was called before: 1 when the model's shapes have no f16 kernels or
