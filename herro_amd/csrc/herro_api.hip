@@ -414,31 +414,50 @@ static std::vector<uint32_t> tile_pack_order(const std::vector<uint32_t>& cnt) {
 // + 226 half tiles).  qmode 2 (A/B): every window of <= 32 rows goes into 32-token tiles; a window of 33..64 opens a 64-token
 // tile and takes the best-fitting small windows along.  Without `pack` the windows keep their batch order inside each class.
 // Windows above 64 rows (the caller admits them up to 64 * FUSED_MAX_SIB, f16 stack only) come FIRST in the stream, each one alone
-// on ceil(rows / 64) consecutive tiles (`tiles_b`; grp[t] = first tile of the window's group | tiles in it << 24).
+// on ceil(rows / 64) consecutive tiles (`tiles_b`; grp[t] = first tile of the window's group | tiles in it << 20 | its tokens in the last tile << 24);
+// small windows may share that last tile.
 struct TilePlan { std::vector<uint32_t> order, tiles, tiles_q, tiles_b, grp; };
 static TilePlan plan_tiles_small(const std::vector<uint32_t>& cnt, bool pack, int qmode, uint32_t n_cu, uint32_t n_busy = 0);
 static TilePlan plan_tiles(const std::vector<uint32_t>& cnt, bool pack, int qmode, uint32_t n_cu) {
-  std::vector<uint32_t> big, small, small_cnt;
+  std::vector<uint32_t> big, small;
   for (size_t i = 0; i < cnt.size(); i++) (cnt[i] > FUSED_MAX_TOK ? big : small).push_back((uint32_t)i);
   if (big.empty()) return plan_tiles_small(cnt, pack, qmode, n_cu);
-  for (uint32_t i : small) small_cnt.push_back(cnt[i]);
-  uint32_t n_sib = 0;
-  for (uint32_t i : big) n_sib += (cnt[i] + FUSED_MAX_TOK - 1) / FUSED_MAX_TOK;
-  TilePlan P = plan_tiles_small(small_cnt, pack, qmode, n_cu, n_sib);   // the sibling tiles share the grid of the 64-token tiles: they count in its rounds
-  for (uint32_t& o : P.order) o = small[o];
+  // the head of the stream: every large window, its last (partial) tile filled with the best-fitting small windows (pack only) — the
+  // sibling code masks a tile's own block by window id like any tile, and the other siblings see only its first `nbig` tokens
+  std::vector<std::vector<uint32_t>> by(FUSED_MAX_TOK + 1);
+  if (pack) for (size_t k = small.size(); k-- > 0;) by[cnt[small[k]]].push_back(small[k]);   // pop_back: ascending index
+  std::vector<uint32_t> head, tiles_b(1, 0), grp;
+  std::vector<char> taken(cnt.size(), 0);
   uint32_t tok = 0;
-  P.tiles_b.push_back(0);
   for (uint32_t i : big) {
-    const uint32_t k = (cnt[i] + FUSED_MAX_TOK - 1) / FUSED_MAX_TOK, g0 = (uint32_t)P.grp.size();
-    for (uint32_t j = 0; j < k; j++) {
-      P.grp.push_back(g0 | (k << 24));
-      P.tiles_b.push_back(tok + std::min(cnt[i], (j + 1) * FUSED_MAX_TOK));
-    }
+    const uint32_t k = (cnt[i] + FUSED_MAX_TOK - 1) / FUSED_MAX_TOK, g0 = (uint32_t)grp.size(), last = cnt[i] - (k - 1) * FUSED_MAX_TOK;
+    head.push_back(i);
+    for (uint32_t j = 0; j + 1 < k; j++) tiles_b.push_back(tok + (j + 1) * FUSED_MAX_TOK);
     tok += cnt[i];
+    uint32_t room = FUSED_MAX_TOK - last, f = room;
+    while (room) {
+      f = std::min(f, room);
+      while (f && by[f].empty()) f--;
+      if (!f) break;
+      const uint32_t w = by[f].back();
+      by[f].pop_back();
+      head.push_back(w);
+      taken[w] = 1;
+      tok += f;
+      room -= f;
+    }
+    tiles_b.push_back(tok);
+    for (uint32_t j = 0; j < k; j++) grp.push_back(g0 | (k << 20) | (last << 24));   // first tile | tiles (<= 15) | the window's tokens in its last tile
   }
+  std::vector<uint32_t> rest, rest_cnt;
+  for (uint32_t i : small) if (!taken[i]) { rest.push_back(i); rest_cnt.push_back(cnt[i]); }
+  TilePlan P = plan_tiles_small(rest_cnt, pack, qmode, n_cu, (uint32_t)grp.size());   // the sibling tiles share the grid of the 64-token tiles: they count in its rounds
+  for (uint32_t& o : P.order) o = rest[o];
   for (uint32_t& t : P.tiles) t += tok;
   for (uint32_t& t : P.tiles_q) t += tok;
-  P.order.insert(P.order.begin(), big.begin(), big.end());
+  P.order.insert(P.order.begin(), head.begin(), head.end());
+  P.tiles_b.swap(tiles_b);
+  P.grp.swap(grp);
   return P;
 }
 static TilePlan plan_tiles_small(const std::vector<uint32_t>& cnt, bool pack, int qmode, uint32_t n_cu, uint32_t n_busy) {
@@ -2454,7 +2473,7 @@ int64_t herro_debug_tile_plan(const uint32_t* cnt, uint32_t n, int packed, uint3
 
 // The same with windows above 64 rows admitted (up to 64 * 8: the f16 stack's sibling tiles, plan_tiles): n_tiles[3] = sibling tiles,
 // 64-token tiles, 32-token tiles; tile_tok (capacity sum(ceil(cnt / 64)) + 2) the first tokens of all tiles in stream order
-// (sibling tiles first) + end; grp (capacity = the sibling tiles) first tile of the window's group | tiles in it << 24.
+// (sibling tiles first) + end; grp (capacity = the sibling tiles) as BatchDev::tile_grp.
 int herro_debug_tile_plan_sib(const uint32_t* cnt, uint32_t n, int packed, uint32_t n_cu, uint32_t* order, uint32_t* n_tiles, uint32_t* tile_tok, uint32_t* grp) {
   if (!cnt || !order || !n_tiles) return HERRO_E_INVALID;
   std::vector<uint32_t> c(cnt, cnt + n);

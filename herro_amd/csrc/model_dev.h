@@ -89,7 +89,7 @@ struct BatchDev {
   // tiles at the HEAD of the token stream and of the 64-token grid — sibling tiles, which exchange their K / V fragments layer by layer (k_layers_p<., 4, true>)
   uint32_t n_tiles_b;
   const uint32_t* tile_tok0_b;  // [n_tiles_b+1]
-  const uint32_t* tile_grp;     // [n_tiles_b] first tile of the window's group | tiles in the group << 24
+  const uint32_t* tile_grp;     // [n_tiles_b] first tile of the window's group | tiles in the group << 20 | tokens of the window in the group's last tile << 24 (small windows may fill the rest of it)
   float* out_info;            // job-level [sum nsup]
   float* out_base;            // job-level [sum nsup][5]
 };

@@ -983,7 +983,8 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
             for (int ct = 0; ct < 2; ct++) orun[pi][ct] = mma(vh[ct][kk], ph, orun[pi][ct]);
           }
         }
-        const uint32_t g0 = grp & 0xffffffu, gk = grp >> 24;
+        const uint32_t g0 = grp & 0xfffffu, gk = (grp >> 20) & 15u, nlast = grp >> 24;   // the group; the window's tokens in its last tile (small windows may fill the rest)
+        const uint32_t nbig = bt == g0 + gk - 1 ? nlast : (uint32_t)HLT;                   // ... in this tile: queries beyond them belong to other windows
 #pragma unroll 1
         for (uint32_t sb = g0; sb < g0 + gk; sb++) {
           if (sb == bt) continue;
@@ -997,7 +998,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          const uint32_t nts = tile_tok0[sb + 1] - tile_tok0[sb];
+          const uint32_t nts = sb == g0 + gk - 1 ? nlast : (uint32_t)HLT;   // the sibling's tokens of this window
           const uint16_t* src = S.sib_kv + ((((uint64_t)sb * 2 + (li & 1u)) * 8 + wave) * 8 * 64 + lane) * 8;
           half8 kf[PT], vf[2][PT / 2];
 #pragma unroll
@@ -1015,7 +1016,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
               st[pj] = mma(kf[pj], qh[pi], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
               for (int r = 0; r < 4; r++) {
-                st[pj][r] = (uint32_t)(pj * 16 + 4 * fg + r) < nts ? st[pj][r] : -INFINITY;   // the sibling's real tokens: all of them are this window's
+                st[pj][r] = ((uint32_t)(pj * 16 + 4 * fg + r) < nts && (uint32_t)(pi * 16) + fr < nbig) ? st[pj][r] : -INFINITY;   // this window's keys, for this window's queries
                 bm = fmaxf(bm, st[pj][r]);
               }
             }

@@ -240,12 +240,13 @@ int64_t herro_debug_job_array(herro_job* job, int which, const void** ptr, uint3
  * small windows along.  *n_half (may be null) receives the number of 32-token tiles; tile_tok (capacity n + 1, may be null)
  * the first token of every tile, the 64-token ones first, then the end of the stream. */
 int64_t herro_debug_tile_plan(const uint32_t* cnt, uint32_t n, int packed, uint32_t n_cu, uint32_t* order, uint32_t* n_half, uint32_t* tile_tok);
-/* The same with windows above 64 informative rows admitted (cnt[i] in 1..512).  The f16 stack keeps such a window fused: alone
- * on ceil(rows / 64) consecutive 64-token tiles at the head of the stream — sibling tiles, which exchange the K / V fragments of
- * their heads layer by layer (inference.rs:134-141 takes any `lens`; windows above 512 rows run layer by layer).  n_tiles[3] =
- * sibling tiles, 64-token tiles, 32-token tiles; tile_tok (capacity sum(ceil(cnt / 64)) + 2, may be null) the first token of every
- * tile in stream order + end; grp (capacity = the sibling tiles, may be null): first tile of the window's group | tiles in it << 24.
- * The sibling tiles count as busy compute units when the last round is sized. */
+/* The same with windows above 64 informative rows admitted (cnt[i] in 1..512).  The f16 stack keeps such a window fused: on
+ * ceil(rows / 64) consecutive 64-token tiles at the head of the stream — sibling tiles, which exchange the K / V fragments of
+ * their heads layer by layer (inference.rs:134-141 takes any `lens`; windows above 512 rows run layer by layer).  The window's
+ * last tile is filled up with the best-fitting small windows (packed plans only).  n_tiles[3] = sibling tiles, 64-token tiles,
+ * 32-token tiles; tile_tok (capacity sum(ceil(cnt / 64)) + 2, may be null) the first token of every tile in stream order + end;
+ * grp (capacity = the sibling tiles, may be null): first tile of the window's group | tiles in it << 20 | tokens of the window
+ * in the group's last tile << 24.  The sibling tiles count as busy compute units when the last round is sized. */
 int herro_debug_tile_plan_sib(const uint32_t* cnt, uint32_t n, int packed, uint32_t n_cu, uint32_t* order, uint32_t* n_tiles,
                               uint32_t* tile_tok, uint32_t* grp);
 

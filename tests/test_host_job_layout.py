@@ -298,11 +298,12 @@ def test_token_tile_plan_short_last_round_in_half_tiles():
 
 
 def test_token_tile_plan_windows_above_64_rows_on_sibling_tiles():
-    """f16 stack: a window of 65 .. 512 informative rows stays fused — alone on ceil(rows / 64) consecutive 64-token tiles at the head of
-    the token stream (sibling tiles, one group per window); the ordinary windows follow, planned as before, with the sibling tiles
-    counted as busy compute units when the last round is sized."""
+    """f16 stack: a window of 65 .. 512 informative rows stays fused — on ceil(rows / 64) consecutive 64-token tiles at the head of the
+    token stream (sibling tiles, one group per window), its last tile filled up with the best-fitting small windows; the other
+    windows follow, planned as before, with the sibling tiles counted as busy compute units when the last round is sized."""
     rng = np.random.default_rng(9)
-    for n_big, n_small, n_cu in ((1, 0, 256), (3, 40, 256), (10, 1014, 256), (5, 507, 256), (40, 3, 64), (2, 2558, 256)):
+    for n_big, n_small, n_cu, packed in ((1, 0, 256, True), (3, 40, 256, True), (10, 1014, 256, True), (5, 507, 256, True), (40, 3, 64, True),
+                                         (2, 2558, 256, True), (6, 300, 256, False)):
         big = rng.integers(65, 513, n_big)
         big[0] = 65
         if n_big > 1:
@@ -311,43 +312,52 @@ def test_token_tile_plan_windows_above_64_rows_on_sibling_tiles():
             big[2] = 128
         small = rng.integers(4, 31, n_small)
         cnt = np.concatenate([big, small]).astype(np.uint32)
-        perm = rng.permutation(len(cnt))
-        cnt = cnt[perm]
-        nb, n64, n32, order, tok, grp = api.debug_tile_plan_sib(cnt, packed=True, qmode=1, n_cu=n_cu)
+        cnt = cnt[rng.permutation(len(cnt))]
+        nb, n64, n32, order, tok, grp = api.debug_tile_plan_sib(cnt, packed=packed, qmode=1, n_cu=n_cu)
         assert sorted(order.tolist()) == list(range(len(cnt)))
         assert nb == int(((cnt[cnt > 64].astype(np.int64) + 63) // 64).sum()) and len(grp) == nb
-        # the stream: windows above 64 rows first (given order), each on its own tiles of 64 (the last one shorter)
         so = cnt[order].astype(np.int64)
-        assert (so[:n_big] > 64).all() and (so[n_big:] <= 64).all()
-        assert order[:n_big].tolist() == np.flatnonzero(cnt > 64).tolist()
-        t, k = 0, 0
-        for rows in so[:n_big]:
-            kk = -(-rows // 64)
+        win_tok = np.concatenate([[0], np.cumsum(so)])
+        # the head of the stream: each large window (in the given order) on its own tiles of 64; its last tile may take small windows along
+        assert order[so > 64].tolist() == np.flatnonzero(cnt > 64).tolist()
+        k, w, guests = 0, 0, 0
+        for _ in range(n_big):
+            rows = so[w]
+            assert rows > 64
+            kk, last = -(-rows // 64), rows - 64 * (-(-rows // 64) - 1)
             for j in range(kk):
-                assert tok[k + j] == t + 64 * j and int(grp[k + j]) == (k | (kk << 24))
-            t += rows
+                assert tok[k + j] == win_tok[w] + 64 * j
+                assert int(grp[k + j]) == (k | (kk << 20) | (last << 24))
+            w += 1
+            room = 64 - last
+            while w < len(so) and so[w] <= 64 and win_tok[w + 1] <= tok[k + kk]:      # the guests of the last tile: whole windows
+                room -= so[w]
+                w += 1
+                guests += 1
+            assert room >= 0 and tok[k + kk] == win_tok[w]
             k += kk
-        assert k == nb and tok[nb] == t
-        # behind them: whole small windows per tile, as the plan without sibling tiles would have them
-        _check_plan(so[n_big:].astype(np.uint32), n64, n32, np.arange(n_small, dtype=np.uint32), tok[nb:] - tok[nb])
+        assert k == nb
+        assert guests == 0 if not packed else (guests > 0 or n_small < 10)
+        # behind them: whole small windows per tile, as a plan without sibling tiles would have them
+        rest = so[w:].astype(np.uint32)
+        assert (rest <= 64).all()
+        _check_plan(rest, n64, n32, np.arange(len(rest), dtype=np.uint32), tok[nb:] - tok[nb])
         assert tok[-1] == cnt.sum()
-        if n_small:
-            m64, m32, _ = api.debug_tile_plan(cnt[cnt <= 64], packed=True, qmode=1, n_cu=n_cu)
-            full, _ = api.debug_tile_plan(cnt[cnt <= 64], packed=True)
+        if len(rest) and packed:
+            full, _ = api.debug_tile_plan(rest, packed=True)
             r = (full + nb) % n_cu                   # the sibling tiles head the grid of the 64-token tiles
             if r and 2 * r <= n_cu and r <= full:
                 assert n32 > 0 and n64 <= full          # the round the sibling tiles make short goes into half tiles
             if r == 0 or 2 * r > n_cu:
                 assert (n64, n32) == (full, 0)          # a last round more than half full stays in 64-token tiles
-            if nb % n_cu == 0:
-                assert (n64, n32) == (m64, m32)
     with pytest.raises(api.HerroError):
         api.debug_tile_plan_sib(np.array([513], np.uint32))
-    # the bench-like batch of tools/large_window_cost.py: 1014 small windows (245 tiles) + 10 windows of 100 rows (20 sibling tiles)
+    # the bench-like batch of tools/large_window_cost.py: 1014 small windows + 10 windows of 100 rows (20 sibling tiles, 28 free slots in every second one)
     cnt = np.clip(np.random.default_rng(3).normal(15.2, 4.5, 1024).round(), 4, 30).astype(np.uint32)
     cnt[:10] = 100
-    nb, n64, n32, *_ = api.debug_tile_plan_sib(cnt, packed=True, qmode=1, n_cu=256)
-    assert nb == 20 and nb + n64 == 256 and n32 > 0      # one full round; the 9 tiles over it went into half tiles
+    nb, n64, n32, order, tok, grp = api.debug_tile_plan_sib(cnt, packed=True, qmode=1, n_cu=256)
+    assert nb == 20 and (np.diff(tok[:21].astype(np.int64))[1::2] >= 36 + 20).all()      # the second tile of every pair took guests
+    assert (nb + n64) % 256 == 0 and n32 > 0
 
 
 def test_two_threads_create_jobs_on_one_context():
