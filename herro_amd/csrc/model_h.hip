@@ -459,24 +459,30 @@ __global__ __launch_bounds__(512, FC_NBUF <= 3 ? 4 : 2) void k_fc_h(const uint16
 // activation tile goes through the LDS, by plain loads (one macro-step ahead, in registers) and ds_write_b128 — one barrier
 // per 64 k.  Per 64 k and wave: 32 MFMAs, 16 ds_read_b128, 4 fragment loads, 2 row loads + 2 ds_writes.
 // ---------------------------------------------------------------------------------------------------
-constexpr int FR_TM = 128;
-constexpr size_t FC_R_SHM = (size_t)2 * FR_TM * 64 * 2;   // two buffers [128 rows][64 k] f16
+constexpr int FR_ROWS = 128;                               // rows of an LDS buffer; a tile takes 32 * G of them
+constexpr size_t FC_R_SHM = (size_t)2 * FR_ROWS * 64 * 2;   // two buffers [128 rows][64 k] f16
 
+// G: groups of two 16-row blocks per tile, i.e. tiles of 32 * G rows (4: 128 rows; 3: 96 — chosen per launch so that the busiest compute unit
+// holds the fewest rows: 38.7 k rows in 128-row tiles are 303 workgroups, two on 47 of the 256 compute units and one on the others; in 96-row
+// tiles 403, and the two-workgroup units carry 192 rows instead of 256).
+template <int G>
 __global__ __launch_bounds__(512, 4) void k_fc_r(const uint16_t* __restrict__ A, uint32_t lda, Weight W, float* C, uint32_t ldc, uint32_t M) {
+  constexpr int FR_TM = 32 * G;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem_fc[];
   uint16_t* s_a = reinterpret_cast<uint16_t*>(smem_fc);   // [2][128][64]: row r at r * 128 B, 16-byte chunk c at (c ^ (r & 7))
   const uint32_t nks = W.K >> 5, nms = W.K >> 6;
   const uint32_t m0 = blockIdx.x * FR_TM;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t fr = lane & 15, fg = lane >> 4;
-  f32x4 acc[8][2];
+  f32x4 acc[2 * G][2];
 #pragma unroll
-  for (int pt = 0; pt < 8; pt++)
+  for (int pt = 0; pt < 2 * G; pt++)
 #pragma unroll
     for (int jt = 0; jt < 2; jt++) acc[pt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
   // activation rows: thread t stages row (t >> 2), 16-byte chunks (t & 3) and (t & 3) + 4 of every 64-k tile
   const uint32_t srow = tid >> 2, sch = tid & 3;
-  const uint16_t* ga = A + (uint64_t)min(m0 + srow, M - 1) * lda + sch * 8;
+  const uint32_t lrow = srow < (uint32_t)FR_TM ? srow : srow - 32u;   // G = 3: the threads of rows 96..127 repeat rows 64..95 (same lines, no new traffic) into LDS rows nobody reads
+  const uint16_t* ga = A + (uint64_t)min(m0 + lrow, M - 1) * lda + sch * 8;
   const uint32_t sdst0 = srow * 64 + ((sch ^ (srow & 7u)) << 3), sdst1 = srow * 64 + (((sch + 4) ^ (srow & 7u)) << 3);
   // weights: fragment (jt, ks) of this wave's 32-column slab
   const uint16_t* gw = W.ph16 + ((uint64_t)(wave * 2) * nks * 64 + lane) * 8;
@@ -488,12 +494,12 @@ __global__ __launch_bounds__(512, 4) void k_fc_r(const uint16_t* __restrict__ A,
     r1 = *reinterpret_cast<const uint4*>(ga + (uint64_t)ms * 64 + 32);
   };
   auto put_a = [&](uint32_t buf, const uint4& r0, const uint4& r1) {
-    *reinterpret_cast<uint4*>(s_a + buf * (FR_TM * 64) + sdst0) = r0;
-    *reinterpret_cast<uint4*>(s_a + buf * (FR_TM * 64) + sdst1) = r1;
+    *reinterpret_cast<uint4*>(s_a + buf * (FR_ROWS * 64) + sdst0) = r0;   // (all 128 rows are staged whatever G: rows beyond the tile are read for nothing)
+    *reinterpret_cast<uint4*>(s_a + buf * (FR_ROWS * 64) + sdst1) = r1;
   };
   // a quarter k-step = 2 row blocks x 2 column blocks = 4 MFMAs; the fragments of the next quarter are read under them
   auto rd = [&](uint32_t buf, uint32_t kk, uint32_t g, half8 (&x)[2]) {
-    const uint16_t* t = s_a + buf * (FR_TM * 64);
+    const uint16_t* t = s_a + buf * (FR_ROWS * 64);
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const uint32_t r = (g * 2 + i) * 16 + fr;
@@ -530,18 +536,18 @@ __global__ __launch_bounds__(512, 4) void k_fc_r(const uint16_t* __restrict__ A,
       rd(u, 0, 0, x);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int q = 0; q < 8; q++) {   // q = 4 kk + g
-        if (q < 7) rd(u, (q + 1) >> 2, (q + 1) & 3, xn);
+      for (int q = 0; q < 2 * G; q++) {   // q = G kk + g
+        if (q < 2 * G - 1) rd(u, (q + 1) / G, (q + 1) % G, xn);
         __builtin_amdgcn_sched_barrier(0);
-        mm(q & 3, x, wr[q >> 2]);
+        mm(q % G, x, wr[q / G]);
         __builtin_amdgcn_sched_barrier(0);
-        if ((q & 3) == 3) {   // the k-step's fragments have been issued: the slot takes the k-step 2 ahead
-          const uint32_t kn = min(s_ * 2 + (q >> 2) + 2, nks - 1);
+        if (q % G == G - 1) {   // the k-step's fragments have been issued: the slot takes the k-step 2 ahead
+          const uint32_t kn = min(s_ * 2 + (q / G) + 2, nks - 1);
 #pragma unroll
-          for (int jt = 0; jt < 2; jt++) wr[q >> 2][jt] = wfrag(jt, kn);
+          for (int jt = 0; jt < 2; jt++) wr[q / G][jt] = wfrag(jt, kn);
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (q == 5) {   // the next tile (in flight since the previous macro-step) goes into the other buffer; its successor is requested
+        if (q == G + 1) {   // the next tile (in flight since the previous macro-step) goes into the other buffer; its successor is requested
           put_a((u + 1) & 1, as0, as1);
           __builtin_amdgcn_sched_barrier(0);
           load_a(min(s_ + 2, nms - 1), as0, as1);
@@ -559,7 +565,7 @@ __global__ __launch_bounds__(512, 4) void k_fc_r(const uint16_t* __restrict__ A,
     for (int q = 0; q < 8; q++) bs[q] = W.bias ? bp[q] : 0.f;
   }
 #pragma unroll
-  for (int pt = 0; pt < 8; pt++) {
+  for (int pt = 0; pt < 2 * G; pt++) {
     const uint32_t m = m0 + pt * 16 + fr;
     if (m < M) {
       float* cp = C + (uint64_t)m * ldc + wave * 32 + 8 * fg;
@@ -1254,7 +1260,13 @@ void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S,
   KT_BEGIN(tm, "fc_gemm", st);
   static const bool fc_r = [] { const char* e = getenv("HERRO_FC_R"); return !e || atoi(e) != 0; }();   // 0: weights through the LDS by LDS-DMA (k_fc_h), for the A/B
   if (fc_r && M.fc.ph16 && M.fc.K % 128 == 0 && h.d_model == 256) {
-    hipLaunchKernelGGL(k_fc_r, dim3((N + FR_TM - 1) / FR_TM), dim3(512), FC_R_SHM, st, S.y2_hi, HERRO_ROWS * h.c2, M.fc, S.x, h.d_model, N);
+    // tile height: the one that leaves the busiest compute unit the fewest rows (two workgroups fit a unit; HERRO_FC_G forces it, for A/B)
+    static const int force_g = [] { const char* e = getenv("HERRO_FC_G"); return e ? atoi(e) : 0; }();
+    static const uint32_t n_cu = [] { int dev = 0, c = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return (uint32_t)std::max(c, 1); }();
+    auto busiest = [&](uint32_t rows) { const uint32_t wg = (N + rows - 1) / rows; return (uint64_t)((wg + n_cu - 1) / n_cu) * rows + (wg > 2 * n_cu ? 1u << 20 : 0u); };
+    const int g = force_g == 3 || force_g == 4 ? force_g : (busiest(96) < busiest(128) ? 3 : 4);
+    if (g == 3) hipLaunchKernelGGL(k_fc_r<3>, dim3((N + 95) / 96), dim3(512), FC_R_SHM, st, S.y2_hi, HERRO_ROWS * h.c2, M.fc, S.x, h.d_model, N);
+    else hipLaunchKernelGGL(k_fc_r<4>, dim3((N + 127) / 128), dim3(512), FC_R_SHM, st, S.y2_hi, HERRO_ROWS * h.c2, M.fc, S.x, h.d_model, N);
   } else {
     opt_in_lds(reinterpret_cast<const void*>(k_fc_h), FC_H_SHM);
     hipLaunchKernelGGL(k_fc_h, dim3((N + FC_TM - 1) / FC_TM), dim3(512), FC_H_SHM, st, S.y2_hi, HERRO_ROWS * h.c2, M.fc, S.x, h.d_model, N);
