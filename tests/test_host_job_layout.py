@@ -360,6 +360,27 @@ def test_token_tile_plan_windows_above_64_rows_on_sibling_tiles():
     assert (nb + n64) % 256 == 0 and n32 > 0
 
 
+def test_limits_that_differ_from_the_reference_are_refused_loudly():
+    """Inputs the reference accepts and this library does not come back as HERRO_E_UNSUPPORTED with a message — never as a
+    wrong result: window sizes outside [16, 8192] (main.rs:69-74 takes any), more than 65535 windows in one read (`wid` is u16 in the
+    reference as well: consensus.rs:22-33)."""
+    UNSUPPORTED = -4
+    lens = np.array([40000, 16 * 65536 + 1], np.uint32)
+    c = api.HostContext(lens)
+    rows = np.array([[0, 40000, 0, 3000, 0, 1, lens[1], 0, 3000]], np.uint32)
+    for W in (8193, 15, 0, 1 << 20):
+        with pytest.raises(api.HerroError) as e:
+            c.create_job([1], rows, [0, 1], [b"3000M"], W)
+        assert e.value.code == UNSUPPORTED and "window_size" in str(e.value), (W, str(e.value))
+    with pytest.raises(api.HerroError) as e:          # 65537 windows of 16 bp
+        c.create_job([1], rows, [0, 1], [b"3000M"], 16)
+    assert e.value.code == UNSUPPORTED and "65535" in str(e.value), str(e.value)
+    j = c.create_job([1], rows, [0, 1], [b"3000M"], 8192)      # the largest window size is served
+    assert j.n_windows == -(-int(lens[1]) // 8192)
+    j.close()
+    c.close()
+
+
 def test_two_threads_create_jobs_on_one_context():
     """The context's host pool takes one parallel section at a time: two threads building jobs on the same context get the same
     descriptors as one thread building them in turn."""
