@@ -10,7 +10,7 @@ A step = one pass of the hot path over one batch of `--batch` (128) 4096-bp wind
 reads, run the model, decode the corrected bases on the device.  `value` counts exactly `--steps` steps with the inputs
 (2-bit read store, window descriptors) resident in HBM before the timed region starts.  The same JSON line also carries
   end_to_end    the same work with herro_job_create (CIGAR text staged and scanned on the GPU, windowing, descriptor
-                upload) and the D2H of the corrected bases INSIDE the timed region, fresh inputs every job, four feeder
+                upload) and the D2H of the corrected bases INSIDE the timed region, fresh inputs every job, six feeder
                 threads (contexts) per GPU; N = 1 only by default;
   roofline      the dominant kernel against its roof, durations from HIP events on the launch stream
                 (roofline_next_kernels: the two behind it; roofline_featurize_group: the featurize kernels together);
@@ -168,7 +168,7 @@ def main():
     ap.add_argument("--e2e-mode", choices=["serial", "producer"], default="serial",
                     help="end_to_end feeders: 'serial' = one thread per context (create k+1, then execute k); 'producer' = a second "
                          "thread per context builds jobs ahead")
-    ap.add_argument("--e2e-feeders", type=int, default=4, help="feeder threads (one context each) of the end_to_end leg")
+    ap.add_argument("--e2e-feeders", type=int, default=6, help="feeder threads (one context each) of the end_to_end leg")
     ap.add_argument("--e2e-jobs", type=int, default=None, help="jobs per feeder thread in the end_to_end leg (default: 6 on one GPU, 0 = skipped on several)")
     ap.add_argument("--self-check", type=int, default=6, help="targets compared with the oracle after the timing (0: skip)")
     ap.add_argument("--long-run-steps", type=int, default=None,
@@ -193,7 +193,7 @@ def main():
         os.environ.setdefault("HERRO_HOST_THREADS", str(cpus_rank))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if args.e2e_jobs is None:   # the end_to_end leg is a single-GPU figure (4 feeder contexts per GPU would have 8 ranks fight for the host)
+    if args.e2e_jobs is None:   # the end_to_end leg is a single-GPU figure (6 feeder contexts per GPU would have 8 ranks fight for the host)
         args.e2e_jobs = 6 if world == 1 else 0
 
     from herro_amd import api, model_io, synth
