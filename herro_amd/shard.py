@@ -611,10 +611,13 @@ def hip_corrector(ctxs, window_size: int, batch: int, read_name, group_targets: 
 
 
 def strong_leg(args, rank: int, world: int, local: int, n_windows: int, n_ctx: int = 3, model_path: str | None = None) -> dict | None:
-    """ONE fixed set of `n_windows` synthetic windows (BASELINE configs[3]) sharded over the ranks: rank 0 ingests, scatters the
-    work, every rank corrects its shard (n_ctx contexts = feeder threads per GPU, two jobs in flight each), the corrected reads
-    are gathered to rank 0.  Timed: scatter -> herro_job_create -> featurize -> infer -> consensus -> D2H -> FASTA text ->
-    gather, i.e. the whole multi-GPU data path, host work included (max over ranks).  Returns the figures on rank 0."""
+    """ONE fixed set of `n_windows` synthetic windows (BASELINE configs[3]) sharded over the ranks.  Default (--strong-ingest local):
+    every rank holds its own share of the parsed alignments (handed out once, outside the timed region — what per-rank ingestion of its
+    own byte range would have produced), sends the targets it does not own to their owners in one all-to-all, corrects what it owns
+    (n_ctx contexts = feeder threads per GPU sharing one read store, two jobs in flight each); the corrected reads are gathered to
+    rank 0.  --strong-ingest rank0: rank 0 ingests everything and scatters the work (the round-3 path).  Timed: routing ->
+    herro_job_create -> featurize -> infer -> consensus -> D2H -> FASTA text -> gather, i.e. the whole multi-GPU data path, host work
+    included (max over ranks).  Returns the figures on rank 0."""
     import os
     import time
     import torch
@@ -712,7 +715,7 @@ def bench_strong(args, rank: int, world: int, local: int):
             "vs_baseline": None, "dtype": {1: "bf16x3", 4: "f16 (encoder proj / FF GEMMs: activation hi+lo)", 5: "f16"}.get(args.precision, str(args.precision)),
             "data": "synthetic (SURVEY §8d generator, seed 0x48455252+3; random-init weights of the assumed architecture)",
             "config": {"workload": f"ONE fixed job of {r['windows']} synthetic 4096-bp windows (32 overlaps each, batch=128) sharded by target read over "
-                                   f"{world} rank(s): rank 0 ingests, scatters the work, gathers the corrected reads (BASELINE configs[3])",
+                                   f"{world} rank(s), ingest = {r.get('ingest', 'local')}; rank 0 gathers the corrected reads (BASELINE configs[3])",
                        "batch": args.batch, "window": 4096, "overlaps": 32, "timed": r["timed"], "precision": args.precision},
             "strong": r,
             "roofline": {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None,
