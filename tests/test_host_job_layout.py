@@ -360,6 +360,56 @@ def test_token_tile_plan_windows_above_64_rows_on_sibling_tiles():
     assert (nb + n64) % 256 == 0 and n32 > 0
 
 
+def _check_sib_plan(cnt, packed, qmode, n_cu):
+    """Invariants of a token-tile plan with sibling tiles, whatever the input: see the two tests above for what they mean."""
+    cnt = np.asarray(cnt, np.uint32)
+    nb, n64, n32, order, tok, grp = api.debug_tile_plan_sib(cnt, packed=packed, qmode=qmode, n_cu=n_cu)
+    n = len(cnt)
+    assert sorted(order.tolist()) == list(range(n))
+    so = cnt[order].astype(np.int64)
+    win_tok = np.concatenate([[0], np.cumsum(so)])
+    assert len(tok) == nb + n64 + n32 + 1 and tok[0] == 0 and tok[-1] == so.sum()
+    size = np.diff(tok.astype(np.int64))
+    assert (size > 0).all() and (size[:nb + n64] <= 64).all() and (size[nb + n64:] <= 32).all()
+    assert nb == int(((so[so > 64] + 63) // 64).sum())
+    # sibling groups: consecutive tiles, the group word identical within a group, the window's tokens first
+    k = 0
+    w = 0
+    while k < nb:
+        g0, kk, last = int(grp[k]) & 0xfffff, (int(grp[k]) >> 20) & 15, int(grp[k]) >> 24
+        assert g0 == k and 2 <= kk <= 8 and 1 <= last <= 64
+        assert all(int(grp[k + j]) == int(grp[k]) for j in range(kk))
+        while so[w] <= 64:                      # guests of the previous group
+            w += 1
+        rows = so[w]
+        assert rows == 64 * (kk - 1) + last and tok[k] == win_tok[w]
+        assert all(size[k + j] == 64 for j in range(kk - 1)) and size[k + kk - 1] >= last
+        assert np.isin(tok[k + kk], win_tok)    # the guests are whole windows
+        w += 1
+        k += kk
+    # everything behind the sibling tiles: tile boundaries on window boundaries
+    assert np.isin(tok[nb:], win_tok).all()
+    # a window of <= 64 rows never straddles tiles; a window above 32 rows is not in a 32-token tile
+    t_of = np.searchsorted(tok, win_tok[:-1], side="right") - 1
+    t_end = np.searchsorted(tok, win_tok[1:] - 1, side="right") - 1
+    small = so <= 64
+    assert (t_of[small] == t_end[small]).all()
+    assert (so[(t_of >= nb + n64)] <= 32).all()
+
+
+def test_token_tile_plan_with_sibling_tiles_property():
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(st.one_of(st.integers(1, 64), st.integers(1, 64), st.integers(65, 512)), min_size=0, max_size=400),
+           st.booleans(), st.sampled_from([0, 1, 2]), st.sampled_from([1, 8, 64, 256, 304]))
+    def run(cnt, packed, qmode, n_cu):
+        _check_sib_plan(cnt, packed, qmode, n_cu)
+    run()
+    _check_sib_plan([512] * 300 + [1] * 50, True, 1, 256)      # more sibling tiles than compute units
+    _check_sib_plan([65, 64, 64, 63, 1], True, 1, 256)
+
+
 def test_limits_that_differ_from_the_reference_are_refused_loudly():
     """Inputs the reference accepts and this library does not come back as HERRO_E_UNSUPPORTED with a message — never as a
     wrong result: window sizes outside [16, 8192] (main.rs:69-74 takes any), more than 65535 windows in one read (`wid` is u16 in the
