@@ -66,10 +66,15 @@ def read_fastx(path: str, min_length: int = 0, core: set[str] | None = None, nei
         raise ValueError(err.value.decode())
     try:
         n = L.herro_reads_count(h)
-        off = np.ctypeslib.as_array(C.cast(L.herro_reads_off(h), C.POINTER(C.c_uint64)), (n + 1,)).copy()
+        def take(addr, count, dt):       # one memcpy out of the library's buffer (np.ctypeslib.as_array builds a ctypes array TYPE of that length first: seconds per GB)
+            out = np.empty(count, dt)
+            if count:
+                C.memmove(out.ctypes.data, addr, out.nbytes)
+            return out
+        off = take(L.herro_reads_off(h), n + 1, np.uint64)
         nb = int(off[-1])
-        seq = np.ctypeslib.as_array(C.cast(L.herro_reads_seq(h), C.POINTER(C.c_uint8)), (max(nb, 1),))[:nb].copy() if nb else np.zeros(0, np.uint8)
-        qual = np.ctypeslib.as_array(C.cast(L.herro_reads_qual(h), C.POINTER(C.c_uint8)), (max(nb, 1),))[:nb].copy() if nb else np.zeros(0, np.uint8)
+        seq = take(L.herro_reads_seq(h), nb, np.uint8)
+        qual = take(L.herro_reads_qual(h), nb, np.uint8)
         idp = C.cast(L.herro_reads_ids(h), C.POINTER(C.c_char_p))
         dp = C.cast(L.herro_reads_descs(h), C.POINTER(C.c_char_p))
         ids = [idp[i] for i in range(n)]

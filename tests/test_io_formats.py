@@ -94,6 +94,83 @@ def test_read_fastx_rules(tmp_path, monkeypatch, chunk):
     assert hio.read_fastx(str(whole)).ids == [b"r0", b"r1", b"r9"]
 
 
+def _same_reads(a, b):
+    assert a.ids == b.ids and a.descriptions == b.descriptions
+    assert np.array_equal(a.off, b.off) and np.array_equal(a.seq, b.seq) and np.array_equal(a.qual, b.qual)
+
+
+@pytest.mark.parametrize("case", ["four_line", "at_qualities", "blank_lines_crlf", "multi_line", "one_huge_read", "no_final_newline", "tiny_records", "fasta_inside"])
+def test_parallel_byte_ranges_equal_one_sequential_pass(tmp_path, monkeypatch, capfd, case):
+    """A plain file of some size is read by several threads over byte ranges (two passes: boundaries + counts, then every record to its
+    final place).  Whatever the ranges cut through — quality lines that start with '@', blank lines, a record longer than a range,
+    multi-line records (which the boundary guess cannot handle: the reader notices and reads sequentially) — the result is the
+    sequential reader's, errors included."""
+    rng = np.random.default_rng(hash(case) % 1000)
+    recs = []
+    n = {"one_huge_read": 12, "tiny_records": 3000}.get(case, 400)
+    for i in range(n):
+        ln = int(rng.integers(1, 40)) if case == "tiny_records" else int(rng.integers(30, 900))
+        if case == "one_huge_read" and i == 5:
+            ln = 60000
+        s_ = bytes(rng.choice(list(b"ACGT"), ln).tolist())
+        q = rng.integers(33, 90, ln).astype(np.uint8)
+        if case == "at_qualities":
+            q[0] = ord("@")                                   # every quality line looks like a header
+            if i % 3 == 0 and ln > 1:
+                s_ = b"A" + s_[1:]
+        head = b"r%d" % i + (b" desc %d\tx" % i if i % 4 == 0 else b"")
+        recs.append((head, s_, q.tobytes()))
+    nl = b"\r\n" if case == "blank_lines_crlf" else b"\n"
+    out = []
+    for i, (h, s_, q) in enumerate(recs):
+        if case == "multi_line" and i % 5 == 0 and len(s_) > 10:
+            k = len(s_) // 3
+            out.append(b"@" + h + nl + s_[:k] + nl + s_[k:] + nl + b"+" + nl + q[:k] + nl + q[k:] + nl)
+        else:
+            out.append(b"@" + h + nl + s_ + nl + b"+" + (h if i % 7 == 0 else b"") + nl + q + nl)
+        if case == "blank_lines_crlf" and i % 6 == 0:
+            out.append(nl + nl)
+    text = b"".join(out)
+    if case == "no_final_newline":
+        text = text.rstrip(b"\n")
+    if case == "fasta_inside":
+        text = text[: len(text) // 2].rsplit(b"@r", 1)[0] + b">fa\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n" + b"@r" + text[len(text) // 2:].split(b"@r", 1)[1]
+    path = str(tmp_path / f"{case}.fastq")
+    open(path, "wb").write(text)
+    monkeypatch.setenv("HERRO_FASTX_THREADS", "1")
+
+    def read(**kw):
+        try:
+            return hio.read_fastx(path, **kw)
+        except ValueError as e:
+            return str(e)
+    want = {k: read(**kw) for k, kw in (("all", {}), ("min", dict(min_length=200)), ("keep", dict(core={"r3", "r11", "r%d" % (n - 1)}, neighbour={"r4"})))}
+    if case == "fasta_inside":
+        assert want["all"] == "Qualities should be present."
+    else:
+        assert len(want["all"].ids) == n
+    monkeypatch.setenv("HERRO_FASTX_TRACE", "1")
+    capfd.readouterr()
+    n_par = n_seq = 0
+    for threads, range_min in (("2", "64"), ("3", "1000"), ("7", "1"), ("8", "5000"), ("16", "300")):
+        monkeypatch.setenv("HERRO_FASTX_THREADS", threads)
+        monkeypatch.setenv("HERRO_FASTX_RANGE_MIN", range_min)
+        for k, kw in (("all", {}), ("min", dict(min_length=200)), ("keep", dict(core={"r3", "r11", "r%d" % (n - 1)}, neighbour={"r4"}))):
+            got = read(**kw)
+            if isinstance(want[k], str):
+                assert got == want[k], (threads, range_min, k)
+            else:
+                _same_reads(got, want[k])
+            trace = capfd.readouterr().err
+            n_par += "read in parallel" in trace
+            n_seq += "sequential pass" in trace
+    assert n_par + n_seq == 15
+    if case in ("four_line", "at_qualities", "blank_lines_crlf", "one_huge_read", "no_final_newline", "tiny_records"):
+        assert n_par == 15, (n_par, n_seq)          # plain four-line records: the ranges always verify
+    if case == "fasta_inside":
+        assert n_seq == 15                          # an error anywhere belongs to the sequential reader
+
+
 def test_features_files_equal_numpy_written(tmp_path):
     sb = synth.generate(2, 700, 8, seed=3, flank_min=30, flank_max=50)
     store = O.store_from_synth(sb)
