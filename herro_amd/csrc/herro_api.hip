@@ -694,21 +694,50 @@ int herro_synchronize(herro_ctx* ctx) {
 }
 
 // ---- codec ---------------------------------------------------------------------------------------
-int64_t herro_encode_2bit(const uint8_t* seq, uint64_t n, uint64_t* words) {
-  uint64_t block = 0, nw = 0;
-  for (uint64_t i = 0; i < n; i++) {
-    const uint8_t b = seq[i];
-    if (b >= 128) return HERRO_E_REFERENCE_PANIC;
-    uint64_t c;
-    switch (b) {
-      case 'A': case 'a': c = 0; break;
-      case 'C': case 'c': c = 1; break;
-      case 'G': case 'g': c = 2; break;
-      case 'T': case 't': c = 3; break;
-      default: c = 255; break;  // OR-ed unmasked, exactly like the reference (haec_io.rs:126-128)
+// A table instead of a switch: random bases make every case a mispredicted branch (0.1 Gbases/s); whole words of plain ACGT / acgt take the
+// table path, a word with anything else goes through the reference's byte-by-byte rule (the 255 of a non-ACGT byte is OR-ed in UNMASKED,
+// haec_io.rs:126-128, and a byte >= 128 is its panic).
+static const uint8_t* enc_table() {
+  static const struct T {
+    uint8_t t[256];
+    T() {
+      for (int i = 0; i < 256; i++) t[i] = 255;
+      t[(int)'A'] = t[(int)'a'] = 0; t[(int)'C'] = t[(int)'c'] = 1; t[(int)'G'] = t[(int)'g'] = 2; t[(int)'T'] = t[(int)'t'] = 3;
     }
-    block |= c << ((i << 1) & 63);
-    if (((i + 1) & 31) == 0 || i == n - 1) { words[nw++] = block; block = 0; }
+  } tab;
+  return tab.t;
+}
+int64_t herro_encode_2bit(const uint8_t* seq, uint64_t n, uint64_t* words) {
+  const uint8_t* T = enc_table();
+  uint64_t nw = 0;
+  for (uint64_t i = 0; i < n;) {
+    const uint32_t m = (uint32_t)std::min<uint64_t>(32, n - i);
+    uint64_t block = 0;
+    uint32_t seen = 0;
+    if (m == 32) {
+#pragma unroll
+      for (int j = 0; j < 32; j++) {
+        const uint32_t c = T[seq[i + j]];
+        seen |= c;
+        block |= (uint64_t)(c & 3u) << (2 * j);
+      }
+    } else {
+      for (uint32_t j = 0; j < m; j++) {
+        const uint32_t c = T[seq[i + j]];
+        seen |= c;
+        block |= (uint64_t)(c & 3u) << (2 * j);
+      }
+    }
+    if (seen & 0x80u) {   // something that is not ACGT / acgt in this word: the reference's rule, byte by byte
+      block = 0;
+      for (uint32_t j = 0; j < m; j++) {
+        const uint8_t b = seq[i + j];
+        if (b >= 128) return HERRO_E_REFERENCE_PANIC;
+        block |= (uint64_t)T[b] << (2 * j);   // 255, unmasked: it spills over the next three bases (and off the word's end)
+      }
+    }
+    words[nw++] = block;
+    i += m;
   }
   return (int64_t)nw;
 }
