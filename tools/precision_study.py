@@ -77,6 +77,26 @@ def make_mm_f16_lo8(dt8):
     return mm
 
 
+def fp8_const(x, dt, shift):
+    """x * 2^shift rounded to fp8 `dt` (saturating), and back: ONE power-of-two scale for the whole operand — what a kernel does that cannot
+    afford a maximum per 32-element block (the MFMA's e8m0 scale operand then carries 2^-shift for every block)."""
+    top = 448.0 if dt == torch.float8_e4m3fn else 57344.0
+    y = np.clip(np.asarray(x, np.float32) * np.float32(2.0 ** shift), -top, top)
+    return torch.from_numpy(np.ascontiguousarray(y)).to(dt).to(torch.float32).numpy() * np.float32(2.0 ** -shift)
+
+
+def make_mm_f16_lo8_const(dt8, shift_a, shift_w):
+    """as make_mm_f16_lo8 with constant scales 2^-shift_a (activation remainder) and 2^-shift_w (weights)"""
+    hf = torch.float16
+
+    def mm(a, wt):
+        a = np.asarray(a, np.float32)
+        ah = rnd(a, hf)
+        wh = rnd(wt, hf)
+        return (ah @ wh.T).astype(np.float32) + (fp8_const(a - ah, dt8, shift_a) @ fp8_const(wt, dt8, shift_w).T).astype(np.float32)
+    return mm
+
+
 def forward(F, hp, bases, quals, lens, indices, mm, mm_fc=None, mm_att=None, by=None):
     """model_numpy.forward with pluggable matmuls (mm_fc: conv2 + FC; mm_att: QK^T and PV; by: {'qkv' | 'proj' | 'ff1' | 'ff2' | 'heads': matmul})."""
     mm_fc = mm_fc or mm
@@ -177,7 +197,12 @@ def main():
         # with the lo term of proj / FF1 / FF2 on MX fp8 operands (round 4 study for the next step: the lo MFMAs are 58 % of the stack's issue)
         one, two, three = make_mm((hf, 1, 1, 1)), make_mm((hf, 2, 1, 2)), make_mm((hf, 2, 2, 2))
         for name, lo in (("p4: proj/FF lo term f16", two), ("p4': lo term MX e4m3", make_mm_f16_lo8(torch.float8_e4m3fn)),
-                         ("p4'': lo term MX e5m2", make_mm_f16_lo8(torch.float8_e5m2)), ("p5: no lo term", one)):
+                         ("p4'': lo term MX e5m2", make_mm_f16_lo8(torch.float8_e5m2)),
+                         ("p4c: lo e4m3, const 2^-14 / 2^-6", make_mm_f16_lo8_const(torch.float8_e4m3fn, 14, 6)),
+                         ("p4c: lo e4m3, const 2^-12 / 2^-4", make_mm_f16_lo8_const(torch.float8_e4m3fn, 12, 4)),
+                         ("p4c: lo e5m2, const 2^-14 / 2^-6", make_mm_f16_lo8_const(torch.float8_e5m2, 14, 6)),
+                         ("p4c: lo e4m3, const 2^-16 / 2^-8", make_mm_f16_lo8_const(torch.float8_e4m3fn, 16, 8)),
+                         ("p5: no lo term", one)):
             out = forward(F, hp, bases, quals, lens, idx, one, by={"proj": lo, "ff1": lo, "ff2": lo, "heads": three})
             e = np.abs(out - ref)
             print(f"  {name:34s} max {e.max():.2e}  rms {np.sqrt((e**2).mean()):.2e}")
