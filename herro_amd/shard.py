@@ -610,7 +610,7 @@ def hip_corrector(ctxs, window_size: int, batch: int, read_name, group_targets: 
     return fn
 
 
-def strong_leg(args, rank: int, world: int, local: int, n_windows: int, n_ctx: int = 3, model_path: str | None = None) -> dict | None:
+def strong_leg(args, rank: int, world: int, local: int, n_windows: int, n_ctx: int | None = None, model_path: str | None = None) -> dict | None:
     """ONE fixed set of `n_windows` synthetic windows (BASELINE configs[3]) sharded over the ranks.  Default (--strong-ingest local):
     every rank holds its own share of the parsed alignments (handed out once, outside the timed region — what per-rank ingestion of its
     own byte range would have produced), sends the targets it does not own to their owners in one all-to-all, corrects what it owns
@@ -629,6 +629,13 @@ def strong_leg(args, rank: int, world: int, local: int, n_windows: int, n_ctx: i
     path = model_path or model_io.default_model_file(os.path.join(root, "tests", "_cache"))[0]
     sb = synth.generate_parallel(n_t, wpt * W, n_ovl, seed=synth.SEED + 3) if rank == 0 else None
     seq, qual, off = broadcast_reads(sb) if world > 1 else (sb.seq, sb.qual, sb.off)
+    if n_ctx is None:
+        # feeder contexts per GPU: what the end_to_end leg of bench.py measured best on one GPU (four -> six feeders: +19 %, eight: slower again,
+        # profiles/r4_ab_runs.json r4_e2e_feeders); with several ranks on one host three each, and the host pools of a rank sized to its share of the CPUs
+        n_ctx = 6 if world == 1 else 3
+    if world > 1 and "HERRO_HOST_THREADS" not in os.environ:
+        per_host = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        os.environ["HERRO_HOST_THREADS"] = str(max(2, synth.usable_cpus() // (per_host * max(1, n_ctx))))   # read when a context starts its pool
     ctxs = []
     for _ in range(max(1, n_ctx)):
         c = api.Context(local)
