@@ -466,7 +466,8 @@ def main():
     if rank == 0:
         total_windows = args.steps * args.batch * world
         kern = {k: {"ms_total": v[0], "calls": v[1], "avg_us": 1e3 * v[0] / max(v[1], 1)} for k, v in tm.items()}
-        feat_names = ["cols", "win", "layout", "tokens", "supgather", "rf_quals"]
+        lean = os.environ.get("HERRO_FEATURIZE_PLANES", "0") in ("", "0")   # the library's default path (k_rows); HERRO_FEATURIZE_PLANES=1: the planes path (k_tokens), for the A/B
+        feat_names = ["cols", "win", "layout", "rows", "tokens", "supgather", "rf_quals"]
         feat_ms = sum(tm[k][0] for k in feat_names if k in tm) / timed_steps
         model_ms = sum(v[0] for k, v in tm.items() if k not in feat_names) / timed_steps
         # ---- algorithmic work per launch (one launch = G steps = G*batch windows); DESIGN.md §4/§5
@@ -474,16 +475,21 @@ def main():
         n_cols = 1 + N_OVL
         tokens = per_job["sum_supported"]
         D, FF, C1, C2, KW, NL = 256, 1024, 64, 128, 3, 4
-        # SURVEY §8 d, minus what this design never moves: featurize writes the TOKEN planes only (31 L' bytes per
-        # window) and reads the 2-bit bases (1/5 of bases + qualities); the qualities are touched only inside the
-        # model's receptive fields (rf_quals: 5 rows x 31 columns per informative row, read + written)
-        rf_bytes = tokens * 5 * 31 * 2.0
-        feat_bytes = per_job["read_bytes"] / 5.0 + per_job["op_bytes"] + per_job["out_bytes"] / 2.0 + rf_bytes
+        # What featurize has to move.  In: the 2-bit bases (1/5 of bases + qualities) and the binary ops.  Out, planes
+        # path: the TOKEN planes (31 L' bytes per window) + the receptive-field records.  Out, lean path (round 5): no planes — the
+        # receptive-field records (16 bytes per informative row and column, 5 quality bytes read for each), the decoder's votes (three
+        # bit planes over the window's positions + a byte per insertion row) and the informative-row lists (8 bytes per row).
+        n_launch_windows = G * args.batch
+        rf_bytes = tokens * 31 * (16.0 + 5.0)
+        vote_bytes = n_launch_windows * 3 * ((W + 31) // 32) * 4 + max(per_job["sum_len"] - n_launch_windows * W, 0.0) + 8.0 * tokens
+        plane_bytes = per_job["out_bytes"] / 2.0
+        feat_bytes = per_job["read_bytes"] / 5.0 + per_job["op_bytes"] + rf_bytes + (vote_bytes if lean else plane_bytes)
         alg = {  # name -> (bound, work per launch, unit)
             "tokens": ("hbm", per_job["out_bytes"] / 2.0, "B"),                                      # the token planes written
             "conv_fused": ("mfma", 2.0 * tokens * 31 * (KW * C1) * C2, "F"),
             "layers_fused": ("mfma", NL * (2.0 * tokens * D * 3 * D + 2.0 * tokens * D * D + 4.0 * tokens * D * FF), "F"),
             "cols": ("hbm", per_job["read_bytes"] / 5.0 + per_job["op_bytes"], "B"),              # 2-bit bases + ops read
+            "rows": ("hbm", n_launch_windows * 30 * 3 * ((W + 31) // 32) * 4 + vote_bytes, "B"),  # the selected columns' planes read once more, votes + lists written
             "patch_conv1": ("hbm", tokens * 31 * KW * C1 * 4, "B"),                               # y1 hi/lo written
             "conv2_gemm": ("mfma", 2.0 * tokens * 31 * (KW * C1) * C2, "F"),
             "fc_gemm": ("mfma", 2.0 * tokens * (31 * C2) * D, "F"),
@@ -541,7 +547,7 @@ def main():
             "mbases_per_s": total_windows / el * W / 1e6,
             "roofline": roof,
             "roofline_featurize_group": {
-                "kernels": feat_names, "bound": "hbm", "achieved": feat_bytes / G / (feat_ms * 1e-3) / 1e9,
+                "kernels": feat_names, "path": "lean (no token planes)" if lean else "planes", "bound": "hbm", "achieved": feat_bytes / G / (feat_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": feat_bytes / G / (feat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_step": feat_bytes / G, "ms_per_step": feat_ms},
             "roofline_next_kernels": roof_next, "repeat_ms_per_step": [r * 1e3 / args.steps for r in repeats], "stage_ms_per_step": {"featurize": feat_ms, "model": model_ms},

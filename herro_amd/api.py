@@ -26,6 +26,7 @@ EXPORTS = [
     "herro_paf_parse", "herro_oec_read", "herro_paf_n_targets", "herro_paf_target_ids", "herro_paf_aln_off",
     "herro_paf_alignments", "herro_paf_free", "herro_name_index_create", "herro_name_index_free", "herro_paf_parse_indexed",
     "herro_oec_read_indexed", "herro_paf_parse_view", "herro_debug_host_ctx", "herro_debug_job_array", "herro_debug_tile_plan", "herro_debug_tile_plan_sib",
+    "herro_debug_set_featurize_planes", "herro_debug_job_rf",
     "herro_pool_create", "herro_pool_destroy", "herro_pool_last_error", "herro_pool_size", "herro_pool_ctx", "herro_pool_set_reads", "herro_pool_load_model",
     "herro_pool_correct", "herro_pool_result", "herro_pool_groups_taken",
     "herro_fastx_read", "herro_reads_count", "herro_reads_seq", "herro_reads_qual", "herro_reads_off", "herro_reads_ids",
@@ -141,6 +142,9 @@ def lib():
         L.herro_debug_host_ctx.argtypes = [u32, vp, vp]
         L.herro_debug_job_array.restype = C.c_int64
         L.herro_debug_job_array.argtypes = [vp, i32, vp, vp]
+        L.herro_debug_set_featurize_planes.argtypes = [vp, i32]
+        L.herro_debug_job_rf.restype = C.c_int64
+        L.herro_debug_job_rf.argtypes = [vp, u32, vp, u64]
         L.herro_debug_tile_plan.restype = C.c_int64
         L.herro_debug_tile_plan.argtypes = [vp, u32, i32, u32, vp, vp, vp]
         L.herro_debug_tile_plan_sib.restype = i32
@@ -330,6 +334,10 @@ class Context:
     def set_precision(self, mode: int):
         self._chk(self._l.herro_set_precision(self.h, mode))
 
+    def featurize_planes(self, on: bool):
+        """test hook: jobs featurized from now on take the planes path (k_tokens) instead of the lean one (k_rows)"""
+        self._chk(self._l.herro_debug_set_featurize_planes(self.h, int(on)))
+
     def describe_model(self) -> str:
         buf = C.create_string_buffer(4096)
         n = self._l.herro_model_describe(self.h, buf, 4096)
@@ -503,6 +511,16 @@ class Job:
             self.ctx._chk(int(got))
         text = out[:got] if as_array else out[:got].tobytes()
         return (text, ends[:n]) if with_ends else text
+
+    def rf_records(self, w: int) -> np.ndarray:
+        """test hook: the receptive-field records the model read for window w, [n_supported, 31, 16] (bytes 0..7 tokens, 8..15 qualities)"""
+        ns = self.info(w).n_supported
+        out = np.zeros((ns, 31, 16), np.uint8)
+        n = self._l.herro_debug_job_rf(self.h, w, out.ctypes.data, out.nbytes)
+        if n < 0:
+            self.ctx._chk(int(n))
+        assert n == ns * 31
+        return out
 
     def stats(self) -> dict[str, int]:
         o = np.zeros(6, np.uint64)

@@ -144,6 +144,9 @@ struct herro_ctx {
   std::vector<uint32_t> read_len, name_class;
   std::vector<uint64_t> h_word_off, h_qual_off;  // host copies: overlap descriptors carry them (saves the kernel a dependent load)
   bool host_only = false;  // herro_debug_host_ctx: no device; herro_job_create stops after the host half
+  // lean: herro_job_featurize derives informative rows, votes and receptive fields without writing the token planes (k_rows); the planes are
+  // built when somebody asks for them.  HERRO_FEATURIZE_PLANES=1 (or herro_debug_set_featurize_planes): the planes path of rounds 3-4 (A/B, parity tests)
+  bool lean = [] { const char* e = getenv("HERRO_FEATURIZE_PLANES"); return !e || atoi(e) == 0; }();
   bool tile_packing = [] { const char* e = getenv("HERRO_TILE_PACK"); return !e || atoi(e) != 0; }();  // 0: windows in batch order (A/B)
   uint64_t* d_words = nullptr;
   uint32_t* d_p0 = nullptr;
@@ -234,7 +237,9 @@ struct herro_job {
   bool featurized = false, synced = false, inferred = false;
   uint32_t host_max_cols = 0, host_n_cls = 0;   // filled for host-only jobs (herro_debug_host_ctx)
   uint64_t host_scr_ops = 0, host_fin_bytes = 0;
-  bool quals_full = false;   // the complete quality planes exist (featurize writes tokens only)
+  bool quals_full = false;   // the complete quality planes exist (featurize never writes them)
+  bool lean = false;         // the last featurize pass ran the lean path (k_rows): votes in position space, no row map
+  bool tokens_full = false;  // the token planes + row map exist (planes path, or launch_full_tokens behind a lean pass)
   // host copies after sync
   std::vector<uint32_t> h_Lf, h_nsup, h_nkept;
   std::vector<uint64_t> sup_off;  // [n_win+1] prefix of nsup
@@ -574,6 +579,10 @@ static int check_sib(herro_ctx* ctx) {
   HIP_TRY(ctx, hipMemcpyAsync(&e, (uint32_t*)ctx->sib_flag + ctx->sib_cap, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (!e) return HERRO_OK;
+  // reported once: the word is cleared so that the context stays usable (it used to stay set, and every later fetch on the context
+  // failed — launches without sibling tiles included — until ensure_sib reallocated).  The caller re-runs herro_job_infer (or selects
+  // precision 1, whose layer-by-layer path has no sibling tiles) for the job whose logits were refused.
+  (void)hipMemsetAsync((uint32_t*)ctx->sib_flag + ctx->sib_cap, 0, 4, ctx->stream);
   ctx->err = "fused stack: a sibling tile of a window above 64 informative rows never published its keys (layer " + std::to_string(e - 1) + "); logits invalid";
   return HERRO_E_STATE;
 }
@@ -1629,6 +1638,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   const size_t o_cseq = take(row_elems), o_ctmp = take(row_elems), o_clen = take((uint64_t)n_win * 4);
   const size_t o_srow = take(row_elems * 4), o_spi = take(row_elems * 4);
   const size_t o_finb = take(fin_bytes), o_finq = take(fin_bytes), o_nd = take((uint64_t)n_cls * 8);
+  const size_t o_vpl = take((uint64_t)n_win * 3 * J.nw * 4);
   const size_t dev_bytes = cur;
   job->dev = arena_acquire(ctx, ctx->free_dev, dev_bytes, 1);
   auto give_back = [&]() {
@@ -1652,6 +1662,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.cons_seq = (uint8_t*)(db + o_cseq); J.cons_tmp = (uint8_t*)(db + o_ctmp); J.cons_len = (uint32_t*)(db + o_clen);
   J.sup_row = (uint32_t*)(db + o_srow); J.sup_pi = (uint32_t*)(db + o_spi);
   J.fin_b = (uint8_t*)(db + o_finb); J.fin_q = (uint8_t*)(db + o_finq); J.nd = (uint32_t*)(db + o_nd);
+  J.vpl = (uint32_t*)(db + o_vpl);
   // one copy, pinned -> device, asynchronous on the context stream: the kernels of herro_job_featurize queue behind it
   // in stream order, nobody waits here
   hipError_t e = hipMemcpyAsync(db, job->pin.p, desc_bytes, hipMemcpyHostToDevice, ctx->stream);
@@ -1720,9 +1731,10 @@ int herro_job_featurize(herro_job* job) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   // everything derived from a previous pass over this job is stale from here on
   job->synced = false; job->inferred = false; job->quals_full = false;
+  job->lean = ctx->lean; job->tokens_full = !ctx->lean;
   job->consensus_done = false; job->consensus_on_host = false; job->logits_on_host = false;
   if (job->J.n_win == 0) { job->featurized = true; return HERRO_OK; }
-  launch_featurize(job->J, ctx->stream, &ctx->timer);
+  launch_featurize(job->J, ctx->stream, &ctx->timer, job->lean);
   HIP_TRY(ctx, hipGetLastError());
   // the per-window counts follow the kernels into pinned memory; whoever needs them waits for the event,
   // not for the stream, so the next job's kernels can already be queued behind this one
@@ -1779,7 +1791,7 @@ static int ensure_logits(herro_job* job, uint64_t rows) {
   if (job->d_info) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); small_release(ctx, job->a_logits); job->d_info = job->d_base = nullptr; }
   job->logit_cap = std::max<uint64_t>(rows + rows / 8, 1);
   const uint64_t o_base = (job->logit_cap * 4 + 255) & ~(uint64_t)255, o_rfq = (o_base + job->logit_cap * 20 + 255) & ~(uint64_t)255;
-  job->a_logits = small_acquire(ctx, o_rfq + job->logit_cap * HERRO_ROWS * 8 + 256);
+  job->a_logits = small_acquire(ctx, o_rfq + job->logit_cap * HERRO_ROWS * 16 + 256);   // 16-byte receptive-field records: 8 tokens + 8 qualities
   if (!job->a_logits.p) { ctx->err = "out of device memory for the logits"; return HERRO_E_NO_DEVICE; }
   job->d_info = (float*)job->a_logits.p;
   job->d_base = (float*)((unsigned char*)job->a_logits.p + o_base);
@@ -1927,9 +1939,13 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   if (max_tiles_b && (rc = ensure_sib(ctx, max_tiles_b))) return rc;
   // the qualities the model will read: rows within 2 * (kw / 2) of an informative row (two stacked convs)
   const uint32_t rf_half = 2 * (ctx->M.h.kw / 2);
-  const bool rf_compact = !job->quals_full && job->d_rfq && 2 * rf_half + 1 <= 8;   // the model reads the compact receptive fields; else the planes
+  const bool rf_compact = job->d_rfq && 2 * rf_half + 1 <= 8;   // the model reads the compact receptive fields (tokens + qualities); else the planes
   const bool rfq_there = job->rfq_spec && rf_compact && job->rfq_spec_half == rf_half && job->rfq_spec_cap >= total_sup;   // gathered behind featurize
-  if (!job->quals_full && !groups.empty() && !rfq_there)
+  if (!rf_compact && !job->tokens_full && !groups.empty()) {   // a receptive field above 8 rows: token planes + row map first
+    launch_full_tokens(job->J, ctx->stream, &ctx->timer);
+    job->tokens_full = true;
+  }
+  if (!(job->quals_full && !rf_compact) && !groups.empty() && !rfq_there)
     launch_rf_quals(job->J, rf_half, job->d_supoff_blob, rf_compact ? job->d_rfq : nullptr, job->logit_cap, ctx->stream, &ctx->timer);
   for (const Offs& o : offs) {
     const unsigned char* base = (const unsigned char*)job->d_bdesc;
@@ -1987,7 +2003,7 @@ int herro_job_consensus(herro_job* job) {
     if (n) HIP_TRY(ctx, hipMemcpyAsync(job->d_supoff, job->sup_off.data(), n * 8ull, hipMemcpyHostToDevice, ctx->stream));
     d_so = job->d_supoff;
   }
-  launch_consensus(job->J, d_so, job->d_base, ctx->stream, &ctx->timer);
+  launch_consensus(job->J, d_so, job->d_base, job->lean, ctx->stream, &ctx->timer);
   HIP_TRY(ctx, hipGetLastError());
   job->consensus_done = true;
   job->consensus_on_host = false;
@@ -2013,6 +2029,12 @@ static int fetch_planes(herro_job* job, uint32_t w, std::vector<uint8_t>& pb, st
   const WinDesc& wd = job->win[w];
   const size_t bytes = (size_t)HERRO_ROWS * wd.lub;
   pb.resize(bytes);
+  if (!job->tokens_full) {  // a lean featurize pass wrote no planes: build them (and the row map the quality planes need) for whoever asks
+    launch_full_tokens(job->J, ctx->stream, nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    job->tokens_full = true;
+  }
   HIP_TRY(ctx, hipMemcpy(pb.data(), job->J.fin_b + wd.fin_off, bytes, hipMemcpyDeviceToHost));
   if (pq) {
     if (!job->quals_full) {  // featurize leaves the quality planes to whoever asks for them
@@ -2446,6 +2468,25 @@ herro_ctx* herro_debug_host_ctx(uint32_t n_reads, const uint32_t* read_len, cons
     ctx->h_qual_off[i + 1] = ctx->h_qual_off[i] + read_len[i];
   }
   return ctx;
+}
+
+int herro_debug_set_featurize_planes(herro_ctx* ctx, int on) {
+  if (!ctx) return HERRO_E_INVALID;
+  ctx->lean = on == 0;
+  return HERRO_OK;
+}
+
+// the receptive-field records the model read for window w (valid once herro_job_infer has run with a compact receptive field)
+int64_t herro_debug_job_rf(herro_job* job, uint32_t w, uint8_t* out, uint64_t cap) {
+  if (!job || w >= job->win.size() || !out) return HERRO_E_INVALID;
+  herro_ctx* ctx = job->ctx;
+  if (!job->inferred || !job->d_rfq) { ctx->err = "herro_job_infer has not run"; return HERRO_E_STATE; }
+  const uint64_t n = (uint64_t)job->h_nsup[w] * HERRO_ROWS;
+  if (n * 16 > cap) { ctx->err = "output buffer too small"; return HERRO_E_INVALID; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (n) HIP_TRY(ctx, hipMemcpy(out, job->d_rfq + job->sup_off[w] * HERRO_ROWS * 16, n * 16, hipMemcpyDeviceToHost));
+  return (int64_t)n;
 }
 
 // which: 0 ops (u32), 1 OwDesc, 2 WinDesc, 3 tile_win (u32), 4 tile_r0 (u32), 5 tgt_win_off (u32).

@@ -81,7 +81,9 @@ struct JobDev {
   uint32_t* nd;          // [2*cls]: matches, mismatches (features.rs:461-500)
   uint32_t* rank_qid;    // [win.ow_begin + rank] ranked query ids (features.rs:569)
   uint8_t* cons_seq;     // [win.row_off ..] corrected bases of the window (ASCII), cons_len[w] of them
-  uint8_t* cons_tmp;     // [win.row_off + row] per-row call before '*' removal
+  uint8_t* cons_tmp;     // planes path (k_tokens): [win.row_off + row] per-row call before '*' removal.  Lean path (k_rows): [win.row_off + i], i = index of an
+                         // INSERTION row among the window's insertion rows (row - position - 1): its majority vote | informative << 7
+  uint32_t* vpl;         // lean path: [win][3][nw] majority vote of every target position's base row as three bit planes (code 0..4 = A C G T *)
   uint32_t* cons_len;    // [win]
   unsigned long long* prof;  // HERRO_PROF_BUILD libraries run with HERRO_PROF=1: [kernel * 16 + phase][32 shards] shader cycles, [.. + 15] workgroups (null otherwise)
 };
@@ -157,14 +159,20 @@ struct KernelTimer {
 #define KT_BEGIN(tm, name, st) do { if ((tm) && (tm)->on) (tm)->begin(name, st); } while (0)
 #define KT_END(tm, st) do { if ((tm) && (tm)->on) (tm)->end(st); } while (0)
 
-void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm);
-// qualities inside the model's receptive fields (rows within `half` of an informative row)
-// rf_q != null: compact layout [(sup_off[w] + k) * 31 + column][8] (needs 2 * half + 1 <= 8), else into the quality planes
-// cap: informative rows rf_q has room for (a window whose slots would lie beyond it is left out: launches in front of the host's count)
-void launch_rf_quals(const JobDev& J, uint32_t half, const uint64_t* sup_off, uint8_t* rf_q, uint64_t cap, hipStream_t st, KernelTimer* tm);
+// lean (the default of herro_job_featurize): no token planes — informative rows, votes and (launch_rf_quals) the receptive fields of the
+// informative rows are derived from the column bit planes in position space; launch_full_tokens builds the planes for whoever asks.
+// !lean: the planes path of rounds 3-4 (k_tokens derives everything while it writes the planes).
+void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm, bool lean);
+void launch_full_tokens(const JobDev& J, hipStream_t st, KernelTimer* tm);   // token planes + row map behind a lean featurize (informative rows / votes are left alone)
+// the model's receptive fields (rows within `half` of an informative row)
+// rf != null: compact, one 16-byte record per (informative row, column) at [(sup_off[w] + k) * 31 + column]: bytes 0..7 the TOKENS of rows
+// sup_row[k] - half .. + 7 - half of that column, bytes 8..15 their qualities (needs 2 * half + 1 <= 8); else the qualities go into the
+// quality planes (which needs the row map, i.e. the planes path or launch_full_tokens)
+// cap: informative rows rf has room for (a window whose slots would lie beyond it is left out: launches in front of the host's count)
+void launch_rf_quals(const JobDev& J, uint32_t half, const uint64_t* sup_off, uint8_t* rf, uint64_t cap, hipStream_t st, KernelTimer* tm);
 void launch_supoff(const JobDev& J, uint64_t* sup_off, hipStream_t st);   // sup_off[0 .. n_win]: prefix of win_nsup
 // the complete quality planes (featurize itself only writes tokens)
 void launch_full_quals(const JobDev& J, hipStream_t st);
-void launch_consensus(const JobDev& J, const uint64_t* sup_off, const float* base_logits, hipStream_t st, KernelTimer* tm);
+void launch_consensus(const JobDev& J, const uint64_t* sup_off, const float* base_logits, bool lean, hipStream_t st, KernelTimer* tm);
 
 }  // namespace herro

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_patch_conv1(ModelDev M, BatchDev B, Mod
   const uint8_t* pb = B.planes_b + B.plane_off[b];
   const uint8_t* pq = B.planes_q + B.plane_off[b];
   const uint32_t ld = B.plane_ld[b];
-  const uint8_t* rq = (B.rf_q && P <= 8) ? B.rf_q + (B.out_off[b] + (n - B.tok_off[b])) * HERRO_ROWS * 8 : nullptr;   // receptive-field qualities, compact
+  const uint8_t* rq = (B.rf_q && P <= 8) ? B.rf_q + (B.out_off[b] + (n - B.tok_off[b])) * HERRO_ROWS * 16 : nullptr;   // the token's receptive fields, compact: per read row 8 tokens + 8 qualities (k_rfq)
 
   for (uint32_t e = threadIdx.x; e < kw * 12 * c1; e += blockDim.x) s_t1[e] = M.t1[e];
   for (uint32_t e = threadIdx.x; e < kw * c1; e += blockDim.x) s_wq[e] = M.wq1[e];
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(256) void k_patch_conv1(ModelDev M, BatchDev B, Mod
     float qn = 0.f;
     if (q >= 0 && q < lmax) {
       if (q < len) {
-        tok = pb[(uint64_t)r * ld + q];
-        qn = norm_qual(rq ? rq[r * 8 + e % P] : pq[(uint64_t)r * ld + q]);
+        tok = rq ? rq[r * 16 + e % P] : pb[(uint64_t)r * ld + q];
+        qn = norm_qual(rq ? rq[r * 16 + 8 + e % P] : pq[(uint64_t)r * ld + q]);
       } else {  // batch padding (inference.rs:86-97)
         tok = TOK_PAD;
         qn = norm_qual(126u);
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void k_patch_conv1_s(ModelDev M, BatchDev B, M
     const uint8_t* pb = B.planes_b + B.plane_off[b];
     const uint8_t* pq = B.planes_q + B.plane_off[b];
     const uint32_t ld = B.plane_ld[b];
-    const uint8_t* rq = (B.rf_q && P <= 8) ? B.rf_q + (B.out_off[b] + (n - B.tok_off[b])) * HERRO_ROWS * 8 : nullptr;   // receptive-field qualities, compact
+    const uint8_t* rq = (B.rf_q && P <= 8) ? B.rf_q + (B.out_off[b] + (n - B.tok_off[b])) * HERRO_ROWS * 16 : nullptr;   // the token's receptive fields, compact: per read row 8 tokens + 8 qualities (k_rfq)
     __syncthreads();
     for (uint32_t e = threadIdx.x; e < HERRO_ROWS * P; e += blockDim.x) {
       const uint32_t r = e / P;
@@ -452,8 +452,8 @@ __global__ __launch_bounds__(256) void k_patch_conv1_s(ModelDev M, BatchDev B, M
       float qn = 0.f;
       if (q >= 0 && q < lmax) {
         if (q < len) {
-          tok = pb[(uint64_t)r * ld + q];
-          qn = norm_qual(rq ? rq[r * 8 + e % P] : pq[(uint64_t)r * ld + q]);
+          tok = rq ? rq[r * 16 + e % P] : pb[(uint64_t)r * ld + q];
+          qn = norm_qual(rq ? rq[r * 16 + 8 + e % P] : pq[(uint64_t)r * ld + q]);
         } else {  // batch padding (inference.rs:86-97)
           tok = TOK_PAD;
           qn = norm_qual(126u);
@@ -1019,8 +1019,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_w(ModelDev M, BatchDev B, Model
   // ---- gather: threads 0..127 fetch the 5 tokens of pair tid, threads 128..255 its 5 qualities
   const uint32_t grr = tid & 127u;
   const bool gq = tid >= 128;
-  const bool rfq = gq && B.rf_q != nullptr;   // qualities from the compact receptive-field array
-  const uint8_t* gplane = gq ? (rfq ? B.rf_q : B.planes_q) : B.planes_b;
+  const bool rfq = B.rf_q != nullptr;   // tokens and qualities from the compact receptive-field records (16 bytes per pair: 8 tokens, 8 qualities)
+  const uint8_t* gplane = rfq ? B.rf_q : (gq ? B.planes_q : B.planes_b);
   struct PairMeta { uint64_t rowbase; uint32_t tok_row, len, lmax; };  // lmax = 0: no such pair
   auto load_meta = [&](uint32_t tile) -> PairMeta {
     const uint32_t m = tile * CW_TP + grr;
@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_w(ModelDev M, BatchDev B, Model
     if (tile < n_tiles && m < n_rows) {
       const TokMeta tm = S.tok_meta[m / HERRO_ROWS];
       r.rowbase = tm.plane_off + (uint64_t)(m % HERRO_ROWS) * tm.plane_ld;  // byte offset of the read row
-      if (rfq) r.rowbase = ((uint64_t)tm.rf_idx * HERRO_ROWS + m % HERRO_ROWS) * 8 - (uint64_t)(int64_t)((int32_t)tm.tok_row - 2);   // + q = slot byte q - (tok_row - 2)
+      if (rfq) r.rowbase = ((uint64_t)tm.rf_idx * HERRO_ROWS + m % HERRO_ROWS) * 16 + (gq ? 8u : 0u) - (uint64_t)(int64_t)((int32_t)tm.tok_row - 2);   // + q = record byte q - (tok_row - 2)
       r.tok_row = tm.tok_row;
       r.len = tm.len;
       r.lmax = tm.lmax;

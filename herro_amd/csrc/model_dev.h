@@ -77,9 +77,10 @@ struct BatchDev {
   const uint32_t* tok_off;    // [B+1] first token of each window
   const uint64_t* sup_off;    // [B] element offset of the window's informative-row list
   const uint64_t* out_off;    // [B] element offset of the window's logits in the job buffers
-  const uint8_t* planes_b;    // tokens
+  const uint8_t* planes_b;    // token planes (used when rf_q is null: the stand-alone entry, receptive fields above 8 rows)
   const uint8_t* planes_q;    // raw qualities (complete planes; used when rf_q is null)
-  const uint8_t* rf_q;        // qualities of the receptive fields only: [(out_off[b] + k) * 31 + row][8], byte i = row tok_row - 2 (kw / 2) + i (k_quals); null: read planes_q
+  const uint8_t* rf_q;        // the receptive fields only, compact (k_rfq): one 16-byte record per (token, read row) at [(out_off[b] + k) * 31 + row]:
+                              // bytes 0..7 the tokens of rows tok_row - 2 (kw / 2) + i, bytes 8..15 their qualities; null: read the planes
   const uint32_t* sup_row;    // informative rows
   uint32_t n_tiles;           // token tiles of whole windows (<= 64 tokens each) for the fused stack; 0: not tileable
   const uint32_t* tile_tok0;  // [n_tiles+1] first token of each tile

@@ -157,7 +157,7 @@ constexpr int CM_NT = 256;
 #endif
 constexpr size_t CONV_M_SHM = (size_t)48 * 1024 + 128 * 4 + 32 * 16 + 256 * 4;
 
-template <int NB, int WPS>
+template <int NB, int WPS, bool RF>   // RF: the cells come as 16-byte receptive-field records (B.rf_q); else from the token / quality planes
 __global__ __launch_bounds__(CM_NT, WPS) void k_conv_m(ModelDev M, BatchDev B, ModelScratch S, uint32_t n_rows, uint32_t n_units) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4* s_w2 = reinterpret_cast<uint4*>(smem);                     // conv2 weights in fragment order: fragment f, lane l at [f * 64 + l]
@@ -179,11 +179,11 @@ __global__ __launch_bounds__(CM_NT, WPS) void k_conv_m(ModelDev M, BatchDev B, M
 #pragma unroll
         for (int tp = 0; tp < 3; tp++) w1[tp][sl][jt] = *reinterpret_cast<const half8*>(p + (uint64_t)(((sl * 2 + jt) * 3 + tp) * 64) * 8);
   }
-  const bool rfq = B.rf_q != nullptr;
+  constexpr bool rfq = RF;
   // The receptive field of pair m: rows tok_row - 2 .. + 2 of read row (m % 31) of the token's window; outside [0, lmax): token 12
   // (zero table row) and no quality; inside the batch padding [len, lmax): pad token and quality 126 (inference.rs:86-97).
   // Two dependent loads (the token's record, then its cells) run two and one unit ahead of the arithmetic.
-  struct Raw { uint32_t t[5], q[5]; uint2 q8; };
+  struct Raw { uint32_t t[5], q[5]; uint4 rf; };
   struct Cells { uint32_t tok[2], q[2], ok; };   // five token bytes, five quality bytes (0xff: none), validity of the three conv1 positions
   auto load_meta = [&](uint32_t m) -> TokCv {
 #if HERRO_CONV_DBG & 1
@@ -196,25 +196,32 @@ __global__ __launch_bounds__(CM_NT, WPS) void k_conv_m(ModelDev M, BatchDev B, M
 #if HERRO_CONV_DBG & 1
     m = lane;
 #endif
-    const uint32_t rr = min(m, n_rows - 1u) % HERRO_ROWS, ld = tm.ld_d1 & 0xffffu, trow = tm.row_ok & 0xffffu;
+    const uint32_t rr = min(m, n_rows - 1u) % HERRO_ROWS;
+    if constexpr (RF) {   // one 16-byte record: the pair's five tokens and five qualities (k_rfq) — no token plane exists on the lean path
+      r.rf = *reinterpret_cast<const uint4*>(B.rf_q + ((uint64_t)tm.rf_idx * HERRO_ROWS + rr) * 16);
+#pragma unroll
+      for (int i = 0; i < 5; i++) { r.t[i] = 0; r.q[i] = 0; }
+      return r;
+    } else {
+    const uint32_t ld = tm.ld_d1 & 0xffffu, trow = tm.row_ok & 0xffffu;
     const uint8_t* pb = B.planes_b + tm.plane_off + (uint64_t)rr * ld;
-    r.q8 = make_uint2(0, 0);
-    if (rfq) r.q8 = *reinterpret_cast<const uint2*>(B.rf_q + ((uint64_t)tm.rf_idx * HERRO_ROWS + rr) * 8);
+    r.rf = make_uint4(0, 0, 0, 0);
     const uint8_t* pq = B.planes_q + tm.plane_off + (uint64_t)rr * ld;
 #pragma unroll
     for (int i = 0; i < 5; i++) {
       const uint32_t row = i < 2 ? (uint32_t)max((int32_t)trow - 2 + i, 0) : trow - 2 + i;   // a row behind the plane's last is read (valid memory) and masked out
       r.t[i] = pb[row];
-      r.q[i] = rfq ? 0u : (uint32_t)pq[row];
+      r.q[i] = (uint32_t)pq[row];
     }
     return r;
+    }
   };
   auto finish = [&](const Raw& r, const TokCv& tm) -> Cells {
     Cells c;
-    const uint32_t t0 = r.t[0] | (r.t[1] << 8) | (r.t[2] << 16) | (r.t[3] << 24);
-    const uint32_t q0 = rfq ? r.q8.x : (r.q[0] | (r.q[1] << 8) | (r.q[2] << 16) | (r.q[3] << 24)), q1 = rfq ? r.q8.y : r.q[4];
+    const uint32_t t0 = rfq ? r.rf.x : (r.t[0] | (r.t[1] << 8) | (r.t[2] << 16) | (r.t[3] << 24)), t1 = rfq ? r.rf.y : r.t[4];
+    const uint32_t q0 = rfq ? r.rf.z : (r.q[0] | (r.q[1] << 8) | (r.q[2] << 16) | (r.q[3] << 24)), q1 = rfq ? r.rf.w : r.q[4];
     const uint32_t mk1 = tm.row_ok >> 24;
-    c.tok[0] = (t0 & tm.mk0) | tm.dt0; c.tok[1] = (r.t[4] & mk1) | ((tm.ld_d1 >> 16) & 0xffu);
+    c.tok[0] = (t0 & tm.mk0) | tm.dt0; c.tok[1] = (t1 & mk1) | ((tm.ld_d1 >> 16) & 0xffu);
     c.q[0] = (q0 & tm.mk0) | tm.dq0; c.q[1] = (q1 & mk1) | (tm.ld_d1 >> 24);
     c.ok = (tm.row_ok >> 16) & 7u;
     return c;
@@ -1245,15 +1252,15 @@ void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S,
   {
     const uint32_t n_rows = N * HERRO_ROWS;
     KT_BEGIN(tm, "conv_fused", st);
-    static const int nb = [] { const char* e = getenv("HERRO_CONV_NB"); return e ? atoi(e) : 1; }();
-    if (nb != 2) {   // one block of 16 pairs per step, three workgroups per compute unit
+    {   // one block of 16 pairs per step, three workgroups per compute unit
       const uint32_t n_units = (n_rows + 15) / 16;
-      opt_in_lds(reinterpret_cast<const void*>(k_conv_m<1, 3>), CONV_M_SHM);
-      hipLaunchKernelGGL((k_conv_m<1, 3>), dim3(std::min<uint32_t>((n_units + 3) / 4, 768u)), dim3(CM_NT), CONV_M_SHM, st, M, B, S, n_rows, n_units);
-    } else {         // HERRO_CONV_NB=2 (A/B): two blocks per step share every read of a conv2 fragment; 226 VGPRs, two workgroups per compute unit
-      const uint32_t n_units = (n_rows + 31) / 32;
-      opt_in_lds(reinterpret_cast<const void*>(k_conv_m<2, 2>), CONV_M_SHM);
-      hipLaunchKernelGGL((k_conv_m<2, 2>), dim3(std::min<uint32_t>((n_units + 3) / 4, 512u)), dim3(CM_NT), CONV_M_SHM, st, M, B, S, n_rows, n_units);
+      if (B.rf_q) {
+        opt_in_lds(reinterpret_cast<const void*>(k_conv_m<1, 3, true>), CONV_M_SHM);
+        hipLaunchKernelGGL((k_conv_m<1, 3, true>), dim3(std::min<uint32_t>((n_units + 3) / 4, 768u)), dim3(CM_NT), CONV_M_SHM, st, M, B, S, n_rows, n_units);
+      } else {
+        opt_in_lds(reinterpret_cast<const void*>(k_conv_m<1, 3, false>), CONV_M_SHM);
+        hipLaunchKernelGGL((k_conv_m<1, 3, false>), dim3(std::min<uint32_t>((n_units + 3) / 4, 768u)), dim3(CM_NT), CONV_M_SHM, st, M, B, S, n_rows, n_units);
+      }
     }
     KT_END(tm, st);
   }

@@ -772,7 +772,9 @@ __device__ __forceinline__ uint32_t dpp_quad_lane0(uint32_t v) {  // value of th
   return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x00, 0xf, 0xf, true);  // quad_perm [0,0,0,0]
 }
 
-__global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J) {
+// aux != 0 (the planes path): informative rows and the decoder's votes come out of this kernel too; aux == 0 (planes requested behind a lean
+// featurize): token planes and row map only — k_rows' lists and votes are left alone.
+__global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J, uint32_t aux) {
   __shared__ __attribute__((aligned(16))) CTab s_ct[32];
   __shared__ __attribute__((aligned(16))) uint16_t s_rowinfo[ROWCAP];   // (position - pa) | base-row flag << 15
   __shared__ uint32_t s_adj[ROWCAP];                                    // per row: inserted A, C, G, T (5 bits each), '*' they replace (bits 20..)
@@ -1015,14 +1017,14 @@ __global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J) {
       const uint32_t cons_v = (c0 < 2u || (c0 == c1 && (i0 == tb0 || i1 == tb0))) ? tb0 : i0;
       consw |= cons_v << (q4 * 8);
     }
-    *reinterpret_cast<uint32_t*>(J.cons_tmp + wd.row_off + r0 + seg * 16u + cg * 4u) = consw;
+    if (aux) *reinterpret_cast<uint32_t*>(J.cons_tmp + wd.row_off + r0 + seg * 16u + cg * 4u) = consw;
     if (supb) atomicOr(&s_supbits[(seg * 16u + cg * 4u) >> 5], supb << ((seg * 16u + cg * 4u) & 31u));
   }
   __syncthreads();
   PROF_MARK(J, 3, 5);
   // -- D: the chunk's informative positions, in row order (SupportedPos, features.rs:896-900), by the first wave; the window's
   // list is put together by k_supgather
-  if (tid < 64) {
+  if (aux && tid < 64) {
     const uint32_t bits = tid < ROWCAP / 32 ? s_supbits[tid] : 0u;
     const uint32_t inc = wscan_incl((uint32_t)__popc(bits));
     uint32_t k = inc - (uint32_t)__popc(bits);
@@ -1068,6 +1070,264 @@ __global__ __launch_bounds__(64) void k_supgather(JobDev J) {
 }
 
 // =====================================================================================================
+// k_rows — one workgroup per window (blockDim.x >= nw): the LEAN path's replacement for k_tokens (round 5)
+// =====================================================================================================
+// Nobody on the inference path reads the [31][L'] token matrix as a matrix: the model reads the five rows around every informative
+// row (~15 of ~4700 rows per window), the decoder reads one vote per row.  Both follow from per-row SYMBOL COUNTS, and the counts of
+// a target position's base row are a position-space quantity: bit-sliced counters over the selected columns' planes, 32 positions
+// per lane, as k_win does for pass 1 — ~30 bit operations per column and word instead of ~170 instructions per column and 16 rows.
+//   * base rows: saturating 2-bit counters per symbol (the threshold is 3, features.rs:558,712) -> informative positions; the
+//     decoder's vote (consensus.rs:178-200) is only consulted on rows that are NOT informative, where at most one symbol reaches 3:
+//     "the symbol with >= 3", else the first symbol with exactly 2 (stable order A C G T *), with the target tie-break when two
+//     symbols have 2, else the target — all expressible on the saturated counters;
+//   * insertion rows (~13 % of the rows): '*' wherever the column covers the position (an exact 5-bit bit-sliced count), minus the
+//     columns that hold an inserted base there, plus those bases — per-row accumulators in LDS fed from k_layout's run lists, as
+//     in k_tokens; the general vote on exact counts.
+// Out: the window's informative rows in row order (sup_row / sup_pi / win_nsup — no k_supgather), the base rows' votes as three bit
+// planes (vpl), the insertion rows' votes as bytes indexed by insertion-row ordinal (cons_tmp).  No token plane, no row map: the
+// receptive fields are gathered by k_rfq from the informative rows' (position, ordinal) and row_of_pos2; k_tokens builds the planes
+// when somebody asks for them (herro_job_window_copy, the features writer, models with receptive fields above 8 rows).
+constexpr uint32_t RW_ICAP = 2048;   // insertion rows per pass (accumulators in LDS); a window with more takes several passes
+#define RI(p) ((p) + ((p) >> 5))     // lane i walks positions 32 i ..: one pad word per 32 keeps the lanes on different banks
+__host__ __device__ inline size_t rows_lds(uint32_t W) { return (size_t)(W + 2 + ((W + 2) >> 5) + 1) * 4; }
+
+// the decoder's vote on exact counts c5 = A C G T * (consensus.rs:186-200): two most common symbols by a stable descending sort,
+// target tie-break
+__device__ __forceinline__ uint32_t vote5(const uint32_t (&c5)[5], uint32_t tb) {
+  uint32_t c0 = c5[0], i0 = 0;
+#pragma unroll
+  for (uint32_t q = 1; q < 5; q++) if (c5[q] > c0) { c0 = c5[q]; i0 = q; }
+  uint32_t c1 = 0, i1 = 5;
+  bool have = false;
+#pragma unroll
+  for (uint32_t q = 0; q < 5; q++)
+    if (q != i0 && (!have || c5[q] > c1)) { c1 = c5[q]; i1 = q; have = true; }
+  return (c0 < 2u || (c0 == c1 && (i0 == tb || i1 == tb))) ? tb : i0;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_rows(JobDev J) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t rw_smem[];
+  uint32_t* s_rop = rw_smem;                                       // [win_len + 1] row of every position, padded (RI)
+  __shared__ __attribute__((aligned(16))) CTab s_ct[32];
+  __shared__ uint32_t s_adj[RW_ICAP];                              // per insertion row: inserted A, C, G, T (5 bits each), '*' they replace (bits 20..)
+  __shared__ __attribute__((aligned(16))) uint8_t s_iv[RW_ICAP];   // ... its vote | informative << 7
+  __shared__ uint32_t s_tx[TCAP + 1];                              // first run of every tile's list (k_layout), relative to the window's
+  __shared__ uint32_t s_wave[NT / 64];
+  const uint32_t w = blockIdx.x, tid = threadIdx.x, nw = J.nw;
+  PROF_BEGIN(J);
+  const WinDesc wd = J.win[w];
+  const uint32_t Lf = J.win_Lf[w], win_len = wd.win_len;
+  const uint32_t tile0 = (uint32_t)wd.col_off, n_t = min((Lf + ROWCAP - 1) / ROWCAP, TCAP);
+  if (tid < 32) s_ct[tid] = J.ctab[(uint64_t)w * 32 + tid];
+  for (uint32_t p = tid; p <= win_len; p += NT) s_rop[RI(p)] = J.row_of_pos2[wd.pos_off + p];
+  for (uint32_t t = tid; t < n_t; t += NT) {
+    const uint2 te = J.tile_ev[tile0 + t];
+    s_tx[t] = te.x;
+    if (t + 1 == n_t) s_tx[n_t] = te.x + te.y;
+  }
+  if (n_t == 0 && tid == 0) s_tx[0] = 0;
+  __syncthreads();
+  PROF_MARK(J, 6, 0);
+  // ---- 1: symbol counts of the base rows in position space
+  const bool active = tid < nw;
+  const uint32_t widx = min(tid, nw - 1u);
+  const int32_t P = (int32_t)(widx << 5);
+  const uint32_t vm = active ? mask_range(0, (int32_t)win_len - P) : 0u;
+  const uint64_t pmax = J.read_n_words + 1;
+  const uint32_t tlo = glb_bits(J.read_p0, s_ct[0].q_woff, pmax, (int32_t)wd.tstart + P) & vm;
+  const uint32_t thi = glb_bits(J.read_p1, s_ct[0].q_woff, pmax, (int32_t)wd.tstart + P) & vm;
+  uint32_t c0[5], c1[5];   // saturating 2-bit counters (0, 1, 2, >= 3) of A C G T *
+  uint32_t nin[5];         // exact count of the columns that cover the position (target included)
+  const uint32_t tsym[4] = {vm & ~tlo & ~thi, tlo & ~thi, thi & ~tlo, tlo & thi};
+#pragma unroll
+  for (int q = 0; q < 4; q++) { c0[q] = tsym[q]; c1[q] = 0; }
+  c0[4] = 0; c1[4] = 0;
+  nin[0] = vm; nin[1] = 0; nin[2] = 0; nin[3] = 0; nin[4] = 0;
+  auto sat_add = [&](int q, uint32_t x) {
+    const uint32_t a = c0[q], b = c1[q];
+    c0[q] = (a ^ x) | (a & b);
+    c1[q] = b | (a & x);
+  };
+  constexpr int UB = 10;   // columns whose plane words are in flight together
+#pragma unroll 1
+  for (uint32_t cb = 1; cb < HERRO_ROWS; cb += UB) {
+    uint32_t M[UB], L[UB], H[UB];
+#pragma unroll
+    for (int u = 0; u < UB; u++) {
+      const uint32_t o = s_ct[cb + u].ow;
+      const uint32_t* __restrict__ g = J.cpl + (o != NONE ? (uint64_t)o : 0ull) * 3 * nw + widx;
+      M[u] = g[0]; L[u] = g[nw]; H[u] = g[2 * nw];
+    }
+#pragma unroll
+    for (int u = 0; u < UB; u++) {
+      const CTab& h = s_ct[cb + u];
+      const uint32_t tt = h.ow != NONE ? h.t_total : 0u;
+      const uint32_t inr = mask_range(h.off - P, h.off + (int32_t)tt - P) & vm;
+      const uint32_t Mi = M[u] & inr, Li = L[u] & Mi, Hi = H[u] & Mi;
+      sat_add(0, Mi & ~Li & ~Hi);
+      sat_add(1, Li & ~Hi);
+      sat_add(2, Hi & ~Li);
+      sat_add(3, Li & Hi);
+      sat_add(4, inr & ~Mi);
+      uint32_t x = inr;
+#pragma unroll
+      for (int b = 0; b < 5; b++) { const uint32_t cy = nin[b] & x; nin[b] ^= x; x = cy; }
+    }
+  }
+  PROF_MARK(J, 6, 1);
+  // informative positions (features.rs:681-722 on the final 31 columns: thresh = (31 * 0.1) as usize = 3) and the votes of the others
+  uint32_t supb, V0, V1, V2;
+  {
+    uint32_t g3[5], e2[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) { g3[q] = c1[q] & c0[q]; e2[q] = c1[q] & ~c0[q]; }
+    uint32_t one = 0, two = 0;
+#pragma unroll
+    for (int q = 0; q < 5; q++) { two |= one & g3[q]; one |= g3[q]; }
+    supb = two & vm;
+    uint32_t f[5], sc[5], seen1 = 0, seen2 = 0;   // first / second symbol with exactly two, in A C G T * order
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+      f[q] = e2[q] & ~seen1;
+      sc[q] = e2[q] & seen1 & ~seen2;
+      seen2 |= seen1 & e2[q];
+      seen1 |= e2[q];
+    }
+    uint32_t tb_in = 0;   // the target's base is one of the two (the target column never shows '*' on a base row)
+#pragma unroll
+    for (int q = 0; q < 4; q++) tb_in |= tsym[q] & (f[q] | sc[q]);
+    const uint32_t any3 = one, tie_t = seen2 & tb_in;
+    const uint32_t use_t = supb | (~any3 & (~seen1 | tie_t));   // informative rows: the model decides (k_consensus); a defined code anyway
+    const uint32_t use_g = any3 & ~supb, use_f = ~any3 & seen1 & ~tie_t;
+    uint32_t v[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) v[q] = (use_g & g3[q]) | (use_f & f[q]) | (q < 4 ? use_t & tsym[q] : 0u);
+    V0 = (v[1] | v[3]) & vm; V1 = (v[2] | v[3]) & vm; V2 = v[4] & vm;
+  }
+  if (active) {
+    uint32_t* __restrict__ vp = J.vpl + (uint64_t)w * 3 * nw + tid;
+    vp[0] = V0; vp[nw] = V1; vp[2 * nw] = V2;
+  }
+  // positions of this lane's word that have insertion rows behind them
+  uint32_t insmask = 0;
+  if (active) {
+    uint32_t rprev = s_rop[RI((uint32_t)P)];
+#pragma unroll 4
+    for (uint32_t k = 0; k < 32; k++) {
+      const uint32_t p = (uint32_t)P + k;
+      const uint32_t rn = s_rop[RI(min(p + 1u, win_len))];
+      if (p < win_len && rn - rprev > 1u) insmask |= 1u << k;
+      rprev = rn;
+    }
+  }
+  PROF_MARK(J, 6, 2);
+  // ---- 2: insertion rows.  Index of an insertion row = its ordinal among the window's insertion rows = row - position - 1.
+  const uint32_t n_irows = Lf - win_len;
+  const uint32_t n_runs = s_tx[n_t];
+  const uint4* __restrict__ tev = J.tev + s_ct[0].ev_off;
+  uint32_t n_isup = 0, insup = 0;   // informative insertion rows of this lane's positions; positions that have one
+  for (uint32_t ch0 = 0; ch0 < n_irows; ch0 += RW_ICAP) {
+    if (ch0) __syncthreads();   // the previous pass's votes are out
+    for (uint32_t i = tid; i < RW_ICAP; i += NT) s_adj[i] = 0;
+    __syncthreads();
+    // inserted bases of the selected columns (features.rs:213-229), from the tiles' run lists: a run that crosses a tile boundary is
+    // listed by both tiles, each takes its own rows; "hidden" rows were overwritten by a later insertion at the same position
+    for (uint32_t e0 = tid; e0 < n_runs; e0 += 2 * NT) {
+      uint4 ve[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) ve[u] = tev[min(e0 + u * NT, n_runs - 1u)];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const uint32_t e = e0 + u * NT;
+        if (e >= n_runs) continue;
+        uint32_t lo = 0, hi = n_t;   // tile of run e: s_tx[lo] <= e < s_tx[hi]
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_tx[mid] <= e) lo = mid; else hi = mid;
+        }
+        const uint32_t tr0 = lo * ROWCAP, tr1 = min(tr0 + ROWCAP, Lf);
+        const uint32_t c = ve[u].w & 0xffu, hide = ve[u].w >> 8;
+        const uint32_t p = ve[u].x & 0xffffu, len = ve[u].x >> 16;
+        if (p >= win_len) continue;
+        const uint32_t rp = s_rop[RI(p)], room = s_rop[RI(p + 1)] - rp - 1u;
+        const bool inr = (uint32_t)((int32_t)p - s_ct[c].off) < s_ct[c].t_total;   // the default under it was '*' (counted), not '.'
+        for (uint32_t k = hide; k < len && k < room; k++) {
+          const uint32_t row = rp + 1u + k;
+          if (row < tr0 || row >= tr1) continue;
+          const uint32_t ir = row - p - 1u - ch0;
+          if (ir >= RW_ICAP) continue;
+          uint32_t code;
+          if (k < 16u) code = (ve[u].z >> (2u * k)) & 3u;
+          else {   // long insertion: bases beyond the 16 carried by the event come from the read store
+            const int32_t si = s_ct[c].sbase + s_ct[c].sdir * (int32_t)(ve[u].y + k);
+            const uint64_t wi = min(s_ct[c].q_woff + ((uint32_t)si >> 5), pmax);
+            code = ((J.read_p0[wi] >> ((uint32_t)si & 31u)) & 1u) | (((J.read_p1[wi] >> ((uint32_t)si & 31u)) & 1u) << 1);
+            if (s_ct[c].sdir < 0) code ^= 3u;
+          }
+          atomicAdd(&s_adj[ir], (1u << (5u * code)) + (inr ? 1u << 20 : 0u));
+        }
+      }
+    }
+    __syncthreads();
+    // every insertion row is evaluated by the lane that owns its position
+    for (uint32_t m = insmask; m; m &= m - 1u) {
+      const uint32_t k = (uint32_t)__ffs((int)m) - 1u, p = (uint32_t)P + k;
+      const uint32_t rp = s_rop[RI(p)], n_ins = s_rop[RI(p + 1)] - rp - 1u;
+      const uint32_t cover = ((nin[0] >> k) & 1u) | (((nin[1] >> k) & 1u) << 1) | (((nin[2] >> k) & 1u) << 2) | (((nin[3] >> k) & 1u) << 3) | (((nin[4] >> k) & 1u) << 4);
+      for (uint32_t j = 0; j < n_ins; j++) {
+        const uint32_t ir = rp - p + j - ch0;
+        if (ir >= RW_ICAP) continue;
+        const uint32_t adj = s_adj[ir];
+        const uint32_t c5[5] = {adj & 31u, (adj >> 5) & 31u, (adj >> 10) & 31u, (adj >> 15) & 31u, cover - (adj >> 20)};
+        uint32_t ns = 0;
+#pragma unroll
+        for (int q = 0; q < 5; q++) ns += c5[q] >= 3u ? 1u : 0u;
+        const uint32_t sup = ns >= 2u ? 1u : 0u;
+        s_iv[ir] = (uint8_t)(vote5(c5, 4u) | (sup << 7));   // the target shows '*' on an insertion row
+        n_isup += sup;
+        if (sup) insup |= 1u << k;
+      }
+    }
+    __syncthreads();
+    {
+      const uint32_t nb = min(RW_ICAP, n_irows - ch0);
+      uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(J.cons_tmp + wd.row_off + ch0);   // row_off and ch0 are multiples of 16
+      for (uint32_t i = tid; i * 4u < nb; i += NT) dst[i] = reinterpret_cast<const uint32_t*>(s_iv)[i];
+    }
+  }
+  PROF_MARK(J, 6, 3);
+  // ---- 3: the informative rows in row order (SupportedPos, features.rs:896-900)
+  const bool iv_lds = n_irows <= RW_ICAP;   // one pass: the flags are still in LDS; else they are read back from the votes just written
+  if (!iv_lds) __syncthreads();
+  uint32_t total;
+  uint32_t kk = blk_scan<NT>((uint32_t)__popc(supb) + n_isup, &total, s_wave);
+  for (uint32_t m = supb | insup; m; m &= m - 1u) {
+    const uint32_t k = (uint32_t)__ffs((int)m) - 1u, p = (uint32_t)P + k;
+    const uint32_t rp = s_rop[RI(p)];
+    if ((supb >> k) & 1u) {
+      J.sup_row[wd.row_off + kk] = rp;
+      J.sup_pi[wd.row_off + kk] = p;
+      kk++;
+    }
+    if ((insup >> k) & 1u) {
+      const uint32_t n_ins = s_rop[RI(p + 1)] - rp - 1u;
+      for (uint32_t j = 0; j < n_ins; j++) {
+        const uint32_t ir = rp - p + j;
+        const uint32_t fl = iv_lds ? (uint32_t)s_iv[ir] : (uint32_t)J.cons_tmp[wd.row_off + ir];
+        if (fl & 0x80u) {
+          J.sup_row[wd.row_off + kk] = rp + 1u + j;
+          J.sup_pi[wd.row_off + kk] = p | ((j + 1u) << 16);
+          kk++;
+        }
+      }
+    }
+  }
+  if (tid == 0) J.win_nsup[w] = total;
+  PROF_MARK(J, 6, 4);
+}
+
+// =====================================================================================================
 // k_quals — one workgroup per window
 // =====================================================================================================
 constexpr int PQ_NT = 256;
@@ -1076,12 +1336,10 @@ __host__ __device__ inline size_t quals_lds(uint32_t nw) {
   return (size_t)(HERRO_ROWS - 1) * nw * 4 + (((size_t)(HERRO_ROWS - 1) * nw * 2 + 15) & ~(size_t)15) + (size_t)QEVCAP * 8;
 }
 
-// FULL: every cell of the window; otherwise the cells within `half` rows of an informative row (the model's receptive fields).
-// rf_q != null (and 2 * half + 1 <= 8): the receptive fields go out compact, [(sup_off[w] + k) * 31 + column][8] with byte i = row
-// sup_row[k] - half + i — dense stores.  (Single bytes scattered over the window's 146 KB of quality planes made every store a
-// read-modify-write of its own line: 0.6 GB of traffic per 4096 windows for 10 MB of payload.)
+// FULL: every cell of the window; otherwise the cells within `half` rows of an informative row (receptive fields wider than the 8 rows of
+// k_rfq's compact records), into the quality planes.  Needs the row map (k_tokens).
 template <bool FULL>
-__global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half, const uint64_t* __restrict__ sup_off, uint8_t* __restrict__ rf_q) {
+__global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pq_smem[];
   const uint32_t nw = J.nw;
   uint32_t* s_M = reinterpret_cast<uint32_t*>(pq_smem);                               // [30][nw] M planes of the selected columns
@@ -1264,12 +1522,9 @@ __global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half, const 
           }
         }
         __syncthreads();
-        // a batch of cells per thread: addresses first (LDS only), then all quality bytes together, then the stores.
-        // Compact: consecutive lanes = consecutive bytes of the 8-byte slots (informative row, column); planes: the 31 columns of a row.
-        const bool compact = rf_q != nullptr && span <= 8;
-        const uint32_t total = compact ? nk * HERRO_ROWS * 8 : nrows * HERRO_ROWS;
-        const uint64_t slot0 = compact ? (sup_off[w] + k0) * HERRO_ROWS * 8 : 0;
-        uint8_t* __restrict__ outp = compact ? rf_q : J.fin_q;
+        // a batch of cells per thread: addresses first (LDS only), then all quality bytes together, then the stores: the 31 columns of a row
+        const uint32_t total = nrows * HERRO_ROWS;
+        uint8_t* __restrict__ outp = J.fin_q;
         constexpr int CB = 10;
         for (uint32_t idx0 = tid; idx0 < total; idx0 += CB * PQ_NT) {
           uint64_t dst[CB], src[CB];
@@ -1277,21 +1532,10 @@ __global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half, const 
 #pragma unroll
           for (int u = 0; u < CB; u++) {
             const uint32_t idx = min(idx0 + u * PQ_NT, total - 1u);
-            uint32_t slot, c;
-            if (compact) {
-              const uint32_t kc = idx >> 3, dd = idx & 7u, k = kc / HERRO_ROWS;
-              c = kc - k * HERRO_ROWS;
-              slot = min(k * span + dd, nrows - 1u);
-              live[u] = dd < span;
-              dst[u] = slot0 + idx;
-            } else {
-              slot = idx / HERRO_ROWS;
-              c = idx - slot * HERRO_ROWS;
-              live[u] = true;
-              dst[u] = wd.fin_off + (uint64_t)c * wd.lub + s_rr[slot];
-            }
+            const uint32_t slot = idx / HERRO_ROWS, c = idx - slot * HERRO_ROWS;
+            dst[u] = wd.fin_off + (uint64_t)c * wd.lub + s_rr[slot];
             const uint32_t rm = s_rm[slot];
-            live[u] = live[u] && idx0 + u * PQ_NT < total && rm != NONE;
+            live[u] = idx0 + u * PQ_NT < total && rm != NONE;
             src[u] = live[u] ? cell_addr(evlds, c, rm & 0xffffu, rm >> 16) : NONE64;
           }
           uint32_t qv[CB];
@@ -1321,7 +1565,12 @@ __global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half, const 
 // 17.7 x the output in HBM traffic; r2 scattered single bytes over the quality planes.)
 constexpr int RQ_NT = 256;
 
-__global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const uint64_t* __restrict__ sup_off, uint8_t* __restrict__ rf_q, uint64_t cap) {
+// Round 5: the slot carries the cells' TOKENS as well (bytes 0..7; qualities 8..15) — on the lean path there is no token plane to read
+// them from — and the rows of a slot are no longer looked up in a row map: the informative row's (position, ordinal) and the rows
+// of the positions around it (row_of_pos2) say which cell each of the slot's rows is.  A base cell's code comes from the column's
+// lo / hi planes (two more words per slot), an inserted base's from its event (the first 16 bases travel with it), the target's from
+// the read store.
+__global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const uint64_t* __restrict__ sup_off, uint8_t* __restrict__ rf, uint64_t cap) {
   __shared__ __attribute__((aligned(16))) CTab s_ct[32];
   const uint32_t w = blockIdx.x, tid = threadIdx.x, nw = J.nw;
   PROF_BEGIN(J);
@@ -1331,45 +1580,76 @@ __global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const ui
   if (tid < 32) s_ct[tid] = J.ctab[(uint64_t)w * 32 + tid];
   __syncthreads();
   PROF_MARK(J, 5, 0);
-  const uint32_t span = 2 * half + 1;
+  const uint32_t span = 2 * half + 1, win_len = wd.win_len;
   const uint64_t tq_off = s_ct[0].qual_off + wd.tstart;
   const uint64_t qmax = J.read_qual_bytes ? J.read_qual_bytes - 1 : 0;
+  const uint64_t pmax = J.read_n_words + 1;
   constexpr uint64_t NONE64 = ~0ull;
   const uint32_t nslots = nsup * HERRO_ROWS;
   const uint64_t out0 = sup_off[w] * HERRO_ROWS;
+  const uint32_t* __restrict__ rop = J.row_of_pos2 + wd.pos_off;
   for (uint32_t sl = tid; sl < nslots; sl += RQ_NT) {
     const uint32_t k = sl / HERRO_ROWS, c = sl - k * HERRO_ROWS;
+    // the slot's rows: row sup_row[k] - half + d is row (r - rop[p]) of the last position p with rop[p] <= r; every position has a
+    // row of its own, so p lies within `half` positions of the informative row's
+    const uint32_t pj = J.sup_pi[wd.row_off + k];
+    const int32_t pc = (int32_t)(pj & 0xffffu);
     const int64_t row0 = (int64_t)J.sup_row[wd.row_off + k] - (int64_t)half;
+    uint32_t rv[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) rv[i] = rop[(uint32_t)min(max(pc - (int32_t)half + i, 0), (int32_t)win_len)];
     uint32_t rm[8];
 #pragma unroll
     for (int d = 0; d < 8; d++) {
       const int64_t r = row0 + d;
-      rm[d] = ((uint32_t)d < span && r >= 0 && r < (int64_t)Lf) ? J.rowmap2[wd.row_off + (uint32_t)r] : NONE;
+      rm[d] = NONE;
+      if ((uint32_t)d < span && r >= 0 && r < (int64_t)Lf) {
+        int32_t pp = 0;
+        uint32_t rb = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int32_t q = pc - (int32_t)half + i;
+          if ((uint32_t)i <= 2 * half && q >= 0 && q < (int32_t)win_len && (int64_t)rv[i] <= r) { pp = q; rb = rv[i]; }
+        }
+        rm[d] = (uint32_t)pp | (((uint32_t)r - rb) << 16);
+      }
     }
     uint64_t addr[8];
+    uint32_t tok[8];
 #pragma unroll
-    for (int d = 0; d < 8; d++) addr[d] = NONE64;
+    for (int d = 0; d < 8; d++) { addr[d] = NONE64; tok[d] = TOK_NONE; }
     const CTab& q = s_ct[c];
     if (c == 0) {
+      const uint64_t tw = s_ct[0].q_woff;
 #pragma unroll
-      for (int d = 0; d < 8; d++)
-        if (rm[d] != NONE && (rm[d] >> 16) == 0) addr[d] = min(tq_off + (rm[d] & 0xffffu), qmax);
+      for (int d = 0; d < 8; d++) {
+        if (rm[d] == NONE) continue;
+        tok[d] = TOK_GAP_F;   // the target shows '*' on an insertion row
+        if ((rm[d] >> 16) == 0) {
+          const uint32_t tp = wd.tstart + (rm[d] & 0xffffu);
+          const uint64_t wi = min(tw + (tp >> 5), pmax);
+          addr[d] = min(tq_off + (rm[d] & 0xffffu), qmax);
+          tok[d] = ((J.read_p0[wi] >> (tp & 31u)) & 1u) | (((J.read_p1[wi] >> (tp & 31u)) & 1u) << 1);
+        }
+      }
     } else if (q.ow != NONE) {
+      const uint32_t tbase = q.tokc & 0xffu, tgap = q.tokc >> 8;
       uint32_t p0 = NONE;   // position of the slot's first row inside the window
 #pragma unroll
       for (int d = 7; d >= 0; d--) if (rm[d] != NONE) p0 = rm[d] & 0xffffu;
       if (p0 != NONE) {
         const uint32_t w0 = min(p0 >> 5, nw - 1u), w1 = min(w0 + 1u, nw - 1u);
         const uint2* __restrict__ dir = J.cdir + (uint64_t)q.ow * nw;
+        const uint32_t* __restrict__ cpl = J.cpl + (uint64_t)q.ow * 3 * nw;
         const uint2 d0 = dir[w0], d1 = dir[w1];
+        const uint32_t l0 = cpl[nw + w0], l1 = cpl[nw + w1], h0 = cpl[2 * nw + w0], h1 = cpl[2 * nw + w1];
         const uint32_t m0 = d0.x, m1 = d1.x;
         const uint32_t n_ev = q.n_ev;
         const uint4* __restrict__ iev = J.iev + q.ev_off;
         uint32_t qw = d0.y & 0xfffffu, e = d0.y >> 20;
         if (d0.y == 0xffffffffu) {   // indices beyond the record's fields: count (M bits and events in front of the word)
-          const uint32_t* __restrict__ M = J.cpl + (uint64_t)q.ow * 3 * nw;
           qw = 0; e = 0;
-          for (uint32_t i = 0; i < w0; i++) qw += (uint32_t)__popc(M[i]);
+          for (uint32_t i = 0; i < w0; i++) qw += (uint32_t)__popc(cpl[i]);
           while (e < n_ev && (iev[e].x & 0xffffu) < (w0 << 5)) { qw += iev[e].x >> 16; e++; }
         }
         // no insertion event between the two words' first positions and no row beyond: the event list is not needed
@@ -1393,16 +1673,34 @@ __global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const ui
           const uint32_t mw = second ? m1 : m0;
           const uint32_t below = (uint32_t)__popc(mw & ((1u << (p & 31u)) - 1u)) + (second ? (uint32_t)__popc(m0) : 0u);
           const uint32_t mbit = (mw >> (p & 31u)) & 1u;
+          const bool inr = p - (uint32_t)q.off < q.t_total;
           uint32_t qi = NONE;
+          tok[d] = inr ? tgap : (uint32_t)TOK_NONE;   // no base here: a gap where the overlap covers the position, '.' outside
           if (j == 0) {
-            if (p - (uint32_t)q.off < q.t_total && mbit) qi = qw + below + cum;
+            if (inr && mbit) {
+              qi = qw + below + cum;
+              tok[d] = tbase + ((((second ? l1 : l0) >> (p & 31u)) & 1u) | ((((second ? h1 : h0) >> (p & 31u)) & 1u) << 1));
+            }
           } else if ((ecur.x & 0xffffu) == p) {
             uint4 x = ecur;
+            uint32_t code = 0;
             for (uint32_t i = e;;) {
-              if ((x.x >> 16) >= j) qi = x.y + j - 1u;
+              if ((x.x >> 16) >= j) {   // the LAST insertion at p that is long enough wrote this row
+                qi = x.y + j - 1u;
+                code = j <= 16u ? (x.z >> (2u * (j - 1u))) & 3u : 4u;
+              }
               if (++i >= n_ev) break;
               x = iev[i];
               if ((x.x & 0xffffu) != p) break;
+            }
+            if (qi != NONE) {
+              if (code == 4u) {   // beyond the 16 bases the event carries: from the read store
+                const int32_t si = q.sbase + q.sdir * (int32_t)qi;
+                const uint64_t wi = min(q.q_woff + ((uint32_t)si >> 5), pmax);
+                code = ((J.read_p0[wi] >> ((uint32_t)si & 31u)) & 1u) | (((J.read_p1[wi] >> ((uint32_t)si & 31u)) & 1u) << 1);
+                if (q.sdir < 0) code ^= 3u;
+              }
+              tok[d] = tbase + code;
             }
           }
           if (qi != NONE) {
@@ -1416,13 +1714,15 @@ __global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const ui
     uint32_t qv[8];
 #pragma unroll
     for (int d = 0; d < 8; d++) qv[d] = J.read_qual[addr[d] == NONE64 ? 0 : addr[d]];
-    uint32_t lo = 0, hi = 0;
+    uint32_t lo = 0, hi = 0, tl = 0, th = 0;
 #pragma unroll
     for (int d = 0; d < 4; d++) {
       lo |= (addr[d] == NONE64 ? 33u : qv[d]) << (8 * d);
       hi |= (addr[d + 4] == NONE64 ? 33u : qv[d + 4]) << (8 * d);
+      tl |= tok[d] << (8 * d);
+      th |= tok[d + 4] << (8 * d);
     }
-    *reinterpret_cast<uint2*>(rf_q + (out0 + sl) * 8) = make_uint2(lo, hi);
+    *reinterpret_cast<uint4*>(rf + (out0 + sl) * 16) = make_uint4(tl, th, lo, hi);
     PROF_MARK(J, 5, 2);
   }
 }
@@ -1486,12 +1786,117 @@ __global__ __launch_bounds__(PC_NT) void k_consensus(JobDev J, const uint64_t* s
   if (threadIdx.x == 0) J.cons_len[w] = total;
 }
 
+// The same for the lean path (k_rows): the votes arrive in position space — three bit planes for the base rows, a byte per insertion
+// row indexed by its ordinal — and so does everything here: a lane owns 32 target positions, counts what they and the insertion rows
+// behind them contribute, and writes its stretch of the corrected sequence; the model's calls are patched into the planes / bytes
+// first.  No per-row array is read or written.
+constexpr uint32_t CP_ICAP = 4096;   // insertion-row votes staged in LDS (a window with more works on the global bytes)
+constexpr uint32_t CP_OCAP = 6144;   // corrected bases staged in LDS for coalesced stores (more: byte stores)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_consensus_p(JobDev J, const uint64_t* sup_off, const float* base_logits) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t cp_smem[];
+  uint32_t* s_rop = cp_smem;                                        // [win_len + 1], padded (RI)
+  __shared__ uint32_t s_v[3][HERRO_MAX_WINDOW / 32];
+  __shared__ __attribute__((aligned(16))) uint8_t s_iv[CP_ICAP];
+  __shared__ __attribute__((aligned(16))) uint8_t s_out[CP_OCAP];
+  __shared__ uint32_t s_wave[NT / 64];
+  const uint32_t w = blockIdx.x, tid = threadIdx.x, nw = J.nw;
+  const WinDesc wd = J.win[w];
+  const uint32_t Lf = J.win_Lf[w], n_kept = J.win_nkept[w], win_len = wd.win_len;
+  const uint32_t n_alns = n_kept < 30u ? n_kept : 30u;
+  uint8_t* __restrict__ seq = J.cons_seq + wd.row_off;
+  if (n_alns < 2) {  // not corrected: the read is split here
+    if (tid == 0) J.cons_len[w] = 0;
+    return;
+  }
+  const uint32_t n_irows = Lf - win_len;
+  const bool iv_lds = n_irows <= CP_ICAP;
+  uint8_t* __restrict__ giv = J.cons_tmp + wd.row_off;
+  for (uint32_t p = tid; p <= win_len; p += NT) s_rop[RI(p)] = J.row_of_pos2[wd.pos_off + p];
+  if (tid < nw) {
+    const uint32_t* __restrict__ vp = J.vpl + (uint64_t)w * 3 * nw + tid;
+    s_v[0][tid] = vp[0]; s_v[1][tid] = vp[nw]; s_v[2][tid] = vp[2 * nw];
+  }
+  if (iv_lds)
+    for (uint32_t i = tid; i * 4u < n_irows; i += NT) reinterpret_cast<uint32_t*>(s_iv)[i] = reinterpret_cast<const uint32_t*>(giv)[i];
+  __syncthreads();
+  // informative rows: the model decides — argmax of the 5 base logits, the LAST maximum wins, NaN is greatest (consensus.rs:136-141)
+  const uint32_t nsup = J.win_nsup[w];
+  const float* lg = base_logits + sup_off[w] * 5;
+  for (uint32_t k = tid; k < nsup; k += NT) {
+    const float* l5 = lg + (uint64_t)k * 5;
+    uint32_t arg = 0;
+    float mx = l5[0];
+#pragma unroll
+    for (uint32_t c = 1; c < 5; c++) {
+      const float v = l5[c];
+      const bool ge = (v != v) ? true : ((mx != mx) ? false : v >= mx);
+      if (ge) { arg = c; mx = v; }
+    }
+    const uint32_t pj = J.sup_pi[wd.row_off + k], p = pj & 0xffffu, j = pj >> 16;
+    if (j == 0) {
+      const uint32_t bit = 1u << (p & 31u);
+#pragma unroll
+      for (uint32_t b = 0; b < 3; b++) {
+        if ((arg >> b) & 1u) atomicOr(&s_v[b][p >> 5], bit); else atomicAnd(&s_v[b][p >> 5], ~bit);
+      }
+    } else {
+      const uint32_t ir = s_rop[RI(p)] - p + j - 1u;
+      if (iv_lds) s_iv[ir] = (uint8_t)arg; else giv[ir] = (uint8_t)arg;
+    }
+  }
+  __syncthreads();
+  // what every lane's 32 positions contribute: base rows that are not '*', insertion rows behind them that are not '*'
+  const bool active = tid < nw;
+  const uint32_t widx = min(tid, nw - 1u), P = widx << 5;
+  const uint32_t vm = active ? mask_range(0, (int32_t)win_len - (int32_t)P) : 0u;
+  const uint32_t v0 = s_v[0][widx], v1 = s_v[1][widx], v2 = s_v[2][widx];
+  const uint32_t keep = vm & ~(v2 & ~v1 & ~v0);
+  uint32_t ia = 0, ib = 0;   // insertion rows [ia, ib) lie behind this lane's positions
+  if (vm) {
+    const uint32_t pe = min(P + 32u, win_len);
+    ia = s_rop[RI(P)] - P;
+    ib = s_rop[RI(pe)] - pe;
+  }
+  auto ivote = [&](uint32_t ir) -> uint32_t { return (uint32_t)(iv_lds ? s_iv[ir] : giv[ir]) & 7u; };
+  uint32_t cnt = (uint32_t)__popc(keep);
+  for (uint32_t ir = ia; ir < ib; ir++) cnt += ivote(ir) != 4u ? 1u : 0u;
+  uint32_t total;
+  uint32_t o = blk_scan<NT>(cnt, &total, s_wave);
+  const bool out_lds = total <= CP_OCAP;
+  uint8_t* __restrict__ dst = out_lds ? s_out : seq;
+  if (cnt) {
+    uint32_t ir = ia;
+    for (uint32_t k = 0; k < 32u; k++) {
+      const uint32_t p = P + k;
+      if (p >= win_len) break;
+      if ((keep >> k) & 1u) {
+        const uint32_t code = ((v0 >> k) & 1u) | (((v1 >> k) & 1u) << 1);   // not '*': A C G T
+        dst[o++] = (uint8_t)"ACGT"[code];
+      }
+      const uint32_t ie = s_rop[RI(p + 1)] - p - 1u;   // insertion rows in front of position p + 1
+      for (; ir < ie; ir++) {
+        const uint32_t vt = ivote(ir);
+        if (vt != 4u) dst[o++] = (uint8_t)"ACGT"[vt & 3u];
+      }
+    }
+  }
+  if (out_lds) {
+    __syncthreads();
+    uint32_t* __restrict__ sq = reinterpret_cast<uint32_t*>(seq);   // row_off is a multiple of 16
+    for (uint32_t i = tid; i * 4u < total; i += NT) sq[i] = reinterpret_cast<const uint32_t*>(s_out)[i];
+  }
+  if (tid == 0) J.cons_len[w] = total;
+}
+
 }  // namespace
 
-void launch_consensus(const JobDev& J, const uint64_t* sup_off, const float* base_logits, hipStream_t st, KernelTimer* tm) {
+void launch_consensus(const JobDev& J, const uint64_t* sup_off, const float* base_logits, bool lean, hipStream_t st, KernelTimer* tm) {
   if (!J.n_win) return;
   KT_BEGIN(tm, "consensus", st);
-  hipLaunchKernelGGL(k_consensus, dim3(J.n_win), dim3(PC_NT), 0, st, J, sup_off, base_logits);
+  if (!lean) hipLaunchKernelGGL(k_consensus, dim3(J.n_win), dim3(PC_NT), 0, st, J, sup_off, base_logits);
+  else if (J.nw <= 128) hipLaunchKernelGGL(k_consensus_p<128>, dim3(J.n_win), dim3(128), rows_lds(J.window_size), st, J, sup_off, base_logits);
+  else hipLaunchKernelGGL(k_consensus_p<256>, dim3(J.n_win), dim3(256), rows_lds(J.window_size), st, J, sup_off, base_logits);
   KT_END(tm, st);
 }
 
@@ -1511,23 +1916,24 @@ void launch_supoff(const JobDev& J, uint64_t* sup_off, hipStream_t st) {
   if (J.n_win) hipLaunchKernelGGL(k_supoff, dim3(1), dim3(256), 0, st, J, sup_off);
 }
 
-void launch_rf_quals(const JobDev& J, uint32_t half, const uint64_t* sup_off, uint8_t* rf_q, uint64_t cap, hipStream_t st, KernelTimer* tm) {
+void launch_rf_quals(const JobDev& J, uint32_t half, const uint64_t* sup_off, uint8_t* rf, uint64_t cap, hipStream_t st, KernelTimer* tm) {
   if (!J.n_win) return;
   KT_BEGIN(tm, "rf_quals", st);
-  if (rf_q && 2 * half + 1 <= 8) {
-    hipLaunchKernelGGL(k_rfq, dim3(J.n_win), dim3(RQ_NT), 0, st, J, half, sup_off, rf_q, cap);
+  if (rf && 2 * half + 1 <= 8) {
+    hipLaunchKernelGGL(k_rfq, dim3(J.n_win), dim3(RQ_NT), 0, st, J, half, sup_off, rf, cap);
     KT_END(tm, st);
     return;
   }
+  // wider receptive fields: the qualities go into the quality planes (the caller has made sure the row map exists)
   pileup_opt_in_lds(reinterpret_cast<const void*>(k_quals<false>), 96 * 1024);   // windows of 8192: 62 KB dynamic + 10 KB static
-  hipLaunchKernelGGL(k_quals<false>, dim3(J.n_win), dim3(PQ_NT), quals_lds(J.nw), st, J, half, sup_off, rf_q);
+  hipLaunchKernelGGL(k_quals<false>, dim3(J.n_win), dim3(PQ_NT), quals_lds(J.nw), st, J, half);
   KT_END(tm, st);
 }
 
 void launch_full_quals(const JobDev& J, hipStream_t st) {
   if (!J.n_win) return;
   pileup_opt_in_lds(reinterpret_cast<const void*>(k_quals<true>), 96 * 1024);
-  hipLaunchKernelGGL(k_quals<true>, dim3(J.n_win), dim3(PQ_NT), quals_lds(J.nw), st, J, 0u, (const uint64_t*)nullptr, (uint8_t*)nullptr);
+  hipLaunchKernelGGL(k_quals<true>, dim3(J.n_win), dim3(PQ_NT), quals_lds(J.nw), st, J, 0u);
 }
 
 template <int NB>
@@ -1543,7 +1949,15 @@ static void trace_point(const char* name, hipStream_t st) {
   fprintf(stderr, "TRACE %s done: %s\n", name, hipGetErrorString(e));
 }
 
-void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm) {
+void launch_full_tokens(const JobDev& J, hipStream_t st, KernelTimer* tm) {
+  if (!J.n_win || !J.n_tiles) return;
+  KT_BEGIN(tm, "tokens", st);
+  hipLaunchKernelGGL(k_tokens, dim3(J.n_tiles), dim3(TK_NT), 0, st, J, 0u);
+  KT_END(tm, st);
+  trace_point("tokens (planes on request)", st);
+}
+
+void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm, bool lean) {
   if (!J.n_win) return;
   if (J.n_ow) {
     KT_BEGIN(tm, "cols", st);
@@ -1569,8 +1983,21 @@ void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm) {
   hipLaunchKernelGGL(k_layout, dim3(J.n_win), dim3(LY_NT), layout_lds(J.window_size), st, J);
   KT_END(tm, st);
   trace_point("layout", st);
+  if (lean) {
+    KT_BEGIN(tm, "rows", st);
+    if (J.nw <= 128) {
+      pileup_opt_in_lds(reinterpret_cast<const void*>(k_rows<128>), 64 * 1024);
+      hipLaunchKernelGGL(k_rows<128>, dim3(J.n_win), dim3(128), rows_lds(J.window_size), st, J);
+    } else {
+      pileup_opt_in_lds(reinterpret_cast<const void*>(k_rows<256>), 64 * 1024);
+      hipLaunchKernelGGL(k_rows<256>, dim3(J.n_win), dim3(256), rows_lds(J.window_size), st, J);
+    }
+    KT_END(tm, st);
+    trace_point("rows", st);
+    return;
+  }
   KT_BEGIN(tm, "tokens", st);
-  if (J.n_tiles) hipLaunchKernelGGL(k_tokens, dim3(J.n_tiles), dim3(TK_NT), 0, st, J);
+  if (J.n_tiles) hipLaunchKernelGGL(k_tokens, dim3(J.n_tiles), dim3(TK_NT), 0, st, J, 1u);
   KT_END(tm, st);
   trace_point("tokens", st);
   KT_BEGIN(tm, "supgather", st);

@@ -231,6 +231,16 @@ int64_t herro_debug_extract_windows(const herro_alignment* a, uint32_t n_windows
 herro_ctx* herro_debug_host_ctx(uint32_t n_reads, const uint32_t* read_len, const uint32_t* name_class);
 int64_t herro_debug_job_array(herro_job* job, int which, const void** ptr, uint32_t* elem_bytes);
 
+/* Test hooks for the two feature-generation paths.  herro_job_featurize runs the LEAN path by default (round 5): informative rows,
+ * decoder votes and the model's receptive fields are derived from the column bit planes in position space and the [31][L'] token
+ * planes (features.rs:547-556) are only built when somebody asks for them (herro_job_window_copy, the features writer, a model
+ * whose receptive field exceeds 8 rows).  herro_debug_set_featurize_planes(ctx, 1) selects the planes path of rounds 3-4 for the
+ * jobs featurized from then on (environment: HERRO_FEATURIZE_PLANES=1) — two independent derivations of the same results, compared
+ * by tests/test_gpu_lean.py.  herro_debug_job_rf copies the 16-byte receptive-field records of window w (after herro_job_infer:
+ * n_supported x 31 records, bytes 0..7 tokens / 8..15 qualities of rows sup_row - half .. ) and returns their number (<0: error). */
+int herro_debug_set_featurize_planes(herro_ctx* ctx, int on);
+int64_t herro_debug_job_rf(herro_job* job, uint32_t w, uint8_t* out, uint64_t cap);
+
 /* Host-only test hook for the token-tile plan of the fused transformer stack (herro_job_infer): n windows of cnt[i]
  * informative rows (1..64) -> order[k] = the window that is k-th in the launch's token stream; returns the number of
  * 64-token tiles of whole windows at the head of the stream.  packed bit 0: the best-fit-decreasing order herro_job_infer

@@ -1,0 +1,96 @@
+"""-m gpu: the two feature-generation paths are two independent derivations of the same results.
+
+The LEAN path (round 5, the default: k_rows) works in position space — bit-sliced symbol counters over the selected
+columns' planes, insertion rows from per-row accumulators — and never writes the [31][L'] token planes
+(features.rs:547-556); the PLANES path (rounds 3-4: k_tokens) counts symbols while it writes every cell.  Here both run
+on the same jobs and must agree on everything downstream (informative rows, logits bit for bit, corrected FASTA), and
+the receptive-field records the model reads on the lean path must be the planes' cells (which test_gpu_features pins
+to the oracle)."""
+import numpy as np
+import pytest
+
+import gpu_common as G
+import oracle_lib as O
+from herro_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "baseline_w4096": dict(W=4096, n=3, tl=4 * 4096, ov=32, kw={}),
+    "low_coverage": dict(W=512, n=4, tl=2048, ov=3, kw=dict(flank_min=60, flank_max=90, p_partial=0.5)),
+    "noisy_w256": dict(W=256, n=4, tl=1500, ov=16, kw=dict(flank_min=30, flank_max=60, p_sub=0.05, p_ins=0.05, p_del=0.05, p_partial=0.2)),
+    "many_overlaps": dict(W=256, n=2, tl=1024, ov=70, kw=dict(flank_min=30, flank_max=60)),
+    "w8192": dict(W=8192, n=2, tl=3 * 8192 + 100, ov=12, kw=dict(p_partial=0.3)),
+    "w1000": dict(W=1000, n=3, tl=3500, ov=10, kw=dict(flank_min=100, flank_max=200, p_partial=0.3)),
+    "diverged_haplotypes": dict(W=4096, n=2, tl=2 * 4096, ov=32, kw=dict(p_snp=0.03)),
+}
+
+
+def _run(job, ids, batch):
+    job.featurize()
+    job.infer(batch, 1)
+    job.consensus()
+    wins = []
+    for w in range(job.n_windows):
+        wi = job.info(w)
+        sp = np.zeros(wi.n_supported, np.uint16)
+        si = np.zeros(wi.n_supported, np.uint8)
+        job.ctx._chk(job._l.herro_job_window_copy(job.h, w, 1, None, None, sp.ctypes.data, si.ctypes.data, None))
+        info, base = job.logits(w)
+        wins.append((wi.length, wi.n_supported, wi.n_alns, sp.copy(), si.copy(), info.copy(), base.copy()))
+    return wins, job.fasta(ids)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_lean_path_equals_planes_path(name):
+    cs = CASES[name]
+    sb = synth.generate(cs["n"], cs["tl"], cs["ov"], seed=synth.SEED + 17 + sum(map(ord, name)), **cs["kw"])
+    c = G.ctx()
+    G.load_synth(c, sb)
+    ids = [f"read{t}" for t in range(sb.n_targets)]
+    job = api.job_from_synth(c, sb, cs["W"])
+    try:
+        c.featurize_planes(False)
+        lean, fa_lean = _run(job, ids, 64)
+        c.featurize_planes(True)
+        planes, fa_planes = _run(job, ids, 64)
+    finally:
+        c.featurize_planes(False)
+    assert len(lean) == len(planes) > 0
+    n_sup = 0
+    for w, (a, b) in enumerate(zip(lean, planes)):
+        assert a[:3] == b[:3], (w, a[:3], b[:3])
+        assert a[3].tolist() == b[3].tolist() and a[4].tolist() == b[4].tolist(), w
+        assert np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6]), (w, "logits differ between the two paths")
+        n_sup += a[1]
+    assert fa_lean == fa_planes
+    if name != "low_coverage":
+        assert n_sup > 0
+    job.close()
+
+
+@pytest.mark.parametrize("name", ["baseline_w4096", "noisy_w256", "w1000"])
+def test_receptive_field_records_are_the_planes_cells(name):
+    cs = CASES[name]
+    sb = synth.generate(cs["n"], cs["tl"], cs["ov"], seed=synth.SEED + 29 + sum(map(ord, name)), **cs["kw"])
+    c = G.ctx()
+    G.load_synth(c, sb)
+    job = api.job_from_synth(c, sb, cs["W"])
+    job.featurize()
+    job.infer(64, 1)
+    n_rec = 0
+    for w in range(job.n_windows):
+        rf = job.rf_records(w)                 # read by the model on the lean path
+        gw = job.window(w, encoded=True)       # planes built on request; test_gpu_features pins them to the oracle
+        L = gw.info.length
+        rows = np.flatnonzero(gw.bases[:, 0] != 4)           # row of every target position (inference.rs:255-268)
+        for k in range(gw.info.n_supported):
+            r0 = int(rows[gw.sup_pos[k]]) + int(gw.sup_ins[k])
+            for d in range(5):
+                r = r0 - 2 + d
+                if 0 <= r < L:
+                    assert rf[k, :, d].tolist() == gw.bases[r].tolist(), (w, k, d, "tokens")
+                    assert rf[k, :, 8 + d].tolist() == gw.quals[r].tolist(), (w, k, d, "qualities")
+                    n_rec += 1
+    assert n_rec > 0
+    job.close()
