@@ -28,7 +28,7 @@ EXPORTS = [
     "herro_oec_read_indexed", "herro_paf_parse_view", "herro_debug_host_ctx", "herro_debug_job_array", "herro_debug_tile_plan", "herro_debug_tile_plan_sib",
     "herro_debug_set_featurize_planes", "herro_debug_job_rf",
     "herro_pool_create", "herro_pool_destroy", "herro_pool_last_error", "herro_pool_size", "herro_pool_ctx", "herro_pool_set_reads", "herro_pool_load_model",
-    "herro_pool_correct", "herro_pool_result", "herro_pool_groups_taken",
+    "herro_pool_correct", "herro_pool_result", "herro_pool_groups_taken", "herro_pool_skipped", "herro_debug_pool_fake", "herro_job_create_status",
     "herro_fastx_read", "herro_reads_count", "herro_reads_seq", "herro_reads_qual", "herro_reads_off", "herro_reads_ids",
     "herro_reads_descs", "herro_reads_free", "herro_write_window_features", "herro_job_write_features",
 ]
@@ -89,6 +89,10 @@ def lib():
         L.herro_pool_result.argtypes = [vp, vp]
         L.herro_pool_groups_taken.restype = u32
         L.herro_pool_groups_taken.argtypes = [vp, u32]
+        L.herro_pool_skipped.argtypes = [vp, vp, vp]
+        L.herro_debug_pool_fake.restype = vp
+        L.herro_debug_pool_fake.argtypes = [u32, vp]
+        L.herro_job_create_status.argtypes = [vp]
         L.herro_load_model.argtypes = [vp, C.c_char_p]
         L.herro_set_precision.argtypes = [vp, i32]
         L.herro_job_create.restype = vp

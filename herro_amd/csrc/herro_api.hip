@@ -188,6 +188,7 @@ struct herro_ctx {
   std::vector<Arena> free_dev, free_pin, free_small;   // free_small: the buffers a job needs only once its counts are known (logits, batch descriptors)
   std::atomic<uint32_t> live_jobs{0};   // herro_job_create may run on another thread than the context's execution calls
   uint64_t reads_gen = 0;   // bumped by herro_set_reads: a job built on an older store refuses to run
+  std::atomic<int> create_code{0};   // HERRO_E_* of the last herro_job_create that returned NULL (herro_job_create_status)
 };
 
 struct BatchPlan {
@@ -1418,8 +1419,10 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   if (!ctx) return nullptr;
   auto fail = [&](int code, const std::string& m) -> herro_job* {
     ctx->err = m + " [code " + std::to_string(code) + "]";
+    ctx->create_code = code;   // herro_job_create returns a pointer: the code travels through herro_job_create_status
     return nullptr;
   };
+  ctx->create_code = HERRO_OK;
   if (!ctx->d_words && !ctx->host_only) return fail(HERRO_E_STATE, "herro_set_reads must be called first");
   if (W < 16 || W > HERRO_MAX_WINDOW) return fail(HERRO_E_UNSUPPORTED, "window_size must be in [16, 8192]");
   if (n_targets && (!rids || !aln_off)) return fail(HERRO_E_INVALID, "null argument");
@@ -1684,6 +1687,8 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   scan_ret.armed = false;   // the job keeps its op array
   return job.release();
 }
+
+int herro_job_create_status(const herro_ctx* ctx) { return ctx ? ctx->create_code.load() : HERRO_E_INVALID; }
 
 int herro_job_skipped(const herro_job* job, uint32_t* n_alignments, uint32_t* n_targets) {
   if (!job) return HERRO_E_INVALID;

@@ -752,7 +752,7 @@ __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
   for (uint32_t b = 0; b < nbatch; b++)
     each_run(b, [&](const uint4& e, uint32_t hide, uint32_t t_lo, uint32_t t_hi) {
       for (uint32_t t = t_lo; t <= t_hi && t < TCAP; t++)
-        J.tev[wbase + atomicAdd(&s_toff[t], 1u)] = make_uint4(e.x, e.y, e.z, lc | (hide << 8));
+        J.tev[wbase + atomicAdd(&s_toff[t], 1u)] = make_uint4(e.x, e.y, e.z, lc | (hide << 8) | (t << 16));   // hide <= 50 (a kept overlap has no longer insertion, features.rs:315-324), t < TCAP
     });
   PROF_MARK(J, 2, 4);
 }
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J, uint32_t aux) {
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         if (e0 + u * TK_NT >= tev_h.y) continue;
-        const uint32_t c = ve[u].w & 0xffu, hide = ve[u].w >> 8;
+        const uint32_t c = ve[u].w & 0xffu, hide = (ve[u].w >> 8) & 0xffu;
         const uint32_t p = ve[u].x & 0xffffu, len = ve[u].x >> 16;
         if (p < pa || p > pb) continue;
         const uint32_t rp = rop(p), room = rop(p + 1) - rp - 1u;
@@ -1112,21 +1112,31 @@ __global__ __launch_bounds__(NT) void k_rows(JobDev J) {
   __shared__ __attribute__((aligned(16))) CTab s_ct[32];
   __shared__ uint32_t s_adj[RW_ICAP];                              // per insertion row: inserted A, C, G, T (5 bits each), '*' they replace (bits 20..)
   __shared__ __attribute__((aligned(16))) uint8_t s_iv[RW_ICAP];   // ... its vote | informative << 7
-  __shared__ uint32_t s_tx[TCAP + 1];                              // first run of every tile's list (k_layout), relative to the window's
+  __shared__ uint32_t s_nruns;
   __shared__ uint32_t s_wave[NT / 64];
   const uint32_t w = blockIdx.x, tid = threadIdx.x, nw = J.nw;
   PROF_BEGIN(J);
   const WinDesc wd = J.win[w];
   const uint32_t Lf = J.win_Lf[w], win_len = wd.win_len;
   const uint32_t tile0 = (uint32_t)wd.col_off, n_t = min((Lf + ROWCAP - 1) / ROWCAP, TCAP);
-  if (tid < 32) s_ct[tid] = J.ctab[(uint64_t)w * 32 + tid];
-  for (uint32_t p = tid; p <= win_len; p += NT) s_rop[RI(p)] = J.row_of_pos2[wd.pos_off + p];
-  for (uint32_t t = tid; t < n_t; t += NT) {
-    const uint2 te = J.tile_ev[tile0 + t];
-    s_tx[t] = te.x;
-    if (t + 1 == n_t) s_tx[n_t] = te.x + te.y;
+  {
+    // every load of the prologue in flight at once (a loop of load -> LDS store pairs was 33 round trips in a row: 37 k of the
+    // kernel's 106 k cycles in its first version)
+    constexpr int RL = 33;   // NT * RL > HERRO_MAX_WINDOW / (256 / NT) + 1: 128 threads cover windows of 4096, 256 threads 8192
+    uint32_t rv[RL];
+    const uint32_t* __restrict__ rop = J.row_of_pos2 + wd.pos_off;
+#pragma unroll
+    for (int u = 0; u < RL; u++) rv[u] = rop[min(tid + (uint32_t)u * NT, win_len)];
+    uint2 te = make_uint2(0, 0);
+    if (tid == 0 && n_t) te = J.tile_ev[tile0 + n_t - 1];
+    if (tid < 32) s_ct[tid] = J.ctab[(uint64_t)w * 32 + tid];
+#pragma unroll
+    for (int u = 0; u < RL; u++) {
+      const uint32_t p = tid + (uint32_t)u * NT;
+      if (p <= win_len) s_rop[RI(p)] = rv[u];
+    }
+    if (tid == 0) s_nruns = te.x + te.y;   // the tiles' run lists lie back to back (k_layout)
   }
-  if (n_t == 0 && tid == 0) s_tx[0] = 0;
   __syncthreads();
   PROF_MARK(J, 6, 0);
   // ---- 1: symbol counts of the base rows in position space
@@ -1149,7 +1159,7 @@ __global__ __launch_bounds__(NT) void k_rows(JobDev J) {
     c0[q] = (a ^ x) | (a & b);
     c1[q] = b | (a & x);
   };
-  constexpr int UB = 10;   // columns whose plane words are in flight together
+  constexpr int UB = 15;   // columns whose plane words are in flight together: two round trips (the workgroups are few per compute unit — LDS —, registers are not short)
 #pragma unroll 1
   for (uint32_t cb = 1; cb < HERRO_ROWS; cb += UB) {
     uint32_t M[UB], L[UB], H[UB];
@@ -1224,7 +1234,7 @@ __global__ __launch_bounds__(NT) void k_rows(JobDev J) {
   PROF_MARK(J, 6, 2);
   // ---- 2: insertion rows.  Index of an insertion row = its ordinal among the window's insertion rows = row - position - 1.
   const uint32_t n_irows = Lf - win_len;
-  const uint32_t n_runs = s_tx[n_t];
+  const uint32_t n_runs = s_nruns;
   const uint4* __restrict__ tev = J.tev + s_ct[0].ev_off;
   uint32_t n_isup = 0, insup = 0;   // informative insertion rows of this lane's positions; positions that have one
   for (uint32_t ch0 = 0; ch0 < n_irows; ch0 += RW_ICAP) {
@@ -1232,22 +1242,20 @@ __global__ __launch_bounds__(NT) void k_rows(JobDev J) {
     for (uint32_t i = tid; i < RW_ICAP; i += NT) s_adj[i] = 0;
     __syncthreads();
     // inserted bases of the selected columns (features.rs:213-229), from the tiles' run lists: a run that crosses a tile boundary is
-    // listed by both tiles, each takes its own rows; "hidden" rows were overwritten by a later insertion at the same position
-    for (uint32_t e0 = tid; e0 < n_runs; e0 += 2 * NT) {
-      uint4 ve[2];
+    // listed by both tiles, each takes its own rows (the tile travels with the record); "hidden" rows were overwritten by a later
+    // insertion at the same position
+    constexpr int EU = 4;
+    for (uint32_t e0 = tid; e0 < n_runs; e0 += EU * NT) {
+      uint4 ve[EU];
 #pragma unroll
-      for (int u = 0; u < 2; u++) ve[u] = tev[min(e0 + u * NT, n_runs - 1u)];
+      for (int u = 0; u < EU; u++) ve[u] = tev[min(e0 + u * NT, n_runs - 1u)];
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
+      for (int u = 0; u < EU; u++) {
         const uint32_t e = e0 + u * NT;
         if (e >= n_runs) continue;
-        uint32_t lo = 0, hi = n_t;   // tile of run e: s_tx[lo] <= e < s_tx[hi]
-        while (hi - lo > 1) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (s_tx[mid] <= e) lo = mid; else hi = mid;
-        }
+        const uint32_t lo = ve[u].w >> 16;
         const uint32_t tr0 = lo * ROWCAP, tr1 = min(tr0 + ROWCAP, Lf);
-        const uint32_t c = ve[u].w & 0xffu, hide = ve[u].w >> 8;
+        const uint32_t c = ve[u].w & 0xffu, hide = (ve[u].w >> 8) & 0xffu;
         const uint32_t p = ve[u].x & 0xffffu, len = ve[u].x >> 16;
         if (p >= win_len) continue;
         const uint32_t rp = s_rop[RI(p)], room = s_rop[RI(p + 1)] - rp - 1u;
@@ -1563,7 +1571,7 @@ __global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half) {
 // of a few words per slot with three dependent steps; nothing is staged.  (r3's version staged the 30 M planes of the window,
 // built rank and event directories for all 4096 positions in LDS — 60 k cycles and 43 KB of LDS per window for ~470 slots,
 // 17.7 x the output in HBM traffic; r2 scattered single bytes over the quality planes.)
-constexpr int RQ_NT = 256;
+constexpr int RQ_NT = 512;   // ~470 slots per window: one per thread — a slot is a chain of 5-7 dependent loads, a second one per thread doubled the kernel (r5)
 
 // Round 5: the slot carries the cells' TOKENS as well (bytes 0..7; qualities 8..15) — on the lean path there is no token plane to read
 // them from — and the rows of a slot are no longer looked up in a row map: the informative row's (position, ordinal) and the rows
@@ -1812,13 +1820,35 @@ __global__ __launch_bounds__(NT) void k_consensus_p(JobDev J, const uint64_t* su
   const uint32_t n_irows = Lf - win_len;
   const bool iv_lds = n_irows <= CP_ICAP;
   uint8_t* __restrict__ giv = J.cons_tmp + wd.row_off;
-  for (uint32_t p = tid; p <= win_len; p += NT) s_rop[RI(p)] = J.row_of_pos2[wd.pos_off + p];
-  if (tid < nw) {
-    const uint32_t* __restrict__ vp = J.vpl + (uint64_t)w * 3 * nw + tid;
-    s_v[0][tid] = vp[0]; s_v[1][tid] = vp[nw]; s_v[2][tid] = vp[2 * nw];
+  {
+    // all loads of the prologue in flight together (rows of the positions, vote planes, insertion-row votes)
+    constexpr int RL = 33;
+    uint32_t rv[RL];
+    const uint32_t* __restrict__ rop = J.row_of_pos2 + wd.pos_off;
+#pragma unroll
+    for (int u = 0; u < RL; u++) rv[u] = rop[min(tid + (uint32_t)u * NT, win_len)];
+    uint32_t vv[3] = {0, 0, 0};
+    if (tid < nw) {
+      const uint32_t* __restrict__ vp = J.vpl + (uint64_t)w * 3 * nw + tid;
+      vv[0] = vp[0]; vv[1] = vp[nw]; vv[2] = vp[2 * nw];
+    }
+    constexpr int IL = CP_ICAP / 4 / NT;
+    uint32_t iw[IL];
+    const uint32_t n_iw = iv_lds ? (n_irows + 3u) / 4u : 0u;
+#pragma unroll
+    for (int u = 0; u < IL; u++) iw[u] = n_iw ? reinterpret_cast<const uint32_t*>(giv)[min(tid + (uint32_t)u * NT, n_iw - 1u)] : 0u;
+#pragma unroll
+    for (int u = 0; u < RL; u++) {
+      const uint32_t p = tid + (uint32_t)u * NT;
+      if (p <= win_len) s_rop[RI(p)] = rv[u];
+    }
+    if (tid < nw) { s_v[0][tid] = vv[0]; s_v[1][tid] = vv[1]; s_v[2][tid] = vv[2]; }
+#pragma unroll
+    for (int u = 0; u < IL; u++) {
+      const uint32_t i = tid + (uint32_t)u * NT;
+      if (i < n_iw) reinterpret_cast<uint32_t*>(s_iv)[i] = iw[u];
+    }
   }
-  if (iv_lds)
-    for (uint32_t i = tid; i * 4u < n_irows; i += NT) reinterpret_cast<uint32_t*>(s_iv)[i] = reinterpret_cast<const uint32_t*>(giv)[i];
   __syncthreads();
   // informative rows: the model decides — argmax of the 5 base logits, the LAST maximum wins, NaN is greatest (consensus.rs:136-141)
   const uint32_t nsup = J.win_nsup[w];

@@ -139,6 +139,9 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
                             const uint64_t* aln_off, const herro_alignment* alns,
                             uint32_t window_size);
 void herro_job_free(herro_job* job);
+/* The HERRO_E_* code behind the last herro_job_create of this context that returned NULL (HERRO_OK after a successful one):
+ * UNSUPPORTED / INVALID / STATE / NO_DEVICE / REFERENCE_PANIC — herro_last_error has the text. */
+int herro_job_create_status(const herro_ctx* ctx);
 uint32_t herro_job_n_windows(const herro_job* job);
 /* Alignments herro_job_create left out instead of failing the call: exactly what parse_paf itself drops before extract_features
  * sees it — self overlaps and a second alignment of a (query, target) pair (overlaps.rs:175-185).  Everything else the reference
@@ -357,6 +360,13 @@ int64_t herro_pool_correct(herro_pool* pool, uint32_t n_targets, const uint32_t*
                            const char* const* descs);
 const char* herro_pool_result(const herro_pool* pool, const uint64_t** rec_end);
 uint32_t herro_pool_groups_taken(const herro_pool* pool, uint32_t i);
+/* Alignments / targets the jobs of the last herro_pool_correct left out (herro_job_skipped summed over its groups). */
+int herro_pool_skipped(const herro_pool* pool, uint64_t* n_alignments, uint64_t* n_targets);
+/* Host-only test hook: a pool of n_ctx stand-in contexts that needs no device — context i "works" us_per_aln[i] microseconds per
+ * alignment of a group, the FASTA of a target is ">id\n" + (rid % 7 + 1) bases; rid 0xfffffffe makes the group's herro_job_create fail
+ * with HERRO_E_UNSUPPORTED, rid 0xfffffffd its herro_job_infer with HERRO_E_STATE; a target whose first alignment has qid == tid
+ * counts as one skipped alignment.  Everything else (queue, two jobs in flight, merge, error paths) is herro_pool_correct's own code. */
+herro_pool* herro_debug_pool_fake(uint32_t n_ctx, const uint32_t* us_per_aln);
 
 #ifdef __cplusplus
 }

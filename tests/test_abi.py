@@ -21,6 +21,17 @@ def test_every_declared_symbol_is_exported():
     assert declared == set(api.EXPORTS)
 
 
+def test_the_library_exports_the_header_and_nothing_else():
+    """A host that links libherro_amd.so (the reference's Rust binary) must not meet helper globals or
+    mangled kernel stubs: the dynamic symbol table is the header's list (csrc/herro_amd.map)."""
+    import subprocess
+    hdr = open(os.path.join(ROOT, "include", "herro_amd.h")).read()
+    declared = set(re.findall(r"\b(herro_[a-z0-9_]+)\s*\(", hdr))
+    out = subprocess.run(["nm", "-D", "--defined-only", api.LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
+
+
 def test_codec_matches_reference_vectors():
     G = json.load(open(os.path.join(ROOT, "tests", "golden", "codec_vectors.json")))
     for v in G["encode"]:
