@@ -225,13 +225,26 @@ class Pool:
     """herro_pool (csrc/pool.cpp): several contexts of one process fed from one queue of target groups — the in-process layout of
     lib.rs:154-200.  device_ids: one entry per context (several may name the same GPU: they share its read store)."""
 
-    def __init__(self, device_ids):
+    def __init__(self, device_ids, fake_us_per_aln=None):
+        """fake_us_per_aln: test hook (herro_debug_pool_fake) — a device-free pool of len(fake_us_per_aln) stand-in contexts."""
         self._l = lib()
+        if fake_us_per_aln is not None:
+            us = np.ascontiguousarray(fake_us_per_aln, np.uint32)
+            self.h = self._l.herro_debug_pool_fake(len(us), us.ctypes.data)
+            self.n = len(us)
+            if not self.h:
+                raise HerroError(-1, "herro_debug_pool_fake")
+            return
         ids = (C.c_int * len(device_ids))(*device_ids)
         self.h = self._l.herro_pool_create(ids, len(device_ids))
         if not self.h:
             raise HerroError(-1, self._l.herro_last_error(None).decode(errors="replace"))
         self.n = len(device_ids)
+
+    def skipped(self) -> tuple[int, int]:
+        a, t = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._l.herro_pool_skipped(self.h, C.byref(a), C.byref(t)))
+        return a.value, t.value
 
     def _chk(self, rc):
         if rc < 0:

@@ -394,6 +394,48 @@ def owner_of(rids, world: int) -> np.ndarray:
     return ((h >> np.uint64(8)) % np.uint64(max(world, 1))).astype(np.int64)
 
 
+def allgather_u32(local: np.ndarray, group=None) -> list[np.ndarray]:
+    """Every rank's u32 array on every rank (sizes by one all_gather of an integer, payloads by one padded all_gather)."""
+    import torch
+    dist = _dist()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    local = np.ascontiguousarray(local, np.uint32)
+    if world == 1:
+        return [local]
+    dev = _dev(group)
+    n = torch.tensor([len(local)], dtype=torch.int64, device=dev)
+    ns = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(ns, n, group=group)
+    sizes = [int(t.item()) for t in ns]
+    cap = max(max(sizes), 1)
+    buf = torch.zeros(cap, dtype=torch.int32, device=dev)
+    if len(local):
+        buf[:len(local)] = torch.from_numpy(local.view(np.int32)).to(dev)
+    out = [torch.zeros(cap, dtype=torch.int32, device=dev) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    return [o[:k].cpu().numpy().view(np.uint32) for o, k in zip(out, sizes)]
+
+
+def owners_by_load(tgt_rid, read_lens, window_size: int, group=None) -> np.ndarray:
+    """The owner of every target of this rank's share, balanced by WORK instead of hashed (SURVEY §8 e; the reference hands its
+    reads out dynamically, lib.rs:154-200 — across processes the nearest thing is to balance what can be known up front):
+    every rank announces the target ids it has seen (one all_gather of 4 bytes per target), the union is cut into shards by
+    partition_targets — greedy longest-first over the targets' window counts ceil(len / W) (features.rs:338), which every rank
+    knows from the replicated read store — and every rank computes the same assignment.  UL reads differ 10x in length: a
+    hash of the id leaves the load of a rank to chance, this bounds max / mean by the longest read's share."""
+    dist = _dist()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    tgt_rid = np.asarray(tgt_rid, np.uint32)
+    if world == 1:
+        return np.zeros(len(tgt_rid), np.int64)
+    union = np.unique(np.concatenate(allgather_u32(tgt_rid, group)))
+    shards = partition_targets(windows_of(np.asarray(read_lens)[union], window_size), world)
+    owner_u = np.empty(len(union), np.int64)
+    for r, sh in enumerate(shards):
+        owner_u[sh] = r
+    return owner_u[np.searchsorted(union, tgt_rid)]
+
+
 class _Share:
     """The arrays shard_arrays / shard_work / work_size read from a data set: tgt_rid, tgt_aln_off, aln, cig_off, cig."""
 
@@ -509,13 +551,14 @@ def merge_pieces(pieces):
     return order_t.astype(np.uint32), aln_off, rows[sel], cig_off[sel], cig
 
 
-def route_to_owners(share: _Share, group=None):
-    """One all-to-all: every rank packs, per destination, the targets of its share that the destination owns (owner_of), and
-    gets back the pieces of its own targets from every rank, merged.  Returns (work arrays, bytes this rank sent)."""
+def route_to_owners(share: _Share, group=None, read_lens=None, window_size: int = 0):
+    """One all-to-all: every rank packs, per destination, the targets of its share that the destination owns, and gets back the
+    pieces of its own targets from every rank, merged.  Ownership: balanced by window count when the read lengths are given
+    (owners_by_load: one small all_gather more), else the hash of the id (owner_of).  Returns (work arrays, bytes this rank sent)."""
     dist = _dist()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    owner = owner_of(share.tgt_rid, world)
+    owner = owners_by_load(share.tgt_rid, read_lens, window_size, group) if read_lens is not None and window_size else owner_of(share.tgt_rid, world)
     mine = np.flatnonzero(owner == rank)
     msgs = [np.zeros(0, np.uint8)] * world
     sent = 0
@@ -538,14 +581,15 @@ def route_to_owners(share: _Share, group=None):
     return merge_pieces(pieces), sent
 
 
-def correct_sharded_local(share: _Share, correct_fn, group=None):
+def correct_sharded_local(share: _Share, correct_fn, group=None, read_lens=None, window_size: int = 0):
     """The sharded data path with per-rank ingestion: `share` = what THIS rank has read (ingest_paf_range of its byte range, or
-    its own batch files); one all-to-all routes every target to its owner; correct_fn runs on the owned targets; the FASTA
-    records are gathered to rank 0.  Returns ((rids, ends, text) on rank 0 else None, owned targets, bytes sent while routing)."""
+    its own batch files); one all-to-all routes every target to its owner (read_lens + window_size: owners balanced by window
+    count, owners_by_load; without them: the hash of the id); correct_fn runs on the owned targets; the FASTA records are gathered
+    to rank 0.  Returns ((rids, ends, text) on rank 0 else None, owned targets, bytes sent while routing)."""
     dist = _dist()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    (rids, aln_off, rows, cig_off, cig), sent = route_to_owners(share, group)
+    (rids, aln_off, rows, cig_off, cig), sent = route_to_owners(share, group, read_lens, window_size)
     rec = correct_fn(rids, aln_off, rows, cig_off, cig) if len(rids) else (np.zeros(0, np.uint32), np.zeros(0, np.uint64), b"")
     if world == 1:
         return merge_records([rec]), len(rids), sent
@@ -646,6 +690,7 @@ def strong_leg(args, rank: int, world: int, local: int, n_windows: int, n_ctx: i
         else:
             c.set_reads(seq, qual, off)
         ctxs.append(c)
+    read_lens = np.diff(np.asarray(off).astype(np.int64))   # every rank knows the read lengths from the replicated store
     fn = hip_corrector(ctxs, W, args.batch, lambda rid: f"read{rid}", group_targets=max(1, args.group * args.batch // wpt))
     nw = np.full(n_t, wpt, np.int64) if rank == 0 else None
     local_ingest = getattr(args, "strong_ingest", "local") != "rank0"
@@ -669,7 +714,7 @@ def strong_leg(args, rank: int, world: int, local: int, n_windows: int, n_ctx: i
 
     def one_pass():
         if local_ingest:
-            return correct_sharded_local(share, fn)
+            return correct_sharded_local(share, fn, read_lens=read_lens, window_size=W)   # owners balanced by window count
         rec_, n_ = correct_sharded(sb, nw, fn)
         return rec_, n_, None
     if args.warmup:                                  # one untimed pass over the same fixed job (arenas, clocks)

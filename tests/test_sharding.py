@@ -237,6 +237,67 @@ def test_per_rank_ingestion_three_ranks(tmp_path):
     paf.close()
 
 
+WORKER4 = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, {root!r})
+    import numpy as np, torch, torch.distributed as dist
+    from herro_amd import shard
+    rank, world = int(sys.argv[1]), int(sys.argv[2])
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    W = 4096
+    rng = np.random.default_rng(11)
+    n_reads = 600
+    lens = rng.integers(3000, 40000, n_reads)
+    lens[rng.choice(n_reads, 25, replace=False)] = rng.integers(200000, 400000, 25)      # ultra-long reads: 10x the windows of the others
+    targets = np.flatnonzero(rng.random(n_reads) < 0.7).astype(np.uint32)
+    # every rank has read SOME alignments of some targets (a byte range of a PAF sorted by nothing): overlapping subsets
+    seen = targets[rng.random((world, len(targets)))[rank] < 0.6]
+    if rank == 1:
+        seen = seen[:0]                                                                    # a rank that read nothing still takes part
+    aln_off = np.arange(len(seen) + 1, dtype=np.uint64)
+    rows = np.zeros((len(seen), 10), np.uint32); rows[:, 5] = seen; rows[:, 0] = 100000 + rank; rows[:, 9] = 2
+    share = shard._Share(seen, aln_off, rows, np.arange(len(seen), dtype=np.uint64) * 2, np.frombuffer(b"1M" * max(len(seen), 1), np.uint8)[:2 * len(seen)].copy())
+
+    def correct(rids, aln_off, rows, cig_off, cig):
+        ends = np.cumsum([len(b">r%d \\nA\\n" % r) for r in rids]).astype(np.uint64) if len(rids) else np.zeros(0, np.uint64)
+        return np.asarray(rids, np.uint32), ends, b"".join(b">r%d \\nA\\n" % r for r in rids)
+    own_h = shard.owner_of(seen, world)
+    own_b = shard.owners_by_load(seen, lens, W)
+    rec, n_mine, sent = shard.correct_sharded_local(share, correct, read_lens=lens, window_size=W)
+    # the load every rank ends up with under both rules (windows of the targets it owns), from the union of what the ranks saw
+    union = np.unique(np.concatenate(shard.allgather_u32(seen)))
+    wins = shard.windows_of(lens[union], W)
+    ob = shard.owners_by_load(union, lens, W)
+    oh = shard.owner_of(union, world)
+    load_b = [int(wins[ob == r].sum()) for r in range(world)]
+    load_h = [int(wins[oh == r].sum()) for r in range(world)]
+    same = shard.gather_counts({{"agree": int((own_b == ob[np.searchsorted(union, seen)]).all())}})
+    if rank == 0:
+        print(json.dumps({{"load_balanced": load_b, "load_hash": load_h, "agree": same["agree"], "records": int(len(rec[0])), "targets": int(len(union))}}))
+    dist.destroy_process_group()
+""")
+
+
+def test_owners_balanced_by_window_count_three_ranks(tmp_path):
+    """across processes ownership was a hash of the read id — with UL reads (10x the windows) the load of a rank
+    was left to chance.  owners_by_load: one all_gather of the target ids every rank has seen, longest-first assignment by window
+    count; every rank computes the same owners, max / mean load <= 1.1, every target is corrected exactly once."""
+    import json
+    port = 37500 + os.getpid() % 2000
+    script = tmp_path / "worker_lpt.py"
+    script.write_text(WORKER4.format(root=ROOT, port=port))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(3)]
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    got = json.loads(outs[0][0].strip().splitlines()[-1])
+    lb = np.array(got["load_balanced"], float)
+    assert got["agree"] == 3 and got["records"] == got["targets"]
+    assert lb.max() / lb.mean() <= 1.1, got
+    lh = np.array(got["load_hash"], float)
+    assert lb.max() <= lh.max()          # never worse than the hash
+
+
 def test_record_messages_round_trip():
     a = (np.array([7, 3], np.uint32), np.array([5, 5], np.uint64), b">r7 \n")
     b = (np.array([1], np.uint32), np.array([6], np.uint64), b">r1 \nA")
