@@ -1641,7 +1641,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   const size_t o_cseq = take(row_elems), o_ctmp = take(row_elems), o_clen = take((uint64_t)n_win * 4);
   const size_t o_srow = take(row_elems * 4), o_spi = take(row_elems * 4);
   const size_t o_finb = take(fin_bytes), o_finq = take(fin_bytes), o_nd = take((uint64_t)n_cls * 8);
-  const size_t o_vpl = take((uint64_t)n_win * 3 * J.nw * 4);
+  const size_t o_vpl = take((uint64_t)n_win * 3 * J.nw * 4), o_snr = take(row_elems * 4);
   const size_t dev_bytes = cur;
   job->dev = arena_acquire(ctx, ctx->free_dev, dev_bytes, 1);
   auto give_back = [&]() {
@@ -1665,7 +1665,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.cons_seq = (uint8_t*)(db + o_cseq); J.cons_tmp = (uint8_t*)(db + o_ctmp); J.cons_len = (uint32_t*)(db + o_clen);
   J.sup_row = (uint32_t*)(db + o_srow); J.sup_pi = (uint32_t*)(db + o_spi);
   J.fin_b = (uint8_t*)(db + o_finb); J.fin_q = (uint8_t*)(db + o_finq); J.nd = (uint32_t*)(db + o_nd);
-  J.vpl = (uint32_t*)(db + o_vpl);
+  J.vpl = (uint32_t*)(db + o_vpl); J.sup_nr = (uint32_t*)(db + o_snr);
   // one copy, pinned -> device, asynchronous on the context stream: the kernels of herro_job_featurize queue behind it
   // in stream order, nobody waits here
   hipError_t e = hipMemcpyAsync(db, job->pin.p, desc_bytes, hipMemcpyHostToDevice, ctx->stream);
@@ -1759,7 +1759,7 @@ int herro_job_featurize(herro_job* job) {
     const uint64_t want = job->logit_cap > 1 ? job->logit_cap : (uint64_t)n * 24;   // ~15 informative rows per window at the bench workload
     if (job->a_supoff_dev.p && ensure_logits(job, want) == HERRO_OK) {
       launch_supoff(job->J, (uint64_t*)job->a_supoff_dev.p, ctx->stream);
-      launch_rf_quals(job->J, rf_half, (const uint64_t*)job->a_supoff_dev.p, job->d_rfq, job->logit_cap, ctx->stream, &ctx->timer);
+      launch_rf_quals(job->J, rf_half, (const uint64_t*)job->a_supoff_dev.p, job->d_rfq, job->logit_cap, job->lean, ctx->stream, &ctx->timer);
       HIP_TRY(ctx, hipGetLastError());
       job->rfq_spec = true; job->rfq_spec_half = rf_half; job->rfq_spec_cap = job->logit_cap;
     }
@@ -1951,7 +1951,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
     job->tokens_full = true;
   }
   if (!(job->quals_full && !rf_compact) && !groups.empty() && !rfq_there)
-    launch_rf_quals(job->J, rf_half, job->d_supoff_blob, rf_compact ? job->d_rfq : nullptr, job->logit_cap, ctx->stream, &ctx->timer);
+    launch_rf_quals(job->J, rf_half, job->d_supoff_blob, rf_compact ? job->d_rfq : nullptr, job->logit_cap, job->lean, ctx->stream, &ctx->timer);
   for (const Offs& o : offs) {
     const unsigned char* base = (const unsigned char*)job->d_bdesc;
     BatchDev B{};

@@ -76,6 +76,8 @@ struct JobDev {
   uint32_t* rowmap2;     // [win.row_off + row] = pos | ins << 16
   uint32_t* sup_row;     // [win.row_off + k]   final row of informative position k
   uint32_t* sup_pi;      // [win.row_off + k]   pos | ins << 16
+  uint32_t* sup_nr;      // [win.row_off + k]   lean path: rows (1 + max insertion, <= 51) of positions pos - 2, pos - 1, pos, pos + 1, 6 bits each (0: outside the window) —
+                         // with sup_row / sup_pi everything k_rfq needs to name the cells of the five rows around the informative row, without the row map
   uint8_t* fin_b;        // final token planes   [win.fin_off + c*lub + row], c in [0,31)
   uint8_t* fin_q;        // qualities: only receptive-field cells after infer, complete after launch_full_quals
   uint32_t* nd;          // [2*cls]: matches, mismatches (features.rs:461-500)
@@ -169,7 +171,8 @@ void launch_full_tokens(const JobDev& J, hipStream_t st, KernelTimer* tm);   // 
 // sup_row[k] - half .. + 7 - half of that column, bytes 8..15 their qualities (needs 2 * half + 1 <= 8); else the qualities go into the
 // quality planes (which needs the row map, i.e. the planes path or launch_full_tokens)
 // cap: informative rows rf has room for (a window whose slots would lie beyond it is left out: launches in front of the host's count)
-void launch_rf_quals(const JobDev& J, uint32_t half, const uint64_t* sup_off, uint8_t* rf, uint64_t cap, hipStream_t st, KernelTimer* tm);
+// lean: the job was featurized on the lean path (sup_nr is valid: the rows around an informative row are named without row_of_pos2)
+void launch_rf_quals(const JobDev& J, uint32_t half, const uint64_t* sup_off, uint8_t* rf, uint64_t cap, bool lean, hipStream_t st, KernelTimer* tm);
 void launch_supoff(const JobDev& J, uint64_t* sup_off, hipStream_t st);   // sup_off[0 .. n_win]: prefix of win_nsup
 // the complete quality planes (featurize itself only writes tokens)
 void launch_full_quals(const JobDev& J, hipStream_t st);

@@ -191,6 +191,9 @@ constexpr uint32_t MDCAP = 192;   // ops per batch (three steps of 64); a slice 
 __host__ __device__ inline uint32_t cols_qcap(uint32_t nw) { return nw + 40u < 320u ? nw + 40u : 320u; }   // staged query plane words
 __host__ __device__ inline uint32_t cols_lds_words(uint32_t nw) { return 3 * MDCAP + 2 * (nw + 1) + 2 * (cols_qcap(nw) + 2) + 2 * (nw + 2); }
 
+// QI: 64-word steps that cover the staged query words (cols_qcap(nw) + 2), NWI: plane words per lane (nw / 64, rounded up) — the loops over
+// them are unrolled, and with the bounds of the largest window (5, 4) a 4096-base window paid for two empty steps of each (r5)
+template <int QI, int NWI>
 __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
   extern __shared__ __attribute__((aligned(16))) uint32_t ca_smem[];
   const uint32_t nw = J.nw, qcap = cols_qcap(nw);
@@ -214,11 +217,11 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
   const uint64_t pmax = J.read_n_words + 1;   // last word of the plane arrays
   const uint32_t qw0 = d.qbeg >> 5, nqw = ((d.qbeg + d.qlen) >> 5) - qw0 + 2;
   const bool staged = nqw <= qcap;
+  const bool packed_scan = d.qlen < 65536u;   // wave-uniform
   // ---- every global load of the wave is issued here, unconditionally (indices clamped), before anything waits
   uint32_t op_r[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) op_r[i] = ops[min(lane + 64u * i, cnt_ops - 1u)];
-  constexpr int QI = 5;
   uint32_t v0[QI], v1[QI], u0[QI], u1[QI];
   {
     // scalar bases, 32-bit lane offsets clamped once against the end of the plane arrays
@@ -262,7 +265,6 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
   };
   uint32_t carry_t = 0, carry_q = 0, n_ev = 0, isum = 0, dsum = 0, longindel = 0;
   uint4* __restrict__ ev = J.iev + d.scr_off;
-  constexpr int NWI = 4;   // plane words per lane (nw <= 256)
   uint32_t pM[NWI], pL[NWI], pH[NWI];
   // directories for k_rfq, per word of 32 positions: alignment-orientation query index of the first base at or behind the word's
   // first position (= M bits + inserted bases in front of it), insertion events in front of it — read off the op that covers
@@ -290,7 +292,16 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
         if (isI) isum += e;
         if (isD) dsum += e;
         const uint32_t tadv = (isM || isD) ? e : 0u, qadv = (isM || isI) ? e : 0u;
-        const uint32_t it = wscan_incl(tadv), iq = wscan_incl(qadv);
+        // one scan for both where the halves cannot meet: target advance in the low half (a slice consumes <= 8192 target bases), query
+        // advance in the high half when the slice's query span (OwDesc::qlen = the sum of all query advances) stays below 65536
+        uint32_t it, iq, last_t, last_q;
+        if (packed_scan) {
+          const uint32_t itq = wscan_incl(tadv | (qadv << 16));
+          const uint32_t last = wlast(itq);
+          it = itq & 0xffffu; iq = itq >> 16; last_t = last & 0xffffu; last_q = last >> 16;
+        } else {
+          it = wscan_incl(tadv); iq = wscan_incl(qadv); last_t = wlast(it); last_q = wlast(iq);
+        }
         const uint32_t t = carry_t + it - tadv, q = carry_q + iq - qadv;
         // insertion behind window position off + t - 1 (features.rs:77, 219-228): position, trimmed length (bases written),
         // query index of its first base, its first 16 bases, untrimmed length (max_ins)
@@ -317,8 +328,8 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
           if (P < ((nw + 1u) << 5)) atomicOr(&s_bm[P >> 5], 1u << (P & 31u));
         }
         n_md += (uint32_t)__popcll(mdmask);
-        carry_t += wlast(it);
-        carry_q += wlast(iq);
+        carry_t += last_t;
+        carry_q += last_q;
       }
     }
     // the wave reads its own LDS writes back: LDS operations of one wave execute in order
@@ -1159,7 +1170,7 @@ __global__ __launch_bounds__(NT) void k_rows(JobDev J) {
     c0[q] = (a ^ x) | (a & b);
     c1[q] = b | (a & x);
   };
-  constexpr int UB = 15;   // columns whose plane words are in flight together: two round trips (the workgroups are few per compute unit — LDS —, registers are not short)
+  constexpr int UB = 10;   // columns whose plane words are in flight together (15: measured no faster)
 #pragma unroll 1
   for (uint32_t cb = 1; cb < HERRO_ROWS; cb += UB) {
     uint32_t M[UB], L[UB], H[UB];
@@ -1239,12 +1250,12 @@ __global__ __launch_bounds__(NT) void k_rows(JobDev J) {
   uint32_t n_isup = 0, insup = 0;   // informative insertion rows of this lane's positions; positions that have one
   for (uint32_t ch0 = 0; ch0 < n_irows; ch0 += RW_ICAP) {
     if (ch0) __syncthreads();   // the previous pass's votes are out
-    for (uint32_t i = tid; i < RW_ICAP; i += NT) s_adj[i] = 0;
+    for (uint32_t i = tid; i < min(RW_ICAP, n_irows - ch0); i += NT) s_adj[i] = 0;
     __syncthreads();
     // inserted bases of the selected columns (features.rs:213-229), from the tiles' run lists: a run that crosses a tile boundary is
     // listed by both tiles, each takes its own rows (the tile travels with the record); "hidden" rows were overwritten by a later
     // insertion at the same position
-    constexpr int EU = 4;
+    constexpr int EU = 8;   // ~10 runs per thread at the bench workload: two round trips
     for (uint32_t e0 = tid; e0 < n_runs; e0 += EU * NT) {
       uint4 ve[EU];
 #pragma unroll
@@ -1313,9 +1324,17 @@ __global__ __launch_bounds__(NT) void k_rows(JobDev J) {
   for (uint32_t m = supb | insup; m; m &= m - 1u) {
     const uint32_t k = (uint32_t)__ffs((int)m) - 1u, p = (uint32_t)P + k;
     const uint32_t rp = s_rop[RI(p)];
+    // rows of the positions around p (6 bits each, 0 outside the window): k_rfq names the cells of the rows around an informative row from these
+    uint32_t nr = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int32_t q = (int32_t)p - 2 + i;
+      if (q >= 0 && q < (int32_t)win_len) nr |= (s_rop[RI((uint32_t)q + 1u)] - s_rop[RI((uint32_t)q)]) << (6 * i);
+    }
     if ((supb >> k) & 1u) {
       J.sup_row[wd.row_off + kk] = rp;
       J.sup_pi[wd.row_off + kk] = p;
+      J.sup_nr[wd.row_off + kk] = nr;
       kk++;
     }
     if ((insup >> k) & 1u) {
@@ -1326,6 +1345,7 @@ __global__ __launch_bounds__(NT) void k_rows(JobDev J) {
         if (fl & 0x80u) {
           J.sup_row[wd.row_off + kk] = rp + 1u + j;
           J.sup_pi[wd.row_off + kk] = p | ((j + 1u) << 16);
+          J.sup_nr[wd.row_off + kk] = nr;
           kk++;
         }
       }
@@ -1578,7 +1598,7 @@ constexpr int RQ_NT = 512;   // ~470 slots per window: one per thread — a slot
 // of the positions around it (row_of_pos2) say which cell each of the slot's rows is.  A base cell's code comes from the column's
 // lo / hi planes (two more words per slot), an inserted base's from its event (the first 16 bases travel with it), the target's from
 // the read store.
-__global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const uint64_t* __restrict__ sup_off, uint8_t* __restrict__ rf, uint64_t cap) {
+__global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const uint64_t* __restrict__ sup_off, uint8_t* __restrict__ rf, uint64_t cap, uint32_t have_nr) {
   __shared__ __attribute__((aligned(16))) CTab s_ct[32];
   const uint32_t w = blockIdx.x, tid = threadIdx.x, nw = J.nw;
   PROF_BEGIN(J);
@@ -1602,10 +1622,22 @@ __global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const ui
     // row of its own, so p lies within `half` positions of the informative row's
     const uint32_t pj = J.sup_pi[wd.row_off + k];
     const int32_t pc = (int32_t)(pj & 0xffffu);
-    const int64_t row0 = (int64_t)J.sup_row[wd.row_off + k] - (int64_t)half;
-    uint32_t rv[8];
+    const uint32_t srow = J.sup_row[wd.row_off + k];
+    const int64_t row0 = (int64_t)srow - (int64_t)half;
+    uint32_t rv[8];   // first row of positions pc - half + i
+    if (have_nr && half == 2) {   // lean path: the neighbours' row counts came with the informative row (k_rows) — one round trip less, no row_of_pos2
+      const uint32_t nr = J.sup_nr[wd.row_off + k];
+      const uint32_t rc = srow - (pj >> 16);                      // row of position pc
+      rv[2] = rc;
+      rv[1] = rc - ((nr >> 6) & 63u);
+      rv[0] = rv[1] - (nr & 63u);
+      rv[3] = rc + ((nr >> 12) & 63u);
+      rv[4] = rv[3] + ((nr >> 18) & 63u);
+      rv[5] = rv[6] = rv[7] = 0;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 8; i++) rv[i] = rop[(uint32_t)min(max(pc - (int32_t)half + i, 0), (int32_t)win_len)];
+      for (int i = 0; i < 8; i++) rv[i] = rop[(uint32_t)min(max(pc - (int32_t)half + i, 0), (int32_t)win_len)];
+    }
     uint32_t rm[8];
 #pragma unroll
     for (int d = 0; d < 8; d++) {
@@ -1666,7 +1698,25 @@ __global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const ui
 #pragma unroll
         for (int d = 0; d < 8; d++) if (rm[d] != NONE) { pl = rm[d] & 0xffffu; ins_row = ins_row || (rm[d] >> 16) != 0; }
         const bool quiet = d0.y != 0xffffffffu && d1.y != 0xffffffffu && w1 != w0 && (d1.y >> 20) == e && (pl >> 5) == w0 && !ins_row;
-        uint4 ecur = (!quiet && e < n_ev) ? iev[e] : make_uint4(0xffffffffu, 0, 0, 0);   // event e (position 0xffff: none left)
+        // the next four events travel together (one round trip for nearly every slot; a fifth is fetched when the walk gets there)
+        const uint32_t e_first = e;
+        const uint4 none4 = make_uint4(0xffffffffu, 0, 0, 0);
+        // (loads unconditional with clamped indices, values selected afterwards: a select between the array and a constant compiles to a
+        // flat load from a stack copy of the constant)
+        const uint32_t e_last = n_ev ? n_ev - 1u : 0u;
+        uint4 ep0 = iev[min(e, e_last)], ep1 = iev[min(e + 1u, e_last)], ep2 = iev[min(e + 2u, e_last)], ep3 = iev[min(e + 3u, e_last)];
+        if (quiet || e >= n_ev) ep0.x = 0xffffffffu;
+        if (quiet || e + 1u >= n_ev) ep1.x = 0xffffffffu;
+        if (quiet || e + 2u >= n_ev) ep2.x = 0xffffffffu;
+        if (quiet || e + 3u >= n_ev) ep3.x = 0xffffffffu;
+        auto ev_at = [&](uint32_t i) -> uint4 {   // event i (position 0xffff: none left)
+          if (i >= n_ev) return none4;
+          const uint32_t o = i - e_first;
+          if (o >= 4u) return iev[i];
+          const uint4 a = (o & 1u) ? ep1 : ep0, b = (o & 1u) ? ep3 : ep2;
+          return (o & 2u) ? b : a;
+        };
+        uint4 ecur = ep0;
         uint32_t cum = 0;   // bases inserted behind positions [32 w0, p)
 #pragma unroll
         for (int d = 0; d < 8; d++) {
@@ -1675,7 +1725,7 @@ __global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const ui
           while ((ecur.x & 0xffffu) < p) {   // events in front of p: [.., e)
             cum += ecur.x >> 16;
             e++;
-            ecur = e < n_ev ? iev[e] : make_uint4(0xffffffffu, 0, 0, 0);
+            ecur = ev_at(e);
           }
           const bool second = (p >> 5) != w0;   // the span is at most 8 rows: two words at most
           const uint32_t mw = second ? m1 : m0;
@@ -1698,7 +1748,7 @@ __global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const ui
                 code = j <= 16u ? (x.z >> (2u * (j - 1u))) & 3u : 4u;
               }
               if (++i >= n_ev) break;
-              x = iev[i];
+              x = ev_at(i);
               if ((x.x & 0xffffu) != p) break;
             }
             if (qi != NONE) {
@@ -1946,11 +1996,11 @@ void launch_supoff(const JobDev& J, uint64_t* sup_off, hipStream_t st) {
   if (J.n_win) hipLaunchKernelGGL(k_supoff, dim3(1), dim3(256), 0, st, J, sup_off);
 }
 
-void launch_rf_quals(const JobDev& J, uint32_t half, const uint64_t* sup_off, uint8_t* rf, uint64_t cap, hipStream_t st, KernelTimer* tm) {
+void launch_rf_quals(const JobDev& J, uint32_t half, const uint64_t* sup_off, uint8_t* rf, uint64_t cap, bool lean, hipStream_t st, KernelTimer* tm) {
   if (!J.n_win) return;
   KT_BEGIN(tm, "rf_quals", st);
   if (rf && 2 * half + 1 <= 8) {
-    hipLaunchKernelGGL(k_rfq, dim3(J.n_win), dim3(RQ_NT), 0, st, J, half, sup_off, rf, cap);
+    hipLaunchKernelGGL(k_rfq, dim3(J.n_win), dim3(RQ_NT), 0, st, J, half, sup_off, rf, cap, lean ? 1u : 0u);
     KT_END(tm, st);
     return;
   }
@@ -1991,7 +2041,8 @@ void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm, bool lea
   if (!J.n_win) return;
   if (J.n_ow) {
     KT_BEGIN(tm, "cols", st);
-    hipLaunchKernelGGL(k_cols, dim3((J.n_ow + CA_NW - 1) / CA_NW), dim3(CA_NT), (size_t)CA_NW * cols_lds_words(J.nw) * 4, st, J);
+    if (J.nw <= 128) hipLaunchKernelGGL((k_cols<3, 2>), dim3((J.n_ow + CA_NW - 1) / CA_NW), dim3(CA_NT), (size_t)CA_NW * cols_lds_words(J.nw) * 4, st, J);   // cols_qcap(128) + 2 = 170 <= 192
+    else hipLaunchKernelGGL((k_cols<5, 4>), dim3((J.n_ow + CA_NW - 1) / CA_NW), dim3(CA_NT), (size_t)CA_NW * cols_lds_words(J.nw) * 4, st, J);
     KT_END(tm, st);
   trace_point("cols", st);
   }
