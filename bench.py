@@ -151,9 +151,10 @@ def main():
                          "reference's concurrent feature / inference threads per device (lib.rs:154-200)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--windows", type=int, default=0, help="--scaling strong: total windows of the fixed job (default steps * batch)")
-    ap.add_argument("--strong-windows", type=int, default=32768,
-                    help="size of the fixed job of the 'strong' leg that follows the weak measurement (the sharded data path: rank 0 ingests, "
-                         "scatter / gather; BASELINE configs[3] uses 100000 — its read set takes ~30 GB of host memory); 0: skip")
+    ap.add_argument("--strong-windows", type=int, default=100000,
+                    help="size of the fixed job of the 'strong' leg that follows the weak measurement (the sharded data path; BASELINE configs[2..3]: "
+                         "100000 windows — generated as copies of at most --strong-base-targets targets, every copy a target read of its own); 0: skip")
+    ap.add_argument("--strong-base-targets", type=int, default=4200, help="targets the generator makes for the 'strong' leg (the job is copies of them)")
     ap.add_argument("--strong-ingest", choices=["local", "rank0"], default="local",
                     help="'local': every rank holds its own share of the parsed alignments and one all-to-all takes targets to their owners "
                          "(scales); 'rank0': rank 0 ingests everything and scatters the work (the literal north_star path)")
@@ -543,7 +544,8 @@ def main():
                                    "(BASELINE configs[2])", "batch": args.batch, "window": W, "overlaps": N_OVL,
                        "mean_len": st["sum_len"] / (G * args.batch), "mean_informative": st["sum_supported"] / (G * args.batch),
                        "model_windows_per_batch": st["n_model_windows"] / G, "batches_per_launch_group": G,
-                       "streams_per_gpu": NS, "distinct_windows_cycled": n_jobs * G * args.batch, "precision": args.precision},
+                       "streams_per_gpu": NS, "distinct_windows_cycled": n_jobs * G * args.batch, "precision": args.precision,
+                       "total_windows": total_windows, "strong_leg_windows": args.strong_windows},
             "mbases_per_s": total_windows / el * W / 1e6,
             "roofline": roof,
             "roofline_featurize_group": {

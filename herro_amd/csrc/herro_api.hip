@@ -1630,12 +1630,12 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.n_tiles = (uint32_t)job->tile_win.size(); J.window_size = W; J.nw = (W + 31) / 32; J.max_cols = max_cols;
   { const char* e = getenv("HERRO_DEBUG_CDIR_OVERFLOW"); J.dbg_flags = (e && atoi(e)) ? 1u : 0u; }
   cur = desc_bytes;
-  const size_t o_cpl = take(((uint64_t)n_ow + 1) * 3 * J.nw * 4), o_iev = take(scr_ops * 16), o_ins_cnt = take((uint64_t)n_ow * 4);
+  const size_t o_cw = take(((uint64_t)n_ow + 1) * J.nw * 16), o_iev = take(scr_ops * 16), o_ins_cnt = take((uint64_t)n_ow * 4);
   const size_t o_ocol = take((uint64_t)n_ow * 16);
   const size_t o_keep = take(n_ow), o_acc = take((uint64_t)n_ow * 4), o_ttot = take((uint64_t)n_ow * 4);
   const size_t o_slot = take((uint64_t)n_ow * 4), o_rqid = take((uint64_t)n_ow * 4), o_sel = take((uint64_t)n_win * 32 * 4);
   const size_t o_ctab = take((uint64_t)n_win * 32 * sizeof(CTab)), o_chdr = take((size_t)J.n_tiles * 8), o_tnsup = take((size_t)J.n_tiles * 4);
-  const size_t o_cdir = take(((uint64_t)n_ow + 1) * J.nw * 8), o_tev = take((scr_ops + 2ull * n_ow) * 16), o_tileev = take((size_t)J.n_tiles * 8);
+  const size_t o_tev = take((scr_ops + 2ull * n_ow) * 16), o_tileev = take((size_t)J.n_tiles * 8);
   const size_t o_dcounts = take((uint64_t)n_win * 12);
   const size_t o_rop = take(pos_elems * 4), o_rmap = take(row_elems * 4);
   const size_t o_cseq = take(row_elems), o_ctmp = take(row_elems), o_clen = take((uint64_t)n_win * 4);
@@ -1654,11 +1654,11 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   unsigned char* db = (unsigned char*)job->dev.p;
   J.ops = ds ? (const uint32_t*)job->scan.p : (const uint32_t*)(db + o_ops); J.ow = (const OwDesc*)(db + o_ow); J.win = (const WinDesc*)(db + o_win);
   J.tile_win = (const uint32_t*)(db + o_tw); J.tile_r0 = (const uint32_t*)(db + o_tr);
-  J.cpl = (uint32_t*)(db + o_cpl); J.iev = (uint4*)(db + o_iev); J.ins_cnt = (uint32_t*)(db + o_ins_cnt); J.ocol = (uint4*)(db + o_ocol);
+  J.cw = (uint4*)(db + o_cw); J.iev = (uint4*)(db + o_iev); J.ins_cnt = (uint32_t*)(db + o_ins_cnt); J.ocol = (uint4*)(db + o_ocol);
   J.ow_keep = (uint8_t*)(db + o_keep); J.ow_acc = (float*)(db + o_acc); J.ow_ttotal = (uint32_t*)(db + o_ttot);
   J.slot_ow = (uint32_t*)(db + o_slot); J.rank_qid = (uint32_t*)(db + o_rqid); J.sel_ow = (uint32_t*)(db + o_sel);
   J.ctab = (CTab*)(db + o_ctab); J.chdr2 = (uint2*)(db + o_chdr); J.tile_nsup = (uint32_t*)(db + o_tnsup);
-  J.cdir = (uint2*)(db + o_cdir); J.tev = (uint4*)(db + o_tev); J.tile_ev = (uint2*)(db + o_tileev);
+  J.tev = (uint4*)(db + o_tev); J.tile_ev = (uint2*)(db + o_tileev);
   job->d_counts = (uint32_t*)(db + o_dcounts);
   J.win_Lf = job->d_counts; J.win_nsup = job->d_counts + n_win; J.win_nkept = job->d_counts + 2ull * n_win;
   J.row_of_pos2 = (uint32_t*)(db + o_rop); J.rowmap2 = (uint32_t*)(db + o_rmap);

@@ -53,9 +53,9 @@ struct JobDev {
   const uint32_t* tile_win;  // [n_tiles] window of each tile of HERRO_TILE rows (tiles cover the upper bound lub of every window)
   const uint32_t* tile_r0;   // [n_tiles] first row of the tile
   // ---- scratch / results
-  uint32_t* cpl;         // [ow][3][nw] column planes over the window's positions: query base present / low / high code bit (kept overlaps)
-  uint2* cdir;           // [ow][nw] per word of 32 positions (kept overlaps; k_rfq): {M word, alignment-orientation query index of the first base at or
-                         // behind position 32 * word | insertion events of the overlap in front of that position << 20} (0xffffffff: does not fit)
+  uint4* cw;             // [ow][nw] per word of 32 window positions of a kept overlap, ONE record: {M plane word (a query base is aligned here), low code bit, high
+                         // code bit (complemented for reverse-strand queries), directory word: alignment-orientation query index of the first base at or
+                         // behind position 32 * word | insertion events of the overlap in front of that position << 20 (0xffffffff: does not fit)}
   uint4* iev;            // per overlap (at scr_off): insertion events {pos | trimmed len << 16, query index, first 16 bases, untrimmed len}
   uint32_t* ins_cnt;     // [ow] number of insertion events
   uint4* ocol;           // [ow] {window position where the overlap starts, target bases covered, kept, ratio class}

@@ -669,9 +669,16 @@ def strong_leg(args, rank: int, world: int, local: int, n_windows: int, n_ctx: i
     from herro_amd import api, model_io, synth
     W, n_ovl, wpt = 4096, 32, 4
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    n_t = max(world, n_windows // wpt)
+    n_t = max(world, -(-n_windows // wpt))
+    # the fixed job at BASELINE's size (configs[3]: 100 000 windows) without minutes of generator time and ~30 GB of host memory: at most
+    # `base_cap` targets are GENERATED, the set is the needed number of copies of them — every copy a target read of its own (own id, own
+    # windows, own FASTA record), the 32 query reads shared (synth.replicate_targets).  The GPU does the work of every window of every copy.
+    base_cap = int(getattr(args, "strong_base_targets", 4200) or 4200)
+    copies = max(1, -(-n_t // base_cap))
+    n_base = -(-n_t // copies)
+    n_t = n_base * copies
     path = model_path or model_io.default_model_file(os.path.join(root, "tests", "_cache"))[0]
-    sb = synth.generate_parallel(n_t, wpt * W, n_ovl, seed=synth.SEED + 3) if rank == 0 else None
+    sb = synth.replicate_targets(synth.generate_parallel(n_base, wpt * W, n_ovl, seed=synth.SEED + 3), copies) if rank == 0 else None
     seq, qual, off = broadcast_reads(sb) if world > 1 else (sb.seq, sb.qual, sb.off)
     if n_ctx is None:
         # feeder contexts per GPU: what the end_to_end leg of bench.py measured best on one GPU (four -> six feeders: +19 %, eight: slower again,
@@ -741,7 +748,32 @@ def strong_leg(args, rank: int, world: int, local: int, n_windows: int, n_ctx: i
         return None
     rids, ends, text = rec
     n_rec = int(np.count_nonzero(np.asarray(text) == ord(">")))
-    return {"windows_per_s": n_t * wpt / el, "windows": n_t * wpt, "seconds": el, "ranks_seen": seen, "contexts_per_gpu": len(ctxs),
+    # size-independent properties of the gathered records: one record per target (every synthetic target has >= 2 alignments in every
+    # window), every copy of a target corrected to the same bases as the original (the copies were computed independently, on whatever
+    # rank owned them), nothing but ACGT in the sequences
+    props = {"one_record_per_target": bool(n_rec == n_t and len(rids) == n_t)}
+    try:
+        tarr = np.asarray(text)
+        order = np.argsort(np.asarray(rids), kind="stable")
+        starts = np.concatenate([[0], np.asarray(ends[:-1], np.int64)])
+        by_rid = {int(rids[i]): (int(starts[i]), int(ends[i])) for i in order}
+
+        def body(rid):
+            a, b = by_rid[rid]
+            rec_ = tarr[a:b].tobytes()
+            return rec_[rec_.index(b"\n") + 1:]
+        sample = list(range(0, n_base, max(1, n_base // 64)))
+        ok_copies, ok_alpha = True, True
+        for t in sample:
+            b0 = body(int(sb.tgt_rid[t]))
+            ok_alpha &= set(b0) <= set(b"ACGT\n")
+            for c in range(1, copies):
+                ok_copies &= body(int(sb.tgt_rid[c * n_base + t])) == b0
+        props.update(copies_agree=bool(ok_copies), acgt_only=bool(ok_alpha), targets_sampled=len(sample))
+    except Exception as e:   # a property that cannot be evaluated is reported, it never takes the measurement down
+        props["error"] = repr(e)
+    return {"windows_per_s": n_t * wpt / el, "windows": n_t * wpt, "targets": n_t, "generated_targets": n_base, "copies_of_each_target": copies,
+            "properties": props, "seconds": el, "ranks_seen": seen, "contexts_per_gpu": len(ctxs),
             "mbases_per_s": (len(text) - 16 * n_rec) / el / 1e6, "fasta_records": n_rec, "fasta_bytes": int(len(text)),
             "ingest": "local" if local_ingest else "rank0",
             "routing_bytes_sent_by_rank0": sent, "routing_bytes_sent_all_ranks": sent_all,

@@ -135,6 +135,43 @@ def merge(batches: list[SynthBatch]) -> SynthBatch:
                       tgt_aln_off=np.concatenate(tgt_offs), tgt_rid=np.concatenate(tgt_rids))
 
 
+def replicate_targets(sb: SynthBatch, copies: int) -> SynthBatch:
+    """`copies` times the targets of `sb` at the cost of one more copy of each TARGET read: copy c > 0 of a target is a new read (its own
+    id, the same bases and qualities) with the same alignments against the same query reads (CIGAR bytes shared).  The windows of every
+    copy are computed on their own — nothing downstream knows they are equal — so a run over the replicated set does the work of `copies` x
+    as many windows; what it saves is generator time (the noise model draws ~16 random numbers per base: 100 000 windows would take minutes
+    to generate) and host memory (32 of a target's 33 reads are shared).  Like real data, where a read overlaps many targets.
+    Targets are ordered copy by copy; corrected records of copy c equal those of copy 0 but for the id (a check the caller can make)."""
+    if copies <= 1:
+        return sb
+    nt, nr = sb.n_targets, sb.n_reads
+    off = sb.off.astype(np.int64)
+    tl = (off[sb.tgt_rid.astype(np.int64) + 1] - off[sb.tgt_rid.astype(np.int64)])
+    extra_len = int(tl.sum())
+    nb = len(sb.seq)
+    seq = np.empty(nb + (copies - 1) * extra_len, np.uint8)
+    qual = np.empty_like(seq)
+    seq[:nb] = sb.seq
+    qual[:nb] = sb.qual
+    tsel = np.concatenate([np.arange(off[r], off[r + 1]) for r in sb.tgt_rid.astype(np.int64)]) if nt else np.zeros(0, np.int64)
+    tseq, tqual = sb.seq[tsel], sb.qual[tsel]
+    for c in range(1, copies):
+        seq[nb + (c - 1) * extra_len: nb + c * extra_len] = tseq
+        qual[nb + (c - 1) * extra_len: nb + c * extra_len] = tqual
+    new_off = np.empty(nr + 1 + (copies - 1) * nt, np.uint64)
+    new_off[:nr + 1] = sb.off
+    ends = np.cumsum(np.tile(tl, copies - 1)) + nb
+    new_off[nr + 1:] = ends.astype(np.uint64)
+    n_aln = len(sb.aln)
+    aln = np.tile(sb.aln, (copies, 1))
+    t_of_aln = np.repeat(np.arange(nt, dtype=np.int64), np.diff(sb.tgt_aln_off.astype(np.int64)))     # target index of every alignment
+    for c in range(1, copies):
+        aln[c * n_aln:(c + 1) * n_aln, 5] = (nr + (c - 1) * nt + t_of_aln).astype(np.uint32)
+    tgt_rid = np.concatenate([sb.tgt_rid] + [np.arange(nr + (c - 1) * nt, nr + c * nt, dtype=np.uint32) for c in range(1, copies)])
+    tao = np.concatenate([sb.tgt_aln_off[:1]] + [sb.tgt_aln_off[1:] + np.uint64(c * n_aln) for c in range(copies)])
+    return SynthBatch(seq=seq, qual=qual, off=new_off, aln=aln, cig_off=np.tile(sb.cig_off, copies), cig=sb.cig, tgt_aln_off=tao, tgt_rid=tgt_rid)
+
+
 def usable_cpus() -> int:
     """CPUs this process may use: hardware threads, the affinity mask and a cgroup CPU quota (a box that shows 256
     threads may grant 16 CPUs of run time per period; starting 256 workers there only buys throttling)."""
