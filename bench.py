@@ -350,6 +350,8 @@ def main():
             c.share_reads(ctxs[0])
             ctxs.append(c)
         prep = api.PreparedAlignments(sb)   # the parsed alignments of the data set, resident on the host (outside the timed region)
+        if os.environ.get("HERRO_ZERO_COPY", "1") not in ("", "0"):
+            prep.register(ctxs[0])          # ... its CIGAR blob pinned once: herro_job_create copies a job's texts up from where they are
 
         def feeder_serial(s_i, ids, timed):
             # one thread per context: create(k+1) on the host while the GPU works on job k
@@ -430,12 +432,14 @@ def main():
             tt = torch.tensor([el2], device="cuda", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el2 = float(tt.item())
+        prep.unregister()
         n_w = n_e2e * G * args.batch
         host_s = sum(s[0] for s in stats)
         e2e = {"windows_per_s": n_w * world / el2, "mbases_per_s": sum(s[1] for s in stats) * world / el2 / 1e6,
                "windows": n_w * world, "usable_cpus": synth.usable_cpus(), "jobs_per_feeder": per, "feeders_per_gpu": NF, "warmup_jobs_per_feeder": n_warm,
                "host_prepare_windows_per_s_per_feeder": n_w / NF / (host_s / NF) if host_s else None,
-               "note": "herro_job_create from host alignments (CIGAR text staged and scanned on the GPU, windows cut on the context's thread pool, "
+               "zero_copy_text": os.environ.get("HERRO_ZERO_COPY", "1") not in ("", "0"),
+               "note": "herro_job_create from host alignments (CIGAR text copied up from the registered blob and scanned on the GPU, windows cut on the context's thread pool, "
                        "one pinned descriptor block, one async H2D) + featurize + infer + consensus + D2H of the corrected bases, all inside the timed region; "
                        "fresh inputs per job; the alignments are resident on the host as one parsed array (what the reference's reader thread "
                        "hands over, lib.rs:141-151); " + ("per context one thread builds jobs ahead, one executes them" if args.e2e_mode == "producer"

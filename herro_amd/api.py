@@ -28,7 +28,7 @@ EXPORTS = [
     "herro_oec_read_indexed", "herro_paf_parse_view", "herro_debug_host_ctx", "herro_debug_job_array", "herro_debug_tile_plan", "herro_debug_tile_plan_sib",
     "herro_debug_set_featurize_planes", "herro_debug_job_rf",
     "herro_pool_create", "herro_pool_destroy", "herro_pool_last_error", "herro_pool_size", "herro_pool_ctx", "herro_pool_set_reads", "herro_pool_load_model",
-    "herro_pool_correct", "herro_pool_result", "herro_pool_groups_taken", "herro_pool_skipped", "herro_debug_pool_fake", "herro_job_create_status",
+    "herro_pool_correct", "herro_pool_result", "herro_pool_groups_taken", "herro_pool_skipped", "herro_debug_pool_fake", "herro_job_create_status", "herro_host_register", "herro_host_unregister", "herro_debug_zero_copy_jobs",
     "herro_fastx_read", "herro_reads_count", "herro_reads_seq", "herro_reads_qual", "herro_reads_off", "herro_reads_ids",
     "herro_reads_descs", "herro_reads_free", "herro_write_window_features", "herro_job_write_features",
 ]
@@ -93,6 +93,10 @@ def lib():
         L.herro_debug_pool_fake.restype = vp
         L.herro_debug_pool_fake.argtypes = [u32, vp]
         L.herro_job_create_status.argtypes = [vp]
+        L.herro_host_register.argtypes = [vp, vp, u64]
+        L.herro_host_unregister.argtypes = [vp, vp]
+        L.herro_debug_zero_copy_jobs.restype = u64
+        L.herro_debug_zero_copy_jobs.argtypes = []
         L.herro_load_model.argtypes = [vp, C.c_char_p]
         L.herro_set_precision.argtypes = [vp, i32]
         L.herro_job_create.restype = vp
@@ -354,6 +358,13 @@ class Context:
     def featurize_planes(self, on: bool):
         """test hook: jobs featurized from now on take the planes path (k_tokens) instead of the lean one (k_rows)"""
         self._chk(self._l.herro_debug_set_featurize_planes(self.h, int(on)))
+
+    def register_host(self, arr: np.ndarray):
+        """herro_host_register: jobs whose CIGAR pointers lie in `arr` (a contiguous u8 array the caller keeps alive) are created zero-copy."""
+        self._chk(self._l.herro_host_register(self.h, arr.ctypes.data, arr.nbytes))
+
+    def unregister_host(self, arr: np.ndarray):
+        self._chk(self._l.herro_host_unregister(self.h, arr.ctypes.data))
 
     def describe_model(self) -> str:
         buf = C.create_string_buffer(4096)
@@ -668,6 +679,18 @@ class PreparedAlignments:
             view["f"][:n, :10] = sb.aln[:, :10]
             view["p"][:n] = self._cig.ctypes.data + np.asarray(sb.cig_off, np.uint64)
         self.n_targets = len(self.rids)
+        self._reg = None
+
+    def register(self, ctx: "Context"):
+        """pin the CIGAR blob for zero-copy job creation (herro_host_register); undo with unregister() before the arrays go away"""
+        if self._reg is None and len(self._cig):
+            ctx.register_host(self._cig)
+            self._reg = ctx
+
+    def unregister(self):
+        if self._reg is not None:
+            self._reg.unregister_host(self._cig)
+            self._reg = None
 
     def job(self, ctx: "Context", t0: int, t1: int, window_size: int) -> "Job":
         """herro_job_create over targets [t0, t1): rids / aln_off are passed as offsets into the resident arrays"""

@@ -8,13 +8,13 @@
 namespace herro {
 
 struct CigIn {            // one alignment (32 B)
-  uint64_t txt_off;       // first byte of its text in the staged blob (16-byte aligned, zero padded to 16)
+  uint64_t txt_off;       // 16-byte aligned offset in the text blob of the 16 bytes that hold its first byte (staged texts start there and are zero padded to 16)
   uint32_t len;           // text bytes
   uint32_t tstart;        // target position of the first op
   uint32_t op_off;        // first slot of its ops in the job's op array (room for len / 2 + 1)
   uint32_t cut_off;       // first slot of its cut records
   uint32_t cut_cap;       // room for that many
-  uint32_t pad;
+  uint32_t skip;          // bytes in front of its text inside those 16 (0..15; texts copied up from where the caller has them keep their host alignment)
 };
 
 enum : uint32_t {

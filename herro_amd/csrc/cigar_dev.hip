@@ -79,9 +79,11 @@ __global__ __launch_bounds__(CT) void k_cigar_scan(const uint8_t* __restrict__ t
   const uint8_t* s = txt + a.txt_off;
   uint32_t* o = ops + a.op_off;
   CigCut* cut = cuts + a.cut_off;
-  const uint32_t len = a.len, room = len / 2 + 1;
+  // positions count from the aligned 16 bytes the text starts in: `skip` bytes in front of it belong to whatever lies there in the caller's
+  // buffer (the zero-copy path of herro_job_create copies a range of the caller's memory as it is) and are masked out
+  const uint32_t skip = a.skip & 15u, len = a.len + skip, room = a.len / 2 + 1;
   if (tid == 0) { s_txt[0] = make_uint4(0, 0, 0, 0); s_ncut = 0; s_flags = 0; }
-  uint32_t k_c = 0, t_c = a.tstart, q_c = 0, i_c = 0, prev1_c = 0;   // carries: ops so far, running totals, position + 1 of the last letter
+  uint32_t k_c = 0, t_c = a.tstart, q_c = 0, i_c = 0, prev1_c = skip;   // carries: ops so far, running totals, position + 1 of the last letter (the first op's digits start at `skip`)
   uint32_t flags = 0;
   for (uint32_t base = 0; base < len; base += CHUNK) {
     const uint32_t my = base + tid * CB;
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(CT) void k_cigar_scan(const uint8_t* __restrict__ t
     uint32_t mask = letter_nibble(v.x) | letter_nibble(v.y) << 4 | letter_nibble(v.z) << 8 | letter_nibble(v.w) << 12;
     const uint32_t nvalid = my < len ? min(CB, len - my) : 0u;
     mask &= (1u << nvalid) - 1u;
+    if (my < skip) mask &= ~((1u << (skip - my)) - 1u);   // (thread 0 of the first chunk)
     const uint32_t cnt = __popc(mask);
     const uint32_t last1 = mask ? my + (31u - __clz(mask)) + 1u : 0u;
     // ---- scan 1: position + 1 of the last letter in front of my bytes
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(CT) void k_cigar_scan(const uint8_t* __restrict__ t
       unsigned long long wnext = ((unsigned long long)(t / W) + 1ull) * W;   // first window boundary above my running target position
       uint32_t m = mask, start = prev1;
       uint32_t prev_i = 0;
-      if (prev1 && prev1 + 15u >= base) prev_i = lb(prev1 - 1u) == 'I';   // the op in front of mine (further back than the 16-byte halo: its successor has 16+ digits and is malformed anyway)
+      if (prev1 > skip && prev1 + 15u >= base) prev_i = lb(prev1 - 1u) == 'I';   // the op in front of mine (further back than the 16-byte halo: its successor has 16+ digits and is malformed anyway)
       while (m) {
         const uint32_t p = my + (uint32_t)__ffs(m) - 1u;
         m &= m - 1;

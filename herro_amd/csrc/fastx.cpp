@@ -41,6 +41,7 @@
 #include <unordered_set>
 #include <vector>
 
+#include "host_cpus.h"
 #include "../../include/herro_amd.h"
 
 struct herro_reads {
@@ -342,7 +343,7 @@ uint64_t find_record_start(const MapText& t, uint64_t from, uint64_t limit) {
 
 uint32_t fastx_threads() {
   if (const char* e = getenv("HERRO_FASTX_THREADS")) return (uint32_t)std::max(1, atoi(e));
-  return std::min(std::max(1u, std::thread::hardware_concurrency()), 16u);
+  return herro::host_threads(16);   // HERRO_HOST_THREADS, else the CPUs the process may use (affinity / cgroup quota, not the hardware threads: ADVICE r4)
 }
 
 // The parallel reader of a plain regular file: T byte ranges, one worker each.  A worker guesses the first record of its range
@@ -369,6 +370,10 @@ bool fastx_read_parallel(const char* path, uint64_t file_size, uint32_t T, uint3
   map.fd = ::open(path, O_RDONLY);
   if (map.fd < 0) return false;
   map.n = file_size;
+  // The file is read through a private mapping: a file that is TRUNCATED by another process while it is being read raises SIGBUS (as for
+  // any mmap reader: needletail's buffered reader in the reference would report a short read instead).  Growth and rewrites that keep the
+  // size are caught by the size checks around the two passes; set HERRO_FASTX_THREADS=1 for the sequential (read()-based) reader if the
+  // input may shrink under the process.
   map.p = mmap(nullptr, file_size, PROT_READ, MAP_PRIVATE, map.fd, 0);
   if (map.p == MAP_FAILED) return false;
   (void)madvise(map.p, file_size, MADV_SEQUENTIAL);

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/herro_amd.h"
+#include "host_cpus.h"
 #include "job_dev.h"
 #include "model_dev.h"
 #include "windowing.hpp"
@@ -276,25 +277,6 @@ struct herro_job {
 
 static int job_sync(herro_job* job);
 static int ensure_logits(herro_job* job, uint64_t rows);
-
-// CPUs the process may actually use: the hardware threads, capped by a cgroup CPU quota when there is one (v2 cpu.max,
-// v1 cpu.cfs_quota_us).  A container that shows 256 hardware threads under a 16-CPU quota must not get a 64-thread pool:
-// every woken thread reserves a bandwidth slice on its CPU, the quota is gone a quarter into each 100 ms period and the
-// whole process — GPU completion waits included — stands still for the rest of it (measured: 75 ms stalls, r2n timeline).
-static uint32_t usable_cpus() {
-  uint32_t n = std::max(1u, std::thread::hardware_concurrency());
-  long long quota = -1, period = 0;
-  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-    char q[32] = {0};
-    if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
-    fclose(f);
-  } else {
-    if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
-    if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = 0; fclose(g); }
-  }
-  if (quota > 0 && period > 0) n = std::min<uint32_t>(n, (uint32_t)std::max<long long>(1, (quota + period - 1) / period));
-  return n;
-}
 
 static HostPool& host_pool(herro_ctx* ctx) {
   if (!ctx->pool) {
@@ -774,6 +756,17 @@ static int upload_reads(herro_ctx* ctx, uint32_t n_reads, const std::vector<uint
   ctx->d_p0 = nullptr; ctx->d_p1 = nullptr;
   ctx->d_words = nullptr; ctx->d_word_off = nullptr; ctx->d_qual = nullptr; ctx->d_qual_off = nullptr;
   hipError_t e;
+  // an error part way through (out of memory, a failed copy) must not leak what was allocated so far: until the owner
+  // below takes the six arrays over, this guard frees them and leaves the context without a store
+  struct Partial {
+    herro_ctx* c; bool armed = true;
+    ~Partial() {
+      if (!armed) return;
+      void* p[6] = {(void*)c->d_words, (void*)c->d_word_off, (void*)c->d_qual, (void*)c->d_qual_off, (void*)c->d_p0, (void*)c->d_p1};
+      for (void* q : p) if (q) (void)hipFree(q);
+      c->d_words = nullptr; c->d_word_off = nullptr; c->d_qual = nullptr; c->d_qual_off = nullptr; c->d_p0 = nullptr; c->d_p1 = nullptr;
+    }
+  } partial{ctx};
   std::vector<uint64_t> wp(words);
   wp.push_back(0);  // pad word: get16() may touch one word past a read
   ctx->d_words = dev_alloc_copy(wp, ctx->stream, e); HIP_TRY(ctx, e);
@@ -827,6 +820,7 @@ static int upload_reads(herro_ctx* ctx, uint32_t n_reads, const std::vector<uint
       if (have) (void)hipSetDevice(cur);
       delete o;
     });
+    partial.armed = false;
   }
   return HERRO_OK;
 }
@@ -1413,6 +1407,51 @@ void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* aln
 }
 }  // namespace
 
+// ---- host ranges registered for zero-copy job creation (herro_host_register) -----------------------------------------------------
+// Process-wide: several contexts (feeder threads) create jobs from the same alignment buffer; a range is pinned once and counted.
+namespace {
+struct HostReg { const unsigned char* p; uint64_t n; int refs; };
+std::mutex g_reg_mu;
+std::vector<HostReg> g_regs;
+std::atomic<uint64_t> g_zero_copy_jobs{0};   // jobs whose texts went up straight from a registered range (herro_debug_zero_copy_jobs)
+bool host_range_registered(const unsigned char* lo, const unsigned char* hi) {
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  for (const HostReg& r : g_regs) if (lo >= r.p && hi <= r.p + r.n) return true;
+  return false;
+}
+}  // namespace
+
+int herro_host_register(herro_ctx* ctx, const void* p, uint64_t bytes) {
+  if (!ctx || !p || !bytes) return HERRO_E_INVALID;
+  if (ctx->host_only) return HERRO_OK;
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  for (HostReg& r : g_regs) if (r.p == (const unsigned char*)p && r.n == bytes) { r.refs++; return HERRO_OK; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterPortable));
+  g_regs.push_back(HostReg{(const unsigned char*)p, bytes, 1});
+  return HERRO_OK;
+}
+
+uint64_t herro_debug_zero_copy_jobs(void) { return g_zero_copy_jobs.load(); }
+
+int herro_host_unregister(herro_ctx* ctx, const void* p) {
+  if (!ctx || !p) return HERRO_E_INVALID;
+  if (ctx->host_only) return HERRO_OK;
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  for (size_t i = 0; i < g_regs.size(); i++)
+    if (g_regs[i].p == (const unsigned char*)p) {
+      if (--g_regs[i].refs == 0) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipDeviceSynchronize();   // no copy out of the range may still be in flight
+        (void)hipHostUnregister(const_cast<void*>(p));
+        g_regs.erase(g_regs.begin() + (long)i);
+      }
+      return HERRO_OK;
+    }
+  ctx->err = "herro_host_unregister: not a registered range";
+  return HERRO_E_INVALID;
+}
+
 // ---- job -------------------------------------------------------------------------------------------
 herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* rids, const uint64_t* aln_off,
                             const herro_alignment* alns, uint32_t W) {
@@ -1455,7 +1494,8 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
     if (nA > 0x7fffffffull) return fail(HERRO_E_UNSUPPORTED, "job too large (alignments)");
     auto up256 = [](uint64_t x) { return (x + 255) & ~uint64_t(255); };
     std::vector<CigIn> in(nA);
-    uint64_t txt = 0, opn = 0, cutn = 0;
+    uint64_t txt = 0, opn = 0, cutn = 0, txt_sum = 0;
+    const unsigned char *t_lo = nullptr, *t_hi = nullptr;   // the range of the caller's memory that holds the job's texts
     for (uint64_t g = 0; g < nA; g++) {
       const herro_alignment& al = alns[a0 + g];
       if (al.cigar_len && !al.cigar) return fail(HERRO_E_INVALID, "alignment without cigar");
@@ -1464,8 +1504,31 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
       txt += ((uint64_t)al.cigar_len + 15) & ~uint64_t(15);
       opn += (uint64_t)al.cigar_len / 2 + 1;
       cutn += cap;
+      if (al.cigar_len) {
+        txt_sum += al.cigar_len;
+        if (!t_lo || al.cigar < t_lo) t_lo = al.cigar;
+        if (!t_hi || al.cigar + al.cigar_len > t_hi) t_hi = al.cigar + al.cigar_len;
+      }
     }
     if (opn > 0xffffffffull || cutn > 0xffffffffull) return fail(HERRO_E_UNSUPPORTED, "job too large (ops exceed 2^32)");
+    // Zero-copy (round 5): when the texts lie densely inside a range the caller registered (herro_host_register: the PAF text of
+    // herro_paf_parse_view, a CIGAR blob), that range goes up in ONE copy from where it is — no staging pass over the bytes (0.9 of the
+    // 3.4 ms an unloaded herro_job_create of 4096 windows took, and the part that fights the other feeders for memory bandwidth).  A
+    // text keeps its alignment modulo 16: the scan kernel reads aligned 16-byte pieces and skips the bytes in front of the text.
+    static const bool allow_direct = [] { const char* e = getenv("HERRO_ZERO_COPY"); return !e || atoi(e) != 0; }();
+    const uint64_t span = t_lo ? (uint64_t)(t_hi - t_lo) : 0;
+    const bool direct = allow_direct && t_lo && span <= txt_sum + txt_sum / 2 + 65536 && host_range_registered(t_lo, t_hi);
+    const uint64_t lead = direct ? ((uintptr_t)t_lo & 15u) : 0;
+    if (direct) {
+      for (uint64_t g = 0; g < nA; g++) {
+        const herro_alignment& al = alns[a0 + g];
+        const uint64_t off = al.cigar_len ? lead + (uint64_t)(al.cigar - t_lo) : 0;
+        in[g].txt_off = off & ~uint64_t(15);
+        in[g].skip = (uint32_t)(off & 15u);
+      }
+      txt = (lead + span + 31) & ~uint64_t(15);
+      g_zero_copy_jobs++;
+    }
     const uint64_t o_in = up256(txt + 16), o_out = o_in + up256(nA * sizeof(CigIn)), o_cut = o_out + up256(nA * sizeof(CigOut));
     const uint64_t blk_bytes = o_cut + cutn * sizeof(CigCut), ops_bytes = up256(opn * 4);
     stage = arena_acquire(ctx, ctx->free_stage, blk_bytes, 0);
@@ -1474,7 +1537,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
     unsigned char* hs = (unsigned char*)stage.p;
     unsigned char* dsb = (unsigned char*)job->scan.p + ops_bytes;
     const uint32_t per = 32, nblk = (uint32_t)((nA + per - 1) / per);
-    hpool.run(nblk, [&](uint32_t b) {
+    if (!direct) hpool.run(nblk, [&](uint32_t b) {
       for (uint64_t g = (uint64_t)b * per; g < std::min<uint64_t>(nA, (uint64_t)(b + 1) * per); g++) {
         const herro_alignment& al = alns[a0 + g];
         unsigned char* d = hs + in[g].txt_off;
@@ -1487,7 +1550,13 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
     hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};   // HERRO_HOST_PROFILE: copy up / kernel / copy down on the device clock
     if (prof) for (auto& ev : pe) (void)hipEventCreate(&ev);
     if (pe[0]) (void)hipEventRecord(pe[0], ctx->prep_stream);
-    hipError_t e = hipMemcpyAsync(dsb, hs, o_in + nA * sizeof(CigIn), hipMemcpyHostToDevice, ctx->prep_stream);
+    hipError_t e;
+    if (direct) {   // the texts from the caller's registered range (same alignment modulo 16), the alignment records from the staging block
+      e = hipMemcpyAsync(dsb + lead, t_lo, span, hipMemcpyHostToDevice, ctx->prep_stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(dsb + o_in, hs + o_in, nA * sizeof(CigIn), hipMemcpyHostToDevice, ctx->prep_stream);
+    } else {
+      e = hipMemcpyAsync(dsb, hs, o_in + nA * sizeof(CigIn), hipMemcpyHostToDevice, ctx->prep_stream);
+    }
     if (pe[1]) (void)hipEventRecord(pe[1], ctx->prep_stream);
     if (e == hipSuccess) {
       launch_cigar_scan(dsb, (const CigIn*)(dsb + o_in), (CigOut*)(dsb + o_out), (CigCut*)(dsb + o_cut), (uint32_t*)job->scan.p, (uint32_t)nA, W, ctx->prep_stream);

@@ -36,6 +36,7 @@
 #include <unordered_set>
 #include <vector>
 
+#include "host_cpus.h"
 #include "../../include/herro_amd.h"
 
 namespace {
@@ -166,8 +167,7 @@ herro_paf* parse_owned(const char* src, size_t src_len, std::string&& owned, siz
   const char* base = src ? (borrow ? src : out->buf.get()) : out->text.data();
   char* wbase = (src && !borrow) ? out->buf.get() : nullptr;   // where the caller's bytes are copied to, if they are
 
-  const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
-  const uint32_t want = n_threads > 0 ? (uint32_t)n_threads : std::min(hw, 32u);
+  const uint32_t want = n_threads > 0 ? (uint32_t)n_threads : herro::host_threads(32);   // the CPUs the process may use, not the hardware threads
   auto run = [&](uint32_t nthr, const std::function<void(uint32_t)>& f) {
     if (nthr <= 1) { f(0); return; }
     std::vector<std::thread> th;

@@ -714,6 +714,14 @@ def strong_leg(args, rank: int, world: int, local: int, n_windows: int, n_ctx: i
         else:
             share = _Share(*unpack_work(scatter_bytes(None, None)))
 
+    reg_blob = None
+    if local_ingest and world == 1 and os.environ.get("HERRO_ZERO_COPY", "1") not in ("", "0") and len(share.cig):
+        reg_blob = np.ascontiguousarray(share.cig, np.uint8)     # on one rank nothing is routed: the corrector sees the share's own blob — pinned once, jobs are created zero-copy
+        if reg_blob is share.cig:
+            ctxs[0].register_host(reg_blob)
+        else:
+            reg_blob = None
+
     def sync():
         if world > 1:
             dist.barrier()
@@ -742,6 +750,8 @@ def strong_leg(args, rank: int, world: int, local: int, n_windows: int, n_ctx: i
         one = torch.tensor([1, int(sent or 0)], device="cuda", dtype=torch.int64)
         dist.all_reduce(one)
         seen, sent_all = int(one[0].item()), int(one[1].item())
+    if reg_blob is not None:
+        ctxs[0].unregister_host(reg_blob)
     for c in ctxs:
         c.close()
     if rank != 0:

@@ -139,6 +139,15 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
                             const uint64_t* aln_off, const herro_alignment* alns,
                             uint32_t window_size);
 void herro_job_free(herro_job* job);
+/* Zero-copy job creation.  herro_job_create has to get the CIGAR text of a job's alignments to the GPU; by default it gathers the texts
+ * into a pinned staging block first.  A caller whose alignments' `cigar` pointers lie in ONE buffer — the PAF text behind
+ * herro_paf_parse_view, a blob of CIGARs — registers that buffer once (it is pinned for the GPU, hipHostRegister): jobs whose texts lie
+ * densely inside a registered range are then copied up straight from it, one copy, no pass over the bytes on the host.  Process-wide
+ * and counted: several contexts may register the same range; unregister before the memory is freed.  (The reference has no counterpart:
+ * its feature threads walk the CIGARs where the parser left them, features.rs:337-361.) */
+int herro_host_register(herro_ctx* ctx, const void* p, uint64_t bytes);
+int herro_host_unregister(herro_ctx* ctx, const void* p);
+uint64_t herro_debug_zero_copy_jobs(void); /* test hook: jobs of this process created through the zero-copy path so far */
 /* The HERRO_E_* code behind the last herro_job_create of this context that returned NULL (HERRO_OK after a successful one):
  * UNSUPPORTED / INVALID / STATE / NO_DEVICE / REFERENCE_PANIC — herro_last_error has the text. */
 int herro_job_create_status(const herro_ctx* ctx);

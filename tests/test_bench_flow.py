@@ -91,6 +91,8 @@ def test_bench_flow(monkeypatch, capsys, argv, steps, strong_mode):
     class FakePrep:
         def __init__(self, sb): pass
         def job(self, ctx, t0, t1, W): return fake_job_from_synth(ctx, None, W, range(t0, t1))
+        def register(self, ctx): pass
+        def unregister(self): pass
     monkeypatch.setattr(api, "PreparedAlignments", FakePrep)
     fake_sb = types.SimpleNamespace(seq=None, qual=None, off=None)
     monkeypatch.setattr(synth, "generate_parallel", lambda *a, **k: fake_sb)

@@ -245,3 +245,38 @@ def test_features_directory_equals_oracle(tmp_path):
             n_files += 1
     assert n_files == 3 * w0
     job.close()
+
+
+def test_zero_copy_job_creation_from_a_registered_blob():
+    """herro_host_register (round 5): a job whose CIGAR texts lie in a registered buffer is created without the staging pass — the
+    range goes up as it is, every text keeps its host alignment modulo 16 and the scan kernel skips the bytes in front of it.
+    The blob is put at an odd address so that no text is 16-byte aligned; features must equal the oracle's as on the staged path."""
+    W = 4096
+    sb = synth.generate(3, 2 * 4096 + 777, 20, seed=91, p_partial=0.3)
+    c = G.ctx()
+    G.load_synth(c, sb)
+    store = O.store_from_synth(sb)
+    blob = np.concatenate([np.full(5, ord("M"), np.uint8), sb.cig, np.full(40, ord("I"), np.uint8)])   # letters in front and behind: they must not leak into a text
+    view = blob[5:5 + len(sb.cig)]
+    before = api.lib().herro_debug_zero_copy_jobs()
+    c.register_host(blob)
+    try:
+        job = c.create_job(sb.tgt_rid, sb.aln, sb.tgt_aln_off, None, W, cig_blob=view, cig_off=sb.cig_off)
+        assert api.lib().herro_debug_zero_copy_jobs() == before + 1
+        job.featurize()
+        assert G.compare_features(job, sb, store, W) > 0
+        job.close()
+        # single targets (texts in the middle of the range), and a job after unregistering takes the staged path again
+        job = c.create_job(sb.tgt_rid[1:2], sb.aln[int(sb.tgt_aln_off[1]):int(sb.tgt_aln_off[2])], sb.tgt_aln_off[1:3] - sb.tgt_aln_off[1], None, W,
+                           cig_blob=view, cig_off=sb.cig_off[int(sb.tgt_aln_off[1]):int(sb.tgt_aln_off[2])])
+        job.featurize()
+        assert G.compare_features(job, sb, store, W, targets=[1]) > 0
+        job.close()
+    finally:
+        c.unregister_host(blob)
+    n = api.lib().herro_debug_zero_copy_jobs()
+    job = c.create_job(sb.tgt_rid, sb.aln, sb.tgt_aln_off, None, W, cig_blob=view, cig_off=sb.cig_off)
+    assert api.lib().herro_debug_zero_copy_jobs() == n
+    job.featurize()
+    assert G.compare_features(job, sb, store, W) > 0
+    job.close()
