@@ -311,7 +311,7 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
           const int32_t pos = off + (int32_t)t - 1;
           uint32_t c0, c1;
           qbits((int32_t)q, c0, c1);
-          const uint32_t codes = spread16(c0) | (spread16(c1) << 1);
+          const uint32_t codes = (c0 & 0xffffu) | (c1 << 16);   // the first 16 bases as two bit planes (low code bits | high code bits << 16): the consumers pick single bases, interleaving here cost ~20 instructions per step
           ev[idx] = make_uint4(((uint32_t)pos & 0xffffu) | (min(e, 0xffffu) << 16), q, codes, min(len, 0xffffu));
         }
         const uint32_t ev_before = n_ev + (uint32_t)__popcll(imask & lt);   // insertion events of the slice in front of this op
@@ -584,11 +584,14 @@ constexpr uint32_t TCAP = 2 * LY_NT;   // tiles per window (8192 positions x 51 
 #define MI(p) ((p) + ((p) >> 4))
 __host__ __device__ inline size_t layout_lds(uint32_t W) { return (size_t)(W + 1 + ((W + 1) >> 4) + 1) * 4; }
 
+// TILES: the inserted-base runs are listed per tile of 1024 rows, a run once for every tile it reaches into (k_tokens works tile by tile);
+// !TILES (the lean path): ONE flat list per window, every run once (k_rows walks them all) — no counting pass, no scan, no second walk.
+template <bool TILES>
 __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
   extern __shared__ __attribute__((aligned(16))) uint32_t ly_smem[];
   uint32_t* s_mi = ly_smem;   // [W+1] max insertion behind every position, then (in place) the row of every position
   __shared__ double s_score[SCAP];
-  __shared__ uint32_t s_sel[32], s_nev[32], s_evoff[32], s_wave[LY_NT / 64], s_maxne;
+  __shared__ uint32_t s_sel[32], s_nev[32], s_evoff[32], s_wave[LY_NT / 64], s_maxne, s_nrun;
   __shared__ uint32_t s_tcnt[TCAP], s_toff[TCAP];   // insertion events per tile of the window, first slot of each tile's list
   const uint32_t w = blockIdx.x, tid = threadIdx.x;
   PROF_BEGIN(J);
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
   const uint32_t n_kept = J.win_nkept[w];
   const uint32_t win_len = wd.win_len;
   if (tid < 32) s_sel[tid] = NONE;
-  if (tid == 0) s_maxne = 0;
+  if (tid == 0) { s_maxne = 0; s_nrun = 0; }
   for (uint32_t t = tid; t < TCAP; t += LY_NT) s_tcnt[t] = 0;
   for (uint32_t p = tid; p <= win_len; p += LY_NT) s_mi[MI(p)] = 0;
   __syncthreads();
@@ -746,6 +749,15 @@ __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
       fn(v[k], hide, (rp + 1u + hide) / ROWCAP, (rp + lenr) / ROWCAP);
     }
   };
+  if constexpr (!TILES) {
+    for (uint32_t b = 0; b < nbatch; b++)
+      each_run(b, [&](const uint4& e, uint32_t hide, uint32_t, uint32_t) {
+        J.tev[wbase + atomicAdd(&s_nrun, 1u)] = make_uint4(e.x, e.y, e.z, lc | (hide << 8) | 0xffff0000u);   // tile field 0xffff: not split by tiles
+      });
+    __syncthreads();
+    if (tid == 0) J.tile_ev[tile0] = make_uint2(0u, s_nrun);   // the window's list: first slot, runs
+    (void)n_t;
+  } else {
   for (uint32_t b = 0; b < nbatch; b++)
     each_run(b, [&](const uint4&, uint32_t, uint32_t t_lo, uint32_t t_hi) {
       for (uint32_t t = t_lo; t <= t_hi && t < TCAP; t++) atomicAdd(&s_tcnt[t], 1u);
@@ -766,6 +778,7 @@ __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
       for (uint32_t t = t_lo; t <= t_hi && t < TCAP; t++)
         J.tev[wbase + atomicAdd(&s_toff[t], 1u)] = make_uint4(e.x, e.y, e.z, lc | (hide << 8) | (t << 16));   // hide <= 50 (a kept overlap has no longer insertion, features.rs:315-324), t < TCAP
     });
+  }
   PROF_MARK(J, 2, 4);
 }
 
@@ -968,7 +981,7 @@ __global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J, uint32_t aux) {
           const uint32_t row = rp + 1u + k;
           if (row < r0 || row >= r1) continue;
           uint32_t code;
-          if (k < 16u) code = (ve[u].z >> (2u * k)) & 3u;
+          if (k < 16u) code = ((ve[u].z >> k) & 1u) | (((ve[u].z >> (16u + k)) & 1u) << 1);
           else {   // long insertion: bases beyond the 16 carried by the event come from the read store
             const int32_t si = s_ct[c].sbase + s_ct[c].sdir * (int32_t)(ve[u].y + k);
             const uint64_t wi = min(s_ct[c].q_woff + ((uint32_t)si >> 5), pmax);
@@ -1140,14 +1153,14 @@ __global__ __launch_bounds__(NT) void k_rows(JobDev J) {
 #pragma unroll
     for (int u = 0; u < RL; u++) rv[u] = rop[min(tid + (uint32_t)u * NT, win_len)];
     uint2 te = make_uint2(0, 0);
-    if (tid == 0 && n_t) te = J.tile_ev[tile0 + n_t - 1];
+    if (tid == 0) te = J.tile_ev[tile0];   // the window's flat run list (k_layout<false>): first slot 0, number of runs
     if (tid < 32) s_ct[tid] = J.ctab[(uint64_t)w * 32 + tid];
 #pragma unroll
     for (int u = 0; u < RL; u++) {
       const uint32_t p = tid + (uint32_t)u * NT;
       if (p <= win_len) s_rop[RI(p)] = rv[u];
     }
-    if (tid == 0) s_nruns = te.x + te.y;   // the tiles' run lists lie back to back (k_layout)
+    if (tid == 0) s_nruns = te.x + te.y;
   }
   __syncthreads();
   PROF_MARK(J, 6, 0);
@@ -1265,8 +1278,8 @@ __global__ __launch_bounds__(NT) void k_rows(JobDev J) {
       for (int u = 0; u < EU; u++) {
         const uint32_t e = e0 + u * NT;
         if (e >= n_runs) continue;
-        const uint32_t lo = ve[u].w >> 16;
-        const uint32_t tr0 = lo * ROWCAP, tr1 = min(tr0 + ROWCAP, Lf);
+        const uint32_t lo = ve[u].w >> 16;   // 0xffff: a run of the flat list (all its rows); else the tile that lists it takes the rows inside it
+        const uint32_t tr0 = lo == 0xffffu ? 0u : lo * ROWCAP, tr1 = lo == 0xffffu ? Lf : min(tr0 + ROWCAP, Lf);
         const uint32_t c = ve[u].w & 0xffu, hide = (ve[u].w >> 8) & 0xffu;
         const uint32_t p = ve[u].x & 0xffffu, len = ve[u].x >> 16;
         if (p >= win_len) continue;
@@ -1278,7 +1291,7 @@ __global__ __launch_bounds__(NT) void k_rows(JobDev J) {
           const uint32_t ir = row - p - 1u - ch0;
           if (ir >= RW_ICAP) continue;
           uint32_t code;
-          if (k < 16u) code = (ve[u].z >> (2u * k)) & 3u;
+          if (k < 16u) code = ((ve[u].z >> k) & 1u) | (((ve[u].z >> (16u + k)) & 1u) << 1);
           else {   // long insertion: bases beyond the 16 carried by the event come from the read store
             const int32_t si = s_ct[c].sbase + s_ct[c].sdir * (int32_t)(ve[u].y + k);
             const uint64_t wi = min(s_ct[c].q_woff + ((uint32_t)si >> 5), pmax);
@@ -1746,7 +1759,7 @@ __global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const ui
             for (uint32_t i = e;;) {
               if ((x.x >> 16) >= j) {   // the LAST insertion at p that is long enough wrote this row
                 qi = x.y + j - 1u;
-                code = j <= 16u ? (x.z >> (2u * (j - 1u))) & 3u : 4u;
+                code = j <= 16u ? (((x.z >> (j - 1u)) & 1u) | (((x.z >> (15u + j)) & 1u) << 1)) : 4u;
               }
               if (++i >= n_ev) break;
               x = ev_at(i);
@@ -2033,6 +2046,9 @@ static void trace_point(const char* name, hipStream_t st) {
 void launch_full_tokens(const JobDev& J, hipStream_t st, KernelTimer* tm) {
   if (!J.n_win || !J.n_tiles) return;
   KT_BEGIN(tm, "tokens", st);
+  // the lean pass listed the inserted-base runs per window; k_tokens wants them per tile: the layout once more, in that mode (same inputs — the
+  // tallies of k_win are still there —, same selection, same rows; only the run lists change shape)
+  hipLaunchKernelGGL(k_layout<true>, dim3(J.n_win), dim3(LY_NT), layout_lds(J.window_size), st, J);
   hipLaunchKernelGGL(k_tokens, dim3(J.n_tiles), dim3(TK_NT), 0, st, J, 0u);
   KT_END(tm, st);
   trace_point("tokens (planes on request)", st);
@@ -2062,7 +2078,8 @@ void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm, bool lea
   KT_END(tm, st);
   trace_point("win", st);
   KT_BEGIN(tm, "layout", st);
-  hipLaunchKernelGGL(k_layout, dim3(J.n_win), dim3(LY_NT), layout_lds(J.window_size), st, J);
+  if (lean) hipLaunchKernelGGL(k_layout<false>, dim3(J.n_win), dim3(LY_NT), layout_lds(J.window_size), st, J);
+  else hipLaunchKernelGGL(k_layout<true>, dim3(J.n_win), dim3(LY_NT), layout_lds(J.window_size), st, J);
   KT_END(tm, st);
   trace_point("layout", st);
   if (lean) {
