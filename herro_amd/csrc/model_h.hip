@@ -478,7 +478,13 @@ __global__ __launch_bounds__(512, 4) void k_fc_r(const uint16_t* __restrict__ A,
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem_fc[];
   uint16_t* s_a = reinterpret_cast<uint16_t*>(smem_fc);   // [2][128][64]: row r at r * 128 B, 16-byte chunk c at (c ^ (r & 7))
   const uint32_t nks = W.K >> 5, nms = W.K >> 6;
+  // tiles are taken from the END of the activation: k_conv_m has just written y2 front to back, and what it wrote last is what the
+  // memory-side cache (256 MB) still holds — reading in the writer's order would evict the tail before reaching it (r5)
+#ifdef HERRO_FWD_ORDER   // (A/B build only)
   const uint32_t m0 = blockIdx.x * FR_TM;
+#else
+  const uint32_t m0 = (gridDim.x - 1u - blockIdx.x) * FR_TM;
+#endif
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t fr = lane & 15, fg = lane >> 4;
   f32x4 acc[2 * G][2];

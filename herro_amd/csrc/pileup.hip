@@ -445,7 +445,13 @@ __global__ __launch_bounds__(256) void k_win(JobDev J) {
   __shared__ float s_acc[RKCAP];
   __shared__ uint8_t s_keep[RKCAP];
   __shared__ uint32_t s_nm[32], s_ns;   // first 32 columns: matches at informative positions; informative positions of the window
+  // windows are taken back to front: k_cols has just written the plane records front to back (268 MB per 4096 windows — more than the
+  // 256 MB memory-side cache holds), so the last windows' records are the ones still cached; k_rows then walks front to back again (r5)
+#ifdef HERRO_FWD_ORDER   // (A/B build only)
   const uint32_t w = blockIdx.x, tid = threadIdx.x, NT = blockDim.x, nw = J.nw;
+#else
+  const uint32_t w = gridDim.x - 1u - blockIdx.x, tid = threadIdx.x, NT = blockDim.x, nw = J.nw;
+#endif
   if (tid < 32) s_nm[tid] = 0;
   if (tid == 0) s_ns = 0;
   PROF_BEGIN(J);

@@ -23,7 +23,7 @@ f, w = avg(sys.argv[1], "FETCH_SIZE"), avg(sys.argv[2], "WRITE_SIZE")
 rename = {"k_cols": "cols", "k_win": "win", "k_layout": "layout", "k_tokens": "tokens", "k_supgather": "supgather", "k_rfq": "rf_quals",
           "k_quals": "rf_quals", "k_consensus": "consensus", "k_cigar_scan": "cigar_scan", "k_patch_conv1_s": "patch_conv1", "k_conv_w": "conv_fused",
           "k_gemm_g": "fc_gemm", "k_layers": "layers_fused", "k_gemm_g256": "fc_gemm", "k_add_pe": "add_pe", "k_build_tokens": "build_tokens",
-          "k_conv_h": "conv_fused", "k_conv_m": "conv_fused", "k_fc_h": "fc_gemm", "k_fc_r": "fc_gemm", "k_supoff": "supoff", "k_layers_p": "layers_fused", "k_build_tokens_h": "build_tokens"}
+          "k_conv_h": "conv_fused", "k_conv_m": "conv_fused", "k_fc_h": "fc_gemm", "k_fc_r": "fc_gemm", "k_supoff": "supoff", "k_rows": "rows", "k_consensus_p": "consensus", "k_layers_p": "layers_fused", "k_build_tokens_h": "build_tokens"}
 out = {"group": int(sys.argv[3]), "windows_per_launch": int(sys.argv[3]) * 128, "precision": int(sys.argv[5]) if len(sys.argv) > 5 else 4,
        "unit": "bytes per launch (per_window: the same divided by windows_per_launch — what bench.py scales to its own launch size)", "kernels": {}}
 for k in sorted(set(f) | set(w)):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's closing record from ONE GPU box: (1) rocprofv3 per-kernel stats of the device-resident leg (one stream) + its bench
 # line, (2) HBM traffic per kernel (two separate --pmc passes), (3) MFMA-pipe / wave-cycle counters of the model kernels,
-# (4) the full default bench line, (5) the full line with the driver's arguments.  usage: gpurun --timeout 1500 -- bash tools/round_record.sh r4z
+# (4) the full line with the driver's arguments (end_to_end, strong, cpu_baseline, long_run = the default size).  usage: gpurun --timeout 1500 -- bash tools/round_record.sh r4z
 tag=${1:-rX}
 out=gpurun_out/$tag
 mkdir -p $out
@@ -15,11 +15,12 @@ timeout 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/w -o w -- $cm
 ff=$(find $out/f -name "*counter_collection.csv" | head -1); fw=$(find $out/w -name "*counter_collection.csv" | head -1)
 [ -n "$ff" ] && [ -n "$fw" ] && python tools/pmc_traffic.py "$ff" "$fw" 32 $out/traffic.json 4 > $out/traffic_summary.txt 2>&1
 rm -rf $out/f $out/w
-timeout 150 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $out/m -o m -- $cmd > /dev/null 2> $out/m.err < /dev/null
+timeout 200 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $out/m -o m -- $cmd > /dev/null 2> $out/m.err < /dev/null
 fm=$(find $out/m -name "*counter_collection.csv" | head -1); [ -n "$fm" ] && python tools/pmc_summary.py "$fm" "k_" > $out/pmc_sq_mfma_counters.txt 2>&1; rm -rf $out/m
-timeout 400 python bench.py > $out/bench.json 2> $out/bench.err < /dev/null
-timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_args.json 2>> $out/bench.err < /dev/null
-head -14 $out/kernel_stats.csv 2>/dev/null | cut -c1-140; cat $out/traffic_summary.txt; grep -E "k_layers|k_conv|k_fc" $out/pmc_sq_mfma_counters.txt | cut -c1-330
+# (the full default-size line is left out since round 5: the driver-arguments line carries the default-size figure as long_run; GPU budget)
+: > $out/bench.err
+timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_args.json 2>> $out/bench.err < /dev/null
+head -14 $out/kernel_stats.csv 2>/dev/null | cut -c1-140; cat $out/traffic_summary.txt; grep -E "k_layers|k_conv|k_fc|k_cols|k_rows|k_win|k_rfq|k_layout" $out/pmc_sq_mfma_counters.txt | cut -c1-330
 python - <<PY
 import json,glob
 for f in sorted(glob.glob("$out/bench*.json")):
