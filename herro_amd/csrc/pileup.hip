@@ -1136,24 +1136,31 @@ __device__ __forceinline__ uint32_t vote5(const uint32_t (&c5)[5], uint32_t tb) 
   return (c0 < 2u || (c0 == c1 && (i0 == tb || i1 == tb))) ? tb : i0;
 }
 
-template <int NT>
-__global__ __launch_bounds__(NT) void k_rows(JobDev J) {
+// NW lanes per half (128: windows up to 4096 positions, 256: up to 8192).  The workgroup is TWO halves of NW threads: both stage the rows and
+// walk the run lists; for the symbol counts lane l of half h takes word l of columns 1 + 15 h .. 15 + 15 h (all fifteen records in flight at
+// once), half 1 hands its counters over through LDS and half 0 — one lane per word — goes on alone.  (One half doing everything: 30 columns in
+// three round trips of ten, 33 staging loads and ~10 runs per thread in a row — the kernel is a chain of latencies, not of arithmetic.)
+template <int NW>
+__global__ __launch_bounds__(2 * NW) void k_rows(JobDev J) {
+  constexpr int NT = 2 * NW;
   extern __shared__ __attribute__((aligned(16))) uint32_t rw_smem[];
   uint32_t* s_rop = rw_smem;                                       // [win_len + 1] row of every position, padded (RI)
+  uint32_t* s_mrg = rw_smem + rows_lds(J.window_size) / 4;         // [15][NW] half 1's counters on their way to half 0
   __shared__ __attribute__((aligned(16))) CTab s_ct[32];
   __shared__ uint32_t s_adj[RW_ICAP];                              // per insertion row: inserted A, C, G, T (5 bits each), '*' they replace (bits 20..)
   __shared__ __attribute__((aligned(16))) uint8_t s_iv[RW_ICAP];   // ... its vote | informative << 7
   __shared__ uint32_t s_nruns;
   __shared__ uint32_t s_wave[NT / 64];
   const uint32_t w = blockIdx.x, tid = threadIdx.x, nw = J.nw;
+  const uint32_t half = tid >= (uint32_t)NW ? 1u : 0u, lt = tid - half * NW;   // wave-uniform (NW is a multiple of 64)
   PROF_BEGIN(J);
   const WinDesc wd = J.win[w];
   const uint32_t Lf = J.win_Lf[w], win_len = wd.win_len;
-  const uint32_t tile0 = (uint32_t)wd.col_off, n_t = min((Lf + ROWCAP - 1) / ROWCAP, TCAP);
+  const uint32_t tile0 = (uint32_t)wd.col_off;
   {
     // every load of the prologue in flight at once (a loop of load -> LDS store pairs was 33 round trips in a row: 37 k of the
     // kernel's 106 k cycles in its first version)
-    constexpr int RL = 33;   // NT * RL > HERRO_MAX_WINDOW / (256 / NT) + 1: 128 threads cover windows of 4096, 256 threads 8192
+    constexpr int RL = 17;   // NT * RL >= 16 * 2 NW + 1 positions: 256 threads cover windows of 4096, 512 threads 8192
     uint32_t rv[RL];
     const uint32_t* __restrict__ rop = J.row_of_pos2 + wd.pos_off;
 #pragma unroll
@@ -1171,8 +1178,8 @@ __global__ __launch_bounds__(NT) void k_rows(JobDev J) {
   __syncthreads();
   PROF_MARK(J, 6, 0);
   // ---- 1: symbol counts of the base rows in position space
-  const bool active = tid < nw;
-  const uint32_t widx = min(tid, nw - 1u);
+  const bool active = lt < nw;
+  const uint32_t widx = min(lt, nw - 1u);
   const int32_t P = (int32_t)(widx << 5);
   const uint32_t vm = active ? mask_range(0, (int32_t)win_len - P) : 0u;
   const uint64_t pmax = J.read_n_words + 1;
@@ -1182,17 +1189,17 @@ __global__ __launch_bounds__(NT) void k_rows(JobDev J) {
   uint32_t nin[5];         // exact count of the columns that cover the position (target included)
   const uint32_t tsym[4] = {vm & ~tlo & ~thi, tlo & ~thi, thi & ~tlo, tlo & thi};
 #pragma unroll
-  for (int q = 0; q < 4; q++) { c0[q] = tsym[q]; c1[q] = 0; }
+  for (int q = 0; q < 4; q++) { c0[q] = half ? 0u : tsym[q]; c1[q] = 0; }   // the target column is counted by half 0
   c0[4] = 0; c1[4] = 0;
-  nin[0] = vm; nin[1] = 0; nin[2] = 0; nin[3] = 0; nin[4] = 0;
+  nin[0] = half ? 0u : vm; nin[1] = 0; nin[2] = 0; nin[3] = 0; nin[4] = 0;
   auto sat_add = [&](int q, uint32_t x) {
     const uint32_t a = c0[q], b = c1[q];
     c0[q] = (a ^ x) | (a & b);
     c1[q] = b | (a & x);
   };
-  constexpr int UB = 10;   // columns whose plane words are in flight together (15: measured no faster)
-#pragma unroll 1
-  for (uint32_t cb = 1; cb < HERRO_ROWS; cb += UB) {
+  {
+    constexpr int UB = 15;   // this half's columns: all their records in flight together
+    const uint32_t cb = 1u + UB * half;
     uint32_t M[UB], L[UB], H[UB];
 #pragma unroll
     for (int u = 0; u < UB; u++) {
@@ -1216,6 +1223,29 @@ __global__ __launch_bounds__(NT) void k_rows(JobDev J) {
       for (int b = 0; b < 5; b++) { const uint32_t cy = nin[b] & x; nin[b] ^= x; x = cy; }
     }
   }
+  // half 1's counters join half 0's: saturating sums of the 2-bit counters, a 5-bit ripple add of the cover counts
+  if (half) {
+#pragma unroll
+    for (int q = 0; q < 5; q++) { s_mrg[(q) * NW + lt] = c0[q]; s_mrg[(5 + q) * NW + lt] = c1[q]; s_mrg[(10 + q) * NW + lt] = nin[q]; }
+  }
+  __syncthreads();
+  if (!half) {
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+      const uint32_t a0 = c0[q], a1 = c1[q], b0 = s_mrg[q * NW + lt], b1 = s_mrg[(5 + q) * NW + lt];
+      const uint32_t s0 = a0 ^ b0, k0 = a0 & b0, s1 = a1 ^ b1 ^ k0, k1 = (a1 & b1) | (k0 & (a1 ^ b1));   // k1: the sum is 4 or more
+      c0[q] = s0 | k1;
+      c1[q] = s1 | k1;
+    }
+    uint32_t cy = 0;
+#pragma unroll
+    for (int b = 0; b < 5; b++) {
+      const uint32_t x = nin[b], y = s_mrg[(10 + b) * NW + lt];
+      nin[b] = x ^ y ^ cy;
+      cy = (x & y) | (cy & (x ^ y));
+    }
+  }
+  const bool lane0 = !half && active;   // the lanes that go on: one per word of the window
   PROF_MARK(J, 6, 1);
   // informative positions (features.rs:681-722 on the final 31 columns: thresh = (31 * 0.1) as usize = 3) and the votes of the others
   uint32_t supb, V0, V1, V2;
@@ -1226,7 +1256,7 @@ __global__ __launch_bounds__(NT) void k_rows(JobDev J) {
     uint32_t one = 0, two = 0;
 #pragma unroll
     for (int q = 0; q < 5; q++) { two |= one & g3[q]; one |= g3[q]; }
-    supb = two & vm;
+    supb = lane0 ? two & vm : 0u;
     uint32_t f[5], sc[5], seen1 = 0, seen2 = 0;   // first / second symbol with exactly two, in A C G T * order
 #pragma unroll
     for (int q = 0; q < 5; q++) {
@@ -1246,13 +1276,13 @@ __global__ __launch_bounds__(NT) void k_rows(JobDev J) {
     for (int q = 0; q < 5; q++) v[q] = (use_g & g3[q]) | (use_f & f[q]) | (q < 4 ? use_t & tsym[q] : 0u);
     V0 = (v[1] | v[3]) & vm; V1 = (v[2] | v[3]) & vm; V2 = v[4] & vm;
   }
-  if (active) {
-    uint32_t* __restrict__ vp = J.vpl + (uint64_t)w * 3 * nw + tid;
+  if (lane0) {
+    uint32_t* __restrict__ vp = J.vpl + (uint64_t)w * 3 * nw + lt;
     vp[0] = V0; vp[nw] = V1; vp[2 * nw] = V2;
   }
   // positions of this lane's word that have insertion rows behind them
   uint32_t insmask = 0;
-  if (active) {
+  if (lane0) {
     uint32_t rprev = s_rop[RI((uint32_t)P)];
 #pragma unroll 4
     for (uint32_t k = 0; k < 32; k++) {
@@ -1275,7 +1305,7 @@ __global__ __launch_bounds__(NT) void k_rows(JobDev J) {
     // inserted bases of the selected columns (features.rs:213-229), from the tiles' run lists: a run that crosses a tile boundary is
     // listed by both tiles, each takes its own rows (the tile travels with the record); "hidden" rows were overwritten by a later
     // insertion at the same position
-    constexpr int EU = 8;   // ~10 runs per thread at the bench workload: two round trips
+    constexpr int EU = 6;   // ~5 runs per thread at the bench workload: one round trip
     for (uint32_t e0 = tid; e0 < n_runs; e0 += EU * NT) {
       uint4 ve[EU];
 #pragma unroll
@@ -1892,7 +1922,7 @@ __global__ __launch_bounds__(NT) void k_consensus_p(JobDev J, const uint64_t* su
   uint8_t* __restrict__ giv = J.cons_tmp + wd.row_off;
   {
     // all loads of the prologue in flight together (rows of the positions, vote planes, insertion-row votes)
-    constexpr int RL = 33;
+    constexpr int RL = 17;   // NT = twice the plane words: 256 threads x 17 cover 4097 positions, 512 x 17 cover 8193
     uint32_t rv[RL];
     const uint32_t* __restrict__ rop = J.row_of_pos2 + wd.pos_off;
 #pragma unroll
@@ -1995,8 +2025,8 @@ void launch_consensus(const JobDev& J, const uint64_t* sup_off, const float* bas
   if (!J.n_win) return;
   KT_BEGIN(tm, "consensus", st);
   if (!lean) hipLaunchKernelGGL(k_consensus, dim3(J.n_win), dim3(PC_NT), 0, st, J, sup_off, base_logits);
-  else if (J.nw <= 128) hipLaunchKernelGGL(k_consensus_p<128>, dim3(J.n_win), dim3(128), rows_lds(J.window_size), st, J, sup_off, base_logits);
-  else hipLaunchKernelGGL(k_consensus_p<256>, dim3(J.n_win), dim3(256), rows_lds(J.window_size), st, J, sup_off, base_logits);
+  else if (J.nw <= 128) hipLaunchKernelGGL(k_consensus_p<256>, dim3(J.n_win), dim3(256), rows_lds(J.window_size), st, J, sup_off, base_logits);   // twice the plane words: the extra threads halve the staging and the patches
+  else hipLaunchKernelGGL(k_consensus_p<512>, dim3(J.n_win), dim3(512), rows_lds(J.window_size), st, J, sup_off, base_logits);
   KT_END(tm, st);
 }
 
@@ -2091,11 +2121,11 @@ void launch_featurize(const JobDev& J, hipStream_t st, KernelTimer* tm, bool lea
   if (lean) {
     KT_BEGIN(tm, "rows", st);
     if (J.nw <= 128) {
-      pileup_opt_in_lds(reinterpret_cast<const void*>(k_rows<128>), 64 * 1024);
-      hipLaunchKernelGGL(k_rows<128>, dim3(J.n_win), dim3(128), rows_lds(J.window_size), st, J);
+      pileup_opt_in_lds(reinterpret_cast<const void*>(k_rows<128>), 96 * 1024);
+      hipLaunchKernelGGL(k_rows<128>, dim3(J.n_win), dim3(256), rows_lds(J.window_size) + (size_t)15 * 128 * 4, st, J);
     } else {
-      pileup_opt_in_lds(reinterpret_cast<const void*>(k_rows<256>), 64 * 1024);
-      hipLaunchKernelGGL(k_rows<256>, dim3(J.n_win), dim3(256), rows_lds(J.window_size), st, J);
+      pileup_opt_in_lds(reinterpret_cast<const void*>(k_rows<256>), 96 * 1024);
+      hipLaunchKernelGGL(k_rows<256>, dim3(J.n_win), dim3(512), rows_lds(J.window_size) + (size_t)15 * 256 * 4, st, J);
     }
     KT_END(tm, st);
     trace_point("rows", st);
