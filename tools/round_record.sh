@@ -6,6 +6,7 @@ tag=${1:-rX}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
+( time timeout 900 python -m pytest tests -q -m gpu 2>&1 | grep -v Warning | tail -12 ) > $out/gpu_tests.log 2>&1; tail -6 $out/gpu_tests.log
 q="--no-cpu-baseline --self-check 0 --e2e-jobs 0 --strong-windows 0 --long-run-steps 0"
 timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o $tag -- python bench.py $q --streams 1 --repeats 0 > $out/bench_streams1.json 2> $out/prof.err < /dev/null
 f=$(find $out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $out/kernel_stats.csv; rm -rf $out/prof
