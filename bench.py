@@ -582,7 +582,11 @@ def main():
             "roofline_featurize_group": {
                 "kernels": feat_names, "path": "lean (no token planes)" if lean else "planes", "bound": "hbm", "achieved": feat_bytes / G / (feat_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": feat_bytes / G / (feat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_step": feat_bytes / G, "ms_per_step": feat_ms},
+                "algorithmic_bytes_per_step": feat_bytes / G, "ms_per_step": feat_ms,
+                # the same time against what a design that writes the token planes has to move (rounds 3-4: 2-bit bases + ops in, planes + receptive
+                # fields out): the lean path does not move those bytes — it removed them — so its own fraction above is the smaller number
+                "planes_path_equivalent": {"algorithmic_bytes_per_step": (per_job["read_bytes"] / 5.0 + per_job["op_bytes"] + plane_bytes + tokens * 5 * 31 * 2.0) / G,
+                                           "frac": (per_job["read_bytes"] / 5.0 + per_job["op_bytes"] + plane_bytes + tokens * 5 * 31 * 2.0) / G / (feat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
             "roofline_next_kernels": roof_next, "repeat_ms_per_step": [r * 1e3 / args.steps for r in repeats], "stage_ms_per_step": {"featurize": feat_ms, "model": model_ms},
             "end_to_end": e2e,
             "self_check": check,

@@ -189,6 +189,7 @@ struct herro_ctx {
   std::vector<Arena> free_dev, free_pin, free_small;   // free_small: the buffers a job needs only once its counts are known (logits, batch descriptors)
   std::atomic<uint32_t> live_jobs{0};   // herro_job_create may run on another thread than the context's execution calls
   uint64_t reads_gen = 0;   // bumped by herro_set_reads: a job built on an older store refuses to run
+  uint64_t n_featurize = 0, n_infer = 0;   // calls so far: a context that featurizes job after job without ever inferring (the `herro features` path) stops gathering receptive fields ahead of time
   std::atomic<int> create_code{0};   // HERRO_E_* of the last herro_job_create that returned NULL (herro_job_create_status)
 };
 
@@ -1822,7 +1823,9 @@ int herro_job_featurize(herro_job* job) {
   job->rfq_spec = false;
   static const bool early = [] { const char* e = getenv("HERRO_RFQ_EARLY"); return !e || atoi(e) != 0; }();
   const uint32_t rf_half = ctx->has_model ? 2 * (ctx->M.h.kw / 2) : 0;
-  if (early && ctx->has_model && 2 * rf_half + 1 <= 8) {
+  ctx->n_featurize++;
+  const bool features_only = ctx->n_featurize > 4 && ctx->n_infer == 0;   // (feature-only jobs paid for the gather and its buffer)
+  if (early && ctx->has_model && !features_only && 2 * rf_half + 1 <= 8) {
     const uint32_t n = job->J.n_win;
     if (!job->a_supoff_dev.p) job->a_supoff_dev = small_acquire(ctx, ((uint64_t)n + 1) * 8);
     const uint64_t want = job->logit_cap > 1 ? job->logit_cap : (uint64_t)n * 24;   // ~15 informative rows per window at the bench workload
@@ -1881,6 +1884,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   herro_ctx* ctx = job->ctx;
   if (!ctx->has_model) { ctx->err = "no model loaded"; return HERRO_E_NO_MODEL; }
   ProfSpan span_(ctx, "infer");
+  ctx->n_infer++;
   int rc = job_sync(job);
   if (rc) return rc;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
