@@ -2548,6 +2548,48 @@ herro_ctx* herro_debug_host_ctx(uint32_t n_reads, const uint32_t* read_len, cons
   return ctx;
 }
 
+// Host-only test hook: the position-space rules of k_rows (pileup_core.h: sat2_add, sat2_merge, base_row_votes) on n count vectors.
+// counts[i][5] = occurrences of A C G T * on a base row (the target's own base included), target[i] = the target's base 0..3; the
+// counts are fed column by column into the saturating bit-sliced counters — split[i][5] of them into a second set that is merged in,
+// as the two halves of k_rows' workgroup do — and the planes are read back: sup[i] = informative, vote[i] = the decoder's call 0..4.
+int herro_debug_base_row_votes(const uint8_t* counts, const uint8_t* split, const uint8_t* target, uint32_t n, uint8_t* sup, uint8_t* vote) {
+  if (!counts || !target || !sup || !vote) return HERRO_E_INVALID;
+  for (uint32_t g0 = 0; g0 < n; g0 += 32) {
+    const uint32_t m = std::min(32u, n - g0);
+    uint32_t a0[5] = {0, 0, 0, 0, 0}, a1[5] = {0, 0, 0, 0, 0}, b0[5] = {0, 0, 0, 0, 0}, b1[5] = {0, 0, 0, 0, 0}, tsym[4] = {0, 0, 0, 0};
+    const uint32_t vm = m == 32 ? 0xffffffffu : ((1u << m) - 1u);
+    for (uint32_t i = 0; i < m; i++) {
+      if (target[g0 + i] > 3) return HERRO_E_INVALID;
+      tsym[target[g0 + i]] |= 1u << i;
+    }
+    for (int q = 0; q < 5; q++)
+      for (uint32_t k = 0; k < 255; k++) {   // column k shows symbol q where the count exceeds k
+        uint32_t xa = 0, xb = 0;
+        for (uint32_t i = 0; i < m; i++) {
+          const uint32_t c = counts[(size_t)(g0 + i) * 5 + q], s = split ? std::min<uint32_t>(split[(size_t)(g0 + i) * 5 + q], c) : 0u;
+          if (k < c - s) xa |= 1u << i;
+          if (k < s) xb |= 1u << i;
+        }
+        if (!xa && !xb) break;
+        sat2_add(a0[q], a1[q], xa);
+        sat2_add(b0[q], b1[q], xb);
+      }
+    for (int q = 0; q < 5; q++) sat2_merge(a0[q], a1[q], b0[q], b1[q]);
+    const RowVotes r = base_row_votes(a0, a1, tsym, vm);
+    for (uint32_t i = 0; i < m; i++) {
+      sup[g0 + i] = (uint8_t)((r.sup >> i) & 1u);
+      vote[g0 + i] = (uint8_t)(((r.v0 >> i) & 1u) | (((r.v1 >> i) & 1u) << 1) | (((r.v2 >> i) & 1u) << 2));
+    }
+  }
+  return HERRO_OK;
+}
+
+// the decoder's vote on exact counts (insertion rows of k_rows; pileup_core.h vote5)
+uint32_t herro_debug_vote5(const uint32_t* c5, uint32_t tb) {
+  const uint32_t c[5] = {c5[0], c5[1], c5[2], c5[3], c5[4]};
+  return vote5(c, tb);
+}
+
 int herro_debug_set_featurize_planes(herro_ctx* ctx, int on) {
   if (!ctx) return HERRO_E_INVALID;
   ctx->lean = on == 0;

@@ -1122,20 +1122,6 @@ constexpr uint32_t RW_ICAP = 2048;   // insertion rows per pass (accumulators in
 #define RI(p) ((p) + ((p) >> 5))     // lane i walks positions 32 i ..: one pad word per 32 keeps the lanes on different banks
 __host__ __device__ inline size_t rows_lds(uint32_t W) { return (size_t)(W + 2 + ((W + 2) >> 5) + 1) * 4; }
 
-// the decoder's vote on exact counts c5 = A C G T * (consensus.rs:186-200): two most common symbols by a stable descending sort,
-// target tie-break
-__device__ __forceinline__ uint32_t vote5(const uint32_t (&c5)[5], uint32_t tb) {
-  uint32_t c0 = c5[0], i0 = 0;
-#pragma unroll
-  for (uint32_t q = 1; q < 5; q++) if (c5[q] > c0) { c0 = c5[q]; i0 = q; }
-  uint32_t c1 = 0, i1 = 5;
-  bool have = false;
-#pragma unroll
-  for (uint32_t q = 0; q < 5; q++)
-    if (q != i0 && (!have || c5[q] > c1)) { c1 = c5[q]; i1 = q; have = true; }
-  return (c0 < 2u || (c0 == c1 && (i0 == tb || i1 == tb))) ? tb : i0;
-}
-
 // NW lanes per half (128: windows up to 4096 positions, 256: up to 8192).  The workgroup is TWO halves of NW threads: both stage the rows and
 // walk the run lists; for the symbol counts lane l of half h takes word l of columns 1 + 15 h .. 15 + 15 h (all fifteen records in flight at
 // once), half 1 hands its counters over through LDS and half 0 — one lane per word — goes on alone.  (One half doing everything: 30 columns in
@@ -1192,11 +1178,7 @@ __global__ __launch_bounds__(2 * NW) void k_rows(JobDev J) {
   for (int q = 0; q < 4; q++) { c0[q] = half ? 0u : tsym[q]; c1[q] = 0; }   // the target column is counted by half 0
   c0[4] = 0; c1[4] = 0;
   nin[0] = half ? 0u : vm; nin[1] = 0; nin[2] = 0; nin[3] = 0; nin[4] = 0;
-  auto sat_add = [&](int q, uint32_t x) {
-    const uint32_t a = c0[q], b = c1[q];
-    c0[q] = (a ^ x) | (a & b);
-    c1[q] = b | (a & x);
-  };
+  auto sat_add = [&](int q, uint32_t x) { sat2_add(c0[q], c1[q], x); };
   {
     constexpr int UB = 15;   // this half's columns: all their records in flight together
     const uint32_t cb = 1u + UB * half;
@@ -1231,12 +1213,7 @@ __global__ __launch_bounds__(2 * NW) void k_rows(JobDev J) {
   __syncthreads();
   if (!half) {
 #pragma unroll
-    for (int q = 0; q < 5; q++) {
-      const uint32_t a0 = c0[q], a1 = c1[q], b0 = s_mrg[q * NW + lt], b1 = s_mrg[(5 + q) * NW + lt];
-      const uint32_t s0 = a0 ^ b0, k0 = a0 & b0, s1 = a1 ^ b1 ^ k0, k1 = (a1 & b1) | (k0 & (a1 ^ b1));   // k1: the sum is 4 or more
-      c0[q] = s0 | k1;
-      c1[q] = s1 | k1;
-    }
+    for (int q = 0; q < 5; q++) sat2_merge(c0[q], c1[q], s_mrg[q * NW + lt], s_mrg[(5 + q) * NW + lt]);
     uint32_t cy = 0;
 #pragma unroll
     for (int b = 0; b < 5; b++) {
@@ -1248,34 +1225,9 @@ __global__ __launch_bounds__(2 * NW) void k_rows(JobDev J) {
   const bool lane0 = !half && active;   // the lanes that go on: one per word of the window
   PROF_MARK(J, 6, 1);
   // informative positions (features.rs:681-722 on the final 31 columns: thresh = (31 * 0.1) as usize = 3) and the votes of the others
-  uint32_t supb, V0, V1, V2;
-  {
-    uint32_t g3[5], e2[5];
-#pragma unroll
-    for (int q = 0; q < 5; q++) { g3[q] = c1[q] & c0[q]; e2[q] = c1[q] & ~c0[q]; }
-    uint32_t one = 0, two = 0;
-#pragma unroll
-    for (int q = 0; q < 5; q++) { two |= one & g3[q]; one |= g3[q]; }
-    supb = lane0 ? two & vm : 0u;
-    uint32_t f[5], sc[5], seen1 = 0, seen2 = 0;   // first / second symbol with exactly two, in A C G T * order
-#pragma unroll
-    for (int q = 0; q < 5; q++) {
-      f[q] = e2[q] & ~seen1;
-      sc[q] = e2[q] & seen1 & ~seen2;
-      seen2 |= seen1 & e2[q];
-      seen1 |= e2[q];
-    }
-    uint32_t tb_in = 0;   // the target's base is one of the two (the target column never shows '*' on a base row)
-#pragma unroll
-    for (int q = 0; q < 4; q++) tb_in |= tsym[q] & (f[q] | sc[q]);
-    const uint32_t any3 = one, tie_t = seen2 & tb_in;
-    const uint32_t use_t = supb | (~any3 & (~seen1 | tie_t));   // informative rows: the model decides (k_consensus); a defined code anyway
-    const uint32_t use_g = any3 & ~supb, use_f = ~any3 & seen1 & ~tie_t;
-    uint32_t v[5];
-#pragma unroll
-    for (int q = 0; q < 5; q++) v[q] = (use_g & g3[q]) | (use_f & f[q]) | (q < 4 ? use_t & tsym[q] : 0u);
-    V0 = (v[1] | v[3]) & vm; V1 = (v[2] | v[3]) & vm; V2 = v[4] & vm;
-  }
+  // (the rules and their derivation: base_row_votes, pileup_core.h — shared with the host so that tests/test_vote_planes.py can run them on every count vector)
+  const RowVotes rvt = base_row_votes(c0, c1, tsym, vm);
+  const uint32_t supb = lane0 ? rvt.sup : 0u, V0 = rvt.v0, V1 = rvt.v1, V2 = rvt.v2;
   if (lane0) {
     uint32_t* __restrict__ vp = J.vpl + (uint64_t)w * 3 * nw + lt;
     vp[0] = V0; vp[nw] = V1; vp[2 * nw] = V2;

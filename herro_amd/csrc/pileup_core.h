@@ -130,6 +130,69 @@ HERRO_HD Cell eval_cell(const uint32_t* ops, const uint32_t* op_t, const uint32_
   return c;
 }
 
+// ---- base rows of the final matrix in position space (k_rows, pileup.hip; round 5) ----------------------------------
+// One bit per target position, 32 positions per word.  A symbol's occurrences over the columns are counted in a saturating 2-bit
+// bit-sliced counter (c1 c0 = 0, 1, 2, ">= 3"): enough for the informative-row rule (two symbols reach thresh = (31 * 0.1) as usize = 3,
+// features.rs:558,712) AND for the decoder's vote (consensus.rs:178-200), which is only consulted on rows that are not informative —
+// where at most one symbol reaches 3.  tests/test_vote_planes.py checks both against the reference's rules on every count vector.
+HERRO_HD void sat2_add(uint32_t& c0, uint32_t& c1, uint32_t x) {   // one more column shows the symbol at the positions of x
+  const uint32_t a = c0, b = c1;
+  c0 = (a ^ x) | (a & b);
+  c1 = b | (a & x);
+}
+HERRO_HD void sat2_merge(uint32_t& c0, uint32_t& c1, uint32_t b0, uint32_t b1) {   // the saturating sum of two such counters
+  const uint32_t a0 = c0, a1 = c1;
+  const uint32_t s0 = a0 ^ b0, k0 = a0 & b0, s1 = a1 ^ b1 ^ k0, k1 = (a1 & b1) | (k0 & (a1 ^ b1));   // k1: the sum is 4 or more
+  c0 = s0 | k1;
+  c1 = s1 | k1;
+}
+struct RowVotes { uint32_t sup, v0, v1, v2; };   // informative positions; the others' vote as three bit planes (code 0..4 = A C G T *)
+// c0 / c1: the counters of A C G T * (the target's own base included); tsym: one-hot planes of the target's base; vm: positions inside the window.
+// consensus.rs:186-200 on a row that is not informative: the two most common symbols by a stable descending sort (ties keep A C G T * order);
+// base = (c0 < 2 || (c0 == c1 && (b0 == target || b1 == target))) ? target : b0.  With at most one symbol at >= 3:
+//   a symbol at >= 3 -> it is b0 and c0 > c1: that symbol;  else no symbol at 2 -> c0 < 2: the target;
+//   else b0 = the first symbol at 2; a second symbol at 2 makes c0 == c1 with b1 = that one: the target if it is one of the two, else b0.
+// On informative rows the model decides (k_consensus_p patches its call in); they get the target's code so that every code is defined.
+HERRO_HD RowVotes base_row_votes(const uint32_t (&c0)[5], const uint32_t (&c1)[5], const uint32_t (&tsym)[4], uint32_t vm) {
+  uint32_t g3[5], e2[5];
+#pragma unroll
+  for (int q = 0; q < 5; q++) { g3[q] = c1[q] & c0[q]; e2[q] = c1[q] & ~c0[q]; }
+  uint32_t one = 0, two = 0;
+#pragma unroll
+  for (int q = 0; q < 5; q++) { two |= one & g3[q]; one |= g3[q]; }
+  const uint32_t sup = two & vm;
+  uint32_t f[5], sc[5], seen1 = 0, seen2 = 0;   // first / second symbol with exactly two, in A C G T * order
+#pragma unroll
+  for (int q = 0; q < 5; q++) {
+    f[q] = e2[q] & ~seen1;
+    sc[q] = e2[q] & seen1 & ~seen2;
+    seen2 |= seen1 & e2[q];
+    seen1 |= e2[q];
+  }
+  uint32_t tb_in = 0;   // the target's base is one of the two (the target column never shows '*' on a base row)
+#pragma unroll
+  for (int q = 0; q < 4; q++) tb_in |= tsym[q] & (f[q] | sc[q]);
+  const uint32_t any3 = one, tie_t = seen2 & tb_in;
+  const uint32_t use_t = sup | (~any3 & (~seen1 | tie_t));
+  const uint32_t use_g = any3 & ~sup, use_f = ~any3 & seen1 & ~tie_t;
+  uint32_t v[5];
+#pragma unroll
+  for (int q = 0; q < 5; q++) v[q] = (use_g & g3[q]) | (use_f & f[q]) | (q < 4 ? use_t & tsym[q] : 0u);
+  return RowVotes{sup, (v[1] | v[3]) & vm, (v[2] | v[3]) & vm, v[4] & vm};
+}
+// The decoder's vote on exact counts c5 = A C G T * (insertion rows: the target shows '*', tb = 4)
+HERRO_HD uint32_t vote5(const uint32_t (&c5)[5], uint32_t tb) {
+  uint32_t m0 = c5[0], i0 = 0;
+#pragma unroll
+  for (uint32_t q = 1; q < 5; q++) if (c5[q] > m0) { m0 = c5[q]; i0 = q; }
+  uint32_t m1 = 0, i1 = 5;
+  bool have = false;
+#pragma unroll
+  for (uint32_t q = 0; q < 5; q++)
+    if (q != i0 && (!have || c5[q] > m1)) { m1 = c5[q]; i1 = q; have = true; }
+  return (m0 < 2u || (m0 == m1 && (i0 == tb || i1 == tb))) ? tb : i0;
+}
+
 // 2-bit read store access (haec_io.rs:163-171).
 HERRO_HD uint32_t read_code(const uint64_t* words, uint64_t word_off, uint32_t i) {
   return (uint32_t)((words[word_off + (i >> 5)] >> ((i & 31u) << 1)) & 3ull);

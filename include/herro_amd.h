@@ -251,6 +251,11 @@ int64_t herro_debug_job_array(herro_job* job, int which, const void** ptr, uint3
  * by tests/test_gpu_lean.py.  herro_debug_job_rf copies the 16-byte receptive-field records of window w (after herro_job_infer:
  * n_supported x 31 records, bytes 0..7 tokens / 8..15 qualities of rows sup_row - half .. ) and returns their number (<0: error). */
 int herro_debug_set_featurize_planes(herro_ctx* ctx, int on);
+/* Host-only test hooks for the rules k_rows applies in position space (csrc/pileup_core.h): n count vectors counts[i][5] (A C G T * on a base row, the
+ * target's base included; split[i][5] of them, or NULL, go through a second counter set that is merged in) with target[i] in 0..3 -> sup[i] (informative:
+ * two symbols reach 3, features.rs:558,712) and vote[i] (consensus.rs:178-200; meaningful where sup[i] == 0); herro_debug_vote5: the vote on exact counts. */
+int herro_debug_base_row_votes(const uint8_t* counts, const uint8_t* split, const uint8_t* target, uint32_t n, uint8_t* sup, uint8_t* vote);
+uint32_t herro_debug_vote5(const uint32_t* c5, uint32_t tb);
 int64_t herro_debug_job_rf(herro_job* job, uint32_t w, uint8_t* out, uint64_t cap);
 
 /* Host-only test hook for the token-tile plan of the fused transformer stack (herro_job_infer): n windows of cnt[i]
