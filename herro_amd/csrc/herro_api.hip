@@ -241,6 +241,12 @@ struct herro_job {
   uint32_t host_max_cols = 0, host_n_cls = 0;   // filled for host-only jobs (herro_debug_host_ctx)
   uint64_t host_scr_ops = 0, host_fin_bytes = 0;
   bool quals_full = false;   // the complete quality planes exist (featurize never writes them)
+  bool rf_fused = false;     // ... and k_rows gathered the receptive fields itself (records at win_rfbase, room for rf_fused_cap rows, half width rf_fused_half)
+  uint64_t rf_fused_cap = 0;
+  uint32_t rf_fused_half = 0, rf_total = 0;
+  bool rf_fused_used = false;   // herro_job_infer read the records k_rows gathered (herro_debug_job_rf_fused)
+  std::vector<uint32_t> h_rfbase;
+  std::vector<uint64_t> rf_base;   // per window: first record of its receptive fields in d_rfq (whichever kernel wrote them), valid after herro_job_infer
   bool lean = false;         // the last featurize pass ran the lean path (k_rows): votes in position space, no row map
   bool tokens_full = false;  // the token planes + row map exist (planes path, or launch_full_tokens behind a lean pass)
   // host copies after sync
@@ -1636,7 +1642,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   const size_t o_ops = take(tot.op * 4), o_ow = take(tot.ow * sizeof(OwDesc)), o_win = take(tot.win * sizeof(WinDesc));
   const size_t o_tw = take(tot.tile * 4), o_tr = take(tot.tile * 4);
   const size_t desc_bytes = cur;
-  const size_t o_counts = take(tot.win * 12);   // host arena only: pinned landing zone of the per-window counts
+  const size_t o_counts = take(tot.win * 16 + 16);   // host arena only: pinned landing zone of the per-window counts (L', informative rows, kept overlaps, first receptive-field record) + the records allocated
   const size_t o_hclen = take(tot.win * 4), o_hcseq = take(row_elems);   // ... and of the corrected bases (device consensus)
   const size_t pin_bytes = cur;
   job->pin = arena_acquire(ctx, ctx->free_pin, pin_bytes, 0);
@@ -1706,7 +1712,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   const size_t o_slot = take((uint64_t)n_ow * 4), o_rqid = take((uint64_t)n_ow * 4), o_sel = take((uint64_t)n_win * 32 * 4);
   const size_t o_ctab = take((uint64_t)n_win * 32 * sizeof(CTab)), o_chdr = take((size_t)J.n_tiles * 8), o_tnsup = take((size_t)J.n_tiles * 4);
   const size_t o_tev = take((scr_ops + 2ull * n_ow) * 16), o_tileev = take((size_t)J.n_tiles * 8);
-  const size_t o_dcounts = take((uint64_t)n_win * 12);
+  const size_t o_dcounts = take((uint64_t)n_win * 16 + 16);
   const size_t o_rop = take(pos_elems * 4), o_rmap = take(row_elems * 4);
   const size_t o_cseq = take(row_elems), o_ctmp = take(row_elems), o_clen = take((uint64_t)n_win * 4);
   const size_t o_srow = take(row_elems * 4), o_spi = take(row_elems * 4);
@@ -1731,6 +1737,8 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.tev = (uint4*)(db + o_tev); J.tile_ev = (uint2*)(db + o_tileev);
   job->d_counts = (uint32_t*)(db + o_dcounts);
   J.win_Lf = job->d_counts; J.win_nsup = job->d_counts + n_win; J.win_nkept = job->d_counts + 2ull * n_win;
+  J.win_rfbase = job->d_counts + 3ull * n_win; J.rf_alloc = job->d_counts + 4ull * n_win;
+  J.rf = nullptr; J.rf_cap = 0; J.rf_half = 0;
   J.row_of_pos2 = (uint32_t*)(db + o_rop); J.rowmap2 = (uint32_t*)(db + o_rmap);
   J.cons_seq = (uint8_t*)(db + o_cseq); J.cons_tmp = (uint8_t*)(db + o_ctmp); J.cons_len = (uint32_t*)(db + o_clen);
   J.sup_row = (uint32_t*)(db + o_srow); J.sup_pi = (uint32_t*)(db + o_spi);
@@ -1809,11 +1817,28 @@ int herro_job_featurize(herro_job* job) {
   job->lean = ctx->lean; job->tokens_full = !ctx->lean;
   job->consensus_done = false; job->consensus_on_host = false; job->logits_on_host = false;
   if (job->J.n_win == 0) { job->featurized = true; return HERRO_OK; }
+  ctx->n_featurize++;
+  const bool features_only = ctx->n_featurize > 4 && ctx->n_infer == 0;   // (ADVICE r4: feature-only jobs paid for the gather and its buffer)
+  const uint32_t rf_half = ctx->has_model ? 2 * (ctx->M.h.kw / 2) : 0;
+  // The model's receptive fields are gathered by k_rows itself on the lean path (records placed by one atomic per window), into a buffer sized by the
+  // job's previous pass or by an estimate; if it turns out too small — or a window has more informative rows than k_rows stages — herro_job_infer
+  // gathers with k_rfq instead.  HERRO_RF_FUSED=0: always k_rfq (A/B).
+  static const bool fuse_rf = [] { const char* e = getenv("HERRO_RF_FUSED"); return !e || atoi(e) != 0; }();
+  job->rf_fused = false;
+  job->J.rf = nullptr;
+  if (job->lean && fuse_rf && ctx->has_model && !features_only && rf_half == 2) {
+    const uint64_t want = job->logit_cap > 1 ? job->logit_cap : (uint64_t)job->J.n_win * 24;   // ~15 informative rows per window at the bench workload
+    if (ensure_logits(job, want) == HERRO_OK) {
+      job->J.rf = job->d_rfq; job->J.rf_cap = std::min<uint64_t>(job->logit_cap, 0xfffffff0ull / HERRO_ROWS); job->J.rf_half = rf_half;
+      job->rf_fused = true; job->rf_fused_cap = job->J.rf_cap; job->rf_fused_half = rf_half;
+      HIP_TRY(ctx, hipMemsetAsync(job->J.rf_alloc, 0, 4, ctx->stream));
+    }
+  }
   launch_featurize(job->J, ctx->stream, &ctx->timer, job->lean);
   HIP_TRY(ctx, hipGetLastError());
   // the per-window counts follow the kernels into pinned memory; whoever needs them waits for the event,
   // not for the stream, so the next job's kernels can already be queued behind this one
-  HIP_TRY(ctx, hipMemcpyAsync(job->h_counts, job->d_counts, (uint64_t)job->J.n_win * 12, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(job->h_counts, job->d_counts, (uint64_t)job->J.n_win * 16 + 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(job->ev_counts, ctx->stream));
   job->featurized = true;
   // The model's receptive-field qualities, gathered NOW (k_rfq needs the informative rows and their job-level slots — a device
@@ -1822,10 +1847,7 @@ int herro_job_featurize(herro_job* job) {
   // count turns out larger, herro_job_infer gathers again.  HERRO_RFQ_EARLY=0: gather in herro_job_infer (A/B).
   job->rfq_spec = false;
   static const bool early = [] { const char* e = getenv("HERRO_RFQ_EARLY"); return !e || atoi(e) != 0; }();
-  const uint32_t rf_half = ctx->has_model ? 2 * (ctx->M.h.kw / 2) : 0;
-  ctx->n_featurize++;
-  const bool features_only = ctx->n_featurize > 4 && ctx->n_infer == 0;   // (ADVICE r4: feature-only jobs paid for the gather and its buffer)
-  if (early && ctx->has_model && !features_only && 2 * rf_half + 1 <= 8) {
+  if (early && !job->rf_fused && ctx->has_model && !features_only && 2 * rf_half + 1 <= 8) {
     const uint32_t n = job->J.n_win;
     if (!job->a_supoff_dev.p) job->a_supoff_dev = small_acquire(ctx, ((uint64_t)n + 1) * 8);
     const uint64_t want = job->logit_cap > 1 ? job->logit_cap : (uint64_t)n * 24;   // ~15 informative rows per window at the bench workload
@@ -1851,6 +1873,8 @@ static int job_sync(herro_job* job) {
   job->h_Lf.assign(job->h_counts, job->h_counts + n);
   job->h_nsup.assign(job->h_counts + n, job->h_counts + 2ull * n);
   job->h_nkept.assign(job->h_counts + 2ull * n, job->h_counts + 3ull * n);
+  job->h_rfbase.assign(job->h_counts + 3ull * n, job->h_counts + 4ull * n);
+  job->rf_total = job->h_counts[4ull * n];
   if (ctx->timer.on) {  // per-kernel timing reads its events back: needs the whole stream
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->timer.collect();
@@ -1874,6 +1898,7 @@ static int ensure_logits(herro_job* job, uint64_t rows) {
   job->d_base = (float*)((unsigned char*)job->a_logits.p + o_base);
   job->d_rfq = (uint8_t*)job->a_logits.p + o_rfq;
   job->rfq_spec = false;   // whatever was gathered lived in the old block
+  job->rf_fused = false;
   return HERRO_OK;
 }
 
@@ -1892,6 +1917,13 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   const uint64_t total_sup = job->sup_off[n];
   if (total_sup > 0xffffffffull / HERRO_ROWS) { ctx->err = "job too large (informative rows x 31 exceed 2^32: TokMeta::rf_idx is a 32-bit job-level index)"; return HERRO_E_UNSUPPORTED; }
   if ((rc = ensure_logits(job, total_sup))) return rc;
+  // the receptive fields k_rows gathered behind featurize are usable if every window got its records (none above RW_SUPCAP rows, the buffer was large enough)
+  bool rf_fused_ok = job->rf_fused && job->rf_total == total_sup && total_sup <= job->rf_fused_cap;
+  if (rf_fused_ok)
+    for (uint32_t w = 0; w < n && rf_fused_ok; w++) rf_fused_ok = job->h_nsup[w] == 0 || job->h_rfbase[w] != 0xffffffffu;
+  job->rf_fused_used = rf_fused_ok;
+  job->rf_base.assign(n, 0);
+  for (uint32_t w = 0; w < n; w++) job->rf_base[w] = rf_fused_ok ? (uint64_t)job->h_rfbase[w] : job->sup_off[w];
   // ---- plan batches (prepare_examples, inference.rs:241-250; flush rule features.rs:884-893)
   job->batches.clear();
   auto flush = [&](std::vector<uint32_t>& cur) {
@@ -1945,7 +1977,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
     std::memcpy(blob.data() + o, p, bytes);
     return o;
   };
-  struct Offs { size_t plane_off, plane_ld, len, lmax, tok_off, sup_off, out_off, tiles, tiles_q, tiles_b, grp; uint32_t n_tiles, n_tiles_q, n_tiles_b, n_win, n_tok, max_win_tok; bool tiled; };
+  struct Offs { size_t plane_off, plane_ld, len, lmax, tok_off, sup_off, out_off, rf_base, tiles, tiles_q, tiles_b, grp; uint32_t n_tiles, n_tiles_q, n_tiles_b, n_win, n_tok, max_win_tok; bool tiled; };
   std::vector<Offs> offs;
   uint32_t max_tok = 0, max_tiles_b = 0;
   const bool fused_mode = ctx->precision == 1 || ctx->precision >= 4;
@@ -1953,7 +1985,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   const int qmode = ctx->precision >= 4 ? model_h_half_tiles(ctx->M) : 0;
   for (auto& g : groups) {
     for (int part = 0; part < 2; part++) {  // 0: windows that fit a fused tile (all of them in the unfused modes), 1: the rest
-      std::vector<uint64_t> plane_off, sup_o, out_o;
+      std::vector<uint64_t> plane_off, sup_o, out_o, rfb;
       std::vector<uint32_t> ld, len, lmax, tok_off(1, 0), sel, sel_lmax, sel_cnt;
       for (size_t bi = g.b0; bi < g.b1; bi++) {
         const BatchPlan& bp = job->batches[bi];
@@ -1980,7 +2012,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
         plane_off.push_back(wd.fin_off); ld.push_back(wd.lub); len.push_back(job->h_Lf[w]);
         lmax.push_back(sel_lmax[i]);
         tok_off.push_back(tok_off.back() + job->h_nsup[w]);
-        sup_o.push_back(wd.row_off); out_o.push_back(job->sup_off[w]);
+        sup_o.push_back(wd.row_off); out_o.push_back(job->sup_off[w]); rfb.push_back(job->rf_base[w]);
       }
       Offs o;
       o.n_win = (uint32_t)B; o.n_tok = tok_off.back(); o.tiled = fused_mode && part == 0;
@@ -1988,7 +2020,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
       o.plane_off = put(plane_off.data(), B * 8); o.plane_ld = put(ld.data(), B * 4);
       o.len = put(len.data(), B * 4); o.lmax = put(lmax.data(), B * 4);
       o.tok_off = put(tok_off.data(), (B + 1) * 4);
-      o.sup_off = put(sup_o.data(), B * 8); o.out_off = put(out_o.data(), B * 8);
+      o.sup_off = put(sup_o.data(), B * 8); o.out_off = put(out_o.data(), B * 8); o.rf_base = put(rfb.data(), B * 8);
       o.n_tiles = plan.tiles.empty() ? 0u : (uint32_t)plan.tiles.size() - 1;
       o.tiles = put(plan.tiles.data(), plan.tiles.size() * 4);
       o.n_tiles_q = plan.tiles_q.empty() ? 0u : (uint32_t)plan.tiles_q.size() - 1;
@@ -2018,7 +2050,8 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   // the qualities the model will read: rows within 2 * (kw / 2) of an informative row (two stacked convs)
   const uint32_t rf_half = 2 * (ctx->M.h.kw / 2);
   const bool rf_compact = job->d_rfq && 2 * rf_half + 1 <= 8;   // the model reads the compact receptive fields (tokens + qualities); else the planes
-  const bool rfq_there = job->rfq_spec && rf_compact && job->rfq_spec_half == rf_half && job->rfq_spec_cap >= total_sup;   // gathered behind featurize
+  const bool rfq_there = rf_compact && ((rf_fused_ok && job->rf_fused_half == rf_half) ||   // gathered by k_rows
+                                        (job->rfq_spec && job->rfq_spec_half == rf_half && job->rfq_spec_cap >= total_sup));   // ... by k_rfq behind featurize
   if (!rf_compact && !job->tokens_full && !groups.empty()) {   // a receptive field above 8 rows: token planes + row map first
     launch_full_tokens(job->J, ctx->stream, &ctx->timer);
     job->tokens_full = true;
@@ -2036,6 +2069,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
     B.tok_off = (const uint32_t*)(base + o.tok_off);
     B.sup_off = (const uint64_t*)(base + o.sup_off);
     B.out_off = (const uint64_t*)(base + o.out_off);
+    B.rf_base = (const uint64_t*)(base + o.rf_base);
     B.n_tiles = o.n_tiles;
     B.tile_tok0 = (const uint32_t*)(base + o.tiles);
     B.n_tiles_q = o.n_tiles_q;
@@ -2596,6 +2630,10 @@ int herro_debug_set_featurize_planes(herro_ctx* ctx, int on) {
   return HERRO_OK;
 }
 
+// 1: the last herro_job_infer read the receptive fields k_rows gathered behind featurize; 0: k_rfq gathered them (a window above 256 informative
+// rows, a buffer sized too small by the estimate of a first pass, the planes path, HERRO_RF_FUSED=0)
+int herro_debug_job_rf_fused(const herro_job* job) { return job && job->inferred ? (job->rf_fused_used ? 1 : 0) : HERRO_E_STATE; }
+
 // the receptive-field records the model read for window w (valid once herro_job_infer has run with a compact receptive field)
 int64_t herro_debug_job_rf(herro_job* job, uint32_t w, uint8_t* out, uint64_t cap) {
   if (!job || w >= job->win.size() || !out) return HERRO_E_INVALID;
@@ -2605,7 +2643,7 @@ int64_t herro_debug_job_rf(herro_job* job, uint32_t w, uint8_t* out, uint64_t ca
   if (n * 16 > cap) { ctx->err = "output buffer too small"; return HERRO_E_INVALID; }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (n) HIP_TRY(ctx, hipMemcpy(out, job->d_rfq + job->sup_off[w] * HERRO_ROWS * 16, n * 16, hipMemcpyDeviceToHost));
+  if (n) HIP_TRY(ctx, hipMemcpy(out, job->d_rfq + job->rf_base[w] * HERRO_ROWS * 16, n * 16, hipMemcpyDeviceToHost));
   return (int64_t)n;
 }
 

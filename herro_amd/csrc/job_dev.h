@@ -85,6 +85,13 @@ struct JobDev {
   uint8_t* cons_seq;     // [win.row_off ..] corrected bases of the window (ASCII), cons_len[w] of them
   uint8_t* cons_tmp;     // planes path (k_tokens): [win.row_off + row] per-row call before '*' removal.  Lean path (k_rows): [win.row_off + i], i = index of an
                          // INSERTION row among the window's insertion rows (row - position - 1): its majority vote | informative << 7
+  // lean path, receptive fields gathered by k_rows itself (null rf: not this pass): the job's record buffer and its room in informative rows, the
+  // receptive field's half width (2), the allocation counter (one atomicAdd per window) and the first record slot every window got (0xffffffff: none)
+  uint8_t* rf;
+  uint64_t rf_cap;
+  uint32_t rf_half;
+  uint32_t* rf_alloc;
+  uint32_t* win_rfbase;  // [win]
   uint32_t* vpl;         // lean path: [win][3][nw] majority vote of every target position's base row as three bit planes (code 0..4 = A C G T *)
   uint32_t* cons_len;    // [win]
   unsigned long long* prof;  // HERRO_PROF_BUILD libraries run with HERRO_PROF=1: [kernel * 16 + phase][32 shards] shader cycles, [.. + 15] workgroups (null otherwise)

@@ -66,7 +66,7 @@ __global__ void k_build_tokens(BatchDev B, ModelScratch S) {
     tm.tok_row = row;
     tm.len = B.len[b];
     tm.lmax = B.lmax[b];
-    tm.rf_idx = (uint32_t)(B.out_off[b] + (n - t0));
+    tm.rf_idx = (uint32_t)((B.rf_base ? B.rf_base[b] : B.out_off[b]) + (n - t0));
     tm.pad1 = 0;
     S.tok_meta[n] = tm;
   }
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_patch_conv1(ModelDev M, BatchDev B, Mod
   const uint8_t* pb = B.planes_b + B.plane_off[b];
   const uint8_t* pq = B.planes_q + B.plane_off[b];
   const uint32_t ld = B.plane_ld[b];
-  const uint8_t* rq = (B.rf_q && P <= 8) ? B.rf_q + (B.out_off[b] + (n - B.tok_off[b])) * HERRO_ROWS * 16 : nullptr;   // the token's receptive fields, compact: per read row 8 tokens + 8 qualities (k_rfq)
+  const uint8_t* rq = (B.rf_q && P <= 8) ? B.rf_q + ((B.rf_base ? B.rf_base[b] : B.out_off[b]) + (n - B.tok_off[b])) * HERRO_ROWS * 16 : nullptr;   // the token's receptive fields, compact: per read row 8 tokens + 8 qualities (k_rfq)
 
   for (uint32_t e = threadIdx.x; e < kw * 12 * c1; e += blockDim.x) s_t1[e] = M.t1[e];
   for (uint32_t e = threadIdx.x; e < kw * c1; e += blockDim.x) s_wq[e] = M.wq1[e];
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void k_patch_conv1_s(ModelDev M, BatchDev B, M
     const uint8_t* pb = B.planes_b + B.plane_off[b];
     const uint8_t* pq = B.planes_q + B.plane_off[b];
     const uint32_t ld = B.plane_ld[b];
-    const uint8_t* rq = (B.rf_q && P <= 8) ? B.rf_q + (B.out_off[b] + (n - B.tok_off[b])) * HERRO_ROWS * 16 : nullptr;   // the token's receptive fields, compact: per read row 8 tokens + 8 qualities (k_rfq)
+    const uint8_t* rq = (B.rf_q && P <= 8) ? B.rf_q + ((B.rf_base ? B.rf_base[b] : B.out_off[b]) + (n - B.tok_off[b])) * HERRO_ROWS * 16 : nullptr;   // the token's receptive fields, compact: per read row 8 tokens + 8 qualities (k_rfq)
     __syncthreads();
     for (uint32_t e = threadIdx.x; e < HERRO_ROWS * P; e += blockDim.x) {
       const uint32_t r = e / P;

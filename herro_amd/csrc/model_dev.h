@@ -77,6 +77,7 @@ struct BatchDev {
   const uint32_t* tok_off;    // [B+1] first token of each window
   const uint64_t* sup_off;    // [B] element offset of the window's informative-row list
   const uint64_t* out_off;    // [B] element offset of the window's logits in the job buffers
+  const uint64_t* rf_base;    // [B] first record of the window's receptive fields in rf_q (k_rows places them by an atomic, k_rfq at out_off); null: out_off
   const uint8_t* planes_b;    // token planes (used when rf_q is null: the stand-alone entry, receptive fields above 8 rows)
   const uint8_t* planes_q;    // raw qualities (complete planes; used when rf_q is null)
   const uint8_t* rf_q;        // the receptive fields only, compact (k_rfq): one 16-byte record per (token, read row) at [(out_off[b] + k) * 31 + row]:

@@ -1206,7 +1206,7 @@ __global__ void k_build_tokens_h(BatchDev B, ModelScratch S) {
     tm.tok_row = row;
     tm.len = B.len[b];
     tm.lmax = B.lmax[b];
-    tm.rf_idx = (uint32_t)(B.out_off[b] + (n - t0));
+    tm.rf_idx = (uint32_t)((B.rf_base ? B.rf_base[b] : B.out_off[b]) + (n - t0));
     tm.pad1 = 0;
     S.tok_meta[n] = tm;
     uint32_t mk[2] = {0, 0}, dt[2] = {0, 0}, dq[2] = {0, 0}, ok = 0;

@@ -1122,6 +1122,10 @@ constexpr uint32_t RW_ICAP = 2048;   // insertion rows per pass (accumulators in
 #define RI(p) ((p) + ((p) >> 5))     // lane i walks positions 32 i ..: one pad word per 32 keeps the lanes on different banks
 __host__ __device__ inline size_t rows_lds(uint32_t W) { return (size_t)(W + 2 + ((W + 2) >> 5) + 1) * 4; }
 
+constexpr uint32_t RW_SUPCAP = 256;   // informative rows of a window whose receptive fields k_rows gathers itself (a window with more: k_rfq, for the whole job)
+__device__ __forceinline__ void rf_slot(const JobDev& J, const CTab* __restrict__ s_ct, const WinDesc& wd, uint32_t Lf, uint32_t half, uint32_t c,
+                                        uint32_t srow, uint32_t pj, uint32_t nr, bool have_nr, uint4* __restrict__ out);
+
 // NW lanes per half (128: windows up to 4096 positions, 256: up to 8192).  The workgroup is TWO halves of NW threads: both stage the rows and
 // walk the run lists; for the symbol counts lane l of half h takes word l of columns 1 + 15 h .. 15 + 15 h (all fifteen records in flight at
 // once), half 1 hands its counters over through LDS and half 0 — one lane per word — goes on alone.  (One half doing everything: 30 columns in
@@ -1135,7 +1139,8 @@ __global__ __launch_bounds__(2 * NW) void k_rows(JobDev J) {
   __shared__ __attribute__((aligned(16))) CTab s_ct[32];
   __shared__ uint32_t s_adj[RW_ICAP];                              // per insertion row: inserted A, C, G, T (5 bits each), '*' they replace (bits 20..)
   __shared__ __attribute__((aligned(16))) uint8_t s_iv[RW_ICAP];   // ... its vote | informative << 7
-  __shared__ uint32_t s_nruns;
+  __shared__ uint32_t s_nruns, s_rfbase;
+  __shared__ uint32_t s_sup[3][RW_SUPCAP];                         // row, position | ordinal << 16, neighbours' row counts of the window's informative rows
   __shared__ uint32_t s_wave[NT / 64];
   const uint32_t w = blockIdx.x, tid = threadIdx.x, nw = J.nw;
   const uint32_t half = tid >= (uint32_t)NW ? 1u : 0u, lt = tid - half * NW;   // wave-uniform (NW is a multiple of 64)
@@ -1337,6 +1342,7 @@ __global__ __launch_bounds__(2 * NW) void k_rows(JobDev J) {
       J.sup_row[wd.row_off + kk] = rp;
       J.sup_pi[wd.row_off + kk] = p;
       J.sup_nr[wd.row_off + kk] = nr;
+      if (kk < RW_SUPCAP) { s_sup[0][kk] = rp; s_sup[1][kk] = p; s_sup[2][kk] = nr; }
       kk++;
     }
     if ((insup >> k) & 1u) {
@@ -1348,6 +1354,7 @@ __global__ __launch_bounds__(2 * NW) void k_rows(JobDev J) {
           J.sup_row[wd.row_off + kk] = rp + 1u + j;
           J.sup_pi[wd.row_off + kk] = p | ((j + 1u) << 16);
           J.sup_nr[wd.row_off + kk] = nr;
+          if (kk < RW_SUPCAP) { s_sup[0][kk] = rp + 1u + j; s_sup[1][kk] = p | ((j + 1u) << 16); s_sup[2][kk] = nr; }
           kk++;
         }
       }
@@ -1355,6 +1362,28 @@ __global__ __launch_bounds__(2 * NW) void k_rows(JobDev J) {
   }
   if (tid == 0) J.win_nsup[w] = total;
   PROF_MARK(J, 6, 4);
+  // ---- 4: the model's receptive fields of this window's informative rows (round 5; a kernel of its own before — k_rfq, 150 us per 4096 windows
+  // for ~470 records per window: a launch, the informative rows read back, the plane records gone cold).  The records' place in the job's
+  // buffer comes from one atomic per window (their order across windows is free: the model finds them through the window's base); a
+  // window above RW_SUPCAP rows, or a buffer that turns out too small, leaves the whole job to k_rfq (the host sees both in the counts).
+  if (J.rf) {   // wave-uniform
+    if (tid == 0) {
+      const uint32_t base = atomicAdd(J.rf_alloc, total);
+      const bool ok = total <= RW_SUPCAP && (uint64_t)base + total <= J.rf_cap;
+      s_rfbase = ok ? base : NONE;
+      J.win_rfbase[w] = ok ? base : NONE;
+    }
+    __syncthreads();   // s_sup, s_rfbase
+    const uint32_t base = s_rfbase;
+    if (base != NONE) {
+      const uint32_t nslots = total * HERRO_ROWS;
+      for (uint32_t sl = tid; sl < nslots; sl += NT) {
+        const uint32_t k = sl / HERRO_ROWS, c = sl - k * HERRO_ROWS;
+        rf_slot(J, s_ct, wd, Lf, J.rf_half, c, s_sup[0][k], s_sup[1][k], s_sup[2][k], true, reinterpret_cast<uint4*>(J.rf + ((uint64_t)base * HERRO_ROWS + sl) * 16));
+      }
+    }
+    PROF_MARK(J, 6, 5);
+  }
 }
 
 // =====================================================================================================
@@ -1600,9 +1629,179 @@ constexpr int RQ_NT = 512;   // ~470 slots per window: one per thread — a slot
 // of the positions around it (row_of_pos2) say which cell each of the slot's rows is.  A base cell's code comes from the column's
 // lo / hi planes (two more words per slot), an inserted base's from its event (the first 16 bases travel with it), the target's from
 // the read store.
+// One receptive-field record: the tokens and qualities of the rows srow - half .. around informative row (pj = position | ordinal << 16) in column c.
+// have_nr: nr carries the row counts of the four positions around (k_rows); else the rows come from row_of_pos2.
+__device__ __forceinline__ void rf_slot(const JobDev& J, const CTab* __restrict__ s_ct, const WinDesc& wd, uint32_t Lf, uint32_t half, uint32_t c,
+                                        uint32_t srow, uint32_t pj, uint32_t nr, bool have_nr, uint4* __restrict__ out) {
+  const uint32_t nw = J.nw;
+  const uint32_t span = 2 * half + 1, win_len = wd.win_len;
+  const uint64_t tq_off = s_ct[0].qual_off + wd.tstart;
+  const uint64_t qmax = J.read_qual_bytes ? J.read_qual_bytes - 1 : 0;
+  const uint64_t pmax = J.read_n_words + 1;
+  constexpr uint64_t NONE64 = ~0ull;
+  const uint32_t* __restrict__ rop = J.row_of_pos2 + wd.pos_off;
+  const int32_t pc = (int32_t)(pj & 0xffffu);
+  const int64_t row0 = (int64_t)srow - (int64_t)half;
+  uint32_t rv[8];   // first row of positions pc - half + i
+  if (have_nr && half == 2) {   // lean path: the neighbours' row counts came with the informative row (k_rows) — one round trip less, no row_of_pos2
+    const uint32_t rc = srow - (pj >> 16);                      // row of position pc
+    rv[2] = rc;
+    rv[1] = rc - ((nr >> 6) & 63u);
+    rv[0] = rv[1] - (nr & 63u);
+    rv[3] = rc + ((nr >> 12) & 63u);
+    rv[4] = rv[3] + ((nr >> 18) & 63u);
+    rv[5] = rv[6] = rv[7] = 0;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; i++) rv[i] = rop[(uint32_t)min(max(pc - (int32_t)half + i, 0), (int32_t)win_len)];
+  }
+  uint32_t rm[8];
+#pragma unroll
+  for (int d = 0; d < 8; d++) {
+    const int64_t r = row0 + d;
+    rm[d] = NONE;
+    if ((uint32_t)d < span && r >= 0 && r < (int64_t)Lf) {
+      int32_t pp = 0;
+      uint32_t rb = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int32_t q = pc - (int32_t)half + i;
+        if ((uint32_t)i <= 2 * half && q >= 0 && q < (int32_t)win_len && (int64_t)rv[i] <= r) { pp = q; rb = rv[i]; }
+      }
+      rm[d] = (uint32_t)pp | (((uint32_t)r - rb) << 16);
+    }
+  }
+  uint64_t addr[8];
+  uint32_t tok[8];
+#pragma unroll
+  for (int d = 0; d < 8; d++) { addr[d] = NONE64; tok[d] = TOK_NONE; }
+  const CTab& q = s_ct[c];
+  if (c == 0) {
+    const uint64_t tw = s_ct[0].q_woff;
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+      if (rm[d] == NONE) continue;
+      tok[d] = TOK_GAP_F;   // the target shows '*' on an insertion row
+      if ((rm[d] >> 16) == 0) {
+        const uint32_t tp = wd.tstart + (rm[d] & 0xffffu);
+        const uint64_t wi = min(tw + (tp >> 5), pmax);
+        addr[d] = min(tq_off + (rm[d] & 0xffffu), qmax);
+        tok[d] = ((J.read_p0[wi] >> (tp & 31u)) & 1u) | (((J.read_p1[wi] >> (tp & 31u)) & 1u) << 1);
+      }
+    }
+  } else if (q.ow != NONE) {
+    const uint32_t tbase = q.tokc & 0xffu, tgap = q.tokc >> 8;
+    uint32_t p0 = NONE;   // position of the slot's first row inside the window
+#pragma unroll
+    for (int d = 7; d >= 0; d--) if (rm[d] != NONE) p0 = rm[d] & 0xffffu;
+    if (p0 != NONE) {
+      const uint32_t w0 = min(p0 >> 5, nw - 1u), w1 = min(w0 + 1u, nw - 1u);
+      const uint4* __restrict__ cw = J.cw + (uint64_t)q.ow * nw;
+      const uint4 c0 = cw[w0], c1 = cw[w1];   // planes + directory word of the slot's (at most two) words: one cache line
+      const uint2 d0 = make_uint2(c0.x, c0.w), d1 = make_uint2(c1.x, c1.w);
+      const uint32_t l0 = c0.y, l1 = c1.y, h0 = c0.z, h1 = c1.z;
+      const uint32_t m0 = d0.x, m1 = d1.x;
+      const uint32_t n_ev = q.n_ev;
+      const uint4* __restrict__ iev = J.iev + q.ev_off;
+      uint32_t qw = d0.y & 0xfffffu, e = d0.y >> 20;
+      if (d0.y == 0xffffffffu) {   // indices beyond the record's fields: count (M bits and events in front of the word)
+        qw = 0; e = 0;
+        for (uint32_t i = 0; i < w0; i++) qw += (uint32_t)__popc(cw[i].x);
+        while (e < n_ev && (iev[e].x & 0xffffu) < (w0 << 5)) { qw += iev[e].x >> 16; e++; }
+      }
+      // no insertion event between the two words' first positions and no row beyond: the event list is not needed
+      uint32_t pl = p0;
+      bool ins_row = false;
+#pragma unroll
+      for (int d = 0; d < 8; d++) if (rm[d] != NONE) { pl = rm[d] & 0xffffu; ins_row = ins_row || (rm[d] >> 16) != 0; }
+      const bool quiet = d0.y != 0xffffffffu && d1.y != 0xffffffffu && w1 != w0 && (d1.y >> 20) == e && (pl >> 5) == w0 && !ins_row;
+      // the next four events travel together (one round trip for nearly every slot; a fifth is fetched when the walk gets there)
+      const uint32_t e_first = e;
+      const uint4 none4 = make_uint4(0xffffffffu, 0, 0, 0);
+      // (loads unconditional with clamped indices, values selected afterwards: a select between the array and a constant compiles to a
+      // flat load from a stack copy of the constant)
+      const uint32_t e_last = n_ev ? n_ev - 1u : 0u;
+      uint4 ep0 = iev[min(e, e_last)], ep1 = iev[min(e + 1u, e_last)], ep2 = iev[min(e + 2u, e_last)], ep3 = iev[min(e + 3u, e_last)];
+      if (quiet || e >= n_ev) ep0.x = 0xffffffffu;
+      if (quiet || e + 1u >= n_ev) ep1.x = 0xffffffffu;
+      if (quiet || e + 2u >= n_ev) ep2.x = 0xffffffffu;
+      if (quiet || e + 3u >= n_ev) ep3.x = 0xffffffffu;
+      auto ev_at = [&](uint32_t i) -> uint4 {   // event i (position 0xffff: none left)
+        if (i >= n_ev) return none4;
+        const uint32_t o = i - e_first;
+        if (o >= 4u) return iev[i];
+        const uint4 a = (o & 1u) ? ep1 : ep0, b = (o & 1u) ? ep3 : ep2;
+        return (o & 2u) ? b : a;
+      };
+      uint4 ecur = ep0;
+      uint32_t cum = 0;   // bases inserted behind positions [32 w0, p)
+#pragma unroll
+      for (int d = 0; d < 8; d++) {
+        if (rm[d] == NONE) continue;
+        const uint32_t p = rm[d] & 0xffffu, j = rm[d] >> 16;
+        while ((ecur.x & 0xffffu) < p) {   // events in front of p: [.., e)
+          cum += ecur.x >> 16;
+          e++;
+          ecur = ev_at(e);
+        }
+        const bool second = (p >> 5) != w0;   // the span is at most 8 rows: two words at most
+        const uint32_t mw = second ? m1 : m0;
+        const uint32_t below = (uint32_t)__popc(mw & ((1u << (p & 31u)) - 1u)) + (second ? (uint32_t)__popc(m0) : 0u);
+        const uint32_t mbit = (mw >> (p & 31u)) & 1u;
+        const bool inr = p - (uint32_t)q.off < q.t_total;
+        uint32_t qi = NONE;
+        tok[d] = inr ? tgap : (uint32_t)TOK_NONE;   // no base here: a gap where the overlap covers the position, '.' outside
+        if (j == 0) {
+          if (inr && mbit) {
+            qi = qw + below + cum;
+            tok[d] = tbase + ((((second ? l1 : l0) >> (p & 31u)) & 1u) | ((((second ? h1 : h0) >> (p & 31u)) & 1u) << 1));
+          }
+        } else if ((ecur.x & 0xffffu) == p) {
+          uint4 x = ecur;
+          uint32_t code = 0;
+          for (uint32_t i = e;;) {
+            if ((x.x >> 16) >= j) {   // the LAST insertion at p that is long enough wrote this row
+              qi = x.y + j - 1u;
+              code = j <= 16u ? (((x.z >> (j - 1u)) & 1u) | (((x.z >> (15u + j)) & 1u) << 1)) : 4u;
+            }
+            if (++i >= n_ev) break;
+            x = ev_at(i);
+            if ((x.x & 0xffffu) != p) break;
+          }
+          if (qi != NONE) {
+            if (code == 4u) {   // beyond the 16 bases the event carries: from the read store
+              const int32_t si = q.sbase + q.sdir * (int32_t)qi;
+              const uint64_t wi = min(q.q_woff + ((uint32_t)si >> 5), pmax);
+              code = ((J.read_p0[wi] >> ((uint32_t)si & 31u)) & 1u) | (((J.read_p1[wi] >> ((uint32_t)si & 31u)) & 1u) << 1);
+              if (q.sdir < 0) code ^= 3u;
+            }
+            tok[d] = tbase + code;
+          }
+        }
+        if (qi != NONE) {
+          const int64_t si = (int64_t)q.sbase + (int64_t)q.sdir * (int64_t)qi;
+          addr[d] = min(q.qual_off + (uint64_t)max(si, (int64_t)0), qmax);
+        }
+      }
+    }
+  }
+  uint32_t qv[8];
+#pragma unroll
+  for (int d = 0; d < 8; d++) qv[d] = J.read_qual[addr[d] == NONE64 ? 0 : addr[d]];
+  uint32_t lo = 0, hi = 0, tl = 0, th = 0;
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    lo |= (addr[d] == NONE64 ? 33u : qv[d]) << (8 * d);
+    hi |= (addr[d + 4] == NONE64 ? 33u : qv[d + 4]) << (8 * d);
+    tl |= tok[d] << (8 * d);
+    th |= tok[d + 4] << (8 * d);
+  }
+  *out = make_uint4(tl, th, lo, hi);
+}
+
 __global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const uint64_t* __restrict__ sup_off, uint8_t* __restrict__ rf, uint64_t cap, uint32_t have_nr) {
   __shared__ __attribute__((aligned(16))) CTab s_ct[32];
-  const uint32_t w = blockIdx.x, tid = threadIdx.x, nw = J.nw;
+  const uint32_t w = blockIdx.x, tid = threadIdx.x;
   PROF_BEGIN(J);
   const uint32_t nsup = J.win_nsup[w], Lf = J.win_Lf[w];
   if (!nsup || sup_off[w] + nsup > cap) return;   // (a launch in front of the host's count of the informative rows: the buffer was sized by an estimate)
@@ -1610,180 +1809,14 @@ __global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const ui
   if (tid < 32) s_ct[tid] = J.ctab[(uint64_t)w * 32 + tid];
   __syncthreads();
   PROF_MARK(J, 5, 0);
-  const uint32_t span = 2 * half + 1, win_len = wd.win_len;
-  const uint64_t tq_off = s_ct[0].qual_off + wd.tstart;
-  const uint64_t qmax = J.read_qual_bytes ? J.read_qual_bytes - 1 : 0;
-  const uint64_t pmax = J.read_n_words + 1;
-  constexpr uint64_t NONE64 = ~0ull;
   const uint32_t nslots = nsup * HERRO_ROWS;
   const uint64_t out0 = sup_off[w] * HERRO_ROWS;
-  const uint32_t* __restrict__ rop = J.row_of_pos2 + wd.pos_off;
   for (uint32_t sl = tid; sl < nslots; sl += RQ_NT) {
     const uint32_t k = sl / HERRO_ROWS, c = sl - k * HERRO_ROWS;
-    // the slot's rows: row sup_row[k] - half + d is row (r - rop[p]) of the last position p with rop[p] <= r; every position has a
-    // row of its own, so p lies within `half` positions of the informative row's
-    const uint32_t pj = J.sup_pi[wd.row_off + k];
-    const int32_t pc = (int32_t)(pj & 0xffffu);
-    const uint32_t srow = J.sup_row[wd.row_off + k];
-    const int64_t row0 = (int64_t)srow - (int64_t)half;
-    uint32_t rv[8];   // first row of positions pc - half + i
-    if (have_nr && half == 2) {   // lean path: the neighbours' row counts came with the informative row (k_rows) — one round trip less, no row_of_pos2
-      const uint32_t nr = J.sup_nr[wd.row_off + k];
-      const uint32_t rc = srow - (pj >> 16);                      // row of position pc
-      rv[2] = rc;
-      rv[1] = rc - ((nr >> 6) & 63u);
-      rv[0] = rv[1] - (nr & 63u);
-      rv[3] = rc + ((nr >> 12) & 63u);
-      rv[4] = rv[3] + ((nr >> 18) & 63u);
-      rv[5] = rv[6] = rv[7] = 0;
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; i++) rv[i] = rop[(uint32_t)min(max(pc - (int32_t)half + i, 0), (int32_t)win_len)];
-    }
-    uint32_t rm[8];
-#pragma unroll
-    for (int d = 0; d < 8; d++) {
-      const int64_t r = row0 + d;
-      rm[d] = NONE;
-      if ((uint32_t)d < span && r >= 0 && r < (int64_t)Lf) {
-        int32_t pp = 0;
-        uint32_t rb = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-          const int32_t q = pc - (int32_t)half + i;
-          if ((uint32_t)i <= 2 * half && q >= 0 && q < (int32_t)win_len && (int64_t)rv[i] <= r) { pp = q; rb = rv[i]; }
-        }
-        rm[d] = (uint32_t)pp | (((uint32_t)r - rb) << 16);
-      }
-    }
-    uint64_t addr[8];
-    uint32_t tok[8];
-#pragma unroll
-    for (int d = 0; d < 8; d++) { addr[d] = NONE64; tok[d] = TOK_NONE; }
-    const CTab& q = s_ct[c];
-    if (c == 0) {
-      const uint64_t tw = s_ct[0].q_woff;
-#pragma unroll
-      for (int d = 0; d < 8; d++) {
-        if (rm[d] == NONE) continue;
-        tok[d] = TOK_GAP_F;   // the target shows '*' on an insertion row
-        if ((rm[d] >> 16) == 0) {
-          const uint32_t tp = wd.tstart + (rm[d] & 0xffffu);
-          const uint64_t wi = min(tw + (tp >> 5), pmax);
-          addr[d] = min(tq_off + (rm[d] & 0xffffu), qmax);
-          tok[d] = ((J.read_p0[wi] >> (tp & 31u)) & 1u) | (((J.read_p1[wi] >> (tp & 31u)) & 1u) << 1);
-        }
-      }
-    } else if (q.ow != NONE) {
-      const uint32_t tbase = q.tokc & 0xffu, tgap = q.tokc >> 8;
-      uint32_t p0 = NONE;   // position of the slot's first row inside the window
-#pragma unroll
-      for (int d = 7; d >= 0; d--) if (rm[d] != NONE) p0 = rm[d] & 0xffffu;
-      if (p0 != NONE) {
-        const uint32_t w0 = min(p0 >> 5, nw - 1u), w1 = min(w0 + 1u, nw - 1u);
-        const uint4* __restrict__ cw = J.cw + (uint64_t)q.ow * nw;
-        const uint4 c0 = cw[w0], c1 = cw[w1];   // planes + directory word of the slot's (at most two) words: one cache line
-        const uint2 d0 = make_uint2(c0.x, c0.w), d1 = make_uint2(c1.x, c1.w);
-        const uint32_t l0 = c0.y, l1 = c1.y, h0 = c0.z, h1 = c1.z;
-        const uint32_t m0 = d0.x, m1 = d1.x;
-        const uint32_t n_ev = q.n_ev;
-        const uint4* __restrict__ iev = J.iev + q.ev_off;
-        uint32_t qw = d0.y & 0xfffffu, e = d0.y >> 20;
-        if (d0.y == 0xffffffffu) {   // indices beyond the record's fields: count (M bits and events in front of the word)
-          qw = 0; e = 0;
-          for (uint32_t i = 0; i < w0; i++) qw += (uint32_t)__popc(cw[i].x);
-          while (e < n_ev && (iev[e].x & 0xffffu) < (w0 << 5)) { qw += iev[e].x >> 16; e++; }
-        }
-        // no insertion event between the two words' first positions and no row beyond: the event list is not needed
-        uint32_t pl = p0;
-        bool ins_row = false;
-#pragma unroll
-        for (int d = 0; d < 8; d++) if (rm[d] != NONE) { pl = rm[d] & 0xffffu; ins_row = ins_row || (rm[d] >> 16) != 0; }
-        const bool quiet = d0.y != 0xffffffffu && d1.y != 0xffffffffu && w1 != w0 && (d1.y >> 20) == e && (pl >> 5) == w0 && !ins_row;
-        // the next four events travel together (one round trip for nearly every slot; a fifth is fetched when the walk gets there)
-        const uint32_t e_first = e;
-        const uint4 none4 = make_uint4(0xffffffffu, 0, 0, 0);
-        // (loads unconditional with clamped indices, values selected afterwards: a select between the array and a constant compiles to a
-        // flat load from a stack copy of the constant)
-        const uint32_t e_last = n_ev ? n_ev - 1u : 0u;
-        uint4 ep0 = iev[min(e, e_last)], ep1 = iev[min(e + 1u, e_last)], ep2 = iev[min(e + 2u, e_last)], ep3 = iev[min(e + 3u, e_last)];
-        if (quiet || e >= n_ev) ep0.x = 0xffffffffu;
-        if (quiet || e + 1u >= n_ev) ep1.x = 0xffffffffu;
-        if (quiet || e + 2u >= n_ev) ep2.x = 0xffffffffu;
-        if (quiet || e + 3u >= n_ev) ep3.x = 0xffffffffu;
-        auto ev_at = [&](uint32_t i) -> uint4 {   // event i (position 0xffff: none left)
-          if (i >= n_ev) return none4;
-          const uint32_t o = i - e_first;
-          if (o >= 4u) return iev[i];
-          const uint4 a = (o & 1u) ? ep1 : ep0, b = (o & 1u) ? ep3 : ep2;
-          return (o & 2u) ? b : a;
-        };
-        uint4 ecur = ep0;
-        uint32_t cum = 0;   // bases inserted behind positions [32 w0, p)
-#pragma unroll
-        for (int d = 0; d < 8; d++) {
-          if (rm[d] == NONE) continue;
-          const uint32_t p = rm[d] & 0xffffu, j = rm[d] >> 16;
-          while ((ecur.x & 0xffffu) < p) {   // events in front of p: [.., e)
-            cum += ecur.x >> 16;
-            e++;
-            ecur = ev_at(e);
-          }
-          const bool second = (p >> 5) != w0;   // the span is at most 8 rows: two words at most
-          const uint32_t mw = second ? m1 : m0;
-          const uint32_t below = (uint32_t)__popc(mw & ((1u << (p & 31u)) - 1u)) + (second ? (uint32_t)__popc(m0) : 0u);
-          const uint32_t mbit = (mw >> (p & 31u)) & 1u;
-          const bool inr = p - (uint32_t)q.off < q.t_total;
-          uint32_t qi = NONE;
-          tok[d] = inr ? tgap : (uint32_t)TOK_NONE;   // no base here: a gap where the overlap covers the position, '.' outside
-          if (j == 0) {
-            if (inr && mbit) {
-              qi = qw + below + cum;
-              tok[d] = tbase + ((((second ? l1 : l0) >> (p & 31u)) & 1u) | ((((second ? h1 : h0) >> (p & 31u)) & 1u) << 1));
-            }
-          } else if ((ecur.x & 0xffffu) == p) {
-            uint4 x = ecur;
-            uint32_t code = 0;
-            for (uint32_t i = e;;) {
-              if ((x.x >> 16) >= j) {   // the LAST insertion at p that is long enough wrote this row
-                qi = x.y + j - 1u;
-                code = j <= 16u ? (((x.z >> (j - 1u)) & 1u) | (((x.z >> (15u + j)) & 1u) << 1)) : 4u;
-              }
-              if (++i >= n_ev) break;
-              x = ev_at(i);
-              if ((x.x & 0xffffu) != p) break;
-            }
-            if (qi != NONE) {
-              if (code == 4u) {   // beyond the 16 bases the event carries: from the read store
-                const int32_t si = q.sbase + q.sdir * (int32_t)qi;
-                const uint64_t wi = min(q.q_woff + ((uint32_t)si >> 5), pmax);
-                code = ((J.read_p0[wi] >> ((uint32_t)si & 31u)) & 1u) | (((J.read_p1[wi] >> ((uint32_t)si & 31u)) & 1u) << 1);
-                if (q.sdir < 0) code ^= 3u;
-              }
-              tok[d] = tbase + code;
-            }
-          }
-          if (qi != NONE) {
-            const int64_t si = (int64_t)q.sbase + (int64_t)q.sdir * (int64_t)qi;
-            addr[d] = min(q.qual_off + (uint64_t)max(si, (int64_t)0), qmax);
-          }
-        }
-      }
-    }
+    const uint32_t pj = J.sup_pi[wd.row_off + k], srow = J.sup_row[wd.row_off + k];
+    const uint32_t nr = have_nr ? J.sup_nr[wd.row_off + k] : 0u;
+    rf_slot(J, s_ct, wd, Lf, half, c, srow, pj, nr, have_nr != 0u, reinterpret_cast<uint4*>(rf + (out0 + sl) * 16));
     PROF_MARK(J, 5, 1);
-    uint32_t qv[8];
-#pragma unroll
-    for (int d = 0; d < 8; d++) qv[d] = J.read_qual[addr[d] == NONE64 ? 0 : addr[d]];
-    uint32_t lo = 0, hi = 0, tl = 0, th = 0;
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-      lo |= (addr[d] == NONE64 ? 33u : qv[d]) << (8 * d);
-      hi |= (addr[d + 4] == NONE64 ? 33u : qv[d + 4]) << (8 * d);
-      tl |= tok[d] << (8 * d);
-      th |= tok[d + 4] << (8 * d);
-    }
-    *reinterpret_cast<uint4*>(rf + (out0 + sl) * 16) = make_uint4(tl, th, lo, hi);
-    PROF_MARK(J, 5, 2);
   }
 }
 

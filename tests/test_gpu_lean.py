@@ -23,6 +23,7 @@ CASES = {
     "w8192": dict(W=8192, n=2, tl=3 * 8192 + 100, ov=12, kw=dict(p_partial=0.3)),
     "w1000": dict(W=1000, n=3, tl=3500, ov=10, kw=dict(flank_min=100, flank_max=200, p_partial=0.3)),
     "diverged_haplotypes": dict(W=4096, n=2, tl=2 * 4096, ov=32, kw=dict(p_snp=0.03)),
+    "very_diverged": dict(W=4096, n=2, tl=2 * 4096, ov=32, kw=dict(p_snp=0.09)),       # windows above 256 informative rows: k_rows leaves the receptive fields to k_rfq
 }
 
 
@@ -69,7 +70,7 @@ def test_lean_path_equals_planes_path(name):
     job.close()
 
 
-@pytest.mark.parametrize("name", ["baseline_w4096", "noisy_w256", "w1000"])
+@pytest.mark.parametrize("name", ["baseline_w4096", "noisy_w256", "w1000", "very_diverged"])
 def test_receptive_field_records_are_the_planes_cells(name):
     cs = CASES[name]
     sb = synth.generate(cs["n"], cs["tl"], cs["ov"], seed=synth.SEED + 29 + sum(map(ord, name)), **cs["kw"])
@@ -78,6 +79,13 @@ def test_receptive_field_records_are_the_planes_cells(name):
     job = api.job_from_synth(c, sb, cs["W"])
     job.featurize()
     job.infer(64, 1)
+    most = max(job.info(w).n_supported for w in range(job.n_windows))
+    if most > 256:
+        assert not job.rf_fused()              # a window above what k_rows stages: k_rfq gathered for the whole job
+    else:
+        job.featurize()                        # a second pass knows the job's size (the first one sizes the record buffer by an estimate) ...
+        job.infer(64, 1)
+        assert job.rf_fused()                  # ... and reads the records k_rows gathered itself
     n_rec = 0
     for w in range(job.n_windows):
         rf = job.rf_records(w)                 # read by the model on the lean path
