@@ -546,7 +546,10 @@ class Job:
 
     def rf_fused(self) -> bool:
         """test hook: the last infer read the receptive fields k_rows gathered itself (False: k_rfq's)"""
-        return bool(self.ctx._chk(self._l.herro_debug_job_rf_fused(self.h)))
+        rc = self._l.herro_debug_job_rf_fused(self.h)
+        if rc < 0:
+            self.ctx._chk(rc)
+        return rc == 1
 
     def rf_records(self, w: int) -> np.ndarray:
         """test hook: the receptive-field records the model read for window w, [n_supported, 31, 16] (bytes 0..7 tokens, 8..15 qualities)"""

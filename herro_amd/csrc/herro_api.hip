@@ -189,6 +189,7 @@ struct herro_ctx {
   std::vector<Arena> free_dev, free_pin, free_small;   // free_small: the buffers a job needs only once its counts are known (logits, batch descriptors)
   std::atomic<uint32_t> live_jobs{0};   // herro_job_create may run on another thread than the context's execution calls
   uint64_t reads_gen = 0;   // bumped by herro_set_reads: a job built on an older store refuses to run
+  std::atomic<int> n_pending{0};   // jobs of this context that are featurized and not yet inferred: > 0 when herro_job_featurize is called means the caller pipelines its jobs
   uint64_t n_featurize = 0, n_infer = 0;   // calls so far: a context that featurizes job after job without ever inferring (the `herro features` path) stops gathering receptive fields ahead of time
   std::atomic<int> create_code{0};   // HERRO_E_* of the last herro_job_create that returned NULL (herro_job_create_status)
 };
@@ -244,6 +245,7 @@ struct herro_job {
   bool rf_fused = false;     // ... and k_rows gathered the receptive fields itself (records at win_rfbase, room for rf_fused_cap rows, half width rf_fused_half)
   uint64_t rf_fused_cap = 0;
   uint32_t rf_fused_half = 0, rf_total = 0;
+  bool pending = false;         // counted in herro_ctx::n_pending
   bool rf_fused_used = false;   // herro_job_infer read the records k_rows gathered (herro_debug_job_rf_fused)
   std::vector<uint32_t> h_rfbase;
   std::vector<uint64_t> rf_base;   // per window: first record of its receptive fields in d_rfq (whichever kernel wrote them), valid after herro_job_infer
@@ -1779,6 +1781,7 @@ void herro_job_free(herro_job* job) {
   if (!job) return;
   herro_ctx* ctx = job->ctx;
   if (ctx->live_jobs.load()) ctx->live_jobs--;
+  if (job->pending) { job->pending = false; ctx->n_pending--; }   // featurized, never inferred
   if (ctx->host_only) {
     std::lock_guard<std::mutex> lk(ctx->arena_mu);
     if (job->pin.p) { if (ctx->free_pin.size() < 6) ctx->free_pin.push_back(job->pin); else std::free(job->pin.p); }
@@ -1823,10 +1826,17 @@ int herro_job_featurize(herro_job* job) {
   // The model's receptive fields are gathered by k_rows itself on the lean path (records placed by one atomic per window), into a buffer sized by the
   // job's previous pass or by an estimate; if it turns out too small — or a window has more informative rows than k_rows stages — herro_job_infer
   // gathers with k_rfq instead.  HERRO_RF_FUSED=0: always k_rfq (A/B).
-  static const bool fuse_rf = [] { const char* e = getenv("HERRO_RF_FUSED"); return !e || atoi(e) != 0; }();
+  // WHEN: if the caller pipelines its jobs (another job of this context is featurized and waits for its herro_job_infer), the GPU has that job's kernels
+  // to run while the host plans this one, and the fused gather is the faster one (k_rows + k_rfq 276 -> 230 us per 4096 windows, +3.8 % at the bench's
+  // default size).  A job on its own (the driver's 20-step run) is better served by k_rfq launched BEHIND the copy of the counts: the host wakes up and
+  // plans the batches while it runs, instead of the GPU idling for the plan (same-box A/B, profiles/r5_ab_runs.json r5i: 2.04 vs 1.96 M windows/s).
+  // HERRO_RF_FUSED=1 / 0 forces one or the other (A/B).
+  static const int fuse_rf = [] { const char* e = getenv("HERRO_RF_FUSED"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  const bool pipelined = ctx->n_pending.load() - (job->pending ? 1 : 0) > 0;
+  if (!job->pending) { job->pending = true; ctx->n_pending++; }
   job->rf_fused = false;
   job->J.rf = nullptr;
-  if (job->lean && fuse_rf && ctx->has_model && !features_only && rf_half == 2) {
+  if (job->lean && (fuse_rf == 1 || (fuse_rf < 0 && pipelined)) && ctx->has_model && !features_only && rf_half == 2) {
     const uint64_t want = job->logit_cap > 1 ? job->logit_cap : (uint64_t)job->J.n_win * 24;   // ~15 informative rows per window at the bench workload
     if (ensure_logits(job, want) == HERRO_OK) {
       job->J.rf = job->d_rfq; job->J.rf_cap = std::min<uint64_t>(job->logit_cap, 0xfffffff0ull / HERRO_ROWS); job->J.rf_half = rf_half;
@@ -1910,6 +1920,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   if (!ctx->has_model) { ctx->err = "no model loaded"; return HERRO_E_NO_MODEL; }
   ProfSpan span_(ctx, "infer");
   ctx->n_infer++;
+  if (job->pending) { job->pending = false; ctx->n_pending--; }
   int rc = job_sync(job);
   if (rc) return rc;
   HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -50,13 +50,26 @@ def test_lean_path_equals_planes_path(name):
     G.load_synth(c, sb)
     ids = [f"read{t}" for t in range(sb.n_targets)]
     job = api.job_from_synth(c, sb, cs["W"])
+    other = None
     try:
         c.featurize_planes(False)
-        lean, fa_lean = _run(job, ids, 64)
+        lean, fa_lean = _run(job, ids, 64)                # a job on its own: receptive fields by k_rfq behind the counts
+        assert not job.rf_fused()
+        other = api.job_from_synth(c, sb, cs["W"], targets=[0])
+        other.featurize()                                 # a pending job: the caller pipelines -> k_rows gathers the receptive fields itself
+        lean2, fa_lean2 = _run(job, ids, 64)
+        fused = job.rf_fused()
+        other.close(); other = None
         c.featurize_planes(True)
         planes, fa_planes = _run(job, ids, 64)
     finally:
         c.featurize_planes(False)
+        if other is not None:
+            other.close()
+    assert fused == (max(a[1] for a in lean) <= 256 and sum(a[1] for a in lean) > 0) or name == "low_coverage"
+    assert fa_lean2 == fa_lean
+    for a, b in zip(lean, lean2):
+        assert a[:3] == b[:3] and np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6])   # both gathers feed the model the same records
     assert len(lean) == len(planes) > 0
     n_sup = 0
     for w, (a, b) in enumerate(zip(lean, planes)):
@@ -79,13 +92,14 @@ def test_receptive_field_records_are_the_planes_cells(name):
     job = api.job_from_synth(c, sb, cs["W"])
     job.featurize()
     job.infer(64, 1)
+    assert not job.rf_fused()                  # a job on its own: k_rfq gathers behind the copy of the counts (the host plans meanwhile)
+    other = api.job_from_synth(c, sb, cs["W"], targets=[0])
+    other.featurize()                          # another job of the context is featurized and waits for its infer: the caller pipelines ...
+    job.featurize()
+    job.infer(64, 1)
     most = max(job.info(w).n_supported for w in range(job.n_windows))
-    if most > 256:
-        assert not job.rf_fused()              # a window above what k_rows stages: k_rfq gathered for the whole job
-    else:
-        job.featurize()                        # a second pass knows the job's size (the first one sizes the record buffer by an estimate) ...
-        job.infer(64, 1)
-        assert job.rf_fused()                  # ... and reads the records k_rows gathered itself
+    assert job.rf_fused() == (most <= 256)     # ... and k_rows gathers the receptive fields itself — unless a window has more rows than it stages
+    other.close()
     n_rec = 0
     for w in range(job.n_windows):
         rf = job.rf_records(w)                 # read by the model on the lean path
