@@ -148,7 +148,7 @@ struct herro_ctx {
   // lean: herro_job_featurize derives informative rows, votes and receptive fields without writing the token planes (k_rows); the planes are
   // built when somebody asks for them.  HERRO_FEATURIZE_PLANES=1 (or herro_debug_set_featurize_planes): the planes path of rounds 3-4 (A/B, parity tests)
   bool lean = [] { const char* e = getenv("HERRO_FEATURIZE_PLANES"); return !e || atoi(e) == 0; }();
-  bool tile_packing = [] { const char* e = getenv("HERRO_TILE_PACK"); return !e || atoi(e) != 0; }();  // 0: windows in batch order (A/B)
+  bool tile_packing = ab_env("HERRO_TILE_PACK", 1) != 0;  // 0 (A/B builds): windows in batch order
   uint64_t* d_words = nullptr;
   uint32_t* d_p0 = nullptr;
   uint32_t* d_p1 = nullptr;
@@ -539,7 +539,7 @@ static TilePlan plan_tiles_small(const std::vector<uint32_t>& cnt, bool pack, in
 // Most informative rows of a window that stays on the fused stack: 64 (one tile), or 64 * FUSED_MAX_SIB with the f16 stack, which
 // spreads a larger window over sibling tiles (HERRO_FUSED_BIG=0: such windows go layer by layer as before, for A/B).
 static uint32_t fused_tok_cap(const herro_ctx* ctx) {
-  static const bool big = [] { const char* e = getenv("HERRO_FUSED_BIG"); return !e || atoi(e) != 0; }();
+  static const bool big = ab_env("HERRO_FUSED_BIG", 1) != 0;
   return (big && ctx->precision >= 4 && model_h_supported(ctx->M)) ? FUSED_MAX_TOK * FUSED_MAX_SIB : FUSED_MAX_TOK;
 }
 // K / V exchange buffers and flags of `n_tiles_b` sibling tiles (128 KB per tile)
@@ -623,8 +623,7 @@ herro_ctx* herro_create(int device_id) {
       if (hipMalloc((void**)&ctx->d_prof, 256 * 32 * 8) == hipSuccess) (void)hipMemset(ctx->d_prof, 0, 256 * 32 * 8); else ctx->d_prof = nullptr;
     }
 #endif
-    const char* hs = getenv("HERRO_HOST_SCAN");
-    ctx->dev_scan = !(hs && atoi(hs) != 0);
+    ctx->dev_scan = ab_env("HERRO_HOST_SCAN", 0) == 0;
   }
   // ln(k+1) table from the host libm — what Rust's f64::ln calls on Linux (features.rs:507)
   std::vector<double> ln(1u << 20);
@@ -1183,7 +1182,7 @@ int herro_set_precision(herro_ctx* ctx, int mode) {
   // the load-time calibration ran and found the f16 kernels outside half the 1e-3 contract on THIS model: an explicit request for
   // them is refused (HERRO_FORCE_PRECISION=1 overrides, for measurements)
   if (mode >= 4 && ctx->has_model && (ctx->calib_err > 5e-4f || std::isnan(ctx->calib_err))) {
-    static const bool force = [] { const char* e = getenv("HERRO_FORCE_PRECISION"); return e && atoi(e) != 0; }();
+    static const bool force = ab_env("HERRO_FORCE_PRECISION", 0) != 0;
     if (!force) {
       char buf[200];
       snprintf(buf, sizeof buf, "precision %d refused: the calibration of this model measured a logit difference of %.3g (> 5e-4) for the f16 kernels", mode, (double)ctx->calib_err);
@@ -1831,7 +1830,7 @@ int herro_job_featurize(herro_job* job) {
   // default size).  A job on its own (the driver's 20-step run) is better served by k_rfq launched BEHIND the copy of the counts: the host wakes up and
   // plans the batches while it runs, instead of the GPU idling for the plan (same-box A/B, profiles/r5_ab_runs.json r5i: 2.04 vs 1.96 M windows/s).
   // HERRO_RF_FUSED=1 / 0 forces one or the other (A/B).
-  static const int fuse_rf = [] { const char* e = getenv("HERRO_RF_FUSED"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  static const int fuse_rf = ab_env("HERRO_RF_FUSED", -1) < 0 ? -1 : (ab_env("HERRO_RF_FUSED", -1) != 0 ? 1 : 0);
   const bool pipelined = ctx->n_pending.load() - (job->pending ? 1 : 0) > 0;
   if (!job->pending) { job->pending = true; ctx->n_pending++; }
   job->rf_fused = false;
@@ -1856,7 +1855,7 @@ int herro_job_featurize(herro_job* job) {
   // kernel instead of having waited for the plan.  The buffer is sized by the job's previous pass or by an estimate; if the
   // count turns out larger, herro_job_infer gathers again.  HERRO_RFQ_EARLY=0: gather in herro_job_infer (A/B).
   job->rfq_spec = false;
-  static const bool early = [] { const char* e = getenv("HERRO_RFQ_EARLY"); return !e || atoi(e) != 0; }();
+  static const bool early = ab_env("HERRO_RFQ_EARLY", 1) != 0;
   if (early && !job->rf_fused && ctx->has_model && !features_only && 2 * rf_half + 1 <= 8) {
     const uint32_t n = job->J.n_win;
     if (!job->a_supoff_dev.p) job->a_supoff_dev = small_acquire(ctx, ((uint64_t)n + 1) * 8);

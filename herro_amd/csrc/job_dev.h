@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -15,6 +16,16 @@
 #define HERRO_TILE 1024       // rows of the final matrix per k_tokens workgroup (a "tile" of the job's tile list)
 
 namespace herro {
+
+// A/B switches of measurements (the environment variables the documents' same-box comparisons were made with) exist only in libraries built
+// with -DHERRO_PROF_BUILD (tools/prof.sh, `build_hip(out=..., defines=("HERRO_PROF_BUILD",))`); a release library takes the default and
+// carries no untested product path behind an environment variable.  Options a user may set stay plain getenv calls:
+// HERRO_HOST_THREADS, HERRO_FEATURIZE_PLANES, HERRO_ZERO_COPY, HERRO_FASTX_*, HERRO_TRACE, HERRO_HOST_PROFILE.
+#ifdef HERRO_PROF_BUILD
+inline int ab_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+inline int ab_env(const char*, int dflt) { return dflt; }
+#endif
 
 // A window's column table (one entry per row of the final matrix; entry 0 = the target): what the token and quality
 // kernels need to know about a selected overlap, written by k_layout.

@@ -18,7 +18,7 @@
 //
 // Kernels (same dataflow as model.hip, re-derived for one 2-byte plane per operand):
 //   k_conv_m   embedding + quality + conv1 as a K = 96 GEMM -> (registers) -> conv2 (K = 192) -> y2 as ONE f16 plane [N*31][128]
-//   k_fc_h     y2[N][3968] . Wfc -> x[N][256]; 128 x 256 tiles, LDS-DMA, three 24 KB buffers, 2 workgroups per CU
+//   k_fc_r     y2[N][3968] . Wfc -> x[N][256]; 128 (or 96) x 256 tiles, weights L2 -> registers, activations through the LDS, 2 workgroups per CU
 //   k_layers_p the whole encoder stack per tile of <= 64 (or 32) tokens: residual stream in registers from the FC output to
 //              the logits (positional encoding added on the way in), weight fragments one half GEMM call ahead;
 //              <., 4, true>: the same grid headed by SIBLING tiles — a window of 65 .. 512 informative rows on ceil(rows / 64) tiles
@@ -358,112 +358,13 @@ __global__ __launch_bounds__(CM_NT, WPS) void k_conv_m(ModelDev M, BatchDev B, M
 }
 
 // ---------------------------------------------------------------------------------------------------
-// FC: x[M][256] = y2[M][K] . W^T + bias, y2 and W single f16 planes.  One workgroup = 128 rows x all 256
-// columns (the 8 KB-per-token A operand passes through L2 once), 8 waves as 2 x 4 with 64 x 64 wave tiles.
-// A and B tiles go global -> LDS by LDS-DMA (3 pieces of 1 KiB per wave and k-step), three 24 KB buffers, counted
-// vmcnt, one barrier per k-step; 72 KB of LDS and <= 128 VGPRs leave room for two workgroups per CU.
-// ---------------------------------------------------------------------------------------------------
-#ifndef HERRO_FC_NBUF
-#define HERRO_FC_NBUF 3
-#endif
-constexpr int FC_TM = 128, FC_TN = 256, FC_NBUF = HERRO_FC_NBUF, FC_NP = 3;
-static_assert(FC_NBUF >= 2 && FC_NBUF <= 5, "wait_vmcnt ladder covers up to three younger tiles");
-constexpr int FC_BS = (FC_TM + FC_TN) * 32;  // u16 elements per buffer
-constexpr size_t FC_H_SHM = (size_t)FC_NBUF * FC_BS * 2;
-
-__global__ __launch_bounds__(512, FC_NBUF <= 3 ? 4 : 2) void k_fc_h(const uint16_t* __restrict__ A, uint32_t lda, Weight W, float* C, uint32_t ldc, uint32_t M) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_fc[];
-  uint16_t* s_raw = reinterpret_cast<uint16_t*>(smem_fc);
-  const uint32_t K = W.K;
-  const uint32_t m0 = blockIdx.x * FC_TM;
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t fr = lane & 15, fc = lane >> 4;
-  const uint32_t wr = wave >> 2, wc = wave & 3;
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bs[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) bs[j] = W.bias ? W.bias[wc * 64 + j * 16 + fr] : 0.f;
-
-  // staging plan: lane l of a piece fills row (l >> 2), 16-byte slot (l & 3); the bank swizzle of the fragment reads is
-  // applied on the SOURCE address (the DMA destination is lane-linear).  Wave w: A rows 16w.., B rows 32w.. (two pieces)
-  const uint32_t lr = lane >> 2, lc = lane & 3;
-  const uint16_t* src[FC_NP];
-  uint32_t dst[FC_NP];
-  {
-    const uint32_t row0 = wave * 16, row = row0 + lr;
-    src[0] = A + (uint64_t)min(m0 + row, M - 1) * lda + (lc ^ ((row >> 1) & 3u)) * 8;
-    dst[0] = row0 * 64;
-  }
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    const uint32_t row0 = (wave * 2 + h) * 16, row = row0 + lr;
-    src[1 + h] = W.h16 + (uint64_t)row * K + (lc ^ ((row >> 1) & 3u)) * 8;
-    dst[1 + h] = FC_TM * 64 + row0 * 64;
-  }
-  const uint32_t lds_base = (uint32_t)(uintptr_t)s_raw;
-  auto stage = [&](uint32_t kt, uint32_t buf) {
-    const uint32_t b0 = lds_base + buf * (FC_BS * 2);
-#pragma unroll
-    for (int p = 0; p < FC_NP; p++) glds16_h(src[p] + kt * 32, __builtin_amdgcn_readfirstlane(b0 + dst[p]));
-  };
-  auto compute = [&](uint32_t buf) {
-    const uint16_t* s_a = s_raw + buf * FC_BS;
-    const uint16_t* s_b = s_a + FC_TM * 32;
-    half8 ah[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const uint32_t ar = wr * 64 + i * 16 + fr;
-      ah[i] = *reinterpret_cast<const half8*>(s_a + ar * 32 + (fc ^ ((ar >> 1) & 3u)) * 8);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const uint32_t br = wc * 64 + j * 16 + fr;
-      const half8 bh = *reinterpret_cast<const half8*>(s_b + br * 32 + (fc ^ ((br >> 1) & 3u)) * 8);
-#pragma unroll
-      for (int i = 0; i < 4; i++) acc[i][j] = mma(ah[i], bh, acc[i][j]);
-    }
-  };
-  const uint32_t nk = K / 32;
-  // tiles run FC_NBUF - 1 k-steps ahead of the MFMAs that read them
-#pragma unroll
-  for (int d = 0; d < FC_NBUF - 1; d++) if ((uint32_t)d < nk) stage(d, d);
-  uint32_t buf = 0, nbuf = FC_NBUF - 1;
-  for (uint32_t k = 0; k < nk; k++) {
-    // this wave's pieces of tile k have landed: at most the younger tiles' pieces are still in flight
-    const uint32_t younger = min(nk - 1 - k, (uint32_t)FC_NBUF - 2);
-    if (younger >= 3) wait_vmcnt_h<3 * FC_NP>(); else if (younger == 2) wait_vmcnt_h<2 * FC_NP>(); else if (younger == 1) wait_vmcnt_h<FC_NP>(); else wait_vmcnt_h<0>();
-    __builtin_amdgcn_s_barrier();                                   // ... everybody's have; tile k-1 is no longer read
-    if (k + FC_NBUF - 1 < nk) stage(k + FC_NBUF - 1, nbuf);
-    compute(buf);
-    buf = buf == FC_NBUF - 1 ? 0 : buf + 1;
-    nbuf = nbuf == FC_NBUF - 1 ? 0 : nbuf + 1;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const uint32_t n = wc * 64 + j * 16 + fr;
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const uint32_t m = m0 + wr * 64 + i * 16 + fc * 4 + r;
-        if (m < M) C[(uint64_t)m * ldc + n] = acc[i][j][r] + bs[j];
-      }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// k_fc_r — the same GEMM with the weights streamed L2 -> registers in fragment order (round 4).
-// What k_fc_h's counters and depth experiments said (r4): a k-step costs ~1.4 us where its MFMAs need 0.25; deeper LDS-DMA prefetch
-// with one workgroup per CU is SLOWER (208 / 201 us against 182 with three buffers and two workgroups): the time is the fixed
-// cost of a k-step — three LDS-DMA pieces per wave (100-185 cycles of issue each beside MFMAs and ds_reads), eight ds_reads, the
-// barrier.  Here the weights (the same for every workgroup, L2-resident) never touch the LDS: a wave owns 32 output columns of all
-// 128 rows, its two fragments per k-step come straight from Weight::ph16 into registers one macro-step ahead; only the
-// activation tile goes through the LDS, by plain loads (one macro-step ahead, in registers) and ds_write_b128 — one barrier
+// k_fc_r — FC: x[M][256] = y2[M][K] . W^T + bias, y2 and W single f16 planes; the weights streamed L2 -> registers in fragment order (round 4).
+// Its predecessor k_fc_h (rounds 2-3, deleted in round 5: git show 4ba82b6:herro_amd/csrc/model_h.hip) moved both operands through the LDS by LDS-DMA; its
+// counters and depth experiments said (r4): a k-step costs ~1.4 us where its MFMAs need 0.25; deeper LDS-DMA prefetch with one workgroup per CU is SLOWER
+// (208 / 201 us against 182 with three buffers and two workgroups): the time is the fixed cost of a k-step — three LDS-DMA pieces per wave (100-185
+// cycles of issue each beside MFMAs and ds_reads), eight ds_reads, the barrier.  Here the weights (the same for every workgroup, L2-resident) never
+// touch the LDS: a wave owns 32 output columns of all 128 rows, its two fragments per k-step come straight from Weight::ph16 into registers one
+// macro-step ahead; only the activation tile goes through the LDS, by plain loads (one macro-step ahead, in registers) and ds_write_b128 — one barrier
 // per 64 k.  Per 64 k and wave: 32 MFMAs, 16 ds_read_b128, 4 fragment loads, 2 row loads + 2 ds_writes.
 // ---------------------------------------------------------------------------------------------------
 constexpr int FR_ROWS = 128;                               // rows of an LDS buffer; a tile takes 32 * G of them
@@ -1236,13 +1137,13 @@ __global__ void k_build_tokens_h(BatchDev B, ModelScratch S) {
 bool model_h_supported(const ModelDev& M) {
   const ModelHyper& h = M.h;
   return h.kw == 3 && h.c1 == 64 && h.c2 == HC2 && h.d_model == 256 && h.n_heads == 8 && h.d_ff % 256 == 0 && h.d_ff <= (uint32_t)PAR_MAX_FF && h.rows == HERRO_ROWS &&
-         M.conv1g.ph16 && M.conv2.ph16 && M.fc.h16 && M.heads.h16 && M.heads.l16 && M.layer[0].qkv.ph16;
+         M.conv1g.ph16 && M.conv2.ph16 && M.fc.h16 && M.fc.ph16 && M.fc.K % 128 == 0 && M.heads.h16 && M.heads.l16 && M.layer[0].qkv.ph16;
 }
 
 // HERRO_LAYERS_Q: 0 keeps every tile at 64 tokens, 2 puts every window of <= 32 rows into 32-token tiles (both for A/B);
 // default 1: 32-token tiles take the short last round of a launch (plan_tiles, herro_api.hip)
 int model_h_half_tiles(const ModelDev& M) {
-  static const int mode = [] { const char* e = getenv("HERRO_LAYERS_Q"); return e ? std::max(0, std::min(2, atoi(e))) : 1; }();
+  static const int mode = std::max(0, std::min(2, ab_env("HERRO_LAYERS_Q", 1)));   // (A/B builds only)
   return model_h_supported(M) ? mode : 0;
 }
 
@@ -1271,18 +1172,14 @@ void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S,
     KT_END(tm, st);
   }
   KT_BEGIN(tm, "fc_gemm", st);
-  static const bool fc_r = [] { const char* e = getenv("HERRO_FC_R"); return !e || atoi(e) != 0; }();   // 0: weights through the LDS by LDS-DMA (k_fc_h), for the A/B
-  if (fc_r && M.fc.ph16 && M.fc.K % 128 == 0 && h.d_model == 256) {
-    // tile height: the one that leaves the busiest compute unit the fewest rows (two workgroups fit a unit; HERRO_FC_G forces it, for A/B)
-    static const int force_g = [] { const char* e = getenv("HERRO_FC_G"); return e ? atoi(e) : 0; }();
+  {
+    // tile height: the one that leaves the busiest compute unit the fewest rows (two workgroups fit a unit; HERRO_FC_G forces it in A/B builds)
+    static const int force_g = ab_env("HERRO_FC_G", 0);
     static const uint32_t n_cu = [] { int dev = 0, c = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return (uint32_t)std::max(c, 1); }();
     auto busiest = [&](uint32_t rows) { const uint32_t wg = (N + rows - 1) / rows; return (uint64_t)((wg + n_cu - 1) / n_cu) * rows + (wg > 2 * n_cu ? 1u << 20 : 0u); };
     const int g = force_g == 3 || force_g == 4 ? force_g : (busiest(96) < busiest(128) ? 3 : 4);
     if (g == 3) hipLaunchKernelGGL(k_fc_r<3>, dim3((N + 95) / 96), dim3(512), FC_R_SHM, st, S.y2_hi, HERRO_ROWS * h.c2, M.fc, S.x, h.d_model, N);
     else hipLaunchKernelGGL(k_fc_r<4>, dim3((N + 127) / 128), dim3(512), FC_R_SHM, st, S.y2_hi, HERRO_ROWS * h.c2, M.fc, S.x, h.d_model, N);
-  } else {
-    opt_in_lds(reinterpret_cast<const void*>(k_fc_h), FC_H_SHM);
-    hipLaunchKernelGGL(k_fc_h, dim3((N + FC_TM - 1) / FC_TM), dim3(512), FC_H_SHM, st, S.y2_hi, HERRO_ROWS * h.c2, M.fc, S.x, h.d_model, N);
   }
   KT_END(tm, st);
   KT_BEGIN(tm, "layers_fused", st);   // one span: the 64-token tiles (windows of 33..64 informative rows and what shares their tiles), then the 32-token ones

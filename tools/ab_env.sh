@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE (round 5): measurement switches (HERRO_RF_FUSED, HERRO_LAYERS_Q, HERRO_FC_G, HERRO_TILE_PACK, ...) exist only in libraries built with
+# -DHERRO_PROF_BUILD: export HERRO_LIB=$PWD/herro_amd/libherro_amd_prof.so for them (tools/prof.sh says how it is built).
 # A/B of one environment switch on the same box: device-resident bench leg at the default launch size and at the driver's.
 # usage: gpurun -- bash tools/ab_env.sh tag VAR "values" [pytest targets]
 tag=$1; var=$2; vals=$3; shift 3

@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE (round 5): measurement switches (HERRO_RF_FUSED, HERRO_LAYERS_Q, HERRO_FC_G, HERRO_TILE_PACK, ...) exist only in libraries built with
+# -DHERRO_PROF_BUILD: export HERRO_LIB=$PWD/herro_amd/libherro_amd_prof.so for them (tools/prof.sh says how it is built).
 # parity tests, then a same-box A/B of one environment switch on the device-resident leg (one stream and the driver's size), twice each
 # usage: gpurun --timeout 700 -- bash tools/r5_ab_env2.sh tag VAR "v0 v1" [pytest targets]
 tag=$1; var=$2; vals=$3; shift 3
