@@ -1718,7 +1718,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   const size_t o_cseq = take(row_elems), o_ctmp = take(row_elems), o_clen = take((uint64_t)n_win * 4);
   const size_t o_srow = take(row_elems * 4), o_spi = take(row_elems * 4);
   const size_t o_finb = take(fin_bytes), o_finq = take(fin_bytes), o_nd = take((uint64_t)n_cls * 8);
-  const size_t o_vpl = take((uint64_t)n_win * 3 * J.nw * 4), o_snr = take(row_elems * 4);
+  const size_t o_vpl = take((uint64_t)n_win * 4 * J.nw * 4), o_snr = take(row_elems * 4);
   const size_t dev_bytes = cur;
   job->dev = arena_acquire(ctx, ctx->free_dev, dev_bytes, 1);
   auto give_back = [&]() {

@@ -103,7 +103,7 @@ struct JobDev {
   uint32_t rf_half;
   uint32_t* rf_alloc;
   uint32_t* win_rfbase;  // [win]
-  uint32_t* vpl;         // lean path: [win][3][nw] majority vote of every target position's base row as three bit planes (code 0..4 = A C G T *)
+  uint32_t* vpl;         // lean path: [win][4][nw] majority vote of every target position's base row as three bit planes (code 0..4 = A C G T *) + the positions with insertion rows behind them
   uint32_t* cons_len;    // [win]
   unsigned long long* prof;  // HERRO_PROF_BUILD libraries run with HERRO_PROF=1: [kernel * 16 + phase][32 shards] shader cycles, [.. + 15] workgroups (null otherwise)
 };

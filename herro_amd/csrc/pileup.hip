@@ -1233,10 +1233,6 @@ __global__ __launch_bounds__(2 * NW) void k_rows(JobDev J) {
   // (the rules and their derivation: base_row_votes, pileup_core.h — shared with the host so that tests/test_vote_planes.py can run them on every count vector)
   const RowVotes rvt = base_row_votes(c0, c1, tsym, vm);
   const uint32_t supb = lane0 ? rvt.sup : 0u, V0 = rvt.v0, V1 = rvt.v1, V2 = rvt.v2;
-  if (lane0) {
-    uint32_t* __restrict__ vp = J.vpl + (uint64_t)w * 3 * nw + lt;
-    vp[0] = V0; vp[nw] = V1; vp[2 * nw] = V2;
-  }
   // positions of this lane's word that have insertion rows behind them
   uint32_t insmask = 0;
   if (lane0) {
@@ -1248,6 +1244,8 @@ __global__ __launch_bounds__(2 * NW) void k_rows(JobDev J) {
       if (p < win_len && rn - rprev > 1u) insmask |= 1u << k;
       rprev = rn;
     }
+    uint32_t* __restrict__ vp = J.vpl + (uint64_t)w * 4 * nw + lt;   // the votes' three planes + the positions with insertion rows (the decoder's emission loop)
+    vp[0] = V0; vp[nw] = V1; vp[2 * nw] = V2; vp[3 * nw] = insmask;
   }
   PROF_MARK(J, 6, 2);
   // ---- 2: insertion rows.  Index of an insertion row = its ordinal among the window's insertion rows = row - position - 1.
@@ -1890,6 +1888,7 @@ __global__ __launch_bounds__(NT) void k_consensus_p(JobDev J, const uint64_t* su
   extern __shared__ __attribute__((aligned(16))) uint32_t cp_smem[];
   uint32_t* s_rop = cp_smem;                                        // [win_len + 1], padded (RI)
   __shared__ uint32_t s_v[3][HERRO_MAX_WINDOW / 32];
+  __shared__ uint32_t s_im[HERRO_MAX_WINDOW / 32];                   // positions with insertion rows behind them (k_rows)
   __shared__ __attribute__((aligned(16))) uint8_t s_iv[CP_ICAP];
   __shared__ __attribute__((aligned(16))) uint8_t s_out[CP_OCAP];
   __shared__ uint32_t s_wave[NT / 64];
@@ -1912,10 +1911,10 @@ __global__ __launch_bounds__(NT) void k_consensus_p(JobDev J, const uint64_t* su
     const uint32_t* __restrict__ rop = J.row_of_pos2 + wd.pos_off;
 #pragma unroll
     for (int u = 0; u < RL; u++) rv[u] = rop[min(tid + (uint32_t)u * NT, win_len)];
-    uint32_t vv[3] = {0, 0, 0};
+    uint32_t vv[4] = {0, 0, 0, 0};
     if (tid < nw) {
-      const uint32_t* __restrict__ vp = J.vpl + (uint64_t)w * 3 * nw + tid;
-      vv[0] = vp[0]; vv[1] = vp[nw]; vv[2] = vp[2 * nw];
+      const uint32_t* __restrict__ vp = J.vpl + (uint64_t)w * 4 * nw + tid;
+      vv[0] = vp[0]; vv[1] = vp[nw]; vv[2] = vp[2 * nw]; vv[3] = vp[3 * nw];
     }
     constexpr int IL = CP_ICAP / 4 / NT;
     uint32_t iw[IL];
@@ -1927,7 +1926,7 @@ __global__ __launch_bounds__(NT) void k_consensus_p(JobDev J, const uint64_t* su
       const uint32_t p = tid + (uint32_t)u * NT;
       if (p <= win_len) s_rop[RI(p)] = rv[u];
     }
-    if (tid < nw) { s_v[0][tid] = vv[0]; s_v[1][tid] = vv[1]; s_v[2][tid] = vv[2]; }
+    if (tid < nw) { s_v[0][tid] = vv[0]; s_v[1][tid] = vv[1]; s_v[2][tid] = vv[2]; s_im[tid] = vv[3]; }
 #pragma unroll
     for (int u = 0; u < IL; u++) {
       const uint32_t i = tid + (uint32_t)u * NT;
@@ -1982,17 +1981,19 @@ __global__ __launch_bounds__(NT) void k_consensus_p(JobDev J, const uint64_t* su
   uint8_t* __restrict__ dst = out_lds ? s_out : seq;
   if (cnt) {
     uint32_t ir = ia;
-    for (uint32_t k = 0; k < 32u; k++) {
-      const uint32_t p = P + k;
-      if (p >= win_len) break;
+    const uint32_t im = s_im[widx];
+    for (uint32_t m = (keep | im) & vm; m; m &= m - 1u) {   // positions that contribute a base or have insertion rows behind them, in order
+      const uint32_t k = (uint32_t)__ffs((int)m) - 1u, p = P + k;
       if ((keep >> k) & 1u) {
         const uint32_t code = ((v0 >> k) & 1u) | (((v1 >> k) & 1u) << 1);   // not '*': A C G T
         dst[o++] = (uint8_t)"ACGT"[code];
       }
-      const uint32_t ie = s_rop[RI(p + 1)] - p - 1u;   // insertion rows in front of position p + 1
-      for (; ir < ie; ir++) {
-        const uint32_t vt = ivote(ir);
-        if (vt != 4u) dst[o++] = (uint8_t)"ACGT"[vt & 3u];
+      if ((im >> k) & 1u) {   // the rows of a position are consulted only where there are insertion rows (~4 positions of a lane's 32)
+        const uint32_t ie = s_rop[RI(p + 1)] - p - 1u;   // insertion rows in front of position p + 1
+        for (; ir < ie; ir++) {
+          const uint32_t vt = ivote(ir);
+          if (vt != 4u) dst[o++] = (uint8_t)"ACGT"[vt & 3u];
+        }
       }
     }
   }
