@@ -470,7 +470,10 @@ __global__ __launch_bounds__(256) void k_win(JobDev J) {
   cnt.add(ColPlanes{vm, tlo, thi, 0u});  // the target column: always a base on these rows
   PROF_MARK(J, 1, 0);
   uint32_t n_kept = 0;
-  constexpr int UB = 8;    // columns whose loads are in flight together (16: two round trips instead of four, but 152 VGPRs — measured no faster)
+#ifndef HERRO_WIN_UB
+#define HERRO_WIN_UB 8
+#endif
+  constexpr int UB = HERRO_WIN_UB;    // columns whose loads are in flight together (16: two round trips instead of four, but 152 VGPRs — measured no faster in r3; -DHERRO_WIN_UB for an A/B build)
   const uint4* __restrict__ ocol = J.ocol;   // read-only here: uniform addresses -> scalar loads
   uint32_t match[4 * UB];  // first 32 columns: positions where the column shows the target's base (kept for the tallies)
 #pragma unroll
@@ -1118,7 +1121,10 @@ __global__ __launch_bounds__(64) void k_supgather(JobDev J) {
 // planes (vpl), the insertion rows' votes as bytes indexed by insertion-row ordinal (cons_tmp).  No token plane, no row map: the
 // receptive fields are gathered by k_rfq from the informative rows' (position, ordinal) and row_of_pos2; k_tokens builds the planes
 // when somebody asks for them (herro_job_window_copy, the features writer, models with receptive fields above 8 rows).
-constexpr uint32_t RW_ICAP = 2048;   // insertion rows per pass (accumulators in LDS); a window with more takes several passes
+#ifndef HERRO_RW_ICAP
+#define HERRO_RW_ICAP 2048
+#endif
+constexpr uint32_t RW_ICAP = HERRO_RW_ICAP;   // insertion rows per pass (accumulators in LDS); a window with more takes several passes (-DHERRO_RW_ICAP for an A/B build)
 #define RI(p) ((p) + ((p) >> 5))     // lane i walks positions 32 i ..: one pad word per 32 keeps the lanes on different banks
 __host__ __device__ inline size_t rows_lds(uint32_t W) { return (size_t)(W + 2 + ((W + 2) >> 5) + 1) * 4; }
 
@@ -1893,6 +1899,7 @@ __global__ __launch_bounds__(NT) void k_consensus_p(JobDev J, const uint64_t* su
   __shared__ __attribute__((aligned(16))) uint8_t s_out[CP_OCAP];
   __shared__ uint32_t s_wave[NT / 64];
   const uint32_t w = blockIdx.x, tid = threadIdx.x, nw = J.nw;
+  PROF_BEGIN(J);
   const WinDesc wd = J.win[w];
   const uint32_t Lf = J.win_Lf[w], n_kept = J.win_nkept[w], win_len = wd.win_len;
   const uint32_t n_alns = n_kept < 30u ? n_kept : 30u;
@@ -1934,6 +1941,7 @@ __global__ __launch_bounds__(NT) void k_consensus_p(JobDev J, const uint64_t* su
     }
   }
   __syncthreads();
+  PROF_MARK(J, 7, 0);
   // informative rows: the model decides — argmax of the 5 base logits, the LAST maximum wins, NaN is greatest (consensus.rs:136-141)
   const uint32_t nsup = J.win_nsup[w];
   const float* lg = base_logits + sup_off[w] * 5;
@@ -1960,6 +1968,7 @@ __global__ __launch_bounds__(NT) void k_consensus_p(JobDev J, const uint64_t* su
     }
   }
   __syncthreads();
+  PROF_MARK(J, 7, 1);
   // what every lane's 32 positions contribute: base rows that are not '*', insertion rows behind them that are not '*'
   const bool active = tid < nw;
   const uint32_t widx = min(tid, nw - 1u), P = widx << 5;
@@ -1977,6 +1986,7 @@ __global__ __launch_bounds__(NT) void k_consensus_p(JobDev J, const uint64_t* su
   for (uint32_t ir = ia; ir < ib; ir++) cnt += ivote(ir) != 4u ? 1u : 0u;
   uint32_t total;
   uint32_t o = blk_scan<NT>(cnt, &total, s_wave);
+  PROF_MARK(J, 7, 2);
   const bool out_lds = total <= CP_OCAP;
   uint8_t* __restrict__ dst = out_lds ? s_out : seq;
   if (cnt) {
@@ -1997,12 +2007,14 @@ __global__ __launch_bounds__(NT) void k_consensus_p(JobDev J, const uint64_t* su
       }
     }
   }
+  PROF_MARK(J, 7, 3);
   if (out_lds) {
     __syncthreads();
     uint32_t* __restrict__ sq = reinterpret_cast<uint32_t*>(seq);   // row_off is a multiple of 16
     for (uint32_t i = tid; i * 4u < total; i += NT) sq[i] = reinterpret_cast<const uint32_t*>(s_out)[i];
   }
   if (tid == 0) J.cons_len[w] = total;
+  PROF_MARK(J, 7, 4);
 }
 
 }  // namespace
