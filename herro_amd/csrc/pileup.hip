@@ -1874,7 +1874,7 @@ __global__ __launch_bounds__(PC_NT) void k_consensus(JobDev J, const uint64_t* s
   for (uint32_t r = a; r < b; r++) {
     const uint32_t base = tmp[r];
     if (base == 4u) continue;
-    const uint32_t ch = (uint32_t)(uint8_t)"ACGT"[base];
+    const uint32_t ch = ((0x54474341u >> (8u * base)) & 0xffu);
     if ((o & 3u) != 0 && nacc == 0) { seq[o++] = (uint8_t)ch; continue; }   // head: up to the next 4-byte boundary
     acc |= ch << (8 * nacc);
     if (++nacc == 4) { *reinterpret_cast<uint32_t*>(seq + o) = acc; o += 4; acc = 0; nacc = 0; }
@@ -1989,6 +1989,8 @@ __global__ __launch_bounds__(NT) void k_consensus_p(JobDev J, const uint64_t* su
   PROF_MARK(J, 7, 2);
   const bool out_lds = total <= CP_OCAP;
   uint8_t* __restrict__ dst = out_lds ? s_out : seq;
+  // (the letters come out of a register constant: `"ACGT"[code]` is a load from constant memory per base — a dependent global round trip in every
+  // iteration of this loop: 35 k of the kernel's 50 k cycles before, profiles/r5k_phase_cycles.txt)
   if (cnt) {
     uint32_t ir = ia;
     const uint32_t im = s_im[widx];
@@ -1996,13 +1998,13 @@ __global__ __launch_bounds__(NT) void k_consensus_p(JobDev J, const uint64_t* su
       const uint32_t k = (uint32_t)__ffs((int)m) - 1u, p = P + k;
       if ((keep >> k) & 1u) {
         const uint32_t code = ((v0 >> k) & 1u) | (((v1 >> k) & 1u) << 1);   // not '*': A C G T
-        dst[o++] = (uint8_t)"ACGT"[code];
+        dst[o++] = (uint8_t)(0x54474341u >> (8u * code));
       }
       if ((im >> k) & 1u) {   // the rows of a position are consulted only where there are insertion rows (~4 positions of a lane's 32)
         const uint32_t ie = s_rop[RI(p + 1)] - p - 1u;   // insertion rows in front of position p + 1
         for (; ir < ie; ir++) {
           const uint32_t vt = ivote(ir);
-          if (vt != 4u) dst[o++] = (uint8_t)"ACGT"[vt & 3u];
+          if (vt != 4u) dst[o++] = (uint8_t)(0x54474341u >> (8u * (vt & 3u)));
         }
       }
     }
