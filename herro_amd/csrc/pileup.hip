@@ -567,18 +567,25 @@ __global__ __launch_bounds__(256) void k_win(JobDev J) {
     if (nm) atomicAdd(&J.nd[2 * (uint64_t)cls], nm);
     if (ns - nm) atomicAdd(&J.nd[2 * (uint64_t)cls + 1], ns - nm);
   }
-  for (uint32_t i = tid; i < n; i += NT) {
-    const uint32_t oi = wd.ow_begin + i;
-    if (!(in_lds ? s_keep[i] : J.ow_keep[oi])) continue;
-    const float ai = in_lds ? s_acc[i] : J.ow_acc[oi];
-    uint32_t rank = 0;
-    for (uint32_t j = 0; j < n; j++) {
-      if (!(in_lds ? s_keep[j] : J.ow_keep[wd.ow_begin + j])) continue;
-      const float aj = in_lds ? s_acc[j] : J.ow_acc[wd.ow_begin + j];
-      if (aj > ai || (aj == ai && j < i)) rank++;
+  // (two instantiations: a choice between an LDS and a global array made per ACCESS — `in_lds ? s_acc[j] : J.ow_acc[..]` — compiles to a select of
+  // pointers and a flat load, 2 n^2 of them here; r5)
+  auto rank_all = [&](auto lds) {
+    constexpr bool LDS = decltype(lds)::value;
+    for (uint32_t i = tid; i < n; i += NT) {
+      const uint32_t oi = wd.ow_begin + i;
+      const uint32_t ki = LDS ? (uint32_t)s_keep[i] : (uint32_t)J.ow_keep[oi];
+      if (!ki) continue;
+      const float ai = LDS ? s_acc[i] : J.ow_acc[oi];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < n; j++) {
+        const uint32_t kj = LDS ? (uint32_t)s_keep[j] : (uint32_t)J.ow_keep[wd.ow_begin + j];
+        const float aj = LDS ? s_acc[j] : J.ow_acc[wd.ow_begin + j];
+        if (kj && (aj > ai || (aj == ai && j < i))) rank++;
+      }
+      J.slot_ow[wd.ow_begin + rank] = oi;
     }
-    J.slot_ow[wd.ow_begin + rank] = oi;
-  }
+  };
+  if (in_lds) rank_all(std::true_type{}); else rank_all(std::false_type{});
   if (tid == 0) J.win_nkept[w] = n_kept;
   PROF_MARK(J, 1, 3);
 }
@@ -1353,7 +1360,8 @@ __global__ __launch_bounds__(2 * NW) void k_rows(JobDev J) {
       const uint32_t n_ins = s_rop[RI(p + 1)] - rp - 1u;
       for (uint32_t j = 0; j < n_ins; j++) {
         const uint32_t ir = rp - p + j;
-        const uint32_t fl = iv_lds ? (uint32_t)s_iv[ir] : (uint32_t)J.cons_tmp[wd.row_off + ir];
+        uint32_t fl;   // (explicit branches: a select between the two arrays is a flat load)
+        if (iv_lds) fl = (uint32_t)s_iv[ir]; else fl = (uint32_t)J.cons_tmp[wd.row_off + ir];
         if (fl & 0x80u) {
           J.sup_row[wd.row_off + kk] = rp + 1u + j;
           J.sup_pi[wd.row_off + kk] = p | ((j + 1u) << 16);
@@ -1981,33 +1989,42 @@ __global__ __launch_bounds__(NT) void k_consensus_p(JobDev J, const uint64_t* su
     ia = s_rop[RI(P)] - P;
     ib = s_rop[RI(pe)] - pe;
   }
-  auto ivote = [&](uint32_t ir) -> uint32_t { return (uint32_t)(iv_lds ? s_iv[ir] : giv[ir]) & 7u; };
   uint32_t cnt = (uint32_t)__popc(keep);
-  for (uint32_t ir = ia; ir < ib; ir++) cnt += ivote(ir) != 4u ? 1u : 0u;
+  if (iv_lds) { for (uint32_t ir = ia; ir < ib; ir++) cnt += ((uint32_t)s_iv[ir] & 7u) != 4u ? 1u : 0u; }
+  else { for (uint32_t ir = ia; ir < ib; ir++) cnt += ((uint32_t)giv[ir] & 7u) != 4u ? 1u : 0u; }
   uint32_t total;
   uint32_t o = blk_scan<NT>(cnt, &total, s_wave);
   PROF_MARK(J, 7, 2);
   const bool out_lds = total <= CP_OCAP;
-  uint8_t* __restrict__ dst = out_lds ? s_out : seq;
   // (the letters come out of a register constant: `"ACGT"[code]` is a load from constant memory per base — a dependent global round trip in every
-  // iteration of this loop: 35 k of the kernel's 50 k cycles before, profiles/r5k_phase_cycles.txt)
-  if (cnt) {
+  // iteration of this loop; and the destination / the insertion votes must be LDS or global at COMPILE time: a pointer chosen at run time makes every
+  // access a flat one, ~800 cycles per base: 35 k, then 28 k of the kernel's 50 k cycles, profiles/r5k_, r5l_phase_cycles.txt)
+  auto emit = [&](auto fast) {
+    constexpr bool FAST = decltype(fast)::value;   // corrected bases staged in LDS and the insertion votes read from LDS (nearly every window)
     uint32_t ir = ia;
     const uint32_t im = s_im[widx];
     for (uint32_t m = (keep | im) & vm; m; m &= m - 1u) {   // positions that contribute a base or have insertion rows behind them, in order
       const uint32_t k = (uint32_t)__ffs((int)m) - 1u, p = P + k;
       if ((keep >> k) & 1u) {
         const uint32_t code = ((v0 >> k) & 1u) | (((v1 >> k) & 1u) << 1);   // not '*': A C G T
-        dst[o++] = (uint8_t)(0x54474341u >> (8u * code));
+        const uint8_t ch = (uint8_t)(0x54474341u >> (8u * code));
+        if (FAST) s_out[o++] = ch; else if (out_lds) s_out[o++] = ch; else seq[o++] = ch;
       }
       if ((im >> k) & 1u) {   // the rows of a position are consulted only where there are insertion rows (~4 positions of a lane's 32)
         const uint32_t ie = s_rop[RI(p + 1)] - p - 1u;   // insertion rows in front of position p + 1
         for (; ir < ie; ir++) {
-          const uint32_t vt = ivote(ir);
-          if (vt != 4u) dst[o++] = (uint8_t)(0x54474341u >> (8u * (vt & 3u)));
+          uint32_t vt;
+          if (FAST) vt = (uint32_t)s_iv[ir] & 7u; else { if (iv_lds) vt = (uint32_t)s_iv[ir] & 7u; else vt = (uint32_t)giv[ir] & 7u; }
+          if (vt != 4u) {
+            const uint8_t ch = (uint8_t)(0x54474341u >> (8u * (vt & 3u)));
+            if (FAST) s_out[o++] = ch; else if (out_lds) s_out[o++] = ch; else seq[o++] = ch;
+          }
         }
       }
     }
+  };
+  if (cnt) {
+    if (out_lds && iv_lds) emit(std::true_type{}); else emit(std::false_type{});
   }
   PROF_MARK(J, 7, 3);
   if (out_lds) {
