@@ -1897,7 +1897,9 @@ __global__ __launch_bounds__(PC_NT) void k_consensus(JobDev J, const uint64_t* s
 // first.  No per-row array is read or written.
 constexpr uint32_t CP_ICAP = 4096;   // insertion-row votes staged in LDS (a window with more works on the global bytes)
 constexpr uint32_t CP_OCAP = 6144;   // corrected bases staged in LDS for coalesced stores (more: byte stores)
-template <int NT>
+// SPW threads per word of 32 positions: each takes a segment of 32 / SPW positions through the (serial, dependent) emission loop — with one lane per
+// word that loop was 25 k of the kernel's 40 k cycles (profiles/r5m_phase_cycles.txt)
+template <int NT, int SPW>
 __global__ __launch_bounds__(NT) void k_consensus_p(JobDev J, const uint64_t* sup_off, const float* base_logits) {
   extern __shared__ __attribute__((aligned(16))) uint32_t cp_smem[];
   uint32_t* s_rop = cp_smem;                                        // [win_len + 1], padded (RI)
@@ -1921,7 +1923,7 @@ __global__ __launch_bounds__(NT) void k_consensus_p(JobDev J, const uint64_t* su
   uint8_t* __restrict__ giv = J.cons_tmp + wd.row_off;
   {
     // all loads of the prologue in flight together (rows of the positions, vote planes, insertion-row votes)
-    constexpr int RL = 17;   // NT = twice the plane words: 256 threads x 17 cover 4097 positions, 512 x 17 cover 8193
+    constexpr int RL = SPW == 4 ? 9 : 17;   // NT * RL > positions: 512 threads x 9 cover windows of 4096 (SPW 4), x 17 of 8192 (SPW 2)
     uint32_t rv[RL];
     const uint32_t* __restrict__ rop = J.row_of_pos2 + wd.pos_off;
 #pragma unroll
@@ -1978,15 +1980,17 @@ __global__ __launch_bounds__(NT) void k_consensus_p(JobDev J, const uint64_t* su
   __syncthreads();
   PROF_MARK(J, 7, 1);
   // what every lane's 32 positions contribute: base rows that are not '*', insertion rows behind them that are not '*'
-  const bool active = tid < nw;
-  const uint32_t widx = min(tid, nw - 1u), P = widx << 5;
-  const uint32_t vm = active ? mask_range(0, (int32_t)win_len - (int32_t)P) : 0u;
+  constexpr uint32_t SEG = 32u / SPW;                       // positions per thread
+  const bool active = tid < nw * SPW;
+  const uint32_t widx = min(tid / SPW, nw - 1u), sub = tid % SPW, P = widx << 5;   // P: first position of the thread's WORD (bit k of a mask = position P + k)
+  const uint32_t segm = (SEG == 32u ? 0xffffffffu : ((1u << SEG) - 1u)) << (sub * SEG);
+  const uint32_t vm = active ? mask_range(0, (int32_t)win_len - (int32_t)P) & segm : 0u;
   const uint32_t v0 = s_v[0][widx], v1 = s_v[1][widx], v2 = s_v[2][widx];
   const uint32_t keep = vm & ~(v2 & ~v1 & ~v0);
-  uint32_t ia = 0, ib = 0;   // insertion rows [ia, ib) lie behind this lane's positions
+  uint32_t ia = 0, ib = 0;   // insertion rows [ia, ib) lie behind this thread's positions
   if (vm) {
-    const uint32_t pe = min(P + 32u, win_len);
-    ia = s_rop[RI(P)] - P;
+    const uint32_t ps = P + sub * SEG, pe = min(ps + SEG, win_len);
+    ia = s_rop[RI(ps)] - ps;
     ib = s_rop[RI(pe)] - pe;
   }
   uint32_t cnt = (uint32_t)__popc(keep);
@@ -2042,8 +2046,8 @@ void launch_consensus(const JobDev& J, const uint64_t* sup_off, const float* bas
   if (!J.n_win) return;
   KT_BEGIN(tm, "consensus", st);
   if (!lean) hipLaunchKernelGGL(k_consensus, dim3(J.n_win), dim3(PC_NT), 0, st, J, sup_off, base_logits);
-  else if (J.nw <= 128) hipLaunchKernelGGL(k_consensus_p<256>, dim3(J.n_win), dim3(256), rows_lds(J.window_size), st, J, sup_off, base_logits);   // twice the plane words: the extra threads halve the staging and the patches
-  else hipLaunchKernelGGL(k_consensus_p<512>, dim3(J.n_win), dim3(512), rows_lds(J.window_size), st, J, sup_off, base_logits);
+  else if (J.nw <= 128) hipLaunchKernelGGL((k_consensus_p<512, 4>), dim3(J.n_win), dim3(512), rows_lds(J.window_size), st, J, sup_off, base_logits);   // four threads per word of 32 positions
+  else hipLaunchKernelGGL((k_consensus_p<512, 2>), dim3(J.n_win), dim3(512), rows_lds(J.window_size), st, J, sup_off, base_logits);
   KT_END(tm, st);
 }
 
