@@ -1813,7 +1813,7 @@ __device__ __forceinline__ void rf_slot(const JobDev& J, const CTab* __restrict_
 
 __global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const uint64_t* __restrict__ sup_off, uint8_t* __restrict__ rf, uint64_t cap, uint32_t have_nr) {
   __shared__ __attribute__((aligned(16))) CTab s_ct[32];
-  const uint32_t w = blockIdx.x, tid = threadIdx.x;
+  const uint32_t w = gridDim.x - 1u - blockIdx.x, tid = threadIdx.x;   // back to front: k_rows has just walked the windows front to back — its last windows' plane records are the cached ones
   PROF_BEGIN(J);
   const uint32_t nsup = J.win_nsup[w], Lf = J.win_Lf[w];
   if (!nsup || sup_off[w] + nsup > cap) return;   // (a launch in front of the host's count of the informative rows: the buffer was sized by an estimate)
