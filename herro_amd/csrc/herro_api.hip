@@ -189,6 +189,7 @@ struct herro_ctx {
   std::vector<Arena> free_dev, free_pin, free_small;   // free_small: the buffers a job needs only once its counts are known (logits, batch descriptors)
   std::atomic<uint32_t> live_jobs{0};   // herro_job_create may run on another thread than the context's execution calls
   uint64_t reads_gen = 0;   // bumped by herro_set_reads: a job built on an older store refuses to run
+  uint32_t n_sib_retry = 0;        // model passes repeated without sibling tiles (sib_retry)
   std::atomic<int> n_pending{0};   // jobs of this context that are featurized and not yet inferred: > 0 when herro_job_featurize is called means the caller pipelines its jobs
   uint64_t n_featurize = 0, n_infer = 0;   // calls so far: a context that featurizes job after job without ever inferring (the `herro features` path) stops gathering receptive fields ahead of time
   std::atomic<int> create_code{0};   // HERRO_E_* of the last herro_job_create that returned NULL (herro_job_create_status)
@@ -247,6 +248,9 @@ struct herro_job {
   uint32_t rf_fused_half = 0, rf_total = 0;
   bool pending = false;         // counted in herro_ctx::n_pending
   bool rf_fused_used = false;   // herro_job_infer read the records k_rows gathered (herro_debug_job_rf_fused)
+  bool no_sib = false;          // a sibling tile of this job timed out once: its windows above 64 rows go layer by layer from now on (sib_retry)
+  uint32_t last_batch_size = 0; // arguments of the last herro_job_infer (sib_retry repeats it)
+  int last_batch_mode = 0;
   std::vector<uint32_t> h_rfbase;
   std::vector<uint64_t> rf_base;   // per window: first record of its receptive fields in d_rfq (whichever kernel wrote them), valid after herro_job_infer
   bool lean = false;         // the last featurize pass ran the lean path (k_rows): votes in position space, no row map
@@ -1919,6 +1923,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   if (!ctx->has_model) { ctx->err = "no model loaded"; return HERRO_E_NO_MODEL; }
   ProfSpan span_(ctx, "infer");
   ctx->n_infer++;
+  job->last_batch_size = batch_size; job->last_batch_mode = batch_mode;
   if (job->pending) { job->pending = false; ctx->n_pending--; }
   int rc = job_sync(job);
   if (rc) return rc;
@@ -1991,7 +1996,7 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   std::vector<Offs> offs;
   uint32_t max_tok = 0, max_tiles_b = 0;
   const bool fused_mode = ctx->precision == 1 || ctx->precision >= 4;
-  const uint32_t tok_cap = fused_tok_cap(ctx);   // most informative rows of a window on the fused stack
+  const uint32_t tok_cap = job->no_sib ? FUSED_MAX_TOK : fused_tok_cap(ctx);   // most informative rows of a window on the fused stack
   const int qmode = ctx->precision >= 4 ? model_h_half_tiles(ctx->M) : 0;
   for (auto& g : groups) {
     for (int part = 0; part < 2; part++) {  // 0: windows that fit a fused tile (all of them in the unfused modes), 1: the rest
@@ -2207,6 +2212,25 @@ int herro_job_window_copy(herro_job* job, uint32_t w, int encoded, uint8_t* base
   return HERRO_OK;
 }
 
+// A sibling tile that never saw its group (check_sib) is not the caller's problem: the job's model pass — and its consensus pass, if that
+// had run — is repeated ONCE with its windows above 64 informative rows on the layer-by-layer kernels, which have no cross-workgroup wait
+// (ADVICE r4).  The error word belongs to the context: with several jobs in flight the one that fetches first repeats its pass, whether
+// or not the stale keys were its own — a repeated pass is only time.  Returns check_sib's code when the repeat cannot run or fails too.
+static int sib_retry(herro_job* job, int rc_sib) {
+  herro_ctx* ctx = job->ctx;
+  if (job->no_sib || !job->last_batch_size) return rc_sib;
+  const bool had_consensus = job->consensus_done;
+  const std::string why = ctx->err.c_str();
+  job->no_sib = true;
+  ctx->n_sib_retry++;
+  int rc = herro_job_infer(job, job->last_batch_size, job->last_batch_mode);
+  if (!rc && had_consensus) rc = herro_job_consensus(job);
+  if (rc) { const std::string second = ctx->err.c_str(); ctx->err = why + "; the repeat without sibling tiles failed: " + second; return rc; }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->timer.collect();
+  return check_sib(ctx);
+}
+
 static int logits_to_host(herro_job* job) {
   herro_ctx* ctx = job->ctx;
   if (!job->inferred) { ctx->err = "herro_job_infer has not run"; return HERRO_E_STATE; }
@@ -2217,7 +2241,7 @@ static int logits_to_host(herro_job* job) {
   job->h_base.resize(tot * 5);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->timer.collect();
-  if (int rc = check_sib(ctx)) return rc;
+  if (int rc = check_sib(ctx)) if ((rc = sib_retry(job, rc))) return rc;
   if (tot) {
     HIP_TRY(ctx, hipMemcpy(job->h_info.data(), job->d_info, tot * 4, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(job->h_base.data(), job->d_base, tot * 20, hipMemcpyDeviceToHost));
@@ -2244,11 +2268,15 @@ static int consensus_to_host(herro_job* job) {
   // device -> the job's pinned arena: no staging copy, no page pinning by the runtime at call time (a pageable destination
   // made the runtime lock user pages under the mm lock, which stalled the page faults of whoever was building the next job:
   // 40 ms spikes in the other feeder's herro_job_create)
-  if (n) HIP_TRY(ctx, hipMemcpyAsync(job->h_cons_len, job->J.cons_len, n * 4ull, hipMemcpyDeviceToHost, ctx->stream));
-  if (job->row_elems) HIP_TRY(ctx, hipMemcpyAsync(job->h_cons_seq, job->J.cons_seq, job->row_elems, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->timer.collect();
-  if (int rc = check_sib(ctx)) return rc;
+  for (int attempt = 0;; attempt++) {
+    if (n) HIP_TRY(ctx, hipMemcpyAsync(job->h_cons_len, job->J.cons_len, n * 4ull, hipMemcpyDeviceToHost, ctx->stream));
+    if (job->row_elems) HIP_TRY(ctx, hipMemcpyAsync(job->h_cons_seq, job->J.cons_seq, job->row_elems, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->timer.collect();
+    int rc = check_sib(ctx);
+    if (!rc) break;
+    if (attempt || (rc = sib_retry(job, rc))) return rc;   // repeated once: copy again what the second pass decoded
+  }
   job->consensus_on_host = true;
   return HERRO_OK;
 }
@@ -2642,6 +2670,16 @@ int herro_debug_set_featurize_planes(herro_ctx* ctx, int on) {
 
 // 1: the last herro_job_infer read the receptive fields k_rows gathered behind featurize; 0: k_rfq gathered them (a window above 256 informative
 // rows, a buffer sized too small by the estimate of a first pass, the planes path, HERRO_RF_FUSED=0)
+// Test hooks of the sibling-tile recovery: raise the context's sticky error word as a tile that timed out would (layer 0), and count the repeats.
+int herro_debug_sib_fault(herro_ctx* ctx) {
+  if (!ctx) return HERRO_E_INVALID;
+  if (int rc = ensure_sib(ctx, 1)) return rc;
+  const uint32_t one = 1;
+  HIP_TRY(ctx, hipMemcpyAsync((uint32_t*)ctx->sib_flag + ctx->sib_cap, &one, 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return HERRO_OK;
+}
+int herro_debug_sib_retries(const herro_ctx* ctx) { return ctx ? (int)ctx->n_sib_retry : HERRO_E_INVALID; }
 int herro_debug_job_rf_fused(const herro_job* job) { return job && job->inferred ? (job->rf_fused_used ? 1 : 0) : HERRO_E_STATE; }
 
 // the receptive-field records the model read for window w (valid once herro_job_infer has run with a compact receptive field)

@@ -158,7 +158,7 @@ constexpr int CM_NT = 256;
 constexpr size_t CONV_M_SHM = (size_t)48 * 1024 + 128 * 4 + 32 * 16 + 256 * 4;
 
 template <int NB, int WPS, bool RF>   // RF: the cells come as 16-byte receptive-field records (B.rf_q); else from the token / quality planes
-__global__ __launch_bounds__(CM_NT, WPS) void k_conv_m(ModelDev M, BatchDev B, ModelScratch S, uint32_t n_rows, uint32_t n_units) {
+__global__ __launch_bounds__(CM_NT, WPS) void k_conv_m(ModelDev M, BatchDev B, ModelScratch S, uint32_t n_rows, uint32_t n_units, uint32_t unit0) {   // units [unit0, n_units) of 16 pairs; n_rows: pairs of the launch group
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4* s_w2 = reinterpret_cast<uint4*>(smem);                     // conv2 weights in fragment order: fragment f, lane l at [f * 64 + l]
   float* s_b2 = reinterpret_cast<float*>(smem + 48 * 1024);
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(CM_NT, WPS) void k_conv_m(ModelDev M, BatchDev B, M
 
   const uint32_t odd = fg & 1u, mq_hi = odd ? 0xffffu : 0u, mq_lo = fg == 1u ? 0xffffu : 0u;
   const uint32_t stride = gridDim.x * (CM_NT / 64);
-  uint32_t unit = blockIdx.x * (CM_NT / 64) + wave;
+  uint32_t unit = unit0 + blockIdx.x * (CM_NT / 64) + wave;
   TokCv mt1[NB], mt2[NB];   // records of the pairs of unit + stride, unit + 2 stride
   Cells cur[NB];
   Raw raw[NB];
@@ -1156,32 +1156,45 @@ void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S,
   KT_BEGIN(tm, "build_tokens", st);
   hipLaunchKernelGGL(k_build_tokens_h, dim3(B.n_win), dim3(64), 0, st, B, S);
   KT_END(tm, st);
-  {
-    const uint32_t n_rows = N * HERRO_ROWS;
-    KT_BEGIN(tm, "conv_fused", st);
-    {   // one block of 16 pairs per step, three workgroups per compute unit
-      const uint32_t n_units = (n_rows + 15) / 16;
-      if (B.rf_q) {
-        opt_in_lds(reinterpret_cast<const void*>(k_conv_m<1, 3, true>), CONV_M_SHM);
-        hipLaunchKernelGGL((k_conv_m<1, 3, true>), dim3(std::min<uint32_t>((n_units + 3) / 4, 768u)), dim3(CM_NT), CONV_M_SHM, st, M, B, S, n_rows, n_units);
-      } else {
-        opt_in_lds(reinterpret_cast<const void*>(k_conv_m<1, 3, false>), CONV_M_SHM);
-        hipLaunchKernelGGL((k_conv_m<1, 3, false>), dim3(std::min<uint32_t>((n_units + 3) / 4, 768u)), dim3(CM_NT), CONV_M_SHM, st, M, B, S, n_rows, n_units);
-      }
+  // conv and FC over the whole launch group, or (A/B builds, HERRO_CONV_CHUNK = tokens per chunk, a multiple of 16) chunk by chunk — conv(k), FC(k), conv(k + 1) ... —
+  // so that a chunk's y2 (7936 B per token) is read back while it can still sit in the 256 MB memory-side cache (measured: profiles/r5_ab_runs.json r5p)
+  static const uint32_t chunk_tok = (uint32_t)std::max(0, ab_env("HERRO_CONV_CHUNK", 0)) & ~15u;
+  static const int force_g = ab_env("HERRO_FC_G", 0);
+  static const uint32_t n_cu = [] { int dev = 0, c = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return (uint32_t)std::max(c, 1); }();
+  const uint32_t n_rows = N * HERRO_ROWS;
+  auto conv = [&](uint32_t t0, uint32_t t1) {   // tokens [t0, t1): t0 a multiple of 16 (so that its first pair opens a unit of 16)
+    const uint32_t unit0 = t0 * HERRO_ROWS / 16, n_units = (std::min(t1 * HERRO_ROWS, n_rows) + 15) / 16, nu = n_units - unit0;
+    // one block of 16 pairs per step, three workgroups per compute unit
+    if (B.rf_q) {
+      opt_in_lds(reinterpret_cast<const void*>(k_conv_m<1, 3, true>), CONV_M_SHM);
+      hipLaunchKernelGGL((k_conv_m<1, 3, true>), dim3(std::min<uint32_t>((nu + 3) / 4, 768u)), dim3(CM_NT), CONV_M_SHM, st, M, B, S, n_rows, n_units, unit0);
+    } else {
+      opt_in_lds(reinterpret_cast<const void*>(k_conv_m<1, 3, false>), CONV_M_SHM);
+      hipLaunchKernelGGL((k_conv_m<1, 3, false>), dim3(std::min<uint32_t>((nu + 3) / 4, 768u)), dim3(CM_NT), CONV_M_SHM, st, M, B, S, n_rows, n_units, unit0);
     }
+  };
+  auto fc = [&](uint32_t t0, uint32_t t1) {
+    // tile height: the one that leaves the busiest compute unit the fewest rows (two workgroups fit a unit; HERRO_FC_G forces it in A/B builds)
+    const uint32_t n = t1 - t0, lda = HERRO_ROWS * h.c2;
+    auto busiest = [&](uint32_t rows) { const uint32_t wg = (n + rows - 1) / rows; return (uint64_t)((wg + n_cu - 1) / n_cu) * rows + (wg > 2 * n_cu ? 1u << 20 : 0u); };
+    const int g = force_g == 3 || force_g == 4 ? force_g : (busiest(96) < busiest(128) ? 3 : 4);
+    const uint16_t* A = S.y2_hi + (uint64_t)t0 * lda;
+    float* C = S.x + (uint64_t)t0 * h.d_model;
+    if (g == 3) hipLaunchKernelGGL(k_fc_r<3>, dim3((n + 95) / 96), dim3(512), FC_R_SHM, st, A, lda, M.fc, C, h.d_model, n);
+    else hipLaunchKernelGGL(k_fc_r<4>, dim3((n + 127) / 128), dim3(512), FC_R_SHM, st, A, lda, M.fc, C, h.d_model, n);
+  };
+  if (chunk_tok && N > chunk_tok) {
+    KT_BEGIN(tm, "conv_fused", st);   // (the span carries both kernels of every chunk)
+    for (uint32_t t0 = 0; t0 < N; t0 += chunk_tok) { conv(t0, std::min(N, t0 + chunk_tok)); fc(t0, std::min(N, t0 + chunk_tok)); }
+    KT_END(tm, st);
+  } else {
+    KT_BEGIN(tm, "conv_fused", st);
+    conv(0, N);
+    KT_END(tm, st);
+    KT_BEGIN(tm, "fc_gemm", st);
+    fc(0, N);
     KT_END(tm, st);
   }
-  KT_BEGIN(tm, "fc_gemm", st);
-  {
-    // tile height: the one that leaves the busiest compute unit the fewest rows (two workgroups fit a unit; HERRO_FC_G forces it in A/B builds)
-    static const int force_g = ab_env("HERRO_FC_G", 0);
-    static const uint32_t n_cu = [] { int dev = 0, c = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev); return (uint32_t)std::max(c, 1); }();
-    auto busiest = [&](uint32_t rows) { const uint32_t wg = (N + rows - 1) / rows; return (uint64_t)((wg + n_cu - 1) / n_cu) * rows + (wg > 2 * n_cu ? 1u << 20 : 0u); };
-    const int g = force_g == 3 || force_g == 4 ? force_g : (busiest(96) < busiest(128) ? 3 : 4);
-    if (g == 3) hipLaunchKernelGGL(k_fc_r<3>, dim3((N + 95) / 96), dim3(512), FC_R_SHM, st, S.y2_hi, HERRO_ROWS * h.c2, M.fc, S.x, h.d_model, N);
-    else hipLaunchKernelGGL(k_fc_r<4>, dim3((N + 127) / 128), dim3(512), FC_R_SHM, st, S.y2_hi, HERRO_ROWS * h.c2, M.fc, S.x, h.d_model, N);
-  }
-  KT_END(tm, st);
   KT_BEGIN(tm, "layers_fused", st);   // one span: the 64-token tiles (windows of 33..64 informative rows and what shares their tiles), then the 32-token ones
   auto launch = [&](auto kern, uint32_t n_tiles, int tokens) {
     opt_in_lds(reinterpret_cast<const void*>(kern), layers_p_shm(tokens));

@@ -1,0 +1,80 @@
+"""-m gpu: a sibling tile that times out is not the caller's problem.
+
+Windows above 64 informative rows run on sibling tiles of the fused f16 stack, which wait for each other's keys across
+workgroups; a tile that gives up leaves a sticky error word on the context.  The fetch that finds it repeats the job's model
+pass (and its consensus pass) once with those windows on the layer-by-layer kernels, and the context stays usable.  The
+fault is injected through herro_debug_sib_fault (the word a timed-out tile writes); both paths are held to the same 1e-3
+contract against the twin elsewhere, so here they are compared with each other."""
+import numpy as np
+import pytest
+
+import gpu_common as G
+from herro_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b):
+    if len(a) != len(b):
+        return abs(len(a) - len(b)) <= 2
+    return sum(x != y for x, y in zip(a, b)) <= max(1, len(a) // 1000)
+
+
+def test_fetch_repeats_the_pass_without_sibling_tiles():
+    sb = synth.generate(2, 2 * 4096, 32, seed=synth.SEED + 71, p_snp=0.03)
+    c = G.ctx()
+    G.load_synth(c, sb)
+    c.set_precision(4)
+    ids = [f"read{t}" for t in range(sb.n_targets)]
+    job = api.job_from_synth(c, sb, 4096)
+    try:
+        job.featurize(); job.infer(64, 1); job.consensus()
+        nsup = [job.info(w).n_supported for w in range(job.n_windows)]
+        assert max(nsup) > 64, "the case needs a window on sibling tiles"
+        fa0 = job.fasta(ids)
+        lg0 = [job.logits(w) for w in range(job.n_windows)]
+        r0 = c.sib_retries()
+
+        # the corrected-bases fetch finds the word: model + consensus repeated, same answer within the two paths' tolerance
+        job.featurize(); job.infer(64, 1); job.consensus()
+        c.sib_fault()
+        fa1 = job.fasta(ids)
+        assert c.sib_retries() == r0 + 1
+        a = [ln for ln in fa0.splitlines()]
+        b = [ln for ln in fa1.splitlines()]
+        assert len(a) == len(b) and all(x == y for x, y in zip(a[::2], b[::2]))
+        assert all(_close(x, y) for x, y in zip(a[1::2], b[1::2]))
+        worst = 0.0
+        for w in range(job.n_windows):
+            if not nsup[w]:
+                continue
+            i1, b1 = job.logits(w)
+            worst = max(worst, float(np.abs(i1 - lg0[w][0]).max()), float(np.abs(b1 - lg0[w][1]).max()))
+        print(f"sibling tiles vs layer-by-layer after the repeat: max abs logit difference {worst:.3e}")
+        assert worst <= 2e-3
+        # small windows ran the same fused kernels both times: bit-identical
+        for w in range(job.n_windows):
+            if 0 < nsup[w] <= 64:
+                assert np.array_equal(job.logits(w)[1], lg0[w][1])
+                break
+
+        # the logits fetch finds it too; the job is past its one repeat, so a second fault on it is reported, once, and the context goes on
+        job2 = api.job_from_synth(c, sb, 4096)
+        try:
+            job2.featurize(); job2.infer(64, 1)
+            c.sib_fault()
+            i2, b2 = job2.logits(int(np.argmax(nsup)))
+            assert c.sib_retries() == r0 + 2
+            assert np.abs(b2 - job.logits(int(np.argmax(nsup)))[1]).max() == 0   # both on the layer-by-layer path now
+            job2.infer(64, 1)
+            c.sib_fault()
+            with pytest.raises(api.HerroError):
+                job2.logits(0)
+            job2.infer(64, 1)
+            job2.logits(0)                      # the word was cleared when it was reported
+            assert c.sib_retries() == r0 + 2
+        finally:
+            job2.close()
+    finally:
+        job.close()
+        c.set_precision(api.DEFAULT_PRECISION)
