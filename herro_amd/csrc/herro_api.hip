@@ -169,6 +169,7 @@ struct herro_ctx {
   bool precision_set = false;   // herro_set_precision was called: herro_load_model keeps the caller's choice
   float wmax = 0.f;             // largest |weight| of the loaded model
   float calib_err = -1.f;       // max |logit difference| mode 4 vs mode 0 (f32 MFMA) on the calibration batch (-1: not run)
+  float calib_err6 = -1.f;      // ... mode 6 vs mode 0
   std::string calib_note;
   ModelScratch S{};
   uint32_t scratch_cap = 0;
@@ -586,7 +587,7 @@ static void run_model(herro_ctx* ctx, const BatchDev& B, bool tiled) {
   if (B.n_tok == 0) return;
   const int p = ctx->precision;
   if (!tiled) { launch_model(ctx->M, B, ctx->S, (p == 1 || p >= 4) ? 3 : p, ctx->stream, &ctx->timer); return; }
-  if (p >= 4) launch_model_h(ctx->M, B, ctx->S, p == 4 ? 2 : 1, ctx->stream, &ctx->timer);
+  if (p >= 4) launch_model_h(ctx->M, B, ctx->S, p == 4 ? 2 : (p == 6 ? 3 : 1), ctx->stream, &ctx->timer);
   else launch_model(ctx->M, B, ctx->S, p, ctx->stream, &ctx->timer);
 }
 
@@ -924,6 +925,24 @@ float h_f16f(uint16_t h) {
   return f;
 }
 
+// f32 -> OCP e4m3 (e4m3fn: bias 7, 3 fraction bits, subnormals in units of 2^-9, largest finite 448 = 0x7e, no infinities), round to nearest even,
+// SATURATING (the weights of precision 6 are scaled below 448 first; the device's own v_cvt_pk_fp8_f32 turns >= 480 into NaN).  Values the
+// device conversion produced for the same inputs: tools/mx_probe.hip (1 -> 0x38, 0.1 -> 0x1d, 3.3 -> 0x45, 0.0176 -> 0x09, 2^-9 -> 0x01, 2^-10 -> 0).
+uint8_t f32_to_e4m3(float f) {
+  const uint8_t sign = std::signbit(f) ? 0x80u : 0u;
+  const float a = std::fabs(f);
+  if (!(a == a)) return (uint8_t)(sign | 0x7fu);           // NaN
+  if (a >= 448.f) return (uint8_t)(sign | 0x7eu);
+  if (a < std::ldexp(1.f, -6)) return (uint8_t)(sign | (uint8_t)std::nearbyint(std::ldexp(a, 9)));   // subnormal (8 -> 0x08 = the smallest normal, as it must)
+  int ex;
+  const float m = std::frexp(a, &ex);                      // a = m * 2^ex, m in [0.5, 1)
+  int q = (int)std::nearbyint(std::ldexp(m, 4)) - 8;        // fraction of 1.fff in eighths, ties to even
+  int e = ex - 1 + 7;
+  if (q == 8) { q = 0; e++; }
+  const int code = (e << 3) | q;
+  return (uint8_t)(sign | (uint8_t)std::min(code, 0x7e));
+}
+
 const float* up_f32(herro_ctx* ctx, const std::vector<float>& v, hipError_t& e) {
   float* p = dev_alloc_copy(v, ctx->stream, e);
   if (p) ctx->model_allocs.push_back(p);
@@ -1025,6 +1044,28 @@ int herro_load_model(herro_ctx* ctx, const char* path) {
         uint16_t* d3 = dev_alloc_copy(ph, ctx->stream, e); ctx->model_allocs.push_back(d3);
         w.ph16 = d3;
       }
+      if (N % 32 == 0 && K % 128 == 0) {   // e4m3 copy for the remainder term of precision 6 (Weight::p8): W * 2^sw, sw the largest power of two that keeps max |W| * 2^sw <= 448
+        float wmax = 0.f;
+        for (float x : wt) wmax = std::max(wmax, std::fabs(x));
+        int sw = 0;
+        if (wmax > 0.f && std::isfinite(wmax)) { int ex; (void)std::frexp(448.0 / (double)wmax, &ex); sw = std::max(-32, std::min(32, ex - 1)); }
+        std::vector<uint8_t> p8(wt.size());
+        const uint32_t ns = K / 128;
+        const float mul = std::ldexp(1.0f, sw);
+        for (uint32_t n32 = 0; n32 < N / 32; n32++)
+          for (uint32_t jt = 0; jt < 2; jt++)
+            for (uint32_t st = 0; st < ns; st++)
+              for (uint32_t hf = 0; hf < 2; hf++)
+                for (uint32_t lane = 0; lane < 64; lane++) {
+                  const uint32_t fr = lane & 15, fg = lane >> 4;
+                  const size_t src = (size_t)(n32 * 32 + 8 * (fr >> 2) + 4 * jt + (fr & 3)) * K + st * 128 + fg * 32 + hf * 16;
+                  const size_t dst = ((((((size_t)n32 * 2 + jt) * ns + st) * 2 + hf) * 64) + lane) * 16;
+                  for (uint32_t j = 0; j < 16; j++) p8[dst + j] = f32_to_e4m3(wt[src + j] * mul);
+                }
+        uint8_t* d8 = dev_alloc_copy(p8, ctx->stream, e); ctx->model_allocs.push_back(d8);
+        w.p8 = d8;
+        w.s8 = (uint32_t)(127 - sw);
+      }
     }
     w.bias = vec(n + ".b", N);
     return w;
@@ -1082,6 +1123,7 @@ int herro_load_model(herro_ctx* ctx, const char* path) {
   ctx->has_model = true;
   ctx->wmax = wmax_seen;
   ctx->calib_err = -1.f;
+  ctx->calib_err6 = -1.f;
   ctx->calib_note.clear();
   // Operand format.  bf16 hi/lo x3 (mode 1, ~1e-5) always works.  f16 (mode 4) needs the shapes its kernels are written
   // for, weights inside the f16 range (|w| >= 65520 rounds to inf, the remainder term to -inf: NaN logits), and — because
@@ -1089,6 +1131,7 @@ int herro_load_model(herro_ctx* ctx, const char* path) {
   const bool f16_ok = model_h_supported(M) && wmax_seen < 65504.f;
   if (ctx->precision_set) {
     if (ctx->precision >= 4 && !f16_ok) { ctx->precision = 1; ctx->calib_note = "f16 modes unavailable for this model (shapes or weight range): mode 1"; }
+    if (ctx->precision == 6 && !model_h_f8_supported(M)) { ctx->precision = 4; ctx->calib_note = "no e4m3 weight copies for this model (K % 128): mode 4"; }
     return HERRO_OK;
   }
   if (!f16_ok) {
@@ -1129,18 +1172,25 @@ int herro_load_model(herro_ctx* ctx, const char* path) {
     std::vector<float> i1((size_t)B * NS), b1((size_t)B * NS * 5), i4(i1.size()), b4(b1.size());
     ctx->precision = 0;
     int rc = herro_model_forward(ctx, B, L, cb.data(), cq.data(), lens.data(), idx.data(), i1.data(), b1.data());
-    ctx->precision = 4;
-    if (rc == HERRO_OK) rc = herro_model_forward(ctx, B, L, cb.data(), cq.data(), lens.data(), idx.data(), i4.data(), b4.data());
+    auto measure = [&](int mode) -> float {   // max |logit(mode) - logit(mode 0)|; inf when the run fails or is not finite
+      ctx->precision = mode;
+      if (herro_model_forward(ctx, B, L, cb.data(), cq.data(), lens.data(), idx.data(), i4.data(), b4.data()) != HERRO_OK) return INFINITY;
+      float err = 0.f;
+      bool finite = true;
+      for (size_t i = 0; i < i1.size(); i++) { finite = finite && std::isfinite(i4[i]); err = std::max(err, std::fabs(i4[i] - i1[i])); }
+      for (size_t i = 0; i < b1.size(); i++) { finite = finite && std::isfinite(b4[i]); err = std::max(err, std::fabs(b4[i] - b1[i])); }
+      return finite ? err : INFINITY;
+    };
     if (rc != HERRO_OK) { ctx->precision = 1; ctx->calib_note = "calibration run failed: mode 1"; return HERRO_OK; }
-    float err = 0.f;
-    bool finite = true;
-    for (size_t i = 0; i < i1.size(); i++) { finite = finite && std::isfinite(i4[i]); err = std::max(err, std::fabs(i4[i] - i1[i])); }
-    for (size_t i = 0; i < b1.size(); i++) { finite = finite && std::isfinite(b4[i]); err = std::max(err, std::fabs(b4[i] - b1[i])); }
-    ctx->calib_err = finite ? err : INFINITY;
-    const bool keep4 = finite && err <= 5e-4f;
-    ctx->precision = keep4 ? 4 : 1;
-    char buf[200];
-    snprintf(buf, sizeof buf, "calibration (256 pileup-shaped rows): max |logit(mode 4, f16) - logit(mode 0, f32)| = %.3g -> mode %d", (double)ctx->calib_err, ctx->precision);
+    ctx->calib_err = measure(4);
+    // precision 6 (the remainder term in e4m3 on the K = 128 instruction) is calibrated alongside so that herro_set_precision(6) can be held to the same bound; it is
+    // NOT chosen here: it takes 28 % of the MFMA pipe time out of proj / FF1 / FF2 and measures no faster (HERRO_ALLOW_P6=1 in A/B builds)
+    static const bool allow6 = ab_env("HERRO_ALLOW_P6", 0) != 0;
+    ctx->calib_err6 = model_h_f8_supported(M) ? measure(6) : INFINITY;
+    ctx->precision = (allow6 && ctx->calib_err6 <= 5e-4f) ? 6 : (ctx->calib_err <= 5e-4f ? 4 : 1);
+    char buf[300];
+    snprintf(buf, sizeof buf, "calibration (256 pileup-shaped rows): max |logit(mode) - logit(mode 0, f32)| = %.3g (mode 4, f16) / %.3g (mode 6, f16 + e4m3 remainder) -> mode %d",
+             (double)ctx->calib_err, (double)ctx->calib_err6, ctx->precision);
     ctx->calib_note = buf;
   }
   return HERRO_OK;
@@ -1174,7 +1224,7 @@ int64_t herro_model_describe(const herro_ctx* ctx, char* out, uint64_t cap) {
 }
 
 int herro_set_precision(herro_ctx* ctx, int mode) {
-  if (!ctx || mode < 0 || mode > 5) return HERRO_E_INVALID;
+  if (!ctx || mode < 0 || mode > 6) return HERRO_E_INVALID;
   if (mode >= 4 && ctx->has_model && ctx->wmax >= 65504.f) {
     ctx->err = "precision 4 / 5 (f16 operands): a weight of this model lies outside the f16 range";
     return HERRO_E_UNSUPPORTED;
@@ -1185,11 +1235,16 @@ int herro_set_precision(herro_ctx* ctx, int mode) {
   }
   // the load-time calibration ran and found the f16 kernels outside half the 1e-3 contract on THIS model: an explicit request for
   // them is refused (HERRO_FORCE_PRECISION=1 overrides, for measurements)
-  if (mode >= 4 && ctx->has_model && (ctx->calib_err > 5e-4f || std::isnan(ctx->calib_err))) {
+  if (mode == 6 && ctx->has_model && !model_h_f8_supported(ctx->M)) {
+    ctx->err = "precision 6 needs the e4m3 copies of proj / ff1 / ff2 (K % 128 == 0)";
+    return HERRO_E_UNSUPPORTED;
+  }
+  const float cal = mode == 6 ? ctx->calib_err6 : ctx->calib_err;
+  if (mode >= 4 && ctx->has_model && (cal > 5e-4f || std::isnan(cal))) {
     static const bool force = ab_env("HERRO_FORCE_PRECISION", 0) != 0;
     if (!force) {
       char buf[200];
-      snprintf(buf, sizeof buf, "precision %d refused: the calibration of this model measured a logit difference of %.3g (> 5e-4) for the f16 kernels", mode, (double)ctx->calib_err);
+      snprintf(buf, sizeof buf, "precision %d refused: the calibration of this model measured a logit difference of %.3g (> 5e-4) for the f16 kernels", mode, (double)cal);
       ctx->err = buf;
       return HERRO_E_UNSUPPORTED;
     }
@@ -2680,6 +2735,7 @@ int herro_debug_sib_fault(herro_ctx* ctx) {
   return HERRO_OK;
 }
 int herro_debug_sib_retries(const herro_ctx* ctx) { return ctx ? (int)ctx->n_sib_retry : HERRO_E_INVALID; }
+uint32_t herro_debug_e4m3(float x) { return f32_to_e4m3(x); }   // the host encoder of the precision-6 weight copies (tests)
 int herro_debug_job_rf_fused(const herro_job* job) { return job && job->inferred ? (job->rf_fused_used ? 1 : 0) : HERRO_E_STATE; }
 
 // the receptive-field records the model read for window w (valid once herro_job_infer has run with a compact receptive field)

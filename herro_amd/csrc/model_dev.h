@@ -40,6 +40,11 @@ struct Weight {
   const uint16_t* h16 = nullptr;
   const uint16_t* l16 = nullptr;
   const uint16_t* ph16 = nullptr;
+  // precision 6 (N % 32 == 0, K % 128 == 0; the encoder's proj / ff1 / ff2): OCP e4m3 of W * 2^(127 - s8) in the fragment order of
+  // v_mfma_scale_f32_16x16x128_f8f6f4 — byte ((((n / 32) * 2 + jt) * (K / 128) + s) * 2 + half) * 1024 + lane * 16 + j  =
+  // W[32 (n/32) + 8 (fr >> 2) + 4 jt + (fr & 3)][128 s + 32 fg + 16 half + j]; s8 = the E8M0 scale byte the instruction takes
+  const uint8_t* p8 = nullptr;
+  uint32_t s8 = 127;
   const float* bias = nullptr;  // [N] or null
   uint32_t K = 0, N = 0;
 };
@@ -147,8 +152,9 @@ struct ModelScratch {  // sized for n_tok tokens
 
 void launch_model(const ModelDev& M, const BatchDev& B, const ModelScratch& S, int precision,
                   hipStream_t st, KernelTimer* tm);
-// f16-operand kernels (model_h.hip): terms = 2 -> precision 4, terms = 1 -> precision 5.  B must be tiled (n_tiles > 0).
+// f16-operand kernels (model_h.hip): terms = 2 -> precision 4, terms = 1 -> precision 5, terms = 3 -> precision 6 (f16 + an e4m3 remainder term).  B must be tiled (n_tiles > 0).
 bool model_h_supported(const ModelDev& M);
+bool model_h_f8_supported(const ModelDev& M);   // ... and every layer's proj / ff1 / ff2 has its e4m3 copy
 int model_h_half_tiles(const ModelDev& M);   // qmode of plan_tiles: 0 no 32-token tiles, 1 for a short last round (default), 2 for every small window (HERRO_LAYERS_Q)
 void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S, int terms, hipStream_t st, KernelTimer* tm);
 #ifdef HERRO_PROF_BUILD

@@ -106,6 +106,40 @@ __device__ __forceinline__ float fg_max(float v) {
 }
 __device__ __forceinline__ f32x4 mma(half8 a, half8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
+// ---- precision 6: the activation remainder (the `lo` term of precision 4) as OCP e4m3 bytes, multiplied with an e4m3 copy of the weight by
+// v_mfma_scale_f32_16x16x128_f8f6f4 — K = 128 per instruction at twice the f16 rate per product (measured, tools/mx_probe.hip: 32 cycles per
+// instruction against 4 x 18 for the same K in f16).  The remainder is <= 2^-11 of the activation, so its 4 significant bits cost 2^-15
+// relative; it is scaled by 2^13 into the e4m3 range (clamped at 448: v_cvt_pk_fp8_f32 turns larger values into NaN) and the weight by a
+// power of two chosen per matrix at load (Weight::s8); both scales go back out through the instruction's E8M0 scale operands.  Operand
+// layout (checked bit-exact against a host product by the probe): lane l holds row / column l % 16 and the 32 k-values 32 (l / 16) + j in
+// byte order — the same for A and B.
+typedef int v8i __attribute__((ext_vector_type(8)));
+constexpr int LO8_SHIFT = 13;
+constexpr int LO8_SCALE_B = (127 - LO8_SHIFT) * 0x01010101;
+__device__ __forceinline__ f32x4 mma8(v8i a, v8i b, f32x4 c, int scale_a) {
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, scale_a, 0, LO8_SCALE_B);
+}
+// eight values -> f16 (round to nearest even) + their remainders as eight e4m3 bytes
+__device__ __forceinline__ void split_h8_f8(const float (&v)[8], half8& hi, uint2& lo8) {
+  uint32_t h[4];
+  float2v r[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float2v x = {v[2 * i], v[2 * i + 1]};
+    const half2v hh = __builtin_convertvector(x, half2v);
+    h[i] = __builtin_bit_cast(uint32_t, hh);
+    const float2v d = (x - __builtin_convertvector(hh, float2v)) * (float)(1 << LO8_SHIFT);
+    r[i] = float2v{__builtin_amdgcn_fmed3f(d.x, -448.f, 448.f), __builtin_amdgcn_fmed3f(d.y, -448.f, 448.f)};
+  }
+  int w[2];
+  w[0] = __builtin_amdgcn_cvt_pk_fp8_f32(r[0].x, r[0].y, 0, false);
+  w[0] = __builtin_amdgcn_cvt_pk_fp8_f32(r[1].x, r[1].y, w[0], true);
+  w[1] = __builtin_amdgcn_cvt_pk_fp8_f32(r[2].x, r[2].y, 0, false);
+  w[1] = __builtin_amdgcn_cvt_pk_fp8_f32(r[3].x, r[3].y, w[1], true);
+  hi = as_half8(h[0], h[1], h[2], h[3]);
+  lo8 = make_uint2((uint32_t)w[0], (uint32_t)w[1]);
+}
+
 __device__ __forceinline__ void glds16_h(const void* gsrc, uint32_t lds_dst) {  // 16 B per lane, global -> LDS, no VGPR staging
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -500,6 +534,8 @@ __global__ __launch_bounds__(512, 4) void k_fc_r(const uint16_t* __restrict__ A,
 //   * the positional encoding is added while x is fetched (no k_add_pe launch, no extra pass over x).
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t hlsw(uint32_t row, uint32_t chunk) { return row * 256 + ((chunk ^ (row & 15u)) << 3); }
+// the e4m3 remainder plane [tokens][256 bytes]: byte offset of 16-byte chunk `chunk` (k / 16) of a row, same XOR swizzle
+__device__ __forceinline__ uint32_t lsw8(uint32_t row, uint32_t chunk) { return row * 256 + ((chunk ^ (row & 15u)) << 4); }
 
 // ---------------------------------------------------------------------------------------------------
 // k_layers_p — the stack with its three exposed latencies taken off the critical path (an un-pipelined first version,
@@ -517,10 +553,26 @@ __device__ __forceinline__ uint32_t hlsw(uint32_t row, uint32_t chunk) { return 
 struct WStream {  // per-lane fragment pointer of one GEMM call: fragment (k, jt) at p + (jt * nks + k) * 512
   const uint16_t* p;
   uint32_t nks;
+  const uint8_t* p8;   // precision 6: e4m3 fragment (s = k / 128, jt, half) at p8 + ((jt * (nks / 4) + s) * 2 + half) * 1024 (Weight::p8)
+  int s8;              // its E8M0 scale in all four bytes
 };
+template <bool F8 = false>
 __device__ __forceinline__ WStream wstream(const Weight& W, uint32_t cb, uint32_t kofs, uint32_t lane) {
   const uint32_t nks = W.K >> 5;
-  return WStream{W.ph16 + ((uint64_t)((cb >> 5) * 2 * nks + (kofs >> 5)) * 64 + lane) * 8, nks};
+  WStream s{W.ph16 + ((uint64_t)((cb >> 5) * 2 * nks + (kofs >> 5)) * 64 + lane) * 8, nks, nullptr, 0};
+  if (F8) {
+    s.p8 = W.p8 + ((uint64_t)((cb >> 5) * 2 * (nks >> 2) + (kofs >> 7)) * 2 * 64 + lane) * 16;
+    s.s8 = (int)(W.s8 * 0x01010101u);
+  }
+  return s;
+}
+__device__ __forceinline__ void wload8(const WStream& s, uint32_t step, v8i (&w)[2]) {
+#pragma unroll
+  for (int jt = 0; jt < 2; jt++) {
+    const uint8_t* q = s.p8 + (uint64_t)((jt * (s.nks >> 2) + step) * 2) * 1024;
+    const uint4 a = *reinterpret_cast<const uint4*>(q), b = *reinterpret_cast<const uint4*>(q + 1024);
+    w[jt] = v8i{(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w};
+  }
 }
 __device__ __forceinline__ void wload4(const WStream& s, uint32_t k0, half8 (&w)[4][2]) {
 #pragma unroll
@@ -529,12 +581,31 @@ __device__ __forceinline__ void wload4(const WStream& s, uint32_t k0, half8 (&w)
     for (int k = 0; k < 4; k++) w[k][jt] = *reinterpret_cast<const half8*>(s.p + (uint64_t)(jt * s.nks + k0 + k) * 512);
 }
 
+#ifndef HERRO_LP_DBG
+#define HERRO_LP_DBG 0   // timing experiments (wrong results): 1 every second activation fragment read from LDS is skipped, 2 every second k-step's MFMAs, 4 the weight loads inside a call,
+                         // 8 (precision 6) no K = 128 instructions, 16 (precision 6) no e4m3 conversion of the remainders (the byte planes stay as they are)
+#endif
 template <bool SWAP, int TERMS, int PT>
 __device__ __forceinline__ void tile_gemm_p(const WStream& cur, half8 (&wa)[4][2], const WStream& nxt, const uint16_t* sh,
                                             const uint16_t* sl, uint32_t fr, uint32_t fg, f32x4 (&acc)[PT][2]) {
   half8 wb[4][2];
-  wload4(cur, 4, wb);
+  if (HERRO_LP_DBG & 4) {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int jt = 0; jt < 2; jt++) wb[k][jt] = wa[k][jt];
+  } else wload4(cur, 4, wb);
+  static_assert(!(SWAP && TERMS == 3), "the e4m3 term is written for weights as the A operand");
+  v8i w8a[2], w8b[2], xb[PT];   // TERMS 3: the e4m3 weight fragments of the call's two K = 128 steps; the remainder fragments of the first
+  auto rd8 = [&](int step, int pt) -> v8i {
+    const uint8_t* s8p = reinterpret_cast<const uint8_t*>(sl);
+    const uint32_t row = (uint32_t)pt * 16 + fr, c = (uint32_t)step * 8 + fg * 2;
+    const uint4 a = *reinterpret_cast<const uint4*>(s8p + lsw8(row, c)), b = *reinterpret_cast<const uint4*>(s8p + lsw8(row, c + 1));
+    return v8i{(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w};
+  };
   half8 xh[PT], xl[PT], xn[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; pt++) { xl[pt] = half8{}; xn[pt] = half8{}; }
   auto rd = [&](const uint16_t* plane, int k, half8 (&x)[PT]) {
 #pragma unroll
     for (int pt = 0; pt < PT; pt++) x[pt] = *reinterpret_cast<const half8*>(plane + hlsw(pt * 16 + fr, k * 4 + fg));
@@ -545,26 +616,73 @@ __device__ __forceinline__ void tile_gemm_p(const WStream& cur, half8 (&wa)[4][2
 #pragma unroll
       for (int jt = 0; jt < 2; jt++) acc[pt][jt] = SWAP ? mma(x[pt], w[jt], acc[pt][jt]) : mma(w[jt], x[pt], acc[pt][jt]);
   };
+  // TERMS 2 reads the next k-step's hi fragments between its two MFMA groups — half a step (8 MFMAs) ahead of their use.  TERMS 3 has one group per k-step and
+  // reads TWO steps ahead into a third buffer (710 -> 705 us per 4096 windows; for TERMS 1 — QKV — the same change measured nothing, 694 -> 693, and is not made:
+  // the two waves of a SIMD take turns on the MFMA pipe, one's wait is the other's issue slot).
+  constexpr bool AHEAD2 = TERMS == 3 && !(HERRO_LP_DBG & 3);
+  half8 xm[PT];
   rd(sh, 0, xh);
+  if (AHEAD2) rd(sh, 1, xn);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    if (k == 4) {  // wa's last reader (k = 3) is behind us: refill it with the head of the next call
+    constexpr bool dbg_rd = (HERRO_LP_DBG & 1) != 0, dbg_mm = (HERRO_LP_DBG & 2) != 0;
+    if (TERMS == 3 && k == 0) { wload8(cur, 0, w8a); __builtin_amdgcn_sched_barrier(0); }   // used behind the f16 k-steps
+    if (k == 4 && !(HERRO_LP_DBG & 4)) {  // wa's last reader (k = 3) is behind us: refill it with the head of the next call
       wload4(nxt, 0, wa);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (TERMS == 2) rd(sl, k, xl);
+    if (TERMS == 3 && k == 6) { wload8(cur, 1, w8b); __builtin_amdgcn_sched_barrier(0); }   // into the registers wb's first two k-steps have left
+    if (TERMS == 3 && k == 7) {   // the remainder fragments of the first K = 128 step, under the last f16 k-step
+#pragma unroll
+      for (int pt = 0; pt < PT; pt++) xb[pt] = rd8(0, pt);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (AHEAD2) {
+      if (k + 2 < 8) rd(sh, k + 2, xm);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k < 4) mm8(xh, wa[k]); else mm8(xh, wb[k - 4]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pt = 0; pt < PT; pt++) { xh[pt] = xn[pt]; xn[pt] = xm[pt]; }
+      continue;
+    }
+    if (TERMS == 2 && !(dbg_rd && (k & 1))) rd(sl, k, xl);
     __builtin_amdgcn_sched_barrier(0);
-    if (k < 4) mm8(xh, wa[k]); else mm8(xh, wb[k - 4]);
+    if (!(dbg_mm && (k & 1))) { if (k < 4) mm8(xh, wa[k]); else mm8(xh, wb[k - 4]); }
     __builtin_amdgcn_sched_barrier(0);
-    if (k < 7) rd(sh, k + 1, xn);
+    if (k < 7 && !(dbg_rd && !(k & 1))) rd(sh, k + 1, xn);
     __builtin_amdgcn_sched_barrier(0);
-    if (TERMS == 2) {
+    if (TERMS == 2 && !(dbg_mm && (k & 1))) {
       if (k < 4) mm8(xl, wa[k]); else mm8(xl, wb[k - 4]);
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int pt = 0; pt < PT; pt++) xh[pt] = xn[pt];
+  }
+  if constexpr (TERMS == 3) {   // + remainder (e4m3, plane `sl` read as bytes) x weight (e4m3): 2 steps of K = 128, 2 * PT * 2 instructions
+    // Fenced pair by pair: left alone, the scheduler pulls the second step of the LAST row block right behind its first (it wants that block's result for the
+    // code that follows the call) — two dependent K = 128 instructions back to back, each waiting out the other's full latency (seen in the ISA: s_nop 9 / 11).
+    // The order of these pure instructions is pinned through their data: the second step's weight fragments pass through (empty) asm statements together with
+    // the accumulators of the first step, so every instruction of the second step follows all of the first (nothing is emitted, nothing waits).
+    v8i xc[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; pt++) xc[pt] = rd8(1, pt);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int pt = 0; pt < PT; pt++) {
+#pragma unroll
+      for (int jt = 0; jt < 2; jt++) if (!(HERRO_LP_DBG & 8)) acc[pt][jt] = mma8(w8a[jt], xb[pt], acc[pt][jt], cur.s8);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int pt = 0; pt < PT; pt++) asm volatile("" : "+v"(acc[pt][0]), "+v"(acc[pt][1]), "+v"(w8b[0]), "+v"(w8b[1]));
+#pragma unroll
+    for (int pt = 0; pt < PT; pt++) {
+#pragma unroll
+      for (int jt = 0; jt < 2; jt++) if (!(HERRO_LP_DBG & 8)) acc[pt][jt] = mma8(w8b[jt], xc[pt], acc[pt][jt], cur.s8);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 
@@ -625,7 +743,8 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
 #define RELAUNDER() asm volatile("" : "+v"(fr), "+v"(fg))
 
   if (tid < HLT) s_win[tid] = tid < nt ? S.tok_win[t0 + tid] : 0xffffff00u + tid;
-  float x[PT][8];
+  f32x4 xr[PT][2];   // the residual stream, in the accumulator layout of the GEMM calls (channel cw + 8 fg + q of token pt * 16 + fr at [pt][q / 4][q % 4]): proj and FF2 accumulate straight into it
+#define XQ(pt, q) xr[pt][(q) >> 2][(q) & 3]
   half8 wa[4][2];  // the first four k-steps of the next GEMM call, always one call ahead
   wload4(wstream(M.layer[0].qkv, cw, 0, lane), 0, wa);
 
@@ -646,7 +765,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
   };
   // LayerNorm over the 256 channels of the register-resident x, two passes (mean, then centred sum of squares).  (The one-barrier
   // form of k_layers_q — per-wave mean and M2 merged exactly — measured no faster here: 726 vs 726 us per 4096 windows.)
-  auto layer_norm = [&](uint32_t og, uint32_t ob, const float* __restrict__ gp, const float* __restrict__ bp, bool want_lo) {
+  auto layer_norm = [&](uint32_t og, uint32_t ob, const float* __restrict__ gp, const float* __restrict__ bp, int want_lo) {   // want_lo: 0 none, 1 an f16 plane, 2 e4m3 bytes
     float mean[PT], rstd[PT];
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
@@ -656,7 +775,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
         float sm = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-          const float d = pass == 0 ? x[pt][q] : x[pt][q] - mean[pt];
+          const float d = pass == 0 ? XQ(pt, q) : XQ(pt, q) - mean[pt];
           sm += pass == 0 ? d : d * d;
         }
         sm = fg_sum(sm);
@@ -686,9 +805,17 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
     for (int pt = 0; pt < PT; pt++) {
       float y[8];
 #pragma unroll
-      for (int q = 0; q < 8; q++) y[q] = (x[pt][q] - mean[pt]) * rstd[pt] * gg[q] + bb[q];
+      for (int q = 0; q < 8; q++) y[q] = (XQ(pt, q) - mean[pt]) * rstd[pt] * gg[q] + bb[q];
       const uint32_t o = hlsw(pt * 16 + fr, wave * 4 + fg);
-      if (want_lo) {
+      if (want_lo == 2 && (HERRO_LP_DBG & 16)) {
+        *reinterpret_cast<half8*>(s_hh + o) = pack_h8(y);
+      } else if (want_lo == 2) {
+        half8 hi;
+        uint2 lo8;
+        split_h8_f8(y, hi, lo8);
+        *reinterpret_cast<half8*>(s_hh + o) = hi;
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(s_hl) + lsw8(pt * 16 + fr, wave * 2 + (fg >> 1)) + (fg & 1u) * 8) = lo8;
+      } else if (want_lo) {
         half8 hi, lo;
         split_h8(y, hi, lo);
         *reinterpret_cast<half8*>(s_hh + o) = hi;
@@ -705,8 +832,18 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
 #pragma unroll
       for (int jt = 0; jt < 2; jt++) a[pt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
-  auto store_act = [&](uint16_t* ph, uint16_t* pl, uint32_t o, const float (&v)[8]) {
-    if (TERMS == 2) {
+  auto store_act = [&](uint16_t* ph, uint16_t* pl, uint32_t o, const float (&v)[8]) {   // o = hlsw(row, wave * 4 + fg)
+    if (TERMS == 3 && (HERRO_LP_DBG & 16)) {
+      *reinterpret_cast<half8*>(ph + o) = pack_h8(v);
+    } else if (TERMS == 3) {
+      half8 hi;
+      uint2 lo8;
+      split_h8_f8(v, hi, lo8);
+      *reinterpret_cast<half8*>(ph + o) = hi;
+      // the same (row, chunk) in the byte plane: 16-byte chunk wave * 2 + fg / 2 of the row (hlsw's 8-half chunk wave * 4 + fg, halved), XORed alike
+      const uint32_t row = o >> 8, ch8 = ((o >> 3) & 31u) ^ (row & 15u);
+      *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(pl) + lsw8(row, ch8 >> 1) + (ch8 & 1u) * 8) = lo8;
+    } else if (TERMS == 2) {
       half8 hi, lo;
       split_h8(v, hi, lo);
       *reinterpret_cast<half8*>(ph + o) = hi;
@@ -731,16 +868,16 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
         b = *reinterpret_cast<const float4*>(xp + 4);
         row = (float)S.tok_row[t0 + tok];
       }
-      x[pt][0] = a.x; x[pt][1] = a.y; x[pt][2] = a.z; x[pt][3] = a.w;
-      x[pt][4] = b.x; x[pt][5] = b.y; x[pt][6] = b.z; x[pt][7] = b.w;
+      xr[pt][0] = f32x4{a.x, a.y, a.z, a.w};
+      xr[pt][1] = f32x4{b.x, b.y, b.z, b.w};
       if (tok < nt) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const float ang = __fmul_rn(row, pd[j]);
           float sn, cs;
           sincosf(ang, &sn, &cs);   // one range reduction for both
-          x[pt][2 * j] += sn;
-          x[pt][2 * j + 1] += cs;
+          XQ(pt, 2 * j) += sn;
+          XQ(pt, 2 * j + 1) += cs;
         }
       }
     }
@@ -753,7 +890,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
     const LayerW& Ln = M.layer[li + 1 < n_layers ? li + 1 : 0];  // after the last layer: a harmless re-read of layer 0
     RELAUNDER();
     LP_MARK(li ? 7 : 0);
-    layer_norm(PAR_LN1G, PAR_LN1B, nullptr, nullptr, false);   // Q, K, V read the hi plane only (see the header: QKV single)
+    layer_norm(PAR_LN1G, PAR_LN1B, nullptr, nullptr, 0);   // Q, K, V read the hi plane only (see the header: QKV single)
     LP_MARK(1);
     RELAUNDER();
     {  // ---- attention, head = wave
@@ -782,7 +919,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
           kh[pt] = pack_h8(v);
         }
         zero(a);
-        tile_gemm_p<true, 1, PT>(wstream(L.qkv, 512 + cw, 0, lane), wa, wstream(L.proj, cw, 0, lane), s_hh, s_hl, fr, fg, a);
+        tile_gemm_p<true, 1, PT>(wstream(L.qkv, 512 + cw, 0, lane), wa, wstream(L.proj, cw, 0, lane), s_hh, s_hl, fr, fg, a);   // (a call only reads the f16 head of its successor)
 #pragma unroll
         for (int ct = 0; ct < 2; ct++) {
           const float bv = s_par[PAR_BQKV + 512 + cw + 8 * (fr >> 2) + 4 * ct + (fr & 3)];
@@ -982,30 +1119,27 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
     LP_MARK(3);
     RELAUNDER();
     {  // ---- output projection + residual
-      f32x4 a[PT][2];
       float bp[8];
-      zero(a);
-      tile_gemm_p<false, TERMS, PT>(wstream(L.proj, cw, 0, lane), wa, wstream(L.ff1, cw, 0, lane), s_ah, s_al, fr, fg, a);
       lds8(PAR_BPROJ + cw + 8 * fg, bp);
 #pragma unroll
       for (int pt = 0; pt < PT; pt++)
 #pragma unroll
-        for (int q = 0; q < 8; q++) x[pt][q] += a[pt][q >> 2][q & 3] + bp[q];
+        for (int q = 0; q < 8; q++) XQ(pt, q) += bp[q];
+      tile_gemm_p<false, TERMS, PT>(wstream<TERMS == 3>(L.proj, cw, 0, lane), wa, wstream(L.ff1, cw, 0, lane), s_ah, s_al, fr, fg, xr);   // x += attention . Wproj
     }
     RELAUNDER();
     LP_MARK(4);
-    layer_norm(PAR_LN2G, PAR_LN2B, nullptr, nullptr, TERMS == 2);
+    layer_norm(PAR_LN2G, PAR_LN2B, nullptr, nullptr, TERMS == 3 ? 2 : (TERMS == 2 ? 1 : 0));
     LP_MARK(5);
     {  // ---- feed-forward, 256 hidden channels at a time
-      f32x4 a2[PT][2];
-      {  // the FF2 accumulator starts from its bias: no parameter is read after the loop's last barrier, which is what
-         // lets the next layer's parameters be staged right behind it
+      {  // FF2 accumulates into the residual stream itself (32 accumulator registers less through the FF loop), which takes the FF2 bias first: no
+         // parameter is read after the loop's last barrier, which is what lets the next layer's parameters be staged right behind it
         float b2[8];
         lds8(PAR_BFF2 + cw + 8 * fg, b2);
 #pragma unroll
         for (int pt = 0; pt < PT; pt++)
 #pragma unroll
-          for (int jt = 0; jt < 2; jt++) a2[pt][jt] = f32x4{b2[4 * jt], b2[4 * jt + 1], b2[4 * jt + 2], b2[4 * jt + 3]};
+          for (int q = 0; q < 8; q++) XQ(pt, q) += b2[q];
       }
       for (uint32_t c = 0; c < d_ff; c += 256) {
         RELAUNDER();
@@ -1018,33 +1152,30 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
 #pragma unroll
             for (int jt = 0; jt < 2; jt++) a1[pt][jt] = f32x4{b1[4 * jt], b1[4 * jt + 1], b1[4 * jt + 2], b1[4 * jt + 3]};
         }
-        tile_gemm_p<false, TERMS, PT>(wstream(L.ff1, c + cw, 0, lane), wa, wstream(L.ff2, cw, c, lane), s_hh, s_hl, fr, fg, a1);
+        tile_gemm_p<false, TERMS, PT>(wstream<TERMS == 3>(L.ff1, c + cw, 0, lane), wa, wstream(L.ff2, cw, c, lane), s_hh, s_hl, fr, fg, a1);
 #pragma unroll
         for (int pt = 0; pt < PT; pt++) {
           float v[8];
 #pragma unroll
-          for (int q = 0; q < 8; q++) v[q] = fmaxf(a1[pt][q >> 2][q & 3], 0.f);
+          for (int q = 0; q < 8; q++) v[q] = __builtin_amdgcn_fmed3f(a1[pt][q >> 2][q & 3], 0.f, __builtin_huge_valf());   // ReLU in ONE instruction (fmaxf: a canonicalising v_max in front of the v_max)
           store_act(s_ah, s_al, hlsw(pt * 16 + fr, wave * 4 + fg), v);
         }
         __syncthreads();
         LP_MARK(6);
         const bool more = c + 256 < d_ff;
         const WStream nx = more ? wstream(L.ff1, c + 256 + cw, 0, lane) : wstream(Ln.qkv, cw, 0, lane);
-        tile_gemm_p<false, TERMS, PT>(wstream(L.ff2, cw, c, lane), wa, nx, s_ah, s_al, fr, fg, a2);
+        tile_gemm_p<false, TERMS, PT>(wstream<TERMS == 3>(L.ff2, cw, c, lane), wa, nx, s_ah, s_al, fr, fg, xr);
         __syncthreads();
         LP_MARK(7);
       }
-#pragma unroll
-      for (int pt = 0; pt < PT; pt++)
-#pragma unroll
-        for (int q = 0; q < 8; q++) x[pt][q] += a2[pt][q >> 2][q & 3];
     }
     // every wave is past its last read of this layer's parameters (the barrier that closed the FF loop)
     if (li + 1 < n_layers) stage_params(Ln);   // visible after the first barrier of the next LayerNorm
   }
   RELAUNDER();
-  layer_norm(0, 0, M.lnf_g, M.lnf_b, true);
+  layer_norm(0, 0, M.lnf_g, M.lnf_b, 1);
 #undef RELAUNDER
+#undef XQ
   if (wave < PT) {  // heads, three terms
     const uint32_t pt = wave;
     f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1140,6 +1271,13 @@ bool model_h_supported(const ModelDev& M) {
          M.conv1g.ph16 && M.conv2.ph16 && M.fc.h16 && M.fc.ph16 && M.fc.K % 128 == 0 && M.heads.h16 && M.heads.l16 && M.layer[0].qkv.ph16;
 }
 
+bool model_h_f8_supported(const ModelDev& M) {
+  if (!model_h_supported(M)) return false;
+  for (uint32_t l = 0; l < M.h.n_layers; l++)
+    if (!M.layer[l].proj.p8 || !M.layer[l].ff1.p8 || !M.layer[l].ff2.p8) return false;
+  return true;
+}
+
 // HERRO_LAYERS_Q: 0 keeps every tile at 64 tokens, 2 puts every window of <= 32 rows into 32-token tiles (both for A/B);
 // default 1: 32-token tiles take the short last round of a launch (plan_tiles, herro_api.hip)
 int model_h_half_tiles(const ModelDev& M) {
@@ -1200,11 +1338,12 @@ void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S,
     opt_in_lds(reinterpret_cast<const void*>(kern), layers_p_shm(tokens));
     hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(512), layers_p_shm(tokens), st, M, B, S);
   };
+  auto launch3 = [&](auto k1, auto k2, auto k3, uint32_t n_tiles, int tokens) { if (terms == 3) launch(k3, n_tiles, tokens); else if (terms == 2) launch(k2, n_tiles, tokens); else launch(k1, n_tiles, tokens); };
   if (B.n_tiles_b) {   // sibling tiles of the windows above 64 informative rows at the head of ONE grid with the ordinary 64-token tiles
     (void)hipMemsetAsync(S.sib_flag, 0, (size_t)B.n_tiles_b * 4, st);
-    if (terms == 2) launch(k_layers_p<2, 4, true>, B.n_tiles_b + B.n_tiles, 64); else launch(k_layers_p<1, 4, true>, B.n_tiles_b + B.n_tiles, 64);
-  } else if (B.n_tiles) { if (terms == 2) launch(k_layers_p<2, 4>, B.n_tiles, 64); else launch(k_layers_p<1, 4>, B.n_tiles, 64); }
-  if (B.n_tiles_q) { if (terms == 2) launch(k_layers_p<2, 2>, B.n_tiles_q, 32); else launch(k_layers_p<1, 2>, B.n_tiles_q, 32); }
+    launch3(k_layers_p<1, 4, true>, k_layers_p<2, 4, true>, k_layers_p<3, 4, true>, B.n_tiles_b + B.n_tiles, 64);
+  } else if (B.n_tiles) launch3(k_layers_p<1, 4>, k_layers_p<2, 4>, k_layers_p<3, 4>, B.n_tiles, 64);
+  if (B.n_tiles_q) launch3(k_layers_p<1, 2>, k_layers_p<2, 2>, k_layers_p<3, 2>, B.n_tiles_q, 32);
   KT_END(tm, st);
 }
 

@@ -115,7 +115,7 @@ def test_baseline_workload_end_to_end():
             e_base = max(float(np.abs(first[wv][1] - ref[wv][1]).max()) for wv in sel)
             errs[f"bs128_default_p{api.DEFAULT_PRECISION}_rf_quals"] = {"info": e_info, "base": e_base, "windows": len(sel),
                                                                         "tokens": int(nsup[sel].sum())}
-        for prec in (1, 4, 5):
+        for prec in (1, 4, 5, 6):
             c.set_precision(prec)
             job.infer(bs, 1)
             e_info = e_base = 0.0

@@ -21,7 +21,7 @@ def _rand_batch(rng, B, L, win_len):
     return bases, quals
 
 
-@pytest.mark.parametrize("precision", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("precision", [0, 1, 2, 3, 4, 5, 6])
 def test_model_forward_vs_twin(precision):
     import model_ref as MR
     rng = np.random.default_rng(11)
@@ -76,6 +76,9 @@ def test_model_forward_tiling_edges(counts):
     c.set_precision(4)   # f16 kernels: same tiles; windows above 64 rows on sibling tiles of the same stack (next test)
     info4, base4 = c.model_forward(bases, quals, lens, flat)
     assert max(np.abs(info4 - ti).max(), np.abs(base4 - tb).max()) <= TOL
+    c.set_precision(6)   # the remainder term in e4m3: same tiles, same contract
+    ih6, bh6 = c.model_forward(bases, quals, lens, flat)
+    assert max(np.abs(ih6 - ti).max(), np.abs(bh6 - tb).max()) <= TOL
     c.set_precision(5)   # the single-term instances of the same kernels
     info5, base5 = c.model_forward(bases, quals, lens, flat)
     assert max(np.abs(info5 - ti).max(), np.abs(base5 - tb).max()) <= TOL
@@ -108,13 +111,13 @@ def test_windows_above_64_rows_on_sibling_tiles(counts):
     ti, tb = MR.run_batch(G.twin(), bases, quals, lens, flat)
     c = G.ctx()
     try:
-        for prec in (4, 5):
+        for prec in (4, 5, 6):
             c.set_precision(prec)
             info, base = c.model_forward(bases, quals, lens, flat)
             assert info.shape == ti.shape and base.shape == tb.shape
             err = max(np.abs(info - ti).max(), np.abs(base - tb).max())
             print(f"precision {prec}, windows of {counts[:6]} rows: max abs logit error {err:.3e}")
-            assert err <= (TOL if prec == 4 else 4e-3), (prec, err)
+            assert err <= (4e-3 if prec == 5 else TOL), (prec, err)
     finally:
         c.set_precision(api.DEFAULT_PRECISION)
 
@@ -284,7 +287,7 @@ def test_torchscript_archive_to_hip_logits(tmp_path):
     c = api.Context(0)
     try:
         c.load_model(flat)
-        for prec in (1, 4):
+        for prec in (1, 4, 6):
             c.set_precision(prec)
             info, base = c.model_forward(bases, quals, lens, np.concatenate(idx).astype(np.int32))
             err = max(np.abs(info - ti.numpy()).max(), np.abs(base - tb.numpy()).max())
@@ -303,10 +306,14 @@ def test_load_time_precision_choice(tmp_path):
     c.load_model(path)
     d = c.describe_model()
     assert "calibration (256 pileup-shaped rows)" in d and "mode 0, f32" in d and "receptive field of an informative row: 5 rows" in d, d
-    assert ("-> mode 4" in d) or ("-> mode 1" in d)
+    assert ("-> mode 4" in d) or ("-> mode 1" in d) or ("-> mode 6" in d)
     import re
-    err = float(re.search(r"= ([0-9.eE+-]+|inf) -> mode", d).group(1))
-    assert ("-> mode 4" in d) == (err <= 5e-4)
+    m = re.search(r"= ([0-9.eE+-]+|inf) \(mode 4, f16\) / ([0-9.eE+-]+|inf) \(mode 6, f16 \+ e4m3 remainder\) -> mode (\d)", d)
+    err4, err6, mode = float(m.group(1)), float(m.group(2)), int(m.group(3))
+    assert mode == (4 if err4 <= 5e-4 else 1), d   # mode 6 is calibrated alongside (herro_set_precision(6) is held to the same bound) but not chosen: it measures no faster
+    if err6 <= 5e-4:
+        c.set_precision(6)
+        c.set_precision(mode)
     big = {k: v.copy() for k, v in raw.items()}
     k0 = "encoder.layers.0.linear1.weight"
     big[k0].flat[0] = 1.0e5                                  # f16: inf
@@ -317,6 +324,8 @@ def test_load_time_precision_choice(tmp_path):
     assert "outside the f16 range" in d2 and "precision mode 1" in d2, d2
     with pytest.raises(api.HerroError):
         c.set_precision(4)
+    with pytest.raises(api.HerroError):
+        c.set_precision(6)
     # a model whose f16 logits drift: weights inside the f16 range, but a final LayerNorm gain that blows the logit scale (and with it
     # the absolute error) up -> the calibration keeps mode 1, and an explicit request for mode 4 is refused
     loud = {k: v.copy() for k, v in raw.items()}
@@ -330,6 +339,8 @@ def test_load_time_precision_choice(tmp_path):
     if "-> mode 1" in d3:
         with pytest.raises(api.HerroError, match="refused"):
             c.set_precision(4)
+        with pytest.raises(api.HerroError, match="refused"):
+            c.set_precision(6)
         c.set_precision(1)
     c.close()
 
