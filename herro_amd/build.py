@@ -23,12 +23,15 @@ def _stale() -> bool:
 
 def build_hip(force: bool = False, out: str | None = None, defines: tuple = ()) -> str:
     """out / defines: a second library next to the release one (phase timers, A/B variants), selected at run time by HERRO_LIB."""
+    prof_env = os.environ.get("HERRO_PROF_BUILD", "0") not in ("", "0")
+    if prof_env and out is None:   # a timer build never replaces the release library: it goes beside it (select it with HERRO_LIB)
+        out = os.path.join(HERE, "libherro_amd_prof.so")
     if out is not None:
         force = True
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = ["-DHERRO_PROF_BUILD"] if os.environ.get("HERRO_PROF_BUILD", "0") not in ("", "0") else []   # kernel phase timers (job_dev.h)
+    extra = ["-DHERRO_PROF_BUILD"] if prof_env else []   # kernel phase timers (job_dev.h)
     extra += ["-D" + d for d in defines]
     cmd = [hipcc] + FLAGS + extra + ["-o", out or LIB] + [os.path.join(CSRC, s) for s in HIP_SOURCES]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

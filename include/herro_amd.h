@@ -107,6 +107,9 @@ int herro_load_model(herro_ctx* ctx, const char* path);
  *      hi + lo (2 MFMAs), heads on three terms — 5.9e-4 max on 36 k rows; the DEFAULT when the model has the tuned shapes.
  *      Windows of 65 .. 512 informative rows stay on the fused stack (sibling tiles of 64 rows that exchange their K / V).
  *   5  f16, single terms everywhere but the heads (7.3e-4: measured, not a default)
+ *   6  as 4, with the activation remainder of proj / FF1 / FF2 as OCP e4m3 against an e4m3 copy of the weight on the K = 128 scaled MFMA
+ *      (v_mfma_scale_f32_16x16x128_f8f6f4; 6.1e-4 end to end; calibrated at load beside mode 4 and refused above 5e-4; 26 % less matrix-pipe time in
+ *      those GEMMs and no faster on an MI355X — DESIGN.md §5 — so not a default)
  * herro_load_model picks the mode itself unless this was called before: 1 when the model's shapes have no f16 kernels or
  * a weight lies outside the f16 range; otherwise it runs a calibration batch of 256 pileup-shaped rows in mode 4 and in
  * mode 0 (f32 MFMA) and keeps 4 only if the logits are finite and differ by at most 5e-4 (half the 1e-3 contract) — the
