@@ -693,7 +693,7 @@ constexpr int PAR_FLOATS = PAR_BFF1 + PAR_MAX_FF;
 
 // Phase timer of the stack, compiled only into HERRO_PROF_BUILD libraries (HERRO_PROF_BUILD=1 python -m herro_amd.build; run with
 // HERRO_PROF=1): thread 0 of one tile in 16 adds the shader cycles since its previous mark to its phase's counter
-// (0 prologue, 1 LayerNorm 1, 2 QKV, 3 attention, 4 proj, 5 LayerNorm 2, 6 FF1 + epilogue, 7 FF2, 8 final LayerNorm + heads; 15 tiles
+// (0 prologue, 1 LayerNorm 1, 2 QKV, 3 attention, 4 proj, 5 LayerNorm 2, 6 the wait behind FF1's epilogue, 7 the wait behind FF2, 8 final LayerNorm + heads, 9 FF1's GEMM, 10 its epilogue, 11 FF2's GEMM; 15 tiles
 // sampled).  Release kernels carry nothing of it.
 #ifdef HERRO_PROF_BUILD
 __device__ unsigned long long g_lp_prof[16];
@@ -1153,6 +1153,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
             for (int jt = 0; jt < 2; jt++) a1[pt][jt] = f32x4{b1[4 * jt], b1[4 * jt + 1], b1[4 * jt + 2], b1[4 * jt + 3]};
         }
         tile_gemm_p<false, TERMS, PT>(wstream<TERMS == 3>(L.ff1, c + cw, 0, lane), wa, wstream(L.ff2, cw, c, lane), s_hh, s_hl, fr, fg, a1);
+        LP_MARK(9);
 #pragma unroll
         for (int pt = 0; pt < PT; pt++) {
           float v[8];
@@ -1160,11 +1161,13 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
           for (int q = 0; q < 8; q++) v[q] = __builtin_amdgcn_fmed3f(a1[pt][q >> 2][q & 3], 0.f, __builtin_huge_valf());   // ReLU in ONE instruction (fmaxf: a canonicalising v_max in front of the v_max)
           store_act(s_ah, s_al, hlsw(pt * 16 + fr, wave * 4 + fg), v);
         }
+        LP_MARK(10);
         __syncthreads();
         LP_MARK(6);
         const bool more = c + 256 < d_ff;
         const WStream nx = more ? wstream(L.ff1, c + 256 + cw, 0, lane) : wstream(Ln.qkv, cw, 0, lane);
         tile_gemm_p<false, TERMS, PT>(wstream<TERMS == 3>(L.ff2, cw, c, lane), wa, nx, s_ah, s_al, fr, fg, xr);
+        LP_MARK(11);
         __syncthreads();
         LP_MARK(7);
       }
@@ -1351,9 +1354,10 @@ void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S,
 void model_h_prof_dump() {
   unsigned long long h[16] = {0};
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lp_prof), sizeof h) != hipSuccess || !h[15]) return;
-  static const char* name[9] = {"prologue", "LN1", "QKV", "attention", "proj", "LN2", "FF1+epilogue", "FF2", "final LN + heads"};
+  // (6 / 7 are the waits at the barriers behind FF1's epilogue / FF2 as wave 0 sees them since round 5's finer marks: 9 FF1's GEMM call, 10 its epilogue, 11 FF2's GEMM call)
+  static const char* name[12] = {"prologue", "LN1", "QKV", "attention", "proj", "LN2", "FF1 barrier wait", "FF2 barrier wait", "final LN + heads", "FF1 gemm", "FF1 epilogue", "FF2 gemm"};
   fprintf(stderr, "PROF k_layers_p (%llu tiles sampled), shader cycles per tile by phase:", h[15]);
-  for (int p = 0; p < 9; p++) fprintf(stderr, " %s %.0f", name[p], (double)h[p] / (double)h[15]);
+  for (int p = 0; p < 12; p++) fprintf(stderr, " %s %.0f", name[p], (double)h[p] / (double)h[15]);
   fprintf(stderr, "\n");
 }
 #endif
