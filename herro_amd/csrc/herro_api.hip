@@ -927,7 +927,7 @@ float h_f16f(uint16_t h) {
 
 // f32 -> OCP e4m3 (e4m3fn: bias 7, 3 fraction bits, subnormals in units of 2^-9, largest finite 448 = 0x7e, no infinities), round to nearest even,
 // SATURATING (the weights of precision 6 are scaled below 448 first; the device's own v_cvt_pk_fp8_f32 turns >= 480 into NaN).  Values the
-// device conversion produced for the same inputs: tools/mx_probe.hip (1 -> 0x38, 0.1 -> 0x1d, 3.3 -> 0x45, 0.0176 -> 0x09, 2^-9 -> 0x01, 2^-10 -> 0).
+// device conversion produced for the same inputs: tools/probes/mx_probe.hip (1 -> 0x38, 0.1 -> 0x1d, 3.3 -> 0x45, 0.0176 -> 0x09, 2^-9 -> 0x01, 2^-10 -> 0).
 uint8_t f32_to_e4m3(float f) {
   const uint8_t sign = std::signbit(f) ? 0x80u : 0u;
   const float a = std::fabs(f);

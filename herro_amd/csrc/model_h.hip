@@ -107,7 +107,7 @@ __device__ __forceinline__ float fg_max(float v) {
 __device__ __forceinline__ f32x4 mma(half8 a, half8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 // ---- precision 6: the activation remainder (the `lo` term of precision 4) as OCP e4m3 bytes, multiplied with an e4m3 copy of the weight by
-// v_mfma_scale_f32_16x16x128_f8f6f4 — K = 128 per instruction at twice the f16 rate per product (measured, tools/mx_probe.hip: 32 cycles per
+// v_mfma_scale_f32_16x16x128_f8f6f4 — K = 128 per instruction at twice the f16 rate per product (measured, tools/probes/mx_probe.hip: 32 cycles per
 // instruction against 4 x 18 for the same K in f16).  The remainder is <= 2^-11 of the activation, so its 4 significant bits cost 2^-15
 // relative; it is scaled by 2^13 into the e4m3 range (clamped at 448: v_cvt_pk_fp8_f32 turns larger values into NaN) and the weight by a
 // power of two chosen per matrix at load (Weight::s8); both scales go back out through the instruction's E8M0 scale operands.  Operand

@@ -1,6 +1,6 @@
 """not-gpu: the host encoder of the precision-6 weight copies (f32 -> OCP e4m3, round to nearest even, saturating) against a brute-force
 nearest-code search over the 127 non-negative finite codes, and against the bytes v_cvt_pk_fp8_f32 produced on an MI355X for the same inputs
-(tools/mx_probe.hip — the device converts the activations, the host the weights: both must be the format the MX MFMA reads)."""
+(tools/probes/mx_probe.hip — the device converts the activations, the host the weights: both must be the format the MX MFMA reads)."""
 import math
 
 import numpy as np
@@ -47,7 +47,7 @@ def test_e4m3_encoder():
         want = nearest(abs(float(x))) | (0x80 if x < 0 else 0)
         assert enc(x) == want, (float(x), enc(x), want)
     assert enc(500.0) == 0x7e and enc(-1e30) == 0xfe and enc(math.inf) == 0x7e and enc(math.nan) & 0x7f == 0x7f
-    # what the device's v_cvt_pk_fp8_f32 returned (tools/mx_probe.hip on gfx950) for values below its NaN threshold
+    # what the device's v_cvt_pk_fp8_f32 returned (tools/probes/mx_probe.hip on gfx950) for values below its NaN threshold
     for x, code in ((0.0, 0x00), (1.0, 0x38), (0.5, 0x30), (1.75, 0x3e), (448.0, 0x7e), (449.0, 0x7e), (2.0 ** -9, 0x01), (2.0 ** -10, 0x00),
                     (0.0176, 0x09), (3.3, 0x45), (0.1, 0x1d), (240.0, 0x77)):
         assert enc(x) == code, (x, enc(x), code)
