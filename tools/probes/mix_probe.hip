@@ -35,14 +35,19 @@ __global__ void k_mix(float* out, int iters, int sa, int sb) {
   if ((threadIdx.x & 63) == 0) { out[(threadIdx.x >> 6) * 2] = (float)(t1 - t0) / (float)iters; out[(threadIdx.x >> 6) * 2 + 1] = s; }
 }
 template <int NF16, int NMX>
-void run(const char* what, int threads, int sa, int sb) {
+void run(const char* what, int threads, int sa, int sb, int blocks = 1, int iters = 500) {
   float* d; float h[16] = {0};
   hipMalloc(&d, 64);
-  k_mix<NF16, NMX><<<1, threads>>>(d, 500, sa, sb);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  k_mix<NF16, NMX><<<blocks, threads>>>(d, iters, sa, sb);   // warm
+  hipEventRecord(e0);
+  k_mix<NF16, NMX><<<blocks, threads>>>(d, iters, sa, sb);   // (every block writes the same slots: the last one's figures stay)
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
   hipMemcpy(h, d, 64, hipMemcpyDeviceToHost);
-  printf("%-34s %d waves, scales %08x/%08x: cycles per iteration, wave 0..: ", what, threads / 64, sa, sb);
+  printf("%-18s %4d blocks x %d waves: counter ticks per iteration, wave 0..: ", what, blocks, threads / 64);
   for (int w = 0; w < threads / 64; w++) printf("%.0f ", h[2 * w]);
-  printf("\n");
+  printf("| kernel %.3f ms = %.1f ns per iteration of the slowest wave -> %.2f ticks per ns\n", ms, 1e6 * ms / iters, h[2 * (threads / 64 - 1)] / (1e6 * ms / iters));
   hipFree(d);
 }
 int main() {
@@ -55,5 +60,9 @@ int main() {
   run<8, 2>("64 f16 + 16 mx", 64, 0x78787878, 0x72727272);
   run<8, 2>("64 f16 + 16 mx", 512, 0x78787878, 0x72727272);
   run<8, 2>("64 f16 + 16 mx", 512, 0x7f7f7f7f, 0x7f7f7f7f);
+  // the whole chip busy: does the counter follow the shader clock, and does the clock hold?
+  run<16, 0>("128 f16", 512, 0, 0, 1, 20000);
+  run<16, 0>("128 f16", 512, 0, 0, 256, 20000);
+  run<16, 0>("128 f16", 512, 0, 0, 1024, 5000);
   return 0;
 }
