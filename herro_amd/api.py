@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HERRO_LIB") or os.path.join(_HERE, "libherro_amd.so")
 _LIB = None
 # GEMM precision used by bench.py / smoke / the end-to-end tests (herro_set_precision): 1 = bf16 hi/lo x3,
-# 4 = f16 (conv / FC / attention single, encoder GEMMs activation hi + lo), see csrc/model_h.hip
+# 4 = f16 (conv / FC / attention single, encoder GEMMs activation hi + lo), see csrc/model_h.hip; 6 = 4 with the activation remainder as e4m3 on the
+# K = 128 MX MFMA (same contract, measured no faster on an MI355X: not the default)
 DEFAULT_PRECISION = 4
 
 EXPORTS = [
