@@ -70,6 +70,7 @@ class FakeCtx:
 @pytest.mark.parametrize("argv,steps,strong_mode", [(["--steps", "12", "--warmup", "4", "--group", "3", "--streams", "2"], 12, "ok"),
                                                     (["--steps", "7", "--warmup", "1", "--group", "32", "--streams", "2"], 7, "ok"),
                                                     (["--steps", "1", "--warmup", "0"], 1, "ok"),
+                                                    (["--steps", "3", "--warmup", "0", "--precision", "6"], 3, "ok"),   # the e4m3-remainder mode has its dtype / MFMA-terms entries
                                                     ([], None, "ok"),
                                                     (["--steps", "2", "--warmup", "0"], 2, "raises"),
                                                     (["--steps", "2", "--warmup", "0", "--strong-timeout", "0.3"], 2, "hangs")])
