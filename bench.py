@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TF = 2500.0     # dense bf16 / f16 MFMA
 W, N_OVL, WINS_PER_TARGET = 4096, 32, 4
 DTYPE = {0: "f32", 1: "bf16x3", 2: "f32-valu", 3: "bf16x3", 4: "f16 (encoder proj / FF GEMMs: activation hi+lo)", 5: "f16", 6: "f16 (encoder proj / FF GEMMs: activation f16 + an e4m3 remainder term on the MX MFMA)"}
-MFMA_TERMS = {1: 3, 3: 3, 4: 1.75, 5: 1, 6: 1.33}   # MFMA products issued per algorithmic product in the encoder GEMMs (4: QKV one, proj / FF1 / FF2 two)
+MFMA_TERMS = {1: 3, 3: 3, 4: 1.75, 5: 1, 6: 1.375}   # MFMA products issued per algorithmic product in the encoder GEMMs (4: QKV one, proj / FF1 / FF2 two; 6: their second term on the MX MFMA at half an f16 product's pipe time)
 
 
 def cpu_baseline(seed: int) -> dict:
