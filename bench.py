@@ -40,8 +40,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TF = 2500.0     # dense bf16 / f16 MFMA
 W, N_OVL, WINS_PER_TARGET = 4096, 32, 4
-DTYPE = {0: "f32", 1: "bf16x3", 2: "f32-valu", 3: "bf16x3", 4: "f16 (encoder proj / FF GEMMs: activation hi+lo)", 5: "f16", 6: "f16 (encoder proj / FF GEMMs: activation f16 + an e4m3 remainder term on the MX MFMA)"}
-MFMA_TERMS = {1: 3, 3: 3, 4: 1.75, 5: 1, 6: 1.375}   # MFMA products issued per algorithmic product in the encoder GEMMs (4: QKV one, proj / FF1 / FF2 two; 6: their second term on the MX MFMA at half an f16 product's pipe time)
+DTYPE = {0: "f32", 1: "bf16x3", 2: "f32-valu", 3: "bf16x3", 4: "f16 (encoder proj / FF GEMMs: activation hi+lo)", 5: "f16", 6: "f16 (encoder proj / FF GEMMs: activation f16 + an e4m3 remainder term on the MX MFMA)",
+         7: "f16 (encoder proj GEMM: activation hi+lo; FF single)", 8: "f16 (encoder FF GEMMs: activation hi+lo; proj single)"}
+# MFMA products issued per algorithmic product in the encoder GEMMs (4: QKV one, proj / FF1 / FF2 two; 6: their second term on the MX MFMA at half an f16 product's pipe time;
+# 7 / 8: the mixed tiers of round 6 — QKV 3 + proj 1 + FF 8 flop units per layer)
+MFMA_TERMS = {1: 3, 3: 3, 4: 1.75, 5: 1, 6: 1.375, 7: 13 / 12, 8: 20 / 12}
 
 
 def cpu_baseline(seed: int) -> dict:
@@ -171,8 +174,8 @@ def main():
                     help="batches per launch group: the windows of GROUP consecutive steps are featurised and run "
                          "through the model in one set of kernel launches (each window keeps its own batch's padding)")
     ap.add_argument("--precision", type=int, default=None,
-                    help="GEMM operand format (herro_set_precision); default = herro_amd.api.DEFAULT_PRECISION, the mode the "
-                         "end-to-end parity test holds to the 1e-3 logits contract")
+                    help="GEMM operand format (herro_set_precision); default = the tier herro_load_model's calibration chooses for the model "
+                         "(the cheapest f16 tier within 5e-4 of the f32 mode on the calibration batch; reported as config.precision / precision_choice)")
     ap.add_argument("--streams", type=int, default=2,
                     help="independent contexts (HIP streams) per GPU, each driven by its own host thread, like the "
                          "reference's concurrent feature / inference threads per device (lib.rs:154-200)")
@@ -225,13 +228,19 @@ def main():
         args.e2e_jobs = 6 if world == 1 else 0
 
     from herro_amd import api, model_io, synth
-    if args.precision is None:
-        args.precision = api.DEFAULT_PRECISION
+    path, _ = model_io.default_model_file(os.path.join(ROOT, "tests", "_cache"))
+    precision_choice = {"how": "requested (--precision)"}
     if args.scaling == "strong":
         from herro_amd import shard
-        return shard.bench_strong(args, rank, world, local)
+        return shard.bench_strong(args, rank, world, local)   # (its contexts keep the load-time choice when --precision is not given)
+    if args.precision is None:   # the library's own choice for THIS model: every context is then set to it explicitly (all legs, child runs, the sharded path)
+        c0 = api.Context(local)
+        c0.load_model(path)
+        args.precision = c0.precision()
+        precision_choice = {"how": "calibrated by herro_load_model (cheapest f16 tier within 5e-4 of mode 0 on 256 pileup-shaped rows)",
+                            "calibration_error": {str(m): c0.calibration_error(m) for m in (5, 7, 8, 4)}}
+        c0.close()
     targets_per_step = args.batch // WINS_PER_TARGET
-    path, _ = model_io.default_model_file(os.path.join(ROOT, "tests", "_cache"))
     # at least two launch groups per timed region when possible, so that featurize(k+1) can overlap infer(k)
     G = max(1, min(args.group, args.steps // max(1, args.min_jobs)))
     n_full, rem = divmod(args.steps, G)
@@ -575,7 +584,7 @@ def main():
                                    "(BASELINE configs[2])", "batch": args.batch, "window": W, "overlaps": N_OVL,
                        "mean_len": st["sum_len"] / (G * args.batch), "mean_informative": st["sum_supported"] / (G * args.batch),
                        "model_windows_per_batch": st["n_model_windows"] / G, "batches_per_launch_group": G,
-                       "streams_per_gpu": NS, "distinct_windows_cycled": n_jobs * G * args.batch, "precision": args.precision,
+                       "streams_per_gpu": NS, "distinct_windows_cycled": n_jobs * G * args.batch, "precision": args.precision, "precision_choice": precision_choice,
                        "total_windows": total_windows, "strong_leg_windows": args.strong_windows},
             "mbases_per_s": total_windows / el * W / 1e6,
             "roofline": roof,

@@ -20,7 +20,7 @@ DEFAULT_PRECISION = 4
 EXPORTS = [
     "herro_version", "herro_create", "herro_destroy", "herro_last_error", "herro_set_stream", "herro_synchronize",
     "herro_encode_2bit", "herro_decode_2bit", "herro_set_reads", "herro_set_reads_packed", "herro_share_reads", "herro_load_model",
-    "herro_set_precision", "herro_model_describe", "herro_job_create", "herro_job_free", "herro_job_n_windows", "herro_job_skipped", "herro_job_featurize",
+    "herro_set_precision", "herro_precision", "herro_calibration_error", "herro_debug_force_precision", "herro_model_describe", "herro_job_create", "herro_job_free", "herro_job_n_windows", "herro_job_skipped", "herro_job_featurize",
     "herro_job_infer", "herro_job_consensus", "herro_job_consensus_fetch", "herro_job_window_info", "herro_job_window_copy", "herro_job_window_logits",
     "herro_job_consensus_fasta", "herro_job_fasta", "herro_model_forward", "herro_timing_enable", "herro_timing_reset",
     "herro_timing_get", "herro_job_stats", "herro_debug_extract_windows",
@@ -100,6 +100,10 @@ def lib():
         L.herro_debug_zero_copy_jobs.argtypes = []
         L.herro_load_model.argtypes = [vp, C.c_char_p]
         L.herro_set_precision.argtypes = [vp, i32]
+        L.herro_precision.argtypes = [vp]
+        L.herro_calibration_error.restype = C.c_float
+        L.herro_calibration_error.argtypes = [vp, i32]
+        L.herro_debug_force_precision.argtypes = [vp, i32]
         L.herro_job_create.restype = vp
         L.herro_job_create.argtypes = [vp, u32, vp, vp, vp, u32]
         L.herro_job_free.argtypes = [vp]
@@ -363,6 +367,18 @@ class Context:
 
     def set_precision(self, mode: int):
         self._chk(self._l.herro_set_precision(self.h, mode))
+
+    def precision(self) -> int:
+        """the mode in force: the caller's, or the tier herro_load_model's calibration chose"""
+        return int(self._l.herro_precision(self.h))
+
+    def calibration_error(self, mode: int) -> float:
+        """max |logit(mode) - logit(mode 0)| on the load-time calibration batch (-1: not measured)"""
+        return float(self._l.herro_calibration_error(self.h, mode))
+
+    def force_precision(self, on: bool):
+        """test hook (herro_debug_force_precision): set_precision / load_model skip the calibration gate"""
+        self._chk(self._l.herro_debug_force_precision(self.h, int(on)))
 
     def featurize_planes(self, on: bool):
         """test hook: jobs featurized from now on take the planes path (k_tokens) instead of the lean one (k_rows)"""

@@ -167,9 +167,9 @@ struct herro_ctx {
   std::vector<void*> model_allocs;
   int precision = 1;
   bool precision_set = false;   // herro_set_precision was called: herro_load_model keeps the caller's choice
+  bool debug_force_precision = false;   // herro_debug_force_precision: herro_set_precision skips the calibration gate (tests measure the modes a model's calibration refuses)
   float wmax = 0.f;             // largest |weight| of the loaded model
-  float calib_err = -1.f;       // max |logit difference| mode 4 vs mode 0 (f32 MFMA) on the calibration batch (-1: not run)
-  float calib_err6 = -1.f;      // ... mode 6 vs mode 0
+  float calib[9] = {-1.f, -1.f, -1.f, -1.f, -1.f, -1.f, -1.f, -1.f, -1.f};   // [mode]: max |logit difference| of f16 mode 4 .. 8 vs mode 0 (f32 MFMA) on the calibration batch (-1: not run)
   std::string calib_note;
   ModelScratch S{};
   uint32_t scratch_cap = 0;
@@ -587,7 +587,7 @@ static void run_model(herro_ctx* ctx, const BatchDev& B, bool tiled) {
   if (B.n_tok == 0) return;
   const int p = ctx->precision;
   if (!tiled) { launch_model(ctx->M, B, ctx->S, (p == 1 || p >= 4) ? 3 : p, ctx->stream, &ctx->timer); return; }
-  if (p >= 4) launch_model_h(ctx->M, B, ctx->S, p == 4 ? 2 : (p == 6 ? 3 : 1), ctx->stream, &ctx->timer);
+  if (p >= 4) launch_model_h(ctx->M, B, ctx->S, p == 4 ? 2 : (p == 6 ? 3 : (p == 7 ? 21 : (p == 8 ? 12 : 1))), ctx->stream, &ctx->timer);
   else launch_model(ctx->M, B, ctx->S, p, ctx->stream, &ctx->timer);
 }
 
@@ -950,6 +950,61 @@ const float* up_f32(herro_ctx* ctx, const std::vector<float>& v, hipError_t& e) 
 }
 }  // namespace
 
+// Calibration of the f16 modes on the loaded model: 4 windows x 96 rows, 64 informative rows each (fused tiles), pileup-shaped — a target column, 30 read
+// columns that cover a stretch of the window on one strand and agree with the target but for ~3 % mismatches and ~2 % gaps, '.' outside their stretch,
+// insertion rows ('*' in the target, a base in a fifth of the reads), qualities ~N(22, 8).  Reference = mode 0 (f32 MFMA).  Fills ctx->calib[mode] for the
+// listed modes with max |logit(mode) - logit(mode 0)| (inf when the run fails or is not finite); ctx->precision is restored.
+static int calibrate(herro_ctx* ctx, const int* modes, int n_modes) {
+  const uint32_t B = 4, L = 96, NS = 64;
+  std::vector<uint8_t> cb((size_t)B * L * HERRO_ROWS), cq(cb.size());
+  uint64_t x = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+  auto uni = [&]() { return (double)(rnd() >> 11) * (1.0 / 9007199254740992.0); };
+  for (uint32_t b = 0; b < B; b++) {
+    std::vector<uint8_t> truth(L);
+    for (uint32_t r = 0; r < L; r++) truth[r] = uni() < 0.08 ? 4 : (uint8_t)(rnd() & 3);   // 4: an insertion row ('*' in the target)
+    for (uint32_t c = 0; c < HERRO_ROWS; c++) {
+      const uint32_t strand = c ? (uint32_t)(rnd() & 1) : 0u, gap = 4 + 5 * strand;
+      const uint32_t lo = c && uni() < 0.3 ? (uint32_t)(uni() * 30) : 0u, hi = c && uni() < 0.3 ? L - (uint32_t)(uni() * 30) : L;
+      for (uint32_t r = 0; r < L; r++) {
+        uint8_t tok;
+        if (r < lo || r >= hi) tok = TOK_NONE;
+        else if (c == 0) tok = truth[r];
+        else if (truth[r] == 4) tok = uni() < 0.2 ? (uint8_t)((rnd() & 3) + 5 * strand) : (uint8_t)gap;
+        else { const double u = uni(); tok = u < 0.95 ? (uint8_t)(truth[r] + 5 * strand) : (u < 0.98 ? (uint8_t)(((truth[r] + 1 + (rnd() % 3)) & 3) + 5 * strand) : (uint8_t)gap); }
+        double g = 0; for (int k = 0; k < 12; k++) g += uni();   // ~N(6, 1)
+        const double q = std::min(50.0, std::max(2.0, std::floor(22.0 + 8.0 * (g - 6.0) + 0.5)));
+        const bool has_q = tok != TOK_NONE && tok != gap && tok != 4;
+        const size_t i = ((size_t)b * L + r) * HERRO_ROWS + c;
+        cb[i] = tok; cq[i] = has_q ? (uint8_t)(33 + q) : (uint8_t)33;
+      }
+    }
+  }
+  std::vector<int32_t> lens(B, (int32_t)NS), idx((size_t)B * NS);
+  for (uint32_t b = 0; b < B; b++) for (uint32_t k = 0; k < NS; k++) idx[(size_t)b * NS + k] = (int32_t)(16 + k);
+  std::vector<float> i1((size_t)B * NS), b1((size_t)B * NS * 5), i4(i1.size()), b4(b1.size());
+  const int keep = ctx->precision;
+  ctx->precision = 0;
+  const int rc = herro_model_forward(ctx, B, L, cb.data(), cq.data(), lens.data(), idx.data(), i1.data(), b1.data());
+  if (rc != HERRO_OK) { ctx->precision = keep; return rc; }
+  for (int m = 0; m < n_modes; m++) {
+    const int mode = modes[m];
+    if (mode < 4 || mode > 8) continue;
+    ctx->precision = mode;
+    float err = INFINITY;
+    if ((mode != 6 || model_h_f8_supported(ctx->M)) && herro_model_forward(ctx, B, L, cb.data(), cq.data(), lens.data(), idx.data(), i4.data(), b4.data()) == HERRO_OK) {
+      err = 0.f;
+      bool finite = true;
+      for (size_t i = 0; i < i1.size(); i++) { finite = finite && std::isfinite(i4[i]); err = std::max(err, std::fabs(i4[i] - i1[i])); }
+      for (size_t i = 0; i < b1.size(); i++) { finite = finite && std::isfinite(b4[i]); err = std::max(err, std::fabs(b4[i] - b1[i])); }
+      if (!finite) err = INFINITY;
+    }
+    ctx->calib[mode] = err;
+  }
+  ctx->precision = keep;
+  return HERRO_OK;
+}
+
 int herro_load_model(herro_ctx* ctx, const char* path) {
   if (!ctx || !path) return HERRO_E_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1119,19 +1174,45 @@ int herro_load_model(herro_ctx* ctx, const char* path) {
   if (missing) { free_all(ctx->model_allocs); return HERRO_E_NO_MODEL; }
   HIP_TRY(ctx, e);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  M.pe_tab = nullptr;
+  M.pe_rows = 0;
+  if (model_h_supported(M)) {   // the positional encoding of rows 0 .. 16383 (a 4096-base window has ~4700 rows, an 8192-base one ~9500), 16 MB; k_layers_p computes the rows beyond it itself
+    const uint32_t rows = 16384;
+    float* tab = nullptr;
+    if (hipMalloc(&tab, (size_t)rows * D * 4) == hipSuccess) {
+      ctx->model_allocs.push_back(tab);
+      launch_pe_table(M.pe_div, tab, rows, D, ctx->stream);
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      M.pe_tab = tab;
+      M.pe_rows = rows;
+    } else (void)hipGetLastError();
+  }
   ctx->M = M;
   ctx->has_model = true;
   ctx->wmax = wmax_seen;
-  ctx->calib_err = -1.f;
-  ctx->calib_err6 = -1.f;
+  for (float& c : ctx->calib) c = -1.f;
   ctx->calib_note.clear();
-  // Operand format.  bf16 hi/lo x3 (mode 1, ~1e-5) always works.  f16 (mode 4) needs the shapes its kernels are written
+  // Operand format.  bf16 hi/lo x3 (mode 1, ~1e-5) always works.  The f16 modes need the shapes their kernels are written
   // for, weights inside the f16 range (|w| >= 65520 rounds to inf, the remainder term to -inf: NaN logits), and — because
-  // its margin to the 1e-3 contract was measured on random-init weights only — a calibration run on THIS model.
+  // their margin to the 1e-3 contract was measured on random-init weights only — a calibration run on THIS model.
   const bool f16_ok = model_h_supported(M) && wmax_seen < 65504.f;
-  if (ctx->precision_set) {
+  static const bool force = ab_env("HERRO_FORCE_PRECISION", 0) != 0;
+  if (ctx->precision_set) {   // the caller's choice stands — held to the same bound as the library's own (a mode set before the load used to go unchecked)
     if (ctx->precision >= 4 && !f16_ok) { ctx->precision = 1; ctx->calib_note = "f16 modes unavailable for this model (shapes or weight range): mode 1"; }
     if (ctx->precision == 6 && !model_h_f8_supported(M)) { ctx->precision = 4; ctx->calib_note = "no e4m3 weight copies for this model (K % 128): mode 4"; }
+    if (ctx->precision >= 4) {
+      const int want = ctx->precision;
+      const int modes[1] = {want};
+      const int rc = calibrate(ctx, modes, 1);
+      ctx->precision = want;
+      if (rc != HERRO_OK || !(ctx->calib[want] <= 5e-4f)) {
+        char buf[200];
+        const bool forced = force || ctx->debug_force_precision;
+        snprintf(buf, sizeof buf, "requested mode %d measured %.3g (> 5e-4) against mode 0 on the calibration batch%s", want, (double)ctx->calib[want], forced ? " (forced)" : ": mode 1");
+        ctx->calib_note = buf;
+        if (!forced) ctx->precision = 1;
+      }
+    }
     return HERRO_OK;
   }
   if (!f16_ok) {
@@ -1139,58 +1220,17 @@ int herro_load_model(herro_ctx* ctx, const char* path) {
     ctx->calib_note = model_h_supported(M) ? "a weight lies outside the f16 range: mode 1" : "no f16 kernels for these shapes: mode 1";
     return HERRO_OK;
   }
-  {  // calibration: 4 windows x 96 rows, 64 informative rows each (fused tiles), pileup-shaped: a target column, 30 read columns that
-     // cover a stretch of the window on one strand and agree with the target but for ~3 % mismatches and ~2 % gaps, '.' outside their
-     // stretch, insertion rows ('*' in the target, a base in a fifth of the reads), qualities ~N(22, 8).  Reference = mode 0 (f32 MFMA).
-    const uint32_t B = 4, L = 96, NS = 64;
-    std::vector<uint8_t> cb((size_t)B * L * HERRO_ROWS), cq(cb.size());
-    uint64_t x = 0x9E3779B97F4A7C15ull;
-    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
-    auto uni = [&]() { return (double)(rnd() >> 11) * (1.0 / 9007199254740992.0); };
-    for (uint32_t b = 0; b < B; b++) {
-      std::vector<uint8_t> truth(L);
-      for (uint32_t r = 0; r < L; r++) truth[r] = uni() < 0.08 ? 4 : (uint8_t)(rnd() & 3);   // 4: an insertion row ('*' in the target)
-      for (uint32_t c = 0; c < HERRO_ROWS; c++) {
-        const uint32_t strand = c ? (uint32_t)(rnd() & 1) : 0u, gap = 4 + 5 * strand;
-        const uint32_t lo = c && uni() < 0.3 ? (uint32_t)(uni() * 30) : 0u, hi = c && uni() < 0.3 ? L - (uint32_t)(uni() * 30) : L;
-        for (uint32_t r = 0; r < L; r++) {
-          uint8_t tok;
-          if (r < lo || r >= hi) tok = TOK_NONE;
-          else if (c == 0) tok = truth[r];
-          else if (truth[r] == 4) tok = uni() < 0.2 ? (uint8_t)((rnd() & 3) + 5 * strand) : (uint8_t)gap;
-          else { const double u = uni(); tok = u < 0.95 ? (uint8_t)(truth[r] + 5 * strand) : (u < 0.98 ? (uint8_t)(((truth[r] + 1 + (rnd() % 3)) & 3) + 5 * strand) : (uint8_t)gap); }
-          double g = 0; for (int k = 0; k < 12; k++) g += uni();   // ~N(6, 1)
-          const double q = std::min(50.0, std::max(2.0, std::floor(22.0 + 8.0 * (g - 6.0) + 0.5)));
-          const bool has_q = tok != TOK_NONE && tok != gap && tok != 4;
-          const size_t i = ((size_t)b * L + r) * HERRO_ROWS + c;
-          cb[i] = tok; cq[i] = has_q ? (uint8_t)(33 + q) : (uint8_t)33;
-        }
-      }
-    }
-    std::vector<int32_t> lens(B, (int32_t)NS), idx((size_t)B * NS);
-    for (uint32_t b = 0; b < B; b++) for (uint32_t k = 0; k < NS; k++) idx[(size_t)b * NS + k] = (int32_t)(16 + k);
-    std::vector<float> i1((size_t)B * NS), b1((size_t)B * NS * 5), i4(i1.size()), b4(b1.size());
-    ctx->precision = 0;
-    int rc = herro_model_forward(ctx, B, L, cb.data(), cq.data(), lens.data(), idx.data(), i1.data(), b1.data());
-    auto measure = [&](int mode) -> float {   // max |logit(mode) - logit(mode 0)|; inf when the run fails or is not finite
-      ctx->precision = mode;
-      if (herro_model_forward(ctx, B, L, cb.data(), cq.data(), lens.data(), idx.data(), i4.data(), b4.data()) != HERRO_OK) return INFINITY;
-      float err = 0.f;
-      bool finite = true;
-      for (size_t i = 0; i < i1.size(); i++) { finite = finite && std::isfinite(i4[i]); err = std::max(err, std::fabs(i4[i] - i1[i])); }
-      for (size_t i = 0; i < b1.size(); i++) { finite = finite && std::isfinite(b4[i]); err = std::max(err, std::fabs(b4[i] - b1[i])); }
-      return finite ? err : INFINITY;
-    };
+  {  // the tiers, cheapest first (MFMA call-terms per encoder layer: 12, 13, 20, 21): the first one within 5e-4 (half the contract) of mode 0 is kept (round 6).
+     // Mode 6 (e4m3 remainder) measures no faster than 4 and is not a candidate; herro_set_precision(6) calibrates it on demand.
+    static const int tiers[4] = {5, 7, 8, 4};
+    const int rc = calibrate(ctx, tiers, 4);
     if (rc != HERRO_OK) { ctx->precision = 1; ctx->calib_note = "calibration run failed: mode 1"; return HERRO_OK; }
-    ctx->calib_err = measure(4);
-    // precision 6 (the remainder term in e4m3 on the K = 128 instruction) is calibrated alongside so that herro_set_precision(6) can be held to the same bound; it is
-    // NOT chosen here: it takes 28 % of the MFMA pipe time out of proj / FF1 / FF2 and measures no faster (HERRO_ALLOW_P6=1 in A/B builds)
-    static const bool allow6 = ab_env("HERRO_ALLOW_P6", 0) != 0;
-    ctx->calib_err6 = model_h_f8_supported(M) ? measure(6) : INFINITY;
-    ctx->precision = (allow6 && ctx->calib_err6 <= 5e-4f) ? 6 : (ctx->calib_err <= 5e-4f ? 4 : 1);
-    char buf[300];
-    snprintf(buf, sizeof buf, "calibration (256 pileup-shaped rows): max |logit(mode) - logit(mode 0, f32)| = %.3g (mode 4, f16) / %.3g (mode 6, f16 + e4m3 remainder) -> mode %d",
-             (double)ctx->calib_err, (double)ctx->calib_err6, ctx->precision);
+    ctx->precision = 1;
+    for (int t : tiers) if (ctx->calib[t] <= 5e-4f) { ctx->precision = t; break; }
+    char buf[400];
+    snprintf(buf, sizeof buf, "calibration (256 pileup-shaped rows): max |logit(mode) - logit(mode 0, f32)| = %.3g (mode 5, f16 single terms) / %.3g (mode 7, FF single) / "
+             "%.3g (mode 8, proj single) / %.3g (mode 4, f16) -> mode %d (the cheapest within 5e-4)",
+             (double)ctx->calib[5], (double)ctx->calib[7], (double)ctx->calib[8], (double)ctx->calib[4], ctx->precision);
     ctx->calib_note = buf;
   }
   return HERRO_OK;
@@ -1224,33 +1264,50 @@ int64_t herro_model_describe(const herro_ctx* ctx, char* out, uint64_t cap) {
 }
 
 int herro_set_precision(herro_ctx* ctx, int mode) {
-  if (!ctx || mode < 0 || mode > 6) return HERRO_E_INVALID;
+  if (!ctx || mode < 0 || mode > 8) return HERRO_E_INVALID;
   if (mode >= 4 && ctx->has_model && ctx->wmax >= 65504.f) {
-    ctx->err = "precision 4 / 5 (f16 operands): a weight of this model lies outside the f16 range";
+    ctx->err = "precision 4 .. 8 (f16 operands): a weight of this model lies outside the f16 range";
     return HERRO_E_UNSUPPORTED;
   }
   if (mode >= 4 && ctx->has_model && !model_h_supported(ctx->M)) {
-    ctx->err = "precision 4 / 5 (f16 kernels) need kw 3, conv 64/128, d_model 256, 8 heads, d_ff % 256 == 0";
+    ctx->err = "precision 4 .. 8 (f16 kernels) need kw 3, conv 64/128, d_model 256, 8 heads, d_ff % 256 == 0";
     return HERRO_E_UNSUPPORTED;
   }
-  // the load-time calibration ran and found the f16 kernels outside half the 1e-3 contract on THIS model: an explicit request for
-  // them is refused (HERRO_FORCE_PRECISION=1 overrides, for measurements)
   if (mode == 6 && ctx->has_model && !model_h_f8_supported(ctx->M)) {
     ctx->err = "precision 6 needs the e4m3 copies of proj / ff1 / ff2 (K % 128 == 0)";
     return HERRO_E_UNSUPPORTED;
   }
-  const float cal = mode == 6 ? ctx->calib_err6 : ctx->calib_err;
-  if (mode >= 4 && ctx->has_model && (cal > 5e-4f || std::isnan(cal))) {
-    static const bool force = ab_env("HERRO_FORCE_PRECISION", 0) != 0;
-    if (!force) {
-      char buf[200];
-      snprintf(buf, sizeof buf, "precision %d refused: the calibration of this model measured a logit difference of %.3g (> 5e-4) for the f16 kernels", mode, (double)cal);
-      ctx->err = buf;
-      return HERRO_E_UNSUPPORTED;
+  // every f16 mode is held to the calibration of THIS model — measured here if the load did not (mode 6 always; any mode when the load-time choice was
+  // switched off by an earlier call) — and refused above 5e-4, half the 1e-3 contract (HERRO_FORCE_PRECISION=1 in A/B builds overrides, for measurements)
+  if (mode >= 4 && ctx->has_model) {
+    if (ctx->calib[mode] < 0.f) {
+      const int modes[1] = {mode};
+      const int rc = calibrate(ctx, modes, 1);
+      if (rc != HERRO_OK) return rc;
+    }
+    const float cal = ctx->calib[mode];
+    if (cal > 5e-4f || std::isnan(cal)) {
+      static const bool force = ab_env("HERRO_FORCE_PRECISION", 0) != 0;
+      if (!force && !ctx->debug_force_precision) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "precision %d refused: the calibration of this model measured a logit difference of %.3g (> 5e-4) for the f16 kernels", mode, (double)cal);
+        ctx->err = buf;
+        return HERRO_E_UNSUPPORTED;
+      }
     }
   }
   ctx->precision = mode;
   ctx->precision_set = true;
+  return HERRO_OK;
+}
+
+int herro_precision(const herro_ctx* ctx) { return ctx ? ctx->precision : HERRO_E_INVALID; }
+
+float herro_calibration_error(const herro_ctx* ctx, int mode) { return (ctx && mode >= 4 && mode <= 8) ? ctx->calib[mode] : -1.f; }
+
+int herro_debug_force_precision(herro_ctx* ctx, int on) {
+  if (!ctx) return HERRO_E_INVALID;
+  ctx->debug_force_precision = on != 0;
   return HERRO_OK;
 }
 
@@ -1270,6 +1327,7 @@ static int ensure_scratch(herro_ctx* ctx, uint32_t n_tok) {
   };
   S.tok_win = (uint32_t*)A(cap * 4);
   S.tok_row = (uint32_t*)A(cap * 4);
+  S.tok_out = (uint64_t*)A(cap * 8);
   S.tok_meta = (TokMeta*)A(cap * sizeof(TokMeta));
   S.tok_cv = (TokCv*)A(cap * sizeof(TokCv));
   S.y1 = (float*)A(cap * HERRO_ROWS * h.kw * h.c1 * 4);
@@ -1285,7 +1343,7 @@ static int ensure_scratch(herro_ctx* ctx, uint32_t n_tok) {
   S.h_hi = (uint16_t*)A(cap * h.d_model * 2); S.h_lo = (uint16_t*)A(cap * h.d_model * 2);
   S.att_hi = (uint16_t*)A(cap * h.d_model * 2); S.att_lo = (uint16_t*)A(cap * h.d_model * 2);
   S.ff_hi = (uint16_t*)A(cap * h.d_ff * 2); S.ff_lo = (uint16_t*)A(cap * h.d_ff * 2);
-  if (!S.y1_hi || !S.y1_lo || !S.y2_hi || !S.y2_lo || !S.h_hi || !S.h_lo || !S.att_hi || !S.att_lo || !S.ff_hi || !S.ff_lo ||!S.tok_win || !S.tok_row || !S.tok_meta || !S.tok_cv || !S.y1 || !S.y2 || !S.x || !S.hbuf || !S.qkv || !S.att || !S.ff || !S.logits) {
+  if (!S.y1_hi || !S.y1_lo || !S.y2_hi || !S.y2_lo || !S.h_hi || !S.h_lo || !S.att_hi || !S.att_lo || !S.ff_hi || !S.ff_lo ||!S.tok_win || !S.tok_row || !S.tok_out || !S.tok_meta || !S.tok_cv || !S.y1 || !S.y2 || !S.x || !S.hbuf || !S.qkv || !S.att || !S.ff || !S.logits) {
     free_all(ctx->scratch_allocs);
     ctx->scratch_cap = 0;
     ctx->err = "out of device memory for model scratch (" + std::to_string(cap) + " tokens)";

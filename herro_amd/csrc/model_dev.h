@@ -63,6 +63,8 @@ struct ModelDev {
   Weight conv2;         // [kw*c1, c2]  (BN folded), k = tap*c1 + c
   Weight fc;            // [rows*c2, d_model], k = row*c2 + c
   const float* pe_div;  // [d_model/2]
+  const float* pe_tab;  // [pe_rows][d_model] the positional encoding of rows 0 .. pe_rows - 1, tabulated at load by the arithmetic k_layers_p used to run per token
+  uint32_t pe_rows;     // (16 sincosf per lane and tile were 17 % of the stack's vector instructions); rows beyond the table are still computed in the kernel; null / 0: no table
   LayerW layer[16];
   const float *lnf_g, *lnf_b;
   Weight heads;         // [d_model, 16]: col 0 info, cols 1..5 bases
@@ -126,6 +128,7 @@ struct __attribute__((aligned(16))) TokCv {
 struct ModelScratch {  // sized for n_tok tokens
   uint32_t* tok_win;  // [N] window (batch-local) of each token
   uint32_t* tok_row;  // [N] row of each token
+  uint64_t* tok_out;  // [N] element offset of each token's logits in the job buffers (k_build_tokens_h; the stack's last phase reads one word instead of three dependent ones)
   TokMeta* tok_meta;  // [N]
   TokCv* tok_cv;      // [N]
   float* y1;          // [N][31][kw][c1]
@@ -152,11 +155,13 @@ struct ModelScratch {  // sized for n_tok tokens
 
 void launch_model(const ModelDev& M, const BatchDev& B, const ModelScratch& S, int precision,
                   hipStream_t st, KernelTimer* tm);
-// f16-operand kernels (model_h.hip): terms = 2 -> precision 4, terms = 1 -> precision 5, terms = 3 -> precision 6 (f16 + an e4m3 remainder term).  B must be tiled (n_tiles > 0).
+// f16-operand kernels (model_h.hip): terms = 2 -> precision 4, terms = 1 -> precision 5, terms = 3 -> precision 6 (f16 + an e4m3 remainder term), 21 -> precision 7 (proj on two
+// terms, FF1 / FF2 on one), 12 -> precision 8 (proj on one, FF on two).  B must be tiled (n_tiles > 0).
 bool model_h_supported(const ModelDev& M);
 bool model_h_f8_supported(const ModelDev& M);   // ... and every layer's proj / ff1 / ff2 has its e4m3 copy
 int model_h_half_tiles(const ModelDev& M);   // qmode of plan_tiles: 0 no 32-token tiles, 1 for a short last round (default), 2 for every small window (HERRO_LAYERS_Q)
 void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S, int terms, hipStream_t st, KernelTimer* tm);
+void launch_pe_table(const float* pe_div, float* tab, uint32_t rows, uint32_t d_model, hipStream_t st);   // tab[row][2 i] = sin(row * pe_div[i]), [2 i + 1] = cos
 #ifdef HERRO_PROF_BUILD
 void model_h_prof_dump();   // phase cycles of k_layers_p (model_h.hip LP_MARK), printed by herro_destroy when HERRO_PROF=1
 #endif

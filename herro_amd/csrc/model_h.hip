@@ -97,12 +97,20 @@ __device__ __forceinline__ float fg_sum(float v) {
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
   return a + b;
 }
+// max(a, b) for values that are never NaN, in ONE instruction: fmaxf compiles to a canonicalising v_max of each operand in front of the v_max (three per maximum:
+// 48 instead of 16 per query block in the softmax); the median of (a, b, +inf) is the same number and has no such prefix
+__device__ __forceinline__ float fmax_nc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_huge_valf()); }
+__device__ __forceinline__ float fmax_asm(float a, float b) {   // ... and where the operands come out of inline asm (the compiler canonicalises those too)
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ float fg_max(float v) {
   float a = v, b = v;
   asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-  a = fmaxf(a, b); b = a;
+  a = fmax_asm(a, b); b = a;
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-  return fmaxf(a, b);
+  return fmax_asm(a, b);
 }
 __device__ __forceinline__ f32x4 mma(half8 a, half8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
@@ -585,9 +593,12 @@ __device__ __forceinline__ void wload4(const WStream& s, uint32_t k0, half8 (&w)
 #define HERRO_LP_DBG 0   // timing experiments (wrong results): 1 every second activation fragment read from LDS is skipped, 2 every second k-step's MFMAs, 4 the weight loads inside a call,
                          // 8 (precision 6) no K = 128 instructions, 16 (precision 6) no e4m3 conversion of the remainders (the byte planes stay as they are)
 #endif
-template <bool SWAP, int TERMS, int PT>
+struct NoMid { __device__ __forceinline__ void operator()(int) const {} };
+// mid(k): a slice of somebody else's vector work (the epilogue of the PREVIOUS feed-forward chunk), issued behind the first MFMA group of k-step k — the
+// matrix pipe is busy with that group (and with the SIMD partner's) while the slice issues, where an epilogue phase of its own leaves it idle
+template <bool SWAP, int TERMS, int PT, class Mid = NoMid>
 __device__ __forceinline__ void tile_gemm_p(const WStream& cur, half8 (&wa)[4][2], const WStream& nxt, const uint16_t* sh,
-                                            const uint16_t* sl, uint32_t fr, uint32_t fg, f32x4 (&acc)[PT][2]) {
+                                            const uint16_t* sl, uint32_t fr, uint32_t fg, f32x4 (&acc)[PT][2], Mid mid = Mid()) {
   half8 wb[4][2];
   if (HERRO_LP_DBG & 4) {
 #pragma unroll
@@ -643,6 +654,8 @@ __device__ __forceinline__ void tile_gemm_p(const WStream& cur, half8 (&wa)[4][2
       __builtin_amdgcn_sched_barrier(0);
       if (k < 4) mm8(xh, wa[k]); else mm8(xh, wb[k - 4]);
       __builtin_amdgcn_sched_barrier(0);
+      mid(k);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int pt = 0; pt < PT; pt++) { xh[pt] = xn[pt]; xn[pt] = xm[pt]; }
       continue;
@@ -652,6 +665,8 @@ __device__ __forceinline__ void tile_gemm_p(const WStream& cur, half8 (&wa)[4][2
     if (!(dbg_mm && (k & 1))) { if (k < 4) mm8(xh, wa[k]); else mm8(xh, wb[k - 4]); }
     __builtin_amdgcn_sched_barrier(0);
     if (k < 7 && !(dbg_rd && !(k & 1))) rd(sh, k + 1, xn);
+    __builtin_amdgcn_sched_barrier(0);
+    mid(k);
     __builtin_amdgcn_sched_barrier(0);
     if (TERMS == 2 && !(dbg_mm && (k & 1))) {
       if (k < 4) mm8(xl, wa[k]); else mm8(xl, wb[k - 4]);
@@ -712,9 +727,13 @@ __device__ unsigned long long g_lp_prof[16];
 #define LP_MARK(ph) do { } while (0)
 #endif
 
+// TERMS: MFMA terms of the two-term candidates proj / FF1 + FF2 — 1, 2, 3 (f16 + e4m3 remainder) for all three, or mixed (round 6, the tiers the load-time
+// calibration chooses from): 21 = proj on two terms, FF1 / FF2 on one ("FF single", precision 7); 12 = proj on one, FF on two ("proj single", precision 8)
 template <int TERMS, int PT, bool SIB = false>
 __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelScratch S) {
   static_assert(!SIB || PT == 4, "sibling tiles are 64-token tiles");
+  constexpr int TP = TERMS == 21 ? 2 : (TERMS == 12 ? 1 : TERMS);   // proj
+  constexpr int TF = TERMS == 21 ? 1 : (TERMS == 12 ? 2 : TERMS);   // FF1, FF2
   // SIB: the grid starts with the batch's B.n_tiles_b sibling tiles (windows above 64 informative rows), the ordinary tiles follow
   const bool big = SIB && blockIdx.x < B.n_tiles_b;
   const uint32_t bt = SIB ? (big ? blockIdx.x : blockIdx.x - B.n_tiles_b) : blockIdx.x;
@@ -755,6 +774,9 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
   // one coalesced pass over the layer's small parameter vectors -> LDS (the GEMM epilogues and LayerNorms then read
   // them with LDS latency instead of one L2 round trip each).  Visible after the next barrier.
   auto stage_params = [&](const LayerW& L) {
+    uint32_t tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));   // (opaque: the addresses below are recomputed here instead of being kept — and spilled — across the layer body)
+    const uint32_t tid = tid_;
     for (uint32_t e = tid; e < 256; e += 512) {
       s_par[PAR_LN1G + e] = L.ln1_g[e]; s_par[PAR_LN1B + e] = L.ln1_b[e];
       s_par[PAR_LN2G + e] = L.ln2_g[e]; s_par[PAR_LN2B + e] = L.ln2_b[e];
@@ -832,10 +854,11 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
 #pragma unroll
       for (int jt = 0; jt < 2; jt++) a[pt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
-  auto store_act = [&](uint16_t* ph, uint16_t* pl, uint32_t o, const float (&v)[8]) {   // o = hlsw(row, wave * 4 + fg)
-    if (TERMS == 3 && (HERRO_LP_DBG & 16)) {
+  auto store_act = [&](auto terms_c, uint16_t* ph, uint16_t* pl, uint32_t o, const float (&v)[8]) {   // o = hlsw(row, wave * 4 + fg); terms_c: the terms of the GEMM that reads the plane
+    constexpr int TA = decltype(terms_c)::value;
+    if (TA == 3 && (HERRO_LP_DBG & 16)) {
       *reinterpret_cast<half8*>(ph + o) = pack_h8(v);
-    } else if (TERMS == 3) {
+    } else if (TA == 3) {
       half8 hi;
       uint2 lo8;
       split_h8_f8(v, hi, lo8);
@@ -843,7 +866,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
       // the same (row, chunk) in the byte plane: 16-byte chunk wave * 2 + fg / 2 of the row (hlsw's 8-half chunk wave * 4 + fg, halved), XORed alike
       const uint32_t row = o >> 8, ch8 = ((o >> 3) & 31u) ^ (row & 15u);
       *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(pl) + lsw8(row, ch8 >> 1) + (ch8 & 1u) * 8) = lo8;
-    } else if (TERMS == 2) {
+    } else if (TA == 2) {
       half8 hi, lo;
       split_h8(v, hi, lo);
       *reinterpret_cast<half8*>(ph + o) = hi;
@@ -860,31 +883,43 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
 #pragma unroll
     for (int pt = 0; pt < PT; pt++) {
       const uint32_t tok = pt * 16 + fr;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, pa = a, pb = a;
       float row = 0.f;
+      uint32_t rowu = 0;
       if (tok < nt) {
         const float* xp = S.x + (uint64_t)(t0 + tok) * 256 + cw + 8 * fg;
         a = *reinterpret_cast<const float4*>(xp);
         b = *reinterpret_cast<const float4*>(xp + 4);
-        row = (float)S.tok_row[t0 + tok];
+        rowu = S.tok_row[t0 + tok];
+        row = (float)rowu;
+        if (rowu < M.pe_rows) {
+          const float* pp = M.pe_tab + (uint64_t)rowu * 256 + cw + 8 * fg;
+          pa = *reinterpret_cast<const float4*>(pp);
+          pb = *reinterpret_cast<const float4*>(pp + 4);
+        }
       }
       xr[pt][0] = f32x4{a.x, a.y, a.z, a.w};
       xr[pt][1] = f32x4{b.x, b.y, b.z, b.w};
       if (tok < nt) {
+        if (rowu < M.pe_rows) {   // the table holds exactly what the branch below computes (launch_pe_table)
+          xr[pt][0] += f32x4{pa.x, pa.y, pa.z, pa.w};
+          xr[pt][1] += f32x4{pb.x, pb.y, pb.z, pb.w};
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const float ang = __fmul_rn(row, pd[j]);
-          float sn, cs;
-          sincosf(ang, &sn, &cs);   // one range reduction for both
-          XQ(pt, 2 * j) += sn;
-          XQ(pt, 2 * j + 1) += cs;
+          for (int j = 0; j < 4; j++) {
+            const float ang = __fmul_rn(row, pd[j]);
+            float sn, cs;
+            sincosf(ang, &sn, &cs);   // one range reduction for both
+            xr[pt][j >> 1][(2 * j) & 3] += sn;
+            xr[pt][j >> 1][(2 * j + 1) & 3] += cs;
+          }
         }
       }
     }
   }
   __syncthreads();  // s_win, s_par
 
-  const float scale = 1.0f / sqrtf(32.f);
+  const float scale = 1.4426950408889634f / sqrtf(32.f);   // 1 / sqrt(head dim) and log2(e): the softmax runs on v_exp_f32 (2^x) without a multiply per score
   for (uint32_t li = 0; li < n_layers; li++) {
     const LayerW& L = M.layer[li];
     const LayerW& Ln = M.layer[li + 1 < n_layers ? li + 1 : 0];  // after the last layer: a harmless re-read of layer 0
@@ -895,31 +930,29 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
     RELAUNDER();
     {  // ---- attention, head = wave
       half8 qh[PT], kh[PT], vh[2][PT / 2];
-      {
-        f32x4 a[PT][2];
-        float bq[8];
-        zero(a);
-        tile_gemm_p<false, 1, PT>(wstream(L.qkv, cw, 0, lane), wa, wstream(L.qkv, 256 + cw, 0, lane), s_hh, s_hl, fr, fg, a);
+      {  // the epilogue of Q (bias, scale, f16 fragment) is issued in slices inside K's call, K's inside V's (round 6; as the feed-forward epilogue below)
+        f32x4 aq[PT][2], ak[PT][2], av[PT][2];
+        float bq[8], bk[8];
+        zero(aq);
+        tile_gemm_p<false, 1, PT>(wstream(L.qkv, cw, 0, lane), wa, wstream(L.qkv, 256 + cw, 0, lane), s_hh, s_hl, fr, fg, aq);
         lds8(PAR_BQKV + cw + 8 * fg, bq);
-#pragma unroll
-        for (int pt = 0; pt < PT; pt++) {
+        zero(ak);
+        tile_gemm_p<false, 1, PT>(wstream(L.qkv, 256 + cw, 0, lane), wa, wstream(L.qkv, 512 + cw, 0, lane), s_hh, s_hl, fr, fg, ak, [&](int k) {
+          if (k >= PT) return;
           float v[8];
 #pragma unroll
-          for (int q = 0; q < 8; q++) v[q] = (a[pt][q >> 2][q & 3] + bq[q]) * scale;
-          qh[pt] = pack_h8(v);
-        }
-        zero(a);
-        tile_gemm_p<false, 1, PT>(wstream(L.qkv, 256 + cw, 0, lane), wa, wstream(L.qkv, 512 + cw, 0, lane), s_hh, s_hl, fr, fg, a);
-        lds8(PAR_BQKV + 256 + cw + 8 * fg, bq);
-#pragma unroll
-        for (int pt = 0; pt < PT; pt++) {
+          for (int q = 0; q < 8; q++) v[q] = (aq[k][q >> 2][q & 3] + bq[q]) * scale;
+          qh[k] = pack_h8(v);
+        });
+        lds8(PAR_BQKV + 256 + cw + 8 * fg, bk);
+        zero(av);
+        tile_gemm_p<true, 1, PT>(wstream(L.qkv, 512 + cw, 0, lane), wa, wstream(L.proj, cw, 0, lane), s_hh, s_hl, fr, fg, av, [&](int k) {   // (a call only reads the f16 head of its successor)
+          if (k >= PT) return;
           float v[8];
 #pragma unroll
-          for (int q = 0; q < 8; q++) v[q] = a[pt][q >> 2][q & 3] + bq[q];
-          kh[pt] = pack_h8(v);
-        }
-        zero(a);
-        tile_gemm_p<true, 1, PT>(wstream(L.qkv, 512 + cw, 0, lane), wa, wstream(L.proj, cw, 0, lane), s_hh, s_hl, fr, fg, a);   // (a call only reads the f16 head of its successor)
+          for (int q = 0; q < 8; q++) v[q] = ak[k][q >> 2][q & 3] + bk[q];
+          kh[k] = pack_h8(v);
+        });
 #pragma unroll
         for (int ct = 0; ct < 2; ct++) {
           const float bv = s_par[PAR_BQKV + 512 + cw + 8 * (fr >> 2) + 4 * ct + (fr & 3)];
@@ -927,7 +960,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
           for (int kk = 0; kk < PT / 2; kk++) {
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = a[2 * kk + (e >> 2)][ct][e & 3] + bv;
+            for (int e = 0; e < 8; e++) v[e] = av[2 * kk + (e >> 2)][ct][e & 3] + bv;
             vh[ct][kk] = pack_h8(v);
           }
         }
@@ -950,7 +983,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             st[pj][r] = wj[pj][r] == wi ? st[pj][r] : -INFINITY;
-            m = fmaxf(m, st[pj][r]);
+            m = fmax_nc(m, st[pj][r]);
           }
         }
         m = fg_max(m);
@@ -959,7 +992,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
         for (int pj = 0; pj < PT; pj++)
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            const float pexp = __expf(st[pj][r] - m);
+            const float pexp = __builtin_amdgcn_exp2f(st[pj][r] - m);
             st[pj][r] = pexp;
             l += pexp;
           }
@@ -978,7 +1011,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] = o[e >> 2][e & 3] * inv;
-        store_act(s_ah, s_al, hlsw(pi * 16 + fr, wave * 4 + fg), v);
+        store_act(std::integral_constant<int, TP>{}, s_ah, s_al, hlsw(pi * 16 + fr, wave * 4 + fg), v);
       }
       } else {
         // ---- a window above 64 informative rows: its tiles (siblings) hold 64 of its tokens each.  Every tile publishes the K / V
@@ -1013,7 +1046,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
 #pragma unroll
             for (int r = 0; r < 4; r++) {
               st[pj][r] = wj[pj][r] == wi ? st[pj][r] : -INFINITY;
-              m = fmaxf(m, st[pj][r]);
+              m = fmax_nc(m, st[pj][r]);
             }
           }
           m = fg_max(m);
@@ -1022,7 +1055,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
           for (int pj = 0; pj < PT; pj++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-              const float pexp = __expf(st[pj][r] - m);
+              const float pexp = __builtin_amdgcn_exp2f(st[pj][r] - m);
               st[pj][r] = pexp;
               l += pexp;
             }
@@ -1074,17 +1107,17 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
 #pragma unroll
               for (int r = 0; r < 4; r++) {
                 st[pj][r] = ((uint32_t)(pj * 16 + 4 * fg + r) < nts && (uint32_t)(pi * 16) + fr < nbig) ? st[pj][r] : -INFINITY;   // this window's keys, for this window's queries
-                bm = fmaxf(bm, st[pj][r]);
+                bm = fmax_nc(bm, st[pj][r]);
               }
             }
-            const float mn = fmaxf(mrun[pi], fg_max(bm));
-            const float alpha = __expf(mrun[pi] - mn);
+            const float mn = fmax_nc(mrun[pi], fg_max(bm));
+            const float alpha = __builtin_amdgcn_exp2f(mrun[pi] - mn);
             float l = 0.f;
 #pragma unroll
             for (int pj = 0; pj < PT; pj++)
 #pragma unroll
               for (int r = 0; r < 4; r++) {
-                const float pexp = __expf(st[pj][r] - mn);
+                const float pexp = __builtin_amdgcn_exp2f(st[pj][r] - mn);
                 st[pj][r] = pexp;
                 l += pexp;
               }
@@ -1111,7 +1144,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
           float v[8];
 #pragma unroll
           for (int e = 0; e < 8; e++) v[e] = orun[pi][e >> 2][e & 3] * inv;
-          store_act(s_ah, s_al, hlsw(pi * 16 + fr, wave * 4 + fg), v);
+          store_act(std::integral_constant<int, TP>{}, s_ah, s_al, hlsw(pi * 16 + fr, wave * 4 + fg), v);
         }
       }
     }
@@ -1125,11 +1158,11 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
       for (int pt = 0; pt < PT; pt++)
 #pragma unroll
         for (int q = 0; q < 8; q++) XQ(pt, q) += bp[q];
-      tile_gemm_p<false, TERMS, PT>(wstream<TERMS == 3>(L.proj, cw, 0, lane), wa, wstream(L.ff1, cw, 0, lane), s_ah, s_al, fr, fg, xr);   // x += attention . Wproj
+      tile_gemm_p<false, TP, PT>(wstream<TP == 3>(L.proj, cw, 0, lane), wa, wstream(L.ff1, cw, 0, lane), s_ah, s_al, fr, fg, xr);   // x += attention . Wproj
     }
     RELAUNDER();
     LP_MARK(4);
-    layer_norm(PAR_LN2G, PAR_LN2B, nullptr, nullptr, TERMS == 3 ? 2 : (TERMS == 2 ? 1 : 0));
+    layer_norm(PAR_LN2G, PAR_LN2B, nullptr, nullptr, TF == 3 ? 2 : (TF == 2 ? 1 : 0));
     LP_MARK(5);
     {  // ---- feed-forward, 256 hidden channels at a time
       {  // FF2 accumulates into the residual stream itself (32 accumulator registers less through the FF loop), which takes the FF2 bias first: no
@@ -1141,41 +1174,86 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
 #pragma unroll
           for (int q = 0; q < 8; q++) XQ(pt, q) += b2[q];
       }
+      // Software pipeline over the chunks of 256 hidden channels (round 6): the call sequence is FF1(0), [FF1(c + 1), FF2(c)] ..., and the epilogue of chunk c
+      // (ReLU, hi / lo split, 2 LDS stores per row block: ~135 vector instructions per wave) is issued in four slices INSIDE FF1(c + 1), behind MFMA groups,
+      // instead of as a phase of its own in which all eight waves run vector code and the matrix pipe waits (r5 timers: 1.77 k of a chunk's 12.1 k cycles).
+      // Two accumulator sets (a1 of chunk c, a1n of chunk c + 1) are live inside that call.  Barriers as before: one in front of FF2(c) (the hidden planes
+      // are complete), one behind it (nobody reads them any more when the next epilogue writes them).
+      auto ff_bias = [&](uint32_t c, f32x4 (&a)[PT][2]) {   // the accumulators start from the bias (the moves that would zero them carry it)
+        float b1[8];
+        lds8(PAR_BFF1 + c + cw + 8 * fg, b1);
+#pragma unroll
+        for (int pt = 0; pt < PT; pt++)
+#pragma unroll
+          for (int jt = 0; jt < 2; jt++) a[pt][jt] = f32x4{b1[4 * jt], b1[4 * jt + 1], b1[4 * jt + 2], b1[4 * jt + 3]};
+      };
+      f32x4 a1[PT][2];
+      auto ff_epi = [&](int pt) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = __builtin_amdgcn_fmed3f(a1[pt][q >> 2][q & 3], 0.f, __builtin_huge_valf());   // ReLU in ONE instruction (fmaxf: a canonicalising v_max in front of the v_max)
+        store_act(std::integral_constant<int, TF>{}, s_ah, s_al, hlsw(pt * 16 + fr, wave * 4 + fg), v);
+      };
+      constexpr bool PIPE = TF != 3;   // precision 6 keeps the plain order FF1(c), epilogue, FF2(c): its e4m3 fragments leave no room for a second accumulator set (83 spilled registers)
+      if constexpr (PIPE) {
+        ff_bias(0, a1);
+        const WStream nx0 = 256 < d_ff ? wstream(L.ff1, 256 + cw, 0, lane) : wstream(L.ff2, cw, 0, lane);
+        tile_gemm_p<false, TF, PT>(wstream<TF == 3>(L.ff1, cw, 0, lane), wa, nx0, s_hh, s_hl, fr, fg, a1);
+        LP_MARK(9);
+      }
       for (uint32_t c = 0; c < d_ff; c += 256) {
         RELAUNDER();
-        f32x4 a1[PT][2];
-        {  // the accumulators start from the bias (the moves that would zero them carry it)
-          float b1[8];
-          lds8(PAR_BFF1 + c + cw + 8 * fg, b1);
+        const bool more = c + 256 < d_ff;
+        if constexpr (!PIPE) {
+          ff_bias(c, a1);
+          tile_gemm_p<false, TF, PT>(wstream<TF == 3>(L.ff1, c + cw, 0, lane), wa, wstream(L.ff2, cw, c, lane), s_hh, s_hl, fr, fg, a1);
+          LP_MARK(9);
 #pragma unroll
-          for (int pt = 0; pt < PT; pt++)
-#pragma unroll
-            for (int jt = 0; jt < 2; jt++) a1[pt][jt] = f32x4{b1[4 * jt], b1[4 * jt + 1], b1[4 * jt + 2], b1[4 * jt + 3]};
+          for (int pt = 0; pt < PT; pt++) ff_epi(pt);
+          LP_MARK(10);
+          __syncthreads();
+          LP_MARK(6);
+          const WStream nx = more ? wstream(L.ff1, c + 256 + cw, 0, lane) : wstream(Ln.qkv, cw, 0, lane);
+          tile_gemm_p<false, TF, PT>(wstream<TF == 3>(L.ff2, cw, c, lane), wa, nx, s_ah, s_al, fr, fg, xr);
+          LP_MARK(11);
+          __syncthreads();
+          LP_MARK(7);
+          continue;
         }
-        tile_gemm_p<false, TERMS, PT>(wstream<TERMS == 3>(L.ff1, c + cw, 0, lane), wa, wstream(L.ff2, cw, c, lane), s_hh, s_hl, fr, fg, a1);
-        LP_MARK(9);
+        f32x4 a1n[PT][2];
+        if (more) {
+          ff_bias(c + 256, a1n);
+          tile_gemm_p<false, TF, PT>(wstream<TF == 3>(L.ff1, c + 256 + cw, 0, lane), wa, wstream(L.ff2, cw, c, lane), s_hh, s_hl, fr, fg, a1n,
+                                        [&](int k) { if (k < PT) ff_epi(k); });
+          LP_MARK(9);
+        } else {
 #pragma unroll
-        for (int pt = 0; pt < PT; pt++) {
-          float v[8];
-#pragma unroll
-          for (int q = 0; q < 8; q++) v[q] = __builtin_amdgcn_fmed3f(a1[pt][q >> 2][q & 3], 0.f, __builtin_huge_valf());   // ReLU in ONE instruction (fmaxf: a canonicalising v_max in front of the v_max)
-          store_act(s_ah, s_al, hlsw(pt * 16 + fr, wave * 4 + fg), v);
+          for (int pt = 0; pt < PT; pt++) ff_epi(pt);
+          LP_MARK(10);
         }
-        LP_MARK(10);
         __syncthreads();
         LP_MARK(6);
-        const bool more = c + 256 < d_ff;
-        const WStream nx = more ? wstream(L.ff1, c + 256 + cw, 0, lane) : wstream(Ln.qkv, cw, 0, lane);
-        tile_gemm_p<false, TERMS, PT>(wstream<TERMS == 3>(L.ff2, cw, c, lane), wa, nx, s_ah, s_al, fr, fg, xr);
+        RELAUNDER();
+        const WStream nx = more ? (c + 512 < d_ff ? wstream(L.ff1, c + 512 + cw, 0, lane) : wstream(L.ff2, cw, c + 256, lane)) : wstream(Ln.qkv, cw, 0, lane);
+        tile_gemm_p<false, TF, PT>(wstream<TF == 3>(L.ff2, cw, c, lane), wa, nx, s_ah, s_al, fr, fg, xr);
         LP_MARK(11);
         __syncthreads();
         LP_MARK(7);
+        if (more) {
+#pragma unroll
+          for (int pt = 0; pt < PT; pt++)
+#pragma unroll
+            for (int jt = 0; jt < 2; jt++) a1[pt][jt] = a1n[pt][jt];
+        }
       }
     }
     // every wave is past its last read of this layer's parameters (the barrier that closed the FF loop)
     if (li + 1 < n_layers) stage_params(Ln);   // visible after the first barrier of the next LayerNorm
   }
   RELAUNDER();
+  // where the logits of this lane's token go, and the heads' bias: requested in front of the last LayerNorm, used behind the heads
+  const uint64_t out_o = (wave < PT && wave * 16 + fr < nt) ? S.tok_out[t0 + wave * 16 + fr] : 0ull;
+  const float4 hb = *reinterpret_cast<const float4*>(M.heads.bias + 4 * fg);
   layer_norm(0, 0, M.lnf_g, M.lnf_b, 1);
 #undef RELAUNDER
 #undef XQ
@@ -1196,12 +1274,12 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
     }
     const uint32_t tok = pt * 16 + fr;
     if (tok < nt) {
-      const uint32_t n = t0 + tok, b = S.tok_win[n];
-      const uint64_t o = B.out_off[b] + (n - B.tok_off[b]);
+      const uint64_t o = out_o;
+      const float hbv[4] = {hb.x, hb.y, hb.z, hb.w};
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const uint32_t ch = 4 * fg + r;
-        const float v = a[r] + W.bias[ch];
+        const float v = a[r] + hbv[r];
         if (ch == 0) B.out_info[o] = v;
         else if (ch < 6) B.out_base[o * 5 + (ch - 1)] = v;
       }
@@ -1235,6 +1313,7 @@ __global__ void k_build_tokens_h(BatchDev B, ModelScratch S) {
     const uint32_t row = B.sup_row[B.sup_off[b] + (n - t0)];
     S.tok_win[n] = b;
     S.tok_row[n] = row;
+    S.tok_out[n] = B.out_off[b] + (n - t0);
     TokMeta tm;
     tm.plane_off = B.plane_off[b];
     tm.plane_ld = B.plane_ld[b];
@@ -1266,7 +1345,23 @@ __global__ void k_build_tokens_h(BatchDev B, ModelScratch S) {
   }
 }
 
+// the positional-encoding table of the stack's prologue: the same two instructions per angle the kernel's own branch runs (a product rounded once, one sincosf)
+__global__ void k_pe_table(const float* __restrict__ pe_div, float* __restrict__ tab, uint32_t rows, uint32_t half_d) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * half_d) return;
+  const uint32_t row = i / half_d, j = i % half_d;
+  const float ang = __fmul_rn((float)row, pe_div[j]);
+  float sn, cs;
+  sincosf(ang, &sn, &cs);
+  *reinterpret_cast<float2*>(tab + (uint64_t)row * (2 * half_d) + 2 * j) = make_float2(sn, cs);
+}
+
 }  // namespace
+
+void launch_pe_table(const float* pe_div, float* tab, uint32_t rows, uint32_t d_model, hipStream_t st) {
+  const uint32_t n = rows * (d_model / 2);
+  hipLaunchKernelGGL(k_pe_table, dim3((n + 255) / 256), dim3(256), 0, st, pe_div, tab, rows, d_model / 2);
+}
 
 bool model_h_supported(const ModelDev& M) {
   const ModelHyper& h = M.h;
@@ -1289,7 +1384,7 @@ int model_h_half_tiles(const ModelDev& M) {
 }
 
 // B must be tileable (windows of <= 64 informative rows in B.tile_tok0 / _q, windows of 65 .. 64 * 8 rows on sibling tiles, B.tile_tok0_b) —
-// herro_job_infer sends still larger windows through the layer-by-layer kernels of model.hip.  terms: 2 (precision 4) or 1 (precision 5).
+// herro_job_infer sends still larger windows through the layer-by-layer kernels of model.hip.  terms: 2 (precision 4), 1 (precision 5), 3 (6), 21 (7: FF single), 12 (8: proj single).
 void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S, int terms, hipStream_t st, KernelTimer* tm) {
   const uint32_t N = B.n_tok;
   if (N == 0 || B.n_tiles + B.n_tiles_q + B.n_tiles_b == 0) return;
@@ -1341,12 +1436,20 @@ void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S,
     opt_in_lds(reinterpret_cast<const void*>(kern), layers_p_shm(tokens));
     hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(512), layers_p_shm(tokens), st, M, B, S);
   };
-  auto launch3 = [&](auto k1, auto k2, auto k3, uint32_t n_tiles, int tokens) { if (terms == 3) launch(k3, n_tiles, tokens); else if (terms == 2) launch(k2, n_tiles, tokens); else launch(k1, n_tiles, tokens); };
+  auto launch5 = [&](auto k1, auto k2, auto k3, auto k21, auto k12, uint32_t n_tiles, int tokens) {
+    switch (terms) {
+      case 3: launch(k3, n_tiles, tokens); break;
+      case 2: launch(k2, n_tiles, tokens); break;
+      case 21: launch(k21, n_tiles, tokens); break;
+      case 12: launch(k12, n_tiles, tokens); break;
+      default: launch(k1, n_tiles, tokens);
+    }
+  };
   if (B.n_tiles_b) {   // sibling tiles of the windows above 64 informative rows at the head of ONE grid with the ordinary 64-token tiles
     (void)hipMemsetAsync(S.sib_flag, 0, (size_t)B.n_tiles_b * 4, st);
-    launch3(k_layers_p<1, 4, true>, k_layers_p<2, 4, true>, k_layers_p<3, 4, true>, B.n_tiles_b + B.n_tiles, 64);
-  } else if (B.n_tiles) launch3(k_layers_p<1, 4>, k_layers_p<2, 4>, k_layers_p<3, 4>, B.n_tiles, 64);
-  if (B.n_tiles_q) launch3(k_layers_p<1, 2>, k_layers_p<2, 2>, k_layers_p<3, 2>, B.n_tiles_q, 32);
+    launch5(k_layers_p<1, 4, true>, k_layers_p<2, 4, true>, k_layers_p<3, 4, true>, k_layers_p<21, 4, true>, k_layers_p<12, 4, true>, B.n_tiles_b + B.n_tiles, 64);
+  } else if (B.n_tiles) launch5(k_layers_p<1, 4>, k_layers_p<2, 4>, k_layers_p<3, 4>, k_layers_p<21, 4>, k_layers_p<12, 4>, B.n_tiles, 64);
+  if (B.n_tiles_q) launch5(k_layers_p<1, 2>, k_layers_p<2, 2>, k_layers_p<3, 2>, k_layers_p<21, 2>, k_layers_p<12, 2>, B.n_tiles_q, 32);
   KT_END(tm, st);
 }
 

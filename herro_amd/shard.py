@@ -691,6 +691,8 @@ def strong_leg(args, rank: int, world: int, local: int, n_windows: int, n_ctx: i
     for _ in range(max(1, n_ctx)):
         c = api.Context(local)
         c.load_model(path)
+        if args.precision is None:
+            args.precision = c.precision()       # the tier the load-time calibration chose for this model
         c.set_precision(args.precision)
         if ctxs:
             c.share_reads(ctxs[0])               # one read store per device
@@ -806,7 +808,7 @@ def bench_strong(args, rank: int, world: int, local: int):
         print(json.dumps({
             "metric": "4096-bp windows corrected/sec at batch=128", "value": r["windows_per_s"], "unit": "windows/s", "n_gpus": world,
             "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * r["seconds"] / max(steps, 1), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": {1: "bf16x3", 4: "f16 (encoder proj / FF GEMMs: activation hi+lo)", 5: "f16"}.get(args.precision, str(args.precision)),
+            "vs_baseline": None, "dtype": {1: "bf16x3", 4: "f16 (encoder proj / FF GEMMs: activation hi+lo)", 5: "f16", 7: "f16 (proj hi+lo, FF single)", 8: "f16 (FF hi+lo, proj single)"}.get(args.precision, str(args.precision)),
             "data": "synthetic (SURVEY §8d generator, seed 0x48455252+3; random-init weights of the assumed architecture)",
             "config": {"workload": f"ONE fixed job of {r['windows']} synthetic 4096-bp windows (32 overlaps each, batch=128) sharded by target read over "
                                    f"{world} rank(s), ingest = {r.get('ingest', 'local')}; rank 0 gathers the corrected reads (BASELINE configs[3])",

@@ -106,17 +106,23 @@ int herro_load_model(herro_ctx* ctx, const char* path);
  *   4  f16: conv2 / FC / attention / QKV on single f16 operands, proj / FF1 / FF2 of every encoder layer on activation
  *      hi + lo (2 MFMAs), heads on three terms — 5.9e-4 max on 36 k rows; the DEFAULT when the model has the tuned shapes.
  *      Windows of 65 .. 512 informative rows stay on the fused stack (sibling tiles of 64 rows that exchange their K / V).
- *   5  f16, single terms everywhere but the heads (7.3e-4: measured, not a default)
+ *   5  f16, single terms everywhere but the heads (8.3e-4 end to end on random-init weights)
  *   6  as 4, with the activation remainder of proj / FF1 / FF2 as OCP e4m3 against an e4m3 copy of the weight on the K = 128 scaled MFMA
- *      (v_mfma_scale_f32_16x16x128_f8f6f4; 6.1e-4 end to end; calibrated at load beside mode 4 and refused above 5e-4; 26 % less matrix-pipe time in
- *      those GEMMs and no faster on an MI355X — DESIGN.md §5 — so not a default)
+ *      (v_mfma_scale_f32_16x16x128_f8f6f4; 6.1e-4 end to end; 26 % less matrix-pipe time in those GEMMs and no faster on an MI355X — DESIGN.md §5 —
+ *      so never chosen by the library; calibrated on demand)
+ *   7  as 4 with FF1 / FF2 on single terms (proj keeps its two): 13 MFMA call-terms per encoder layer instead of 21
+ *   8  as 4 with proj on a single term (FF1 / FF2 keep two): 20 call-terms
  * herro_load_model picks the mode itself unless this was called before: 1 when the model's shapes have no f16 kernels or
- * a weight lies outside the f16 range; otherwise it runs a calibration batch of 256 pileup-shaped rows in mode 4 and in
- * mode 0 (f32 MFMA) and keeps 4 only if the logits are finite and differ by at most 5e-4 (half the 1e-3 contract) — the
- * margin of the f16 formats was measured on random-init weights, a trained model decides for itself.  A later
- * herro_set_precision(4 / 5) on a model that failed this calibration is refused (HERRO_E_UNSUPPORTED; HERRO_FORCE_PRECISION=1
- * overrides).  herro_model_describe reports the outcome. */
+ * a weight lies outside the f16 range; otherwise it runs a calibration batch of 256 pileup-shaped rows in mode 0 (f32 MFMA) and in
+ * the f16 tiers 5, 7, 8, 4 — cheapest first — and keeps the FIRST whose logits are finite and within 5e-4 (half the 1e-3 contract)
+ * of mode 0; none: mode 1.  The margin of the f16 formats was measured on random-init weights; a trained model decides for itself.
+ * herro_set_precision(4 .. 8) is held to the same bound — the mode is calibrated here if the load did not measure it — and refused
+ * above it (HERRO_E_UNSUPPORTED; HERRO_FORCE_PRECISION=1 in A/B builds overrides); a mode set BEFORE herro_load_model is calibrated by
+ * the load and replaced by mode 1 when it fails.  herro_model_describe reports the outcome, herro_precision the mode in force,
+ * herro_calibration_error what a mode measured (-1: not measured). */
 int herro_set_precision(herro_ctx* ctx, int mode);
+int herro_precision(const herro_ctx* ctx);
+float herro_calibration_error(const herro_ctx* ctx, int mode);
 
 /* Text description of the loaded model: hyper-parameters, receptive field of an informative row (rows the conv stack
  * evaluates per token), GEMM FLOP per token and per 4096-bp window at 15 informative rows, the precision mode in force and
@@ -263,6 +269,7 @@ int64_t herro_debug_job_rf(herro_job* job, uint32_t w, uint8_t* out, uint64_t ca
 int herro_debug_job_rf_fused(const herro_job* job);   /* 1: the last herro_job_infer read records k_rows gathered itself; 0: k_rfq's */
 uint32_t herro_debug_e4m3(float x);                   /* host f32 -> OCP e4m3 (round to nearest even, saturating) as used for the precision-6 weight copies */
 int herro_debug_sib_fault(herro_ctx* ctx);            /* raises the context's sibling-tile error word as a tile that timed out would: the next fetch repeats its job's model pass without sibling tiles */
+int herro_debug_force_precision(herro_ctx* ctx, int on); /* tests: herro_set_precision / herro_load_model skip the calibration gate (to MEASURE a mode the model's calibration refuses) */
 int herro_debug_sib_retries(const herro_ctx* ctx);    /* model passes repeated that way on this context */
 
 /* Host-only test hook for the token-tile plan of the fused transformer stack (herro_job_infer): n windows of cnt[i]

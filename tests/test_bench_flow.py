@@ -54,6 +54,8 @@ class FakeCtx:
 
     def load_model(self, p): pass
     def set_precision(self, m): pass
+    def precision(self): return 4
+    def calibration_error(self, m): return 4.0e-4 if m == 4 else 6.0e-4
     def set_reads(self, *a): pass
     def share_reads(self, other): assert isinstance(other, FakeCtx)
     def synchronize(self): pass

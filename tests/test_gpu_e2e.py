@@ -107,6 +107,7 @@ def test_baseline_workload_end_to_end():
     # ---- logits vs the fp32 twin on the GPU, same grouping; every precision
     twin = MR.build(G.raw_params(), model_io.Hyper()).to(torch.device("cuda", 0))
     errs = {}
+    selectable = {}
     for bs, sel in ((128, wins), (64, wins[:640])):
         ref = _twin_logits(twin, sel, enc, quals, sup_rows, bs)
         if bs == 128:
@@ -115,8 +116,8 @@ def test_baseline_workload_end_to_end():
             e_base = max(float(np.abs(first[wv][1] - ref[wv][1]).max()) for wv in sel)
             errs[f"bs128_default_p{api.DEFAULT_PRECISION}_rf_quals"] = {"info": e_info, "base": e_base, "windows": len(sel),
                                                                         "tokens": int(nsup[sel].sum())}
-        for prec in (1, 4, 5, 6):
-            c.set_precision(prec)
+        for prec in (1, 4, 5, 6, 7, 8):
+            selectable[prec] = G.select_precision(c, prec)
             job.infer(bs, 1)
             e_info = e_base = 0.0
             for wv in sel:
@@ -127,7 +128,8 @@ def test_baseline_workload_end_to_end():
                     # this pass reads the COMPLETE quality planes (materialised by the window copies above, bit-exact against the oracle);
                     # the first pass read k_rfq's compact receptive fields: same bytes -> the same logits to the bit, every window
                     assert np.array_equal(gi, first[wv][0]) and np.array_equal(gb, first[wv][1]), f"receptive-field qualities differ from the planes, window {wv}"
-            errs[f"bs{bs}_p{prec}"] = {"info": e_info, "base": e_base, "windows": len(sel), "tokens": int(nsup[sel].sum())}
+            errs[f"bs{bs}_p{prec}"] = {"info": e_info, "base": e_base, "windows": len(sel), "tokens": int(nsup[sel].sum()), "selectable": selectable[prec],
+                                       "calibration_error": c.calibration_error(prec) if prec >= 4 else None}
     try:
         os.makedirs(os.path.join(G.ROOT, "gpurun_out"), exist_ok=True)
         json.dump(errs, open(os.path.join(G.ROOT, "gpurun_out", "e2e_errors.json"), "w"), indent=1)
@@ -135,7 +137,7 @@ def test_baseline_workload_end_to_end():
         pass
     print(json.dumps(errs))
     for k, v in errs.items():
-        lim = 4e-3 if k.endswith("p5") else (1e-4 if "p1" in k else TOL)   # p5 (single f16 terms) is measured, not shipped
+        lim = 1e-4 if k.endswith("p1") else (TOL if v.get("selectable", True) else G.LOOSE)   # whatever a caller can select is held to the contract; a mode the calibration refuses is measured only
         assert max(v["info"], v["base"]) <= lim, (k, v)
 
     # ---- consensus on the device in the default precision: FASTA == oracle decode of the same logits
