@@ -100,10 +100,14 @@ def lib():
         L.herro_debug_zero_copy_jobs.argtypes = []
         L.herro_load_model.argtypes = [vp, C.c_char_p]
         L.herro_set_precision.argtypes = [vp, i32]
-        L.herro_precision.argtypes = [vp]
-        L.herro_calibration_error.restype = C.c_float
-        L.herro_calibration_error.argtypes = [vp, i32]
-        L.herro_debug_force_precision.argtypes = [vp, i32]
+        try:   # (an older build of the library selected by HERRO_LIB for a same-box A/B lacks the round-6 entries)
+            L.herro_precision.argtypes = [vp]
+            L.herro_calibration_error.restype = C.c_float
+            L.herro_calibration_error.argtypes = [vp, i32]
+            L.herro_debug_force_precision.argtypes = [vp, i32]
+        except AttributeError:
+            if not os.environ.get("HERRO_LIB"):
+                raise
         L.herro_job_create.restype = vp
         L.herro_job_create.argtypes = [vp, u32, vp, vp, vp, u32]
         L.herro_job_free.argtypes = [vp]

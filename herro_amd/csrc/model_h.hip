@@ -415,8 +415,12 @@ constexpr size_t FC_R_SHM = (size_t)2 * FR_ROWS * 64 * 2;   // two buffers [128 
 // G: groups of two 16-row blocks per tile, i.e. tiles of 32 * G rows (4: 128 rows; 3: 96 — chosen per launch so that the busiest compute unit
 // holds the fewest rows: 38.7 k rows in 128-row tiles are 303 workgroups, two on 47 of the 256 compute units and one on the others; in 96-row
 // tiles 403, and the two-workgroup units carry 192 rows instead of 256).
+// pe_tab (round 6): the positional encoding of a token's row is added HERE, from the table of herro_load_model (ModelDev::pe_tab), for rows inside the table — the stack's
+// prologue, where every compute unit fetches its tile at the same moment, reads 64 KB per tile instead of 128 (and ran 16 sincosf per lane before the table existed);
+// k_layers_p adds the encoding of the rows BEYOND the table itself (the same rule on both sides: row < pe_rows)
 template <int G>
-__global__ __launch_bounds__(512, 4) void k_fc_r(const uint16_t* __restrict__ A, uint32_t lda, Weight W, float* C, uint32_t ldc, uint32_t M) {
+__global__ __launch_bounds__(512, 4) void k_fc_r(const uint16_t* __restrict__ A, uint32_t lda, Weight W, float* C, uint32_t ldc, uint32_t M,
+                                                 const uint32_t* __restrict__ tok_row, const float* __restrict__ pe_tab, uint32_t pe_rows) {
   constexpr int FR_TM = 32 * G;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem_fc[];
   uint16_t* s_a = reinterpret_cast<uint16_t*>(smem_fc);   // [2][128][64]: row r at r * 128 B, 16-byte chunk c at (c ^ (r & 7))
@@ -520,13 +524,23 @@ __global__ __launch_bounds__(512, 4) void k_fc_r(const uint16_t* __restrict__ A,
 #pragma unroll
     for (int q = 0; q < 8; q++) bs[q] = W.bias ? bp[q] : 0.f;
   }
+  uint32_t prow[2 * G];
+#pragma unroll
+  for (int pt = 0; pt < 2 * G; pt++) prow[pt] = pe_tab ? tok_row[min(m0 + pt * 16 + fr, M - 1)] : 0xffffffffu;
 #pragma unroll
   for (int pt = 0; pt < 2 * G; pt++) {
     const uint32_t m = m0 + pt * 16 + fr;
     if (m < M) {
+      float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
+      if (prow[pt] < pe_rows) {
+        const float* pp = pe_tab + (uint64_t)prow[pt] * ldc + wave * 32 + 8 * fg;
+        p0 = *reinterpret_cast<const float4*>(pp);
+        p1 = *reinterpret_cast<const float4*>(pp + 4);
+      }
       float* cp = C + (uint64_t)m * ldc + wave * 32 + 8 * fg;
-      *reinterpret_cast<float4*>(cp) = make_float4(acc[pt][0][0] + bs[0], acc[pt][0][1] + bs[1], acc[pt][0][2] + bs[2], acc[pt][0][3] + bs[3]);
-      *reinterpret_cast<float4*>(cp + 4) = make_float4(acc[pt][1][0] + bs[4], acc[pt][1][1] + bs[5], acc[pt][1][2] + bs[6], acc[pt][1][3] + bs[7]);
+      // (bias first, then the encoding: the sum the stack's prologue used to form)
+      *reinterpret_cast<float4*>(cp) = make_float4((acc[pt][0][0] + bs[0]) + p0.x, (acc[pt][0][1] + bs[1]) + p0.y, (acc[pt][0][2] + bs[2]) + p0.z, (acc[pt][0][3] + bs[3]) + p0.w);
+      *reinterpret_cast<float4*>(cp + 4) = make_float4((acc[pt][1][0] + bs[4]) + p1.x, (acc[pt][1][1] + bs[5]) + p1.y, (acc[pt][1][2] + bs[6]) + p1.z, (acc[pt][1][3] + bs[7]) + p1.w);
     }
   }
 }
@@ -593,12 +607,9 @@ __device__ __forceinline__ void wload4(const WStream& s, uint32_t k0, half8 (&w)
 #define HERRO_LP_DBG 0   // timing experiments (wrong results): 1 every second activation fragment read from LDS is skipped, 2 every second k-step's MFMAs, 4 the weight loads inside a call,
                          // 8 (precision 6) no K = 128 instructions, 16 (precision 6) no e4m3 conversion of the remainders (the byte planes stay as they are)
 #endif
-struct NoMid { __device__ __forceinline__ void operator()(int) const {} };
-// mid(k): a slice of somebody else's vector work (the epilogue of the PREVIOUS feed-forward chunk), issued behind the first MFMA group of k-step k — the
-// matrix pipe is busy with that group (and with the SIMD partner's) while the slice issues, where an epilogue phase of its own leaves it idle
-template <bool SWAP, int TERMS, int PT, class Mid = NoMid>
+template <bool SWAP, int TERMS, int PT>
 __device__ __forceinline__ void tile_gemm_p(const WStream& cur, half8 (&wa)[4][2], const WStream& nxt, const uint16_t* sh,
-                                            const uint16_t* sl, uint32_t fr, uint32_t fg, f32x4 (&acc)[PT][2], Mid mid = Mid()) {
+                                            const uint16_t* sl, uint32_t fr, uint32_t fg, f32x4 (&acc)[PT][2]) {
   half8 wb[4][2];
   if (HERRO_LP_DBG & 4) {
 #pragma unroll
@@ -654,8 +665,6 @@ __device__ __forceinline__ void tile_gemm_p(const WStream& cur, half8 (&wa)[4][2
       __builtin_amdgcn_sched_barrier(0);
       if (k < 4) mm8(xh, wa[k]); else mm8(xh, wb[k - 4]);
       __builtin_amdgcn_sched_barrier(0);
-      mid(k);
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int pt = 0; pt < PT; pt++) { xh[pt] = xn[pt]; xn[pt] = xm[pt]; }
       continue;
@@ -665,8 +674,6 @@ __device__ __forceinline__ void tile_gemm_p(const WStream& cur, half8 (&wa)[4][2
     if (!(dbg_mm && (k & 1))) { if (k < 4) mm8(xh, wa[k]); else mm8(xh, wb[k - 4]); }
     __builtin_amdgcn_sched_barrier(0);
     if (k < 7 && !(dbg_rd && !(k & 1))) rd(sh, k + 1, xn);
-    __builtin_amdgcn_sched_barrier(0);
-    mid(k);
     __builtin_amdgcn_sched_barrier(0);
     if (TERMS == 2 && !(dbg_mm && (k & 1))) {
       if (k < 4) mm8(xl, wa[k]); else mm8(xl, wb[k - 4]);
@@ -809,8 +816,8 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
         float sm = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; w++) sm += red[w * HLT + pt * 16 + fr];
-        if (pass == 0) mean[pt] = sm / 256.f;
-        else rstd[pt] = 1.0f / sqrtf(sm / 256.f + eps);
+        if (pass == 0) mean[pt] = sm * (1.0f / 256.f);
+        else rstd[pt] = __builtin_amdgcn_rsqf(sm * (1.0f / 256.f) + eps);   // v_rsq_f32 (1 ulp) instead of a correctly rounded square root and division: ~25 instructions per row block less, 100 per LayerNorm
       }
     }
     float gg[8], bb[8];
@@ -883,7 +890,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
 #pragma unroll
     for (int pt = 0; pt < PT; pt++) {
       const uint32_t tok = pt * 16 + fr;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, pa = a, pb = a;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
       float row = 0.f;
       uint32_t rowu = 0;
       if (tok < nt) {
@@ -892,19 +899,11 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
         b = *reinterpret_cast<const float4*>(xp + 4);
         rowu = S.tok_row[t0 + tok];
         row = (float)rowu;
-        if (rowu < M.pe_rows) {
-          const float* pp = M.pe_tab + (uint64_t)rowu * 256 + cw + 8 * fg;
-          pa = *reinterpret_cast<const float4*>(pp);
-          pb = *reinterpret_cast<const float4*>(pp + 4);
-        }
       }
       xr[pt][0] = f32x4{a.x, a.y, a.z, a.w};
       xr[pt][1] = f32x4{b.x, b.y, b.z, b.w};
       if (tok < nt) {
-        if (rowu < M.pe_rows) {   // the table holds exactly what the branch below computes (launch_pe_table)
-          xr[pt][0] += f32x4{pa.x, pa.y, pa.z, pa.w};
-          xr[pt][1] += f32x4{pb.x, pb.y, pb.z, pb.w};
-        } else {
+        if (rowu >= M.pe_rows) {   // rows inside the table got their encoding in k_fc_r's epilogue (the table holds exactly what this branch computes: launch_pe_table)
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             const float ang = __fmul_rn(row, pd[j]);
@@ -930,29 +929,31 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
     RELAUNDER();
     {  // ---- attention, head = wave
       half8 qh[PT], kh[PT], vh[2][PT / 2];
-      {  // the epilogue of Q (bias, scale, f16 fragment) is issued in slices inside K's call, K's inside V's (round 6; as the feed-forward epilogue below)
-        f32x4 aq[PT][2], ak[PT][2], av[PT][2];
-        float bq[8], bk[8];
-        zero(aq);
-        tile_gemm_p<false, 1, PT>(wstream(L.qkv, cw, 0, lane), wa, wstream(L.qkv, 256 + cw, 0, lane), s_hh, s_hl, fr, fg, aq);
+      {
+        f32x4 a[PT][2];
+        float bq[8];
+        zero(a);
+        tile_gemm_p<false, 1, PT>(wstream(L.qkv, cw, 0, lane), wa, wstream(L.qkv, 256 + cw, 0, lane), s_hh, s_hl, fr, fg, a);
         lds8(PAR_BQKV + cw + 8 * fg, bq);
-        zero(ak);
-        tile_gemm_p<false, 1, PT>(wstream(L.qkv, 256 + cw, 0, lane), wa, wstream(L.qkv, 512 + cw, 0, lane), s_hh, s_hl, fr, fg, ak, [&](int k) {
-          if (k >= PT) return;
+#pragma unroll
+        for (int pt = 0; pt < PT; pt++) {
           float v[8];
 #pragma unroll
-          for (int q = 0; q < 8; q++) v[q] = (aq[k][q >> 2][q & 3] + bq[q]) * scale;
-          qh[k] = pack_h8(v);
-        });
-        lds8(PAR_BQKV + 256 + cw + 8 * fg, bk);
-        zero(av);
-        tile_gemm_p<true, 1, PT>(wstream(L.qkv, 512 + cw, 0, lane), wa, wstream(L.proj, cw, 0, lane), s_hh, s_hl, fr, fg, av, [&](int k) {   // (a call only reads the f16 head of its successor)
-          if (k >= PT) return;
+          for (int q = 0; q < 8; q++) v[q] = (a[pt][q >> 2][q & 3] + bq[q]) * scale;
+          qh[pt] = pack_h8(v);
+        }
+        zero(a);
+        tile_gemm_p<false, 1, PT>(wstream(L.qkv, 256 + cw, 0, lane), wa, wstream(L.qkv, 512 + cw, 0, lane), s_hh, s_hl, fr, fg, a);
+        lds8(PAR_BQKV + 256 + cw + 8 * fg, bq);
+#pragma unroll
+        for (int pt = 0; pt < PT; pt++) {
           float v[8];
 #pragma unroll
-          for (int q = 0; q < 8; q++) v[q] = ak[k][q >> 2][q & 3] + bk[q];
-          kh[k] = pack_h8(v);
-        });
+          for (int q = 0; q < 8; q++) v[q] = a[pt][q >> 2][q & 3] + bq[q];
+          kh[pt] = pack_h8(v);
+        }
+        zero(a);
+        tile_gemm_p<true, 1, PT>(wstream(L.qkv, 512 + cw, 0, lane), wa, wstream(L.proj, cw, 0, lane), s_hh, s_hl, fr, fg, a);   // (a call only reads the f16 head of its successor)
 #pragma unroll
         for (int ct = 0; ct < 2; ct++) {
           const float bv = s_par[PAR_BQKV + 512 + cw + 8 * (fr >> 2) + 4 * ct + (fr & 3)];
@@ -960,7 +961,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
           for (int kk = 0; kk < PT / 2; kk++) {
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = av[2 * kk + (e >> 2)][ct][e & 3] + bv;
+            for (int e = 0; e < 8; e++) v[e] = a[2 * kk + (e >> 2)][ct][e & 3] + bv;
             vh[ct][kk] = pack_h8(v);
           }
         }
@@ -989,13 +990,14 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
         m = fg_max(m);
         float l = 0.f;
 #pragma unroll
-        for (int pj = 0; pj < PT; pj++)
+        for (int pj = 0; pj < PT; pj++) {
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const float pexp = __builtin_amdgcn_exp2f(st[pj][r] - m);
             st[pj][r] = pexp;
             l += pexp;
           }
+        }
         l = fg_sum(l);
         f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -1007,7 +1009,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
 #pragma unroll
           for (int ct = 0; ct < 2; ct++) o[ct] = mma(vh[ct][kk], ph, o[ct]);
         }
-        const float inv = 1.0f / l;
+        const float inv = __builtin_amdgcn_rcpf(l);
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] = o[e >> 2][e & 3] * inv;
@@ -1140,7 +1142,7 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
         }
 #pragma unroll
         for (int pi = 0; pi < PT; pi++) {
-          const float inv = 1.0f / lrun[pi];
+          const float inv = __builtin_amdgcn_rcpf(lrun[pi]);
           float v[8];
 #pragma unroll
           for (int e = 0; e < 8; e++) v[e] = orun[pi][e >> 2][e & 3] * inv;
@@ -1174,77 +1176,45 @@ __global__ __launch_bounds__(512) void k_layers_p(ModelDev M, BatchDev B, ModelS
 #pragma unroll
           for (int q = 0; q < 8; q++) XQ(pt, q) += b2[q];
       }
-      // Software pipeline over the chunks of 256 hidden channels (round 6): the call sequence is FF1(0), [FF1(c + 1), FF2(c)] ..., and the epilogue of chunk c
-      // (ReLU, hi / lo split, 2 LDS stores per row block: ~135 vector instructions per wave) is issued in four slices INSIDE FF1(c + 1), behind MFMA groups,
-      // instead of as a phase of its own in which all eight waves run vector code and the matrix pipe waits (r5 timers: 1.77 k of a chunk's 12.1 k cycles).
-      // Two accumulator sets (a1 of chunk c, a1n of chunk c + 1) are live inside that call.  Barriers as before: one in front of FF2(c) (the hidden planes
-      // are complete), one behind it (nobody reads them any more when the next epilogue writes them).
-      auto ff_bias = [&](uint32_t c, f32x4 (&a)[PT][2]) {   // the accumulators start from the bias (the moves that would zero them carry it)
-        float b1[8];
-        lds8(PAR_BFF1 + c + cw + 8 * fg, b1);
-#pragma unroll
-        for (int pt = 0; pt < PT; pt++)
-#pragma unroll
-          for (int jt = 0; jt < 2; jt++) a[pt][jt] = f32x4{b1[4 * jt], b1[4 * jt + 1], b1[4 * jt + 2], b1[4 * jt + 3]};
-      };
-      f32x4 a1[PT][2];
-      auto ff_epi = [&](int pt) {
-        float v[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = __builtin_amdgcn_fmed3f(a1[pt][q >> 2][q & 3], 0.f, __builtin_huge_valf());   // ReLU in ONE instruction (fmaxf: a canonicalising v_max in front of the v_max)
-        store_act(std::integral_constant<int, TF>{}, s_ah, s_al, hlsw(pt * 16 + fr, wave * 4 + fg), v);
-      };
-      constexpr bool PIPE = TF != 3;   // precision 6 keeps the plain order FF1(c), epilogue, FF2(c): its e4m3 fragments leave no room for a second accumulator set (83 spilled registers)
-      if constexpr (PIPE) {
-        ff_bias(0, a1);
-        const WStream nx0 = 256 < d_ff ? wstream(L.ff1, 256 + cw, 0, lane) : wstream(L.ff2, cw, 0, lane);
-        tile_gemm_p<false, TF, PT>(wstream<TF == 3>(L.ff1, cw, 0, lane), wa, nx0, s_hh, s_hl, fr, fg, a1);
-        LP_MARK(9);
-      }
+      // Round 6, measured on one box against the round-5 library (profiles/r6_ab_layers.txt): (i) the epilogue of chunk c issued in slices INSIDE FF1(c + 1)
+      // (call order FF1(0), [FF1(c + 1), FF2(c)] ..., two accumulator sets) — the matrix pipe was meant to stay busy while a wave splits and stores; every
+      // wave at k-steps 0..3 or the two waves of a SIMD in different halves of the call: +5 % / +6 % kernel time, every phase of the layer slower, not only
+      // the feed-forward; (ii) the epilogues of Q / K inside the calls of K / V: no change; (iii) key blocks that share no window with a query block skipped
+      // in the attention: the phase 8 % shorter, the kernel the same.  None of them is kept (git show 2a15d40 has (i) and (ii)).  What is kept: with ONE term in
+      // FF1 / FF2 (precisions 5, 7) nobody uses the lo planes during the loop, so the hidden chunk alternates between s_ah and s_al and the barrier BEHIND
+      // FF2(c) goes: a wave that is through its FF2 starts FF1(c + 1) while its SIMD partner still streams — the skew a barrier removes is what overlaps one
+      // wave's epilogue with the other's MFMAs.
+      constexpr bool TWO_BUF = TF == 1;
       for (uint32_t c = 0; c < d_ff; c += 256) {
         RELAUNDER();
-        const bool more = c + 256 < d_ff;
-        if constexpr (!PIPE) {
-          ff_bias(c, a1);
-          tile_gemm_p<false, TF, PT>(wstream<TF == 3>(L.ff1, c + cw, 0, lane), wa, wstream(L.ff2, cw, c, lane), s_hh, s_hl, fr, fg, a1);
-          LP_MARK(9);
-#pragma unroll
-          for (int pt = 0; pt < PT; pt++) ff_epi(pt);
-          LP_MARK(10);
-          __syncthreads();
-          LP_MARK(6);
-          const WStream nx = more ? wstream(L.ff1, c + 256 + cw, 0, lane) : wstream(Ln.qkv, cw, 0, lane);
-          tile_gemm_p<false, TF, PT>(wstream<TF == 3>(L.ff2, cw, c, lane), wa, nx, s_ah, s_al, fr, fg, xr);
-          LP_MARK(11);
-          __syncthreads();
-          LP_MARK(7);
-          continue;
-        }
-        f32x4 a1n[PT][2];
-        if (more) {
-          ff_bias(c + 256, a1n);
-          tile_gemm_p<false, TF, PT>(wstream<TF == 3>(L.ff1, c + 256 + cw, 0, lane), wa, wstream(L.ff2, cw, c, lane), s_hh, s_hl, fr, fg, a1n,
-                                        [&](int k) { if (k < PT) ff_epi(k); });
-          LP_MARK(9);
-        } else {
-#pragma unroll
-          for (int pt = 0; pt < PT; pt++) ff_epi(pt);
-          LP_MARK(10);
-        }
-        __syncthreads();
-        LP_MARK(6);
-        RELAUNDER();
-        const WStream nx = more ? (c + 512 < d_ff ? wstream(L.ff1, c + 512 + cw, 0, lane) : wstream(L.ff2, cw, c + 256, lane)) : wstream(Ln.qkv, cw, 0, lane);
-        tile_gemm_p<false, TF, PT>(wstream<TF == 3>(L.ff2, cw, c, lane), wa, nx, s_ah, s_al, fr, fg, xr);
-        LP_MARK(11);
-        __syncthreads();
-        LP_MARK(7);
-        if (more) {
+        uint16_t* hid = (TWO_BUF && ((c >> 8) & 1u)) ? s_al : s_ah;   // (read as an f16 hi plane in either case: TF == 1 has no lo plane)
+        f32x4 a1[PT][2];
+        {  // the accumulators start from the bias (the moves that would zero them carry it)
+          float b1[8];
+          lds8(PAR_BFF1 + c + cw + 8 * fg, b1);
 #pragma unroll
           for (int pt = 0; pt < PT; pt++)
 #pragma unroll
-            for (int jt = 0; jt < 2; jt++) a1[pt][jt] = a1n[pt][jt];
+            for (int jt = 0; jt < 2; jt++) a1[pt][jt] = f32x4{b1[4 * jt], b1[4 * jt + 1], b1[4 * jt + 2], b1[4 * jt + 3]};
         }
+        tile_gemm_p<false, TF, PT>(wstream<TF == 3>(L.ff1, c + cw, 0, lane), wa, wstream(L.ff2, cw, c, lane), s_hh, s_hl, fr, fg, a1);
+        LP_MARK(9);
+#pragma unroll
+        for (int pt = 0; pt < PT; pt++) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) v[q] = __builtin_amdgcn_fmed3f(a1[pt][q >> 2][q & 3], 0.f, __builtin_huge_valf());   // ReLU in ONE instruction (fmaxf: a canonicalising v_max in front of the v_max)
+          store_act(std::integral_constant<int, TF>{}, hid, s_al, hlsw(pt * 16 + fr, wave * 4 + fg), v);
+        }
+        LP_MARK(10);
+        __syncthreads();   // the hidden chunk is complete; TWO_BUF: ... and every wave is through FF2(c - 1), whose buffer the NEXT epilogue writes
+        LP_MARK(6);
+        const bool more = c + 256 < d_ff;
+        const WStream nx = more ? wstream(L.ff1, c + 256 + cw, 0, lane) : wstream(Ln.qkv, cw, 0, lane);
+        tile_gemm_p<false, TF, PT>(wstream<TF == 3>(L.ff2, cw, c, lane), wa, nx, hid, s_al, fr, fg, xr);
+        LP_MARK(11);
+        if (!TWO_BUF || !more) __syncthreads();   // (the loop's last barrier stays: the next layer's parameters are staged behind it)
+        LP_MARK(7);
       }
     }
     // every wave is past its last read of this layer's parameters (the barrier that closed the FF loop)
@@ -1416,8 +1386,9 @@ void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S,
     const int g = force_g == 3 || force_g == 4 ? force_g : (busiest(96) < busiest(128) ? 3 : 4);
     const uint16_t* A = S.y2_hi + (uint64_t)t0 * lda;
     float* C = S.x + (uint64_t)t0 * h.d_model;
-    if (g == 3) hipLaunchKernelGGL(k_fc_r<3>, dim3((n + 95) / 96), dim3(512), FC_R_SHM, st, A, lda, M.fc, C, h.d_model, n);
-    else hipLaunchKernelGGL(k_fc_r<4>, dim3((n + 127) / 128), dim3(512), FC_R_SHM, st, A, lda, M.fc, C, h.d_model, n);
+    const uint32_t* rows = S.tok_row + t0;
+    if (g == 3) hipLaunchKernelGGL(k_fc_r<3>, dim3((n + 95) / 96), dim3(512), FC_R_SHM, st, A, lda, M.fc, C, h.d_model, n, rows, M.pe_tab, M.pe_rows);
+    else hipLaunchKernelGGL(k_fc_r<4>, dim3((n + 127) / 128), dim3(512), FC_R_SHM, st, A, lda, M.fc, C, h.d_model, n, rows, M.pe_tab, M.pe_rows);
   };
   if (chunk_tok && N > chunk_tok) {
     KT_BEGIN(tm, "conv_fused", st);   // (the span carries both kernels of every chunk)

@@ -75,6 +75,17 @@ def _dist():
     return dist
 
 
+# LOOPBACK (tests; HERRO_SHARD_LOOPBACK=1): with ONE rank every collective below is still issued — sizes, broadcasts, all_gathers on the
+# transport's device — and a rank's message to ITSELF goes through the same grouped isend / irecv as a peer's instead of the local shortcut.
+# A world_size-1 `nccl` group on one GPU then executes every RCCL call, tensor dtype and device staging of the N-rank path
+# (tests/test_gpu_sharded.py::test_device_staged_collectives_on_rccl_with_one_rank); what it cannot show is a transfer between two GPUs.
+LOOPBACK = os.environ.get("HERRO_SHARD_LOOPBACK", "0") not in ("", "0")
+
+
+def _alone(world: int) -> bool:
+    return world == 1 and not (LOOPBACK and _dist().is_initialized())
+
+
 def _dev(group=None):
     import torch
     dist = _dist()
@@ -211,12 +222,20 @@ def scatter_bytes(messages, group=None, sizes=None) -> np.ndarray:
     import torch
     dist = _dist()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    if world == 1:
+    if _alone(world):
         return np.ascontiguousarray(messages[0], np.uint8)
     dev = _dev(group)
     if rank == 0 and sizes is None:
         sizes = [len(m) for m in messages]
     sizes = _exchange_sizes(sizes if rank == 0 else None, 0, True, group)
+    if rank == 0 and LOOPBACK:   # rank 0's own message through the transport as well
+        m0 = messages[0]() if callable(messages[0]) else messages[0]
+        t = torch.from_numpy(np.array(m0, np.uint8)).to(dev)
+        back = torch.empty(len(t), dtype=torch.uint8, device=dev)
+        if len(t):
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, t, 0, group=group), dist.P2POp(dist.irecv, back, 0, group=group)]):
+                w.wait()
+        messages = [back.cpu().numpy()] + list(messages[1:])
     if rank == 0:
         # a message may be a callable that builds it (sizes given by the caller): the peers' messages are packed and staged on
         # the transport's device by a few threads at once (numpy copies and torch's H2D release the GIL), then sent in one group
@@ -249,16 +268,19 @@ def gather_bytes(message, group=None):
     dist = _dist()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     mine = np.frombuffer(message, np.uint8) if isinstance(message, (bytes, bytearray, memoryview)) else np.ascontiguousarray(message, np.uint8)
-    if world == 1:
+    if _alone(world):
         return [mine]
     dev = _dev(group)
     sizes = _exchange_sizes(None, len(mine), False, group)
     if rank == 0:
         bufs = [None] + [torch.empty(sizes[r], dtype=torch.uint8, device=dev) for r in range(1, world)]
         ops = [dist.P2POp(dist.irecv, bufs[r], r, group=group) for r in range(1, world) if sizes[r]]
+        if LOOPBACK and len(mine):   # its own records through the transport as well
+            bufs[0] = torch.empty(len(mine), dtype=torch.uint8, device=dev)
+            ops += [dist.P2POp(dist.isend, torch.from_numpy(np.array(mine, np.uint8)).to(dev), 0, group=group), dist.P2POp(dist.irecv, bufs[0], 0, group=group)]
         for w in (dist.batch_isend_irecv(ops) if ops else []):
             w.wait()
-        return [mine] + [bufs[r].cpu().numpy() for r in range(1, world)]
+        return [mine if bufs[0] is None else bufs[0].cpu().numpy()] + [bufs[r].cpu().numpy() for r in range(1, world)]
     if len(mine):
         t = torch.from_numpy(mine if mine.flags.writeable else mine.copy()).to(dev)   # (torch wants a writeable array to wrap)
         for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, t, 0, group=group)]):
@@ -271,7 +293,7 @@ def broadcast_reads(sb, group=None):
     import torch
     dist = _dist()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    if world == 1:
+    if _alone(world):
         return sb.seq, sb.qual, sb.off
     dev = _dev(group)
     n = torch.tensor([len(sb.seq), len(sb.off)] if rank == 0 else [0, 0], dtype=torch.int64, device=dev)
@@ -360,14 +382,14 @@ def correct_sharded(sb, n_windows_per_target, correct_fn, group=None):
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if rank == 0:   # its own shard needs no message: views into the data set
         parts = partition_targets(n_windows_per_target, world)
-        if world > 1:
+        if not _alone(world):
             scatter_bytes([np.zeros(0, np.uint8)] + [(lambda p=p, r=r: shard_work(sb, p, slot=("work", r))) for r, p in enumerate(parts[1:], 1)], group,
                           sizes=[0] + [work_size(sb, p) for p in parts[1:]])
         rids, aln_off, rows, cig_off, cig = shard_arrays(sb, parts[0])
     else:
         rids, aln_off, rows, cig_off, cig = unpack_work(scatter_bytes(None, group))
     rec = correct_fn(rids, aln_off, rows, cig_off, cig) if len(rids) else (np.zeros(0, np.uint32), np.zeros(0, np.uint64), b"")
-    if world == 1:
+    if _alone(world):
         return merge_records([rec]), len(rids)
     gathered = gather_bytes(pack_records(*rec), group)
     if rank != 0:
@@ -400,7 +422,7 @@ def allgather_u32(local: np.ndarray, group=None) -> list[np.ndarray]:
     dist = _dist()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     local = np.ascontiguousarray(local, np.uint32)
-    if world == 1:
+    if _alone(world):
         return [local]
     dev = _dev(group)
     n = torch.tensor([len(local)], dtype=torch.int64, device=dev)
@@ -426,7 +448,7 @@ def owners_by_load(tgt_rid, read_lens, window_size: int, group=None) -> np.ndarr
     dist = _dist()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     tgt_rid = np.asarray(tgt_rid, np.uint32)
-    if world == 1:
+    if _alone(world):
         return np.zeros(len(tgt_rid), np.int64)
     union = np.unique(np.concatenate(allgather_u32(tgt_rid, group)))
     shards = partition_targets(windows_of(np.asarray(read_lens)[union], window_size), world)
@@ -504,21 +526,22 @@ def exchange_bytes(messages, group=None):
     import torch
     dist = _dist()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    if world == 1:
+    if _alone(world):
         return [np.ascontiguousarray(messages[0], np.uint8)]
     dev = _dev(group)
+    self_too = LOOPBACK   # the message to this rank itself through the transport as well
     mine = torch.tensor([len(m) for m in messages], dtype=torch.int64, device=dev)
     allsz = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(allsz, mine, group=group)
     sizes = [[int(x) for x in t.cpu().tolist()] for t in allsz]          # sizes[src][dst]
-    send = {d: torch.from_numpy(np.ascontiguousarray(messages[d], np.uint8)).to(dev) for d in range(world) if d != rank and sizes[rank][d]}
-    recv = {r: torch.empty(sizes[r][rank], dtype=torch.uint8, device=dev) for r in range(world) if r != rank and sizes[r][rank]}
+    send = {d: torch.from_numpy(np.array(messages[d], np.uint8)).to(dev) for d in range(world) if (d != rank or self_too) and sizes[rank][d]}
+    recv = {r: torch.empty(sizes[r][rank], dtype=torch.uint8, device=dev) for r in range(world) if (r != rank or self_too) and sizes[r][rank]}
     ops = [dist.P2POp(dist.isend, t, d, group=group) for d, t in send.items()] + [dist.P2POp(dist.irecv, t, r, group=group) for r, t in recv.items()]
     for w in (dist.batch_isend_irecv(ops) if ops else []):
         w.wait()
     out = []
     for r in range(world):
-        out.append(np.ascontiguousarray(messages[rank], np.uint8) if r == rank else (recv[r].cpu().numpy() if r in recv else np.zeros(0, np.uint8)))
+        out.append(np.ascontiguousarray(messages[rank], np.uint8) if (r == rank and not self_too) else (recv[r].cpu().numpy() if r in recv else np.zeros(0, np.uint8)))
     return out
 
 
@@ -563,16 +586,16 @@ def route_to_owners(share: _Share, group=None, read_lens=None, window_size: int 
     msgs = [np.zeros(0, np.uint8)] * world
     sent = 0
     for d in range(world):
-        if d == rank:
+        if d == rank and not LOOPBACK:
             continue
         tg = np.flatnonzero(owner == d)
         if len(tg):
             msgs[d] = shard_work(share, tg, slot=("route", d))
-            sent += len(msgs[d])
-    got = exchange_bytes(msgs, group) if world > 1 else [msgs[0]]
+            sent += len(msgs[d]) if d != rank else 0
+    got = exchange_bytes(msgs, group) if not _alone(world) else [msgs[0]]
     pieces = []
     for r in range(world):
-        if r == rank:
+        if r == rank and not LOOPBACK:
             if len(mine):
                 rids, aln_off, rows, src_off, blob = shard_arrays(share, mine)
                 pieces.append((rids, aln_off, rows, src_off, blob))
@@ -591,7 +614,7 @@ def correct_sharded_local(share: _Share, correct_fn, group=None, read_lens=None,
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     (rids, aln_off, rows, cig_off, cig), sent = route_to_owners(share, group, read_lens, window_size)
     rec = correct_fn(rids, aln_off, rows, cig_off, cig) if len(rids) else (np.zeros(0, np.uint32), np.zeros(0, np.uint64), b"")
-    if world == 1:
+    if _alone(world):
         return merge_records([rec]), len(rids), sent
     gathered = gather_bytes(pack_records(*rec), group)
     if rank != 0:
@@ -679,7 +702,7 @@ def strong_leg(args, rank: int, world: int, local: int, n_windows: int, n_ctx: i
     n_t = n_base * copies
     path = model_path or model_io.default_model_file(os.path.join(root, "tests", "_cache"))[0]
     sb = synth.replicate_targets(synth.generate_parallel(n_base, wpt * W, n_ovl, seed=synth.SEED + 3), copies) if rank == 0 else None
-    seq, qual, off = broadcast_reads(sb) if world > 1 else (sb.seq, sb.qual, sb.off)
+    seq, qual, off = broadcast_reads(sb) if not _alone(world) else (sb.seq, sb.qual, sb.off)
     if n_ctx is None:
         # feeder contexts per GPU: what the end_to_end leg of bench.py measured best on one GPU (four -> six feeders: +19 %, eight: slower again,
         # profiles/r4_ab_runs.json r4_e2e_feeders); with several ranks on one host three each, and the host pools of a rank sized to its share of the CPUs
@@ -710,7 +733,7 @@ def strong_leg(args, rank: int, world: int, local: int, n_windows: int, n_ctx: i
         if rank == 0:
             blocks = np.array_split(np.arange(n_t, dtype=np.int64), world)
             msgs = [np.zeros(0, np.uint8)] + [(lambda p=p, r=r: shard_work(sb, p, slot=("share", r))) for r, p in enumerate(blocks[1:], 1)]
-            if world > 1:
+            if not _alone(world):
                 scatter_bytes(msgs, None, sizes=[0] + [work_size(sb, p) for p in blocks[1:]])
             share = _Share(*shard_arrays(sb, blocks[0]))
         else:
@@ -725,7 +748,7 @@ def strong_leg(args, rank: int, world: int, local: int, n_windows: int, n_ctx: i
             reg_blob = None
 
     def sync():
-        if world > 1:
+        if not _alone(world):
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -745,7 +768,7 @@ def strong_leg(args, rank: int, world: int, local: int, n_windows: int, n_ctx: i
     sync()
     seen = world
     sent_all = sent
-    if world > 1:
+    if not _alone(world):
         tt = torch.tensor([el], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())

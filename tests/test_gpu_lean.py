@@ -116,3 +116,58 @@ def test_receptive_field_records_are_the_planes_cells(name):
                     n_rec += 1
     assert n_rec > 0
     job.close()
+
+
+TOKMAP = np.full(256, 255, np.uint8)
+for _i, _ch in enumerate("ACGT*acgt#."):     # inference.rs BASES_MAP: the token of every cell of the oracle's matrix
+    TOKMAP[ord(_ch)] = _i
+
+
+@pytest.mark.parametrize("name", ["baseline_w4096", "low_coverage", "noisy_w256", "diverged_haplotypes"])
+def test_receptive_field_records_are_the_oracles_cells(name):
+    """the records the model reads on the lean path (written by k_rfq behind a job on its own, by k_rows itself for a
+    pipelining caller) against cells cut from the ORACLE's [L', 31] bases / quals (features.rs:110-266; rows from get_target_indices,
+    inference.rs:255-268) — byte for byte, with no token plane of the product involved: the records are read out BEFORE anything asks for
+    the planes (the planes path is not the reference here, the oracle is)."""
+    cs = CASES[name]
+    n = 6 if name == "baseline_w4096" else cs["n"]          # 24 windows of the BASELINE workload (4096 bp x 32 overlaps)
+    sb = synth.generate(n, cs["tl"], cs["ov"], seed=synth.SEED + 41 + sum(map(ord, name)), **cs["kw"])
+    store = O.store_from_synth(sb)
+    c = G.ctx()
+    G.load_synth(c, sb)
+    c.featurize_planes(False)
+    job = api.job_from_synth(c, sb, cs["W"])
+    job.featurize()
+    job.infer(64, 1)
+    assert not job.rf_fused()
+    recs = {"k_rfq": [job.rf_records(w) for w in range(job.n_windows)]}
+    other = api.job_from_synth(c, sb, cs["W"], targets=[0])
+    other.featurize()                          # a pending job: k_rows gathers the receptive fields itself
+    job.featurize()
+    job.infer(64, 1)
+    if job.rf_fused():
+        recs["k_rows"] = [job.rf_records(w) for w in range(job.n_windows)]
+    other.close()
+    assert name == "low_coverage" or "k_rows" in recs or name == "diverged_haplotypes"
+    n_cells = w = 0
+    for t in range(sb.n_targets):
+        rid, rows, cigs = O.target_alignments(sb, t)
+        res = store.extract_features(rid, rows, cigs, cs["W"])
+        for wi in range(len(res)):
+            ow = res.window(wi)
+            enc = TOKMAP[ow.bases]
+            L = enc.shape[0]
+            tidx = np.flatnonzero(enc[:, 0] != 4)
+            r0 = (tidx[ow.sup_pos.astype(np.int64)] + ow.sup_ins).astype(np.int64)
+            for who, rr in recs.items():
+                rf = rr[w]
+                assert rf.shape[0] == len(r0), (who, t, wi)
+                for d in range(5):
+                    r = r0 - 2 + d
+                    ok = (r >= 0) & (r < L)
+                    assert np.array_equal(rf[ok][:, :, d], enc[r[ok]]), (who, t, wi, d, "tokens")
+                    assert np.array_equal(rf[ok][:, :, 8 + d], ow.quals[r[ok]]), (who, t, wi, d, "qualities")
+                    n_cells += int(ok.sum()) * 31
+            w += 1
+    assert w == job.n_windows and (n_cells > 0 or name == "low_coverage")
+    job.close()
