@@ -205,6 +205,12 @@ def main():
     ap.add_argument("--long-run-steps", type=int, default=None,
                     help="after a SHORT measurement (steps < 64, one GPU) the same device-resident leg is run once more with this many steps in a "
                          "child process and reported as 'long_run' in the same line (default 256; 0: skip)")
+    ap.add_argument("--sustained", type=float, default=None,
+                    help="seconds of the `sustained` leg: the device-resident loop repeated for at least this long, windows/s of its first and last half second and the "
+                         "shader clock sampled every half second (default 2 on one GPU when steps >= 64 — a short run gets it from its long_run child; 0: skip)")
+    ap.add_argument("--sensitivity", type=int, default=None,
+                    help="1: `value` re-measured, one pass each, on data sets with more informative rows per window (p_snp 8e-3, 3e-2 next to the workload's 2e-3): "
+                         "the throughput is roughly inversely proportional to that mean (default 1 on one GPU, 0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -365,6 +371,68 @@ def main():
         return el_
     el = timed_pass()                                    # THE measurement: exactly K steps
     repeats = [timed_pass() for _ in range(max(0, args.repeats))]   # reported beside it (run-to-run spread), never used for `value`
+    # ---- sustained: the same device-resident steps for seconds instead of milliseconds — is the figure above a transient of clocks and caches?
+    sustained = None
+    sus_s = args.sustained if args.sustained is not None else (2.0 if (world == 1 and args.steps >= 64) else 0.0)
+    if sus_s > 0 and world == 1:
+        marks, clocks = [], []
+        t0_ = time.perf_counter()
+        next_probe, done_w = 0.0, 0
+        while True:
+            run_steps(args.steps)
+            for c in ctxs:
+                c.synchronize()
+            done_w += args.steps * args.batch
+            now = time.perf_counter() - t0_
+            marks.append((now, done_w))
+            if now >= next_probe:
+                try:
+                    clocks.append((round(now, 3), round(ctx.clock_probe(), 1)))
+                except Exception as e:   # a probe that fails costs the sample, not the leg
+                    clocks.append((round(now, 3), repr(e)))
+                next_probe = now + 0.5
+            if now >= sus_s:
+                break
+        T_ = marks[-1][0]
+
+        def rate(a, b):   # windows/s between the first pass boundaries at or behind a and b seconds
+            ia = next((i for i, (t, _) in enumerate(marks) if t >= a), len(marks) - 1) if a > 0 else -1
+            ib = next((i for i, (t, _) in enumerate(marks) if t >= b), len(marks) - 1)
+            ta, wa_ = (0.0, 0) if ia < 0 else marks[ia]
+            tb, wb_ = marks[ib]
+            return (wb_ - wa_) / (tb - ta) if tb > ta else None
+        mhz = [c_[1] for c_ in clocks if isinstance(c_[1], float)]
+        sustained = {"seconds": T_, "steps": len(marks) * args.steps, "passes": len(marks), "windows_per_s": marks[-1][1] / T_,
+                     "first_half_second_windows_per_s": rate(0.0, 0.5), "last_half_second_windows_per_s": rate(max(0.0, T_ - 0.5), T_),
+                     "shader_clock_mhz": clocks, "shader_clock_mhz_min_max": [min(mhz), max(mhz)] if mhz else None,
+                     "note": "the timed region of `value` repeated back to back (each pass synchronised); shader clock = s_memtime / s_memrealtime of a one-wave probe "
+                             "queued behind a pass (herro_clock_probe)"}
+    # ---- sensitivity: the workload's 2e-3 SNP rate gives ~15 informative rows per window; throughput falls with that mean (the transformer's share grows)
+    sensitivity = None
+    if (args.sensitivity if args.sensitivity is not None else 1) and world == 1:
+        sensitivity = []
+        s_steps = max(1, min(args.steps, 32))
+        for p_snp in (8e-3, 3e-2):
+            try:
+                sb_s = synth.generate_parallel(s_steps * targets_per_step, WINS_PER_TARGET * W, N_OVL, seed=synth.SEED + 77, workers=min(cpus_rank, 64), p_snp=p_snp)
+                c_s = api.Context(local)
+                c_s.load_model(path)
+                c_s.set_precision(args.precision)
+                c_s.set_reads(sb_s.seq, sb_s.qual, sb_s.off)
+                j_s = api.job_from_synth(c_s, sb_s, W, range(s_steps * targets_per_step))
+                for _ in range(2):        # warm (arenas, late buffers)
+                    j_s.featurize(); j_s.infer(args.batch, 1); j_s.consensus()
+                c_s.synchronize()
+                t_ = time.perf_counter()
+                j_s.featurize(); j_s.infer(args.batch, 1); j_s.consensus()
+                c_s.synchronize()
+                e_ = time.perf_counter() - t_
+                st_s = j_s.stats()
+                sensitivity.append({"p_snp": p_snp, "mean_informative": st_s["sum_supported"] / j_s.n_windows, "windows_per_s": j_s.n_windows / e_,
+                                    "ms_per_step": 1e3 * e_ / s_steps, "steps": s_steps, "windows": j_s.n_windows})
+                j_s.close(); c_s.close()
+            except Exception as e:   # never the measured line
+                sensitivity.append({"p_snp": p_snp, "error": repr(e)})
     if world > 1:
         tt = torch.tensor([el], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -598,6 +666,8 @@ def main():
                                            "frac": (per_job["read_bytes"] / 5.0 + per_job["op_bytes"] + plane_bytes + tokens * 5 * 31 * 2.0) / G / (feat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
             "roofline_next_kernels": roof_next, "repeat_ms_per_step": [r * 1e3 / args.steps for r in repeats], "stage_ms_per_step": {"featurize": feat_ms, "model": model_ms},
             "end_to_end": e2e,
+            "sustained": sustained,
+            "sensitivity": sensitivity,
             "self_check": check,
             "kernels": kern,
         }
@@ -642,13 +712,16 @@ def main():
     elif rank == 0 and world == 1 and lr_steps > 0 and args.steps < 64:
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(lr_steps), "--warmup", "8", "--no-cpu-baseline", "--self-check", "0", "--e2e-jobs", "0",
-               "--strong-windows", "0", "--repeats", "1", "--long-run-steps", "0", "--precision", str(args.precision), "--batch", str(args.batch)]
+               "--strong-windows", "0", "--repeats", "1", "--long-run-steps", "0", "--precision", str(args.precision), "--batch", str(args.batch),
+               "--sustained", str(2.0 if args.sustained is None else args.sustained), "--sensitivity", "0"]
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=150)
             d = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
             out["long_run"] = {k: d[k] for k in ("steps", "warmup", "value", "ms_per_step", "timed_region_s", "repeat_ms_per_step")}
             out["long_run"]["roofline_frac"] = d["roofline"]["frac"]
             out["long_run"]["streams_per_gpu"] = d["config"]["streams_per_gpu"]
+            if d.get("sustained") and not out.get("sustained"):
+                out["sustained"] = dict(d["sustained"], measured_in="the long_run child (256-step passes, two streams)")
         except Exception as e:   # never the measured line
             out["long_run"] = {"error": repr(e)}
     if rank == 0:

@@ -20,7 +20,7 @@ DEFAULT_PRECISION = 4
 EXPORTS = [
     "herro_version", "herro_create", "herro_destroy", "herro_last_error", "herro_set_stream", "herro_synchronize",
     "herro_encode_2bit", "herro_decode_2bit", "herro_set_reads", "herro_set_reads_packed", "herro_share_reads", "herro_load_model",
-    "herro_set_precision", "herro_precision", "herro_calibration_error", "herro_debug_force_precision", "herro_model_describe", "herro_job_create", "herro_job_free", "herro_job_n_windows", "herro_job_skipped", "herro_job_featurize",
+    "herro_set_precision", "herro_precision", "herro_clock_probe", "herro_calibration_error", "herro_debug_force_precision", "herro_model_describe", "herro_job_create", "herro_job_free", "herro_job_n_windows", "herro_job_skipped", "herro_job_featurize",
     "herro_job_infer", "herro_job_consensus", "herro_job_consensus_fetch", "herro_job_window_info", "herro_job_window_copy", "herro_job_window_logits",
     "herro_job_consensus_fasta", "herro_job_fasta", "herro_model_forward", "herro_timing_enable", "herro_timing_reset",
     "herro_timing_get", "herro_job_stats", "herro_debug_extract_windows",
@@ -105,6 +105,7 @@ def lib():
             L.herro_calibration_error.restype = C.c_float
             L.herro_calibration_error.argtypes = [vp, i32]
             L.herro_debug_force_precision.argtypes = [vp, i32]
+            L.herro_clock_probe.argtypes = [vp, vp]
         except AttributeError:
             if not os.environ.get("HERRO_LIB"):
                 raise
@@ -379,6 +380,12 @@ class Context:
     def calibration_error(self, mode: int) -> float:
         """max |logit(mode) - logit(mode 0)| on the load-time calibration batch (-1: not measured)"""
         return float(self._l.herro_calibration_error(self.h, mode))
+
+    def clock_probe(self) -> float:
+        """shader clock in MHz right behind the work queued on this context's stream (herro_clock_probe; synchronises the stream)"""
+        v = C.c_double(0.0)
+        self._chk(self._l.herro_clock_probe(self.h, C.byref(v)))
+        return float(v.value)
 
     def force_precision(self, on: bool):
         """test hook (herro_debug_force_precision): set_precision / load_model skip the calibration gate"""
@@ -727,12 +734,19 @@ class PreparedAlignments:
     def register(self, ctx: "Context"):
         """pin the CIGAR blob for zero-copy job creation (herro_host_register); undo with unregister() before the arrays go away"""
         if self._reg is None and len(self._cig):
-            ctx.register_host(self._cig)
-            self._reg = ctx
+            try:
+                ctx.register_host(self._cig)
+            except HerroError as e:       # e.g. the memlock limit: jobs are staged instead (the zero-copy path is an optimisation, never a requirement)
+                if e.code != -4:   # HERRO_E_UNSUPPORTED
+                    raise
+                return
+            self._reg = True
 
     def unregister(self):
         if self._reg is not None:
-            self._reg.unregister_host(self._cig)
+            rc = lib().herro_host_unregister(None, self._cig.ctypes.data)   # the registry is process-wide: no context needed (the one that registered may be closed by now)
+            if rc:
+                raise HerroError(int(rc), "herro_host_unregister")
             self._reg = None
 
     def job(self, ctx: "Context", t0: int, t1: int, window_size: int) -> "Job":

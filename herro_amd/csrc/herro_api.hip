@@ -191,8 +191,8 @@ struct herro_ctx {
   std::atomic<uint32_t> live_jobs{0};   // herro_job_create may run on another thread than the context's execution calls
   uint64_t reads_gen = 0;   // bumped by herro_set_reads: a job built on an older store refuses to run
   uint32_t n_sib_retry = 0;        // model passes repeated without sibling tiles (sib_retry)
+  std::vector<herro_job*> sib_suspects;   // jobs whose last model pass launched sibling tiles and has not been seen clean yet (check_sib): a raised error word is theirs
   std::atomic<int> n_pending{0};   // jobs of this context that are featurized and not yet inferred: > 0 when herro_job_featurize is called means the caller pipelines its jobs
-  uint64_t n_featurize = 0, n_infer = 0;   // calls so far: a context that featurizes job after job without ever inferring (the `herro features` path) stops gathering receptive fields ahead of time
   std::atomic<int> create_code{0};   // HERRO_E_* of the last herro_job_create that returned NULL (herro_job_create_status)
 };
 
@@ -249,6 +249,7 @@ struct herro_job {
   uint32_t rf_fused_half = 0, rf_total = 0;
   bool pending = false;         // counted in herro_ctx::n_pending
   bool rf_fused_used = false;   // herro_job_infer read the records k_rows gathered (herro_debug_job_rf_fused)
+  bool sib_stale = false;       // the context's sibling-tile error word was found raised while this job's pass was unchecked: its logits are not to be trusted (sib_retry repeats the pass)
   bool no_sib = false;          // a sibling tile of this job timed out once: its windows above 64 rows go layer by layer from now on (sib_retry)
   uint32_t last_batch_size = 0; // arguments of the last herro_job_infer (sib_retry repeats it)
   int last_batch_mode = 0;
@@ -569,20 +570,37 @@ static int ensure_sib(herro_ctx* ctx, uint32_t n_tiles_b) {
   ctx->S.sib_err = (uint32_t*)ctx->sib_flag + cap;
   return HERRO_OK;
 }
-// the sticky error word of the sibling tiles (checked where the logits come back to the host)
-static int check_sib(herro_ctx* ctx) {
+// The error word of the sibling tiles, read where logits / corrected bases come back to the host (the stream has been synchronised: every model pass queued so far
+// is complete).  The word carries no job identity, so a raised word taints EVERY job whose sibling-tile pass has not been seen clean yet (ctx->sib_suspects): all of
+// them are marked stale and each repeats its pass when it is fetched (sib_retry) — the fetch that finds the word is not necessarily the job that owned the stale keys
+// (with two inferred jobs in flight the first fetch used to repeat ITS pass, clear the word, and the other job's fetch then returned invalid logits).  A job
+// whose pass launched no sibling tiles cannot be affected and is served.  job == nullptr: the stand-alone forward, which is its own suspect.
+static int check_sib(herro_ctx* ctx, herro_job* job) {
   if (!ctx->sib_flag) return HERRO_OK;
   uint32_t e = 0;
   HIP_TRY(ctx, hipMemcpyAsync(&e, (uint32_t*)ctx->sib_flag + ctx->sib_cap, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (!e) return HERRO_OK;
-  // reported once: the word is cleared so that the context stays usable (it used to stay set, and every later fetch on the context
-  // failed — launches without sibling tiles included — until ensure_sib reallocated).  The caller re-runs herro_job_infer (or selects
-  // precision 1, whose layer-by-layer path has no sibling tiles) for the job whose logits were refused.
-  (void)hipMemsetAsync((uint32_t*)ctx->sib_flag + ctx->sib_cap, 0, 4, ctx->stream);
-  ctx->err = "fused stack: a sibling tile of a window above 64 informative rows never published its keys (layer " + std::to_string(e - 1) + "); logits invalid";
-  return HERRO_E_STATE;
+  if (e) {
+    for (herro_job* j : ctx->sib_suspects) j->sib_stale = true;
+    (void)hipMemsetAsync((uint32_t*)ctx->sib_flag + ctx->sib_cap, 0, 4, ctx->stream);   // reported (to its suspects): the context stays usable
+  }
+  ctx->sib_suspects.clear();   // clean, or marked
+  if (job ? job->sib_stale : e != 0) {
+    ctx->err = "fused stack: a sibling tile of a window above 64 informative rows never published its keys" + (e ? " (layer " + std::to_string(e - 1) + ")" : std::string()) + "; logits invalid";
+    return HERRO_E_STATE;
+  }
+  return HERRO_OK;
 }
+// One wave reads the shader clock counter (s_memtime) and the constant-rate one (s_memrealtime) around ~40 us of dependent adds: the ratio is the shader clock
+// the chip runs at right behind whatever the stream just executed (bench.py's `sustained` leg samples it; the release kernels carry no timers)
+__global__ void k_clock_probe(unsigned long long* out, uint32_t spin) {
+  const unsigned long long c0 = clock64(), w0 = wall_clock64();
+  uint32_t x = threadIdx.x;
+  for (uint32_t i = 0; i < spin; i++) x = x * 1664525u + 1013904223u;
+  const unsigned long long c1 = clock64(), w1 = wall_clock64();
+  if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; out[2] = x; }
+}
+
 static void run_model(herro_ctx* ctx, const BatchDev& B, bool tiled) {
   if (B.n_tok == 0) return;
   const int p = ctx->precision;
@@ -1549,32 +1567,52 @@ bool host_range_registered(const unsigned char* lo, const unsigned char* hi) {
 int herro_host_register(herro_ctx* ctx, const void* p, uint64_t bytes) {
   if (!ctx || !p || !bytes) return HERRO_E_INVALID;
   if (ctx->host_only) return HERRO_OK;
-  std::lock_guard<std::mutex> lk(g_reg_mu);
-  for (HostReg& r : g_regs) if (r.p == (const unsigned char*)p && r.n == bytes) { r.refs++; return HERRO_OK; }
+  {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    for (HostReg& r : g_regs) if (r.p == (const unsigned char*)p && r.n == bytes) { r.refs++; return HERRO_OK; }
+  }
+  // the pinning (a multi-GB blob takes a while) runs OUTSIDE the registry's lock: every feeder's herro_job_create looks ranges up under it
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterPortable));
+  const hipError_t e = hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterPortable);
+  if (e != hipSuccess) {   // e.g. the memlock limit: not fatal — jobs over this range are staged like any unregistered text
+    (void)hipGetLastError();
+    ctx->err = std::string("herro_host_register: ") + hipGetErrorString(e) + " (jobs over this range will be staged)";
+    return HERRO_E_UNSUPPORTED;
+  }
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  for (HostReg& r : g_regs)
+    if (r.p == (const unsigned char*)p && r.n == bytes) {   // somebody registered the same range meanwhile: one registration is enough
+      r.refs++;
+      (void)hipHostUnregister(const_cast<void*>(p));
+      return HERRO_OK;
+    }
   g_regs.push_back(HostReg{(const unsigned char*)p, bytes, 1});
   return HERRO_OK;
 }
-
 uint64_t herro_debug_zero_copy_jobs(void) { return g_zero_copy_jobs.load(); }
 
+// (ctx may be NULL: the registry is process-wide and the range outlives no particular context)
 int herro_host_unregister(herro_ctx* ctx, const void* p) {
-  if (!ctx || !p) return HERRO_E_INVALID;
-  if (ctx->host_only) return HERRO_OK;
-  std::lock_guard<std::mutex> lk(g_reg_mu);
-  for (size_t i = 0; i < g_regs.size(); i++)
-    if (g_regs[i].p == (const unsigned char*)p) {
-      if (--g_regs[i].refs == 0) {
-        (void)hipSetDevice(ctx->device);
-        (void)hipDeviceSynchronize();   // no copy out of the range may still be in flight
-        (void)hipHostUnregister(const_cast<void*>(p));
-        g_regs.erase(g_regs.begin() + (long)i);
-      }
-      return HERRO_OK;
-    }
-  ctx->err = "herro_host_unregister: not a registered range";
-  return HERRO_E_INVALID;
+  if (!p) return HERRO_E_INVALID;
+  if (ctx && ctx->host_only) return HERRO_OK;
+  bool last = false;
+  {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    size_t i = 0;
+    for (; i < g_regs.size(); i++) if (g_regs[i].p == (const unsigned char*)p) break;
+    if (i == g_regs.size()) { if (ctx) ctx->err = "herro_host_unregister: not a registered range"; return HERRO_E_INVALID; }
+    if (--g_regs[i].refs == 0) { g_regs.erase(g_regs.begin() + (long)i); last = true; }   // off the list first: no new job takes the zero-copy path over it
+  }
+  if (last) {
+    // no copy out of the range may still be in flight — on ANY device: the registration is portable, contexts of other GPUs may be reading from it on their prep streams
+    int n = 0, cur = 0;
+    (void)hipGetDevice(&cur);
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    for (int d = 0; d < n; d++) if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
+    (void)hipSetDevice(cur);
+    (void)hipHostUnregister(const_cast<void*>(p));
+  }
+  return HERRO_OK;
 }
 
 // ---- job -------------------------------------------------------------------------------------------
@@ -1898,6 +1936,7 @@ void herro_job_free(herro_job* job) {
   herro_ctx* ctx = job->ctx;
   if (ctx->live_jobs.load()) ctx->live_jobs--;
   if (job->pending) { job->pending = false; ctx->n_pending--; }   // featurized, never inferred
+  ctx->sib_suspects.erase(std::remove(ctx->sib_suspects.begin(), ctx->sib_suspects.end(), job), ctx->sib_suspects.end());
   if (ctx->host_only) {
     std::lock_guard<std::mutex> lk(ctx->arena_mu);
     if (job->pin.p) { if (ctx->free_pin.size() < 6) ctx->free_pin.push_back(job->pin); else std::free(job->pin.p); }
@@ -1936,8 +1975,8 @@ int herro_job_featurize(herro_job* job) {
   job->lean = ctx->lean; job->tokens_full = !ctx->lean;
   job->consensus_done = false; job->consensus_on_host = false; job->logits_on_host = false;
   if (job->J.n_win == 0) { job->featurized = true; return HERRO_OK; }
-  ctx->n_featurize++;
-  const bool features_only = ctx->n_featurize > 4 && ctx->n_infer == 0;   // (feature-only jobs paid for the gather and its buffer)
+  // (the receptive fields are gathered ahead of herro_job_infer exactly when a model is loaded: a context that only writes features — `herro features` — loads
+  // none and pays for no gather; the call-history heuristic of round 5 made jobs 5.. of a featurize-all-then-infer caller lose the early gather: ADVICE r5)
   const uint32_t rf_half = ctx->has_model ? 2 * (ctx->M.h.kw / 2) : 0;
   // The model's receptive fields are gathered by k_rows itself on the lean path (records placed by one atomic per window), into a buffer sized by the
   // job's previous pass or by an estimate; if it turns out too small — or a window has more informative rows than k_rows stages — herro_job_infer
@@ -1952,7 +1991,7 @@ int herro_job_featurize(herro_job* job) {
   if (!job->pending) { job->pending = true; ctx->n_pending++; }
   job->rf_fused = false;
   job->J.rf = nullptr;
-  if (job->lean && (fuse_rf == 1 || (fuse_rf < 0 && pipelined)) && ctx->has_model && !features_only && rf_half == 2) {
+  if (job->lean && (fuse_rf == 1 || (fuse_rf < 0 && pipelined)) && ctx->has_model && rf_half == 2) {
     const uint64_t want = job->logit_cap > 1 ? job->logit_cap : (uint64_t)job->J.n_win * 24;   // ~15 informative rows per window at the bench workload
     if (ensure_logits(job, want) == HERRO_OK) {
       job->J.rf = job->d_rfq; job->J.rf_cap = std::min<uint64_t>(job->logit_cap, 0xfffffff0ull / HERRO_ROWS); job->J.rf_half = rf_half;
@@ -1973,7 +2012,7 @@ int herro_job_featurize(herro_job* job) {
   // count turns out larger, herro_job_infer gathers again.  HERRO_RFQ_EARLY=0: gather in herro_job_infer (A/B).
   job->rfq_spec = false;
   static const bool early = ab_env("HERRO_RFQ_EARLY", 1) != 0;
-  if (early && !job->rf_fused && ctx->has_model && !features_only && 2 * rf_half + 1 <= 8) {
+  if (early && !job->rf_fused && ctx->has_model && 2 * rf_half + 1 <= 8) {
     const uint32_t n = job->J.n_win;
     if (!job->a_supoff_dev.p) job->a_supoff_dev = small_acquire(ctx, ((uint64_t)n + 1) * 8);
     const uint64_t want = job->logit_cap > 1 ? job->logit_cap : (uint64_t)n * 24;   // ~15 informative rows per window at the bench workload
@@ -2035,7 +2074,6 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   herro_ctx* ctx = job->ctx;
   if (!ctx->has_model) { ctx->err = "no model loaded"; return HERRO_E_NO_MODEL; }
   ProfSpan span_(ctx, "infer");
-  ctx->n_infer++;
   job->last_batch_size = batch_size; job->last_batch_mode = batch_mode;
   if (job->pending) { job->pending = false; ctx->n_pending--; }
   int rc = job_sync(job);
@@ -2208,9 +2246,11 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
     B.planes_b = job->J.fin_b; B.planes_q = job->J.fin_q; B.sup_row = job->J.sup_row;
     B.rf_q = rf_compact ? job->d_rfq : nullptr;
     B.out_info = job->d_info; B.out_base = job->d_base;
+    if (o.tiled && o.n_tiles_b && std::find(ctx->sib_suspects.begin(), ctx->sib_suspects.end(), job) == ctx->sib_suspects.end()) ctx->sib_suspects.push_back(job);
     run_model(ctx, B, o.tiled);
   }
   HIP_TRY(ctx, hipGetLastError());
+  job->sib_stale = false;   // (a new pass supersedes whatever the previous one was suspected of; this pass is a suspect again if it launched sibling tiles)
   job->inferred = true;
   job->logits_on_host = false;
   job->consensus_done = false;
@@ -2325,23 +2365,23 @@ int herro_job_window_copy(herro_job* job, uint32_t w, int encoded, uint8_t* base
   return HERRO_OK;
 }
 
-// A sibling tile that never saw its group (check_sib) is not the caller's problem: the job's model pass — and its consensus pass, if that
-// had run — is repeated ONCE with its windows above 64 informative rows on the layer-by-layer kernels, which have no cross-workgroup wait
-// (ADVICE r4).  The error word belongs to the context: with several jobs in flight the one that fetches first repeats its pass, whether
-// or not the stale keys were its own — a repeated pass is only time.  Returns check_sib's code when the repeat cannot run or fails too.
+// A sibling tile that never saw its group (check_sib) is not the caller's problem: the model pass of every job the raised word may belong to — and its consensus
+// pass, if that had run — is repeated ONCE with its windows above 64 informative rows on the layer-by-layer kernels, which have no cross-workgroup wait,
+// each when it is fetched (the job that fetches first is not the only one).  Returns check_sib's code when the repeat cannot run or fails too.
 static int sib_retry(herro_job* job, int rc_sib) {
   herro_ctx* ctx = job->ctx;
   if (job->no_sib || !job->last_batch_size) return rc_sib;
   const bool had_consensus = job->consensus_done;
   const std::string why = ctx->err.c_str();
   job->no_sib = true;
+  job->sib_stale = false;
   ctx->n_sib_retry++;
   int rc = herro_job_infer(job, job->last_batch_size, job->last_batch_mode);
   if (!rc && had_consensus) rc = herro_job_consensus(job);
   if (rc) { const std::string second = ctx->err.c_str(); ctx->err = why + "; the repeat without sibling tiles failed: " + second; return rc; }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->timer.collect();
-  return check_sib(ctx);
+  return check_sib(ctx, job);
 }
 
 static int logits_to_host(herro_job* job) {
@@ -2354,7 +2394,7 @@ static int logits_to_host(herro_job* job) {
   job->h_base.resize(tot * 5);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->timer.collect();
-  if (int rc = check_sib(ctx)) if ((rc = sib_retry(job, rc))) return rc;
+  if (int rc = check_sib(ctx, job)) if ((rc = sib_retry(job, rc))) return rc;
   if (tot) {
     HIP_TRY(ctx, hipMemcpy(job->h_info.data(), job->d_info, tot * 4, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(job->h_base.data(), job->d_base, tot * 20, hipMemcpyDeviceToHost));
@@ -2386,7 +2426,7 @@ static int consensus_to_host(herro_job* job) {
     if (job->row_elems) HIP_TRY(ctx, hipMemcpyAsync(job->h_cons_seq, job->J.cons_seq, job->row_elems, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->timer.collect();
-    int rc = check_sib(ctx);
+    int rc = check_sib(ctx, job);
     if (!rc) break;
     if (attempt || (rc = sib_retry(job, rc))) return rc;   // repeated once: copy again what the second pass decoded
   }
@@ -2708,7 +2748,7 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return done(HERRO_E_NO_DEVICE); }
   ctx->timer.collect();
-  if ((rc = check_sib(ctx))) return done(rc);
+  if ((rc = check_sib(ctx, nullptr))) return done(rc);
   HIP_TRY(ctx, hipMemcpy(info_logits, d_info, N * 4, hipMemcpyDeviceToHost));
   HIP_TRY(ctx, hipMemcpy(bases_logits, d_base, N * 20, hipMemcpyDeviceToHost));
   return done(HERRO_OK);
@@ -2793,6 +2833,23 @@ int herro_debug_sib_fault(herro_ctx* ctx) {
   return HERRO_OK;
 }
 int herro_debug_sib_retries(const herro_ctx* ctx) { return ctx ? (int)ctx->n_sib_retry : HERRO_E_INVALID; }
+
+int herro_clock_probe(herro_ctx* ctx, double* shader_mhz) {
+  if (!ctx || !shader_mhz) return HERRO_E_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int wall_khz = 0;
+  HIP_TRY(ctx, hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, ctx->device));
+  unsigned long long* d = nullptr;
+  HIP_TRY(ctx, hipMalloc((void**)&d, 32));
+  hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, ctx->stream, d, 20000u);
+  unsigned long long h[3] = {0, 0, 0};
+  hipError_t e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d);
+  HIP_TRY(ctx, e);
+  *shader_mhz = h[1] ? (double)h[0] / (double)h[1] * (double)wall_khz * 1e-3 : 0.0;
+  return HERRO_OK;
+}
 uint32_t herro_debug_e4m3(float x) { return f32_to_e4m3(x); }   // the host encoder of the precision-6 weight copies (tests)
 int herro_debug_job_rf_fused(const herro_job* job) { return job && job->inferred ? (job->rf_fused_used ? 1 : 0) : HERRO_E_STATE; }
 

@@ -122,6 +122,9 @@ int herro_load_model(herro_ctx* ctx, const char* path);
  * herro_calibration_error what a mode measured (-1: not measured). */
 int herro_set_precision(herro_ctx* ctx, int mode);
 int herro_precision(const herro_ctx* ctx);
+/* Measurement aid: the shader clock (MHz) the device runs at right behind the work queued on the context's stream — one wave reads the
+ * shader-clock and the constant-rate counters around ~40 us of dependent adds (synchronises the stream).  bench.py's `sustained` leg samples it. */
+int herro_clock_probe(herro_ctx* ctx, double* shader_mhz);
 float herro_calibration_error(const herro_ctx* ctx, int mode);
 
 /* Text description of the loaded model: hyper-parameters, receptive field of an informative row (rows the conv stack
@@ -152,7 +155,9 @@ void herro_job_free(herro_job* job);
  * into a pinned staging block first.  A caller whose alignments' `cigar` pointers lie in ONE buffer — the PAF text behind
  * herro_paf_parse_view, a blob of CIGARs — registers that buffer once (it is pinned for the GPU, hipHostRegister): jobs whose texts lie
  * densely inside a registered range are then copied up straight from it, one copy, no pass over the bytes on the host.  Process-wide
- * and counted: several contexts may register the same range; unregister before the memory is freed.  (The reference has no counterpart:
+ * and counted: several contexts may register the same range; unregister before the memory is freed (herro_host_unregister waits for the copies of
+ * EVERY device and accepts ctx == NULL: the range outlives no particular context).  A range that cannot be pinned (the memlock limit) returns
+ * HERRO_E_UNSUPPORTED and changes nothing: its jobs are staged.  (The reference has no counterpart:
  * its feature threads walk the CIGARs where the parser left them, features.rs:337-361.) */
 int herro_host_register(herro_ctx* ctx, const void* p, uint64_t bytes);
 int herro_host_unregister(herro_ctx* ctx, const void* p);

@@ -55,6 +55,7 @@ class FakeCtx:
     def load_model(self, p): pass
     def set_precision(self, m): pass
     def precision(self): return 4
+    def clock_probe(self): return 2100.0
     def calibration_error(self, m): return 4.0e-4 if m == 4 else 6.0e-4
     def set_reads(self, *a): pass
     def share_reads(self, other): assert isinstance(other, FakeCtx)
@@ -72,7 +73,7 @@ class FakeCtx:
 @pytest.mark.parametrize("argv,steps,strong_mode", [(["--steps", "12", "--warmup", "4", "--group", "3", "--streams", "2"], 12, "ok"),
                                                     (["--steps", "7", "--warmup", "1", "--group", "32", "--streams", "2"], 7, "ok"),
                                                     (["--steps", "1", "--warmup", "0"], 1, "ok"),
-                                                    (["--steps", "3", "--warmup", "0", "--precision", "6"], 3, "ok"),   # the e4m3-remainder mode has its dtype / MFMA-terms entries
+                                                    (["--steps", "3", "--warmup", "0", "--precision", "6", "--sustained", "0.05"], 3, "ok"),   # the e4m3-remainder mode has its dtype / MFMA-terms entries
                                                     ([], None, "ok"),
                                                     (["--steps", "2", "--warmup", "0"], 2, "raises"),
                                                     (["--steps", "2", "--warmup", "0", "--strong-timeout", "0.3"], 2, "hangs")])
@@ -120,7 +121,8 @@ def test_bench_flow(monkeypatch, capsys, argv, steps, strong_mode):
                            "roofline": {"frac": 0.22}, "config": {"streams_per_gpu": 2}})
         return types.SimpleNamespace(stdout="noise\n" + line + "\n", returncode=0)
     monkeypatch.setattr(subprocess, "run", fake_run)
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--no-cpu-baseline", "--self-check", "0"] + argv)
+    extra_legs = "--precision" in argv      # one case runs the `sustained` / `sensitivity` legs too (they re-run jobs back to back: the ordering checks below are about the timed passes)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--no-cpu-baseline", "--self-check", "0"] + ([] if extra_legs else ["--sensitivity", "0"]) + argv)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
     sys.path.insert(0, ROOT)
@@ -169,6 +171,12 @@ def test_bench_flow(monkeypatch, capsys, argv, steps, strong_mode):
         if ev == "I":
             assert last.get(jid) == "F"
         last[jid] = ev
+    if extra_legs:   # the extra legs of round 6 ride in the same line
+        su = d["sustained"]
+        assert su["seconds"] >= 0.05 and su["passes"] >= 1 and su["windows_per_s"] > 0 and su["shader_clock_mhz"][0][1] == 2100.0
+        assert [x["p_snp"] for x in d["sensitivity"]] == [8e-3, 3e-2] and all(x["windows_per_s"] > 0 and x["mean_informative"] == 15 for x in d["sensitivity"])
+        return
+    assert d["sensitivity"] is None
     # a run of at least one full launch group cycles two or more DISTINCT jobs (the timed job is not the one that was just warmed)
     inferred = [jid for ev, jid in FakeJob.log if ev == "I"]
     if d["steps"] >= d["config"]["batches_per_launch_group"]:
