@@ -27,7 +27,7 @@ EXPORTS = [
     "herro_paf_parse", "herro_oec_read", "herro_paf_n_targets", "herro_paf_target_ids", "herro_paf_aln_off",
     "herro_paf_alignments", "herro_paf_free", "herro_name_index_create", "herro_name_index_free", "herro_paf_parse_indexed",
     "herro_oec_read_indexed", "herro_paf_parse_view", "herro_debug_host_ctx", "herro_debug_job_array", "herro_debug_tile_plan", "herro_debug_tile_plan_sib",
-    "herro_debug_set_featurize_planes", "herro_debug_job_rf", "herro_debug_job_rf_fused", "herro_debug_e4m3", "herro_debug_sib_fault", "herro_debug_sib_retries", "herro_debug_base_row_votes", "herro_debug_vote5",
+    "herro_debug_set_featurize_planes", "herro_debug_set_host_build", "herro_debug_job_dev_built", "herro_debug_job_rf", "herro_debug_job_rf_fused", "herro_debug_e4m3", "herro_debug_sib_fault", "herro_debug_sib_retries", "herro_debug_base_row_votes", "herro_debug_vote5",
     "herro_pool_create", "herro_pool_destroy", "herro_pool_last_error", "herro_pool_size", "herro_pool_ctx", "herro_pool_set_reads", "herro_pool_load_model",
     "herro_pool_correct", "herro_pool_result", "herro_pool_groups_taken", "herro_pool_skipped", "herro_debug_pool_fake", "herro_job_create_status", "herro_host_register", "herro_host_unregister", "herro_debug_zero_copy_jobs",
     "herro_fastx_read", "herro_reads_count", "herro_reads_seq", "herro_reads_qual", "herro_reads_off", "herro_reads_ids",
@@ -161,6 +161,8 @@ def lib():
         L.herro_debug_job_array.restype = C.c_int64
         L.herro_debug_job_array.argtypes = [vp, i32, vp, vp]
         L.herro_debug_set_featurize_planes.argtypes = [vp, i32]
+        L.herro_debug_set_host_build.argtypes = [vp, i32]
+        L.herro_debug_job_dev_built.argtypes = [vp]
         L.herro_debug_base_row_votes.argtypes = [vp, vp, vp, u32, vp, vp]
         L.herro_debug_vote5.restype = u32
         L.herro_debug_vote5.argtypes = [vp, u32]
@@ -390,6 +392,20 @@ class Context:
     def force_precision(self, on: bool):
         """test hook (herro_debug_force_precision): set_precision / load_model skip the calibration gate"""
         self._chk(self._l.herro_debug_force_precision(self.h, int(on)))
+
+    def job_arrays(self, job: "Job") -> dict:
+        out = {}
+        for which, (name, dt) in enumerate([("ops", np.dtype("<u4")), ("ow", OW_DTYPE), ("win", WIN_DTYPE), ("tile_win", np.dtype("<u4")),
+                                            ("tile_r0", np.dtype("<u4")), ("tgt_win_off", np.dtype("<u4"))]):
+            p, eb = C.c_void_p(), C.c_uint32()
+            n = self._l.herro_debug_job_array(job.h, which, C.byref(p), C.byref(eb))
+            assert n >= 0 and eb.value == dt.itemsize, (name, n, eb.value, dt.itemsize)
+            out[name] = np.frombuffer((C.c_char * (n * dt.itemsize)).from_address(p.value), dt, n).copy() if n else np.zeros(0, dt)
+        return out
+
+    def host_build(self, on: bool):
+        """test hook: jobs created from now on are windowed / described by the host (rounds 3-5) instead of on the device (build_dev.hip)"""
+        self._chk(self._l.herro_debug_set_host_build(self.h, int(on)))
 
     def featurize_planes(self, on: bool):
         """test hook: jobs featurized from now on take the planes path (k_tokens) instead of the lean one (k_rows)"""
@@ -622,17 +638,6 @@ class HostContext(Context):
         rl = np.ascontiguousarray(read_len, np.uint32)
         nc = None if name_class is None else np.ascontiguousarray(name_class, np.uint32)
         self.h = self._l.herro_debug_host_ctx(len(rl), rl.ctypes.data, None if nc is None else nc.ctypes.data)
-
-    def job_arrays(self, job: "Job") -> dict:
-        out = {}
-        for which, (name, dt) in enumerate([("ops", np.dtype("<u4")), ("ow", OW_DTYPE), ("win", WIN_DTYPE), ("tile_win", np.dtype("<u4")),
-                                            ("tile_r0", np.dtype("<u4")), ("tgt_win_off", np.dtype("<u4"))]):
-            p, eb = C.c_void_p(), C.c_uint32()
-            n = self._l.herro_debug_job_array(job.h, which, C.byref(p), C.byref(eb))
-            assert n >= 0 and eb.value == dt.itemsize, (name, n, eb.value, dt.itemsize)
-            out[name] = np.frombuffer((C.c_char * (n * dt.itemsize)).from_address(p.value), dt, n).copy() if n else np.zeros(0, dt)
-        return out
-
 
 class NameIndex:
     """read name -> read id, built once per read set (herro_name_index_create; the reference's `name_to_id`, lib.rs:136-140)."""

@@ -7,8 +7,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libherro_amd.so")
-HIP_SOURCES = ["pileup.hip", "model.hip", "model_h.hip", "cigar_dev.hip", "herro_api.hip", "ingest.cpp", "fastx.cpp", "pool.cpp"]
-HEADERS = ["herro_amd.map", "host_cpus.h", "job_dev.h", "model_dev.h", "pileup_core.h", "windowing.hpp", "cigar_dev.h", os.path.join("..", "..", "include", "herro_amd.h")]
+HIP_SOURCES = ["pileup.hip", "model.hip", "model_h.hip", "cigar_dev.hip", "build_dev.hip", "herro_api.hip", "ingest.cpp", "fastx.cpp", "pool.cpp"]
+HEADERS = ["herro_amd.map", "host_cpus.h", "job_dev.h", "model_dev.h", "pileup_core.h", "windowing.hpp", "cigar_dev.h", "build_dev.h", os.path.join("..", "..", "include", "herro_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
          "-fno-gpu-rdc", "-Wl,--version-script=" + os.path.join(CSRC, "herro_amd.map")]   # exports: the C ABI (herro_*) only
 

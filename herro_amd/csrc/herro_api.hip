@@ -23,6 +23,7 @@
 #include "job_dev.h"
 #include "model_dev.h"
 #include "windowing.hpp"
+#include "build_dev.h"
 #include "cigar_dev.h"
 
 using namespace herro;
@@ -187,6 +188,7 @@ struct herro_ctx {
   hipEvent_t prep_ev = nullptr;
   unsigned long long* d_prof = nullptr;                // HERRO_PROF_BUILD + HERRO_PROF=1: per-kernel phase cycles (job_dev.h PROF_MARK), printed by herro_destroy
   bool dev_scan = true;                                // HERRO_HOST_SCAN=1: decode the text on the host instead (A/B, debugging)
+  bool dev_build = true;                               // windows and descriptors on the device behind the scan (build_dev.hip); herro_debug_set_host_build(ctx, 1): by the host from the cut records, as until round 5
   std::vector<Arena> free_dev, free_pin, free_small;   // free_small: the buffers a job needs only once its counts are known (logits, batch descriptors)
   std::atomic<uint32_t> live_jobs{0};   // herro_job_create may run on another thread than the context's execution calls
   uint64_t reads_gen = 0;   // bumped by herro_set_reads: a job built on an older store refuses to run
@@ -237,6 +239,9 @@ struct herro_job {
   Arena scan{};                    // device: the op array written by the CIGAR scan (+ the staged text it was read from)
   uint64_t scan_ops = 0;           // slots in it
   std::vector<uint32_t> dbg_ops;   // herro_debug_job_array(ops) of such a job: fetched on demand
+  bool dev_built = false;          // windows and descriptors were built on the device (build_dev.hip): the overlap descriptors and the tile list exist there only
+  std::vector<OwDesc> dbg_ow;      // ... and come down for herro_debug_job_array
+  std::vector<uint32_t> dbg_tw, dbg_tr;
   uint64_t reads_gen = 0;
   uint32_t n_skipped_alns = 0, n_failed_targets = 0;  // inputs the library does not support, left out (herro_job_skipped)
   std::string first_skip;
@@ -1323,6 +1328,14 @@ int herro_precision(const herro_ctx* ctx) { return ctx ? ctx->precision : HERRO_
 
 float herro_calibration_error(const herro_ctx* ctx, int mode) { return (ctx && mode >= 4 && mode <= 8) ? ctx->calib[mode] : -1.f; }
 
+int herro_debug_set_host_build(herro_ctx* ctx, int on) {
+  if (!ctx) return HERRO_E_INVALID;
+  ctx->dev_build = on == 0;
+  return HERRO_OK;
+}
+
+int herro_debug_job_dev_built(const herro_job* job) { return job ? (job->dev_built ? 1 : 0) : HERRO_E_INVALID; }
+
 int herro_debug_force_precision(herro_ctx* ctx, int on) {
   if (!ctx) return HERRO_E_INVALID;
   ctx->debug_force_precision = on != 0;
@@ -1652,6 +1665,15 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   const DevScanView* ds = nullptr;
   const uint64_t a0 = n_targets ? aln_off[0] : 0, nA = n_targets ? aln_off[n_targets] - a0 : 0;
   auto t_scanned = t_begin;
+  bool try_dev = false, dev_built = false;
+  std::vector<TgtMeta> tmeta;
+  std::vector<AlnMeta> ameta;
+  std::vector<uint64_t> pre_cls;
+  std::vector<uint32_t> pre_skip;
+  std::vector<std::string> pre_first;
+  uint32_t pre_nwin = 0, pre_ncls = 0;
+  BuildDev BD{};
+  BuildTotals btot{};
   if (!ctx->host_only && ctx->dev_scan && nA) {
     if (!alns) return fail(HERRO_E_INVALID, "null argument");
     if (nA > 0x7fffffffull) return fail(HERRO_E_UNSUPPORTED, "job too large (alignments)");
@@ -1674,6 +1696,72 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
       }
     }
     if (opn > 0xffffffffull || cutn > 0xffffffffull) return fail(HERRO_E_UNSUPPORTED, "job too large (ops exceed 2^32)");
+    // ---- device build (round 6): what needs no CIGAR is settled here — who is left out (parse_paf's rules), the ratio classes, the windows of every target —
+    // and goes up beside the text; anything this pass would have to report sends the job down the host path below, which words it.
+    try_dev = ctx->dev_build;
+    if (try_dev) {
+      tmeta.resize(n_targets);
+      ameta.resize(nA);
+      uint64_t nwin = 0, ncls = 0;
+      for (uint32_t t = 0; t < n_targets && try_dev; t++) {
+        const uint32_t rid = rids[t];
+        if (rid >= ctx->n_reads) { try_dev = false; break; }
+        const uint32_t tlen = ctx->read_len[rid], nwt = (tlen + W - 1) / W;
+        if (nwt > 65535) { try_dev = false; break; }
+        tmeta[t] = TgtMeta{rid, tlen, nwt, (uint32_t)nwin, (uint32_t)(aln_off[t] - a0), (uint32_t)(aln_off[t + 1] - aln_off[t]), 0, 0};
+        job->tgt_win_off[t] = (uint32_t)nwin;
+        nwin += nwt;
+      }
+      if (nwin > 0xffffffffull || nwin == 0) try_dev = false;
+      if (try_dev) {
+        job->tgt_win_off[n_targets] = (uint32_t)nwin;
+        pre_cls.assign(n_targets + 1, 0);
+        pre_skip.assign(n_targets, 0);
+        pre_first.assign(n_targets, std::string());
+        std::atomic<bool> ok{true};
+        hpool.run(n_targets, [&](uint32_t t) {
+          const TgtMeta& tm_ = tmeta[t];
+          std::unordered_map<uint32_t, uint32_t> cls_of_name;
+          std::unordered_map<uint32_t, uint32_t> seen_qid;
+          uint32_t ncl = 0;
+          for (uint32_t a = 0; a < tm_.n_aln; a++) {
+            const herro_alignment& al = alns[a0 + tm_.aln0 + a];
+            AlnMeta& m = ameta[tm_.aln0 + a];
+            m = AlnMeta{al.qid, al.qstart, al.qend, al.tstart, al.tend, al.strand ? 1u : 0u, t, 0};
+            if (al.tid != tm_.rid || al.qid >= ctx->n_reads) { ok = false; return; }
+            const char* why = nullptr;
+            if (al.qid == tm_.rid) why = "self overlap (dropped by parse_paf, overlaps.rs:175-179)";
+            else if (seen_qid.count(al.qid)) why = "second alignment of the same (query,target) pair (dropped by parse_paf, overlaps.rs:181-185)";
+            if (why) {
+              m.flags |= 2u;
+              if (!pre_skip[t]++) pre_first[t] = "target rid " + std::to_string(tm_.rid) + ", alignment " + std::to_string(a) + " (qid " + std::to_string(al.qid) + "): " + why;
+              continue;
+            }
+            seen_qid[al.qid] = a;
+            if (al.tlen != tm_.tlen || al.qend > ctx->read_len[al.qid] || al.tend > tm_.tlen) { ok = false; return; }
+            const uint32_t nc = ctx->name_class[al.qid];
+            auto it = cls_of_name.find(nc);
+            if (it == cls_of_name.end()) it = cls_of_name.emplace(nc, ncl++).first;
+            m.cls = it->second;   // target-local; the job-level base is added below
+          }
+          pre_cls[t + 1] = ncl;
+        });
+        if (!ok) try_dev = false;
+        else {
+          for (uint32_t t = 0; t < n_targets; t++) pre_cls[t + 1] += pre_cls[t];
+          ncls = pre_cls[n_targets];
+          if (ncls > 0xffffffffull) try_dev = false;
+        }
+        if (try_dev) {
+          hpool.run(n_targets, [&](uint32_t t) {
+            const TgtMeta& tm_ = tmeta[t];
+            for (uint32_t a = 0; a < tm_.n_aln; a++) ameta[tm_.aln0 + a].cls += (uint32_t)pre_cls[t];
+          });
+          pre_nwin = (uint32_t)nwin;
+          pre_ncls = (uint32_t)ncls;
+        }
+      }
+    }
     // Zero-copy (round 5): when the texts lie densely inside a range the caller registered (herro_host_register: the PAF text of
     // herro_paf_parse_view, a CIGAR blob), that range goes up in ONE copy from where it is — no staging pass over the bytes (0.9 of the
     // 3.4 ms an unloaded herro_job_create of 4096 windows took, and the part that fights the other feeders for memory bandwidth).  A
@@ -1692,11 +1780,19 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
       txt = (lead + span + 31) & ~uint64_t(15);
       g_zero_copy_jobs++;
     }
-    const uint64_t o_in = up256(txt + 16), o_out = o_in + up256(nA * sizeof(CigIn)), o_cut = o_out + up256(nA * sizeof(CigOut));
-    const uint64_t blk_bytes = o_cut + cutn * sizeof(CigCut), ops_bytes = up256(opn * 4);
+    // block layout: [text][CigIn][AlnMeta][TgtMeta][window -> target]  (host -> device, one copy)  |  [CigOut][cuts][totals]  (device -> host when the host builds)
+    //               |  [AlnHead][HowRec][WinAcc][window prefixes]  (device only)
+    const uint64_t o_in = up256(txt + 16), o_am = o_in + up256(nA * sizeof(CigIn)), o_tm = o_am + (try_dev ? up256(nA * sizeof(AlnMeta)) : 0);
+    const uint64_t o_wt = o_tm + (try_dev ? up256((uint64_t)n_targets * sizeof(TgtMeta)) : 0), o_out = o_wt + (try_dev ? up256((uint64_t)pre_nwin * 4) : 0);
+    const uint64_t o_cut = o_out + up256(nA * sizeof(CigOut)), o_tot = o_cut + up256(cutn * sizeof(CigCut));
+    const uint64_t blk_bytes = o_tot + 256;   // what the pinned staging block mirrors
+    const uint64_t o_head = blk_bytes, o_how = o_head + (try_dev ? up256(nA * sizeof(AlnHead)) : 0), o_wacc = o_how + (try_dev ? up256(cutn * sizeof(HowRec)) : 0);
+    const uint64_t o_pfx = o_wacc + (try_dev ? up256((uint64_t)pre_nwin * sizeof(WinAcc)) : 0);
+    const uint64_t pfx_each = up256(((uint64_t)pre_nwin + 1) * 8);
+    const uint64_t dev_blk_bytes = o_pfx + (try_dev ? 4 * pfx_each : 0), ops_bytes = up256(opn * 4);
     stage = arena_acquire(ctx, ctx->free_stage, blk_bytes, 0);
-    job->scan = arena_acquire(ctx, ctx->free_scan, ops_bytes + blk_bytes, 1);
-    if (!stage.p || !job->scan.p) return fail(HERRO_E_NO_DEVICE, "out of memory for the CIGAR scan (" + std::to_string((ops_bytes + blk_bytes) >> 20) + " MiB)");
+    job->scan = arena_acquire(ctx, ctx->free_scan, ops_bytes + dev_blk_bytes, 1);
+    if (!stage.p || !job->scan.p) return fail(HERRO_E_NO_DEVICE, "out of memory for the CIGAR scan (" + std::to_string((ops_bytes + dev_blk_bytes) >> 20) + " MiB)");
     unsigned char* hs = (unsigned char*)stage.p;
     unsigned char* dsb = (unsigned char*)job->scan.p + ops_bytes;
     const uint32_t per = 32, nblk = (uint32_t)((nA + per - 1) / per);
@@ -1709,6 +1805,13 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
       }
     });
     std::memcpy(hs + o_in, in.data(), nA * sizeof(CigIn));
+    if (try_dev) {
+      std::memcpy(hs + o_am, ameta.data(), nA * sizeof(AlnMeta));
+      std::memcpy(hs + o_tm, tmeta.data(), (size_t)n_targets * sizeof(TgtMeta));
+      uint32_t* wt = (uint32_t*)(hs + o_wt);
+      hpool.run(n_targets, [&](uint32_t t) { for (uint32_t w = 0; w < tmeta[t].n_windows; w++) wt[tmeta[t].win0 + w] = t; });
+      std::memset(hs + o_tot, 0, sizeof(BuildTotals));
+    }
     const auto t_staged = tnow();
     hipEvent_t pe[4] = {nullptr, nullptr, nullptr, nullptr};   // HERRO_HOST_PROFILE: copy up / kernel / copy down on the device clock
     if (prof) for (auto& ev : pe) (void)hipEventCreate(&ev);
@@ -1716,25 +1819,47 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
     hipError_t e;
     if (direct) {   // the texts from the caller's registered range (same alignment modulo 16), the alignment records from the staging block
       e = hipMemcpyAsync(dsb + lead, t_lo, span, hipMemcpyHostToDevice, ctx->prep_stream);
-      if (e == hipSuccess) e = hipMemcpyAsync(dsb + o_in, hs + o_in, nA * sizeof(CigIn), hipMemcpyHostToDevice, ctx->prep_stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(dsb + o_in, hs + o_in, o_out - o_in, hipMemcpyHostToDevice, ctx->prep_stream);
     } else {
-      e = hipMemcpyAsync(dsb, hs, o_in + nA * sizeof(CigIn), hipMemcpyHostToDevice, ctx->prep_stream);
+      e = hipMemcpyAsync(dsb, hs, o_out, hipMemcpyHostToDevice, ctx->prep_stream);
     }
+    if (try_dev && e == hipSuccess) e = hipMemcpyAsync(dsb + o_tot, hs + o_tot, sizeof(BuildTotals), hipMemcpyHostToDevice, ctx->prep_stream);
     if (pe[1]) (void)hipEventRecord(pe[1], ctx->prep_stream);
     if (e == hipSuccess) {
       launch_cigar_scan(dsb, (const CigIn*)(dsb + o_in), (CigOut*)(dsb + o_out), (CigCut*)(dsb + o_cut), (uint32_t*)job->scan.p, (uint32_t)nA, W, ctx->prep_stream);
       e = hipGetLastError();
     }
     if (pe[2]) (void)hipEventRecord(pe[2], ctx->prep_stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(hs + o_out, dsb + o_out, blk_bytes - o_out, hipMemcpyDeviceToHost, ctx->prep_stream);
-    if (pe[3]) (void)hipEventRecord(pe[3], ctx->prep_stream);
-    if (e == hipSuccess) e = hipEventRecord(ctx->prep_ev, ctx->prep_stream);
-    if (e == hipSuccess) e = hipEventSynchronize(ctx->prep_ev);
+    if (try_dev && e == hipSuccess) {   // windows and counts behind the scan; 64 bytes of totals come down instead of the cut records
+      BD.in = (const CigIn*)(dsb + o_in); BD.out = (const CigOut*)(dsb + o_out); BD.cuts = (CigCut*)(dsb + o_cut);
+      BD.am = (const AlnMeta*)(dsb + o_am); BD.tm = (const TgtMeta*)(dsb + o_tm); BD.win_tgt = (const uint32_t*)(dsb + o_wt);
+      BD.head = (AlnHead*)(dsb + o_head); BD.how = (HowRec*)(dsb + o_how); BD.wacc = (WinAcc*)(dsb + o_wacc); BD.tot = (BuildTotals*)(dsb + o_tot);
+      BD.n_aln = (uint32_t)nA; BD.n_tgt = n_targets; BD.n_win = pre_nwin; BD.W = W;
+      BD.read_word_off = ctx->d_word_off; BD.read_qual_off = ctx->d_qual_off;
+      uint32_t* p_owb = (uint32_t*)(dsb + o_pfx);
+      uint64_t *p_ev = (uint64_t*)(dsb + o_pfx + pfx_each), *p_tile = (uint64_t*)(dsb + o_pfx + 2 * pfx_each), *p_row = (uint64_t*)(dsb + o_pfx + 3 * pfx_each);
+      BD.ow_begin = p_owb; BD.ev_off = p_ev; BD.tile_off = p_tile; BD.row_off = p_row;
+      launch_build_phase1(BD, p_owb, p_ev, p_tile, p_row, ctx->prep_stream);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipMemcpyAsync(hs + o_tot, dsb + o_tot, sizeof(BuildTotals), hipMemcpyDeviceToHost, ctx->prep_stream);
+      if (e == hipSuccess) e = hipEventRecord(ctx->prep_ev, ctx->prep_stream);
+      if (e == hipSuccess) e = hipEventSynchronize(ctx->prep_ev);
+      if (e == hipSuccess) {
+        std::memcpy(&btot, hs + o_tot, sizeof btot);
+        dev_built = btot.err == 0;
+      }
+    }
+    if (!dev_built) {   // the host cuts the windows from the scan's records (and words whatever is wrong with the input)
+      if (e == hipSuccess) e = hipMemcpyAsync(hs + o_out, dsb + o_out, o_tot - o_out, hipMemcpyDeviceToHost, ctx->prep_stream);
+      if (pe[3]) (void)hipEventRecord(pe[3], ctx->prep_stream);
+      if (e == hipSuccess) e = hipEventRecord(ctx->prep_ev, ctx->prep_stream);
+      if (e == hipSuccess) e = hipEventSynchronize(ctx->prep_ev);
+    } else if (pe[3]) (void)hipEventRecord(pe[3], ctx->prep_stream);
     if (prof && e == hipSuccess) {
       float up = 0, kn = 0, dn = 0;
       (void)hipEventElapsedTime(&up, pe[0], pe[1]); (void)hipEventElapsedTime(&kn, pe[1], pe[2]); (void)hipEventElapsedTime(&dn, pe[2], pe[3]);
       fprintf(stderr, "  cigar scan: %.1f MiB text staged in %.2f ms; device: copy up %.2f ms, kernel %.2f, copy down %.2f (%.1f MiB); wall %.2f ms\n", txt / 1048576.0,
-              std::chrono::duration<double, std::milli>(t_staged - t_begin).count(), up, kn, dn, (blk_bytes - o_out) / 1048576.0,
+              std::chrono::duration<double, std::milli>(t_staged - t_begin).count(), up, kn, dn, (dev_built ? 64.0 : (double)(o_tot - o_out)) / 1048576.0,
               std::chrono::duration<double, std::milli>(tnow() - t_staged).count());
     }
     for (auto& ev : pe) if (ev) (void)hipEventDestroy(ev);
@@ -1747,8 +1872,8 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
     job->scan_ops = opn;
     t_scanned = tnow();
   }
-  std::vector<TargetOut> outs(n_targets);
-  hpool.run(n_targets, [&](uint32_t t) {
+  std::vector<TargetOut> outs(dev_built ? 0 : n_targets);
+  if (!dev_built) hpool.run(n_targets, [&](uint32_t t) {
     build_target(ctx, rids[t], alns + aln_off[t], (uint32_t)(aln_off[t + 1] - aln_off[t]), W, outs[t], ds, aln_off[t] - a0);
   });
   auto t_built = tnow();
@@ -1759,7 +1884,17 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   std::vector<Base> base(n_targets + 1);
   uint32_t n_cls = 0, max_cols = 1;
   uint64_t scr_ops = 0, fin_bytes = 0, row_elems = 0, pos_elems = 0;
-  {
+  if (dev_built) {   // the device's totals (build_dev.hip) stand in for the sums over the per-target outputs
+    Base b{0, btot.n_ow, pre_nwin, btot.n_tiles, pre_ncls, btot.scr_ops, btot.fin_bytes, btot.row_elems, (uint64_t)pre_nwin * ((uint64_t)W + 1)};
+    base[n_targets] = b;
+    n_cls = pre_ncls; max_cols = btot.max_cols; scr_ops = btot.scr_ops; fin_bytes = btot.fin_bytes; row_elems = btot.row_elems; pos_elems = b.pos;
+    job->alg_read_bytes = btot.rd_bytes; job->alg_op_bytes = btot.op_bytes;
+    for (uint32_t t = 0; t < n_targets; t++)
+      if (pre_skip[t]) {
+        if (!job->n_skipped_alns) job->first_skip = pre_first[t];
+        job->n_skipped_alns += pre_skip[t];
+      }
+  } else {
     Base b{0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t t = 0; t < n_targets; t++) {
       const TargetOut& o = outs[t];
@@ -1814,7 +1949,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
     job->h_cons_len = (uint32_t*)(hb + o_hclen);
     job->h_cons_seq = hb + o_hcseq;
   }
-  hpool.run(n_targets, [&](uint32_t t) {
+  if (!dev_built) hpool.run(n_targets, [&](uint32_t t) {
     TargetOut& o = outs[t];
     const Base& b = base[t];
     if (!o.ops.empty()) std::memcpy(job->ops.data() + b.op, o.ops.data(), o.ops.size() * 4);
@@ -1900,9 +2035,23 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.sup_row = (uint32_t*)(db + o_srow); J.sup_pi = (uint32_t*)(db + o_spi);
   J.fin_b = (uint8_t*)(db + o_finb); J.fin_q = (uint8_t*)(db + o_finq); J.nd = (uint32_t*)(db + o_nd);
   J.vpl = (uint32_t*)(db + o_vpl); J.sup_nr = (uint32_t*)(db + o_snr);
-  // one copy, pinned -> device, asynchronous on the context stream: the kernels of herro_job_featurize queue behind it
-  // in stream order, nobody waits here
-  hipError_t e = hipMemcpyAsync(db, job->pin.p, desc_bytes, hipMemcpyHostToDevice, ctx->stream);
+  hipError_t e;
+  if (dev_built) {
+    // the descriptors are written where they are read (build_dev.hip, behind the scan on the prep stream); the window descriptors come down — the host hands
+    // windows out by them — and the context's stream waits for the event, so the kernels of herro_job_featurize queue behind the build in stream order
+    BD.ow = (OwDesc*)(db + o_ow); BD.win = (WinDesc*)(db + o_win); BD.tile_win = (uint32_t*)(db + o_tw); BD.tile_r0 = (uint32_t*)(db + o_tr);
+    launch_build_phase2(BD, ctx->prep_stream);
+    e = hipGetLastError();
+    if (e == hipSuccess && n_win) e = hipMemcpyAsync(job->win.data(), db + o_win, (size_t)n_win * sizeof(WinDesc), hipMemcpyDeviceToHost, ctx->prep_stream);
+    if (e == hipSuccess) e = hipEventRecord(ctx->prep_ev, ctx->prep_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->prep_ev, 0);
+    if (e == hipSuccess) e = hipEventSynchronize(ctx->prep_ev);
+    job->dev_built = true;
+  } else {
+    // one copy, pinned -> device, asynchronous on the context stream: the kernels of herro_job_featurize queue behind it
+    // in stream order, nobody waits here
+    e = hipMemcpyAsync(db, job->pin.p, desc_bytes, hipMemcpyHostToDevice, ctx->stream);
+  }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&job->ev_counts, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&job->ev_blob, hipEventDisableTiming);
   if (e != hipSuccess) {
@@ -2882,10 +3031,31 @@ int64_t herro_debug_job_array(herro_job* job, int which, const void** ptr, uint3
       }
       *ptr = job->ops.data();
       return (int64_t)job->ops.size();
-    case 1: *ptr = job->ow.data(); *elem_bytes = sizeof(OwDesc); return (int64_t)job->ow.size();
+    case 1:
+      *elem_bytes = sizeof(OwDesc);
+      if (job->dev_built) {
+        job->dbg_ow.resize(job->J.n_ow);
+        if (hipSetDevice(job->ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            (job->J.n_ow && hipMemcpy(job->dbg_ow.data(), job->J.ow, (size_t)job->J.n_ow * sizeof(OwDesc), hipMemcpyDeviceToHost) != hipSuccess)) return HERRO_E_NO_DEVICE;
+        *ptr = job->dbg_ow.data();
+        return (int64_t)job->dbg_ow.size();
+      }
+      *ptr = job->ow.data();
+      return (int64_t)job->ow.size();
     case 2: *ptr = job->win.data(); *elem_bytes = sizeof(WinDesc); return (int64_t)job->win.size();
-    case 3: *ptr = job->tile_win.data(); *elem_bytes = 4; return (int64_t)job->tile_win.size();
-    case 4: *ptr = job->tile_r0.data(); *elem_bytes = 4; return (int64_t)job->tile_r0.size();
+    case 3:
+    case 4:
+      *elem_bytes = 4;
+      if (job->dev_built) {
+        std::vector<uint32_t>& v = which == 3 ? job->dbg_tw : job->dbg_tr;
+        v.resize(job->J.n_tiles);
+        if (hipSetDevice(job->ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            (job->J.n_tiles && hipMemcpy(v.data(), which == 3 ? job->J.tile_win : job->J.tile_r0, (size_t)job->J.n_tiles * 4, hipMemcpyDeviceToHost) != hipSuccess)) return HERRO_E_NO_DEVICE;
+        *ptr = v.data();
+        return (int64_t)v.size();
+      }
+      *ptr = which == 3 ? job->tile_win.data() : job->tile_r0.data();
+      return (int64_t)(which == 3 ? job->tile_win.size() : job->tile_r0.size());
     case 5: *ptr = job->tgt_win_off.data(); *elem_bytes = 4; return (int64_t)job->tgt_win_off.size();
     default: return HERRO_E_INVALID;
   }

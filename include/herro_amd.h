@@ -265,6 +265,12 @@ int64_t herro_debug_job_array(herro_job* job, int which, const void** ptr, uint3
  * by tests/test_gpu_lean.py.  herro_debug_job_rf copies the 16-byte receptive-field records of window w (after herro_job_infer:
  * n_supported x 31 records, bytes 0..7 tokens / 8..15 qualities of rows sup_row - half .. ) and returns their number (<0: error). */
 int herro_debug_set_featurize_planes(herro_ctx* ctx, int on);
+/* Test hooks for the two ways a job's windows and descriptors are built (herro_job_create): on the device behind the CIGAR scan (csrc/build_dev.hip, the
+ * default since round 6) or by the host from the scan's cut records (rounds 3-5; still what runs when the device meets anything it does not settle itself —
+ * a text the scan kernel flags, an input the reference panics on — and what words the error).  herro_debug_set_host_build(ctx, 1) selects the host build for
+ * the jobs created from then on; herro_debug_job_dev_built says which one built a job.  tests/test_gpu_build_dev.py compares their descriptor arrays. */
+int herro_debug_set_host_build(herro_ctx* ctx, int on);
+int herro_debug_job_dev_built(const herro_job* job);
 /* Host-only test hooks for the rules k_rows applies in position space (csrc/pileup_core.h): n count vectors counts[i][5] (A C G T * on a base row, the
  * target's base included; split[i][5] of them, or NULL, go through a second counter set that is merged in) with target[i] in 0..3 -> sup[i] (informative:
  * two symbols reach 3, features.rs:558,712) and vote[i] (consensus.rs:178-200; meaningful where sup[i] == 0); herro_debug_vote5: the vote on exact counts. */
