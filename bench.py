@@ -543,8 +543,9 @@ def main():
                "windows": n_w * world, "usable_cpus": synth.usable_cpus(), "jobs_per_feeder": per, "feeders_per_gpu": NF, "warmup_jobs_per_feeder": n_warm,
                "host_prepare_windows_per_s_per_feeder": n_w / NF / (host_s / NF) if host_s else None,
                "zero_copy_text": os.environ.get("HERRO_ZERO_COPY", "1") not in ("", "0"),
-               "note": "herro_job_create from host alignments (CIGAR text copied up from the registered blob and scanned on the GPU, windows cut on the context's thread pool, "
-                       "one pinned descriptor block, one async H2D) + featurize + infer + consensus + D2H of the corrected bases, all inside the timed region; "
+               "note": "herro_job_create from host alignments (CIGAR text copied up from the registered blob and scanned on the GPU, windows cut and descriptors written "
+                       "on the device behind the scan — build_dev.hip, round 6; 64 bytes of totals and the window descriptors come back) + featurize + infer + consensus + "
+                       "D2H of the corrected bases, all inside the timed region; "
                        "fresh inputs per job; the alignments are resident on the host as one parsed array (what the reference's reader thread "
                        "hands over, lib.rs:141-151); " + ("per context one thread builds jobs ahead, one executes them" if args.e2e_mode == "producer"
                                                      else "one feeder thread per context: create(k+1) runs on the host while the GPU works on job k"),

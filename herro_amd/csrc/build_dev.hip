@@ -126,7 +126,8 @@ __global__ __launch_bounds__(1024) void k_scan_alns(BuildDev B) {
   const uint32_t tid = threadIdx.x, n = B.n_aln, per = (n + 1023) / 1024;
   const uint32_t a0 = min(tid * per, n), a1 = min(a0 + per, n);
   uint64_t local = 0;
-  for (uint32_t a = a0; a < a1; a++) local += B.head[a].op_sum;
+#pragma unroll 8
+  for (uint32_t a = a0; a < a1; a++) local += B.head[a].op_sum;   // (independent loads: unrolled so that they are in flight together — one block, its latency is the job's)
   s_part[tid] = local;
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(1024) void k_scan_alns(BuildDev B) {
     __syncthreads();
   }
   uint64_t run = s_part[tid] - local;
+#pragma unroll 8
   for (uint32_t a = a0; a < a1; a++) {
     const uint32_t v = B.head[a].op_sum;
     B.head[a].scr_base = (uint32_t)run;
@@ -267,6 +269,7 @@ __global__ __launch_bounds__(1024) void k_scan_wins(BuildDev B, uint32_t* ow_beg
   const uint32_t w0 = min(tid * per, n), w1 = min(w0 + per, n);
   uint64_t l[4] = {0, 0, 0, 0}, rd = 0, opb = 0;
   uint32_t mx = 0;
+#pragma unroll 4
   for (uint32_t w = w0; w < w1; w++) {
     const WinAcc r = B.wacc[w];
     l[0] += r.ow_cnt; l[1] += r.ev; l[2] += (r.lub + HERRO_TILE - 1) / HERRO_TILE; l[3] += r.lub;

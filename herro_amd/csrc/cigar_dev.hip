@@ -7,11 +7,12 @@
 // alignment the totals and the few ops that reach a window boundary ("cuts", windowing.hpp) — and the host cuts windows
 // from those records without ever seeing an op (window_cuts).
 //
-// Per alignment, 256 threads sweep the text in chunks of 4096 bytes (16 per thread, one 16-byte load each):
-//   letters    bit 6 of a byte separates 'A'..'Z' from '0'..'9': a 16-bit letter mask per thread
+// Per alignment, ONE WAVE sweeps the text in steps of 1024 bytes (16 per lane, one 16-byte load each; round 6 — a workgroup of 256 threads per alignment
+// with block scans until round 5):
+//   letters    bit 6 of a byte separates 'A'..'Z' from '0'..'9': a 16-bit letter mask per lane
 //   scan 1     exclusive max over "position of my last letter": where the digits of my first op start
-//   pass 1     decode my ops (<= 8) from LDS: per-thread op count and target / query / insertion totals
-//   scan 2     exclusive sums of those four
+//   pass 1     decode my ops (<= 8) from the wave's LDS copy of the step: per-lane op count and target / query / insertion totals
+//   scan 2     exclusive sums of those four (DPP)
 //   pass 2     decode again, now with op index and running totals known: write the op, test for a window boundary
 // Malformed text (what CigarIter panics on, aligners.rs:252-293) only raises a flag; the host re-reads that one text
 // for the message.  Reference: extract_windows walks the same ops one by one on a feature thread (windowing.rs:44-273).
@@ -22,27 +23,37 @@
 namespace herro {
 namespace {
 
-constexpr uint32_t CT = 256;          // threads per alignment
-constexpr uint32_t CB = 16;           // text bytes per thread and chunk
-constexpr uint32_t CHUNK = CT * CB;
+constexpr uint32_t CW = 4;            // alignments (waves) per workgroup
+constexpr uint32_t CB = 16;           // text bytes per lane and step
+constexpr uint32_t CHUNK = 64 * CB;   // ... per wave and step
 
+// Wave scans on the DPP network (row_shr inside rows of 16 lanes, then the two row broadcasts): six vector instructions each.  The kernel's first version ran
+// five scans per chunk over __shfl_up — a round trip through the LDS crossbar per step, thirty dependent ones per chunk — inside a 256-thread workgroup per
+// alignment with three block barriers; the texts of the bench's alignments are 1.5 KB, 96 lanes' worth.  Round 6: one WAVE per alignment, no barrier.
 __device__ inline uint32_t wave_incl_sum(uint32_t v) {
-  const uint32_t lane = threadIdx.x & 63u;
-#pragma unroll
-  for (uint32_t d = 1; d < 64; d <<= 1) {
-    const uint32_t u = __shfl_up(v, d);
-    if (lane >= d) v += u;
-  }
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
   return v;
 }
-__device__ inline uint32_t wave_incl_max(uint32_t v) {
-  const uint32_t lane = threadIdx.x & 63u;
-#pragma unroll
-  for (uint32_t d = 1; d < 64; d <<= 1) {
-    const uint32_t u = __shfl_up(v, d);
-    if (lane >= d) v = max(v, u);
-  }
+__device__ inline uint32_t wave_incl_max(uint32_t v) {   // (values are >= 0: lanes a shift does not reach read 0)
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
   return v;
+}
+__device__ inline uint32_t lane63(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+// the wave reads back what its other lanes wrote to the LDS: LDS operations of one wave execute in order
+__device__ inline void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // letter flags of four text bytes as a 4-bit mask (bit 6 of each byte, gathered by one multiply)
@@ -69,46 +80,45 @@ __device__ inline Op decode(uint32_t p, uint32_t start, LB lb) {
   return r;
 }
 
-__global__ __launch_bounds__(CT) void k_cigar_scan(const uint8_t* __restrict__ txt, const CigIn* __restrict__ in, CigOut* __restrict__ out,
-                                                   CigCut* __restrict__ cuts, uint32_t* __restrict__ ops, uint32_t W) {
-  __shared__ uint4 s_txt[1 + CT];      // [0]: the 16 bytes in front of the chunk; [1 + t]: thread t's bytes
-  __shared__ uint32_t s_w[5][4];       // wave totals of the block scans
-  __shared__ uint32_t s_ncut, s_flags;
-  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-  const CigIn a = in[blockIdx.x];
+__global__ __launch_bounds__(CW * 64) void k_cigar_scan(const uint8_t* __restrict__ txt, const CigIn* __restrict__ in, CigOut* __restrict__ out,
+                                                        CigCut* __restrict__ cuts, uint32_t* __restrict__ ops, uint32_t W, uint32_t n_aln) {
+  __shared__ uint4 s_txt_all[CW][1 + 64];   // per wave: [0] the 16 bytes in front of the step's text, [1 + l] lane l's bytes
+  __shared__ uint32_t s_nc[CW], s_fl[CW];
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const uint32_t ai = blockIdx.x * CW + wv;
+  if (ai >= n_aln) return;   // (wave-uniform; no block barrier anywhere below)
+  uint4* s_txt = s_txt_all[wv];
+  const CigIn a = in[ai];
   const uint8_t* s = txt + a.txt_off;
   uint32_t* o = ops + a.op_off;
   CigCut* cut = cuts + a.cut_off;
   // positions count from the aligned 16 bytes the text starts in: `skip` bytes in front of it belong to whatever lies there in the caller's
   // buffer (the zero-copy path of herro_job_create copies a range of the caller's memory as it is) and are masked out
   const uint32_t skip = a.skip & 15u, len = a.len + skip, room = a.len / 2 + 1;
-  if (tid == 0) { s_txt[0] = make_uint4(0, 0, 0, 0); s_ncut = 0; s_flags = 0; }
+  if (lane == 0) { s_txt[0] = make_uint4(0, 0, 0, 0); s_nc[wv] = 0; s_fl[wv] = 0; }
   uint32_t k_c = 0, t_c = a.tstart, q_c = 0, i_c = 0, prev1_c = skip;   // carries: ops so far, running totals, position + 1 of the last letter (the first op's digits start at `skip`)
   uint32_t flags = 0;
   for (uint32_t base = 0; base < len; base += CHUNK) {
-    const uint32_t my = base + tid * CB;
+    const uint32_t my = base + lane * CB;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (my < len) v = *reinterpret_cast<const uint4*>(s + my);
-    s_txt[1 + tid] = v;
-    __syncthreads();
+    s_txt[1 + lane] = v;
+    wave_lds_sync();
     auto lb = [&](uint32_t pos) -> uint32_t { return reinterpret_cast<const uint8_t*>(s_txt)[16u + pos - base]; };   // pos >= base - 16 (wraps correctly in u32)
     uint32_t mask = letter_nibble(v.x) | letter_nibble(v.y) << 4 | letter_nibble(v.z) << 8 | letter_nibble(v.w) << 12;
     const uint32_t nvalid = my < len ? min(CB, len - my) : 0u;
     mask &= (1u << nvalid) - 1u;
-    if (my < skip) mask &= ~((1u << (skip - my)) - 1u);   // (thread 0 of the first chunk)
+    if (my < skip) mask &= ~((1u << (skip - my)) - 1u);   // (lane 0 of the first step)
     const uint32_t cnt = __popc(mask);
     const uint32_t last1 = mask ? my + (31u - __clz(mask)) + 1u : 0u;
     // ---- scan 1: position + 1 of the last letter in front of my bytes
-    uint32_t mx = wave_incl_max(last1);
-    if (lane == 63) s_w[4][wave] = mx;
-    __syncthreads();
+    const uint32_t mx = wave_incl_max(last1);
     uint32_t prev1 = prev1_c;
-    for (uint32_t w = 0; w < wave; w++) prev1 = max(prev1, s_w[4][w]);
     {
-      const uint32_t up = __shfl_up(mx, 1);
+      const uint32_t up = __builtin_amdgcn_update_dpp(0, (int)mx, 0x138, 0xf, 0xf, false);   // wave_shr:1
       if (lane) prev1 = max(prev1, up);
     }
-    const uint32_t chunk_last1 = max(max(s_w[4][0], s_w[4][1]), max(s_w[4][2], s_w[4][3]));
+    const uint32_t chunk_last1 = lane63(mx);
     // ---- pass 1: my totals
     uint32_t st = 0, sq = 0, si = 0;
     {
@@ -127,14 +137,7 @@ __global__ __launch_bounds__(CT) void k_cigar_scan(const uint8_t* __restrict__ t
     }
     // ---- scan 2: op index and running totals in front of my first op
     const uint32_t in_n = wave_incl_sum(cnt), in_t = wave_incl_sum(st), in_q = wave_incl_sum(sq), in_i = wave_incl_sum(si);
-    if (lane == 63) { s_w[0][wave] = in_n; s_w[1][wave] = in_t; s_w[2][wave] = in_q; s_w[3][wave] = in_i; }
-    __syncthreads();
     uint32_t k = k_c + in_n - cnt, t = t_c + in_t - st, q = q_c + in_q - sq, ins = i_c + in_i - si;
-    uint32_t tot_n = 0, tot_t = 0, tot_q = 0, tot_i = 0;
-    for (uint32_t w = 0; w < 4; w++) {
-      if (w < wave) { k += s_w[0][w]; t += s_w[1][w]; q += s_w[2][w]; ins += s_w[3][w]; }
-      tot_n += s_w[0][w]; tot_t += s_w[1][w]; tot_q += s_w[2][w]; tot_i += s_w[3][w];
-    }
     // ---- pass 2: emit
     if (mask) {
       unsigned long long wnext = ((unsigned long long)(t / W) + 1ull) * W;   // first window boundary above my running target position
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(CT) void k_cigar_scan(const uint8_t* __restrict__ t
         if (is_i & prev_i) flags |= CIG_INS_PAIR;
         const uint32_t tnew = t + (is_i ? 0u : l);
         if (!is_i && (unsigned long long)tnew >= wnext) {
-          const uint32_t slot = atomicAdd(&s_ncut, 1u);
+          const uint32_t slot = atomicAdd(&s_nc[wv], 1u);
           if (slot < a.cut_cap) {
             CigCut c{k, t, q, ins, r.op, 0, 0, 0};
             cut[slot] = c;
@@ -168,38 +171,35 @@ __global__ __launch_bounds__(CT) void k_cigar_scan(const uint8_t* __restrict__ t
         start = p + 1;
       }
     }
-    k_c += tot_n; t_c += tot_t; q_c += tot_q; i_c += tot_i;
+    k_c += lane63(in_n); t_c += lane63(in_t); q_c += lane63(in_q); i_c += lane63(in_i);
     prev1_c = max(prev1_c, chunk_last1);
-    __syncthreads();   // every read of this chunk's text and of the scan totals is done
-    if (tid == CT - 1) s_txt[0] = v;
+    // every read of this step's text is issued (LDS operations of a wave execute in order): the next step's halo goes in
+    if (lane == 63) s_txt[0] = v;
   }
   if (len && prev1_c != len) flags |= CIG_MALFORMED;   // text ends inside an op
-  if (flags) atomicOr(&s_flags, flags);
-  // Workgroup scope is all that is needed (the readers below are waves of this workgroup, behind the same L1), and all
-  // that is affordable: an agent-scope fence writes the XCD's whole L2 back on gfx950, once per wave — measured 8.5 ms
-  // per 4096 alignments instead of 0.1.
-  // Release by the writers, acquire by the readers, both at workgroup scope: what the memory model asks for whatever the
-  // workgroup's placement (threadgroup-split mode included); on gfx950 in the default mode neither costs an instruction
-  // beyond the barrier's own wait.
+  if (flags) atomicOr(&s_fl[wv], flags);
+  // The lanes read back ops and cuts their neighbours wrote to global memory.  Release by the writers, acquire by the readers, at workgroup scope
+  // (an agent-scope fence writes the XCD's whole L2 back on gfx950, once per wave — measured 8.5 ms per 4096 alignments instead of 0.1).
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   // ---- the two ops behind every cut, first / last op, totals
   const uint32_t n_ops = min(k_c, room);
   auto ld = [&](uint32_t idx) { return __hip_atomic_load(o + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); };
-  const uint32_t n_cut = min(s_ncut, a.cut_cap);
-  for (uint32_t c = tid; c < n_cut; c += CT) {
+  const uint32_t n_cut_all = __hip_atomic_load(&s_nc[wv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const uint32_t n_cut = min(n_cut_all, a.cut_cap);
+  for (uint32_t c = lane; c < n_cut; c += 64) {
     const uint32_t kk = __hip_atomic_load(&cut[c].k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
     cut[c].o1 = kk + 1 < n_ops ? ld(kk + 1) : 0u;
     cut[c].o2 = kk + 2 < n_ops ? ld(kk + 2) : 0u;
   }
-  if (tid == 0) {
+  if (lane == 0) {
     CigOut r;
     r.n_ops = n_ops; r.t_end = t_c; r.q_end = q_c; r.ins_end = i_c;
-    r.n_cuts = s_ncut; r.flags = s_flags;
+    r.n_cuts = n_cut_all; r.flags = __hip_atomic_load(&s_fl[wv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     r.op0 = n_ops ? ld(0) : 0u;
     r.opn = n_ops ? ld(n_ops - 1) : 0u;
-    out[blockIdx.x] = r;
+    out[ai] = r;
   }
 }
 
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(CT) void k_cigar_scan(const uint8_t* __restrict__ t
 void launch_cigar_scan(const uint8_t* d_txt, const CigIn* d_in, CigOut* d_out, CigCut* d_cuts, uint32_t* d_ops, uint32_t n_aln,
                        uint32_t W, hipStream_t st) {
   if (n_aln == 0) return;
-  hipLaunchKernelGGL(k_cigar_scan, dim3(n_aln), dim3(CT), 0, st, d_txt, d_in, d_out, d_cuts, d_ops, W);
+  hipLaunchKernelGGL(k_cigar_scan, dim3((n_aln + CW - 1) / CW), dim3(CW * 64), 0, st, d_txt, d_in, d_out, d_cuts, d_ops, W, n_aln);
 }
 
 }  // namespace herro

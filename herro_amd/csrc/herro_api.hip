@@ -652,6 +652,7 @@ herro_ctx* herro_create(int device_id) {
     }
 #endif
     ctx->dev_scan = ab_env("HERRO_HOST_SCAN", 0) == 0;
+    { const char* e = getenv("HERRO_HOST_BUILD"); ctx->dev_build = !(e && atoi(e)); }   // HERRO_HOST_BUILD=1: windows and descriptors by the host, as until round 5 (same results; for comparisons)
   }
   // ln(k+1) table from the host libm — what Rust's f64::ln calls on Linux (features.rs:507)
   std::vector<double> ln(1u << 20);
