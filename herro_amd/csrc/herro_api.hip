@@ -1052,7 +1052,7 @@ int herro_load_model(herro_ctx* ctx, const char* path) {
   }
   std::fclose(f);
   if (!ok) { ctx->err = "malformed model file"; return HERRO_E_NO_MODEL; }
-  if (h.rows != HERRO_ROWS || h.n_layers > 16 || (h.kw & 1) == 0 || h.d_model % 64 || h.d_model / h.n_heads != 32 || h.n_heads > 32 ||
+  if (h.rows != HERRO_ROWS || h.n_layers > 16 || (h.kw & 1) == 0 || h.d_model % 64 || h.n_heads == 0 || h.d_model % h.n_heads || (h.d_model / h.n_heads != 32 && h.d_model / h.n_heads != 64) || h.n_heads > 32 ||
       (h.kw * h.c1) % 32 || (h.rows * h.c2) % 32 || h.d_ff % 32 || h.c2 % 16) {
     ctx->err = "unsupported model hyper-parameters";
     return HERRO_E_UNSUPPORTED;
@@ -1193,7 +1193,20 @@ int herro_load_model(herro_ctx* ctx, const char* path) {
     M.layer[l].ff1 = weight(p + "ff1", D, h.d_ff);
     M.layer[l].ff2 = weight(p + "ff2", h.d_ff, D);
   }
-  M.lnf_g = vec("lnf.g", D); M.lnf_b = vec("lnf.b", D);
+  M.act = 0; M.norm_first = 1; M.pe_kind = 0; M.final_norm = 1; M.pe_learned = nullptr; M.pe_learned_rows = 0;
+  if (auto it = T.find("cfg"); it != T.end()) {   // a variant of the family (absent: the defaults)
+    const std::vector<float>& c = it->second.data;
+    if (c.size() < 4 || c[0] < 0 || c[0] > 2 || c[1] < 0 || c[1] > 1 || c[2] < 0 || c[2] > 2 || c[3] < 0 || c[3] > 1) { free_all(ctx->model_allocs); ctx->err = "model file: cfg tensor not understood"; return HERRO_E_UNSUPPORTED; }
+    M.act = (uint32_t)c[0]; M.norm_first = (uint32_t)c[1]; M.pe_kind = (uint32_t)c[2]; M.final_norm = (uint32_t)c[3];
+  }
+  if (M.pe_kind == 1) {
+    auto it = T.find("pe_table");
+    if (it == T.end() || it->second.dims.size() != 2 || it->second.dims[1] != D || it->second.dims[0] == 0) { free_all(ctx->model_allocs); ctx->err = "model file: learned position table missing / mis-shaped"; return HERRO_E_NO_MODEL; }
+    M.pe_learned = up_f32(ctx, it->second.data, e);
+    M.pe_learned_rows = it->second.dims[0];
+  }
+  if (M.final_norm) { M.lnf_g = vec("lnf.g", D); M.lnf_b = vec("lnf.b", D); }
+  else { M.lnf_g = nullptr; M.lnf_b = nullptr; }
   M.heads = weight("heads", D, 16);
   if (missing) { free_all(ctx->model_allocs); return HERRO_E_NO_MODEL; }
   HIP_TRY(ctx, e);
@@ -1280,6 +1293,18 @@ int64_t herro_model_describe(const herro_ctx* ctx, char* out, uint64_t cap) {
              h.rows, h.kw, h.c1, h.c2, h.d_model, h.n_heads, h.d_ff, h.n_layers, rf, per_tok, conv, fc, h.n_layers * layer, 15.0 * per_tok,
              (double)ctx->wmax, ctx->precision, ctx->calib_note.empty() ? "" : "; ", ctx->calib_note.c_str());
     t = buf;
+    {  // the variant of the family and the kernels that serve it
+      const ModelDev& M = ctx->M;
+      static const char* act_n[3] = {"ReLU", "GELU (erf)", "GELU (tanh)"};
+      static const char* pe_n[3] = {"sinusoidal position", "learned position table", "no position term"};
+      char vb[400];
+      snprintf(vb, sizeof vb, "; variant: %s, %s, %s%s, %s, head dim %u; kernels: %s", M.norm_first ? "Pre-LN" : "Post-LN", act_n[M.act % 3], pe_n[M.pe_kind % 3],
+               M.pe_kind == 1 ? (" of " + std::to_string(M.pe_learned_rows) + " rows").c_str() : "", M.final_norm ? "final LayerNorm" : "no final LayerNorm",
+               h.d_model / std::max(h.n_heads, 1u),
+               model_h_supported(M) ? "f16 MFMA (k_conv_m, k_fc_r, k_layers_p)" :
+               (model_default_variant(M) && h.d_model == 256 && h.n_heads == 8 && h.d_ff % 256 == 0 ? "generic conv / FC + the fused bf16x3 stack (k_layers)" : "generic bf16x3, layer by layer"));
+      t += vb;
+    }
   }
   const uint64_t n = std::min<uint64_t>(t.size(), cap - 1);
   std::memcpy(out, t.data(), n);
@@ -2233,6 +2258,12 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   const uint64_t total_sup = job->sup_off[n];
   if (total_sup > 0xffffffffull / HERRO_ROWS) { ctx->err = "job too large (informative rows x 31 exceed 2^32: TokMeta::rf_idx is a 32-bit job-level index)"; return HERRO_E_UNSUPPORTED; }
   if ((rc = ensure_logits(job, total_sup))) return rc;
+  if (ctx->M.pe_kind == 1)   // a learned position table is indexed by the row: a window longer than the table would raise an index error in the archive
+    for (uint32_t w = 0; w < n; w++)
+      if (job->h_nsup[w] && job->h_Lf[w] > ctx->M.pe_learned_rows) {
+        ctx->err = "a window of " + std::to_string(job->h_Lf[w]) + " rows exceeds the model's learned position table (" + std::to_string(ctx->M.pe_learned_rows) + " rows): the archive would raise an index error";
+        return HERRO_E_REFERENCE_PANIC;
+      }
   // the receptive fields k_rows gathered behind featurize are usable if every window got its records (none above RW_SUPCAP rows, the buffer was large enough)
   bool rf_fused_ok = job->rf_fused && job->rf_total == total_sup && total_sup <= job->rf_fused_cap;
   if (rf_fused_ok)
@@ -2824,6 +2855,7 @@ int herro_model_forward(herro_ctx* ctx, uint32_t B, uint32_t L, const uint8_t* b
   srow.resize(N);
   for (uint64_t i = 0; i < N; i++) {
     if (indices[i] < 0 || (uint32_t)indices[i] >= L) { ctx->err = "index out of range"; return HERRO_E_REFERENCE_PANIC; }
+    if (ctx->M.pe_kind == 1 && (uint32_t)indices[i] >= ctx->M.pe_learned_rows) { ctx->err = "index beyond the model's learned position table"; return HERRO_E_REFERENCE_PANIC; }
     srow[i] = (uint32_t)indices[i];
   }
   if (N == 0) return HERRO_OK;

@@ -139,6 +139,14 @@ __global__ __launch_bounds__(256) void k_patch_conv1(ModelDev M, BatchDev B, Mod
 // Generic GEMM: C[M,N] = epi(A[M,K] . W[K,N] + bias) (+ R).  W is stored transposed ([N][K]).
 // 64x64 tile per workgroup (4 waves as 2x2, each 32x32 = 2x2 MFMA 16x16 tiles), BK = 32.
 // ---------------------------------------------------------------------------------------------------
+// activation codes of the GEMM epilogues (the `relu` argument of rounds 1-5, widened in round 6): 0 none, 1 ReLU, 2 GELU (erf), 3 GELU (tanh approximation) —
+// torch.nn.functional.gelu's two forms, for archives whose encoder was built with activation = "gelu"
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 2) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  if (act == 3) return 0.5f * v * (1.0f + tanhf(0.79788456080286535588f * (v + 0.044715f * v * v * v)));
+  return v;
+}
 static constexpr int BM = 64, BN = 64, BK = 32;
 static constexpr int LDH = BK + 8;  // bf16 row stride (80 B: keeps 16-B alignment, spreads banks)
 static constexpr int LDF = BK + 1;  // f32 row stride
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, uint3
         const uint32_t m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
         if (m < M && n < N) {
           float v = vacc[i][j] + (W.bias ? W.bias[n] : 0.f);
-          if (relu) v = fmaxf(v, 0.f);
+          v = apply_act(v, relu);
           if (R) v += R[(uint64_t)m * ldc + n];
           C[(uint64_t)m * ldc + n] = v;
         }
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, uint3
           const uint32_t m = m0 + wy * 32 + i * 16 + (lane >> 4) * 4 + r;
           if (m < M && n < N) {
             float v = acc[i][j][r] + bias;
-            if (relu) v = fmaxf(v, 0.f);
+            v = apply_act(v, relu);
             if (R) v += R[(uint64_t)m * ldc + n];
             C[(uint64_t)m * ldc + n] = v;
           }
@@ -317,13 +325,20 @@ __global__ void k_add_pe(ModelDev M, ModelScratch S, uint32_t n_tok) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (uint64_t)n_tok * half) return;
   const uint32_t n = (uint32_t)(i / half), k = (uint32_t)(i % half);
-  const float ang = __fmul_rn((float)S.tok_row[n], M.pe_div[k]);
   float* x = S.x + (uint64_t)n * M.h.d_model;
+  if (M.pe_kind == 1) {   // a learned table, indexed by the row (herro_job_infer / herro_model_forward refuse rows beyond it: the archive would raise there)
+    const float2 t = *reinterpret_cast<const float2*>(M.pe_learned + (uint64_t)min(S.tok_row[n], M.pe_learned_rows - 1u) * M.h.d_model + 2 * k);
+    x[2 * k] += t.x;
+    x[2 * k + 1] += t.y;
+    return;
+  }
+  const float ang = __fmul_rn((float)S.tok_row[n], M.pe_div[k]);
   x[2 * k] += sinf(ang);
   x[2 * k + 1] += cosf(ang);
 }
 
 // one wave per row
+// (y may be x: Post-LN layers normalise the residual stream in place)
 __global__ __launch_bounds__(256) void k_layernorm(const float* x, float* y, const float* g, const float* b,
                                                    uint32_t n_rows, uint32_t D, float eps) {
   const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -644,7 +659,7 @@ __global__ __launch_bounds__(256) void k_gemm_g(const uint16_t* __restrict__ Ahi
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             float v = acc[i][j][r] + bs[j];
-            if (relu) v = fmaxf(v, 0.f);
+            v = apply_act(v, relu);
             const uint16_t hb = f32_to_bf16_rne(v);
             so[(i * 16 + (lane >> 4) * 4 + r) * OLD + nl] = plane == 0 ? hb : f32_to_bf16_rne(v - bf16_to_f32(hb));
           }
@@ -687,7 +702,7 @@ __global__ __launch_bounds__(256) void k_gemm_g(const uint16_t* __restrict__ Ahi
           if (m < M && n < N) {
             float v = acc[i][j][r] + bs[j];
             if (relu) {
-              v = fmaxf(v, 0.f);
+              v = apply_act(v, relu);
               if (R) v += R[(uint64_t)m * ldc + n];
             }
             C[(uint64_t)m * ldc + n] = v;
@@ -800,7 +815,7 @@ __global__ __launch_bounds__(512) void k_gemm_g256(const uint16_t* __restrict__ 
         const uint32_t m = m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
         if (m < M) {
           float v = acc[i][j][r] + bs[j];
-          if (relu) v = fmaxf(v, 0.f);
+          v = apply_act(v, relu);
           if (R) v += R[(uint64_t)m * ldc + n];
           C[(uint64_t)m * ldc + n] = v;
         }
@@ -927,7 +942,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_w(const uint16_t* __restrict__ 
         }
       if (relu) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = fmaxf(v[q], 0.f);
+        for (int q = 0; q < 8; q++) v[q] = apply_act(v[q], relu);
       }
       if constexpr (OUT_SPLIT) {
         uint4 hv, lv;
@@ -1224,11 +1239,17 @@ static void gemm_s(const uint16_t* Ahi, const uint16_t* Alo, uint32_t lda, const
 }
 
 // LayerNorm, one wave per row, output pre-split
+// g == nullptr: no normalisation, the planes are the split of x itself (what a Post-LN layer's QKV GEMM reads).  xo != nullptr: the normalised row is also written
+// back as f32 (Post-LN: the LayerNorm output IS the residual stream; xo may be x)
 __global__ __launch_bounds__(256) void k_layernorm_s(const float* x, uint16_t* yh, uint16_t* yl, const float* g,
-                                                     const float* b, uint32_t n_rows, uint32_t D, float eps) {
+                                                     const float* b, uint32_t n_rows, uint32_t D, float eps, float* xo) {
   const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= n_rows) return;
   const float* xr = x + (uint64_t)row * D;
+  if (!g) {
+    for (uint32_t i = lane; i < D; i += 64) split_store(yh, yl, (uint64_t)row * D + i, xr[i]);
+    return;
+  }
   float s = 0.f;
   for (uint32_t i = lane; i < D; i += 64) s += xr[i];
 #pragma unroll
@@ -1242,7 +1263,11 @@ __global__ __launch_bounds__(256) void k_layernorm_s(const float* x, uint16_t* y
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
   const float rstd = 1.0f / sqrtf(v / (float)D + eps);
-  for (uint32_t i = lane; i < D; i += 64) split_store(yh, yl, (uint64_t)row * D + i, (xr[i] - mean) * rstd * g[i] + b[i]);
+  for (uint32_t i = lane; i < D; i += 64) {
+    const float y = (xr[i] - mean) * rstd * g[i] + b[i];
+    split_store(yh, yl, (uint64_t)row * D + i, y);
+    if (xo) xo[(uint64_t)row * D + i] = y;
+  }
 }
 
 // Attention inside one window, all heads in one workgroup: 16 lanes per head, a lane owns one query
@@ -1731,46 +1756,57 @@ static void launch_model_s(const ModelDev& M, const BatchDev& B, const ModelScra
   gemm_s(S.y2_hi, S.y2_lo, HERRO_ROWS * h.c2, M.fc, S.x, nullptr, nullptr, D, nullptr, N, 0, st);
   KT_END(tm, st);
   KT_BEGIN(tm, "add_pe", st);
-  {
+  if (M.pe_kind != 2) {
     const uint64_t tot = (uint64_t)N * (D / 2);
     hipLaunchKernelGGL(k_add_pe, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, st, M, S, N);
   }
   KT_END(tm, st);
-  if (fused && B.n_tiles && D == 256 && h.n_heads == 8 && h.d_ff % 256 == 0) {
+  if (fused && B.n_tiles && D == 256 && h.n_heads == 8 && h.d_ff % 256 == 0 && model_default_variant(M)) {
     opt_in_dynamic_lds(reinterpret_cast<const void*>(k_layers), LAYERS_SHM);
     KT_BEGIN(tm, "layers_fused", st);
     hipLaunchKernelGGL(k_layers, dim3(B.n_tiles), dim3(512), LAYERS_SHM, st, M, B, S);
     KT_END(tm, st);
     return;
   }
+  // Layer by layer: every variant of the family (round 6).  Pre-LN: x += f(LN(x)); Post-LN: x = LN(x + f(x)) — the LayerNorm output is then the residual
+  // stream itself (written back as f32 next to the planes the next GEMM reads), and the first layer's QKV reads the split of x as it is.
   const dim3 ln_grid((N + 3) / 4);
+  const bool pre = M.norm_first != 0;
+  const int ff_act = 1 + (int)M.act;   // apply_act: 1 ReLU, 2 GELU (erf), 3 GELU (tanh)
+  const uint32_t dh = D / h.n_heads;
+  auto ln = [&](const float* g, const float* b, float* xo) {
+    KT_BEGIN(tm, "layernorm", st);
+    hipLaunchKernelGGL(k_layernorm_s, ln_grid, dim3(256), 0, st, S.x, S.h_hi, S.h_lo, g, b, N, D, h.ln_eps, xo);
+    KT_END(tm, st);
+  };
+  if (!pre) ln(nullptr, nullptr, nullptr);   // planes of x
   for (uint32_t li = 0; li < h.n_layers; li++) {
     const LayerW& L = M.layer[li];
-    KT_BEGIN(tm, "layernorm", st);
-    hipLaunchKernelGGL(k_layernorm_s, ln_grid, dim3(256), 0, st, S.x, S.h_hi, S.h_lo, L.ln1_g, L.ln1_b, N, D, h.ln_eps);
-    KT_END(tm, st);
+    if (pre) ln(L.ln1_g, L.ln1_b, nullptr);
     KT_BEGIN(tm, "qkv_gemm", st);
     gemm_s(S.h_hi, S.h_lo, D, L.qkv, S.qkv, nullptr, nullptr, 3 * D, nullptr, N, 0, st);
     KT_END(tm, st);
     KT_BEGIN(tm, "attention", st);
-    hipLaunchKernelGGL(k_attention_s<32>, dim3(B.n_win, std::max(1u, std::min((B.max_win_tok + 15) / 16, 64u))), dim3(16 * h.n_heads), (size_t)2 * KC * D * 4, st, B, S, D);
+    {
+      const dim3 grid(B.n_win, std::max(1u, std::min((B.max_win_tok + 15) / 16, 64u)));
+      if (dh == 64) hipLaunchKernelGGL(k_attention_s<64>, grid, dim3(16 * h.n_heads), (size_t)2 * KC * D * 4, st, B, S, D);
+      else hipLaunchKernelGGL(k_attention_s<32>, grid, dim3(16 * h.n_heads), (size_t)2 * KC * D * 4, st, B, S, D);
+    }
     KT_END(tm, st);
     KT_BEGIN(tm, "proj_gemm", st);
     gemm_s(S.att_hi, S.att_lo, D, L.proj, S.x, nullptr, nullptr, D, S.x, N, 0, st);
     KT_END(tm, st);
-    KT_BEGIN(tm, "layernorm", st);
-    hipLaunchKernelGGL(k_layernorm_s, ln_grid, dim3(256), 0, st, S.x, S.h_hi, S.h_lo, L.ln2_g, L.ln2_b, N, D, h.ln_eps);
-    KT_END(tm, st);
+    if (pre) ln(L.ln2_g, L.ln2_b, nullptr); else ln(L.ln1_g, L.ln1_b, S.x);
     KT_BEGIN(tm, "ff1_gemm", st);
-    gemm_s(S.h_hi, S.h_lo, D, L.ff1, nullptr, S.ff_hi, S.ff_lo, h.d_ff, nullptr, N, 1, st);
+    gemm_s(S.h_hi, S.h_lo, D, L.ff1, nullptr, S.ff_hi, S.ff_lo, h.d_ff, nullptr, N, ff_act, st);
     KT_END(tm, st);
     KT_BEGIN(tm, "ff2_gemm", st);
     gemm_s(S.ff_hi, S.ff_lo, h.d_ff, L.ff2, S.x, nullptr, nullptr, D, S.x, N, 0, st);
     KT_END(tm, st);
+    if (!pre) ln(L.ln2_g, L.ln2_b, S.x);
   }
-  KT_BEGIN(tm, "layernorm", st);
-  hipLaunchKernelGGL(k_layernorm_s, ln_grid, dim3(256), 0, st, S.x, S.h_hi, S.h_lo, M.lnf_g, M.lnf_b, N, D, h.ln_eps);
-  KT_END(tm, st);
+  if (M.final_norm) ln(M.lnf_g, M.lnf_b, nullptr);
+  else if (pre) ln(nullptr, nullptr, nullptr);   // (Post-LN without a final norm: the planes of the last LayerNorm are what the heads read)
   KT_BEGIN(tm, "heads_gemm", st);
   gemm_s(S.h_hi, S.h_lo, D, M.heads, S.logits, nullptr, nullptr, 16, nullptr, N, 0, st);
   KT_END(tm, st);
@@ -1806,42 +1842,46 @@ void launch_model(const ModelDev& M, const BatchDev& B, const ModelScratch& S, i
   gemm(S.y2, HERRO_ROWS * h.c2, M.fc, S.x, D, nullptr, N, 0, precision, st);
   KT_END(tm, st);
   KT_BEGIN(tm, "add_pe", st);
-  {
+  if (M.pe_kind != 2) {
     const uint64_t tot = (uint64_t)N * (D / 2);
     hipLaunchKernelGGL(k_add_pe, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, st, M, S, N);
   }
   KT_END(tm, st);
 
   const dim3 ln_grid((N + 3) / 4);
+  const bool pre = M.norm_first != 0;
+  const int ff_act = 1 + (int)M.act;
+  const uint32_t dh = D / h.n_heads;
+  auto ln = [&](const float* x, float* y, const float* g, const float* b) {
+    KT_BEGIN(tm, "layernorm", st);
+    hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, st, x, y, g, b, N, D, h.ln_eps);
+    KT_END(tm, st);
+  };
   for (uint32_t li = 0; li < h.n_layers; li++) {
     const LayerW& L = M.layer[li];
-    KT_BEGIN(tm, "layernorm", st);
-    hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, st, S.x, S.hbuf, L.ln1_g, L.ln1_b, N, D, h.ln_eps);
-    KT_END(tm, st);
+    if (pre) ln(S.x, S.hbuf, L.ln1_g, L.ln1_b);
     KT_BEGIN(tm, "qkv_gemm", st);
-    gemm(S.hbuf, D, L.qkv, S.qkv, 3 * D, nullptr, N, 0, precision, st);
+    gemm(pre ? S.hbuf : S.x, D, L.qkv, S.qkv, 3 * D, nullptr, N, 0, precision, st);
     KT_END(tm, st);
     KT_BEGIN(tm, "attention", st);
-    hipLaunchKernelGGL(k_attention<32>, dim3(B.n_win, h.n_heads), dim3(64), 0, st, B, S, D);
+    if (dh == 64) hipLaunchKernelGGL(k_attention<64>, dim3(B.n_win, h.n_heads), dim3(64), 0, st, B, S, D);
+    else hipLaunchKernelGGL(k_attention<32>, dim3(B.n_win, h.n_heads), dim3(64), 0, st, B, S, D);
     KT_END(tm, st);
     KT_BEGIN(tm, "proj_gemm", st);
     gemm(S.att, D, L.proj, S.x, D, S.x, N, 0, precision, st);
     KT_END(tm, st);
-    KT_BEGIN(tm, "layernorm", st);
-    hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, st, S.x, S.hbuf, L.ln2_g, L.ln2_b, N, D, h.ln_eps);
-    KT_END(tm, st);
+    if (pre) ln(S.x, S.hbuf, L.ln2_g, L.ln2_b); else ln(S.x, S.x, L.ln1_g, L.ln1_b);   // Post-LN: the residual stream is normalised in place
     KT_BEGIN(tm, "ff1_gemm", st);
-    gemm(S.hbuf, D, L.ff1, S.ff, h.d_ff, nullptr, N, 1, precision, st);
+    gemm(pre ? S.hbuf : S.x, D, L.ff1, S.ff, h.d_ff, nullptr, N, ff_act, precision, st);
     KT_END(tm, st);
     KT_BEGIN(tm, "ff2_gemm", st);
     gemm(S.ff, h.d_ff, L.ff2, S.x, D, S.x, N, 0, precision, st);
     KT_END(tm, st);
+    if (!pre) ln(S.x, S.x, L.ln2_g, L.ln2_b);
   }
-  KT_BEGIN(tm, "layernorm", st);
-  hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, st, S.x, S.hbuf, M.lnf_g, M.lnf_b, N, D, h.ln_eps);
-  KT_END(tm, st);
+  if (M.final_norm) ln(S.x, S.hbuf, M.lnf_g, M.lnf_b);
   KT_BEGIN(tm, "heads_gemm", st);
-  gemm(S.hbuf, D, M.heads, S.logits, 16, nullptr, N, 0, precision, st);
+  gemm(M.final_norm ? S.hbuf : S.x, D, M.heads, S.logits, 16, nullptr, N, 0, precision, st);
   KT_END(tm, st);
   KT_BEGIN(tm, "scatter_logits", st);
   hipLaunchKernelGGL(k_scatter_logits, dim3(B.n_win), dim3(64), 0, st, B, S);

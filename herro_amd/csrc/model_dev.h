@@ -66,9 +66,18 @@ struct ModelDev {
   const float* pe_tab;  // [pe_rows][d_model] the positional encoding of rows 0 .. pe_rows - 1, tabulated at load by the arithmetic k_layers_p used to run per token
   uint32_t pe_rows;     // (16 sincosf per lane and tile were 17 % of the stack's vector instructions); rows beyond the table are still computed in the kernel; null / 0: no table
   LayerW layer[16];
-  const float *lnf_g, *lnf_b;
+  const float *lnf_g, *lnf_b;   // null: no LayerNorm behind the last layer (final_norm == 0)
   Weight heads;         // [d_model, 16]: col 0 info, cols 1..5 bases
+  // Variants of the family (round 6; "cfg" / "pe_table" of the weight file, herro_amd/model_io.py Hyper).  The fused / f16 kernels implement the defaults;
+  // every other combination runs on the layer-by-layer kernels (model.hip launch_model / launch_model_s).
+  uint32_t act;         // encoder feed-forward activation: 0 ReLU, 1 GELU (erf), 2 GELU (tanh approximation)
+  uint32_t norm_first;  // 1 Pre-LN, 0 Post-LN
+  uint32_t pe_kind;     // 0 sinusoidal of the row index, 1 learned table, 2 none
+  uint32_t final_norm;  // 1: lnf_g / lnf_b behind the last layer
+  const float* pe_learned;   // [pe_learned_rows][d_model]
+  uint32_t pe_learned_rows;
 };
+inline bool model_default_variant(const ModelDev& M) { return M.act == 0 && M.norm_first == 1 && M.pe_kind == 0 && M.final_norm == 1; }
 
 // One launch group = one or more inference batches back to back: windows are ragged planes
 // [31][len] (stride lub), never padded in memory; the batch a window belongs to only matters through

@@ -1335,7 +1335,7 @@ void launch_pe_table(const float* pe_div, float* tab, uint32_t rows, uint32_t d_
 
 bool model_h_supported(const ModelDev& M) {
   const ModelHyper& h = M.h;
-  return h.kw == 3 && h.c1 == 64 && h.c2 == HC2 && h.d_model == 256 && h.n_heads == 8 && h.d_ff % 256 == 0 && h.d_ff <= (uint32_t)PAR_MAX_FF && h.rows == HERRO_ROWS &&
+  return model_default_variant(M) && h.kw == 3 && h.c1 == 64 && h.c2 == HC2 && h.d_model == 256 && h.n_heads == 8 && h.d_ff % 256 == 0 && h.d_ff <= (uint32_t)PAR_MAX_FF && h.rows == HERRO_ROWS &&
          M.conv1g.ph16 && M.conv2.ph16 && M.fc.h16 && M.fc.ph16 && M.fc.K % 128 == 0 && M.heads.h16 && M.heads.l16 && M.layer[0].qkv.ph16;
 }
 

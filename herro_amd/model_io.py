@@ -36,6 +36,13 @@ class Hyper:
     n_layers: int = 4
     ln_eps: float = 1e-5
     bn_eps: float = 1e-5
+    # variants of the family an archive may hold (round 6; the f16 / fused kernels serve the defaults, the layer-by-layer kernels every combination):
+    act: int = 0          # encoder feed-forward activation: 0 ReLU, 1 GELU (erf), 2 GELU (tanh approximation)
+    norm_first: int = 1   # 1 Pre-LN (x + f(LN(x))), 0 Post-LN (LN(x + f(x)))
+    pe: int = 0           # position: 0 sinusoidal of the row index, 1 learned table [pe_rows, d_model], 2 none
+    final_norm: int = 1   # LayerNorm behind the last encoder layer
+    pe_rows: int = 0      # rows of the learned table
+    bn: int = 1           # BatchNorm behind the convolutions (0: none)
 
 
 def random_raw_params(hp: Hyper = Hyper(), seed: int = 0x48455252) -> dict[str, np.ndarray]:
@@ -56,7 +63,7 @@ def random_raw_params(hp: Hyper = Hyper(), seed: int = 0x48455252) -> dict[str, 
     p["conv1.bias"] = uni((hp.c1,), cin * hp.kw)
     p["conv2.weight"] = uni((hp.c2, hp.c1, hp.kw, 1), hp.c1 * hp.kw)
     p["conv2.bias"] = uni((hp.c2,), hp.c1 * hp.kw)
-    for n, c in (("bn1", hp.c1), ("bn2", hp.c2)):
+    for n, c in ((("bn1", hp.c1), ("bn2", hp.c2)) if hp.bn else ()):
         p[f"{n}.weight"] = g.uniform(0.5, 1.5, c).astype(f32)
         p[f"{n}.bias"] = g.normal(0, 0.1, c).astype(f32)
         p[f"{n}.running_mean"] = g.normal(0, 0.1, c).astype(f32)
@@ -77,8 +84,11 @@ def random_raw_params(hp: Hyper = Hyper(), seed: int = 0x48455252) -> dict[str, 
         for n in ("norm1", "norm2"):
             p[q + n + ".weight"] = g.uniform(0.8, 1.2, D).astype(f32)
             p[q + n + ".bias"] = g.normal(0, 0.05, D).astype(f32)
-    p["encoder.norm.weight"] = g.uniform(0.8, 1.2, D).astype(f32)
-    p["encoder.norm.bias"] = g.normal(0, 0.05, D).astype(f32)
+    if hp.final_norm:
+        p["encoder.norm.weight"] = g.uniform(0.8, 1.2, D).astype(f32)
+        p["encoder.norm.bias"] = g.normal(0, 0.05, D).astype(f32)
+    if hp.pe == 1:
+        p["pos_table"] = g.normal(0, 0.5, (hp.pe_rows, D)).astype(f32)
     p["info_head.weight"] = uni((1, D), D)
     p["info_head.bias"] = uni((1,), D)
     p["base_head.weight"] = uni((5, D), D)
@@ -98,6 +108,9 @@ def fold(raw: dict[str, np.ndarray], hp: Hyper) -> dict[str, np.ndarray]:
     out: dict[str, np.ndarray] = {}
 
     def bn_scale_shift(n):
+        if f"{n}.weight" not in raw:      # no BatchNorm behind this convolution
+            c = raw[("conv1" if n == "bn1" else "conv2") + ".weight"].shape[0]
+            return np.ones(c, f64), np.zeros(c, f64)
         s = raw[f"{n}.weight"].astype(f64) / np.sqrt(raw[f"{n}.running_var"].astype(f64) + hp.bn_eps)
         return s, raw[f"{n}.bias"].astype(f64) - raw[f"{n}.running_mean"].astype(f64) * s
 
@@ -125,7 +138,12 @@ def fold(raw: dict[str, np.ndarray], hp: Hyper) -> dict[str, np.ndarray]:
         out[o + "proj.wt"], out[o + "proj.b"] = raw[q + "self_attn.out_proj.weight"], raw[q + "self_attn.out_proj.bias"]
         out[o + "ff1.wt"], out[o + "ff1.b"] = raw[q + "linear1.weight"], raw[q + "linear1.bias"]
         out[o + "ff2.wt"], out[o + "ff2.b"] = raw[q + "linear2.weight"], raw[q + "linear2.bias"]
-    out["lnf.g"], out["lnf.b"] = raw["encoder.norm.weight"], raw["encoder.norm.bias"]
+    if hp.final_norm:
+        out["lnf.g"], out["lnf.b"] = raw["encoder.norm.weight"], raw["encoder.norm.bias"]
+    if hp.pe == 1:
+        out["pe_table"] = raw["pos_table"]
+    if (hp.act, hp.norm_first, hp.pe, hp.final_norm) != (0, 1, 0, 1):   # the defaults need no record: files of earlier rounds stay what they were
+        out["cfg"] = np.array([hp.act, hp.norm_first, hp.pe, hp.final_norm], np.float32)
     heads_w = np.zeros((16, hp.d_model), np.float32)
     heads_b = np.zeros(16, np.float32)
     heads_w[0], heads_b[0] = raw["info_head.weight"][0], raw["info_head.bias"][0]
@@ -160,7 +178,8 @@ def default_model_file(cache_dir: str, hp: Hyper = Hyper(), seed: int = 0x484552
     import os
     os.makedirs(cache_dir, exist_ok=True)
     raw = random_raw_params(hp, seed)
-    path = os.path.join(cache_dir, f"herro_random_{seed:x}_{hp.kw}_{hp.c1}_{hp.c2}_{hp.d_model}_{hp.n_layers}.hrro")
+    var = "" if (hp.act, hp.norm_first, hp.pe, hp.final_norm, hp.bn, hp.n_heads, hp.d_ff) == (0, 1, 0, 1, 1, 8, 1024) else f"_v{hp.act}{hp.norm_first}{hp.pe}{hp.final_norm}{hp.bn}_{hp.n_heads}_{hp.d_ff}"
+    path = os.path.join(cache_dir, f"herro_random_{seed:x}_{hp.kw}_{hp.c1}_{hp.c2}_{hp.d_model}_{hp.n_layers}{var}.hrro")
     if not os.path.exists(path):
         export(raw, hp, path + ".tmp")
         os.replace(path + ".tmp", path)

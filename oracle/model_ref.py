@@ -42,29 +42,41 @@ class HerroNet(nn.Module):
         self.embedding = nn.Embedding(12, hp.emb, padding_idx=11)
         cin = hp.emb + 1
         pad = (hp.kw // 2, 0)
+        # variants of the family (herro_amd.model_io.Hyper, round 6): BatchNorm or none, ReLU / GELU, Pre- / Post-LN, final LayerNorm or none, position term
+        bn = getattr(hp, "bn", 1)
         self.conv1 = nn.Conv2d(cin, hp.c1, (hp.kw, 1), padding=pad)
-        self.bn1 = nn.BatchNorm2d(hp.c1, eps=hp.bn_eps)
+        self.bn1 = nn.BatchNorm2d(hp.c1, eps=hp.bn_eps) if bn else nn.Identity()
         self.conv2 = nn.Conv2d(hp.c1, hp.c2, (hp.kw, 1), padding=pad)
-        self.bn2 = nn.BatchNorm2d(hp.c2, eps=hp.bn_eps)
+        self.bn2 = nn.BatchNorm2d(hp.c2, eps=hp.bn_eps) if bn else nn.Identity()
         self.fc = nn.Linear(hp.rows * hp.c2, hp.d_model)
-        layer = nn.TransformerEncoderLayer(hp.d_model, hp.n_heads, hp.d_ff, dropout=0.0, activation="relu",
-                                           layer_norm_eps=hp.ln_eps, batch_first=True, norm_first=True)
-        self.encoder = nn.TransformerEncoder(layer, hp.n_layers, norm=nn.LayerNorm(hp.d_model, eps=hp.ln_eps),
+        act = getattr(hp, "act", 0)
+        activation = {0: "relu", 1: "gelu"}.get(act) or (lambda t: F.gelu(t, approximate="tanh"))
+        layer = nn.TransformerEncoderLayer(hp.d_model, hp.n_heads, hp.d_ff, dropout=0.0, activation=activation,
+                                           layer_norm_eps=hp.ln_eps, batch_first=True, norm_first=bool(getattr(hp, "norm_first", 1)))
+        self.encoder = nn.TransformerEncoder(layer, hp.n_layers, norm=nn.LayerNorm(hp.d_model, eps=hp.ln_eps) if getattr(hp, "final_norm", 1) else None,
                                              enable_nested_tensor=False)
         self.info_head = nn.Linear(hp.d_model, 1)
         self.base_head = nn.Linear(hp.d_model, 5)
         from herro_amd.model_io import pe_div_term  # a constant table, shared verbatim
         self.register_buffer("pe_div", torch.from_numpy(pe_div_term(hp.d_model)))
+        self.pe_kind = getattr(hp, "pe", 0)
+        if self.pe_kind == 1:
+            self.pos_table = nn.Parameter(torch.zeros(hp.pe_rows, hp.d_model))
 
     def load_raw(self, raw: dict):
         sd = {k: torch.from_numpy(np.asarray(v)) for k, v in raw.items()}
         sd["pe_div"] = self.pe_div
-        for n in ("bn1", "bn2"):
-            sd[f"{n}.num_batches_tracked"] = torch.tensor(0)
+        if getattr(self.hp, "bn", 1):
+            for n in ("bn1", "bn2"):
+                sd[f"{n}.num_batches_tracked"] = torch.tensor(0)
         self.load_state_dict(sd)
         return self
 
     def positional(self, idx: torch.Tensor) -> torch.Tensor:
+        if self.pe_kind == 1:
+            return self.pos_table[idx.long()]      # (an index beyond the table raises, as it would in an archive)
+        if self.pe_kind == 2:
+            return torch.zeros(idx.shape[0], self.hp.d_model)
         ang = idx.to(torch.float32)[:, None] * self.pe_div[None, :]  # f32 product, as on device
         pe = torch.zeros(idx.shape[0], self.hp.d_model)
         pe[:, 0::2] = torch.sin(ang)
@@ -110,6 +122,8 @@ class HerroNet(nn.Module):
     @torch.no_grad()
     def forward_gemm(self, bases, quals, lens, indices, win_chunk: int = 8):
         hp = self.hp
+        assert (getattr(hp, "act", 0), getattr(hp, "norm_first", 1), getattr(hp, "pe", 0), getattr(hp, "final_norm", 1), getattr(hp, "bn", 1)) == (0, 1, 0, 1, 1), \
+            "forward_gemm is written for the default variant (the end-to-end test's model); forward() serves every variant"
         dev = self.fc.weight.device
         B, L, R = bases.shape
         kw, h, D, H = hp.kw, hp.kw // 2, hp.d_model, hp.n_heads

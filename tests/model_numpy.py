@@ -53,14 +53,26 @@ def forward(F, hp, bases, quals, lens, indices, win_len=None):
     y2 = np.maximum(a2 @ F["conv2.wt"].T + F["conv2.b"], 0).reshape(N, R * c2)
     x = y2 @ F["fc.wt"].T + F["fc.b"]
     rows = np.array([l for _, l in toks], np.float32)
-    ang = (rows[:, None] * F["pe_div"][None, :]).astype(np.float32)
-    x[:, 0::2] += np.sin(ang)
-    x[:, 1::2] += np.cos(ang)
+    pe_kind, pre, act = getattr(hp, "pe", 0), bool(getattr(hp, "norm_first", 1)), getattr(hp, "act", 0)
+    if pe_kind == 0:
+        ang = (rows[:, None] * F["pe_div"][None, :]).astype(np.float32)
+        x[:, 0::2] += np.sin(ang)
+        x[:, 1::2] += np.cos(ang)
+    elif pe_kind == 1:
+        x += F["pe_table"][rows.astype(np.int64)]
+
+    def activation(t):
+        if act == 0:
+            return np.maximum(t, 0)
+        if act == 1:
+            from scipy.special import erf
+            return 0.5 * t * (1.0 + erf(t / np.sqrt(2.0)))
+        return 0.5 * t * (1.0 + np.tanh(0.7978845608028654 * (t + 0.044715 * t ** 3)))
     H, dh = hp.n_heads, D // hp.n_heads
     starts = np.concatenate([[0], np.cumsum(lens)]).astype(int)
     for li in range(hp.n_layers):
         p = f"L{li}."
-        hb = layernorm(x, F[p + "ln1.g"], F[p + "ln1.b"], hp.ln_eps)
+        hb = layernorm(x, F[p + "ln1.g"], F[p + "ln1.b"], hp.ln_eps) if pre else x
         qkv = hb @ F[p + "qkv.wt"].T + F[p + "qkv.b"]
         att = np.zeros_like(x)
         for b in range(B):
@@ -75,9 +87,14 @@ def forward(F, hp, bases, quals, lens, indices, win_len=None):
                 sc = np.exp(sc - sc.max(-1, keepdims=True))
                 att[s:e, hd * dh:(hd + 1) * dh] = (sc / sc.sum(-1, keepdims=True)) @ v
         x = x + att @ F[p + "proj.wt"].T + F[p + "proj.b"]
-        hb = layernorm(x, F[p + "ln2.g"], F[p + "ln2.b"], hp.ln_eps)
-        ff = np.maximum(hb @ F[p + "ff1.wt"].T + F[p + "ff1.b"], 0)
+        if pre:
+            hb = layernorm(x, F[p + "ln2.g"], F[p + "ln2.b"], hp.ln_eps)
+        else:
+            x = hb = layernorm(x, F[p + "ln1.g"], F[p + "ln1.b"], hp.ln_eps)
+        ff = activation(hb @ F[p + "ff1.wt"].T + F[p + "ff1.b"])
         x = x + ff @ F[p + "ff2.wt"].T + F[p + "ff2.b"]
-    hb = layernorm(x, F["lnf.g"], F["lnf.b"], hp.ln_eps)
+        if not pre:
+            x = layernorm(x, F[p + "ln2.g"], F[p + "ln2.b"], hp.ln_eps)
+    hb = layernorm(x, F["lnf.g"], F["lnf.b"], hp.ln_eps) if getattr(hp, "final_norm", 1) else x
     lg = hb @ F["heads.wt"].T + F["heads.b"]
     return lg[:, 0], lg[:, 1:6]

@@ -372,6 +372,78 @@ def test_load_time_precision_choice(tmp_path):
     c.close()
 
 
+ARCHIVE_VARIANTS = {   # what a real archive may plausibly hold instead of the assumed defaults — accepted, not refused
+    "gelu": dict(act=1),
+    "post_ln": dict(norm_first=0),
+    "post_ln_no_final_norm_gelu": dict(norm_first=0, final_norm=0, act=1),
+    "pre_ln_no_final_norm": dict(final_norm=0),
+    "learned_position": dict(pe=1, pe_rows=300),
+    "no_position_no_batchnorm": dict(pe=2, bn=0),
+    "head_dim_64": dict(n_heads=4),
+    "kw1_two_layers": dict(kw=1, n_layers=2),
+    "kw5_eight_layers": dict(kw=5, c1=32, c2=64, n_layers=8, d_ff=512),
+    "d_model_320_heads_of_32_gelu_learned": dict(d_model=320, n_heads=10, d_ff=640, act=1, pe=1, pe_rows=300, n_layers=2),
+    "d_model_128_heads_of_64_post_ln": dict(d_model=128, n_heads=2, d_ff=256, norm_first=0, n_layers=3),
+}
+
+
+@pytest.mark.parametrize("name", list(ARCHIVE_VARIANTS))
+def test_variant_archives_to_hip_logits(tmp_path, name):
+    """A TorchScript archive of every variant -> tools/export_weights.py (recognises the variant, converts, checks the conversion against the archive) ->
+    herro_load_model -> HIP logits <= 1e-3 of torch.jit.load(archive) on the CPU (inference.rs:185-186, 155-163).  The layer-by-layer kernels serve the
+    variants (herro_model_describe names the variant and the kernels); windows above the 64-row tile included."""
+    import os, sys
+    import torch
+    sys.path.insert(0, os.path.join(G.ROOT, "tools"))
+    import export_weights as EW
+    import scripted_twin as ST
+    from herro_amd import model_io as mio
+    import model_numpy as MN
+    hp = mio.Hyper(**{**dict(n_layers=3, d_ff=512), **ARCHIVE_VARIANTS[name]})
+    raw = mio.random_raw_params(hp, seed=4300 + len(name))
+    pt, flat = str(tmp_path / "model.pt"), str(tmp_path / "model.hrro")
+    ST.save_archive(pt, raw, hp)
+    got_hp, _, err = EW.convert(pt, flat, do_verify=True, quiet=True)
+    assert got_hp == hp and err <= 2e-5
+    rng = np.random.default_rng(12)
+    B, L = 4, 260
+    win_len = np.array([260, 200, 260, 231])
+    bases, quals = _rand_batch(rng, B, L, win_len)
+    idx = [np.sort(rng.choice(win_len[b], size=k, replace=False)) for b, k in enumerate([33, 70, 7, 50])]
+    idx[0][:2] = [0, 1]
+    idx[2][-1] = 259
+    lens = np.array([len(i) for i in idx], np.int32)
+    flat_idx = np.concatenate(idx).astype(np.int32)
+    ts = torch.jit.load(pt, map_location="cpu").eval()
+    with torch.no_grad():
+        ti, tb = ts(torch.from_numpy(bases.astype(np.int32)), torch.from_numpy(MN.norm_qual(quals)), torch.from_numpy(lens),
+                    [torch.from_numpy(i.astype(np.int32)) for i in idx])
+    c = api.Context(0)
+    try:
+        c.load_model(flat)
+        d = c.describe_model()
+        dflt = (hp.act, hp.norm_first, hp.pe, hp.final_norm) == (0, 1, 0, 1)
+        assert "variant: " in d and ("Post-LN" if not hp.norm_first else "Pre-LN") in d and ("GELU" in d) == (hp.act != 0), d
+        assert (f"head dim {hp.d_model // hp.n_heads}" in d) and (("layer by layer" in d) or dflt), d
+        assert c.precision() == 1, d            # no f16 kernels for these members of the family: the bf16x3 kernels
+        for prec in (1, 0):
+            c.set_precision(prec)
+            info, base = c.model_forward(bases, quals, lens, flat_idx)
+            e = max(np.abs(info - ti.numpy()).max(), np.abs(base - tb.numpy()).max())
+            print(f"{name}, precision {prec}: max abs logit error {e:.3e}")
+            assert info.shape == tuple(ti.shape) and e <= (TOL if prec else 1e-4), (name, prec, e)
+        with pytest.raises(api.HerroError):
+            c.set_precision(4)
+        if hp.pe == 1:                          # a row beyond the learned table: the archive raises an index error, the library refuses
+            big_idx = flat_idx.copy()
+            L2 = hp.pe_rows + 10
+            b2 = np.full((1, L2, 31), 10, np.uint8); q2 = np.full((1, L2, 31), 40, np.uint8)
+            with pytest.raises(api.HerroError):
+                c.model_forward(b2, q2, np.array([1], np.int32), np.array([L2 - 1], np.int32))
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("hp_kw", [
     dict(n_layers=1, d_ff=256),
     dict(n_layers=2, d_ff=512),

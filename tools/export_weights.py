@@ -14,8 +14,10 @@ is the bridge for the day such a file is at hand:
    layers), map the state dict to the names `herro_amd.model_io.fold` consumes, and check the graph against the
    architecture the HIP kernels implement (embedding + quality -> two Conv(k,1)+BatchNorm+ReLU blocks -> Linear over
    the 31 rows -> gather -> sinusoidal position -> Pre-LN Transformer encoder (ReLU) + final LayerNorm -> two
-   heads).  Anything else — an operator outside that family, a parameter no rule claims, GELU, post-LN, a learned
-   position table — stops the conversion with the list of what was not understood.  Nothing is guessed.
+   heads) and its VARIANTS (round 6): BatchNorm or none, ReLU / GELU in the encoder, Pre- / Post-LN, a final LayerNorm or none, a sinusoidal / learned /
+   absent position term, heads of 32 or 64, any odd conv width, up to 16 layers.  Anything else — an operator outside that family, a parameter no rule
+   claims — stops the conversion with the list of what was not understood.  Nothing is guessed: what the shapes cannot tell is read from the module
+   attributes or the graph, and the conversion check (step 4) runs the archive against the folded tensors in the variant that was read.
 3. Fold (BatchNorm into the convs, the embedding through conv1) and write the flat file; print the FLOP-per-window
    formula evaluated on the recovered shapes ("the builder must print it with the formula").
 4. --verify: run the archive on a small random batch on the CPU and compare with a numpy evaluation of the FOLDED
@@ -55,14 +57,14 @@ ALLOWED_OPS = {
     "aten::is_nested", "aten::numel", "aten::is_cuda", "aten::is_cpu",
     # arithmetic of the model
     "aten::add", "aten::add_", "aten::sub", "aten::mul", "aten::mul_", "aten::div", "aten::neg", "aten::sqrt", "aten::rsqrt", "aten::pow",
-    "aten::exp", "aten::log", "aten::sin", "aten::cos", "aten::relu", "aten::relu_", "aten::dropout", "aten::dropout_", "aten::feature_dropout",
+    "aten::exp", "aten::log", "aten::sin", "aten::cos", "aten::relu", "aten::relu_", "aten::gelu", "aten::gelu_", "aten::erf", "aten::dropout", "aten::dropout_", "aten::feature_dropout",
     "aten::conv2d", "aten::conv1d", "aten::_convolution", "aten::convolution", "aten::batch_norm", "aten::linear", "aten::matmul", "aten::addmm",
     "aten::bmm", "aten::baddbmm", "aten::mm", "aten::t", "aten::layer_norm", "aten::native_layer_norm", "aten::softmax", "aten::_softmax",
     "aten::scaled_dot_product_attention", "aten::_native_multi_head_attention", "aten::_transformer_encoder_layer_fwd",
     "aten::multi_head_attention_forward",
 }
 FORBIDDEN_HINT = {
-    "aten::gelu": "GELU activation (the kernels implement ReLU)", "aten::silu": "SiLU activation", "aten::tanh": "tanh activation",
+    "aten::silu": "SiLU activation", "aten::tanh": "tanh activation",
     "aten::sigmoid": "sigmoid inside the model", "aten::lstm": "recurrent layer", "aten::gru": "recurrent layer",
     "aten::max_pool2d": "pooling", "aten::avg_pool2d": "pooling", "aten::adaptive_avg_pool2d": "pooling", "aten::group_norm": "GroupNorm",
     "aten::instance_norm": "InstanceNorm", "aten::leaky_relu": "LeakyReLU", "aten::elu": "ELU",
@@ -131,9 +133,30 @@ def check_graph(m) -> list[str]:
     return problems
 
 
+def gelu_kind(m):
+    """0: no GELU in the graph; 1: erf form; 2: tanh approximation (the `approximate` argument of aten::gelu)"""
+    kind = 0
+
+    def walk(block):
+        nonlocal kind
+        for n in block.nodes():
+            if n.kind() in ("aten::gelu", "aten::gelu_"):
+                ins = list(n.inputs())
+                ap = ins[1].toIValue() if len(ins) > 1 else "none"
+                kind = max(kind, 2 if ap == "tanh" else 1)
+            for b in n.blocks():
+                walk(b)
+    walk(m.inlined_graph)
+    return kind
+
+
 def recover(m):
-    """state dict of the archive -> (Hyper, raw dict under model_io's canonical names).  Raises Unsupported."""
+    """state dict of the archive -> (Hyper, raw dict under model_io's canonical names).  Raises Unsupported.
+    Variants of the family are RECOGNISED, not refused (round 6): BatchNorm behind the convolutions or none, ReLU / GELU in the encoder, Pre- / Post-LN,
+    a final LayerNorm or none, a sinusoidal / learned / absent position term, heads of 32 or 64 — the conversion check then runs the archive against the
+    folded tensors in exactly that variant, so a wrong reading cannot produce a file."""
     sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    ops = graph_ops(m)
     used: set[str] = set()
     notes: list[str] = []
 
@@ -178,8 +201,10 @@ def recover(m):
         used.add(bk)
     # ---- batch norms: running_mean of size C1 / C2
     bns = [k[: -len("running_mean")] for k in sd if k.endswith("running_mean")]
-    if len(bns) != 2 or sd[bns[0] + "running_mean"].shape != (C1,) or sd[bns[1] + "running_mean"].shape != (C2,):
-        raise Unsupported(f"expected BatchNorm({C1}) and BatchNorm({C2}) after the convolutions, found {bns}")
+    if bns and (len(bns) != 2 or sd[bns[0] + "running_mean"].shape != (C1,) or sd[bns[1] + "running_mean"].shape != (C2,)):
+        raise Unsupported(f"expected BatchNorm({C1}) and BatchNorm({C2}) after the convolutions (or none), found {bns}")
+    if not bns:
+        notes.append("no BatchNorm behind the convolutions")
     for n, pfx in zip(("bn1", "bn2"), bns):
         for f in ("weight", "bias", "running_mean", "running_var"):
             raw[f"{n}.{f}"] = sd[pfx + f]
@@ -214,10 +239,12 @@ def recover(m):
         if FF not in (None, ff):
             raise Unsupported("encoder layers with different feed-forward widths")
         FF = ff
-    if pfx + "norm.weight" not in sd:
-        raise Unsupported(f"no final LayerNorm ({pfx}norm.weight): the kernels apply one after the last layer")
-    raw["encoder.norm.weight"], raw["encoder.norm.bias"] = sd[pfx + "norm.weight"], sd[pfx + "norm.bias"]
-    used.update({pfx + "norm.weight", pfx + "norm.bias"})
+    final_norm = int(pfx + "norm.weight" in sd)
+    if final_norm:
+        raw["encoder.norm.weight"], raw["encoder.norm.bias"] = sd[pfx + "norm.weight"], sd[pfx + "norm.bias"]
+        used.update({pfx + "norm.weight", pfx + "norm.bias"})
+    else:
+        notes.append("no LayerNorm behind the last encoder layer")
     # ---- heads: [1, D] and [5, D]
     k1, w1 = find([r"\.weight$"], lambda s: tuple(s) == (1, D), "info head (1 x D)")
     k5, w5 = find([r"\.weight$"], lambda s: tuple(s) == (5, D), "base head (5 x D)")
@@ -236,23 +263,29 @@ def recover(m):
         elif v.ndim >= 2 and v.shape[-1] == D:                                # a [max_len, D] table
             t = v.reshape(-1, D)
             pos = np.arange(t.shape[0], dtype=np.float64)[:, None] * model_io.pe_div_term(D).astype(np.float64)[None, :]
-            if not (np.allclose(t[:, 0::2], np.sin(pos), atol=1e-5) and np.allclose(t[:, 1::2], np.cos(pos), atol=1e-5)):
-                raise Unsupported(f"{k}: a learned / non-sinusoidal position table (the kernels compute sin / cos of the row index)")
+            if np.allclose(t[:, 0::2], np.sin(pos), atol=1e-5) and np.allclose(t[:, 1::2], np.cos(pos), atol=1e-5):
+                notes.append(f"{k}: sinusoidal table, reproduced on the device by sin / cos of the row index")
+            else:
+                if "pos_table" in raw:
+                    raise Unsupported(f"{k}: a second position table")
+                raw["pos_table"] = t
+                notes.append(f"{k}: learned position table of {t.shape[0]} rows (windows longer than that are refused at run time, as the archive would raise)")
             used.add(k)
-            notes.append(f"{k}: sinusoidal table, reproduced on the device by sin / cos of the row index")
     left = [k for k in sd if k not in used]
     if left:
         raise Unsupported("tensors no rule claims: " + ", ".join(f"{k}{tuple(sd[k].shape)}" for k in left))
     # ---- attributes that shapes cannot tell: heads, eps, norm_first, activation
-    n_heads, ln_eps, bn_eps = None, 1e-5, 1e-5
+    n_heads, ln_eps, bn_eps, norm_first = None, 1e-5, 1e-5, None
     for name, sub in m.named_modules():
         on = getattr(sub, "original_name", "")
         if on == "MultiheadAttention" and hasattr(sub, "num_heads"):
             n_heads = int(sub.num_heads)
         if on == "TransformerEncoderLayer":
             if hasattr(sub, "norm_first"):
-                if not bool(sub.norm_first):
-                    raise Unsupported(f"{name}: post-LN encoder layer (norm_first = False); the kernels implement Pre-LN")
+                nf = int(bool(sub.norm_first))
+                if norm_first not in (None, nf):
+                    raise Unsupported("encoder layers that differ in norm_first")
+                norm_first = nf
             else:
                 notes.append(f"{name}: norm_first not readable from the archive: assuming Pre-LN (the conversion check decides)")
         if on == "LayerNorm" and hasattr(sub, "eps"):
@@ -263,8 +296,18 @@ def recover(m):
         mm = re.search(r"num_heads\s*=\s*(\d+)|, (\d+), # num_heads", m.code if hasattr(m, "code") else "")
         n_heads = int(next(g for g in mm.groups() if g)) if mm else D // 32
         notes.append(f"num_heads not readable from the archive: assuming head_dim 32 -> {n_heads} heads")
+    gk = gelu_kind(m)
+    has_sin = any(k in ops for k in ("aten::sin", "aten::cos"))
+    pe = 1 if "pos_table" in raw else (0 if has_sin else 2)
+    if pe == 2:
+        notes.append("no sin / cos and no position table in the archive: no position term")
+    if gk:
+        notes.append("GELU (" + ("tanh approximation" if gk == 2 else "erf") + ") in the encoder's feed-forward")
+    if norm_first == 0:
+        notes.append("Post-LN encoder layers (norm_first = False)")
     hp = model_io.Hyper(rows=31, emb=E, kw=kw, c1=C1, c2=C2, d_model=D, n_heads=n_heads, d_ff=FF, n_layers=len(layer_ids),
-                        ln_eps=ln_eps, bn_eps=bn_eps)
+                        ln_eps=ln_eps, bn_eps=bn_eps, act=gk, norm_first=1 if norm_first is None else norm_first, pe=pe, final_norm=final_norm,
+                        pe_rows=raw["pos_table"].shape[0] if pe == 1 else 0, bn=int(bool(bns)))
     return hp, {k: np.ascontiguousarray(v, np.float32) for k, v in raw.items()}, notes
 
 
@@ -323,8 +366,8 @@ def convert(path: str, out: str, dump: str | None = None, do_verify: bool = True
         raise Unsupported("the archive's graph is not the architecture the kernels implement:\n  " + "\n  ".join(problems))
     hp, raw, notes = recover(m)
     kernel_limits = []
-    if hp.d_model // hp.n_heads != 32 or hp.d_model % 64 or (hp.kw * hp.c1) % 32 or (hp.rows * hp.c2) % 32 or hp.d_ff % 32 or hp.c2 % 16 or hp.n_layers > 16:
-        kernel_limits.append("herro_load_model accepts head_dim 32, d_model % 64 == 0, kw*c1 / 31*c2 / d_ff multiples of 32, <= 16 layers")
+    if hp.d_model % hp.n_heads or hp.d_model // hp.n_heads not in (32, 64) or hp.d_model % 64 or (hp.kw * hp.c1) % 32 or (hp.rows * hp.c2) % 32 or hp.d_ff % 32 or hp.c2 % 16 or hp.n_layers > 16:
+        kernel_limits.append("herro_load_model accepts head_dim 32 / 64, d_model % 64 == 0, kw*c1 / 31*c2 / d_ff multiples of 32, <= 16 layers")
     if kernel_limits:
         raise Unsupported("; ".join(kernel_limits) + f" — recovered {hp}")
     # the conversion check runs BEFORE anything is written: a file that fails it must not be left where it can be loaded
@@ -344,9 +387,10 @@ def convert(path: str, out: str, dump: str | None = None, do_verify: bool = True
         print(f"recovered {hp}")
         for n in notes:
             print("note:", n)
-        fast = hp.kw == 3 and hp.c1 == 64 and hp.c2 == 128 and hp.d_model == 256 and hp.n_heads == 8 and hp.d_ff % 256 == 0
-        print("kernel path:", "fused conv / FC / encoder kernels (precision 1, 4, 5)" if fast else
-              "generic layer-by-layer kernels only (precision 0-3): shapes differ from the tuned ones")
+        dflt = (hp.act, hp.norm_first, hp.pe, hp.final_norm) == (0, 1, 0, 1)
+        fast = dflt and hp.kw == 3 and hp.c1 == 64 and hp.c2 == 128 and hp.d_model == 256 and hp.n_heads == 8 and hp.d_ff % 256 == 0
+        print("kernel path:", "f16 MFMA conv / FC / encoder kernels (precision 4 .. 8, chosen by the load-time calibration)" if fast else
+              "generic bf16x3 kernels, layer by layer (precision 1 / 3): " + ("shapes differ from the tuned ones" if dflt else "a variant of the family the fused kernels do not implement"))
         print(flop_report(hp))
         print(f"wrote {out} ({os.path.getsize(out):,} bytes)")
     return hp, raw, err
