@@ -1301,7 +1301,7 @@ int64_t herro_model_describe(const herro_ctx* ctx, char* out, uint64_t cap) {
       snprintf(vb, sizeof vb, "; variant: %s, %s, %s%s, %s, head dim %u; kernels: %s", M.norm_first ? "Pre-LN" : "Post-LN", act_n[M.act % 3], pe_n[M.pe_kind % 3],
                M.pe_kind == 1 ? (" of " + std::to_string(M.pe_learned_rows) + " rows").c_str() : "", M.final_norm ? "final LayerNorm" : "no final LayerNorm",
                h.d_model / std::max(h.n_heads, 1u),
-               model_h_supported(M) ? "f16 MFMA (k_conv_m, k_fc_r, k_layers_p)" :
+               model_h_supported(M) ? (model_h_conv_supported(M) ? "f16 MFMA (k_conv_m, k_fc_r, k_layers_p)" : "generic bf16x3 conv / FC in front of the f16 MFMA stack (k_layers_p)") :
                (model_default_variant(M) && h.d_model == 256 && h.n_heads == 8 && h.d_ff % 256 == 0 ? "generic conv / FC + the fused bf16x3 stack (k_layers)" : "generic bf16x3, layer by layer"));
       t += vb;
     }
@@ -1319,7 +1319,7 @@ int herro_set_precision(herro_ctx* ctx, int mode) {
     return HERRO_E_UNSUPPORTED;
   }
   if (mode >= 4 && ctx->has_model && !model_h_supported(ctx->M)) {
-    ctx->err = "precision 4 .. 8 (f16 kernels) need kw 3, conv 64/128, d_model 256, 8 heads, d_ff % 256 == 0";
+    ctx->err = "precision 4 .. 8 (the f16 encoder stack) need d_model 256, 8 heads of 32, d_ff % 256 == 0 and the default variant (Pre-LN, ReLU, sinusoidal position, final LayerNorm)";
     return HERRO_E_UNSUPPORTED;
   }
   if (mode == 6 && ctx->has_model && !model_h_f8_supported(ctx->M)) {

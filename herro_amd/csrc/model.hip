@@ -60,6 +60,7 @@ __global__ void k_build_tokens(BatchDev B, ModelScratch S) {
     const uint32_t row = B.sup_row[B.sup_off[b] + (n - t0)];
     S.tok_win[n] = b;
     S.tok_row[n] = row;
+    S.tok_out[n] = B.out_off[b] + (n - t0);   // (read by k_layers_p when the f16 stack runs behind this front end)
     TokMeta tm;
     tm.plane_off = B.plane_off[b];
     tm.plane_ld = B.plane_ld[b];
@@ -1730,7 +1731,9 @@ __global__ __launch_bounds__(512) void k_layers(ModelDev M, BatchDev B, ModelScr
   }
 }
 
-static void launch_model_s(const ModelDev& M, const BatchDev& B, const ModelScratch& S, bool fused, hipStream_t st, KernelTimer* tm) {
+// The front of the model in bf16x3 for ANY conv stack of the family: token table, embedding + conv1 + conv2, the projection over the 31 rows, the position
+// term -> S.x (f32).  Used by launch_model_s below and (round 6) by launch_model_h when a model has the f16 stack's encoder shapes but another conv stack.
+void launch_front_generic(const ModelDev& M, const BatchDev& B, const ModelScratch& S, hipStream_t st, KernelTimer* tm) {
   const uint32_t N = B.n_tok;
   const ModelHyper& h = M.h;
   const uint32_t D = h.d_model;
@@ -1761,6 +1764,13 @@ static void launch_model_s(const ModelDev& M, const BatchDev& B, const ModelScra
     hipLaunchKernelGGL(k_add_pe, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, st, M, S, N);
   }
   KT_END(tm, st);
+}
+
+static void launch_model_s(const ModelDev& M, const BatchDev& B, const ModelScratch& S, bool fused, hipStream_t st, KernelTimer* tm) {
+  const uint32_t N = B.n_tok;
+  const ModelHyper& h = M.h;
+  const uint32_t D = h.d_model;
+  launch_front_generic(M, B, S, st, tm);
   if (fused && B.n_tiles && D == 256 && h.n_heads == 8 && h.d_ff % 256 == 0 && model_default_variant(M)) {
     opt_in_dynamic_lds(reinterpret_cast<const void*>(k_layers), LAYERS_SHM);
     KT_BEGIN(tm, "layers_fused", st);

@@ -166,7 +166,9 @@ void launch_model(const ModelDev& M, const BatchDev& B, const ModelScratch& S, i
                   hipStream_t st, KernelTimer* tm);
 // f16-operand kernels (model_h.hip): terms = 2 -> precision 4, terms = 1 -> precision 5, terms = 3 -> precision 6 (f16 + an e4m3 remainder term), 21 -> precision 7 (proj on two
 // terms, FF1 / FF2 on one), 12 -> precision 8 (proj on one, FF on two).  B must be tiled (n_tiles > 0).
-bool model_h_supported(const ModelDev& M);
+bool model_h_supported(const ModelDev& M);        // the f16 encoder stack serves the model (d_model 256, 8 heads of 32, d_ff % 256 == 0, the default variant): precisions 4 .. 8 exist
+bool model_h_conv_supported(const ModelDev& M);   // ... and the f16 conv / FC kernels too (kw 3, 64 -> 128 channels); otherwise the bf16x3 front end of model.hip feeds the f16 stack
+void launch_front_generic(const ModelDev& M, const BatchDev& B, const ModelScratch& S, hipStream_t st, KernelTimer* tm);   // model.hip
 bool model_h_f8_supported(const ModelDev& M);   // ... and every layer's proj / ff1 / ff2 has its e4m3 copy
 int model_h_half_tiles(const ModelDev& M);   // qmode of plan_tiles: 0 no 32-token tiles, 1 for a short last round (default), 2 for every small window (HERRO_LAYERS_Q)
 void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S, int terms, hipStream_t st, KernelTimer* tm);

@@ -1335,8 +1335,17 @@ void launch_pe_table(const float* pe_div, float* tab, uint32_t rows, uint32_t d_
 
 bool model_h_supported(const ModelDev& M) {
   const ModelHyper& h = M.h;
-  return model_default_variant(M) && h.kw == 3 && h.c1 == 64 && h.c2 == HC2 && h.d_model == 256 && h.n_heads == 8 && h.d_ff % 256 == 0 && h.d_ff <= (uint32_t)PAR_MAX_FF && h.rows == HERRO_ROWS &&
-         M.conv1g.ph16 && M.conv2.ph16 && M.fc.h16 && M.fc.ph16 && M.fc.K % 128 == 0 && M.heads.h16 && M.heads.l16 && M.layer[0].qkv.ph16;
+  if (!(model_default_variant(M) && h.d_model == 256 && h.n_heads == 8 && h.d_ff % 256 == 0 && h.d_ff <= (uint32_t)PAR_MAX_FF && h.rows == HERRO_ROWS && M.heads.h16 && M.heads.l16)) return false;
+  for (uint32_t l = 0; l < h.n_layers; l++)
+    if (!M.layer[l].qkv.ph16 || !M.layer[l].proj.ph16 || !M.layer[l].ff1.ph16 || !M.layer[l].ff2.ph16) return false;
+  return true;
+}
+
+// the f16 conv / FC kernels are written for ONE conv stack (kw 3, 64 -> 128 channels); any other member of the family with the encoder shapes above takes
+// the bf16x3 front end of model.hip (launch_front_generic) and the f16 stack behind it (round 6: until then such a model ran entirely on the generic kernels)
+bool model_h_conv_supported(const ModelDev& M) {
+  const ModelHyper& h = M.h;
+  return h.kw == 3 && h.c1 == 64 && h.c2 == HC2 && M.conv1g.ph16 && M.conv2.ph16 && M.fc.h16 && M.fc.ph16 && M.fc.K % 128 == 0;
 }
 
 bool model_h_f8_supported(const ModelDev& M) {
@@ -1359,6 +1368,12 @@ void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S,
   const uint32_t N = B.n_tok;
   if (N == 0 || B.n_tiles + B.n_tiles_q + B.n_tiles_b == 0) return;
   const ModelHyper& h = M.h;
+  const bool f16_front = model_h_conv_supported(M);
+  ModelDev M_enc = M;
+  if (!f16_front) {
+    launch_front_generic(M, B, S, st, tm);   // token table, conv stack, projection, position term: S.x complete
+    M_enc.pe_rows = 0xffffffffu;             // (the stack's prologue adds the encoding of rows >= pe_rows itself: nothing left to add)
+  } else {
   KT_BEGIN(tm, "build_tokens", st);
   hipLaunchKernelGGL(k_build_tokens_h, dim3(B.n_win), dim3(64), 0, st, B, S);
   KT_END(tm, st);
@@ -1402,10 +1417,11 @@ void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S,
     fc(0, N);
     KT_END(tm, st);
   }
+  }
   KT_BEGIN(tm, "layers_fused", st);   // one span: the 64-token tiles (windows of 33..64 informative rows and what shares their tiles), then the 32-token ones
   auto launch = [&](auto kern, uint32_t n_tiles, int tokens) {
     opt_in_lds(reinterpret_cast<const void*>(kern), layers_p_shm(tokens));
-    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(512), layers_p_shm(tokens), st, M, B, S);
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(512), layers_p_shm(tokens), st, M_enc, B, S);
   };
   auto launch5 = [&](auto k1, auto k2, auto k3, auto k21, auto k12, uint32_t n_tiles, int tokens) {
     switch (terms) {

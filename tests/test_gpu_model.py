@@ -424,16 +424,23 @@ def test_variant_archives_to_hip_logits(tmp_path, name):
         d = c.describe_model()
         dflt = (hp.act, hp.norm_first, hp.pe, hp.final_norm) == (0, 1, 0, 1)
         assert "variant: " in d and ("Post-LN" if not hp.norm_first else "Pre-LN") in d and ("GELU" in d) == (hp.act != 0), d
-        assert (f"head dim {hp.d_model // hp.n_heads}" in d) and (("layer by layer" in d) or dflt), d
-        assert c.precision() == 1, d            # no f16 kernels for these members of the family: the bf16x3 kernels
+        f16_stack = dflt and hp.d_model == 256 and hp.n_heads == 8 and hp.d_ff % 256 == 0   # the default variant with the f16 stack's encoder shapes behind another conv stack
+        assert f"head dim {hp.d_model // hp.n_heads}" in d and ("in front of the f16 MFMA stack" if f16_stack else "layer by layer") in d, d
+        if f16_stack:
+            assert c.precision() >= 4, d
+            info, base = c.model_forward(bases, quals, lens, flat_idx)
+            assert max(np.abs(info - ti.numpy()).max(), np.abs(base - tb.numpy()).max()) <= TOL
+        else:
+            assert c.precision() == 1, d        # no f16 stack for these members of the family: the bf16x3 kernels
         for prec in (1, 0):
             c.set_precision(prec)
             info, base = c.model_forward(bases, quals, lens, flat_idx)
             e = max(np.abs(info - ti.numpy()).max(), np.abs(base - tb.numpy()).max())
             print(f"{name}, precision {prec}: max abs logit error {e:.3e}")
             assert info.shape == tuple(ti.shape) and e <= (TOL if prec else 1e-4), (name, prec, e)
-        with pytest.raises(api.HerroError):
-            c.set_precision(4)
+        if not f16_stack:
+            with pytest.raises(api.HerroError):
+                c.set_precision(4)
         if hp.pe == 1:                          # a row beyond the learned table: the archive raises an index error, the library refuses
             big_idx = flat_idx.copy()
             L2 = hp.pe_rows + 10
@@ -484,15 +491,18 @@ def test_f16_kernels_serve_other_depths_and_ff_widths(tmp_path, hp_kw):
         c.close()
 
 
-@pytest.mark.parametrize("hp_kw", [
-    dict(kw=5, c1=32, c2=64, d_model=128, n_heads=4, d_ff=512, n_layers=2),      # a smaller family member: wider kernel, 9-row receptive field... (4 * (kw / 2) + 1)
-    dict(kw=3, c1=64, c2=128, d_model=512, n_heads=16, d_ff=1024, n_layers=3),   # a wider residual stream
-    dict(kw=7, c1=32, c2=32, d_model=256, n_heads=8, d_ff=768, n_layers=5),      # the f16 kernels' d_model with another conv stack: 13-row receptive field
+@pytest.mark.parametrize("hp_kw,f16_stack", [
+    (dict(kw=5, c1=32, c2=64, d_model=128, n_heads=4, d_ff=512, n_layers=2), False),      # a smaller family member: wider kernel, 9-row receptive field... (4 * (kw / 2) + 1)
+    (dict(kw=3, c1=64, c2=128, d_model=512, n_heads=16, d_ff=1024, n_layers=3), False),   # a wider residual stream
+    (dict(kw=7, c1=32, c2=32, d_model=256, n_heads=8, d_ff=768, n_layers=5), True),       # the f16 stack's encoder shapes behind another conv stack: 13-row receptive field
+    (dict(kw=5, c1=32, c2=64, d_model=256, n_heads=8, d_ff=512, n_layers=3), True),       # ... 9 rows
+    (dict(kw=1, c1=64, c2=128, d_model=256, n_heads=8, d_ff=1024, n_layers=4), True),     # ... a pointwise conv stack
 ])
-def test_other_hyper_parameters_run_on_the_generic_kernels(tmp_path, hp_kw):
-    """The f16 kernels serve ONE point of the architecture family (kw 3, 64 / 128 channels, d_model 256); any other member of it —
-    conv width, channels, d_model (heads of 32), d_ff, layer count — loads, is sent to the generic bf16x3 kernels by
-    herro_load_model (mode 1; herro_model_describe says so) and meets the same 1e-3 contract against its own dense twin."""
+def test_other_hyper_parameters(tmp_path, hp_kw, f16_stack):
+    """The f16 conv / FC kernels serve ONE conv stack (kw 3, 64 / 128 channels) and the f16 encoder stack one residual width (d_model 256, 8 heads of 32).  Any
+    other member of the family loads and meets the same 1e-3 contract against its own dense twin: with the encoder shapes of the f16 stack it runs the bf16x3
+    front end of model.hip IN FRONT OF k_layers_p (round 6 — an f16 tier chosen by the load-time calibration; herro_model_describe says so), with another
+    d_model the generic bf16x3 kernels throughout (mode 1)."""
     import model_ref as MR
     hp = model_io.Hyper(**hp_kw)
     raw = model_io.random_raw_params(hp, seed=77 + hp.kw)
@@ -503,9 +513,12 @@ def test_other_hyper_parameters_run_on_the_generic_kernels(tmp_path, hp_kw):
         c.load_model(path)
         d = c.describe_model()
         assert f"conv kw {hp.kw}" in d and f"d_model {hp.d_model}" in d and f"layers {hp.n_layers}" in d, d
-        assert "mode 1" in d, d
-        with pytest.raises(api.HerroError):
-            c.set_precision(4)                       # no f16 kernels for these shapes
+        if f16_stack:
+            assert "in front of the f16 MFMA stack" in d and c.precision() >= 4, d
+        else:
+            assert "mode 1" in d and c.precision() == 1, d
+            with pytest.raises(api.HerroError):
+                c.set_precision(4)                       # no f16 stack for these shapes
         rng = np.random.default_rng(5)
         B, L = 4, 220
         win_len = np.array([220, 200, 220, 130])
@@ -515,10 +528,13 @@ def test_other_hyper_parameters_run_on_the_generic_kernels(tmp_path, hp_kw):
         idx[2][-1] = 219
         lens = np.array([len(i) for i in idx], np.int32)
         flat = np.concatenate(idx).astype(np.int32)
-        info, base = c.model_forward(bases, quals, lens, flat)
         ti, tb = MR.run_batch(MR.build(raw, hp), bases, quals, lens, flat)
+        info, base = c.model_forward(bases, quals, lens, flat)      # the calibrated choice
         err = max(np.abs(info - ti).max(), np.abs(base - tb).max())
-        print(f"{hp_kw}: max abs logit error {err:.3e}")
+        print(f"{hp_kw}: mode {c.precision()}, max abs logit error {err:.3e}")
         assert info.shape == ti.shape and err <= TOL
+        if f16_stack and G.select_precision(c, 4):                 # ... and the two-term tier
+            i4, b4 = c.model_forward(bases, quals, lens, flat)
+            assert max(np.abs(i4 - ti).max(), np.abs(b4 - tb).max()) <= TOL
     finally:
         c.close()
