@@ -27,7 +27,7 @@ EXPORTS = [
     "herro_paf_parse", "herro_oec_read", "herro_paf_n_targets", "herro_paf_target_ids", "herro_paf_aln_off",
     "herro_paf_alignments", "herro_paf_free", "herro_name_index_create", "herro_name_index_free", "herro_paf_parse_indexed",
     "herro_oec_read_indexed", "herro_paf_parse_view", "herro_debug_host_ctx", "herro_debug_job_array", "herro_debug_tile_plan", "herro_debug_tile_plan_sib",
-    "herro_debug_set_featurize_planes", "herro_debug_set_host_build", "herro_debug_job_dev_built", "herro_debug_job_rf", "herro_debug_job_rf_fused", "herro_debug_e4m3", "herro_debug_sib_fault", "herro_debug_sib_retries", "herro_debug_base_row_votes", "herro_debug_vote5",
+    "herro_debug_set_featurize_planes", "herro_debug_set_host_build", "herro_debug_job_dev_built", "herro_debug_job_rf", "herro_debug_job_rf_fused", "herro_debug_job_rf_left", "herro_debug_e4m3", "herro_debug_sib_fault", "herro_debug_sib_retries", "herro_debug_base_row_votes", "herro_debug_vote5",
     "herro_pool_create", "herro_pool_destroy", "herro_pool_last_error", "herro_pool_size", "herro_pool_ctx", "herro_pool_set_reads", "herro_pool_load_model",
     "herro_pool_correct", "herro_pool_result", "herro_pool_groups_taken", "herro_pool_skipped", "herro_debug_pool_fake", "herro_job_create_status", "herro_host_register", "herro_host_unregister", "herro_debug_zero_copy_jobs",
     "herro_fastx_read", "herro_reads_count", "herro_reads_seq", "herro_reads_qual", "herro_reads_off", "herro_reads_ids",
@@ -167,6 +167,7 @@ def lib():
         L.herro_debug_vote5.restype = u32
         L.herro_debug_vote5.argtypes = [vp, u32]
         L.herro_debug_job_rf_fused.argtypes = [vp]
+        L.herro_debug_job_rf_left.argtypes = [vp]
         L.herro_debug_sib_fault.argtypes = [vp]
         L.herro_debug_e4m3.argtypes = [C.c_float]
         L.herro_debug_e4m3.restype = C.c_uint32
@@ -598,6 +599,13 @@ class Job:
             self.ctx._chk(int(got))
         text = out[:got] if as_array else out[:got].tobytes()
         return (text, ends[:n]) if with_ends else text
+
+    def rf_left(self) -> int:
+        """test hook: windows of the last infer whose receptive fields k_rfq filled BEHIND a fused gather (more informative rows than k_rows stages)"""
+        rc = self._l.herro_debug_job_rf_left(self.h)
+        if rc < 0:
+            self.ctx._chk(rc)
+        return rc
 
     def rf_fused(self) -> bool:
         """test hook: the last infer read the receptive fields k_rows gathered itself (False: k_rfq's)"""

@@ -254,6 +254,7 @@ struct herro_job {
   uint32_t rf_fused_half = 0, rf_total = 0;
   bool pending = false;         // counted in herro_ctx::n_pending
   bool rf_fused_used = false;   // herro_job_infer read the records k_rows gathered (herro_debug_job_rf_fused)
+  uint32_t rf_left_windows = 0; // ... of which this many windows were filled by k_rfq behind it (above the rows k_rows stages; herro_debug_job_rf_left)
   bool sib_stale = false;       // the context's sibling-tile error word was found raised while this job's pass was unchecked: its logits are not to be trusted (sib_retry repeats the pass)
   bool no_sib = false;          // a sibling tile of this job timed out once: its windows above 64 rows go layer by layer from now on (sib_retry)
   uint32_t last_batch_size = 0; // arguments of the last herro_job_infer (sib_retry repeats it)
@@ -1592,13 +1593,22 @@ void build_target(const herro_ctx* ctx, uint32_t rid, const herro_alignment* aln
 // ---- host ranges registered for zero-copy job creation (herro_host_register) -----------------------------------------------------
 // Process-wide: several contexts (feeder threads) create jobs from the same alignment buffer; a range is pinned once and counted.
 namespace {
-struct HostReg { const unsigned char* p; uint64_t n; int refs; };
+struct HostReg { const unsigned char* p; uint64_t n; int refs; const unsigned char* dp; };   // dp: the range as kernels see it (hipHostGetDevicePointer; null: not mapped)
 std::mutex g_reg_mu;
 std::vector<HostReg> g_regs;
 std::atomic<uint64_t> g_zero_copy_jobs{0};   // jobs whose texts went up straight from a registered range (herro_debug_zero_copy_jobs)
-bool host_range_registered(const unsigned char* lo, const unsigned char* hi) {
+// *dev (may be null): where kernels read the byte at `lo` directly, if the range is mapped AND 16-byte pieces read around [lo, hi) stay on its pinned pages
+bool host_range_registered(const unsigned char* lo, const unsigned char* hi, const unsigned char** dev = nullptr) {
   std::lock_guard<std::mutex> lk(g_reg_mu);
-  for (const HostReg& r : g_regs) if (lo >= r.p && hi <= r.p + r.n) return true;
+  for (const HostReg& r : g_regs)
+    if (lo >= r.p && hi <= r.p + r.n) {
+      if (dev) {
+        const uintptr_t page_lo = (uintptr_t)r.p & ~uintptr_t(4095), page_hi = ((uintptr_t)r.p + r.n + 4095) & ~uintptr_t(4095);
+        const bool safe = ((uintptr_t)lo & ~uintptr_t(15)) >= page_lo && (((uintptr_t)hi + 31) & ~uintptr_t(15)) <= page_hi;
+        *dev = (r.dp && safe) ? r.dp + (lo - r.p) : nullptr;
+      }
+      return true;
+    }
   return false;
 }
 }  // namespace
@@ -1612,7 +1622,7 @@ int herro_host_register(herro_ctx* ctx, const void* p, uint64_t bytes) {
   }
   // the pinning (a multi-GB blob takes a while) runs OUTSIDE the registry's lock: every feeder's herro_job_create looks ranges up under it
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const hipError_t e = hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterPortable);
+  const hipError_t e = hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterPortable | hipHostRegisterMapped);
   if (e != hipSuccess) {   // e.g. the memlock limit: not fatal — jobs over this range are staged like any unregistered text
     (void)hipGetLastError();
     ctx->err = std::string("herro_host_register: ") + hipGetErrorString(e) + " (jobs over this range will be staged)";
@@ -1625,7 +1635,9 @@ int herro_host_register(herro_ctx* ctx, const void* p, uint64_t bytes) {
       (void)hipHostUnregister(const_cast<void*>(p));
       return HERRO_OK;
     }
-  g_regs.push_back(HostReg{(const unsigned char*)p, bytes, 1});
+  void* dp = nullptr;
+  if (hipHostGetDevicePointer(&dp, const_cast<void*>(p), 0) != hipSuccess) { (void)hipGetLastError(); dp = nullptr; }
+  g_regs.push_back(HostReg{(const unsigned char*)p, bytes, 1, (const unsigned char*)dp});
   return HERRO_OK;
 }
 uint64_t herro_debug_zero_copy_jobs(void) { return g_zero_copy_jobs.load(); }
@@ -1792,9 +1804,14 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
     // herro_paf_parse_view, a CIGAR blob), that range goes up in ONE copy from where it is — no staging pass over the bytes (0.9 of the
     // 3.4 ms an unloaded herro_job_create of 4096 windows took, and the part that fights the other feeders for memory bandwidth).  A
     // text keeps its alignment modulo 16: the scan kernel reads aligned 16-byte pieces and skips the bytes in front of the text.
-    static const bool allow_direct = [] { const char* e = getenv("HERRO_ZERO_COPY"); return !e || atoi(e) != 0; }();
+    // HERRO_ZERO_COPY: 0 stage every text; 1 (default) copy a registered range up as it is; 2 (round 6, measured in profiles/r6_e2e_ab.txt) no copy at all — the scan kernel
+    // reads the registered range over PCIe where the caller has it (no blit kernel, no 50 MB through HBM and back per 4096 windows)
+    static const int zc_mode = [] { const char* e = getenv("HERRO_ZERO_COPY"); return e ? atoi(e) : 1; }();
+    const bool allow_direct = zc_mode != 0;
     const uint64_t span = t_lo ? (uint64_t)(t_hi - t_lo) : 0;
-    const bool direct = allow_direct && t_lo && span <= txt_sum + txt_sum / 2 + 65536 && host_range_registered(t_lo, t_hi);
+    const unsigned char* t_dev = nullptr;
+    const bool direct = allow_direct && t_lo && span <= txt_sum + txt_sum / 2 + 65536 && host_range_registered(t_lo, t_hi, &t_dev);
+    const bool read_host = direct && zc_mode == 2 && t_dev != nullptr;
     const uint64_t lead = direct ? ((uintptr_t)t_lo & 15u) : 0;
     if (direct) {
       for (uint64_t g = 0; g < nA; g++) {
@@ -1844,7 +1861,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
     if (pe[0]) (void)hipEventRecord(pe[0], ctx->prep_stream);
     hipError_t e;
     if (direct) {   // the texts from the caller's registered range (same alignment modulo 16), the alignment records from the staging block
-      e = hipMemcpyAsync(dsb + lead, t_lo, span, hipMemcpyHostToDevice, ctx->prep_stream);
+      e = read_host ? hipSuccess : hipMemcpyAsync(dsb + lead, t_lo, span, hipMemcpyHostToDevice, ctx->prep_stream);
       if (e == hipSuccess) e = hipMemcpyAsync(dsb + o_in, hs + o_in, o_out - o_in, hipMemcpyHostToDevice, ctx->prep_stream);
     } else {
       e = hipMemcpyAsync(dsb, hs, o_out, hipMemcpyHostToDevice, ctx->prep_stream);
@@ -1852,7 +1869,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
     if (try_dev && e == hipSuccess) e = hipMemcpyAsync(dsb + o_tot, hs + o_tot, sizeof(BuildTotals), hipMemcpyHostToDevice, ctx->prep_stream);
     if (pe[1]) (void)hipEventRecord(pe[1], ctx->prep_stream);
     if (e == hipSuccess) {
-      launch_cigar_scan(dsb, (const CigIn*)(dsb + o_in), (CigOut*)(dsb + o_out), (CigCut*)(dsb + o_cut), (uint32_t*)job->scan.p, (uint32_t)nA, W, ctx->prep_stream);
+      launch_cigar_scan(read_host ? t_dev - lead : dsb, (const CigIn*)(dsb + o_in), (CigOut*)(dsb + o_out), (CigCut*)(dsb + o_cut), (uint32_t*)job->scan.p, (uint32_t)nA, W, ctx->prep_stream);
       e = hipGetLastError();
     }
     if (pe[2]) (void)hipEventRecord(pe[2], ctx->prep_stream);
@@ -2266,11 +2283,16 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
       }
   // the receptive fields k_rows gathered behind featurize are usable if every window got its records (none above RW_SUPCAP rows, the buffer was large enough)
   bool rf_fused_ok = job->rf_fused && job->rf_total == total_sup && total_sup <= job->rf_fused_cap;
+  uint32_t rf_left = 0;   // windows whose slots k_rows reserved but did not fill (above the rows it stages): k_rfq fills exactly those (round 6)
   if (rf_fused_ok)
-    for (uint32_t w = 0; w < n && rf_fused_ok; w++) rf_fused_ok = job->h_nsup[w] == 0 || job->h_rfbase[w] != 0xffffffffu;
+    for (uint32_t w = 0; w < n && rf_fused_ok; w++) {
+      rf_fused_ok = job->h_nsup[w] == 0 || job->h_rfbase[w] != 0xffffffffu;
+      rf_left += job->h_nsup[w] && job->h_rfbase[w] != 0xffffffffu && (job->h_rfbase[w] & 0x80000000u) ? 1u : 0u;
+    }
   job->rf_fused_used = rf_fused_ok;
+  job->rf_left_windows = rf_fused_ok ? rf_left : 0;
   job->rf_base.assign(n, 0);
-  for (uint32_t w = 0; w < n; w++) job->rf_base[w] = rf_fused_ok ? (uint64_t)job->h_rfbase[w] : job->sup_off[w];
+  for (uint32_t w = 0; w < n; w++) job->rf_base[w] = rf_fused_ok ? (uint64_t)(job->h_rfbase[w] & 0x7fffffffu) : job->sup_off[w];
   // ---- plan batches (prepare_examples, inference.rs:241-250; flush rule features.rs:884-893)
   job->batches.clear();
   auto flush = [&](std::vector<uint32_t>& cur) {
@@ -2405,6 +2427,8 @@ int herro_job_infer(herro_job* job, uint32_t batch_size, int batch_mode) {
   }
   if (!(job->quals_full && !rf_compact) && !groups.empty() && !rfq_there)
     launch_rf_quals(job->J, rf_half, job->d_supoff_blob, rf_compact ? job->d_rfq : nullptr, job->logit_cap, job->lean, ctx->stream, &ctx->timer);
+  else if (rf_compact && rf_fused_ok && job->rf_fused_half == rf_half && job->rf_left_windows && !groups.empty())
+    launch_rf_quals(job->J, rf_half, job->d_supoff_blob, job->d_rfq, job->logit_cap, job->lean, ctx->stream, &ctx->timer, /*left_only=*/true);
   for (const Offs& o : offs) {
     const unsigned char* base = (const unsigned char*)job->d_bdesc;
     BatchDev B{};
@@ -3034,6 +3058,7 @@ int herro_clock_probe(herro_ctx* ctx, double* shader_mhz) {
 }
 uint32_t herro_debug_e4m3(float x) { return f32_to_e4m3(x); }   // the host encoder of the precision-6 weight copies (tests)
 int herro_debug_job_rf_fused(const herro_job* job) { return job && job->inferred ? (job->rf_fused_used ? 1 : 0) : HERRO_E_STATE; }
+int herro_debug_job_rf_left(const herro_job* job) { return job && job->inferred ? (int)job->rf_left_windows : HERRO_E_STATE; }
 
 // the receptive-field records the model read for window w (valid once herro_job_infer has run with a compact receptive field)
 int64_t herro_debug_job_rf(herro_job* job, uint32_t w, uint8_t* out, uint64_t cap) {

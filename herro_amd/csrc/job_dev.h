@@ -190,7 +190,8 @@ void launch_full_tokens(const JobDev& J, hipStream_t st, KernelTimer* tm);   // 
 // quality planes (which needs the row map, i.e. the planes path or launch_full_tokens)
 // cap: informative rows rf has room for (a window whose slots would lie beyond it is left out: launches in front of the host's count)
 // lean: the job was featurized on the lean path (sup_nr is valid: the rows around an informative row are named without row_of_pos2)
-void launch_rf_quals(const JobDev& J, uint32_t half, const uint64_t* sup_off, uint8_t* rf, uint64_t cap, bool lean, hipStream_t st, KernelTimer* tm);
+// left_only: behind a fused gather (k_rows) — only the windows it reserved slots for and did not fill (more informative rows than it stages), at those slots
+void launch_rf_quals(const JobDev& J, uint32_t half, const uint64_t* sup_off, uint8_t* rf, uint64_t cap, bool lean, hipStream_t st, KernelTimer* tm, bool left_only = false);
 void launch_supoff(const JobDev& J, uint64_t* sup_off, hipStream_t st);   // sup_off[0 .. n_win]: prefix of win_nsup
 // the complete quality planes (featurize itself only writes tokens)
 void launch_full_quals(const JobDev& J, hipStream_t st);

@@ -50,6 +50,7 @@ namespace herro {
 namespace {
 
 constexpr uint32_t NONE = 0xffffffffu;
+constexpr uint32_t RF_LEFT = 0x80000000u;   // JobDev::win_rfbase: the window's receptive-field slots are reserved (low 31 bits) but k_rows did not fill them
 constexpr uint32_t ROWCAP = HERRO_TILE;   // rows of the final matrix per k_tokens workgroup (1024)
 constexpr uint32_t SCAP = 128;            // overlaps per window whose scores are cached in LDS
 constexpr uint32_t QEVCAP = 2048;         // insertion events (position | length, query index) staged in LDS by k_quals
@@ -1381,9 +1382,11 @@ __global__ __launch_bounds__(2 * NW) void k_rows(JobDev J) {
   if (J.rf) {   // wave-uniform
     if (tid == 0) {
       const uint32_t base = atomicAdd(J.rf_alloc, total);
-      const bool ok = total <= RW_SUPCAP && (uint64_t)base + total <= J.rf_cap;
+      const bool room = (uint64_t)base + total <= J.rf_cap, ok = room && total <= RW_SUPCAP;
       s_rfbase = ok ? base : NONE;
-      J.win_rfbase[w] = ok ? base : NONE;
+      // a window above RW_SUPCAP rows keeps the slots it reserved and says so (RF_LEFT): k_rfq fills exactly those windows behind this kernel (round 6, ADVICE r5 — one
+      // such window used to send the whole job through k_rfq); only a buffer that is too small (NONE) still does
+      J.win_rfbase[w] = ok ? base : (room ? (base | RF_LEFT) : NONE);
     }
     __syncthreads();   // s_sup, s_rfbase
     const uint32_t base = s_rfbase;
@@ -1816,13 +1819,23 @@ __global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const ui
   const uint32_t w = gridDim.x - 1u - blockIdx.x, tid = threadIdx.x;   // back to front: k_rows has just walked the windows front to back — its last windows' plane records are the cached ones
   PROF_BEGIN(J);
   const uint32_t nsup = J.win_nsup[w], Lf = J.win_Lf[w];
-  if (!nsup || sup_off[w] + nsup > cap) return;   // (a launch in front of the host's count of the informative rows: the buffer was sized by an estimate)
+  const bool left_only = (have_nr & 2u) != 0u;   // only the windows k_rows reserved slots for and left (RF_LEFT), at those slots
+  have_nr &= 1u;
+  uint64_t slot0;
+  if (left_only) {
+    const uint32_t rb = J.win_rfbase[w];
+    if (!nsup || rb == NONE || !(rb & RF_LEFT)) return;
+    slot0 = rb & ~RF_LEFT;
+  } else {
+    if (!nsup || sup_off[w] + nsup > cap) return;   // (a launch in front of the host's count of the informative rows: the buffer was sized by an estimate)
+    slot0 = sup_off[w];
+  }
   const WinDesc wd = J.win[w];
   if (tid < 32) s_ct[tid] = J.ctab[(uint64_t)w * 32 + tid];
   __syncthreads();
   PROF_MARK(J, 5, 0);
   const uint32_t nslots = nsup * HERRO_ROWS;
-  const uint64_t out0 = sup_off[w] * HERRO_ROWS;
+  const uint64_t out0 = slot0 * HERRO_ROWS;
   for (uint32_t sl = tid; sl < nslots; sl += RQ_NT) {
     const uint32_t k = sl / HERRO_ROWS, c = sl - k * HERRO_ROWS;
     const uint32_t pj = J.sup_pi[wd.row_off + k], srow = J.sup_row[wd.row_off + k];
@@ -2067,11 +2080,11 @@ void launch_supoff(const JobDev& J, uint64_t* sup_off, hipStream_t st) {
   if (J.n_win) hipLaunchKernelGGL(k_supoff, dim3(1), dim3(256), 0, st, J, sup_off);
 }
 
-void launch_rf_quals(const JobDev& J, uint32_t half, const uint64_t* sup_off, uint8_t* rf, uint64_t cap, bool lean, hipStream_t st, KernelTimer* tm) {
+void launch_rf_quals(const JobDev& J, uint32_t half, const uint64_t* sup_off, uint8_t* rf, uint64_t cap, bool lean, hipStream_t st, KernelTimer* tm, bool left_only) {
   if (!J.n_win) return;
   KT_BEGIN(tm, "rf_quals", st);
   if (rf && 2 * half + 1 <= 8) {
-    hipLaunchKernelGGL(k_rfq, dim3(J.n_win), dim3(RQ_NT), 0, st, J, half, sup_off, rf, cap, lean ? 1u : 0u);
+    hipLaunchKernelGGL(k_rfq, dim3(J.n_win), dim3(RQ_NT), 0, st, J, half, sup_off, rf, cap, (lean ? 1u : 0u) | (left_only ? 2u : 0u));
     KT_END(tm, st);
     return;
   }

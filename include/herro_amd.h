@@ -278,6 +278,7 @@ int herro_debug_base_row_votes(const uint8_t* counts, const uint8_t* split, cons
 uint32_t herro_debug_vote5(const uint32_t* c5, uint32_t tb);
 int64_t herro_debug_job_rf(herro_job* job, uint32_t w, uint8_t* out, uint64_t cap);
 int herro_debug_job_rf_fused(const herro_job* job);   /* 1: the last herro_job_infer read records k_rows gathered itself; 0: k_rfq's */
+int herro_debug_job_rf_left(const herro_job* job);    /* ... of which this many windows (above the 256 informative rows k_rows stages) were filled by k_rfq behind it, the others staying fused */
 uint32_t herro_debug_e4m3(float x);                   /* host f32 -> OCP e4m3 (round to nearest even, saturating) as used for the precision-6 weight copies */
 int herro_debug_sib_fault(herro_ctx* ctx);            /* raises the context's sibling-tile error word as a tile that timed out would: the next fetch repeats its job's model pass without sibling tiles */
 int herro_debug_force_precision(herro_ctx* ctx, int on); /* tests: herro_set_precision / herro_load_model skip the calibration gate (to MEASURE a mode the model's calibration refuses) */

@@ -66,7 +66,7 @@ def test_lean_path_equals_planes_path(name):
         c.featurize_planes(False)
         if other is not None:
             other.close()
-    assert fused == (max(a[1] for a in lean) <= 256 and sum(a[1] for a in lean) > 0) or name == "low_coverage"
+    assert fused == (sum(a[1] for a in lean) > 0) or name == "low_coverage"   # (a window above the 256 rows k_rows stages no longer takes the job off the fused gather: k_rfq fills that window)
     assert fa_lean2 == fa_lean
     for a, b in zip(lean, lean2):
         assert a[:3] == b[:3] and np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6])   # both gathers feed the model the same records
@@ -97,8 +97,9 @@ def test_receptive_field_records_are_the_planes_cells(name):
     other.featurize()                          # another job of the context is featurized and waits for its infer: the caller pipelines ...
     job.featurize()
     job.infer(64, 1)
-    most = max(job.info(w).n_supported for w in range(job.n_windows))
-    assert job.rf_fused() == (most <= 256)     # ... and k_rows gathers the receptive fields itself — unless a window has more rows than it stages
+    big = sum(1 for w in range(job.n_windows) if job.info(w).n_supported > 256)
+    assert job.rf_fused() and job.rf_left() == big   # ... and k_rows gathers the receptive fields itself; a window with more rows than it stages is filled by k_rfq, alone (round 6)
+    assert (big > 0) == (name == "very_diverged")
     other.close()
     n_rec = 0
     for w in range(job.n_windows):
@@ -148,7 +149,7 @@ def test_receptive_field_records_are_the_oracles_cells(name):
     if job.rf_fused():
         recs["k_rows"] = [job.rf_records(w) for w in range(job.n_windows)]
     other.close()
-    assert name == "low_coverage" or "k_rows" in recs or name == "diverged_haplotypes"
+    assert name == "low_coverage" or "k_rows" in recs
     n_cells = w = 0
     for t in range(sb.n_targets):
         rid, rows, cigs = O.target_alignments(sb, t)
