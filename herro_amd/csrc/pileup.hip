@@ -190,7 +190,7 @@ __device__ __forceinline__ uint32_t wsum(uint32_t v) { return wlast(wscan_incl(v
 constexpr int CA_NT = 256, CA_NW = CA_NT / 64;
 constexpr uint32_t MDCAP = 192;   // ops per batch (three steps of 64); a slice with more ops runs several batches
 __host__ __device__ inline uint32_t cols_qcap(uint32_t nw) { return nw + 40u < 320u ? nw + 40u : 320u; }   // staged query plane words
-__host__ __device__ inline uint32_t cols_lds_words(uint32_t nw) { return 3 * MDCAP + 2 * (nw + 1) + 2 * (cols_qcap(nw) + 2) + 2 * (nw + 2); }
+__host__ __device__ inline uint32_t cols_lds_words(uint32_t nw) { return 3 * MDCAP + 2 * (nw + 1) + 2 * (cols_qcap(nw) + 2) + 2 * (nw + 2) + 3 * nw; }
 
 // QI: 64-word steps that cover the staged query words (cols_qcap(nw) + 2), NWI: plane words per lane (nw / 64, rounded up) — the loops over
 // them are unrolled, and with the bounds of the largest window (5, 4) a 4096-base window paid for two empty steps of each (r5)
@@ -210,6 +210,9 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
   uint32_t* q1 = q0 + qcap + 2;
   uint32_t* t0 = q1 + qcap + 1;                                   // [nw+2] target code planes, raw words from the window's first word
   uint32_t* t1 = t0 + (nw + 2);
+  uint32_t* s_pM = t1 + (nw + 2);                                 // [nw] x 3: the plane bits the op lanes write (an M op's stretch inside the word it starts in)
+  uint32_t* s_pL = s_pM + nw;
+  uint32_t* s_pH = s_pL + nw;
   PROF_BEGIN(J);
   const OwDesc d = J.ow[o];   // carries the window's and the reads' offsets: no further lookups before the data
   const uint32_t cnt_ops = d.op_cnt;
@@ -244,24 +247,31 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
 #pragma unroll
   for (int i = 0; i < QI; i++) {
     const uint32_t idx = lane + 64u * i;
-    if (staged && idx < nqw) { q0[idx] = v0[i]; q1[idx] = v1[i]; }
+    // a reverse-strand query is staged complemented and end to end reversed (word nqw - 1 - i = ~brev(word i)): staged bit s0 + k is alignment-orientation
+    // base k on either strand, and the reads below carry no strand branch (round 6; ~brev at every read before)
+    if (staged && idx < nqw) {
+      if (d.strand) { q0[nqw - 1u - idx] = ~__brev(v0[i]); q1[nqw - 1u - idx] = ~__brev(v1[i]); }
+      else { q0[idx] = v0[i]; q1[idx] = v1[i]; }
+    }
     if (staged && i == 0 && lane < 2) { q0[lane ? (int)nqw : -1] = 0; q1[lane ? (int)nqw : -1] = 0; }
     if (idx < nw + 2) { t0[idx] = u0[i]; t1[idx] = u1[i]; }
+    if (idx < nw) { s_pM[idx] = 0; s_pL[idx] = 0; s_pH[idx] = 0; }
   }
   PROF_MARK(J, 0, 0);
   const int32_t sbase = d.strand ? (int32_t)(d.qbeg + d.qlen - 1u) : (int32_t)d.qbeg;   // stored index of alignment-orientation base 0
   const int32_t rel = -(int32_t)(qw0 << 5);
+  const int32_t s0 = d.strand ? (int32_t)(nqw << 5) - 1 - (sbase + rel) : sbase + rel;    // staged bit of alignment-orientation base 0
   // code planes of the 32 alignment-orientation query bases qidx .. qidx + 31 (bits of bases outside the region are
   // meaningless: callers mask).  Reverse strand: base k is the complement of stored base sbase - k (features.rs:128-153).
   auto qbits = [&](int32_t qidx, uint32_t& b0, uint32_t& b1) {
-    if (d.strand == 0) {
+    if (staged) {
+      b0 = lds_bits(q0, nqw, s0 + qidx); b1 = lds_bits(q1, nqw, s0 + qidx);
+    } else if (d.strand == 0) {
       const int32_t s = sbase + qidx;
-      if (staged) { b0 = lds_bits(q0, nqw, s + rel); b1 = lds_bits(q1, nqw, s + rel); }
-      else { b0 = glb_bits(J.read_p0, d.q_woff, pmax, s); b1 = glb_bits(J.read_p1, d.q_woff, pmax, s); }
+      b0 = glb_bits(J.read_p0, d.q_woff, pmax, s); b1 = glb_bits(J.read_p1, d.q_woff, pmax, s);
     } else {
       const int32_t s = sbase - qidx - 31;
-      if (staged) { b0 = ~__brev(lds_bits(q0, nqw, s + rel)); b1 = ~__brev(lds_bits(q1, nqw, s + rel)); }
-      else { b0 = ~__brev(glb_bits(J.read_p0, d.q_woff, pmax, s)); b1 = ~__brev(glb_bits(J.read_p1, d.q_woff, pmax, s)); }
+      b0 = ~__brev(glb_bits(J.read_p0, d.q_woff, pmax, s)); b1 = ~__brev(glb_bits(J.read_p1, d.q_woff, pmax, s));
     }
   };
   uint32_t carry_t = 0, carry_q = 0, n_ev = 0, isum = 0, dsum = 0, longindel = 0;
@@ -307,11 +317,24 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
         // insertion behind window position off + t - 1 (features.rs:77, 219-228): position, trimmed length (bases written),
         // query index of its first base, its first 16 bases, untrimmed length (max_ins)
         const uint64_t imask = __ballot(isI);
+        // ONE read of the query planes serves both kinds of lanes (round 6): an insertion's lane wants the bases from q on, an M op's lane the bases that fall
+        // into the word of 32 window positions its first base lies in — it ORs that stretch into the LDS planes itself.  The plane walk further down is
+        // then left with ONE op per word, the one that covers the word's first position: it used to walk every op that touches the word, each wave as
+        // many turns as its busiest lane (~5 at ~40 instructions, twice: the largest phase of the kernel)
+        const int32_t Pm = off + (int32_t)t;
+        const bool isMs = isM && e != 0u && Pm < (int32_t)d.wlen;
+        uint32_t c0 = 0, c1 = 0;
+        if (isI || isMs) qbits(isI ? (int32_t)q : (int32_t)q - (Pm & 31), c0, c1);
+        if (isMs) {
+          const uint32_t wP = (uint32_t)Pm >> 5;
+          const uint32_t seg = mask_range(Pm & 31, min((Pm & 31) + (int32_t)e, (int32_t)d.wlen - (int32_t)(wP << 5)));
+          atomicOr(&s_pM[wP], seg);
+          atomicOr(&s_pL[wP], c0 & seg);
+          atomicOr(&s_pH[wP], c1 & seg);
+        }
         if (isI) {
           const uint32_t idx = n_ev + (uint32_t)__popcll(imask & lt);
           const int32_t pos = off + (int32_t)t - 1;
-          uint32_t c0, c1;
-          qbits((int32_t)q, c0, c1);
           const uint32_t codes = (c0 & 0xffffu) | (c1 << 16);   // the first 16 bases as two bit planes (low code bits | high code bits << 16): the consumers pick single bases, interleaving here cost ~20 instructions per step
           ev[idx] = make_uint4(((uint32_t)pos & 0xffffu) | (min(e, 0xffffu) << 16), q, codes, min(len, 0xffffu));
         }
@@ -352,40 +375,40 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     PROF_MARK(J, 0, 2);
-    // planes of the batch's positions: a lane owns 32 positions, the op covering the first one is a popcount away
+    // planes of the batch's positions: a lane owns 32 positions, the op covering the first one is a popcount away; the ops that START inside the word
+    // have written their stretches themselves (above)
     const int32_t Pb1 = min(off + (int32_t)carry_t, (int32_t)d.wlen);
 #pragma unroll
     for (int wi_i = 0; wi_i < NWI; wi_i++) {
       const uint32_t wi = lane + 64u * wi_i;
       const int32_t ws = (int32_t)(wi << 5);
-      const int32_t lo_p = max(ws, Pb0), hi_p = min(ws + 32, Pb1);
-      if (wi < nw && lo_p < hi_p) {
-        uint32_t r = s_cum[wi] + (uint32_t)__popc(s_bm[wi] & (0xffffffffu >> (31u - ((uint32_t)lo_p & 31u)))) - 1u;
-        int32_t P = lo_p;
-        if (lo_p == ws && r < n_md) {
+      if (wi < nw && ws >= Pb0 && ws < Pb1) {
+        const uint32_t r = s_cum[wi] + (s_bm[wi] & 1u) - 1u;   // M/D ops of the batch that start at or in front of the word's first position, less one
+        if (r < n_md) {
           const uint32_t ll = s_ml[r];
-          dQ[wi_i] = s_mq[r] + ((ll >> 31) ? (uint32_t)(ws - (int32_t)s_mt[r]) : 0u);
-          dE[wi_i] = (ll >> 14) & 0x1ffffu;
-        } else if (b0 == 0 && ws < Pb0) {
-          dE[wi_i] = 0;
-        }
-        while (P < hi_p && r < n_md) {
           const int32_t tP = (int32_t)s_mt[r];
-          const uint32_t ll = s_ml[r];
-          const int32_t se = min(hi_p, tP + (int32_t)(ll & 0x3fffu));
-          const uint32_t seg = mask_range(P - ws, se - ws);
+          const uint32_t qq = s_mq[r];
+          dQ[wi_i] = qq + ((ll >> 31) ? (uint32_t)(ws - tP) : 0u);
+          dE[wi_i] = (ll >> 14) & 0x1ffffu;
           if (ll >> 31) {
+            const uint32_t seg = mask_range(0, min(Pb1, tP + (int32_t)(ll & 0x3fffu)) - ws);
             uint32_t c0, c1;
-            qbits((int32_t)s_mq[r] + (ws - tP), c0, c1);
+            qbits((int32_t)qq + (ws - tP), c0, c1);
             pM[wi_i] |= seg;
             pL[wi_i] |= c0 & seg;
             pH[wi_i] |= c1 & seg;
           }
-          P = se;
-          r++;
         }
       }
     }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int wi_i = 0; wi_i < NWI; wi_i++) {
+    const uint32_t wi = min(lane + 64u * wi_i, nw - 1u);
+    pM[wi_i] |= s_pM[wi]; pL[wi_i] |= s_pL[wi]; pH[wi_i] |= s_pH[wi];
   }
   PROF_MARK(J, 0, 3);
   const uint32_t t_total = carry_t;
