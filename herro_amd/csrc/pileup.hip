@@ -181,6 +181,15 @@ __device__ __forceinline__ uint32_t wscan_incl(uint32_t v) {
 #endif
   return v;
 }
+__device__ __forceinline__ uint32_t wscan_max(uint32_t v) {   // inclusive prefix maximum (unsigned; lanes a step does not reach contribute 0)
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+  return v;
+}
 __device__ __forceinline__ uint32_t wlast(uint32_t incl) { return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63); }
 __device__ __forceinline__ uint32_t wsum(uint32_t v) { return wlast(wscan_incl(v)); }
 
@@ -190,7 +199,7 @@ __device__ __forceinline__ uint32_t wsum(uint32_t v) { return wlast(wscan_incl(v
 constexpr int CA_NT = 256, CA_NW = CA_NT / 64;
 constexpr uint32_t MDCAP = 192;   // ops per batch (three steps of 64); a slice with more ops runs several batches
 __host__ __device__ inline uint32_t cols_qcap(uint32_t nw) { return nw + 40u < 320u ? nw + 40u : 320u; }   // staged query plane words
-__host__ __device__ inline uint32_t cols_lds_words(uint32_t nw) { return 3 * MDCAP + 2 * (nw + 1) + 2 * (cols_qcap(nw) + 2) + 2 * (nw + 2) + 3 * nw; }
+__host__ __device__ inline uint32_t cols_lds_words(uint32_t nw) { return 2 * MDCAP + nw + 2 * (cols_qcap(nw) + 2) + 3 * nw; }   // 4.9 KB per wave at nw = 128: eight workgroups per compute unit
 
 // QI: 64-word steps that cover the staged query words (cols_qcap(nw) + 2), NWI: plane words per lane (nw / 64, rounded up) — the loops over
 // them are unrolled, and with the bounds of the largest window (5, 4) a 4096-base window paid for two empty steps of each (r5)
@@ -201,16 +210,13 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
   const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t o = blockIdx.x * CA_NW + wave;
   if (o >= J.n_ow) return;
-  uint32_t* s_mt = ca_smem + (size_t)wave * cols_lds_words(nw);   // M/D ops of the batch: window position of the first base
+  static_assert(NWI + 1 <= QI, "the target words of a lane's plane words and of the word behind them");
+  uint32_t* s_mt = ca_smem + (size_t)wave * cols_lds_words(nw);   // M/D ops of the batch: window position of the first base | length << 14 | M << 31
   uint32_t* s_mq = s_mt + MDCAP;                                  // ... query index of it
-  uint32_t* s_ml = s_mq + MDCAP;                                  // ... length | insertion events in front of it << 14 | M << 31
-  uint32_t* s_bm = s_ml + MDCAP;                                  // [nw+1] bitmap of op starts over window positions
-  uint32_t* s_cum = s_bm + (nw + 1);                              // [nw+1] op starts in front of each word
-  uint32_t* q0 = s_cum + (nw + 1) + 1;                            // [-1 .. qcap] query code planes (stored orientation) between two zero words
+  uint32_t* s_cov = s_mq + MDCAP;                                 // [nw] per word: (table slot + 1) << 12 | insertion events in front, of the last op that starts in (32 w - 32, 32 w]
+  uint32_t* q0 = s_cov + nw + 1;                                  // [-1 .. qcap] query code planes (alignment orientation) between two zero words
   uint32_t* q1 = q0 + qcap + 2;
-  uint32_t* t0 = q1 + qcap + 1;                                   // [nw+2] target code planes, raw words from the window's first word
-  uint32_t* t1 = t0 + (nw + 2);
-  uint32_t* s_pM = t1 + (nw + 2);                                 // [nw] x 3: the plane bits the op lanes write (an M op's stretch inside the word it starts in)
+  uint32_t* s_pM = q1 + qcap + 1;                                 // [nw] x 3: the plane bits the op lanes write (an M op's stretch inside the word it starts in)
   uint32_t* s_pL = s_pM + nw;
   uint32_t* s_pH = s_pL + nw;
   PROF_BEGIN(J);
@@ -254,8 +260,22 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
       else { q0[idx] = v0[i]; q1[idx] = v1[i]; }
     }
     if (staged && i == 0 && lane < 2) { q0[lane ? (int)nqw : -1] = 0; q1[lane ? (int)nqw : -1] = 0; }
-    if (idx < nw + 2) { t0[idx] = u0[i]; t1[idx] = u1[i]; }
     if (idx < nw) { s_pM[idx] = 0; s_pL[idx] = 0; s_pH[idx] = 0; }
+  }
+  // the window's target code planes, 32 positions per lane like the planes built below (for the accuracy): lane l holds words l, l + 64, .. of the raw
+  // planes from the window's first word; the word behind comes from the next lane (round 6: they were staged in LDS, 1 KB per wave that cost occupancy)
+  uint32_t tl[NWI], th[NWI];
+  {
+    const uint32_t tsh = d.wtstart & 31u;
+#pragma unroll
+    for (int i = 0; i < NWI; i++) {
+      uint32_t n0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u0[i], 0x130, 0xf, 0xf, false);   // wave_shl:1
+      uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u1[i], 0x130, 0xf, 0xf, false);
+      const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)u0[i + 1]), f1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)u1[i + 1]);
+      if (lane == 63u) { n0 = f0; n1 = f1; }
+      tl[i] = __funnelshift_r(u0[i], n0, tsh);
+      th[i] = __funnelshift_r(u1[i], n1, tsh);
+    }
   }
   PROF_MARK(J, 0, 0);
   const int32_t sbase = d.strand ? (int32_t)(d.qbeg + d.qlen - 1u) : (int32_t)d.qbeg;   // stored index of alignment-orientation base 0
@@ -286,7 +306,7 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
   const uint64_t lt = (1ull << lane) - 1ull;
 
   for (uint32_t b0 = 0; b0 < cnt_ops; b0 += MDCAP) {
-    for (uint32_t i = lane; i <= nw; i += 64) s_bm[i] = 0;
+    for (uint32_t i = lane; i < nw; i += 64) s_cov[i] = 0;
     uint32_t n_md = 0;
     const int32_t Pb0 = off + (int32_t)carry_t;   // first window position of the batch
 #pragma unroll
@@ -346,10 +366,12 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
         if (isMD) {
           const uint32_t idx = n_md + (uint32_t)__popcll(mdmask & lt);
           const uint32_t P = (uint32_t)(off + (int32_t)t);
-          s_mt[idx] = P;
+          s_mt[idx] = min(P, 0x3fffu) | (e << 14) | (isM ? 0x80000000u : 0u);   // P, e <= 8192
           s_mq[idx] = q;
-          s_ml[idx] = e | (min(ev_before, 0x1ffffu) << 14) | (isM ? 0x80000000u : 0u);   // e <= 8192
-          if (P < ((nw + 1u) << 5)) atomicOr(&s_bm[P >> 5], 1u << (P & 31u));
+          // the op that covers a word's first position = the last one that starts at or in front of it: table slots grow with the position, and so do the
+          // events in front — a maximum per word here, a prefix maximum over the words below (round 6; a bitmap of op starts + a rank directory before)
+          const uint32_t slot = (P + 31u) >> 5;
+          if (slot < nw) atomicMax(&s_cov[slot], ((idx + 1u) << 12) | min(ev_before, 0xfffu));
         }
         n_md += (uint32_t)__popcll(mdmask);
         carry_t += last_t;
@@ -361,19 +383,17 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     PROF_MARK(J, 0, 1);
-    {  // rank directory: op starts in front of every bitmap word
+    uint32_t cv[NWI];   // per plane word of this lane: the op that covers its first position (s_cov's format)
+    {
       uint32_t carry = 0;
-      for (uint32_t bb = 0; bb <= nw; bb += 64) {
-        const uint32_t i = bb + lane;
-        const uint32_t pc = i <= nw ? (uint32_t)__popc(s_bm[i]) : 0u;
-        const uint32_t inc = wscan_incl(pc);
-        if (i <= nw) s_cum[i] = carry + inc - pc;
-        carry += wlast(inc);
+#pragma unroll
+      for (int wi_i = 0; wi_i < NWI; wi_i++) {
+        const uint32_t i = lane + 64u * wi_i;
+        const uint32_t v = max(wscan_max(i < nw ? s_cov[i] : 0u), carry);
+        cv[wi_i] = v;
+        carry = wlast(v);
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     PROF_MARK(J, 0, 2);
     // planes of the batch's positions: a lane owns 32 positions, the op covering the first one is a popcount away; the ops that START inside the word
     // have written their stretches themselves (above)
@@ -383,15 +403,15 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
       const uint32_t wi = lane + 64u * wi_i;
       const int32_t ws = (int32_t)(wi << 5);
       if (wi < nw && ws >= Pb0 && ws < Pb1) {
-        const uint32_t r = s_cum[wi] + (s_bm[wi] & 1u) - 1u;   // M/D ops of the batch that start at or in front of the word's first position, less one
-        if (r < n_md) {
-          const uint32_t ll = s_ml[r];
-          const int32_t tP = (int32_t)s_mt[r];
+        if (cv[wi_i]) {
+          const uint32_t r = (cv[wi_i] >> 12) - 1u;
+          const uint32_t ll = s_mt[r];
+          const int32_t tP = (int32_t)(ll & 0x3fffu);
           const uint32_t qq = s_mq[r];
           dQ[wi_i] = qq + ((ll >> 31) ? (uint32_t)(ws - tP) : 0u);
-          dE[wi_i] = (ll >> 14) & 0x1ffffu;
+          dE[wi_i] = cv[wi_i] & 0xfffu;
           if (ll >> 31) {
-            const uint32_t seg = mask_range(0, min(Pb1, tP + (int32_t)(ll & 0x3fffu)) - ws);
+            const uint32_t seg = mask_range(0, min(Pb1, tP + (int32_t)((ll >> 14) & 0x3fffu)) - ws);
             uint32_t c0, c1;
             qbits((int32_t)qq + (ws - tP), c0, c1);
             pM[wi_i] |= seg;
@@ -415,17 +435,12 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
   const bool keep = __ballot(longindel != 0u) == 0ull;
   // accuracy: matches / mismatches over M ops (features.rs:650-665)
   uint32_t mm = 0, ss = 0;
-  {
-    const uint32_t tsh = d.wtstart & 31u;
 #pragma unroll
-    for (int wi_i = 0; wi_i < NWI; wi_i++) {
-      const uint32_t wi = lane + 64u * wi_i;
-      if (wi < nw) {
-        const uint32_t tl = __funnelshift_r(t0[wi], t0[wi + 1], tsh), th = __funnelshift_r(t1[wi], t1[wi + 1], tsh);
-        const uint32_t x = (pL[wi_i] ^ tl) | (pH[wi_i] ^ th);
-        ss += __popc(pM[wi_i] & x);
-        mm += __popc(pM[wi_i]);
-      }
+  for (int wi_i = 0; wi_i < NWI; wi_i++) {
+    if (lane + 64u * wi_i < nw) {
+      const uint32_t x = (pL[wi_i] ^ tl[wi_i]) | (pH[wi_i] ^ th[wi_i]);
+      ss += __popc(pM[wi_i] & x);
+      mm += __popc(pM[wi_i]);
     }
   }
   {
