@@ -483,7 +483,7 @@ template <int NB>
 __global__ __launch_bounds__(256) void k_win(JobDev J) {
   __shared__ float s_acc[RKCAP];
   __shared__ uint8_t s_keep[RKCAP];
-  __shared__ uint32_t s_nm[32], s_ns;   // first 32 columns: matches at informative positions; informative positions of the window
+  __shared__ uint32_t s_nm2[16], s_ns;  // first 32 columns: matches at informative positions, two columns per word (u | u + 16 << 16: a window has <= 8192 positions); informative positions of the window
   // windows are taken back to front: k_cols has just written the plane records front to back (268 MB per 4096 windows — more than the
   // 256 MB memory-side cache holds), so the last windows' records are the ones still cached; k_rows then walks front to back again (r5)
 #ifdef HERRO_FWD_ORDER   // (A/B build only)
@@ -491,8 +491,9 @@ __global__ __launch_bounds__(256) void k_win(JobDev J) {
 #else
   const uint32_t w = gridDim.x - 1u - blockIdx.x, tid = threadIdx.x, NT = blockDim.x, nw = J.nw;
 #endif
-  if (tid < 32) s_nm[tid] = 0;
+  if (tid < 16) s_nm2[tid] = 0;
   if (tid == 0) s_ns = 0;
+  __syncthreads();
   PROF_BEGIN(J);
   const WinDesc wd = J.win[w];
   const uint32_t n = wd.ow_cnt;
@@ -512,6 +513,7 @@ __global__ __launch_bounds__(256) void k_win(JobDev J) {
 #ifndef HERRO_WIN_UB
 #define HERRO_WIN_UB 8
 #endif
+  static_assert(HERRO_WIN_UB == 8, "the tallies pair column u with column u + 16");
   constexpr int UB = HERRO_WIN_UB;    // columns whose loads are in flight together (16: two round trips instead of four, but 152 VGPRs — measured no faster in r3; -DHERRO_WIN_UB for an A/B build)
   const uint4* __restrict__ ocol = J.ocol;   // read-only here: uniform addresses -> scalar loads
   uint32_t match[4 * UB];  // first 32 columns: positions where the column shows the target's base (kept for the tallies)
@@ -563,16 +565,21 @@ __global__ __launch_bounds__(256) void k_win(JobDev J) {
   // ---- tallies (features.rs:478-498): every kept column is scored at every informative target position; anything but
   // the target's base ('.', '*', '#', another base) is a mismatch.  Informative positions are rare: only the lanes whose
   // word holds one take part; the first 32 columns' match masks are still in registers, further columns are read again.
-  if (sup) {
+  // Round 6: the sums over the wave's lanes are DPP reductions, one LDS atomic per word from one lane.  (Every lane adding its own count to the column's
+  // LDS word: the compiler turns an atomic on a wave-uniform address into a SCALAR loop over the active lanes — 33 of them here, ~13 k of the kernel's 66 k
+  // cycles; profiles/r6_k_win_tallies.txt.)
+  if (__ballot(sup != 0u)) {   // wave-uniform: all lanes inside
+    const uint32_t lane = tid & 63u;
     const uint32_t nsup = (uint32_t)__popc(sup);
-    atomicAdd(&s_ns, nsup);
+    uint32_t acc = 0;
 #pragma unroll
-    for (int u = 0; u < 4 * UB; u++) {
-      if ((keepmask >> u) & 1u) {
-        const uint32_t nm = (uint32_t)__popc(sup & match[u]);
-        if (nm) atomicAdd(&s_nm[u], nm);   // in LDS first: one pair of global atomics per column and window, not per lane
-      }
+    for (int u = 0; u < 2 * UB; u++) {   // match[] of a column that was not kept is 0
+      const uint32_t r = wsum((uint32_t)__popc(sup & match[u]) | ((uint32_t)__popc(sup & match[u + 2 * UB]) << 16));   // <= 2048 per half
+      if (lane == (uint32_t)u) acc = r;
     }
+    const uint32_t ns_w = wsum(nsup);
+    if (lane < 2u * UB && acc) atomicAdd(&s_nm2[lane], acc);
+    if (lane == 2u * UB) atomicAdd(&s_ns, ns_w);
     for (uint32_t c0 = 4 * UB; c0 < n; c0 += UB) {
       uint4 oc2[UB];
       uint32_t M[UB], L[UB], H[UB];
@@ -585,12 +592,14 @@ __global__ __launch_bounds__(256) void k_win(JobDev J) {
       }
 #pragma unroll
       for (int u = 0; u < UB; u++) {
-        if (c0 + u < n && oc2[u].z) {
+        if (c0 + u < n && oc2[u].z) {   // uniform
           const int32_t off = (int32_t)oc2[u].x;
           const uint32_t inr = mask_range(off - P, off + (int32_t)oc2[u].y - P) & vm;
-          const uint32_t nm = (uint32_t)__popc(sup & M[u] & inr & ~((L[u] ^ tlo) | (H[u] ^ thi)));
-          if (nm) atomicAdd(&J.nd[2 * (uint64_t)oc2[u].w], nm);
-          if (nsup - nm) atomicAdd(&J.nd[2 * (uint64_t)oc2[u].w + 1], nsup - nm);
+          const uint32_t nm = wsum((uint32_t)__popc(sup & M[u] & inr & ~((L[u] ^ tlo) | (H[u] ^ thi))));
+          if (lane == 0u) {
+            if (nm) atomicAdd(&J.nd[2 * (uint64_t)oc2[u].w], nm);
+            if (ns_w - nm) atomicAdd(&J.nd[2 * (uint64_t)oc2[u].w + 1], ns_w - nm);
+          }
         }
       }
     }
@@ -602,7 +611,7 @@ __global__ __launch_bounds__(256) void k_win(JobDev J) {
     for (uint32_t i = tid; i < n; i += NT) { s_acc[i] = J.ow_acc[wd.ow_begin + i]; s_keep[i] = J.ow_keep[wd.ow_begin + i]; }
   __syncthreads();
   if (tid < 32 && tid < n && ((keepmask >> tid) & 1u) && s_ns) {   // keepmask is uniform
-    const uint32_t cls = ocol[wd.ow_begin + tid].w, nm = s_nm[tid], ns = s_ns;
+    const uint32_t cls = ocol[wd.ow_begin + tid].w, nm = (s_nm2[tid & 15u] >> (tid & 16u)) & 0xffffu, ns = s_ns;
     if (nm) atomicAdd(&J.nd[2 * (uint64_t)cls], nm);
     if (ns - nm) atomicAdd(&J.nd[2 * (uint64_t)cls + 1], ns - nm);
   }
@@ -1246,6 +1255,7 @@ __global__ __launch_bounds__(2 * NW) void k_rows(JobDev J) {
       const uint4 g = J.cw[(o != NONE ? (uint64_t)o : 0ull) * nw + widx];
       M[u] = g.x; L[u] = g.y; H[u] = g.z;
     }
+    PROF_MARK(J, 6, 10);
 #pragma unroll
     for (int u = 0; u < UB; u++) {
       const CTab& h = s_ct[cb + u];
@@ -1280,6 +1290,20 @@ __global__ __launch_bounds__(2 * NW) void k_rows(JobDev J) {
     }
   }
   const bool lane0 = !half && active;   // the lanes that go on: one per word of the window
+  // half 1's counters are merged: their LDS now carries what the insertion rows need (round 6) — the position of every insertion row (written by the
+  // threads that walk the runs), the cover counts as five bit planes, and per word of 32 positions which of them have an informative insertion row
+  constexpr uint32_t IP_ROWS = (RW_ICAP * 2 + NW * 4 - 1) / (NW * 4);
+  static_assert(IP_ROWS + 7 <= 15, "s_mrg holds the insertion rows' positions, five cover planes and two words per lane");
+  uint16_t* s_ip = reinterpret_cast<uint16_t*>(s_mrg);          // [RW_ICAP]
+  uint32_t* s_nin = s_mrg + IP_ROWS * NW;                       // [5][NW]
+  uint32_t* s_insup = s_nin + 5 * NW;                           // [NW] positions with an informative insertion row
+  uint32_t* s_nisup = s_insup + NW;                             // [NW] informative insertion rows of the word's positions
+  if (!half) {   // (a lane's own column of s_mrg: read above by nobody else)
+#pragma unroll
+    for (int b = 0; b < 5; b++) s_nin[b * NW + lt] = nin[b];
+    s_insup[lt] = 0;
+    s_nisup[lt] = 0;
+  }
   PROF_MARK(J, 6, 1);
   // informative positions (features.rs:681-722 on the final 31 columns: thresh = (31 * 0.1) as usize = 3) and the votes of the others
   // (the rules and their derivation: base_row_votes, pileup_core.h — shared with the host so that tests/test_vote_planes.py can run them on every count vector)
@@ -1309,14 +1333,19 @@ __global__ __launch_bounds__(2 * NW) void k_rows(JobDev J) {
     if (ch0) __syncthreads();   // the previous pass's votes are out
     for (uint32_t i = tid; i < min(RW_ICAP, n_irows - ch0); i += NT) s_adj[i] = 0;
     __syncthreads();
+    PROF_MARK(J, 6, 7);
     // inserted bases of the selected columns (features.rs:213-229), from the tiles' run lists: a run that crosses a tile boundary is
     // listed by both tiles, each takes its own rows (the tile travels with the record); "hidden" rows were overwritten by a later
     // insertion at the same position
     constexpr int EU = 6;   // ~5 runs per thread at the bench workload: one round trip
-    for (uint32_t e0 = tid; e0 < n_runs; e0 += EU * NT) {
-      uint4 ve[EU];
+    uint4 ve[EU];
 #pragma unroll
-      for (int u = 0; u < EU; u++) ve[u] = tev[min(e0 + u * NT, n_runs - 1u)];
+    for (int u = 0; u < EU; u++) ve[u] = n_runs ? tev[min(tid + u * NT, n_runs - 1u)] : make_uint4(0, 0, 0, 0);   // (uniform)
+    for (uint32_t e0 = tid; e0 < n_runs; e0 += EU * NT) {
+      if (e0 != tid) {
+#pragma unroll
+        for (int u = 0; u < EU; u++) ve[u] = tev[min(e0 + u * NT, n_runs - 1u)];
+      }
 #pragma unroll
       for (int u = 0; u < EU; u++) {
         const uint32_t e = e0 + u * NT;
@@ -1342,30 +1371,34 @@ __global__ __launch_bounds__(2 * NW) void k_rows(JobDev J) {
             if (s_ct[c].sdir < 0) code ^= 3u;
           }
           atomicAdd(&s_adj[ir], (1u << (5u * code)) + (inr ? 1u << 20 : 0u));
+          s_ip[ir] = (uint16_t)p;   // (every run that reaches the row writes the same position)
         }
       }
     }
     __syncthreads();
-    // every insertion row is evaluated by the lane that owns its position
-    for (uint32_t m = insmask; m; m &= m - 1u) {
-      const uint32_t k = (uint32_t)__ffs((int)m) - 1u, p = (uint32_t)P + k;
-      const uint32_t rp = s_rop[RI(p)], n_ins = s_rop[RI(p + 1)] - rp - 1u;
-      const uint32_t cover = ((nin[0] >> k) & 1u) | (((nin[1] >> k) & 1u) << 1) | (((nin[2] >> k) & 1u) << 2) | (((nin[3] >> k) & 1u) << 3) | (((nin[4] >> k) & 1u) << 4);
-      for (uint32_t j = 0; j < n_ins; j++) {
-        const uint32_t ir = rp - p + j - ch0;
-        if (ir >= RW_ICAP) continue;
-        const uint32_t adj = s_adj[ir];
-        const uint32_t c5[5] = {adj & 31u, (adj >> 5) & 31u, (adj >> 10) & 31u, (adj >> 15) & 31u, cover - (adj >> 20)};
-        uint32_t ns = 0;
-#pragma unroll
-        for (int q = 0; q < 5; q++) ns += c5[q] >= 3u ? 1u : 0u;
-        const uint32_t sup = ns >= 2u ? 1u : 0u;
-        s_iv[ir] = (uint8_t)(vote5(c5, 4u) | (sup << 7));   // the target shows '*' on an insertion row
-        n_isup += sup;
-        if (sup) insup |= 1u << k;
+    PROF_MARK(J, 6, 8);
+    // every insertion row is evaluated by one thread (round 6; by the lane that owns its position before — the vote is ~80 instructions a row, and the
+    // workgroup waited for its busiest lane: 18 k of the kernel's 62 k cycles, profiles/r6_k_rows_phases.txt).  A row no run reached holds no inserted
+    // base: '*' whatever the cover count, not informative.
+    for (uint32_t i = tid; i < min(RW_ICAP, n_irows - ch0); i += NT) {
+      const uint32_t adj = s_adj[i];
+      uint32_t cover = 0, p = 0;
+      if (adj) {
+        p = s_ip[i];
+        const uint32_t pw = p >> 5, pb = p & 31u;
+        cover = ((s_nin[pw] >> pb) & 1u) | (((s_nin[NW + pw] >> pb) & 1u) << 1) | (((s_nin[2 * NW + pw] >> pb) & 1u) << 2) |
+                (((s_nin[3 * NW + pw] >> pb) & 1u) << 3) | (((s_nin[4 * NW + pw] >> pb) & 1u) << 4);
       }
+      const uint32_t c5[5] = {adj & 31u, (adj >> 5) & 31u, (adj >> 10) & 31u, (adj >> 15) & 31u, cover - (adj >> 20)};
+      uint32_t ns = 0;
+#pragma unroll
+      for (int q = 0; q < 5; q++) ns += c5[q] >= 3u ? 1u : 0u;
+      s_iv[i] = (uint8_t)(vote5(c5, 4u) | ((ns >= 2u ? 1u : 0u) << 7));   // the target shows '*' on an insertion row
+      if (ns >= 2u) { atomicOr(&s_insup[p >> 5], 1u << (p & 31u)); atomicAdd(&s_nisup[p >> 5], 1u); }
     }
     __syncthreads();
+    PROF_MARK(J, 6, 9);
+    if (lane0) { insup = s_insup[lt]; n_isup = s_nisup[lt]; }   // (they accumulate over the passes)
     {
       const uint32_t nb = min(RW_ICAP, n_irows - ch0);
       uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(J.cons_tmp + wd.row_off + ch0);   // row_off and ch0 are multiples of 16
