@@ -1184,6 +1184,7 @@ constexpr uint32_t RW_ICAP = HERRO_RW_ICAP;   // insertion rows per pass (accumu
 __host__ __device__ inline size_t rows_lds(uint32_t W) { return (size_t)(W + 2 + ((W + 2) >> 5) + 1) * 4; }
 
 constexpr uint32_t RW_SUPCAP = 256;   // informative rows of a window whose receptive fields k_rows gathers itself (a window with more: k_rfq, for the whole job)
+template <int SP>
 __device__ __forceinline__ void rf_slot(const JobDev& J, const CTab* __restrict__ s_ct, const WinDesc& wd, uint32_t Lf, uint32_t half, uint32_t c,
                                         uint32_t srow, uint32_t pj, uint32_t nr, bool have_nr, uint4* __restrict__ out);
 
@@ -1465,7 +1466,9 @@ __global__ __launch_bounds__(2 * NW) void k_rows(JobDev J) {
       const uint32_t nslots = total * HERRO_ROWS;
       for (uint32_t sl = tid; sl < nslots; sl += NT) {
         const uint32_t k = sl / HERRO_ROWS, c = sl - k * HERRO_ROWS;
-        rf_slot(J, s_ct, wd, Lf, J.rf_half, c, s_sup[0][k], s_sup[1][k], s_sup[2][k], true, reinterpret_cast<uint4*>(J.rf + ((uint64_t)base * HERRO_ROWS + sl) * 16));
+        uint4* __restrict__ out = reinterpret_cast<uint4*>(J.rf + ((uint64_t)base * HERRO_ROWS + sl) * 16);
+        if (J.rf_half <= 2u) rf_slot<5>(J, s_ct, wd, Lf, J.rf_half, c, s_sup[0][k], s_sup[1][k], s_sup[2][k], true, out);   // (uniform)
+        else rf_slot<8>(J, s_ct, wd, Lf, J.rf_half, c, s_sup[0][k], s_sup[1][k], s_sup[2][k], true, out);
       }
     }
     PROF_MARK(J, 6, 5);
@@ -1717,6 +1720,7 @@ constexpr int RQ_NT = 512;   // ~470 slots per window: one per thread — a slot
 // the read store.
 // One receptive-field record: the tokens and qualities of the rows srow - half .. around informative row (pj = position | ordinal << 16) in column c.
 // have_nr: nr carries the row counts of the four positions around (k_rows); else the rows come from row_of_pos2.
+template <int SP>   // rows of a record the slot fills: 5 (receptive field of half 2, the model's) or 8 — the arrays below are per row, and with 8 of each the kernel held 104 registers (round 6)
 __device__ __forceinline__ void rf_slot(const JobDev& J, const CTab* __restrict__ s_ct, const WinDesc& wd, uint32_t Lf, uint32_t half, uint32_t c,
                                         uint32_t srow, uint32_t pj, uint32_t nr, bool have_nr, uint4* __restrict__ out) {
   const uint32_t nw = J.nw;
@@ -1728,7 +1732,7 @@ __device__ __forceinline__ void rf_slot(const JobDev& J, const CTab* __restrict_
   const uint32_t* __restrict__ rop = J.row_of_pos2 + wd.pos_off;
   const int32_t pc = (int32_t)(pj & 0xffffu);
   const int64_t row0 = (int64_t)srow - (int64_t)half;
-  uint32_t rv[8];   // first row of positions pc - half + i
+  uint32_t rv[SP];   // first row of positions pc - half + i
   if (have_nr && half == 2) {   // lean path: the neighbours' row counts came with the informative row (k_rows) — one round trip less, no row_of_pos2
     const uint32_t rc = srow - (pj >> 16);                      // row of position pc
     rv[2] = rc;
@@ -1736,36 +1740,36 @@ __device__ __forceinline__ void rf_slot(const JobDev& J, const CTab* __restrict_
     rv[0] = rv[1] - (nr & 63u);
     rv[3] = rc + ((nr >> 12) & 63u);
     rv[4] = rv[3] + ((nr >> 18) & 63u);
-    rv[5] = rv[6] = rv[7] = 0;
+    if constexpr (SP > 5) { rv[5] = 0; rv[6] = 0; rv[7] = 0; }
   } else {
 #pragma unroll
-    for (int i = 0; i < 8; i++) rv[i] = rop[(uint32_t)min(max(pc - (int32_t)half + i, 0), (int32_t)win_len)];
+    for (int i = 0; i < SP; i++) rv[i] = rop[(uint32_t)min(max(pc - (int32_t)half + i, 0), (int32_t)win_len)];
   }
-  uint32_t rm[8];
+  uint32_t rm[SP];
 #pragma unroll
-  for (int d = 0; d < 8; d++) {
+  for (int d = 0; d < SP; d++) {
     const int64_t r = row0 + d;
     rm[d] = NONE;
     if ((uint32_t)d < span && r >= 0 && r < (int64_t)Lf) {
       int32_t pp = 0;
       uint32_t rb = 0;
 #pragma unroll
-      for (int i = 0; i < 8; i++) {
+      for (int i = 0; i < SP; i++) {
         const int32_t q = pc - (int32_t)half + i;
         if ((uint32_t)i <= 2 * half && q >= 0 && q < (int32_t)win_len && (int64_t)rv[i] <= r) { pp = q; rb = rv[i]; }
       }
       rm[d] = (uint32_t)pp | (((uint32_t)r - rb) << 16);
     }
   }
-  uint64_t addr[8];
-  uint32_t tok[8];
+  uint64_t addr[SP];
+  uint32_t tok[SP];
 #pragma unroll
-  for (int d = 0; d < 8; d++) { addr[d] = NONE64; tok[d] = TOK_NONE; }
+  for (int d = 0; d < SP; d++) { addr[d] = NONE64; tok[d] = TOK_NONE; }
   const CTab& q = s_ct[c];
   if (c == 0) {
     const uint64_t tw = s_ct[0].q_woff;
 #pragma unroll
-    for (int d = 0; d < 8; d++) {
+    for (int d = 0; d < SP; d++) {
       if (rm[d] == NONE) continue;
       tok[d] = TOK_GAP_F;   // the target shows '*' on an insertion row
       if ((rm[d] >> 16) == 0) {
@@ -1779,7 +1783,7 @@ __device__ __forceinline__ void rf_slot(const JobDev& J, const CTab* __restrict_
     const uint32_t tbase = q.tokc & 0xffu, tgap = q.tokc >> 8;
     uint32_t p0 = NONE;   // position of the slot's first row inside the window
 #pragma unroll
-    for (int d = 7; d >= 0; d--) if (rm[d] != NONE) p0 = rm[d] & 0xffffu;
+    for (int d = SP - 1; d >= 0; d--) if (rm[d] != NONE) p0 = rm[d] & 0xffffu;
     if (p0 != NONE) {
       const uint32_t w0 = min(p0 >> 5, nw - 1u), w1 = min(w0 + 1u, nw - 1u);
       const uint4* __restrict__ cw = J.cw + (uint64_t)q.ow * nw;
@@ -1799,7 +1803,7 @@ __device__ __forceinline__ void rf_slot(const JobDev& J, const CTab* __restrict_
       uint32_t pl = p0;
       bool ins_row = false;
 #pragma unroll
-      for (int d = 0; d < 8; d++) if (rm[d] != NONE) { pl = rm[d] & 0xffffu; ins_row = ins_row || (rm[d] >> 16) != 0; }
+      for (int d = 0; d < SP; d++) if (rm[d] != NONE) { pl = rm[d] & 0xffffu; ins_row = ins_row || (rm[d] >> 16) != 0; }
       const bool quiet = d0.y != 0xffffffffu && d1.y != 0xffffffffu && w1 != w0 && (d1.y >> 20) == e && (pl >> 5) == w0 && !ins_row;
       // the next four events travel together (one round trip for nearly every slot; a fifth is fetched when the walk gets there)
       const uint32_t e_first = e;
@@ -1822,7 +1826,7 @@ __device__ __forceinline__ void rf_slot(const JobDev& J, const CTab* __restrict_
       uint4 ecur = ep0;
       uint32_t cum = 0;   // bases inserted behind positions [32 w0, p)
 #pragma unroll
-      for (int d = 0; d < 8; d++) {
+      for (int d = 0; d < SP; d++) {
         if (rm[d] == NONE) continue;
         const uint32_t p = rm[d] & 0xffffu, j = rm[d] >> 16;
         while ((ecur.x & 0xffffu) < p) {   // events in front of p: [.., e)
@@ -1871,21 +1875,28 @@ __device__ __forceinline__ void rf_slot(const JobDev& J, const CTab* __restrict_
       }
     }
   }
-  uint32_t qv[8];
+  uint32_t qv[SP];
 #pragma unroll
-  for (int d = 0; d < 8; d++) qv[d] = J.read_qual[addr[d] == NONE64 ? 0 : addr[d]];
+  for (int d = 0; d < SP; d++) qv[d] = J.read_qual[addr[d] == NONE64 ? 0 : addr[d]];
   uint32_t lo = 0, hi = 0, tl = 0, th = 0;
 #pragma unroll
   for (int d = 0; d < 4; d++) {
     lo |= (addr[d] == NONE64 ? 33u : qv[d]) << (8 * d);
-    hi |= (addr[d + 4] == NONE64 ? 33u : qv[d + 4]) << (8 * d);
     tl |= tok[d] << (8 * d);
-    th |= tok[d + 4] << (8 * d);
+    if (d + 4 < SP) {   // (compile time)
+      hi |= (addr[(d + 4) % SP] == NONE64 ? 33u : qv[(d + 4) % SP]) << (8 * d);
+      th |= tok[(d + 4) % SP] << (8 * d);
+    } else {
+      hi |= 33u << (8 * d);
+      th |= (uint32_t)TOK_NONE << (8 * d);
+    }
   }
   *out = make_uint4(tl, th, lo, hi);
 }
 
-__global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const uint64_t* __restrict__ sup_off, uint8_t* __restrict__ rf, uint64_t cap, uint32_t have_nr) {
+template <int SP>
+__global__ __launch_bounds__(RQ_NT) void k_rfq(
+JobDev J, uint32_t half, const uint64_t* __restrict__ sup_off, uint8_t* __restrict__ rf, uint64_t cap, uint32_t have_nr) {
   __shared__ __attribute__((aligned(16))) CTab s_ct[32];
   const uint32_t w = gridDim.x - 1u - blockIdx.x, tid = threadIdx.x;   // back to front: k_rows has just walked the windows front to back — its last windows' plane records are the cached ones
   PROF_BEGIN(J);
@@ -1911,7 +1922,7 @@ __global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const ui
     const uint32_t k = sl / HERRO_ROWS, c = sl - k * HERRO_ROWS;
     const uint32_t pj = J.sup_pi[wd.row_off + k], srow = J.sup_row[wd.row_off + k];
     const uint32_t nr = have_nr ? J.sup_nr[wd.row_off + k] : 0u;
-    rf_slot(J, s_ct, wd, Lf, half, c, srow, pj, nr, have_nr != 0u, reinterpret_cast<uint4*>(rf + (out0 + sl) * 16));
+    rf_slot<SP>(J, s_ct, wd, Lf, half, c, srow, pj, nr, have_nr != 0u, reinterpret_cast<uint4*>(rf + (out0 + sl) * 16));
     PROF_MARK(J, 5, 1);
   }
 }
@@ -2155,7 +2166,8 @@ void launch_rf_quals(const JobDev& J, uint32_t half, const uint64_t* sup_off, ui
   if (!J.n_win) return;
   KT_BEGIN(tm, "rf_quals", st);
   if (rf && 2 * half + 1 <= 8) {
-    hipLaunchKernelGGL(k_rfq, dim3(J.n_win), dim3(RQ_NT), 0, st, J, half, sup_off, rf, cap, (lean ? 1u : 0u) | (left_only ? 2u : 0u));
+    if (half <= 2u) hipLaunchKernelGGL(k_rfq<5>, dim3(J.n_win), dim3(RQ_NT), 0, st, J, half, sup_off, rf, cap, (lean ? 1u : 0u) | (left_only ? 2u : 0u));
+    else hipLaunchKernelGGL(k_rfq<8>, dim3(J.n_win), dim3(RQ_NT), 0, st, J, half, sup_off, rf, cap, (lean ? 1u : 0u) | (left_only ? 2u : 0u));
     KT_END(tm, st);
     return;
   }
