@@ -4,10 +4,11 @@
 // global round trips in front of its arithmetic; k_cols and k_tokens end up bound by VALU issue (a wave64 instruction holds
 // its SIMD four cycles on gfx950), the rest by latency (DESIGN.md §4 has the counters).
 //
-//   k_cols      one WAVE per overlap-window, no barriers: CIGAR ops -> prefix sums (DPP wave scans) -> table of M/D
-//               ops + bitmap of op starts (rank directory, one popcount finds the op covering a position) -> the
+//   k_cols      one WAVE per overlap-window, no barriers: CIGAR ops -> prefix sums (DPP wave scans) -> the
 //               overlap's column as three BIT PLANES over the window's target positions (M: a query base is aligned
-//               here; lo / hi: its 2-bit code), 32 positions per lane, from the bit-plane copy of the read store;
+//               here; lo / hi: its 2-bit code) from the bit-plane copy of the read store: the lane of an M op writes the
+//               op's stretch of the word it starts in, the lane that owns a word of 32 positions adds the op that covers
+//               the word's first position (a prefix maximum over per-word slots finds it; round 6);
 //               insertion events (position, length, first bases).  From the planes: accuracy (features.rs:585-679) =
 //               popcounts of M & (query ^ target); long-indel filter (features.rs:315-324).
 //   k_win       one workgroup per window: informative positions of pass 1 in bit-sliced counters over the kept
@@ -1895,8 +1896,7 @@ __device__ __forceinline__ void rf_slot(const JobDev& J, const CTab* __restrict_
 }
 
 template <int SP>
-__global__ __launch_bounds__(RQ_NT) void k_rfq(
-JobDev J, uint32_t half, const uint64_t* __restrict__ sup_off, uint8_t* __restrict__ rf, uint64_t cap, uint32_t have_nr) {
+__global__ __launch_bounds__(RQ_NT) void k_rfq(JobDev J, uint32_t half, const uint64_t* __restrict__ sup_off, uint8_t* __restrict__ rf, uint64_t cap, uint32_t have_nr) {
   __shared__ __attribute__((aligned(16))) CTab s_ct[32];
   const uint32_t w = gridDim.x - 1u - blockIdx.x, tid = threadIdx.x;   // back to front: k_rows has just walked the windows front to back — its last windows' plane records are the cached ones
   PROF_BEGIN(J);
