@@ -280,3 +280,47 @@ def test_zero_copy_job_creation_from_a_registered_blob():
     job.featurize()
     assert G.compare_features(job, sb, store, W) > 0
     job.close()
+
+
+def test_window_slice_with_a_query_span_above_the_staged_planes():
+    """k_cols stages a slice's query planes in LDS — cols_qcap(nw) = nw + 40 words; a window whose slice consumes more query than that (thirty insertions of 50 bases,
+    the longest the long-indel filter keeps, inside one 256-base window: 1650 query bases = 53 words against 48) reads the read store directly instead.  Both
+    strands; the deletions that keep the alignment's spans are spread over the other windows."""
+    W, n_ins, ins = 256, 30, 50
+    sb = synth.generate(2, 2300, 12, seed=4242, flank_min=30, flank_max=60)
+    tgt_of = np.searchsorted(sb.tgt_aln_off, np.arange(len(sb.aln)), side="right") - 1
+    kept, strands = {}, set()
+    for a in range(len(sb.aln)):
+        row = [int(x) for x in sb.aln[a, :9]]
+        qspan, tspan = row[3] - row[2], row[8] - row[7]
+        head = (-row[7]) % W + 8                                  # the insertions start 8 positions into a window
+        used_t, used_q = head + 5 * n_ins, head + (ins + 5) * n_ins
+        rest_t, rest_q = tspan - used_t, qspan - used_q
+        d_total = rest_t - rest_q
+        if rest_q < 64 or d_total < 0 or a % 3 == 2:
+            continue
+        dels = [40] * (d_total // 40) + ([d_total % 40] if d_total % 40 else [])
+        if rest_q < len(dels) + 1:
+            continue
+        ms = [rest_q // (len(dels) + 1)] * (len(dels) + 1)
+        ms[-1] += rest_q - sum(ms)
+        tail = "".join(f"{m}M{d}D" for m, d in zip(ms, dels)) + f"{ms[-1]}M"
+        cg = f"{head}M" + "".join(f"{ins}I5M" for _ in range(n_ins)) + tail
+        trial = _with_cigars(sb, {**kept, a: (None, cg.encode())})
+        try:
+            rid, rows, cigs = O.target_alignments(trial, int(tgt_of[a]))
+            O.store_from_synth(trial).extract_features(rid, rows, cigs, W)
+            kept[a] = (None, cg.encode())
+            strands.add(row[4])
+        except O.OracleError:
+            pass
+    assert len(kept) >= 4 and strands == {0, 1}, (len(kept), strands)
+    sb2 = _with_cigars(sb, kept)
+    c = G.ctx()
+    G.load_synth(c, sb2)
+    store = O.store_from_synth(sb2)
+    job = api.job_from_synth(c, sb2, W)
+    assert job.skipped() == (0, 0)
+    job.featurize()
+    assert G.compare_features(job, sb2, store, W) > 0
+    job.close()
