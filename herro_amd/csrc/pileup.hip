@@ -103,16 +103,6 @@ __device__ __forceinline__ uint32_t glb_bits(const uint32_t* __restrict__ pl, ui
   return __funnelshift_r(pl[min(w, wmax)], pl[min(w + 1, wmax)], (uint32_t)s & 31u);
 }
 
-// bits 0..15 of x -> even bit positions 0, 2, .. 30
-__device__ __forceinline__ uint32_t spread16(uint32_t x) {
-  x &= 0xffffu;
-  x = (x | (x << 8)) & 0x00ff00ffu;
-  x = (x | (x << 4)) & 0x0f0f0f0fu;
-  x = (x | (x << 2)) & 0x33333333u;
-  x = (x | (x << 1)) & 0x55555555u;
-  return x;
-}
-
 struct ColPlanes { uint32_t m, lo, hi, gap; };  // per position bit: query base present / code planes / deletion
 
 template <int NB>
