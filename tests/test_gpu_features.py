@@ -324,3 +324,26 @@ def test_window_slice_with_a_query_span_above_the_staged_planes():
     job.featurize()
     assert G.compare_features(job, sb2, store, W) > 0
     job.close()
+
+
+@pytest.mark.parametrize("trial", range(16))
+def test_features_bit_exact_on_random_configurations(trial):
+    """A seeded sweep over window sizes, depths, error rates and partial overlaps (round 6: k_cols' plane build was re-formulated — op lanes write the word they start in, one op
+    per word left to the walk — and every such combination runs the multi-batch, clipped and reverse-strand branches in different proportions): oracle vs HIP, cell by cell."""
+    g = np.random.default_rng(0x6a09e667 + trial)
+    W = int(g.choice([16, 48, 100, 256, 512, 1000, 2048, 4096, 8192]))
+    n_win = int(g.integers(1, 4))
+    tl = n_win * W + int(g.integers(0, W))
+    ov = int(g.integers(1, 40))
+    fl = max(2, min(W // 4, 400))
+    kw = dict(flank_min=fl // 2 + 1, flank_max=fl + 2, p_sub=float(g.choice([0.002, 0.01, 0.05])), p_ins=float(g.choice([0.002, 0.01, 0.06])),
+              p_del=float(g.choice([0.002, 0.01, 0.06])), p_partial=float(g.choice([0.0, 0.3, 0.7])), p_long_indel=float(g.choice([0.0, 0.0, 0.02])),
+              p_snp=float(g.choice([0.0, 0.01])))
+    sb = synth.generate(int(g.integers(1, 4)), tl, ov, seed=int(g.integers(1, 1 << 30)), **kw)
+    c = G.ctx()
+    G.load_synth(c, sb)
+    store = O.store_from_synth(sb)
+    job = api.job_from_synth(c, sb, W)
+    job.featurize()
+    assert G.compare_features(job, sb, store, W) > 0, (W, tl, ov, kw)
+    job.close()
