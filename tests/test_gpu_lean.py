@@ -172,3 +172,43 @@ def test_receptive_field_records_are_the_oracles_cells(name):
             w += 1
     assert w == job.n_windows and (n_cells > 0 or name == "low_coverage")
     job.close()
+
+
+@pytest.mark.parametrize("trial", range(10))
+def test_lean_equals_planes_on_random_configurations(trial):
+    """A seeded sweep (round 6: k_rows evaluates the insertion rows one per thread from positions the run walkers leave and cover counts in LDS planes; k_rfq's records come in a
+    5-row instantiation): informative rows, logits bit for bit and FASTA of the lean path against the planes path on window sizes, depths and — above all — insertion
+    rates the named cases do not reach."""
+    g = np.random.default_rng(0xbb67ae85 + trial)
+    W = int(g.choice([100, 256, 512, 1000, 2048, 4096]))
+    tl = int(g.integers(1, 4)) * W + int(g.integers(0, W))
+    ov = int(g.integers(2, 45))
+    fl = max(8, min(W // 4, 300))
+    kw = dict(flank_min=fl // 2 + 1, flank_max=fl + 2, p_sub=float(g.choice([0.004, 0.02])), p_ins=float(g.choice([0.004, 0.03, 0.08])),
+              p_del=float(g.choice([0.004, 0.03])), p_partial=float(g.choice([0.0, 0.4])), p_snp=float(g.choice([0.0, 0.01, 0.05])))
+    sb = synth.generate(int(g.integers(1, 4)), tl, ov, seed=int(g.integers(1, 1 << 30)), **kw)
+    c = G.ctx()
+    G.load_synth(c, sb)
+    ids = [f"read{t}" for t in range(sb.n_targets)]
+    job = api.job_from_synth(c, sb, W)
+    other = None
+    try:
+        c.featurize_planes(False)
+        lean, fa_lean = _run(job, ids, 64)
+        other = api.job_from_synth(c, sb, W, targets=[0])
+        other.featurize()                                 # the caller pipelines: the fused gather
+        lean2, fa_lean2 = _run(job, ids, 64)
+        other.close(); other = None
+        c.featurize_planes(True)
+        planes, fa_planes = _run(job, ids, 64)
+    finally:
+        c.featurize_planes(False)
+        if other is not None:
+            other.close()
+    assert fa_lean == fa_planes == fa_lean2, (W, tl, ov, kw)
+    assert len(lean) == len(planes) > 0
+    for w, (a, b, a2) in enumerate(zip(lean, planes, lean2)):
+        assert a[:3] == b[:3] == a2[:3], (w, a[:3], b[:3])
+        assert a[3].tolist() == b[3].tolist() and a[4].tolist() == b[4].tolist(), (w, W, kw)
+        assert np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6]) and np.array_equal(a[5], a2[5]) and np.array_equal(a[6], a2[6]), (w, "logits differ")
+    job.close()
