@@ -122,30 +122,59 @@ __global__ __launch_bounds__(256) void k_window_cuts(BuildDev B) {
 
 // one block: exclusive prefix of the alignments' op counts
 __global__ __launch_bounds__(1024) void k_scan_alns(BuildDev B) {
-  __shared__ uint64_t s_part[1024];
-  const uint32_t tid = threadIdx.x, n = B.n_aln, per = (n + 1023) / 1024;
-  const uint32_t a0 = min(tid * per, n), a1 = min(a0 + per, n);
-  uint64_t local = 0;
-#pragma unroll 8
-  for (uint32_t a = a0; a < a1; a++) local += B.head[a].op_sum;   // (independent loads: unrolled so that they are in flight together — one block, its latency is the job's)
-  s_part[tid] = local;
-  __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {
-    const uint64_t v = tid >= d ? s_part[tid - d] : 0;
+  // One workgroup (its latency is the job's).  Round 6: the records are read and written COALESCED — lane t takes record r0 + 1024 j + t — and change hands through the LDS to the
+  // thread that scans eight consecutive ones; a thread reading ITS 32 consecutive records made every load instruction 64 separate cache-line requests on one compute unit (50 us
+  // for 33 k alignments, three passes of ~15), and the block scan was a 20-barrier ladder.
+  constexpr uint32_t E = 8, R = 1024 * E;
+  __shared__ uint32_t s_v[R + R / 32];   // record i at i + i / 32 (one pad word per 32: a thread's eight consecutive words against its neighbours')
+  __shared__ uint64_t s_wsum[16];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, n = B.n_aln;
+  auto at = [](uint32_t i) { return i + (i >> 5); };
+  uint64_t carry = 0;
+  for (uint32_t r0 = 0; r0 < n; r0 += R) {
+    uint32_t v[E];
+#pragma unroll
+    for (uint32_t j = 0; j < E; j++) {
+      const uint32_t e = r0 + j * 1024u + tid;
+      v[j] = e < n ? B.head[e].op_sum : 0u;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < E; j++) s_v[at(j * 1024u + tid)] = v[j];
     __syncthreads();
-    s_part[tid] += v;
+    uint32_t x[E];
+    uint64_t local = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < E; k++) { x[k] = s_v[at(tid * E + k)]; local += x[k]; }
+    uint64_t inc = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t o = __shfl_up(inc, d, 64);
+      if (lane >= (uint32_t)d) inc += o;
+    }
+    if (lane == 63u) s_wsum[wv] = inc;
     __syncthreads();
+    uint64_t base = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; w++) {
+      const uint64_t y = s_wsum[w];
+      if (w < wv) base += y;
+      total += y;
+    }
+    uint64_t run = carry + base + inc - local;
+#pragma unroll
+    for (uint32_t k = 0; k < E; k++) { s_v[at(tid * E + k)] = (uint32_t)run; run += x[k]; }   // (a thread's own eight words)
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < E; j++) {
+      const uint32_t e = r0 + j * 1024u + tid;
+      if (e < n) B.head[e].scr_base = s_v[at(j * 1024u + tid)];
+    }
+    carry += total;
+    __syncthreads();   // s_v and s_wsum go round again
   }
-  uint64_t run = s_part[tid] - local;
-#pragma unroll 8
-  for (uint32_t a = a0; a < a1; a++) {
-    const uint32_t v = B.head[a].op_sum;
-    B.head[a].scr_base = (uint32_t)run;
-    run += v;
-  }
-  if (tid == 1023) {
-    B.tot->scr_ops = s_part[1023];
-    if (s_part[1023] > 0xffffffffull) atomicOr(&B.tot->err, BLD_SIZE);
+  if (tid == 0) {
+    B.tot->scr_ops = carry;
+    if (carry > 0xffffffffull) atomicOr(&B.tot->err, BLD_SIZE);
   }
 }
 

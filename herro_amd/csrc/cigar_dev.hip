@@ -67,16 +67,17 @@ __device__ inline Op decode(uint32_t p, uint32_t start, LB lb) {
   Op r{(1u << 2) | OP_M, 0};
   const uint32_t nd = p - start;
   if (nd - 1u > 9u) { r.bad = 1; return r; }   // no digits, or more than ten
-  unsigned long long val = 0;
+  uint32_t val = 0, big = 0;   // 32-bit arithmetic (round 6): a value that is about to leave the 30 bits an op holds is flagged in front of the multiply that could wrap
   for (uint32_t j = 0; j < nd; j++) {
     const uint32_t d = (uint32_t)lb(start + j) - (uint32_t)'0';
     if (d > 9u) r.bad = 1;
-    val = val * 10 + d;
+    big |= val > 0x3fffffffu / 10u ? 1u : 0u;
+    val = val * 10u + d;
   }
   const uint32_t c = lb(p);
   const uint32_t ty = c == 'M' ? OP_M : c == 'I' ? OP_I : c == 'D' ? OP_D : 3u;
-  if (ty == 3u || val == 0 || val > 0x3fffffffull) { r.bad = 1; return r; }
-  if (!r.bad) r.op = ((uint32_t)val << 2) | ty;
+  if (ty == 3u || val == 0 || big || val > 0x3fffffffu) { r.bad = 1; return r; }
+  if (!r.bad) r.op = (val << 2) | ty;
   return r;
 }
 
@@ -98,10 +99,14 @@ __global__ __launch_bounds__(CW * 64) void k_cigar_scan(const uint8_t* __restric
   if (lane == 0) { s_txt[0] = make_uint4(0, 0, 0, 0); s_nc[wv] = 0; s_fl[wv] = 0; }
   uint32_t k_c = 0, t_c = a.tstart, q_c = 0, i_c = 0, prev1_c = skip;   // carries: ops so far, running totals, position + 1 of the last letter (the first op's digits start at `skip`)
   uint32_t flags = 0;
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (lane * CB < len) v = *reinterpret_cast<const uint4*>(s + lane * CB);
   for (uint32_t base = 0; base < len; base += CHUNK) {
     const uint32_t my = base + lane * CB;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (my < len) v = *reinterpret_cast<const uint4*>(s + my);
+    // the next step's bytes are requested before this step's are looked at (round 6: a text of the bench's alignments is two steps — the second load used to wait for the first step's
+    // two decoding passes and five scans)
+    uint4 vn = make_uint4(0, 0, 0, 0);
+    if (my + CHUNK < len) vn = *reinterpret_cast<const uint4*>(s + my + CHUNK);
     s_txt[1 + lane] = v;
     wave_lds_sync();
     auto lb = [&](uint32_t pos) -> uint32_t { return reinterpret_cast<const uint8_t*>(s_txt)[16u + pos - base]; };   // pos >= base - 16 (wraps correctly in u32)
@@ -110,6 +115,7 @@ __global__ __launch_bounds__(CW * 64) void k_cigar_scan(const uint8_t* __restric
     mask &= (1u << nvalid) - 1u;
     if (my < skip) mask &= ~((1u << (skip - my)) - 1u);   // (lane 0 of the first step)
     const uint32_t cnt = __popc(mask);
+    if (cnt > 8u) flags |= CIG_MALFORMED;   // more than eight letters in sixteen bytes: two of them are neighbours (an op without digits) — the passes below hold eight ops per lane
     const uint32_t last1 = mask ? my + (31u - __clz(mask)) + 1u : 0u;
     // ---- scan 1: position + 1 of the last letter in front of my bytes
     const uint32_t mx = wave_incl_max(last1);
@@ -121,18 +127,24 @@ __global__ __launch_bounds__(CW * 64) void k_cigar_scan(const uint8_t* __restric
     const uint32_t chunk_last1 = lane63(mx);
     // ---- pass 1: my totals
     uint32_t st = 0, sq = 0, si = 0;
+    uint32_t ro[8];   // my ops (16 bytes hold at most eight), decoded once: pass 2 reads them back (it decoded the text a second time until round 6)
     {
       uint32_t m = mask, start = prev1;
-      while (m) {
-        const uint32_t p = my + (uint32_t)__ffs(m) - 1u;
-        m &= m - 1;
-        const Op r = decode(p, start, lb);
-        flags |= r.bad ? CIG_MALFORMED : 0u;
-        const uint32_t ty = op_type(r.op), l = op_len(r.op);
-        st += ty != OP_I ? l : 0u;
-        sq += ty != OP_D ? l : 0u;
-        si += ty == OP_I ? l : 0u;
-        start = p + 1;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        ro[i] = 0;
+        if (m) {
+          const uint32_t p = my + (uint32_t)__ffs(m) - 1u;
+          m &= m - 1;
+          const Op r = decode(p, start, lb);
+          flags |= r.bad ? CIG_MALFORMED : 0u;
+          ro[i] = r.op;
+          const uint32_t ty = op_type(r.op), l = op_len(r.op);
+          st += ty != OP_I ? l : 0u;
+          sq += ty != OP_D ? l : 0u;
+          si += ty == OP_I ? l : 0u;
+          start = p + 1;
+        }
       }
     }
     // ---- scan 2: op index and running totals in front of my first op
@@ -141,13 +153,12 @@ __global__ __launch_bounds__(CW * 64) void k_cigar_scan(const uint8_t* __restric
     // ---- pass 2: emit
     if (mask) {
       unsigned long long wnext = ((unsigned long long)(t / W) + 1ull) * W;   // first window boundary above my running target position
-      uint32_t m = mask, start = prev1;
       uint32_t prev_i = 0;
       if (prev1 > skip && prev1 + 15u >= base) prev_i = lb(prev1 - 1u) == 'I';   // the op in front of mine (further back than the 16-byte halo: its successor has 16+ digits and is malformed anyway)
-      while (m) {
-        const uint32_t p = my + (uint32_t)__ffs(m) - 1u;
-        m &= m - 1;
-        const Op r = decode(p, start, lb);
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        if ((uint32_t)i >= cnt) break;
+        struct { uint32_t op; } r{ro[i]};
         const uint32_t ty = op_type(r.op), l = op_len(r.op);
         if (k < room) o[k] = r.op; else flags |= CIG_MALFORMED;
         const uint32_t is_i = ty == OP_I;
@@ -168,13 +179,13 @@ __global__ __launch_bounds__(CW * 64) void k_cigar_scan(const uint8_t* __restric
         ins += is_i ? l : 0u;
         prev_i = is_i;
         k++;
-        start = p + 1;
       }
     }
     k_c += lane63(in_n); t_c += lane63(in_t); q_c += lane63(in_q); i_c += lane63(in_i);
     prev1_c = max(prev1_c, chunk_last1);
     // every read of this step's text is issued (LDS operations of a wave execute in order): the next step's halo goes in
     if (lane == 63) s_txt[0] = v;
+    v = vn;
   }
   if (len && prev1_c != len) flags |= CIG_MALFORMED;   // text ends inside an op
   if (flags) atomicOr(&s_fl[wv], flags);
