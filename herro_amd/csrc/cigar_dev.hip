@@ -13,7 +13,8 @@
 //   scan 1     exclusive max over "position of my last letter": where the digits of my first op start
 //   pass 1     decode my ops (<= 8) from the wave's LDS copy of the step: per-lane op count and target / query / insertion totals
 //   scan 2     exclusive sums of those four (DPP)
-//   pass 2     decode again, now with op index and running totals known: write the op, test for a window boundary
+//   pass 2     the same ops (kept in registers: at most eight per lane), now with op index and running totals known: write the op, test for a window boundary
+//              (the next step's 1 KB is requested before the current one is looked at)
 // Malformed text (what CigarIter panics on, aligners.rs:252-293) only raises a flag; the host re-reads that one text
 // for the message.  Reference: extract_windows walks the same ops one by one on a feature thread (windowing.rs:44-273).
 #include "cigar_dev.h"
