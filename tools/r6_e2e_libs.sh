@@ -2,8 +2,8 @@
 # round 6: the end_to_end leg of two libraries on one box, alternating, three repeats (4096-window jobs, six feeders)
 # usage: gpurun --timeout 1500 -- bash tools/r6_e2e_libs.sh tag libA.so libB.so
 tag=$1; shift; out=gpurun_out/$tag; mkdir -p $out
-q="--no-cpu-baseline --self-check 0 --strong-windows 0 --repeats 0 --steps 64 --warmup 32 --sustained 0 --sensitivity 0 --long-run-steps 0"
-for rep in 1 2 3; do
+q="--no-cpu-baseline --self-check 0 --strong-windows 0 --repeats 0 --steps ${STEPS:-64} --warmup ${WARM:-32} --sustained 0 --sensitivity 0 --long-run-steps 0"
+for rep in 1 2 3 4; do
   for lib in "$@"; do
     HERRO_LIB=$PWD/herro_amd/$lib timeout 250 python bench.py $q > $out/${lib}_$rep.json 2>> $out/err.txt < /dev/null
     python - <<PY
