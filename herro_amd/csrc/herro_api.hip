@@ -2040,7 +2040,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   J.n_tiles = (uint32_t)job->tile_win.size(); J.window_size = W; J.nw = (W + 31) / 32; J.max_cols = max_cols;
   { const char* e = getenv("HERRO_DEBUG_CDIR_OVERFLOW"); J.dbg_flags = (e && atoi(e)) ? 1u : 0u; }
   cur = desc_bytes;
-  const size_t o_cw = take(((uint64_t)n_ow + 1) * J.nw * 16), o_iev = take(scr_ops * 16), o_ins_cnt = take((uint64_t)n_ow * 4);
+  const size_t o_cw = take(((uint64_t)n_ow + 1) * J.nw * 12), o_cwd = take(((uint64_t)n_ow + 1) * J.nw * 4), o_iev = take(scr_ops * 16), o_ins_cnt = take((uint64_t)n_ow * 4);
   const size_t o_ocol = take((uint64_t)n_ow * 16);
   const size_t o_keep = take(n_ow), o_acc = take((uint64_t)n_ow * 4), o_ttot = take((uint64_t)n_ow * 4);
   const size_t o_slot = take((uint64_t)n_ow * 4), o_rqid = take((uint64_t)n_ow * 4), o_sel = take((uint64_t)n_win * 32 * 4);
@@ -2064,7 +2064,7 @@ herro_job* herro_job_create(herro_ctx* ctx, uint32_t n_targets, const uint32_t* 
   unsigned char* db = (unsigned char*)job->dev.p;
   J.ops = ds ? (const uint32_t*)job->scan.p : (const uint32_t*)(db + o_ops); J.ow = (const OwDesc*)(db + o_ow); J.win = (const WinDesc*)(db + o_win);
   J.tile_win = (const uint32_t*)(db + o_tw); J.tile_r0 = (const uint32_t*)(db + o_tr);
-  J.cw = (uint4*)(db + o_cw); J.iev = (uint4*)(db + o_iev); J.ins_cnt = (uint32_t*)(db + o_ins_cnt); J.ocol = (uint4*)(db + o_ocol);
+  J.cw = (PlaneRec*)(db + o_cw); J.cwd = (uint32_t*)(db + o_cwd); J.iev = (uint4*)(db + o_iev); J.ins_cnt = (uint32_t*)(db + o_ins_cnt); J.ocol = (uint4*)(db + o_ocol);
   J.ow_keep = (uint8_t*)(db + o_keep); J.ow_acc = (float*)(db + o_acc); J.ow_ttotal = (uint32_t*)(db + o_ttot);
   J.slot_ow = (uint32_t*)(db + o_slot); J.rank_qid = (uint32_t*)(db + o_rqid); J.sel_ow = (uint32_t*)(db + o_sel);
   J.ctab = (CTab*)(db + o_ctab); J.chdr2 = (uint2*)(db + o_chdr); J.tile_nsup = (uint32_t*)(db + o_tnsup);

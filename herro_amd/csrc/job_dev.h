@@ -41,6 +41,8 @@ struct __attribute__((aligned(16))) CTab {
   uint64_t q_woff;     // first bit-plane word of the read
 };
 
+struct PlaneRec { uint32_t m, lo, hi; };   // (12 bytes, 4-byte aligned: one global_load_dwordx3)
+
 struct JobDev {
   // ---- read store (context-owned; HBM-resident for the life of the context)
   const uint64_t* read_words;     // 2-bit packed bases, every read starts on a u64 boundary (+1 pad word)
@@ -64,9 +66,11 @@ struct JobDev {
   const uint32_t* tile_win;  // [n_tiles] window of each tile of HERRO_TILE rows (tiles cover the upper bound lub of every window)
   const uint32_t* tile_r0;   // [n_tiles] first row of the tile
   // ---- scratch / results
-  uint4* cw;             // [ow][nw] per word of 32 window positions of a kept overlap, ONE record: {M plane word (a query base is aligned here), low code bit, high
-                         // code bit (complemented for reverse-strand queries), directory word: alignment-orientation query index of the first base at or
-                         // behind position 32 * word | insertion events of the overlap in front of that position << 20 (0xffffffff: does not fit)}
+  PlaneRec* cw;          // [ow][nw] per word of 32 window positions of a kept overlap, ONE 12-byte record: {M plane word (a query base is aligned here), low code bit, high
+                         // code bit (complemented for reverse-strand queries)} — what k_win and k_rows stream (every column of every window), and
+  uint32_t* cwd;         // [ow][nw] the word's directory: alignment-orientation query index of the first base at or behind position 32 * word | insertion events of the
+                         // overlap in front of that position << 20 (0xffffffff: does not fit).  Only k_rfq reads it; inside the record (16 bytes, rounds 5-6) it was a quarter
+                         // of the bytes k_win / k_rows move
   uint4* iev;            // per overlap (at scr_off): insertion events {pos | trimmed len << 16, query index, first 16 bases, untrimmed len}
   uint32_t* ins_cnt;     // [ow] number of insertion events
   uint4* ocol;           // [ow] {window position where the overlap starts, target bases covered, kept, ratio class}

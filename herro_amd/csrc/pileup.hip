@@ -448,7 +448,8 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
     J.ocol[o] = make_uint4((uint32_t)off, t_total, keep ? 1u : 0u, d.cls);
   }
   if (keep) {
-    uint4* __restrict__ g = J.cw + (uint64_t)o * nw;
+    PlaneRec* __restrict__ g = J.cw + (uint64_t)o * nw;
+    uint32_t* __restrict__ gd = J.cwd + (uint64_t)o * nw;
 #pragma unroll
     for (int wi_i = 0; wi_i < NWI; wi_i++) {
       const uint32_t wi = lane + 64u * wi_i;
@@ -458,7 +459,8 @@ __global__ __launch_bounds__(CA_NT) void k_cols(JobDev J) {
         // plane arrays + an 8-byte directory record before: 20 bytes in four places — a slot of k_rfq touched four cache lines where it now
         // touches one, and k_win / k_rows issue one load per column instead of three).  Directory indices that do not fit (2^20 bases /
         // 2^12 events in one overlap-window) are flagged; k_rfq then counts
-        g[wi] = make_uint4(pM[wi_i], pL[wi_i], pH[wi_i], (dQ[wi_i] < (1u << 20) && de < 0xfffu && !(J.dbg_flags & 1u)) ? (dQ[wi_i] | (de << 20)) : 0xffffffffu);
+        g[wi] = PlaneRec{pM[wi_i], pL[wi_i], pH[wi_i]};
+        gd[wi] = (dQ[wi_i] < (1u << 20) && de < 0xfffu && !(J.dbg_flags & 1u)) ? (dQ[wi_i] | (de << 20)) : 0xffffffffu;
       }
     }
   }
@@ -517,9 +519,9 @@ __global__ __launch_bounds__(256) void k_win(JobDev J) {
 #pragma unroll
     for (int u = 0; u < UB; u++) {
       const uint64_t o = wd.ow_begin + min(c0 + u, n - 1u);
-      const uint4 g = J.cw[o * nw + widx];   // planes of overlaps that were not kept are never written: loaded, ignored
+      const PlaneRec g = J.cw[o * nw + widx];   // planes of overlaps that were not kept are never written: loaded, ignored
       oc[u] = ocol[o];
-      M[u] = g.x; L[u] = g.y; H[u] = g.z;
+      M[u] = g.m; L[u] = g.lo; H[u] = g.hi;
     }
 #pragma unroll
     for (int u = 0; u < UB; u++) {
@@ -577,9 +579,9 @@ __global__ __launch_bounds__(256) void k_win(JobDev J) {
 #pragma unroll
       for (int u = 0; u < UB; u++) {
         const uint64_t o = wd.ow_begin + min(c0 + u, n - 1u);
-        const uint4 g = J.cw[o * nw + widx];
+        const PlaneRec g = J.cw[o * nw + widx];
         oc2[u] = ocol[o];
-        M[u] = g.x; L[u] = g.y; H[u] = g.z;
+        M[u] = g.m; L[u] = g.lo; H[u] = g.hi;
       }
 #pragma unroll
       for (int u = 0; u < UB; u++) {
@@ -902,7 +904,7 @@ __global__ __launch_bounds__(TK_NT, 4) void k_tokens(JobDev J, uint32_t aux) {
       const uint32_t cp = it / WST, k = it - cp * WST, c = 1 + cp / 3, pi = cp - (c - 1) * 3;
       const uint32_t o = s_ct[c].ow;
       const uint32_t wi = min(w_lo + k, nw - 1u);
-      pv[u] = reinterpret_cast<const uint32_t*>(J.cw)[((o != NONE ? (uint64_t)o : 0ull) * nw + wi) * 4 + pi];
+      pv[u] = reinterpret_cast<const uint32_t*>(J.cw)[((o != NONE ? (uint64_t)o : 0ull) * nw + wi) * 3 + pi];
     }
     if (tid < wcnt) {
       const int32_t P = (int32_t)((w_lo + tid) << 5);
@@ -1244,8 +1246,8 @@ __global__ __launch_bounds__(2 * NW) void k_rows(JobDev J) {
 #pragma unroll
     for (int u = 0; u < UB; u++) {
       const uint32_t o = s_ct[cb + u].ow;
-      const uint4 g = J.cw[(o != NONE ? (uint64_t)o : 0ull) * nw + widx];
-      M[u] = g.x; L[u] = g.y; H[u] = g.z;
+      const PlaneRec g = J.cw[(o != NONE ? (uint64_t)o : 0ull) * nw + widx];
+      M[u] = g.m; L[u] = g.lo; H[u] = g.hi;
     }
     PROF_MARK(J, 6, 10);
 #pragma unroll
@@ -1533,7 +1535,7 @@ __global__ __launch_bounds__(PQ_NT) void k_quals(JobDev J, uint32_t half) {
         const uint32_t it = min(it0 + u * PQ_NT, items - 1u);
         const uint32_t c = it / nw, wi = it - c * nw;
         const uint32_t o = s_ct[c + 1].ow;
-        mv[u] = J.cw[(o != NONE ? (uint64_t)o : 0ull) * nw + wi].x;
+        mv[u] = J.cw[(o != NONE ? (uint64_t)o : 0ull) * nw + wi].m;
       }
 #pragma unroll
       for (int u = 0; u < MI; u++) {
@@ -1777,17 +1779,20 @@ __device__ __forceinline__ void rf_slot(const JobDev& J, const CTab* __restrict_
     for (int d = SP - 1; d >= 0; d--) if (rm[d] != NONE) p0 = rm[d] & 0xffffu;
     if (p0 != NONE) {
       const uint32_t w0 = min(p0 >> 5, nw - 1u), w1 = min(w0 + 1u, nw - 1u);
-      const uint4* __restrict__ cw = J.cw + (uint64_t)q.ow * nw;
-      const uint4 c0 = cw[w0], c1 = cw[w1];   // planes + directory word of the slot's (at most two) words: one cache line
-      const uint2 d0 = make_uint2(c0.x, c0.w), d1 = make_uint2(c1.x, c1.w);
-      const uint32_t l0 = c0.y, l1 = c1.y, h0 = c0.z, h1 = c1.z;
+      const PlaneRec* __restrict__ cw = J.cw + (uint64_t)q.ow * nw;
+      const uint32_t* __restrict__ cwd = J.cwd + (uint64_t)q.ow * nw;
+      const PlaneRec c0 = cw[w0], c1 = cw[w1];   // planes of the slot's (at most two) words, and their directory words — ONE 8-byte read: the word behind the row's last
+      uint2 dd;                                  // is the next overlap's first (or the array's spare row), and is not used
+      __builtin_memcpy(&dd, cwd + w0, 8);
+      const uint2 d0 = make_uint2(c0.m, dd.x), d1 = make_uint2(c1.m, w1 != w0 ? dd.y : dd.x);
+      const uint32_t l0 = c0.lo, l1 = c1.lo, h0 = c0.hi, h1 = c1.hi;
       const uint32_t m0 = d0.x, m1 = d1.x;
       const uint32_t n_ev = q.n_ev;
       const uint4* __restrict__ iev = J.iev + q.ev_off;
       uint32_t qw = d0.y & 0xfffffu, e = d0.y >> 20;
       if (d0.y == 0xffffffffu) {   // indices beyond the record's fields: count (M bits and events in front of the word)
         qw = 0; e = 0;
-        for (uint32_t i = 0; i < w0; i++) qw += (uint32_t)__popc(cw[i].x);
+        for (uint32_t i = 0; i < w0; i++) qw += (uint32_t)__popc(cw[i].m);
         while (e < n_ev && (iev[e].x & 0xffffu) < (w0 << 5)) { qw += iev[e].x >> 16; e++; }
       }
       // no insertion event between the two words' first positions and no row beyond: the event list is not needed
