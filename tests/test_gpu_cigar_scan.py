@@ -69,7 +69,12 @@ def test_device_scan_text_corner_cases():
     for bad, what in [(canon + b"12", "ends inside an op"), (b"M" + canon, "longer than 0"), (canon.replace(b"M", b"M0I", 1), "longer than 0"),
                       (canon.replace(b"M", b"m", 1), "Unexpected cigar operation"), (canon.replace(b"M", b":", 1), "Unexpected cigar operation"),
                       (canon.replace(b"M", b"\xc8", 1), "Unexpected cigar operation"), (b"99999999999M" + canon, "overflows 30 bits"),
-                      (canon[:5000] + b"X" + canon[5000:], "")]:
+                      (canon[:5000] + b"X" + canon[5000:], ""),
+                      # round 6 (the scan keeps a lane's ops in eight registers and decodes in 32-bit arithmetic): nine letters inside sixteen bytes with every one of the
+                      # first eight well-formed; lengths at and around the 30-bit limit, with and without leading zeros
+                      (canon[:4096] + b"1M1I1M1I1M1I1M1IM" + canon[4096:], "longer than 0"), (canon[:1600] + b"MMMMMMMMMMMMMMMM" + canon[1600:], "longer than 0"),
+                      (b"1073741824M" + canon, "overflows 30 bits"), (b"4294967297M" + canon, "overflows 30 bits"), (b"9999999999M" + canon, "overflows 30 bits"),
+                      (b"01073741824M" + canon, "")]:
         with pytest.raises(api.HerroError) as e:
             c.create_job(rid, row, aoff, [bad], 1000)
         assert what in str(e.value), (bad[:30], str(e.value))
