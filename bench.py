@@ -200,7 +200,7 @@ def main():
                     help="end_to_end feeders: 'serial' = one thread per context (create k+1, then execute k); 'producer' = a second "
                          "thread per context builds jobs ahead")
     ap.add_argument("--e2e-feeders", type=int, default=6, help="feeder threads (one context each) of the end_to_end leg")
-    ap.add_argument("--e2e-jobs", type=int, default=None, help="jobs per feeder thread in the end_to_end leg (default: 6 on one GPU, 0 = skipped on several)")
+    ap.add_argument("--e2e-jobs", type=int, default=None, help="jobs per feeder thread in the end_to_end leg (default: 24 on one GPU, 0 = skipped on several)")
     ap.add_argument("--self-check", type=int, default=6, help="targets compared with the oracle after the timing (0: skip)")
     ap.add_argument("--long-run-steps", type=int, default=None,
                     help="after a SHORT measurement (steps < 64, one GPU) the same device-resident leg is run once more with this many steps in a "
@@ -231,7 +231,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if args.e2e_jobs is None:   # the end_to_end leg is a single-GPU figure (6 feeder contexts per GPU would have 8 ranks fight for the host)
-        args.e2e_jobs = 6 if world == 1 else 0
+        # 24 jobs per feeder (round 6; 6 before): with 6 the timed region was ~60 ms, much of it the pipeline filling and draining — 1.06-1.45 M windows/s where, on the same
+        # box, 12 jobs measure 1.42-1.74 M, 16 1.73-1.77 M, 24 1.88-1.93 M, 32 1.96 M, 48 1.91 M (profiles/r6_e2e_jobs_per_feeder.txt: the leg levels off near 0.8 x value);
+        # the line says how many it ran (end_to_end.jobs_per_feeder)
+        args.e2e_jobs = 24 if world == 1 else 0
 
     from herro_amd import api, model_io, synth
     path, _ = model_io.default_model_file(os.path.join(ROOT, "tests", "_cache"))
