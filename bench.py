@@ -200,7 +200,7 @@ def main():
                     help="end_to_end feeders: 'serial' = one thread per context (create k+1, then execute k); 'producer' = a second "
                          "thread per context builds jobs ahead")
     ap.add_argument("--e2e-feeders", type=int, default=6, help="feeder threads (one context each) of the end_to_end leg")
-    ap.add_argument("--e2e-jobs", type=int, default=None, help="jobs per feeder thread in the end_to_end leg (default: 24 on one GPU, 0 = skipped on several)")
+    ap.add_argument("--e2e-jobs", type=int, default=None, help="jobs per feeder thread in the end_to_end leg (default: 32 on one GPU — 8 distinct jobs per feeder, cycled —, 0 = skipped on several)")
     ap.add_argument("--self-check", type=int, default=6, help="targets compared with the oracle after the timing (0: skip)")
     ap.add_argument("--long-run-steps", type=int, default=None,
                     help="after a SHORT measurement (steps < 64, one GPU) the same device-resident leg is run once more with this many steps in a "
@@ -231,10 +231,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if args.e2e_jobs is None:   # the end_to_end leg is a single-GPU figure (6 feeder contexts per GPU would have 8 ranks fight for the host)
-        # 24 jobs per feeder (round 6; 6 before): with 6 the timed region was ~60 ms, much of it the pipeline filling and draining — 1.06-1.45 M windows/s where, on the same
+        # 32 jobs per feeder, 8 distinct ones cycled (round 6; 6 before): with 6 the timed region was ~60 ms, much of it the pipeline filling and draining — 1.06-1.45 M windows/s where, on the same
         # box, 12 jobs measure 1.42-1.74 M, 16 1.73-1.77 M, 24 1.88-1.93 M, 32 1.96 M, 48 1.91 M (profiles/r6_e2e_jobs_per_feeder.txt: the leg levels off near 0.8 x value);
         # the line says how many it ran (end_to_end.jobs_per_feeder)
-        args.e2e_jobs = 24 if world == 1 else 0
+        args.e2e_jobs = 32 if world == 1 else 0
 
     from herro_amd import api, model_io, synth
     path, _ = model_io.default_model_file(os.path.join(ROOT, "tests", "_cache"))
@@ -260,7 +260,8 @@ def main():
     n_jobs = NS * pool
     tpj = G * targets_per_step                                  # targets per job
     NF = max(NS, args.e2e_feeders)                              # feeder threads (= contexts) of the end_to_end leg
-    n_e2e = args.e2e_jobs * NF if (args.e2e_jobs > 0 and n_full) else 0
+    E2E_DISTINCT = 8   # distinct jobs per feeder of the end_to_end leg (cycled when it runs more: 8 x 6 x 31 MB of CIGAR text and ~100 MB of reads per job are far beyond any cache)
+    n_e2e = min(args.e2e_jobs, E2E_DISTINCT) * NF if (args.e2e_jobs > 0 and n_full) else 0
     n_t = (n_jobs + n_e2e) * tpj + rem * targets_per_step
 
     def job_targets(i):
@@ -532,7 +533,8 @@ def main():
         run_feeders([[(s_i * pool + k) % n_jobs for k in range(n_warm)] for s_i in range(NF)], False)
         barrier()
         t1 = time.perf_counter()
-        run_feeders([[n_jobs + s_i * per + k for k in range(per)] for s_i in range(NF)], True)
+        dist_j = min(per, E2E_DISTINCT)
+        run_feeders([[n_jobs + s_i * dist_j + k % dist_j for k in range(per)] for s_i in range(NF)], True)
         el2 = time.perf_counter() - t1
         barrier()
         if world > 1:
@@ -540,16 +542,16 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el2 = float(tt.item())
         prep.unregister()
-        n_w = n_e2e * G * args.batch
+        n_w = per * NF * G * args.batch
         host_s = sum(s[0] for s in stats)
         e2e = {"windows_per_s": n_w * world / el2, "mbases_per_s": sum(s[1] for s in stats) * world / el2 / 1e6,
-               "windows": n_w * world, "usable_cpus": synth.usable_cpus(), "jobs_per_feeder": per, "feeders_per_gpu": NF, "warmup_jobs_per_feeder": n_warm,
+               "windows": n_w * world, "usable_cpus": synth.usable_cpus(), "jobs_per_feeder": per, "distinct_jobs_per_feeder": dist_j, "feeders_per_gpu": NF, "warmup_jobs_per_feeder": n_warm,
                "host_prepare_windows_per_s_per_feeder": n_w / NF / (host_s / NF) if host_s else None,
                "zero_copy_text": os.environ.get("HERRO_ZERO_COPY", "1") not in ("", "0"),
                "note": "herro_job_create from host alignments (CIGAR text copied up from the registered blob and scanned on the GPU, windows cut and descriptors written "
                        "on the device behind the scan — build_dev.hip, round 6; 64 bytes of totals and the window descriptors come back) + featurize + infer + consensus + "
                        "D2H of the corrected bases, all inside the timed region; "
-                       "fresh inputs per job; the alignments are resident on the host as one parsed array (what the reference's reader thread "
+                       "fresh inputs per job (a feeder cycles through its distinct jobs when it runs more than it has); the alignments are resident on the host as one parsed array (what the reference's reader thread "
                        "hands over, lib.rs:141-151); " + ("per context one thread builds jobs ahead, one executes them" if args.e2e_mode == "producer"
                                                      else "one feeder thread per context: create(k+1) runs on the host while the GPU works on job k"),
                "mode": args.e2e_mode}
