@@ -807,13 +807,8 @@ __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
     }
   };
   if constexpr (!TILES) {
-    for (uint32_t b = 0; b < nbatch; b++)
-      each_run(b, [&](const uint4& e, uint32_t hide, uint32_t, uint32_t) {
-        J.tev[wbase + atomicAdd(&s_nrun, 1u)] = make_uint4(e.x, e.y, e.z, lc | (hide << 8) | 0xffff0000u);   // tile field 0xffff: not split by tiles
-      });
-    __syncthreads();
-    if (tid == 0) J.tile_ev[tile0] = make_uint2(0u, s_nrun);   // the window's list: first slot, runs
-    (void)n_t;
+    // the lean path lists nothing: k_rows walks the selected columns' events itself (round 6; a flat run list per window until then)
+    (void)n_t; (void)tile0; (void)wbase; (void)each_run;
   } else {
   for (uint32_t b = 0; b < nbatch; b++)
     each_run(b, [&](const uint4&, uint32_t, uint32_t t_lo, uint32_t t_hi) {
@@ -1194,7 +1189,7 @@ __global__ __launch_bounds__(2 * NW) void k_rows(JobDev J) {
   __shared__ __attribute__((aligned(16))) CTab s_ct[32];
   __shared__ uint32_t s_adj[RW_ICAP];                              // per insertion row: inserted A, C, G, T (5 bits each), '*' they replace (bits 20..)
   __shared__ __attribute__((aligned(16))) uint8_t s_iv[RW_ICAP];   // ... its vote | informative << 7
-  __shared__ uint32_t s_nruns, s_rfbase;
+  __shared__ uint32_t s_rfbase;
   __shared__ uint32_t s_sup[3][RW_SUPCAP];                         // row, position | ordinal << 16, neighbours' row counts of the window's informative rows
   __shared__ uint32_t s_wave[NT / 64];
   const uint32_t w = blockIdx.x, tid = threadIdx.x, nw = J.nw;
@@ -1211,15 +1206,12 @@ __global__ __launch_bounds__(2 * NW) void k_rows(JobDev J) {
     const uint32_t* __restrict__ rop = J.row_of_pos2 + wd.pos_off;
 #pragma unroll
     for (int u = 0; u < RL; u++) rv[u] = rop[min(tid + (uint32_t)u * NT, win_len)];
-    uint2 te = make_uint2(0, 0);
-    if (tid == 0) te = J.tile_ev[tile0];   // the window's flat run list (k_layout<false>): first slot 0, number of runs
     if (tid < 32) s_ct[tid] = J.ctab[(uint64_t)w * 32 + tid];
 #pragma unroll
     for (int u = 0; u < RL; u++) {
       const uint32_t p = tid + (uint32_t)u * NT;
       if (p <= win_len) s_rop[RI(p)] = rv[u];
     }
-    if (tid == 0) s_nruns = te.x + te.y;
   }
   __syncthreads();
   PROF_MARK(J, 6, 0);
@@ -1320,41 +1312,48 @@ __global__ __launch_bounds__(2 * NW) void k_rows(JobDev J) {
   PROF_MARK(J, 6, 2);
   // ---- 2: insertion rows.  Index of an insertion row = its ordinal among the window's insertion rows = row - position - 1.
   const uint32_t n_irows = Lf - win_len;
-  const uint32_t n_runs = s_nruns;
-  const uint4* __restrict__ tev = J.tev + s_ct[0].ev_off;
   uint32_t n_isup = 0, insup = 0;   // informative insertion rows of this lane's positions; positions that have one
   for (uint32_t ch0 = 0; ch0 < n_irows; ch0 += RW_ICAP) {
     if (ch0) __syncthreads();   // the previous pass's votes are out
     for (uint32_t i = tid; i < min(RW_ICAP, n_irows - ch0); i += NT) s_adj[i] = 0;
     __syncthreads();
     PROF_MARK(J, 6, 7);
-    // inserted bases of the selected columns (features.rs:213-229), from the tiles' run lists: a run that crosses a tile boundary is
-    // listed by both tiles, each takes its own rows (the tile travels with the record); "hidden" rows were overwritten by a later
-    // insertion at the same position
-    constexpr int EU = 6;   // ~5 runs per thread at the bench workload: one round trip
-    uint4 ve[EU];
+    // inserted bases of the selected columns (features.rs:213-229), straight from the columns' event lists, NT / 32 threads per column (round 6: k_layout listed the
+    // runs of a window for this loop — 19 KB written and read back per window, a fifth of k_layout's time; what it worked out per run, the rows hidden by a later
+    // insertion of the same column at the same position, is three instructions here and a loop only where such a pair exists)
+    constexpr uint32_t TPC = NT / 32;
+    constexpr int EU = 6;   // ~5 events per thread at the bench workload: one round trip
+    const uint32_t c = tid / TPC, sub = tid % TPC;   // (column 31 is never a selected overlap)
+    const uint32_t ne = (c >= 1u && s_ct[c].ow != NONE) ? s_ct[c].n_ev : 0u;
+    const uint4* __restrict__ iev = J.iev + s_ct[c].ev_off;
+    for (uint32_t i0 = sub; i0 < ne; i0 += EU * TPC) {
+      uint4 ve[EU];
+      uint32_t nx[EU];
 #pragma unroll
-    for (int u = 0; u < EU; u++) ve[u] = n_runs ? tev[min(tid + u * NT, n_runs - 1u)] : make_uint4(0, 0, 0, 0);   // (uniform)
-    for (uint32_t e0 = tid; e0 < n_runs; e0 += EU * NT) {
-      if (e0 != tid) {
-#pragma unroll
-        for (int u = 0; u < EU; u++) ve[u] = tev[min(e0 + u * NT, n_runs - 1u)];
+      for (int u = 0; u < EU; u++) {
+        const uint32_t i = i0 + u * TPC;
+        ve[u] = iev[min(i, ne - 1u)];
+        nx[u] = iev[min(i + 1u, ne - 1u)].x;
       }
 #pragma unroll
       for (int u = 0; u < EU; u++) {
-        const uint32_t e = e0 + u * NT;
-        if (e >= n_runs) continue;
-        const uint32_t lo = ve[u].w >> 16;   // 0xffff: a run of the flat list (all its rows); else the tile that lists it takes the rows inside it
-        const uint32_t tr0 = lo == 0xffffu ? 0u : lo * ROWCAP, tr1 = lo == 0xffffu ? Lf : min(tr0 + ROWCAP, Lf);
-        const uint32_t c = ve[u].w & 0xffu, hide = (ve[u].w >> 8) & 0xffu;
+        const uint32_t i = i0 + u * TPC;
+        if (i >= ne) continue;
         const uint32_t p = ve[u].x & 0xffffu, len = ve[u].x >> 16;
         if (p >= win_len) continue;
         const uint32_t rp = s_rop[RI(p)], room = s_rop[RI(p + 1)] - rp - 1u;
+        uint32_t hide = 0;   // rows a later insertion of this column at the same position overwrote (features.rs:219-228: the reference's sequential writes)
+        if (i + 1u < ne && (nx[u] & 0xffffu) == p) {
+          hide = nx[u] >> 16;
+          for (uint32_t e2 = i + 2u; e2 < ne; e2++) {
+            const uint32_t x3 = iev[e2].x;
+            if ((x3 & 0xffffu) != p) break;
+            hide = max(hide, x3 >> 16);
+          }
+        }
         const bool inr = (uint32_t)((int32_t)p - s_ct[c].off) < s_ct[c].t_total;   // the default under it was '*' (counted), not '.'
         for (uint32_t k = hide; k < len && k < room; k++) {
-          const uint32_t row = rp + 1u + k;
-          if (row < tr0 || row >= tr1) continue;
-          const uint32_t ir = row - p - 1u - ch0;
+          const uint32_t ir = rp + k - p - ch0;   // row rp + 1 + k, ordinal row - p - 1
           if (ir >= RW_ICAP) continue;
           uint32_t code;
           if (k < 16u) code = ((ve[u].z >> k) & 1u) | (((ve[u].z >> (16u + k)) & 1u) << 1);
