@@ -657,9 +657,10 @@ __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
   const uint32_t win_len = wd.win_len;
   if (tid < 32) s_sel[tid] = NONE;
   if (tid == 0) { s_maxne = 0; s_nrun = 0; }
-  for (uint32_t t = tid; t < TCAP; t += LY_NT) s_tcnt[t] = 0;
+  if constexpr (TILES) for (uint32_t t = tid; t < TCAP; t += LY_NT) s_tcnt[t] = 0;
   for (uint32_t p = tid; p <= win_len; p += LY_NT) s_mi[MI(p)] = 0;
   __syncthreads();
+  PROF_MARK(J, 2, 5);
   // ---- score n/(n+d)*ln(n+d+1) in f64 (features.rs:505-510); stable descending rank (features.rs:512-513)
   {
     auto score_of = [&](uint32_t k) -> double {
@@ -674,16 +675,35 @@ __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
     if (cached) {
       for (uint32_t k = tid; k < n_kept; k += LY_NT) s_score[k] = score_of(k);
       __syncthreads();
+      PROF_MARK(J, 2, 6);
     }
     for (uint32_t k = tid; k < n_kept; k += LY_NT) {
+      // (round 6: the overlap's query id is requested BEFORE the ranking loop, and the loop reads its LDS scores eight at a time — one dependent LDS round trip per score and two
+      // dependent global ones behind the loop were 12 k of the kernel's 46 k cycles)
+      const uint32_t o = J.slot_ow[wd.ow_begin + k];
+      const uint32_t qid = J.ow[o].qid;
       const double sk = cached ? s_score[k] : score_of(k);
       uint32_t rank = 0;
-      for (uint32_t i = 0; i < n_kept; i++) {
-        const double si = cached ? s_score[i] : score_of(i);
-        if (si > sk || (si == sk && i < k)) rank++;
+      if (cached) {
+        uint32_t i = 0;
+        for (; i + 8 <= n_kept; i += 8) {
+          double sv[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) sv[u] = s_score[i + u];
+#pragma unroll
+          for (int u = 0; u < 8; u++) if (sv[u] > sk || (sv[u] == sk && i + u < k)) rank++;
+        }
+        for (; i < n_kept; i++) {
+          const double si = s_score[i];
+          if (si > sk || (si == sk && i < k)) rank++;
+        }
+      } else {
+        for (uint32_t i = 0; i < n_kept; i++) {
+          const double si = score_of(i);
+          if (si > sk || (si == sk && i < k)) rank++;
+        }
       }
-      const uint32_t o = J.slot_ow[wd.ow_begin + k];
-      J.rank_qid[wd.ow_begin + rank] = J.ow[o].qid;
+      J.rank_qid[wd.ow_begin + rank] = qid;
       if (rank < 30u) s_sel[rank + 1] = o;
     }
     __syncthreads();
@@ -743,7 +763,7 @@ __global__ __launch_bounds__(LY_NT) void k_layout(JobDev J) {
     for (int k = 0; k < 8; k++) {
       const uint32_t i = b * 64u + sub + 8u * k;
       v[k] = ne ? J.iev[eo + min(i, ne - 1u)] : make_uint4(0, 0, 0, 0);
-      hx[k] = ne ? J.iev[eo + min(i + 1u, ne - 1u)].x : 0u;
+      if constexpr (TILES) hx[k] = ne ? J.iev[eo + min(i + 1u, ne - 1u)].x : 0u; else hx[k] = 0u;   // (only the run lists look at the event behind)
     }
   };
   for (uint32_t b = 0; b < nbatch; b++) {
