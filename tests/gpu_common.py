@@ -14,6 +14,13 @@ CACHE = os.path.join(ROOT, "tests", "_cache")
 _CTX = {}
 
 
+
+def sweep_trials(n):
+    """Trial numbers of a seeded sweep: 0 .. n - 1 in the suite; HERRO_SWEEP_FIRST / HERRO_SWEEP_TRIALS move and widen the range for a soak run on the GPU box
+    (tools/r6_sweep_soak.sh; every trial is its own seed, so a failing one is reproduced by its number)."""
+    first = int(os.environ.get("HERRO_SWEEP_FIRST", "0") or 0)
+    return range(first, first + int(os.environ.get("HERRO_SWEEP_TRIALS", str(n)) or n))
+
 def ctx():
     if "c" not in _CTX:
         c = api.Context(0)

@@ -326,7 +326,7 @@ def test_window_slice_with_a_query_span_above_the_staged_planes():
     job.close()
 
 
-@pytest.mark.parametrize("trial", range(16))
+@pytest.mark.parametrize("trial", G.sweep_trials(16))
 def test_features_bit_exact_on_random_configurations(trial):
     """A seeded sweep over window sizes, depths, error rates and partial overlaps (round 6: k_cols' plane build was re-formulated — op lanes write the word they start in, one op
     per word left to the walk — and every such combination runs the multi-batch, clipped and reverse-strand branches in different proportions): oracle vs HIP, cell by cell."""

@@ -174,7 +174,7 @@ def test_receptive_field_records_are_the_oracles_cells(name):
     job.close()
 
 
-@pytest.mark.parametrize("trial", range(10))
+@pytest.mark.parametrize("trial", G.sweep_trials(10))
 def test_lean_equals_planes_on_random_configurations(trial):
     """A seeded sweep (round 6: k_rows evaluates the insertion rows one per thread from positions the run walkers leave and cover counts in LDS planes; k_rfq's records come in a
     5-row instantiation): informative rows, logits bit for bit and FASTA of the lean path against the planes path on window sizes, depths and — above all — insertion
