@@ -7,6 +7,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 from herro_amd import shard
 
@@ -190,7 +191,8 @@ WORKER3 = textwrap.dedent("""
 """)
 
 
-def test_per_rank_ingestion_three_ranks(tmp_path):
+@pytest.mark.parametrize("world", [3, 8])   # 8: the node the driver scales to — more ranks than targets (7), ranks that own nothing and ranks whose byte range holds no line of their own targets
+def test_per_rank_ingestion_three_ranks(tmp_path, world):
     """Round 4: no rank reads or ships the whole alignment set.  Every rank parses its own byte range of the PAF, one all-to-all
     takes every target to its owner (a hash of the read id), the owner merges the pieces in file order and drops a second alignment of a
     (query, target) pair ACROSS pieces as parse_paf does inside one file; the gathered FASTA equals the single-rank one, and the
@@ -217,8 +219,8 @@ def test_per_rank_ingestion_three_ranks(tmp_path):
     single = subprocess.run([sys.executable, str(script), "0", "1", str(path)], capture_output=True, text=True, env=env, timeout=240)
     assert single.returncode == 0, single.stderr
     want = json.loads(single.stdout.strip().splitlines()[-1])
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), "3", str(path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
-             for r in range(3)]
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(world)]
     outs = [p.communicate(timeout=240) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     got = json.loads(outs[0][0].strip().splitlines()[-1])
@@ -230,7 +232,7 @@ def test_per_rank_ingestion_three_ranks(tmp_path):
     paf = api.Paf(names, text=path.read_bytes())
     rows = paf.rows()
     merged = shard.merge_pieces([shard.shard_arrays(sh, np.arange(len(sh.tgt_rid))) for sh in
-                                 (shard.ingest_paf_range(shard.paf_byte_range(str(path), r, 3), names) for r in range(3))])
+                                 (shard.ingest_paf_range(shard.paf_byte_range(str(path), r, world), names) for r in range(world))])
     assert merged[0].tolist() == paf.targets.tolist() and merged[1].tolist() == paf.aln_off.tolist()
     for a in range(len(rows)):
         assert merged[2][a, :9].tolist() == list(rows[a][:9]) and merged[4][int(merged[3][a]):int(merged[3][a]) + int(merged[2][a, 9])].tobytes() == rows[a][9]
