@@ -18,7 +18,7 @@
 //
 // Kernels (same dataflow as model.hip, re-derived for one 2-byte plane per operand):
 //   k_conv_m   embedding + quality + conv1 as a K = 96 GEMM -> (registers) -> conv2 (K = 192) -> y2 as ONE f16 plane [N*31][128]
-//   k_fc_r     y2[N][3968] . Wfc -> x[N][256]; 128 (or 96) x 256 tiles, weights L2 -> registers, activations through the LDS, 2 workgroups per CU
+//   k_fc_r     y2[N][3968] . Wfc -> x[N][256]; (64 .. 128) x 256 tiles, weights L2 -> registers, activations through the LDS, 2 workgroups per CU
 //   k_layers_p the whole encoder stack per tile of <= 64 (or 32) tokens: residual stream in registers from the FC output to
 //              the logits (positional encoding added on the way in), weight fragments one half GEMM call ahead;
 //              <., 4, true>: the same grid headed by SIBLING tiles — a window of 65 .. 512 informative rows on ceil(rows / 64) tiles
@@ -412,16 +412,19 @@ __global__ __launch_bounds__(CM_NT, WPS) void k_conv_m(ModelDev M, BatchDev B, M
 constexpr int FR_ROWS = 128;                               // rows of an LDS buffer; a tile takes 32 * G of them
 constexpr size_t FC_R_SHM = (size_t)2 * FR_ROWS * 64 * 2;   // two buffers [128 rows][64 k] f16
 
-// G: groups of two 16-row blocks per tile, i.e. tiles of 32 * G rows (4: 128 rows; 3: 96 — chosen per launch so that the busiest compute unit
-// holds the fewest rows: 38.7 k rows in 128-row tiles are 303 workgroups, two on 47 of the 256 compute units and one on the others; in 96-row
-// tiles 403, and the two-workgroup units carry 192 rows instead of 256).
+// NB: 16-row blocks per tile, i.e. tiles of 16 * NB rows (4 .. 8: 64 .. 128 rows) — chosen per launch so that the busiest compute unit holds the fewest
+// rows (two workgroups fit a unit): 38.7 k rows in 128-row tiles are 303 workgroups, two on 47 of the 256 compute units and one on the others; in 96-row
+// tiles 404, and the two-workgroup units carry 192 rows; in 80-row tiles (round 6, last change: the tile height was 32 * G, G = 3 | 4, before) 484 — at most
+// two per unit, 160 rows where the even share would be 151.  The row blocks go through the k-step in pairs (one read of the weight fragments' registers per
+// pair); an odd NB leaves one block on its own.  The order of the k-steps per output element does not depend on NB: every height gives the same bits.
 // pe_tab (round 6): the positional encoding of a token's row is added HERE, from the table of herro_load_model (ModelDev::pe_tab), for rows inside the table — the stack's
 // prologue, where every compute unit fetches its tile at the same moment, reads 64 KB per tile instead of 128 (and ran 16 sincosf per lane before the table existed);
 // k_layers_p adds the encoding of the rows BEYOND the table itself (the same rule on both sides: row < pe_rows)
-template <int G>
+template <int NB>
 __global__ __launch_bounds__(512, 4) void k_fc_r(const uint16_t* __restrict__ A, uint32_t lda, Weight W, float* C, uint32_t ldc, uint32_t M,
                                                  const uint32_t* __restrict__ tok_row, const float* __restrict__ pe_tab, uint32_t pe_rows) {
-  constexpr int FR_TM = 32 * G;
+  constexpr int FR_TM = 16 * NB, G = (NB + 1) / 2;   // G: pairs of row blocks (the last one single when NB is odd)
+  static_assert(NB >= 3 && NB <= 8, "tiles of 48 .. 128 rows");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem_fc[];
   uint16_t* s_a = reinterpret_cast<uint16_t*>(smem_fc);   // [2][128][64]: row r at r * 128 B, 16-byte chunk c at (c ^ (r & 7))
   const uint32_t nks = W.K >> 5, nms = W.K >> 6;
@@ -434,14 +437,14 @@ __global__ __launch_bounds__(512, 4) void k_fc_r(const uint16_t* __restrict__ A,
 #endif
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t fr = lane & 15, fg = lane >> 4;
-  f32x4 acc[2 * G][2];
+  f32x4 acc[NB][2];
 #pragma unroll
-  for (int pt = 0; pt < 2 * G; pt++)
+  for (int pt = 0; pt < NB; pt++)
 #pragma unroll
     for (int jt = 0; jt < 2; jt++) acc[pt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
   // activation rows: thread t stages row (t >> 2), 16-byte chunks (t & 3) and (t & 3) + 4 of every 64-k tile
   const uint32_t srow = tid >> 2, sch = tid & 3;
-  const uint32_t lrow = srow < (uint32_t)FR_TM ? srow : srow - 32u;   // G = 3: the threads of rows 96..127 repeat rows 64..95 (same lines, no new traffic) into LDS rows nobody reads
+  const uint32_t lrow = srow < (uint32_t)FR_TM ? srow : srow - (uint32_t)(FR_ROWS - FR_TM);   // below 128 rows: the threads of the rows beyond the tile repeat its last rows (same lines, no new traffic) into LDS rows nobody reads
   const uint16_t* ga = A + (uint64_t)min(m0 + lrow, M - 1) * lda + sch * 8;
   const uint32_t sdst0 = srow * 64 + ((sch ^ (srow & 7u)) << 3), sdst1 = srow * 64 + (((sch + 4) ^ (srow & 7u)) << 3);
   // weights: fragment (jt, ks) of this wave's 32-column slab
@@ -462,6 +465,7 @@ __global__ __launch_bounds__(512, 4) void k_fc_r(const uint16_t* __restrict__ A,
     const uint16_t* t = s_a + buf * (FR_ROWS * 64);
 #pragma unroll
     for (int i = 0; i < 2; i++) {
+      if (g * 2 + i >= (uint32_t)NB) continue;   // (compile time: the loops around are unrolled)
       const uint32_t r = (g * 2 + i) * 16 + fr;
       x[i] = *reinterpret_cast<const half8*>(t + r * 64 + (((kk * 4 + fg) ^ (r & 7u)) << 3));
     }
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(512, 4) void k_fc_r(const uint16_t* __restrict__ A,
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-      for (int jt = 0; jt < 2; jt++) acc[g * 2 + i][jt] = mma(w[jt], x[i], acc[g * 2 + i][jt]);
+      for (int jt = 0; jt < 2; jt++) if (g * 2 + i < (uint32_t)NB) acc[g * 2 + i][jt] = mma(w[jt], x[i], acc[g * 2 + i][jt]);
   };
   // prologue: tile 0 into LDS, tile 1 in flight, weights of k-steps 0, 1
   {
@@ -524,11 +528,11 @@ __global__ __launch_bounds__(512, 4) void k_fc_r(const uint16_t* __restrict__ A,
 #pragma unroll
     for (int q = 0; q < 8; q++) bs[q] = W.bias ? bp[q] : 0.f;
   }
-  uint32_t prow[2 * G];
+  uint32_t prow[NB];
 #pragma unroll
-  for (int pt = 0; pt < 2 * G; pt++) prow[pt] = pe_tab ? tok_row[min(m0 + pt * 16 + fr, M - 1)] : 0xffffffffu;
+  for (int pt = 0; pt < NB; pt++) prow[pt] = pe_tab ? tok_row[min(m0 + pt * 16 + fr, M - 1)] : 0xffffffffu;
 #pragma unroll
-  for (int pt = 0; pt < 2 * G; pt++) {
+  for (int pt = 0; pt < NB; pt++) {
     const uint32_t m = m0 + pt * 16 + fr;
     if (m < M) {
       float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
@@ -1395,15 +1399,25 @@ void launch_model_h(const ModelDev& M, const BatchDev& B, const ModelScratch& S,
     }
   };
   auto fc = [&](uint32_t t0, uint32_t t1) {
-    // tile height: the one that leaves the busiest compute unit the fewest rows (two workgroups fit a unit; HERRO_FC_G forces it in A/B builds)
+    // tile height (16-row blocks, 4 .. 8): the one that leaves the busiest compute unit the fewest rows — two workgroups fit a unit, a third would wait for a slot —, the taller
+    // one on a tie (every workgroup streams the whole weight matrix: fewer of them, less L2 traffic).  HERRO_FC_G forces a height in A/B builds (3 | 4: the 96 | 128 rows of
+    // the kernel's first version, 5 .. 8 and 14 (= 4): blocks)
     const uint32_t n = t1 - t0, lda = HERRO_ROWS * h.c2;
     auto busiest = [&](uint32_t rows) { const uint32_t wg = (n + rows - 1) / rows; return (uint64_t)((wg + n_cu - 1) / n_cu) * rows + (wg > 2 * n_cu ? 1u << 20 : 0u); };
-    const int g = force_g == 3 || force_g == 4 ? force_g : (busiest(96) < busiest(128) ? 3 : 4);
+    int nb = 8;
+    for (int b = 7; b >= 4; b--) if (busiest(16u * b) < busiest(16u * nb)) nb = b;
+    if (force_g == 3) nb = 6; else if (force_g == 4) nb = 8; else if (force_g == 14) nb = 4; else if (force_g >= 5 && force_g <= 8) nb = force_g;
     const uint16_t* A = S.y2_hi + (uint64_t)t0 * lda;
     float* C = S.x + (uint64_t)t0 * h.d_model;
     const uint32_t* rows = S.tok_row + t0;
-    if (g == 3) hipLaunchKernelGGL(k_fc_r<3>, dim3((n + 95) / 96), dim3(512), FC_R_SHM, st, A, lda, M.fc, C, h.d_model, n, rows, M.pe_tab, M.pe_rows);
-    else hipLaunchKernelGGL(k_fc_r<4>, dim3((n + 127) / 128), dim3(512), FC_R_SHM, st, A, lda, M.fc, C, h.d_model, n, rows, M.pe_tab, M.pe_rows);
+    const dim3 grid((n + 16u * nb - 1) / (16u * nb));
+    switch (nb) {
+      case 4: hipLaunchKernelGGL(k_fc_r<4>, grid, dim3(512), FC_R_SHM, st, A, lda, M.fc, C, h.d_model, n, rows, M.pe_tab, M.pe_rows); break;
+      case 5: hipLaunchKernelGGL(k_fc_r<5>, grid, dim3(512), FC_R_SHM, st, A, lda, M.fc, C, h.d_model, n, rows, M.pe_tab, M.pe_rows); break;
+      case 6: hipLaunchKernelGGL(k_fc_r<6>, grid, dim3(512), FC_R_SHM, st, A, lda, M.fc, C, h.d_model, n, rows, M.pe_tab, M.pe_rows); break;
+      case 7: hipLaunchKernelGGL(k_fc_r<7>, grid, dim3(512), FC_R_SHM, st, A, lda, M.fc, C, h.d_model, n, rows, M.pe_tab, M.pe_rows); break;
+      default: hipLaunchKernelGGL(k_fc_r<8>, grid, dim3(512), FC_R_SHM, st, A, lda, M.fc, C, h.d_model, n, rows, M.pe_tab, M.pe_rows);
+    }
   };
   if (chunk_tok && N > chunk_tok) {
     KT_BEGIN(tm, "conv_fused", st);   // (the span carries both kernels of every chunk)
