@@ -450,8 +450,17 @@ __global__ __launch_bounds__(512, 4) void k_fc_r(const uint16_t* __restrict__ A,
   // weights: fragment (jt, ks) of this wave's 32-column slab
   const uint16_t* gw = W.ph16 + ((uint64_t)(wave * 2) * nks * 64 + lane) * 8;
   auto wfrag = [&](uint32_t jt, uint32_t ks) -> half8 { return *reinterpret_cast<const half8*>(gw + (uint64_t)(jt * nks + ks) * 512); };
-  half8 wr[2][2];       // ring: k-step & 1 (a slot is refilled with the k-step 2 ahead as soon as its MFMAs are issued)
-  uint4 as0, as1;       // the activation tile of the next macro-step, in flight
+  // DEEP (tiles of <= 96 rows, whose accumulators leave the registers for it): weight fragments four k-steps and activation tiles two macro-steps ahead of their use — the
+  // loop ran at one macro-step per round trip of the loads it had requested one macro-step earlier (1.65 us per 64 k whatever the tile height: 129 | 124.5 us at 96 | 80 rows)
+#ifdef HERRO_FC_SHALLOW
+  constexpr bool DEEP = false;
+#else
+  constexpr bool DEEP = NB <= 6;
+#endif
+  constexpr int WD = DEEP ? 4 : 2;
+  half8 wr[WD][2];      // ring: k-step & (WD - 1) (a slot is refilled with the k-step WD ahead as soon as its MFMAs are issued)
+  uint4 as0, as1;       // the activation tile of the next macro-step, in flight (DEEP: of an odd macro-step)
+  uint4 bs0, bs1;       // DEEP: the tile of an even macro-step, in flight
   auto load_a = [&](uint32_t ms, uint4& r0, uint4& r1) {
     r0 = *reinterpret_cast<const uint4*>(ga + (uint64_t)ms * 64);
     r1 = *reinterpret_cast<const uint4*>(ga + (uint64_t)ms * 64 + 32);
@@ -481,8 +490,9 @@ __global__ __launch_bounds__(512, 4) void k_fc_r(const uint16_t* __restrict__ A,
     uint4 t0, t1;
     load_a(0, t0, t1);
     load_a(min(1u, nms - 1), as0, as1);
+    if constexpr (DEEP) load_a(min(2u, nms - 1), bs0, bs1); else { bs0 = make_uint4(0, 0, 0, 0); bs1 = bs0; }
 #pragma unroll
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < WD; k++)
 #pragma unroll
       for (int jt = 0; jt < 2; jt++) wr[k][jt] = wfrag(jt, min((uint32_t)k, nks - 1));
     put_a(0, t0, t1);
@@ -503,18 +513,25 @@ __global__ __launch_bounds__(512, 4) void k_fc_r(const uint16_t* __restrict__ A,
       for (int q = 0; q < 2 * G; q++) {   // q = G kk + g
         if (q < 2 * G - 1) rd(u, (q + 1) / G, (q + 1) % G, xn);
         __builtin_amdgcn_sched_barrier(0);
-        mm(q % G, x, wr[q / G]);
+        const int ws = DEEP ? u * 2 + q / G : q / G;   // ring slot of this k-step (a constant once the loops are unrolled)
+        mm(q % G, x, wr[ws]);
         __builtin_amdgcn_sched_barrier(0);
-        if (q % G == G - 1) {   // the k-step's fragments have been issued: the slot takes the k-step 2 ahead
-          const uint32_t kn = min(s_ * 2 + (q / G) + 2, nks - 1);
+        if (q % G == G - 1) {   // the k-step's fragments have been issued: the slot takes the k-step WD ahead
+          const uint32_t kn = min(s_ * 2 + (q / G) + WD, nks - 1);
 #pragma unroll
-          for (int jt = 0; jt < 2; jt++) wr[q / G][jt] = wfrag(jt, kn);
+          for (int jt = 0; jt < 2; jt++) wr[ws][jt] = wfrag(jt, kn);
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (q == G + 1) {   // the next tile (in flight since the previous macro-step) goes into the other buffer; its successor is requested
-          put_a((u + 1) & 1, as0, as1);
-          __builtin_amdgcn_sched_barrier(0);
-          load_a(min(s_ + 2, nms - 1), as0, as1);
+        if (q == G + 1) {   // the next tile (in flight since the previous macro-step; DEEP: since the one before) goes into the other buffer; its successor is requested
+          if (DEEP && u == 1) {   // (compile time) tile s_ + 1 is even
+            put_a(0, bs0, bs1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(min(s_ + 3, nms - 1), bs0, bs1);
+          } else {
+            put_a((u + 1) & 1, as0, as1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(min(s_ + (DEEP ? 3 : 2), nms - 1), as0, as1);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
