@@ -450,8 +450,9 @@ __global__ __launch_bounds__(512, 4) void k_fc_r(const uint16_t* __restrict__ A,
   // weights: fragment (jt, ks) of this wave's 32-column slab
   const uint16_t* gw = W.ph16 + ((uint64_t)(wave * 2) * nks * 64 + lane) * 8;
   auto wfrag = [&](uint32_t jt, uint32_t ks) -> half8 { return *reinterpret_cast<const half8*>(gw + (uint64_t)(jt * nks + ks) * 512); };
-  // DEEP (tiles of <= 96 rows, whose accumulators leave the registers for it): weight fragments four k-steps and activation tiles two macro-steps ahead of their use — the
-  // loop ran at one macro-step per round trip of the loads it had requested one macro-step earlier (1.65 us per 64 k whatever the tile height: 129 | 124.5 us at 96 | 80 rows)
+  // DEEP (tiles of <= 96 rows, whose accumulators leave the registers for it): weight fragments four k-steps and activation tiles two macro-steps ahead of their use —
+  // 123-128 -> 120-121 us at the driver's size (profiles/r6_ab_fc_prefetch_depth.txt; -DHERRO_FC_SHALLOW builds the other side of that A/B).  Worth 3 %: load latency is not
+  // what the ~1.6 us per macro-step are made of (nor LDS latency, nor the barrier count: DESIGN §5, profiles/r6_probe_mfma_lds_vmem_overlap.txt)
 #ifdef HERRO_FC_SHALLOW
   constexpr bool DEEP = false;
 #else
